@@ -1,0 +1,254 @@
+/*
+ * sdm.h — C ABI of libsdm_hip: the MI355X-native particle-grid update of
+ * tud-amr/semantic_dsp_map (hot path only).
+ *
+ * The library replaces the private sub-object level of the reference's
+ * SemanticDSPMap class; each entry point cites the reference interface it stands
+ * in for (paths relative to the reference's include/).  The header-only adapter
+ * include/semantic_dsp_map.h puts the reference's own class and method
+ * signatures back on top of these calls.
+ *
+ * Conventions: plain C, caller owns every pointer, nothing is retained after a
+ * call returns, no exceptions cross the boundary, every function returns an
+ * sdm_status (0 = ok).  One map per handle (the reference allows one per
+ * process: its map is a set of header-defined globals, mc_ring/buffer.h:86-120).
+ * Calls on one handle must come from one thread at a time (the reference is
+ * single-threaded, src/mapping.cpp:156).
+ */
+#ifndef SDM_H_
+#define SDM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdm_map sdm_map;
+
+typedef enum {
+  SDM_OK = 0,
+  SDM_ERR_INVALID_ARGUMENT = 1, /* bad config / null pointer / size mismatch          */
+  SDM_ERR_NO_DEVICE = 2,        /* no HIP device, or the requested ordinal is missing */
+  SDM_ERR_HIP = 3,              /* a HIP runtime call failed (sdm_last_error has text)  */
+  SDM_ERR_CAPACITY = 4,         /* a per-frame work list overflowed its capacity      */
+  SDM_ERR_NOT_CONVERGED = 5,    /* frustum flood fill needed more rounds than budgeted */
+  SDM_ERR_COMM = 6              /* multi-GPU exchange failed                           */
+} sdm_status;
+
+/* Compile-time constants of the reference (settings/settings.h:18-150:
+ * C_VOXEL_NUM_AXIS_*_N, C_MAX_PARTICLE_NUM_PER_VOXEL_N, C_VOXEL_SIZE, g_camera_*,
+ * g_image_*, g_depth_range_*, BOOST_MODE window) as run-time configuration. */
+typedef struct {
+  int32_t x_n, y_n, z_n;      /* log2 voxels per axis (x_n+y_n+z_n+p_n <= 31, operations.h:54-58) */
+  int32_t p_n;                /* log2 slots per voxel, 1..4; slot 0 is the time particle         */
+  float voxel_size;           /* metres                                                           */
+  float fx, fy, cx, cy;       /* pinhole intrinsics                                               */
+  int32_t width, height;      /* image size                                                       */
+  float depth_min, depth_max; /* metres                                                           */
+  int32_t window_half;        /* SMC-PHD neighbour half-size: 5, or 3 in BOOST mode (semantic_dsp_map.h:964-970) */
+  int32_t max_movable_track;  /* g_max_movable_object_instance_id (utils/data_base.h:196)         */
+  int32_t device;             /* HIP device ordinal                                               */
+  int32_t shard_rank;         /* Z-slab sharding: this process owns ring-z slab shard_rank of shard_count */
+  int32_t shard_count;        /* 1 = whole map on one GPU                                         */
+  int64_t max_visible;        /* capacity of the per-frame visible-particle list, 0 = default     */
+} sdm_config;
+
+/* SemanticDSPMap::setMapParameters / setMapOptions / setDepthNoiseModelParameters
+ * (semantic_dsp_map.h:101-125, 161-166).  Field spelling follows the reference. */
+typedef struct {
+  float detection_probability;
+  float noise_number;
+  int32_t nb_ptc_num_per_point;
+  float occupancy_threshold;
+  int32_t max_obersevation_lost_time;
+  float forgetting_rate;
+  int32_t max_forget_count;
+  float match_score_threshold;
+  float id_transition_probability;
+  int32_t if_consider_depth_noise;
+  int32_t if_use_independent_filter;
+  float depth_noise_first_order;
+  float depth_noise_zero_order;
+} sdm_params;
+
+/* LabeledPoint (utils/data_base.h:78-92): position in the global frame, sigma,
+ * track id, label id, validity.  20 bytes, same field order. */
+typedef struct {
+  float x, y, z;
+  float sigma;
+  uint16_t track_id;
+  uint8_t label_id;
+  uint8_t is_valid;
+} sdm_labeled_point;
+
+/* One rigid-body motion handed down by the object layer: the track id and
+ * rigidbody_tmatrix_vec[0] cast to float (semantic_dsp_map.h:673-679), row-major. */
+typedef struct {
+  int32_t track_id;
+  float T[16];
+} sdm_object_move;
+
+/* Per-voxel result of determineIfVoxelOccupied (mc_ring/operations.h:623-639),
+ * indexed by storage voxel index.  8 bytes. */
+typedef struct {
+  float wsum;     /* weight sum, -1 = unknown voxel                       */
+  uint16_t track; /* winning track id (0 if none)                          */
+  uint8_t label;  /* its label id                                          */
+  int8_t occ;     /* -1 unknown, 0 free, 1 occupied, 2 guessed occupied    */
+} sdm_voxel_result;
+
+/* One emitted voxel of getOccupancyResult (semantic_dsp_map.h:1239-1383): min-corner
+ * position (global frame, or camera-centred) and the raw semantics; colouring stays
+ * in the adapter. 16 bytes. */
+typedef struct {
+  float x, y, z;
+  uint16_t track;
+  uint8_t label;
+  int8_t occ;
+} sdm_point;
+
+/* sdm_update flags */
+#define SDM_INPUT_ON_DEVICE 0x1u /* depth / cloud are device pointers already resident in HBM */
+#define SDM_SKIP_OCCUPANCY 0x2u  /* do not run the occupancy sweep (debug)                     */
+
+/* stage ids (also indices of sdm_stats.stage_ms): the reference's own stage timers,
+ * semantic_dsp_map.h:916-921 */
+enum {
+  SDM_STAGE_ALL = 0,
+  SDM_STAGE_EGO = 1,
+  SDM_STAGE_MOVE = 2,
+  SDM_STAGE_REMOVE = 3,
+  SDM_STAGE_VISIBILITY = 4,
+  SDM_STAGE_WEIGHT = 5,
+  SDM_STAGE_BIRTH = 6,
+  SDM_STAGE_OCCUPANCY = 7
+};
+
+typedef struct {
+  uint32_t global_time_stamp;
+  int32_t moved_steps[3];
+  int32_t eq_steps[3];
+  float map_center[3];
+  float last_pos[3];
+  int32_t birth_cursor;
+  int32_t move_cursor;
+} sdm_ring_state;
+
+typedef struct {
+  int64_t live_particles;   /* filled by sdm_get_stats(…, count_live=1) only */
+  int64_t n_visible;
+  int64_t n_birth_attempts;
+  int64_t n_birth_success;
+  int64_t n_resampled_voxels;
+  int64_t n_moved;
+  int64_t n_move_reinserted;
+  int64_t n_frustum_voxels;
+  int64_t n_occupied;
+  int64_t flood_rounds;
+  int64_t bfs_start_in_frustum;
+  double stage_ms[8];       /* GPU time per stage of the last update when profiling is on */
+} sdm_stats;
+
+/* ---- life cycle: SemanticDSPMap() / ~SemanticDSPMap() / clear() (semantic_dsp_map.h:25-81),
+ * RingBufferOperations::initialize / clear (mc_ring/operations.h:684-767) */
+sdm_status sdm_create(const sdm_config *cfg, sdm_map **out);
+sdm_status sdm_destroy(sdm_map *m);
+sdm_status sdm_clear(sdm_map *m);
+
+/* ---- setters (semantic_dsp_map.h:101-166) */
+sdm_status sdm_set_params(sdm_map *m, const sdm_params *p);
+
+/* ---- Gaussian noise table, GaussianRandomCalculator::calculateGaussianTable
+ * (utils/basic_algorithms.h:394-402): n floats ~ N(0, stddev^2).  Either generated on
+ * the device with rocRAND (Philox4x32-10) or uploaded by the caller. */
+sdm_status sdm_generate_noise_table(sdm_map *m, uint64_t seed, int32_t n, float stddev);
+sdm_status sdm_upload_noise_table(sdm_map *m, const float *table, int32_t n);
+sdm_status sdm_download_noise_table(sdm_map *m, float *table, int32_t n);
+/* standard_gaussian_pdf (basic_algorithms.h:405-407), 20000 floats, for cross-checks */
+sdm_status sdm_download_pdf_table(sdm_map *m, float *table, int32_t n);
+
+/* ---- the hot path: one call of SemanticDSPMap::subObjectLevelUpdate
+ * (semantic_dsp_map.h:576-955) preceded by global_time_stamp += 1 (:173).
+ *   depth          H*W float32 metres (cv::Mat CV_32FC1, src/mapping.cpp:180)
+ *   cloud          H*W labeled points (output of generateLabeledPointCloud, :227)
+ *   cam_pos,cam_q  camera pose in the global frame, q = (w,x,y,z), already cast to float (:584, :745-746)
+ *   moves          objects the object layer decided to move this frame (:593-693), caller's order
+ *   remove_tracks  lost / floating objects to wipe (:702-736)
+ *   stop_after     SDM_STAGE_ALL, or a stage id to stop after (parity debugging)
+ * Asynchronous: returns after enqueueing; results are fetched with the getters below. */
+sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *cloud,
+                      const float cam_pos[3], const float cam_q[4],
+                      const sdm_object_move *moves, int32_t n_moves,
+                      const int32_t *remove_tracks, int32_t n_remove,
+                      uint32_t flags, int32_t stop_after);
+
+/* The same frame split at its one cross-shard dependency: sdm_update_begin runs the
+ * prediction, visibility/binning and this shard's partial ck image (pass 1 of updateParticles,
+ * semantic_dsp_map.h:973-1037) and hands back its device pointer; the caller gathers the partial images of
+ * all Z-slab shards (RCCL all-gather) and passes them, in slab order, to sdm_update_finish, which forms
+ * ck+kappa, updates the weights and runs births, resampling and the occupancy sweep.
+ * sdm_update == begin + finish with the shard's own image. */
+sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_point *cloud,
+                            const float cam_pos[3], const float cam_q[4],
+                            const sdm_object_move *moves, int32_t n_moves,
+                            const int32_t *remove_tracks, int32_t n_remove,
+                            uint32_t flags, int32_t stop_after, const float **ck_part_dev);
+sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_parts, uint32_t flags,
+                             int32_t stop_after);
+/* the HIP stream (hipStream_t) all work of this map is enqueued on */
+sdm_status sdm_stream(sdm_map *m, void **stream_out);
+
+/* Wait for all enqueued work of this map; surfaces deferred device-side errors. */
+sdm_status sdm_synchronize(sdm_map *m);
+
+/* ---- results (getOccupancyResult, semantic_dsp_map.h:1239-1383) */
+/* all voxels in storage order; out has 2^(x_n+y_n+z_n) entries (this shard's slab if sharded) */
+sdm_status sdm_get_voxels(sdm_map *m, sdm_voxel_result *out);
+/* compacted list of voxels with occ > 0 (occupied) or occ == 0 (free) in increasing storage index */
+sdm_status sdm_get_occupied(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t zero_center);
+sdm_status sdm_get_freespace(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t zero_center);
+/* device pointer to the per-voxel result array (valid until the next update) */
+sdm_status sdm_voxels_device_ptr(sdm_map *m, const sdm_voxel_result **out);
+
+/* ---- owner sets of the object layer: ObjectParticleHashMap (object_layer.h:20-52) */
+sdm_status sdm_object_particle_count(sdm_map *m, int32_t track_id, int64_t *count);
+
+/* ---- introspection / checkpoint (tests, fixtures; SURVEY.md §5 checkpoint row) */
+sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live);
+sdm_status sdm_set_profiling(sdm_map *m, int32_t on);
+sdm_status sdm_get_ring_state(sdm_map *m, sdm_ring_state *out);
+sdm_status sdm_set_ring_state(sdm_map *m, const sdm_ring_state *in);
+sdm_status sdm_get_stamps(sdm_map *m, uint32_t *sx, uint32_t *sy, uint32_t *sz);
+sdm_status sdm_set_stamps(sdm_map *m, const uint32_t *sx, const uint32_t *sy, const uint32_t *sz);
+/* SoA dump/load of every slot of this shard (V*S entries per array; NULL = skip on dump) */
+sdm_status sdm_dump_state(sdm_map *m, float *px, float *py, float *pz, float *w, uint16_t *ts,
+                          uint16_t *track, uint8_t *label, uint8_t *status, uint8_t *forget,
+                          uint16_t *owner);
+sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const float *pz,
+                          const float *w, const uint16_t *ts, const uint16_t *track,
+                          const uint8_t *label, const uint8_t *status, const uint8_t *forget,
+                          const uint16_t *owner);
+/* diagnostics of the last update: ck+kappa image, per-pixel bin counts, extrinsic */
+sdm_status sdm_get_ck_kappa(sdm_map *m, float *out);
+sdm_status sdm_get_bin_counts(sdm_map *m, uint32_t *out);
+sdm_status sdm_get_bins(sdm_map *m, uint32_t *out, int64_t cap, int64_t *n_out);
+sdm_status sdm_get_extrinsic(sdm_map *m, float *out16);
+
+/* ---- timing of single kernels for bench.py's roofline line: runs the occupancy sweep
+ * `iters` times on the map's stream bracketed by HIP events, returns average ms per launch. */
+sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms);
+
+/* ---- device-side unit tests of the hand-written primitives (tests/test_primitives_gpu.py) */
+sdm_status sdm_test_scan(const uint32_t *in, uint32_t *out, int64_t n);
+sdm_status sdm_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
+                               uint32_t *vals_out, int64_t n, int32_t nbits);
+
+const char *sdm_last_error(void);
+const char *sdm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDM_H_ */

@@ -1,0 +1,940 @@
+// kernels.hip — the per-frame particle/voxel kernels of libsdm_hip (gfx950).
+//
+// Each kernel restates one CPU loop of the reference (file:line cited per kernel) as a
+// data-parallel pass over SoA slot arrays.  Sequential-order semantics of the reference
+// (first vacant slot, 9-pass stride-3 birth raster, one resample per voxel per frame) are
+// preserved by grouping work per voxel and replaying each voxel's ordered list in one thread:
+// all state such a list touches is voxel-local.
+//
+// Float arithmetic that decides an integer (voxel index, pixel, LUT index, resample survivor)
+// is written in the reference's operation order with contraction off.
+#include "sdm_internal.h"
+#include "sdm_scratch.h"
+
+#pragma clang fp contract(off)
+
+namespace sdm {
+
+namespace {
+
+constexpr int TPB = 256;
+
+template <typename T, int N>
+__device__ __forceinline__ void load_vec(T (&dst)[N], const T *src) {
+  constexpr int B = (int)sizeof(T) * N;
+  constexpr int A = B > 16 ? 16 : B;
+  __builtin_memcpy(dst, __builtin_assume_aligned(src, A), B);
+}
+template <typename T, int N>
+__device__ __forceinline__ void store_vec(T *dst, const T (&src)[N]) {
+  constexpr int B = (int)sizeof(T) * N;
+  constexpr int A = B > 16 ? 16 : B;
+  __builtin_memcpy(__builtin_assume_aligned(dst, A), src, B);
+}
+
+__device__ __forceinline__ uint32_t stamp_max(const State &st, uint32_t rx, uint32_t ry, uint32_t rz) {
+  uint32_t a = st.stamps_x[rx], b = st.stamps_y[ry], c = st.stamps_z[rz];
+  uint32_t m = a > b ? a : b;
+  return m > c ? m : c;
+}
+
+// ------------------------------------------------------------------------------------ A13
+// RingBufferOperations::clear (mc_ring/operations.h:684-723): slot 0 = TIMEPTC, others INVALID.
+// (the zero fields are cleared with hipMemsetAsync by the launcher)
+__global__ __launch_bounds__(TPB) void k_clear_status(uint8_t *__restrict__ status, uint32_t n_slots, uint32_t slot_mask) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (; i < n_slots; i += stride) status[i] = (i & slot_mask) == 0 ? (uint8_t)ST_TIMEPTC : (uint8_t)ST_INVALID;
+}
+
+// ------------------------------------------------------------------------------------ A10
+// getOccupancyResult -> determineIfVoxelOccupied -> calculateWeightAndSemanticsInVoxel
+// (semantic_dsp_map.h:1239-1257, mc_ring/operations.h:623-639, 390-448).
+// One thread per voxel; all S slots of the voxel are fetched with wide loads (SoA arrays are
+// voxel-contiguous), the 8-byte result is one store.  HBM-bound: 80 B/voxel at S=8.
+template <int S>
+__global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, State st) {
+  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;  // local voxel of this shard
+  if (lv >= d.v_count) return;
+  uint32_t v = d.v_begin + lv;
+  uint32_t rx, ry, rz;
+  voxel_to_ring(d, v, rx, ry, rz);
+  const uint32_t smax = stamp_max(st, rx, ry, rz);
+  const size_t base = (size_t)lv * S;
+
+  uint16_t tsv[S];
+  load_vec(tsv, st.ts + base);
+  sdm_voxel_result out;
+  out.track = 0;
+  out.label = 0;
+  const uint32_t t0 = tsv[0];
+  if (t0 == 0 || t0 < smax) {  // isVoxelValid, operations.h:824-837
+    out.wsum = -1.f;
+    out.occ = -1;
+    st.res[lv] = out;
+    return;
+  }
+  uint8_t stv[S];
+  float wv[S];
+  uint16_t trk[S];
+  uint8_t lab[S];
+  load_vec(stv, st.status + base);
+  load_vec(wv, st.w + base);
+  load_vec(trk, st.track + base);
+  load_vec(lab, st.label + base);
+
+  float weight_sum = 0.f, guessed = 0.f;
+  bool vote[S];
+  bool dirty_w = false, dirty_s = false;
+  vote[0] = false;
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    vote[i] = false;
+    bool vacant = stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax;  // isParticleVacant, operations.h:810-816
+    if (!vacant) {
+      weight_sum += wv[i];
+      if (wv[i] > 1.f) {
+        wv[i] = 1.f;
+        dirty_w = true;
+      }
+      if (stv[i] == ST_GUESSED_BORN) {
+        guessed += wv[i];
+        vote[i] = true;
+      } else if (stv[i] == ST_UPDATED && wv[i] < SDM_OCC_INIT_WEIGHT) {
+        stv[i] = ST_INVALID;
+        dirty_s = true;
+      } else {
+        vote[i] = true;
+      }
+    }
+  }
+  // std::map<track, weight> accumulated in slot order; winner = max weight, ties -> smallest track,
+  // only weights > 0 (operations.h:429-447).
+  float best_w = 0.f;
+  uint32_t best_t = 0;
+  uint8_t best_l = 0;
+  bool have = false;
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    if (!vote[i]) continue;
+    float tot = 0.f;
+    uint8_t l = lab[i];
+#pragma unroll
+    for (int j = 1; j < S; ++j) {
+      if (vote[j] && trk[j] == trk[i]) {
+        tot += wv[j];
+        l = lab[j];  // map assignment: the last contributor's label stays
+      }
+    }
+    if (tot > 0.f) {
+      if (!have || tot > best_w || (tot == best_w && trk[i] < best_t)) {
+        have = true;
+        best_w = tot;
+        best_t = trk[i];
+        best_l = l;
+      }
+    }
+  }
+  if (have) {
+    out.track = (uint16_t)best_t;
+    out.label = best_l;
+  }
+  out.wsum = weight_sum;
+  if (weight_sum > occ_threshold) out.occ = 1;
+  else if (guessed >= SDM_OCC_INIT_WEIGHT) out.occ = 2;
+  else out.occ = 0;
+  st.res[lv] = out;
+  if (dirty_w) store_vec(st.w + base, wv);
+  if (dirty_s) store_vec(st.status + base, stv);
+}
+
+// ------------------------------------------------------------------------------------ A6
+// Frustum vertex mask (isPointInFrustum of every grid vertex in the conservative bounding box,
+// mc_ring/operations.h:1338-1340).  One wave per 64 vertices along x; ballot packs the bits.
+__global__ __launch_bounds__(TPB) void k_vertex_mask(Dims d, Frame f, uint64_t *__restrict__ M, int wpl, uint32_t n_words) {
+  uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (gw >= n_words) return;
+  const int lane = threadIdx.x & 63;
+  const int VY = d.NY + 1;
+  int xw = gw % wpl;
+  int line = gw / wpl;
+  int y = line % VY, z = line / VY;
+  int x = xw * 64 + lane;
+  bool in = false;
+  if (x >= f.bb0[0] && x <= f.bb1[0] && y >= f.bb0[1] && y <= f.bb1[1] && z >= f.bb0[2] && z <= f.bb1[2] &&
+      x <= (int)d.NX) {
+    // vertex position: idx * size + (map_center + map_min), operations.h:1304,1338
+    float gx = (float)x * d.voxel_size + (f.center[0] + d.pmin[0]);
+    float gy = (float)y * d.voxel_size + (f.center[1] + d.pmin[1]);
+    float gz = (float)z * d.voxel_size + (f.center[2] + d.pmin[2]);
+    in = point_in_frustum(d, f, gx, gy, gz);
+  }
+  uint64_t mask = __ballot(in);
+  if (lane == 0) M[gw] = mask;
+}
+
+// seed of the BFS (operations.h:1312-1324): the start vertex is reached iff it is inside the frustum
+__global__ void k_flood_seed(Dims d, Frame f, const uint64_t *__restrict__ M, uint64_t *__restrict__ R, int wpl,
+                             Counters *cnt) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!f.start_ok) return;
+  const int VY = d.NY + 1;
+  size_t word = ((size_t)f.start_v[2] * VY + f.start_v[1]) * wpl + (f.start_v[0] >> 6);
+  uint64_t bit = 1ull << (f.start_v[0] & 63);
+  if (M[word] & bit) {
+    R[word] = bit;
+    cnt->start_in_frustum = 1;
+  }
+}
+
+// occluded (Kogge-Stone) fill of g through the set bits of p, both directions inside one word
+__device__ __forceinline__ uint64_t fill64(uint64_t g, uint64_t p) {
+  g &= p;
+  uint64_t gu = g, pu = p;
+  gu |= pu & (gu << 1);  pu &= (pu << 1);
+  gu |= pu & (gu << 2);  pu &= (pu << 2);
+  gu |= pu & (gu << 4);  pu &= (pu << 4);
+  gu |= pu & (gu << 8);  pu &= (pu << 8);
+  gu |= pu & (gu << 16); pu &= (pu << 16);
+  gu |= pu & (gu << 32);
+  uint64_t gd = g, pd = p;
+  gd |= pd & (gd >> 1);  pd &= (pd >> 1);
+  gd |= pd & (gd >> 2);  pd &= (pd >> 2);
+  gd |= pd & (gd >> 4);  pd &= (pd >> 4);
+  gd |= pd & (gd >> 8);  pd &= (pd >> 8);
+  gd |= pd & (gd >> 16); pd &= (pd >> 16);
+  gd |= pd & (gd >> 32);
+  return gu | gd;
+}
+
+constexpr int MAX_WPL = 9;  // 513 vertices along x at most (x_n <= 9)
+
+// The BFS over 6-connected in-frustum vertices (operations.h:1327-1456) reaches exactly the connected
+// component of the start vertex.  It is computed here as a bit-parallel flood: line fills along x,
+// carry sweeps along y and z, repeated until a whole round changes nothing.
+__global__ __launch_bounds__(TPB) void k_flood_x(Dims d, Frame f, const uint64_t *__restrict__ M, uint64_t *__restrict__ R,
+                                                 int wpl, int round, Counters *cnt) {
+  if (round > 0 && cnt->flood_changed[round - 1] == 0) return;
+  const int VY = d.NY + 1;
+  int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ny * nz) return;
+  int y = f.bb0[1] + t % ny, z = f.bb0[2] + t / ny;
+  size_t base = ((size_t)z * VY + y) * wpl;
+  uint64_t r[MAX_WPL], m[MAX_WPL];
+  uint64_t any = 0;
+  for (int i = 0; i < wpl; ++i) {
+    r[i] = R[base + i];
+    any |= r[i];
+  }
+  if (!any) return;
+  for (int i = 0; i < wpl; ++i) m[i] = M[base + i];
+  bool changed = false;
+  uint64_t carry = 0;
+  for (int i = 0; i < wpl; ++i) {  // upward across words
+    uint64_t g = fill64(r[i] | (carry ? 1ull : 0ull), m[i]);
+    carry = g >> 63;
+    if (g != r[i]) changed = true;
+    r[i] = g;
+  }
+  carry = 0;
+  for (int i = wpl - 1; i >= 0; --i) {  // downward across words
+    uint64_t g = fill64(r[i] | (carry ? (1ull << 63) : 0ull), m[i]);
+    carry = g & 1ull;
+    if (g != r[i]) changed = true;
+    r[i] = g;
+  }
+  if (changed) {
+    for (int i = 0; i < wpl; ++i) R[base + i] = r[i];
+    cnt->flood_changed[round] = 1;
+  }
+}
+
+// axis: 1 = sweep along y (threads over z,xw), 2 = sweep along z (threads over y,xw)
+__global__ __launch_bounds__(TPB) void k_flood_sweep(Dims d, Frame f, const uint64_t *__restrict__ M,
+                                                     uint64_t *__restrict__ R, int wpl, int axis, int round, Counters *cnt) {
+  if (round > 0 && cnt->flood_changed[round - 1] == 0) return;
+  const int VY = d.NY + 1;
+  int xw0 = f.bb0[0] >> 6, xw1 = f.bb1[0] >> 6;
+  int nxw = xw1 - xw0 + 1;
+  int other = axis == 1 ? 2 : 1;
+  int no = f.bb1[other] - f.bb0[other] + 1;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nxw * no) return;
+  int xw = xw0 + t % nxw;
+  int o = f.bb0[other] + t / nxw;
+  int a0 = f.bb0[axis], a1 = f.bb1[axis];
+  size_t stride = axis == 1 ? (size_t)wpl : (size_t)VY * wpl;
+  size_t base = (axis == 1 ? (size_t)o * VY * wpl : (size_t)o * wpl) + xw;
+  bool changed = false;
+  uint64_t carry = 0;
+  for (int a = a0; a <= a1; ++a) {
+    size_t idx = base + (size_t)a * stride;
+    uint64_t r = R[idx];
+    uint64_t nr = r | (carry & M[idx]);
+    if (nr != r) {
+      R[idx] = nr;
+      changed = true;
+    }
+    carry = nr;
+  }
+  carry = 0;
+  for (int a = a1; a >= a0; --a) {
+    size_t idx = base + (size_t)a * stride;
+    uint64_t r = R[idx];
+    uint64_t nr = r | (carry & M[idx]);
+    if (nr != r) {
+      R[idx] = nr;
+      changed = true;
+    }
+    carry = nr;
+  }
+  if (changed) cnt->flood_changed[round] = 1;
+}
+
+__device__ __forceinline__ bool vbit(const uint64_t *__restrict__ R, size_t line_base, int x) {
+  return (R[line_base + (x >> 6)] >> (x & 63)) & 1ull;
+}
+
+// Per-voxel body of getIdxOfVisibleParitlces (operations.h:1344-1436): every voxel that shares a reached
+// in-frustum vertex is handled exactly once (order does not matter: all effects are voxel-local except the
+// per-pixel bins, whose order is made canonical afterwards).
+template <int S>
+__global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, Scratch sc) {
+  int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];  // voxel box [bb0,bb1)
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bx <= 0 || by <= 0 || bz <= 0 || t >= (uint32_t)bx * by * bz) return;
+  int ax = f.bb0[0] + (int)(t % bx);
+  int ay = f.bb0[1] + (int)((t / bx) % by);
+  int az = f.bb0[2] + (int)(t / ((uint32_t)bx * by));
+  const int VY = d.NY + 1;
+  bool reached = false;
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      size_t lb = ((size_t)(az + dz) * VY + (ay + dy)) * sc.wpl;
+      reached = reached || vbit(sc.reach, lb, ax) || vbit(sc.reach, lb, ax + 1);
+    }
+  if (!reached) return;
+  uint32_t rx = axis_correct(ax + f.eq[0], d.NX);
+  uint32_t ry = axis_correct(ay + f.eq[1], d.NY);
+  uint32_t rz = axis_correct(az + f.eq[2], d.NZ);
+  if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) return;  // another shard's slab
+  atomicAdd(&sc.cnt->n_frustum_voxels, 1u);
+  uint32_t v = ring_to_voxel(d, rx, ry, rz);
+  uint32_t lv = v - d.v_begin;
+  const uint32_t smax = stamp_max(st, rx, ry, rz);
+  const size_t base = (size_t)lv * S;
+  uint8_t stv[S];
+  uint16_t tsv[S];
+  load_vec(stv, st.status + base);
+  load_vec(tsv, st.ts + base);
+  bool dirty = false, observed = false;
+  int valid_n = 0;
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    if (stv[i] == ST_INVALID) continue;
+    if ((uint32_t)tsv[i] < smax) {  // outdated: delete (operations.h:1374-1378)
+      stv[i] = ST_INVALID;
+      dirty = true;
+      continue;
+    }
+    valid_n++;
+    float4 p = st.pos4[base + i];
+    int row, col;
+    float cam_z;
+    if (project_to_image(d, f, p.x, p.y, p.z, row, col, cam_z)) {
+      float dpt = sc.depth[(size_t)row * d.W + col];
+      if (dpt > d.dmax) {  // nothing measurable along this ray: free (operations.h:1389-1395)
+        st.w[base + i] = SDM_OCC_INIT_WEIGHT;
+        observed = true;
+        continue;
+      }
+      if (cam_z > dpt * d.occl_coeff) continue;  // occluded (operations.h:1397-1400)
+      observed = true;
+      uint32_t pix = (uint32_t)(row * d.W + col);
+      uint32_t k = atomicAdd(&sc.cnt->n_vis, 1u);
+      uint32_t pib = atomicAdd(&sc.bin_count[pix], 1u);
+      if (k < sc.cap_vis) {
+        sc.vis_pix[k] = pix;
+        sc.vis_idx[k] = (uint32_t)(((size_t)v << d.p_n) + i);
+        sc.vis_pib[k] = pib;
+      } else {
+        sc.cnt->overflow = 1;
+      }
+    }
+  }
+  if (dirty) store_vec(st.status + base, stv);
+  if (observed) {
+    st.ts[base] = (uint16_t)f.gts;
+  } else if (valid_n == 0) {
+    // imaginary particle at the voxel's min corner, mapXYZIdxToGlobalPose (operations.h:986-991, 1418-1431)
+    float ix = (float)(uint32_t)ax * d.voxel_size + d.pmin[0] + f.center[0];
+    float iy = (float)(uint32_t)ay * d.voxel_size + d.pmin[1] + f.center[1];
+    float iz = (float)(uint32_t)az * d.voxel_size + d.pmin[2] + f.center[2];
+    int row, col;
+    float cam_z;
+    if (project_to_image(d, f, ix, iy, iz, row, col, cam_z)) {
+      if (cam_z <= sc.depth[(size_t)row * d.W + col]) st.ts[base] = (uint16_t)f.gts;
+    }
+  }
+}
+
+// counting sort of the visible particles by pixel: scatter into the scanned bin ranges
+__global__ __launch_bounds__(TPB) void k_bin_fill(Scratch sc) {
+  if (sc.cnt->overflow) return;
+  uint32_t n = sc.cnt->n_vis;
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+    sc.bin_idx[sc.bin_start[sc.vis_pix[k]] + sc.vis_pib[k]] = sc.vis_idx[k];
+}
+
+__device__ __forceinline__ void sift_down(uint32_t *a, uint32_t start, uint32_t end) {
+  uint32_t root = start;
+  while (2 * root + 1 <= end) {
+    uint32_t child = 2 * root + 1, sw = root;
+    if (a[sw] < a[child]) sw = child;
+    if (child + 1 <= end && a[sw] < a[child + 1]) sw = child + 1;
+    if (sw == root) return;
+    uint32_t t = a[root];
+    a[root] = a[sw];
+    a[sw] = t;
+    root = sw;
+  }
+}
+
+// Canonical bin order = ascending particle index (the reference's push order is its BFS order),
+// then gather the fields the weight update reads into arrays laid out in bin order (pixel-major), so that
+// a window row is one contiguous segment.
+__global__ __launch_bounds__(TPB) void k_bin_sort_gather(Dims d, State st, Scratch sc) {
+  if (sc.cnt->overflow) return;
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (uint32_t)(d.W * d.H)) return;
+  uint32_t n = sc.bin_count[p];
+  if (n == 0) return;
+  uint32_t s = sc.bin_start[p];
+  uint32_t *a = sc.bin_idx + s;
+  if (n > 1) {
+    if (n <= 32) {
+      for (uint32_t i = 1; i < n; ++i) {
+        uint32_t x = a[i];
+        uint32_t j = i;
+        while (j > 0 && a[j - 1] > x) {
+          a[j] = a[j - 1];
+          --j;
+        }
+        a[j] = x;
+      }
+    } else {  // heap sort, in place
+      for (int start = (int)(n - 2) / 2; start >= 0; --start) sift_down(a, (uint32_t)start, n - 1);
+      for (uint32_t end = n - 1; end > 0; --end) {
+        uint32_t t = a[end];
+        a[end] = a[0];
+        a[0] = t;
+        sift_down(a, 0, end - 1);
+      }
+    }
+  }
+  const size_t slot_base = (size_t)d.v_begin << d.p_n;
+  for (uint32_t i = 0; i < n; ++i) {
+    size_t li = (size_t)a[i] - slot_base;
+    float4 q = st.pos4[li];
+    sc.vx[s + i] = q.x;
+    sc.vy[s + i] = q.y;
+    sc.vz[s + i] = q.z;
+    sc.vw[s + i] = st.w[li];
+    sc.vtrack[s + i] = st.track[li];
+    sc.vforget[s + i] = (uint8_t)(__float_as_uint(q.w) & 0xffu);
+    sc.vpix[s + i] = p;
+  }
+}
+
+// ------------------------------------------------------------------------------------ A7
+// SemanticDSPMap::updateParticles pass 1 (semantic_dsp_map.h:973-1037): ck + kappa per valid pixel.
+// One thread per pixel accumulates in the reference's order (window rows, columns, bin order).
+__global__ __launch_bounds__(TPB) void k_ck(Dims d, Filter flt, State st, Scratch sc, float *__restrict__ ck_out) {
+  if (sc.cnt->overflow) return;
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.W * d.H) return;
+  const sdm_labeled_point o = sc.cloud[p];
+  if (!o.is_valid) return;
+  const int i = p / d.W, j = p % d.W;
+  const int h = d.window_half;
+  const float sigma = o.sigma;
+  const float *__restrict__ pdf = st.pdf;
+  float ck = 0.f;
+  int j0 = j - h < 0 ? 0 : j - h;
+  int j1 = j + h >= d.W ? d.W - 1 : j + h;
+  for (int m = -h; m <= h; ++m) {
+    int ni = i + m;
+    if (ni < 0 || ni >= d.H) continue;
+    uint32_t s = sc.bin_start[ni * d.W + j0];
+    uint32_t e = sc.bin_start[ni * d.W + j1 + 1];
+    for (uint32_t k = s; k < e; ++k) {
+      uint16_t ptrack = sc.vtrack[k];
+      if (flt.independent && ptrack != o.track_id) continue;
+      float gk = query_pdf(pdf, sc.vx[k], o.x, sigma) * query_pdf(pdf, sc.vy[k], o.y, sigma) *
+                 query_pdf(pdf, sc.vz[k], o.z, sigma);
+      if (!flt.independent) {
+        gk *= flt.forget[sc.vforget[k] & 7];
+        if (ptrack != o.track_id) gk *= flt.id_transition;
+      }
+      ck += sc.vw[k] * gk;
+    }
+  }
+  ck_out[p] = ck;
+}
+
+// ck_kappa = ck * P_d + noise_number (semantic_dsp_map.h:1035); ck_parts > 1: sum of per-slab partial
+// images in slab order (multi-GPU path)
+__global__ __launch_bounds__(TPB) void k_ck_finish(Dims d, Filter flt, Scratch sc, const float *__restrict__ parts,
+                                                   int n_parts) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.W * d.H) return;
+  if (!sc.cloud[p].is_valid) return;
+  float ck = 0.f;
+  size_t hw = (size_t)d.W * d.H;
+  if (n_parts == 1) ck = parts[p];
+  else
+    for (int g = 0; g < n_parts; ++g) ck += parts[(size_t)g * hw + p];
+  sc.ck_kappa[p] = ck * flt.p_detect + flt.noise_number;
+}
+
+// pass 2 (semantic_dsp_map.h:1041-1119): one thread per binned particle.
+__global__ __launch_bounds__(TPB) void k_weight(Dims d, Frame f, Filter flt, State st, Scratch sc) {
+  if (sc.cnt->overflow) return;
+  const uint32_t n = sc.cnt->n_vis;
+  const float *__restrict__ pdf = st.pdf;
+  const int h = d.window_half;
+  const size_t slot_base = (size_t)d.v_begin << d.p_n;
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    const uint32_t p = sc.vpix[k];
+    const int i = p / d.W, j = p % d.W;
+    const float sigma = sc.cloud[p].sigma;  // sigma of the particle's own pixel (semantic_dsp_map.h:1047)
+    const float x = sc.vx[k], y = sc.vy[k], z = sc.vz[k];
+    const uint16_t ptrack = sc.vtrack[k];
+    const uint32_t fc = sc.vforget[k];
+    const float ff = flt.forget[fc & 7];
+    float acc = 0.f;
+    bool right_id = false;
+    for (int m = -h; m <= h; ++m) {
+      int ni = i + m;
+      if (ni < 0 || ni >= d.H) continue;
+      for (int nn = -h; nn <= h; ++nn) {
+        int nj = j + nn;
+        if (nj < 0 || nj >= d.W) continue;
+        const int q = ni * d.W + nj;
+        const sdm_labeled_point o = sc.cloud[q];
+        if (!o.is_valid) continue;
+        if (flt.independent && o.track_id != ptrack) continue;
+        float gk = query_pdf(pdf, x, o.x, sigma) * query_pdf(pdf, y, o.y, sigma) * query_pdf(pdf, z, o.z, sigma);
+        if (!flt.independent) {
+          if (ptrack != o.track_id) {
+            gk *= flt.id_transition;
+          } else {
+            if (gk > SDM_MIN_RIGHT_PDF) right_id = true;
+          }
+          gk *= ff;
+        }
+        acc += gk / sc.ck_kappa[q];
+      }
+    }
+    const size_t li = (size_t)sc.bin_idx[k] - slot_base;
+    float wnew = sc.vw[k] * (acc * flt.p_detect + 1.f - flt.p_detect);
+    st.w[li] = wnew;
+    st.status[li] = ST_UPDATED;
+    st.ts[li] = (uint16_t)f.gts;
+    if (!flt.independent) {
+      uint32_t nf = right_id ? 0u : (fc < 5u ? fc + 1u : fc);
+      if (nf != fc) {
+        float4 q4 = st.pos4[li];
+        q4.w = __uint_as_float(nf);
+        st.pos4[li] = q4;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ A8 / A9
+// Birth raster order (semantic_dsp_map.h:778-800): 9 interleaved stride-3 passes.
+__device__ __forceinline__ void birth_seq_to_pixel(const BirthOrder &bo, int q, int &i, int &j) {
+  int p = 0;
+#pragma unroll
+  for (int k = 1; k < 9; ++k)
+    if (q >= bo.off[k]) p = k;
+  int r = q - bo.off[p];
+  int cols = bo.cols[p];
+  i = p / 3 + 3 * (r / cols);
+  j = p % 3 + 3 * (r % cols);
+}
+
+__global__ __launch_bounds__(TPB) void k_birth_flags(Dims d, BirthOrder bo, Scratch sc) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= d.W * d.H) return;
+  int i, j;
+  birth_seq_to_pixel(bo, q, i, j);
+  sc.b_valid[q] = sc.cloud[i * d.W + j].is_valid ? 1u : 0u;
+}
+
+// One thread per birth candidate b = q * nb + n (q = position in the raster order, n = copy).
+// The table cursor of the reference advances by 3 per copy of every valid pixel in raster order
+// (semantic_dsp_map.h:1180-1188, basic_algorithms.h:426-440), so the draw index is a function of the
+// exclusive rank of q among valid pixels.
+__global__ __launch_bounds__(TPB) void k_birth_candidates(Dims d, Frame f, Filter flt, BirthOrder bo, State st, Scratch sc) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t total = (uint32_t)(d.W * d.H) * (uint32_t)flt.nb;
+  if (b >= total) return;
+  int q = (int)(b / (uint32_t)flt.nb), n = (int)(b % (uint32_t)flt.nb);
+  int i, j;
+  birth_seq_to_pixel(bo, q, i, j);
+  const sdm_labeled_point pt = sc.cloud[i * d.W + j];
+  uint32_t key = d.V;  // sorts behind every real voxel
+  float x = pt.x, y = pt.y, z = pt.z;
+  if (pt.is_valid) {
+    if (flt.use_rng) {
+      long long draw = (long long)sc.cur->birth_cursor + 3ll * ((long long)flt.nb * sc.b_rank[q] + n);
+      float nx = pt.sigma * st.noise[(draw + 1) % flt.noise_n];
+      float ny = pt.sigma * st.noise[(draw + 2) % flt.noise_n];
+      float nz = pt.sigma * st.noise[(draw + 3) % flt.noise_n];
+      x = pt.x + nx;
+      y = pt.y + ny;
+      z = pt.z + nz;
+    }
+    uint32_t rx, ry, rz;
+    uint32_t v = global_pos_to_voxel(d, f, x, y, z, rx, ry, rz);
+    if (v != INVALID_INDEX && rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) key = v;
+  }
+  sc.bkey_a[b] = key;
+  sc.bval_a[b] = b;
+  sc.bpos[b] = make_float4(x, y, z, __uint_as_float((uint32_t)pt.track_id | ((uint32_t)pt.label_id << 16)));
+}
+
+__global__ void k_birth_cursor(Dims d, Filter flt, Scratch sc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int last = d.W * d.H - 1;
+  uint32_t n_valid = sc.b_rank[last] + sc.b_valid[last];
+  sc.cnt->n_valid_px = n_valid;
+  sc.cnt->n_birth_attempts = n_valid * (uint32_t)flt.nb;
+  if (flt.use_rng) {
+    long long c = (long long)sc.cur->birth_cursor + 3ll * flt.nb * (long long)n_valid;
+    sc.cur->birth_cursor = (int32_t)(c % flt.noise_n);
+  }
+}
+
+// resampleParticlesInVoxel (semantic_dsp_map.h:1448-1519) on the register copy of one voxel.
+template <int S>
+__device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t base, uint8_t (&stv)[S]) {
+  float weight_sum = 0.f;
+  uint32_t updated = 0;
+  float wv[S];
+  load_vec(wv, st.w + base);
+#pragma unroll
+  for (int i = 1; i < S; ++i)
+    if (stv[i] == ST_UPDATED) {
+      weight_sum += wv[i];
+      ++updated;
+    }
+  const uint32_t trigger = S >> 1;
+  if (updated <= trigger) return false;
+  if (weight_sum < 0.01f) {
+#pragma unroll
+    for (int i = 1; i < S; ++i)
+      if (stv[i] == ST_UPDATED) {
+        stv[i] = ST_INVALID;
+        st.status[base + i] = ST_INVALID;
+        if (st.owner[base + i] == st.track[base + i]) st.owner[base + i] = OWNER_NONE;  // removeParticleFromObj
+      }
+    return true;
+  }
+  float wpp = weight_sum / (float)trigger;
+  if (wpp > 1.f) wpp = 1.f;
+  float run = 0.f, thr = wpp;
+#pragma unroll
+  for (int i = 1; i < S; ++i)
+    if (stv[i] == ST_UPDATED) {
+      run += wv[i];
+      if (run < thr) {
+        stv[i] = ST_INVALID;
+        st.status[base + i] = ST_INVALID;
+        if (st.owner[base + i] == st.track[base + i]) st.owner[base + i] = OWNER_NONE;
+      } else {
+        st.w[base + i] = wpp;
+        thr += wpp;
+        while (run > thr) thr += wpp;
+      }
+    }
+  return true;
+}
+
+// Ordered per-voxel replay of the births (addNewbornParticleAndResample / ...WithNoiseAndResample,
+// semantic_dsp_map.h:1148-1230; addParticleByGlobalPos, operations.h:782-803).  The sorted list keeps
+// raster order inside each voxel segment; the segment head thread replays it and stops at the fixed point
+// (voxel full and its one resample per frame used up or impossible).
+template <int S>
+__global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter flt, State st, Scratch sc,
+                                                      const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+                                                      uint32_t total) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const uint32_t v = skey[t];
+  if (v >= d.V) return;
+  if (t > 0 && skey[t - 1] == v) return;  // not a segment head
+  uint32_t rx, ry, rz;
+  voxel_to_ring(d, v, rx, ry, rz);
+  const uint32_t smax = stamp_max(st, rx, ry, rz);
+  const size_t base = (size_t)(v - d.v_begin) * S;
+  uint8_t stv[S];
+  uint16_t tsv[S];
+  load_vec(stv, st.status + base);
+  load_vec(tsv, st.ts + base);
+  bool resampled = false, checked = false;
+  uint32_t n_success = 0;
+  for (uint32_t u = t; u < total && skey[u] == v; ++u) {
+    const float4 bp = sc.bpos[sval[u]];
+    const uint32_t tl = __float_as_uint(bp.w);
+    const uint16_t track = (uint16_t)(tl & 0xffffu);
+    const uint8_t label = (uint8_t)((tl >> 16) & 0xffu);
+    bool inserted = false;
+#pragma unroll
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      int slot = -1;
+#pragma unroll
+      for (int i = S - 1; i >= 1; --i)
+        if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) slot = i;  // lowest vacant slot
+      if (slot > 0) {
+        // addNewParticleWithSemantics (operations.h:171-184)
+        st.pos4[base + slot] = make_float4(bp.x, bp.y, bp.z, __uint_as_float(0u));
+        st.w[base + slot] = SDM_OCC_INIT_WEIGHT;
+        st.ts[base + slot] = (uint16_t)f.gts;
+        st.track[base + slot] = track;
+        st.label[base + slot] = label;
+        st.status[base + slot] = ST_REGULAR_BORN;
+        if ((int)track <= d.max_movable) st.owner[base + slot] = track;  // addParticleToObj
+#pragma unroll
+        for (int i = 1; i < S; ++i)
+          if (i == slot) {
+            stv[i] = ST_REGULAR_BORN;
+            tsv[i] = (uint16_t)f.gts;
+          }
+        inserted = true;
+        ++n_success;
+        break;
+      }
+      // voxel full
+      if (!flt.consider_depth_noise) break;     // no retry in the no-noise flavour
+      if (attempt == 1 || resampled || checked) break;
+      if (resample_voxel<S>(d, st, base, stv)) {
+        resampled = true;
+        atomicAdd(&sc.cnt->n_resampled, 1u);
+      } else {
+        checked = true;
+        break;
+      }
+    }
+    if (!flt.consider_depth_noise && !resampled && !checked) {
+      // semantic_dsp_map.h:1165-1170: after every add, resample until it has triggered once
+      if (resample_voxel<S>(d, st, base, stv)) {
+        resampled = true;
+        atomicAdd(&sc.cnt->n_resampled, 1u);
+      } else {
+        checked = true;
+      }
+    }
+    if (!inserted && (resampled || checked)) break;  // fixed point: later births of this voxel change nothing
+  }
+  if (n_success) atomicAdd(&sc.cnt->n_birth_success, n_success);
+}
+
+// ------------------------------------------------------------------------------------ utilities
+__global__ __launch_bounds__(TPB) void k_count_live(Dims d, State st, unsigned long long *out) {
+  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t c = 0;
+  if (lv < d.v_count) {
+    uint32_t v = d.v_begin + lv, rx, ry, rz;
+    voxel_to_ring(d, v, rx, ry, rz);
+    uint32_t smax = stamp_max(st, rx, ry, rz);
+    size_t base = (size_t)lv * d.S;
+    for (uint32_t i = 1; i < d.S; ++i)
+      if (st.status[base + i] != ST_INVALID && (uint32_t)st.ts[base + i] >= smax) c++;
+  }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+__global__ __launch_bounds__(TPB) void k_count_owner(Dims d, State st, uint16_t track, unsigned long long *out) {
+  size_t n = (size_t)d.v_count * d.S;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t c = 0;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (st.owner[i] == track) c++;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+// pack / unpack between the C-ABI's SoA dump format and pos4
+__global__ __launch_bounds__(TPB) void k_pack_pos4(float4 *pos4, const float *px, const float *py, const float *pz,
+                                                   const uint8_t *forget, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pos4[i] = make_float4(px[i], py[i], pz[i], __uint_as_float((uint32_t)forget[i]));
+}
+__global__ __launch_bounds__(TPB) void k_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uint8_t *forget,
+                                                     size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float4 q = pos4[i];
+    px[i] = q.x;
+    py[i] = q.y;
+    pz[i] = q.z;
+    forget[i] = (uint8_t)(__float_as_uint(q.w) & 0xffu);
+  }
+}
+
+// stable compaction of voxels by result code (getOccupancyResult's emission order = storage order,
+// semantic_dsp_map.h:1244,1353): flag pass, scan, scatter.
+__global__ __launch_bounds__(TPB) void k_flag_results(Dims d, State st, uint32_t *flags, int want_free) {
+  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lv >= d.v_count) return;
+  int8_t occ = st.res[lv].occ;
+  flags[lv] = want_free ? (occ == 0) : (occ > 0);
+}
+__global__ __launch_bounds__(TPB) void k_emit_points(Dims d, Frame f, State st, const uint32_t *flags,
+                                                     const uint32_t *offs, sdm_point *out, uint32_t cap, float sub_x,
+                                                     float sub_y, float sub_z) {
+  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lv >= d.v_count || !flags[lv]) return;
+  uint32_t o = offs[lv];
+  if (o >= cap) return;
+  uint32_t v = d.v_begin + lv, rx, ry, rz;
+  voxel_to_ring(d, v, rx, ry, rz);
+  // voxelIdxToGlobalFramePos: ring -> map index -> min corner (operations.h:940-983, 1022-1033)
+  uint32_t mx = axis_correct((int)rx - f.eq[0], d.NX);
+  uint32_t my = axis_correct((int)ry - f.eq[1], d.NY);
+  uint32_t mz = axis_correct((int)rz - f.eq[2], d.NZ);
+  float x = (float)mx * d.voxel_size + d.pmin[0];
+  float y = (float)my * d.voxel_size + d.pmin[1];
+  float z = (float)mz * d.voxel_size + d.pmin[2];
+  x += f.center[0];
+  y += f.center[1];
+  z += f.center[2];
+  sdm_voxel_result r = st.res[lv];
+  sdm_point pt;
+  pt.x = x - sub_x;
+  pt.y = y - sub_y;
+  pt.z = z - sub_z;
+  pt.track = r.track;
+  pt.label = r.label;
+  pt.occ = r.occ;
+  out[o] = pt;
+}
+
+inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
+
+}  // namespace
+
+// ============================================================================ launchers
+void launch_clear(const Dims &d, const State &st, hipStream_t s) {
+  size_t n = (size_t)d.v_count * d.S;
+  hipMemsetAsync(st.pos4, 0, n * sizeof(float4), s);
+  hipMemsetAsync(st.w, 0, n * sizeof(float), s);
+  hipMemsetAsync(st.ts, 0, n * sizeof(uint16_t), s);
+  hipMemsetAsync(st.track, 0, n * sizeof(uint16_t), s);
+  hipMemsetAsync(st.label, 0, n, s);
+  hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
+  hipMemsetAsync(st.res, 0, (size_t)d.v_count * sizeof(sdm_voxel_result), s);
+  hipLaunchKernelGGL(k_clear_status, dim3(4096), dim3(TPB), 0, s, st.status, (uint32_t)n, d.S - 1);
+}
+
+#define SDM_DISPATCH_S(kernel, grid, s, ...)                                                      \
+  switch (d.p_n) {                                                                                 \
+    case 1: hipLaunchKernelGGL(kernel<2>, grid, dim3(TPB), 0, s, __VA_ARGS__); break;              \
+    case 2: hipLaunchKernelGGL(kernel<4>, grid, dim3(TPB), 0, s, __VA_ARGS__); break;              \
+    case 3: hipLaunchKernelGGL(kernel<8>, grid, dim3(TPB), 0, s, __VA_ARGS__); break;              \
+    default: hipLaunchKernelGGL(kernel<16>, grid, dim3(TPB), 0, s, __VA_ARGS__); break;            \
+  }
+
+void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s) {
+  dim3 grid(blocks_for(d.v_count));
+  SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st);
+}
+
+void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int flood_rounds, hipStream_t s) {
+  const int VY = d.NY + 1, VZ = d.NZ + 1;
+  const uint32_t n_words = (uint32_t)VZ * VY * sc.wpl;
+  hipMemsetAsync(sc.reach, 0, (size_t)n_words * 8, s);
+  hipMemsetAsync(sc.bin_count, 0, ((size_t)d.W * d.H + 1) * 4, s);
+  hipLaunchKernelGGL(k_vertex_mask, dim3(blocks_for((size_t)n_words * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl, n_words);
+  hipLaunchKernelGGL(k_flood_seed, dim3(1), dim3(64), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, sc.cnt);
+  int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
+  int nxw = (f.bb1[0] >> 6) - (f.bb0[0] >> 6) + 1;
+  if (ny > 0 && nz > 0 && nxw > 0) {
+    for (int r = 0; r < flood_rounds; ++r) {
+      hipLaunchKernelGGL(k_flood_x, dim3(blocks_for((size_t)ny * nz)), dim3(TPB), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, r, sc.cnt);
+      hipLaunchKernelGGL(k_flood_sweep, dim3(blocks_for((size_t)nxw * nz)), dim3(TPB), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, 1, r, sc.cnt);
+      hipLaunchKernelGGL(k_flood_sweep, dim3(blocks_for((size_t)nxw * ny)), dim3(TPB), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, 2, r, sc.cnt);
+    }
+  }
+  int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];
+  if (bx > 0 && by > 0 && bz > 0) {
+    dim3 grid(blocks_for((size_t)bx * by * bz));
+    SDM_DISPATCH_S(k_visibility, grid, s, d, f, st, sc);
+  }
+  // bins: scan the per-pixel counts, scatter, canonical order + gather
+  exclusive_scan_u32(sc.bin_count, sc.bin_start, (size_t)d.W * d.H + 1, sc.scan_scratch, s);
+  hipLaunchKernelGGL(k_bin_fill, dim3(2048), dim3(TPB), 0, s, sc);
+  hipLaunchKernelGGL(k_bin_sort_gather, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, st, sc);
+}
+
+void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_ck, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, st, sc, ck_out);
+}
+void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s) {
+  hipLaunchKernelGGL(k_ck_finish, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, parts, n_parts);
+}
+void launch_weight(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s) {
+  hipLaunchKernelGGL(k_weight, dim3(4096), dim3(TPB), 0, s, d, f, flt, st, sc);
+}
+
+void launch_births(const Dims &d, const Frame &f, const Filter &flt, const BirthOrder &bo, const State &st,
+                   const Scratch &sc, hipStream_t s) {
+  const size_t hw = (size_t)d.W * d.H;
+  const size_t total = hw * flt.nb;
+  hipLaunchKernelGGL(k_birth_flags, dim3(blocks_for(hw)), dim3(TPB), 0, s, d, bo, sc);
+  exclusive_scan_u32(sc.b_valid, sc.b_rank, hw, sc.scan_scratch, s);
+  hipLaunchKernelGGL(k_birth_candidates, dim3(blocks_for(total)), dim3(TPB), 0, s, d, f, flt, bo, st, sc);
+  hipLaunchKernelGGL(k_birth_cursor, dim3(1), dim3(64), 0, s, d, flt, sc);
+  int nbits = d.x_n + d.y_n + d.z_n + 1;
+  int which = radix_sort_pairs(sc.bkey_a, sc.bval_a, sc.bkey_b, sc.bval_b, total, nbits, sc.sort_scratch, s);
+  const uint32_t *skey = which ? sc.bkey_b : sc.bkey_a;
+  const uint32_t *sval = which ? sc.bval_b : sc.bval_a;
+  dim3 grid(blocks_for(total));
+  SDM_DISPATCH_S(k_birth_replay, grid, s, d, f, flt, st, sc, skey, sval, (uint32_t)total);
+}
+
+void launch_count_live(const Dims &d, const State &st, unsigned long long *out, hipStream_t s) {
+  hipMemsetAsync(out, 0, 8, s);
+  hipLaunchKernelGGL(k_count_live, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st, out);
+}
+void launch_count_owner(const Dims &d, const State &st, uint16_t track, unsigned long long *out, hipStream_t s) {
+  hipMemsetAsync(out, 0, 8, s);
+  hipLaunchKernelGGL(k_count_owner, dim3(2048), dim3(TPB), 0, s, d, st, track, out);
+}
+void launch_pack_pos4(float4 *pos4, const float *px, const float *py, const float *pz, const uint8_t *forget, size_t n,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_pos4, dim3(blocks_for(n)), dim3(TPB), 0, s, pos4, px, py, pz, forget, n);
+}
+void launch_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_unpack_pos4, dim3(blocks_for(n)), dim3(TPB), 0, s, pos4, px, py, pz, forget, n);
+}
+void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t *flags, uint32_t *offs,
+                        uint32_t *scan_scratch, sdm_point *out, uint32_t cap, int want_free, const float sub[3],
+                        hipStream_t s) {
+  hipLaunchKernelGGL(k_flag_results, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st, flags, want_free);
+  hipMemsetAsync(flags + d.v_count, 0, 4, s);
+  exclusive_scan_u32(flags, offs, (size_t)d.v_count + 1, scan_scratch, s);
+  hipLaunchKernelGGL(k_emit_points, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, f, st, flags, offs, out, cap, sub[0],
+                     sub[1], sub[2]);
+}
+
+}  // namespace sdm

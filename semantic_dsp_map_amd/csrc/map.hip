@@ -1,0 +1,1044 @@
+// map.hip — host side of libsdm_hip: the map object behind the C ABI (include/sdm.h).
+//
+// Host work per frame is O(axis length): the ego-centre ring shift of the reference moves no particle
+// data, it only stamps the slabs that were recycled (mc_ring/operations.h:68-96, 1111-1191); everything
+// else is enqueued on one HIP stream with no host synchronisation inside a frame.
+#include <rocrand/rocrand.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sdm_internal.h"
+#include "sdm_scratch.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+thread_local std::string g_last_error;
+
+void set_error(const char *what, const char *file, int line, const char *detail) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), "%s (%s:%d): %s", what, file, line, detail ? detail : "");
+  g_last_error = buf;
+}
+
+#define HIP_TRY(expr)                                                        \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      set_error(#expr, __FILE__, __LINE__, hipGetErrorString(e_));           \
+      return SDM_ERR_HIP;                                                    \
+    }                                                                        \
+  } while (0)
+
+template <typename T>
+hipError_t dev_alloc(T **p, size_t n) {
+  return hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T));
+}
+
+}  // namespace
+
+using namespace sdm;
+
+struct sdm_map {
+  sdm_config cfg{};
+  sdm_params prm{};
+  Dims d{};
+  Frame f{};
+  Filter flt{};
+  BirthOrder bo{};
+  State st{};
+  Scratch sc{};
+  hipStream_t stream = nullptr;
+  int device = 0;
+
+  // host ring-buffer state (mc_ring/buffer.h:97-120)
+  std::vector<uint32_t> stamps_x, stamps_y, stamps_z;
+  int moved_steps[3]{}, eq_steps[3]{};
+  float map_center[3]{}, ego_center[3]{}, last_pos[3]{};
+  uint32_t global_time_stamp = 0;
+  float forgetting_function[5]{};
+  bool forgetting_initialized = false;
+  float cam_R[9]{}, cam_p[3]{};
+
+  // owned device buffers for inputs
+  float *d_depth = nullptr;
+  sdm_labeled_point *d_cloud = nullptr;
+  float *d_ck_part = nullptr;
+  MoveSet *d_moveset = nullptr;
+  uint16_t *d_remove = nullptr;
+  unsigned long long *d_u64 = nullptr;
+  uint32_t *d_flags = nullptr, *d_offs = nullptr;
+  sdm_point *d_points = nullptr;
+  size_t points_cap = 0;
+  int nb_alloc = 0;
+  size_t sort_cap = 0;
+  int noise_n = 0;
+  int flood_rounds = 5;
+
+  bool profiling = false;
+  hipEvent_t ev[9]{};
+  bool ev_valid = false;
+  bool stage_ran[9]{};
+  sdm_stats last_stats{};
+  std::vector<void *> allocs;
+};
+
+namespace {
+
+template <typename T>
+sdm_status alloc_tracked(sdm_map *m, T **p, size_t n) {
+  HIP_TRY(dev_alloc(p, n));
+  m->allocs.push_back((void *)*p);
+  return SDM_OK;
+}
+
+// GaussianRandomCalculator::calculateGaussianTable, PDF part (utils/basic_algorithms.h:405-407, 456-460):
+// entry i = (1/sqrt(2*(pi/2))) * expf(-x^2/2), x = (i-10000)*0.001.  The quirky normaliser is the reference's.
+void build_pdf_table(std::vector<float> &pdf) {
+  pdf.resize(PDF_NUM);
+  const float pi_2 = 1.5707964f;  // M_PI_2f32
+  for (int i = 0; i < PDF_NUM; ++i) {
+    float value = (float)(i - PDF_NUM / 2) * 0.001f;
+    pdf[i] = (1.f / (sqrtf(2.f * pi_2))) * expf(-powf(value, 2) / (2));
+  }
+}
+
+// getForgettingFactor (utils/basic_algorithms.h:32-48): table frozen at first use.
+void refresh_filter(sdm_map *m) {
+  Filter &flt = m->flt;
+  const sdm_params &p = m->prm;
+  if (!m->forgetting_initialized) {
+    for (int i = 0; i < 5; ++i) m->forgetting_function[i] = (float)pow(2.5, -i / p.forgetting_rate);
+  }
+  for (int c = 0; c < 8; ++c)
+    flt.forget[c] = (c < p.max_forget_count && c < 5) ? m->forgetting_function[c] : 0.f;
+  flt.p_detect = p.detection_probability;
+  flt.noise_number = p.noise_number;
+  flt.occ_threshold = p.occupancy_threshold;
+  flt.id_transition = p.id_transition_probability;
+  flt.independent = p.if_use_independent_filter ? 1 : 0;
+  flt.consider_depth_noise = p.if_consider_depth_noise ? 1 : 0;
+  // births per valid pixel: the noise flavour makes nb copies, the plain flavour one (semantic_dsp_map.h:789-795)
+  flt.nb = p.if_consider_depth_noise ? std::max(p.nb_ptc_num_per_point, 0) : 1;
+  flt.use_rng = (p.if_consider_depth_noise && p.nb_ptc_num_per_point != 1) ? 1 : 0;  // :1183-1188
+  flt.noise_n = m->noise_n;
+}
+
+void build_birth_order(sdm_map *m) {
+  const int W = m->d.W, H = m->d.H;
+  int off = 0;
+  for (int p = 0; p < 9; ++p) {
+    int rs = p / 3, cs = p % 3;
+    int rows = rs < H ? (H - rs + 2) / 3 : 0;
+    int cols = cs < W ? (W - cs + 2) / 3 : 0;
+    m->bo.off[p] = off;
+    m->bo.cols[p] = cols > 0 ? cols : 1;
+    off += rows * cols;
+  }
+  m->bo.off[9] = off;
+}
+
+sdm_status ensure_birth_buffers(sdm_map *m) {
+  const size_t hw = (size_t)m->d.W * m->d.H;
+  const int nb = std::max(m->flt.nb, 1);
+  if (nb <= m->nb_alloc) return SDM_OK;
+  size_t need = std::max(hw * nb, (size_t)m->sc.cap_move);
+  auto re = [&](auto **p, size_t n) -> hipError_t {
+    if (*p) (void)hipFree(*p);
+    return dev_alloc(p, n);
+  };
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  HIP_TRY(re(&m->sc.bkey_a, need));
+  HIP_TRY(re(&m->sc.bval_a, need));
+  HIP_TRY(re(&m->sc.bkey_b, need));
+  HIP_TRY(re(&m->sc.bval_b, need));
+  HIP_TRY(re(&m->sc.bpos, hw * nb));
+  HIP_TRY(re(&m->sc.sort_scratch, sort_scratch_elems(need)));
+  m->nb_alloc = nb;
+  m->sort_cap = need;
+  return SDM_OK;
+}
+
+// updateRingbufferIndexParams (mc_ring/operations.h:1111-1191) + getEquivalentSteps* (:1196-1230)
+void update_ring_index_params(sdm_map *m) {
+  const Dims &d = m->d;
+  int steps[3];
+  for (int a = 0; a < 3; ++a) steps[a] = static_cast<int>(m->ego_center[a] * d.recip);
+  for (int a = 0; a < 3; ++a) m->map_center[a] = static_cast<float>(steps[a]) * d.voxel_size;
+  const uint32_t N[3] = {d.NX, d.NY, d.NZ};
+  std::vector<uint32_t> *st[3] = {&m->stamps_x, &m->stamps_y, &m->stamps_z};
+  for (int a = 0; a < 3; ++a) {
+    const int new_moved = steps[a] - m->moved_steps[a];
+    const int n = (int)N[a];
+    if (new_moved > 0) {
+      for (int i = 0; i < new_moved; ++i) (*st[a])[axis_correct(i + m->eq_steps[a], N[a])] = m->global_time_stamp;
+    } else if (new_moved < 0) {
+      for (int i = 0; i < -new_moved; ++i)
+        (*st[a])[axis_correct(n - 1 - i + m->eq_steps[a], N[a])] = m->global_time_stamp;
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    m->moved_steps[a] = steps[a];
+    const int n = (int)N[a];
+    const int o = steps[a];
+    m->eq_steps[a] = o > 0 ? o % n : (o < 0 ? -(-o % n) : 0);
+  }
+}
+
+// updateEgoCenterPos (mc_ring/operations.h:68-96): jumps larger than a quarter of the smallest axis are split.
+// PINNED: norm = sqrt((x*x + y*y) + z*z), normalized() divides by it when it is > 0.
+void update_ego_center(sdm_map *m, const float pos[3]) {
+  const Dims &d = m->d;
+  const float mx = (1 << (d.x_n - 2)) * d.voxel_size;
+  const float my = (1 << (d.y_n - 2)) * d.voxel_size;
+  const float mz = (1 << (d.z_n - 2)) * d.voxel_size;
+  const float max_once = std::min(std::min(mx, my), mz);
+  float mv[3] = {pos[0] - m->last_pos[0], pos[1] - m->last_pos[1], pos[2] - m->last_pos[2]};
+  const float sq = (mv[0] * mv[0] + mv[1] * mv[1]) + mv[2] * mv[2];
+  float dist = sqrtf(sq);
+  float unit[3] = {mv[0], mv[1], mv[2]};
+  if (sq > 0.f)
+    for (int a = 0; a < 3; ++a) unit[a] = mv[a] / dist;
+  float new_pos[3] = {m->last_pos[0], m->last_pos[1], m->last_pos[2]};
+  while (dist > max_once) {
+    for (int a = 0; a < 3; ++a) new_pos[a] = new_pos[a] + unit[a] * max_once;
+    for (int a = 0; a < 3; ++a) m->ego_center[a] = new_pos[a];
+    update_ring_index_params(m);
+    for (int a = 0; a < 3; ++a) mv[a] = pos[a] - new_pos[a];
+    dist = sqrtf((mv[0] * mv[0] + mv[1] * mv[1]) + mv[2] * mv[2]);
+  }
+  for (int a = 0; a < 3; ++a) m->ego_center[a] = pos[a];
+  update_ring_index_params(m);
+  for (int a = 0; a < 3; ++a) m->last_pos[a] = pos[a];
+}
+
+// Extrinsic = inverse of [R(q) | p] (semantic_dsp_map.h:744-747).  PINNED: Eigen's toRotationMatrix
+// formula in float, and the rigid inverse [R^T | -(R^T p)] (Eigen's general 4x4 inverse is version-dependent).
+void compute_extrinsic(sdm_map *m, const float pos[3], const float q[4]) {
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * x, txy = ty * x, txz = tz * x;
+  const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  float *R = m->cam_R;
+  R[0] = 1.f - (tyy + tzz);
+  R[1] = txy - twz;
+  R[2] = txz + twy;
+  R[3] = txy + twz;
+  R[4] = 1.f - (txx + tzz);
+  R[5] = tyz - twx;
+  R[6] = txz - twy;
+  R[7] = tyz + twx;
+  R[8] = 1.f - (txx + tyy);
+  for (int a = 0; a < 3; ++a) m->cam_p[a] = pos[a];
+  float *E = m->f.E;
+  for (int r = 0; r < 3; ++r) {
+    const float a = R[0 * 3 + r], b = R[1 * 3 + r], c = R[2 * 3 + r];
+    E[r * 4 + 0] = a;
+    E[r * 4 + 1] = b;
+    E[r * 4 + 2] = c;
+    E[r * 4 + 3] = -((a * pos[0] + b * pos[1]) + c * pos[2]);
+  }
+  E[12] = E[13] = E[14] = 0.f;
+  E[15] = 1.f;
+}
+
+// Conservative map-index bounding box of the view frustum (the BFS of operations.h:1327-1456 never leaves it)
+// and the BFS start vertex (operations.h:1312-1321).
+void compute_frustum_box(sdm_map *m) {
+  const Dims &d = m->d;
+  Frame &f = m->f;
+  double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+  const double zs[2] = {d.dmin, d.dmax};
+  for (int zi = 0; zi < 2; ++zi)
+    for (int sx = -1; sx <= 1; sx += 2)
+      for (int sy = -1; sy <= 1; sy += 2) {
+        // slightly inflated so that float rounding in the device-side test cannot escape the box
+        double c[3] = {sx * zs[zi] * d.tanx * 1.001, sy * zs[zi] * d.tany * 1.001, zs[zi] * (zi ? 1.001 : 0.999)};
+        for (int a = 0; a < 3; ++a) {
+          double g = (double)m->cam_R[a * 3 + 0] * c[0] + (double)m->cam_R[a * 3 + 1] * c[1] +
+                     (double)m->cam_R[a * 3 + 2] * c[2] + (double)m->cam_p[a];
+          double idx = (g - (double)m->map_center[a] - (double)d.pmin[a]) / (double)d.voxel_size;
+          lo[a] = std::min(lo[a], idx);
+          hi[a] = std::max(hi[a], idx);
+        }
+      }
+  const int N[3] = {(int)d.NX, (int)d.NY, (int)d.NZ};
+  for (int a = 0; a < 3; ++a) {
+    long l = (long)std::floor(lo[a]) - 2, h = (long)std::ceil(hi[a]) + 2;
+    f.bb0[a] = (int)std::min<long>(std::max<long>(l, 0), N[a]);
+    f.bb1[a] = (int)std::min<long>(std::max<long>(h, 0), N[a]);
+  }
+  // start vertex: the point 1 m in front of the camera, p + R*(0,0,1)
+  const float sg[3] = {m->cam_R[2] + m->cam_p[0], m->cam_R[5] + m->cam_p[1], m->cam_R[8] + m->cam_p[2]};
+  f.start_ok = 1;
+  for (int a = 0; a < 3; ++a) {
+    const float sm = sg[a] - m->map_center[a];
+    const int v = static_cast<int>((sm + d.pmax[a]) * d.recip);
+    f.start_v[a] = v;
+    if (v < 0 || v > N[a]) f.start_ok = 0;
+    // keep the start vertex inside the box so that the flood sees it
+    if (f.start_ok) {
+      f.bb0[a] = std::min(f.bb0[a], std::max(v - 1, 0));
+      f.bb1[a] = std::max(f.bb1[a], std::min(v + 1, N[a]));
+    }
+  }
+}
+
+void sync_frame_scalars(sdm_map *m) {
+  for (int a = 0; a < 3; ++a) {
+    m->f.eq[a] = m->eq_steps[a];
+    m->f.center[a] = m->map_center[a];
+  }
+  m->f.gts = m->global_time_stamp;
+}
+
+sdm_status upload_stamps(sdm_map *m) {
+  HIP_TRY(hipMemcpyAsync(m->st.stamps_x, m->stamps_x.data(), m->d.NX * 4, hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipMemcpyAsync(m->st.stamps_y, m->stamps_y.data(), m->d.NY * 4, hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipMemcpyAsync(m->st.stamps_z, m->stamps_z.data(), m->d.NZ * 4, hipMemcpyHostToDevice, m->stream));
+  return SDM_OK;
+}
+
+void host_initialize(sdm_map *m) {
+  std::fill(m->stamps_x.begin(), m->stamps_x.end(), 0u);
+  std::fill(m->stamps_y.begin(), m->stamps_y.end(), 0u);
+  std::fill(m->stamps_z.begin(), m->stamps_z.end(), 0u);
+  m->global_time_stamp = 0;
+}
+
+sdm_status check_counters(sdm_map *m, Counters *out) {
+  Counters c;
+  HIP_TRY(hipMemcpyAsync(&c, m->sc.cnt, sizeof(Counters), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (out) *out = c;
+  if (c.overflow) {
+    set_error("capacity", __FILE__, __LINE__, "visible-particle or move list overflowed (raise sdm_config.max_visible)");
+    return SDM_ERR_CAPACITY;
+  }
+  for (int r = 0; r < 8; ++r)
+    if (r == m->flood_rounds - 1 && c.flood_changed[r]) {
+      set_error("flood", __FILE__, __LINE__, "frustum flood fill still changing in its last round");
+      return SDM_ERR_NOT_CONVERGED;
+    }
+  return SDM_OK;
+}
+
+}  // namespace
+
+// ======================================================================================= C ABI
+extern "C" {
+
+const char *sdm_last_error(void) { return g_last_error.c_str(); }
+const char *sdm_version(void) { return "libsdm_hip 0.1 (gfx950)"; }
+
+sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
+  if (!cfg || !out) return SDM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  // runSystemChecking (mc_ring/operations.h:54-64)
+  if (cfg->x_n + cfg->y_n + cfg->z_n + cfg->p_n > 31 || cfg->x_n < 2 || cfg->y_n < 2 || cfg->z_n < 2 || cfg->p_n < 1 ||
+      cfg->p_n > 4 || cfg->x_n > 9 || cfg->width <= 0 || cfg->height <= 0 || !(cfg->voxel_size > 0.f) ||
+      cfg->window_half < 0) {
+    set_error("sdm_create", __FILE__, __LINE__, "invalid configuration");
+    return SDM_ERR_INVALID_ARGUMENT;
+  }
+  int shard_count = cfg->shard_count > 0 ? cfg->shard_count : 1;
+  if (cfg->shard_rank < 0 || cfg->shard_rank >= shard_count || ((1u << cfg->z_n) % (uint32_t)shard_count) != 0) {
+    set_error("sdm_create", __FILE__, __LINE__, "invalid shard rank/count (count must divide the z axis)");
+    return SDM_ERR_INVALID_ARGUMENT;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+    set_error("sdm_create", __FILE__, __LINE__, "no HIP device / bad device ordinal: libsdm_hip has no CPU path");
+    return SDM_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(cfg->device));
+  sdm_map *m = new sdm_map();
+  m->cfg = *cfg;
+  m->cfg.shard_count = shard_count;
+  m->device = cfg->device;
+  Dims &d = m->d;
+  d.x_n = cfg->x_n;
+  d.y_n = cfg->y_n;
+  d.z_n = cfg->z_n;
+  d.p_n = cfg->p_n;
+  d.NX = 1u << d.x_n;
+  d.NY = 1u << d.y_n;
+  d.NZ = 1u << d.z_n;
+  d.S = 1u << d.p_n;
+  d.V = d.NX * d.NY * d.NZ;
+  d.rz_count = d.NZ / shard_count;
+  d.rz_begin = d.rz_count * cfg->shard_rank;
+  d.v_count = d.V / shard_count;
+  d.v_begin = d.v_count * cfg->shard_rank;
+  d.voxel_size = cfg->voxel_size;
+  d.recip = 1.f / cfg->voxel_size;  // voxel_size_recip, operations.h:743
+  d.pmax[0] = (d.NX >> 1) * cfg->voxel_size;  // operations.h:735-741
+  d.pmax[1] = (d.NY >> 1) * cfg->voxel_size;
+  d.pmax[2] = (d.NZ >> 1) * cfg->voxel_size;
+  for (int a = 0; a < 3; ++a) d.pmin[a] = -d.pmax[a];
+  d.W = cfg->width;
+  d.H = cfg->height;
+  d.fx = cfg->fx;
+  d.fy = cfg->fy;
+  d.cx = cfg->cx;
+  d.cy = cfg->cy;
+  d.dmin = cfg->depth_min;
+  d.dmax = cfg->depth_max;
+  d.tanx = (float)tan(atan2(cfg->width / 2.0, (double)cfg->fx));   // operations.h:1249-1250
+  d.tany = (float)tan(atan2(cfg->height / 2.0, (double)cfg->fy));
+  d.occl_coeff = 0.1f + 1.f;  // g_depth_error_stddev_at_one_meter + 1.f (settings.h:150, operations.h:1387)
+  d.window_half = cfg->window_half;
+  d.max_movable = cfg->max_movable_track;
+  m->stamps_x.assign(d.NX, 0);
+  m->stamps_y.assign(d.NY, 0);
+  m->stamps_z.assign(d.NZ, 0);
+  // defaults of the SemanticDSPMap constructor (semantic_dsp_map.h:25-42)
+  m->prm.detection_probability = 0.95f;
+  m->prm.noise_number = 0.1f;
+  m->prm.nb_ptc_num_per_point = 3;
+  m->prm.occupancy_threshold = 0.2f;
+  m->prm.max_obersevation_lost_time = 5;
+  m->prm.forgetting_rate = 1.0f;
+  m->prm.max_forget_count = 5;
+  m->prm.match_score_threshold = 0.3f;
+  m->prm.id_transition_probability = 0.1f;
+  m->prm.if_consider_depth_noise = 0;
+  m->prm.if_use_independent_filter = 0;
+  m->prm.depth_noise_first_order = 0.f;
+  m->prm.depth_noise_zero_order = 0.1f;
+
+  HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  const size_t n_slots = (size_t)d.v_count * d.S;
+  const size_t hw = (size_t)d.W * d.H;
+  sdm_status rc;
+#define A(ptr, n) \
+  if ((rc = alloc_tracked(m, &(ptr), (n))) != SDM_OK) return rc;
+  A(m->st.pos4, n_slots);
+  A(m->st.w, n_slots);
+  A(m->st.ts, n_slots);
+  A(m->st.track, n_slots);
+  A(m->st.label, n_slots);
+  A(m->st.status, n_slots);
+  A(m->st.owner, n_slots);
+  A(m->st.res, d.v_count);
+  A(m->st.stamps_x, d.NX);
+  A(m->st.stamps_y, d.NY);
+  A(m->st.stamps_z, d.NZ);
+  A(m->st.pdf, PDF_NUM);
+  m->noise_n = 1000000;  // GAUSSIAN_RANDOM_NUM, basic_algorithms.h:377
+  A(m->st.noise, m->noise_n);
+  HIP_TRY(hipMemsetAsync(m->st.noise, 0, (size_t)m->noise_n * 4, m->stream));
+  {
+    std::vector<float> pdf;
+    build_pdf_table(pdf);
+    HIP_TRY(hipMemcpy(m->st.pdf, pdf.data(), PDF_NUM * 4, hipMemcpyHostToDevice));
+  }
+  Scratch &sc = m->sc;
+  sc.wpl = (int)((d.NX + 1 + 63) / 64);
+  const size_t n_words = (size_t)(d.NZ + 1) * (d.NY + 1) * sc.wpl;
+  A(sc.vmask, n_words);
+  A(sc.reach, n_words);
+  A(m->d_depth, hw);
+  A(m->d_cloud, hw);
+  A(sc.bin_count, hw + 1);
+  A(sc.bin_start, hw + 1);
+  size_t cap_vis = cfg->max_visible > 0 ? (size_t)cfg->max_visible : std::min<size_t>(n_slots, (size_t)16 << 20);
+  cap_vis = std::min<size_t>(cap_vis, 0xffffff00u);
+  sc.cap_vis = (uint32_t)cap_vis;
+  A(sc.vis_pix, cap_vis);
+  A(sc.vis_idx, cap_vis);
+  A(sc.vis_pib, cap_vis);
+  A(sc.bin_idx, cap_vis);
+  A(sc.vpix, cap_vis);
+  A(sc.vx, cap_vis);
+  A(sc.vy, cap_vis);
+  A(sc.vz, cap_vis);
+  A(sc.vw, cap_vis);
+  A(sc.vtrack, cap_vis);
+  A(sc.vforget, cap_vis);
+  A(sc.ck_kappa, hw);
+  A(m->d_ck_part, hw);
+  A(sc.b_valid, hw + 1);
+  A(sc.b_rank, hw + 1);
+  sc.cap_move = (uint32_t)std::min<size_t>(n_slots, (size_t)1 << 20);
+  A(sc.mv_src, sc.cap_move);
+  A(sc.mv_total, 4);
+  const size_t mv_cnt_n = (size_t)MAX_MOVE_OBJECTS * move_blocks(d) + 1;
+  A(sc.mv_cnt, mv_cnt_n);
+  A(sc.mv_pos, sc.cap_move);
+  A(sc.mv_w, sc.cap_move);
+  A(sc.mv_ts, sc.cap_move);
+  A(sc.mv_track, sc.cap_move);
+  A(sc.mv_owner, sc.cap_move);
+  A(sc.mv_label, sc.cap_move);
+  A(sc.mv_status, sc.cap_move);
+  A(sc.track_to_obj, 65536);
+  HIP_TRY(hipMemsetAsync(sc.track_to_obj, 0xFF, 65536, m->stream));
+  size_t scan_need = std::max({scan_scratch_elems(hw + 1), scan_scratch_elems(mv_cnt_n), scan_scratch_elems((size_t)d.v_count + 1)});
+  A(sc.scan_scratch, scan_need + 16);
+  A(sc.cnt, 1);
+  A(sc.cur, 1);
+  HIP_TRY(hipMemsetAsync(sc.cnt, 0, sizeof(Counters), m->stream));
+  HIP_TRY(hipMemsetAsync(sc.cur, 0, sizeof(Cursors), m->stream));
+  A(m->d_moveset, 1);
+  A(m->d_remove, 1024);
+  A(m->d_u64, 1);
+  A(m->d_flags, (size_t)d.v_count + 1);
+  A(m->d_offs, (size_t)d.v_count + 1);
+#undef A
+  sc.depth = m->d_depth;
+  sc.cloud = m->d_cloud;
+  refresh_filter(m);
+  build_birth_order(m);
+  if ((rc = ensure_birth_buffers(m)) != SDM_OK) return rc;
+  for (int i = 0; i < 9; ++i) HIP_TRY(hipEventCreate(&m->ev[i]));
+  m->ev_valid = true;
+  // RingBufferOperations::initialize (operations.h:726-767)
+  host_initialize(m);
+  launch_clear(d, m->st, m->stream);
+  if ((rc = upload_stamps(m)) != SDM_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  *out = m;
+  return SDM_OK;
+}
+
+sdm_status sdm_destroy(sdm_map *m) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(m->device);
+  (void)hipStreamSynchronize(m->stream);
+  for (void *p : m->allocs) (void)hipFree(p);
+  void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points};
+  for (void *p : extra)
+    if (p) (void)hipFree(p);
+  if (m->ev_valid)
+    for (int i = 0; i < 9; ++i) (void)hipEventDestroy(m->ev[i]);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+  return SDM_OK;
+}
+
+// SemanticDSPMap::clear (semantic_dsp_map.h:74-81): ring buffer + stamps + global time stamp + object sets;
+// the movement of the ring buffer is retained (operations.h:683).
+sdm_status sdm_clear(sdm_map *m) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  host_initialize(m);
+  launch_clear(m->d, m->st, m->stream);
+  return upload_stamps(m);
+}
+
+sdm_status sdm_set_params(sdm_map *m, const sdm_params *p) {
+  if (!m || !p) return SDM_ERR_INVALID_ARGUMENT;
+  if (p->nb_ptc_num_per_point < 0 || p->nb_ptc_num_per_point > 64) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  m->prm = *p;
+  refresh_filter(m);
+  return ensure_birth_buffers(m);
+}
+
+sdm_status sdm_generate_noise_table(sdm_map *m, uint64_t seed, int32_t n, float stddev) {
+  if (!m || n <= 0 || n > m->noise_n || (n & 1)) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  rocrand_generator gen;
+  if (rocrand_create_generator(&gen, ROCRAND_RNG_PSEUDO_PHILOX4_32_10) != ROCRAND_STATUS_SUCCESS) {
+    set_error("rocrand_create_generator", __FILE__, __LINE__, "failed");
+    return SDM_ERR_HIP;
+  }
+  rocrand_status rs = rocrand_set_seed(gen, seed);
+  if (rs == ROCRAND_STATUS_SUCCESS) rs = rocrand_set_stream(gen, m->stream);
+  if (rs == ROCRAND_STATUS_SUCCESS) rs = rocrand_generate_normal(gen, m->st.noise, (size_t)n, 0.0f, stddev);
+  (void)hipStreamSynchronize(m->stream);
+  rocrand_destroy_generator(gen);
+  if (rs != ROCRAND_STATUS_SUCCESS) {
+    set_error("rocrand_generate_normal", __FILE__, __LINE__, "failed");
+    return SDM_ERR_HIP;
+  }
+  m->flt.noise_n = n;
+  return SDM_OK;
+}
+
+sdm_status sdm_upload_noise_table(sdm_map *m, const float *table, int32_t n) {
+  if (!m || !table || n <= 0 || n > m->noise_n) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMemcpyAsync(m->st.noise, table, (size_t)n * 4, hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  m->flt.noise_n = n;
+  return SDM_OK;
+}
+
+sdm_status sdm_download_noise_table(sdm_map *m, float *table, int32_t n) {
+  if (!m || !table || n <= 0 || n > m->noise_n) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMemcpyAsync(table, m->st.noise, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return SDM_OK;
+}
+
+sdm_status sdm_download_pdf_table(sdm_map *m, float *table, int32_t n) {
+  if (!m || !table || n <= 0 || n > PDF_NUM) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMemcpyAsync(table, m->st.pdf, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return SDM_OK;
+}
+
+// ---- the frame ---------------------------------------------------------------------------------
+// First half of subObjectLevelUpdate (semantic_dsp_map.h:576-764): prediction, visibility/binning and
+// this shard's partial ck image.  ck_part_dev receives the device pointer of that image (H*W floats).
+sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
+                            const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
+                            const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after,
+                            const float **ck_part_dev) {
+  if (!m || !depth || !cloud || !cam_pos || !cam_q || n_moves < 0 || n_remove < 0 || (n_moves && !moves) ||
+      (n_remove && !remove_tracks) || n_moves > MAX_MOVE_OBJECTS || n_remove > 1024)
+    return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  const Dims &d = m->d;
+  const size_t hw = (size_t)d.W * d.H;
+  auto done = [&](int stage) { return stop_after != 0 && stop_after <= stage; };
+  for (int i = 0; i < 9; ++i) m->stage_ran[i] = false;
+  auto mark = [&](int stage) {
+    if (m->profiling) {
+      (void)hipEventRecord(m->ev[stage], s);
+      m->stage_ran[stage] = true;
+    }
+  };
+
+  m->global_time_stamp += 1;  // semantic_dsp_map.h:173
+  mark(0);
+  HIP_TRY(hipMemsetAsync(m->sc.cnt, 0, sizeof(Counters), s));
+  if (flags & SDM_INPUT_ON_DEVICE) {
+    m->sc.depth = depth;
+    m->sc.cloud = cloud;
+  } else {
+    HIP_TRY(hipMemcpyAsync(m->d_depth, depth, hw * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(m->d_cloud, cloud, hw * sizeof(sdm_labeled_point), hipMemcpyHostToDevice, s));
+    m->sc.depth = m->d_depth;
+    m->sc.cloud = m->d_cloud;
+  }
+  // P1: ego-centre ring shift (semantic_dsp_map.h:584-585)
+  update_ego_center(m, cam_pos);
+  sync_frame_scalars(m);
+  sdm_status rc = upload_stamps(m);
+  if (rc != SDM_OK) return rc;
+  refresh_filter(m);
+  m->forgetting_initialized = true;  // the reference freezes its forgetting table at the first update
+  compute_extrinsic(m, cam_pos, cam_q);
+  compute_frustum_box(m);
+  mark(1);
+  if (done(1)) return SDM_OK;
+
+  // P2: object moves (semantic_dsp_map.h:588-699)
+  if (n_moves > 0) {
+    MoveSet ms;
+    memset(&ms, 0, sizeof(ms));
+    ms.n = n_moves;
+    for (int k = 0; k < n_moves; ++k) {
+      ms.track[k] = (uint16_t)moves[k].track_id;
+      memcpy(ms.T[k], moves[k].T, 12 * sizeof(float));
+    }
+    HIP_TRY(hipMemcpyAsync(m->d_moveset, &ms, sizeof(ms), hipMemcpyHostToDevice, s));
+    launch_moves(d, m->f, m->flt, m->d_moveset, n_moves, m->st, m->sc, s);
+  }
+  mark(2);
+  if (done(2)) return SDM_OK;
+
+  // P3: removals (semantic_dsp_map.h:702-736)
+  if (n_remove > 0) {
+    std::vector<uint16_t> tr(n_remove);
+    for (int k = 0; k < n_remove; ++k) tr[k] = (uint16_t)remove_tracks[k];
+    HIP_TRY(hipMemcpyAsync(m->d_remove, tr.data(), n_remove * 2, hipMemcpyHostToDevice, s));
+    launch_remove(d, m->st, m->d_remove, n_remove, s);
+  }
+  mark(3);
+  if (done(3)) return SDM_OK;
+
+  // U1: visibility + binning (semantic_dsp_map.h:749)
+  launch_visibility(d, m->f, m->st, m->sc, m->flood_rounds, s);
+  mark(4);
+  if (done(4)) return SDM_OK;
+
+  // U2 pass 1: this shard's ck partial sums
+  launch_ck(d, m->flt, m->st, m->sc, m->d_ck_part, s);
+  if (ck_part_dev) *ck_part_dev = m->d_ck_part;
+  return SDM_OK;
+}
+
+// Second half: ck_kappa from the per-shard partial images (n_parts consecutive H*W images, slab order),
+// weight update, births/resampling, occupancy sweep.
+sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_parts, uint32_t flags, int32_t stop_after) {
+  if (!m || n_parts < 1) return SDM_ERR_INVALID_ARGUMENT;
+  if (stop_after != 0 && stop_after <= SDM_STAGE_VISIBILITY) return SDM_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  const Dims &d = m->d;
+  auto done = [&](int stage) { return stop_after != 0 && stop_after <= stage; };
+  auto mark = [&](int stage) {
+    if (m->profiling) {
+      (void)hipEventRecord(m->ev[stage], s);
+      m->stage_ran[stage] = true;
+    }
+  };
+  launch_ck_finish(d, m->flt, m->sc, ck_parts_dev ? ck_parts_dev : m->d_ck_part, ck_parts_dev ? n_parts : 1, s);
+  launch_weight(d, m->f, m->flt, m->st, m->sc, s);
+  mark(5);
+  if (done(5)) return SDM_OK;
+  launch_births(d, m->f, m->flt, m->bo, m->st, m->sc, s);
+  mark(6);
+  if (done(6)) return SDM_OK;
+  if (!(flags & SDM_SKIP_OCCUPANCY)) launch_occupancy(d, m->flt, m->st, s);
+  mark(7);
+  return SDM_OK;
+}
+
+sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
+                      const float cam_q[4], const sdm_object_move *moves, int32_t n_moves, const int32_t *remove_tracks,
+                      int32_t n_remove, uint32_t flags, int32_t stop_after) {
+  sdm_status rc = sdm_update_begin(m, depth, cloud, cam_pos, cam_q, moves, n_moves, remove_tracks, n_remove, flags,
+                                   stop_after, nullptr);
+  if (rc != SDM_OK) return rc;
+  return sdm_update_finish(m, nullptr, 1, flags, stop_after);
+}
+
+sdm_status sdm_synchronize(sdm_map *m) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return check_counters(m, nullptr);
+}
+
+sdm_status sdm_stream(sdm_map *m, void **stream_out) {
+  if (!m || !stream_out) return SDM_ERR_INVALID_ARGUMENT;
+  *stream_out = (void *)m->stream;
+  return SDM_OK;
+}
+
+// ---- results ----------------------------------------------------------------------------------
+sdm_status sdm_get_voxels(sdm_map *m, sdm_voxel_result *out) {
+  if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMemcpyAsync(out, m->st.res, (size_t)m->d.v_count * sizeof(sdm_voxel_result), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return SDM_OK;
+}
+
+static sdm_status get_points(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int zero_center, int want_free) {
+  if (!m || !n_out || (cap && !out)) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  if (cap > m->points_cap) {
+    if (m->d_points) HIP_TRY(hipFree(m->d_points));
+    m->d_points = nullptr;
+    HIP_TRY(dev_alloc(&m->d_points, cap));
+    m->points_cap = cap;
+  }
+  // visualize_with_zero_center: subtract the camera position (semantic_dsp_map.h:1263-1271)
+  float sub[3] = {0.f, 0.f, 0.f};
+  if (zero_center)
+    for (int a = 0; a < 3; ++a) sub[a] = m->cam_p[a];
+  uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0xffffffffu);
+  launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->sc.scan_scratch, m->d_points, cap32, want_free, sub, m->stream);
+  uint32_t total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, m->d_offs + m->d.v_count, 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  *n_out = total;
+  size_t ncopy = std::min<size_t>(total, cap);
+  if (ncopy) HIP_TRY(hipMemcpy(out, m->d_points, ncopy * sizeof(sdm_point), hipMemcpyDeviceToHost));
+  return SDM_OK;
+}
+sdm_status sdm_get_occupied(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t zero_center) {
+  return get_points(m, out, cap, n_out, zero_center, 0);
+}
+sdm_status sdm_get_freespace(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t zero_center) {
+  return get_points(m, out, cap, n_out, zero_center, 1);
+}
+sdm_status sdm_voxels_device_ptr(sdm_map *m, const sdm_voxel_result **out) {
+  if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
+  *out = m->st.res;
+  return SDM_OK;
+}
+
+sdm_status sdm_object_particle_count(sdm_map *m, int32_t track_id, int64_t *count) {
+  if (!m || !count || track_id < 0 || track_id > 65535) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  launch_count_owner(m->d, m->st, (uint16_t)track_id, m->d_u64, m->stream);
+  unsigned long long c = 0;
+  HIP_TRY(hipMemcpyAsync(&c, m->d_u64, 8, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  *count = (int64_t)c;
+  return SDM_OK;
+}
+
+// ---- introspection ------------------------------------------------------------------------------
+sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
+  if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  Counters c;
+  sdm_status rc = check_counters(m, &c);
+  memset(out, 0, sizeof(*out));
+  out->n_visible = c.n_vis;
+  out->n_birth_attempts = c.n_birth_attempts;
+  out->n_birth_success = c.n_birth_success;
+  out->n_resampled_voxels = c.n_resampled;
+  out->n_moved = c.n_moved;
+  out->n_move_reinserted = c.n_move_reinserted;
+  out->n_frustum_voxels = c.n_frustum_voxels;
+  out->bfs_start_in_frustum = c.start_in_frustum;
+  for (int r = 0; r < 8; ++r)
+    if (c.flood_changed[r]) out->flood_rounds = r + 1;
+  if (m->profiling) {
+    int prev = 0;
+    for (int sidx = 1; sidx <= 7; ++sidx) {
+      if (!m->stage_ran[sidx]) continue;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, m->ev[prev], m->ev[sidx]) == hipSuccess) out->stage_ms[sidx] = ms;
+      prev = sidx;
+    }
+  }
+  if (count_live) {
+    launch_count_live(m->d, m->st, m->d_u64, m->stream);
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, m->d_u64, 8, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    out->live_particles = (int64_t)n;
+    size_t nocc = 0;
+    // occupied voxel count from the result array
+    const float zero3[3] = {0.f, 0.f, 0.f};
+    launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->sc.scan_scratch, m->d_points, 0, 0, zero3, m->stream);
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, m->d_offs + m->d.v_count, 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    nocc = total;
+    out->n_occupied = (int64_t)nocc;
+  }
+  return rc;
+}
+
+sdm_status sdm_set_profiling(sdm_map *m, int32_t on) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  m->profiling = on != 0;
+  return SDM_OK;
+}
+
+sdm_status sdm_get_ring_state(sdm_map *m, sdm_ring_state *o) {
+  if (!m || !o) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  Cursors c;
+  HIP_TRY(hipMemcpyAsync(&c, m->sc.cur, sizeof(c), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  o->global_time_stamp = m->global_time_stamp;
+  for (int a = 0; a < 3; ++a) {
+    o->moved_steps[a] = m->moved_steps[a];
+    o->eq_steps[a] = m->eq_steps[a];
+    o->map_center[a] = m->map_center[a];
+    o->last_pos[a] = m->last_pos[a];
+  }
+  o->birth_cursor = c.birth_cursor;
+  o->move_cursor = c.move_cursor;
+  return SDM_OK;
+}
+
+sdm_status sdm_set_ring_state(sdm_map *m, const sdm_ring_state *o) {
+  if (!m || !o) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  m->global_time_stamp = o->global_time_stamp;
+  for (int a = 0; a < 3; ++a) {
+    m->moved_steps[a] = o->moved_steps[a];
+    m->eq_steps[a] = o->eq_steps[a];
+    m->map_center[a] = o->map_center[a];
+    m->last_pos[a] = o->last_pos[a];
+  }
+  Cursors c{o->birth_cursor, o->move_cursor};
+  HIP_TRY(hipMemcpyAsync(m->sc.cur, &c, sizeof(c), hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  sync_frame_scalars(m);
+  return SDM_OK;
+}
+
+sdm_status sdm_get_stamps(sdm_map *m, uint32_t *sx, uint32_t *sy, uint32_t *sz) {
+  if (!m || !sx || !sy || !sz) return SDM_ERR_INVALID_ARGUMENT;
+  memcpy(sx, m->stamps_x.data(), m->d.NX * 4);
+  memcpy(sy, m->stamps_y.data(), m->d.NY * 4);
+  memcpy(sz, m->stamps_z.data(), m->d.NZ * 4);
+  return SDM_OK;
+}
+sdm_status sdm_set_stamps(sdm_map *m, const uint32_t *sx, const uint32_t *sy, const uint32_t *sz) {
+  if (!m || !sx || !sy || !sz) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  memcpy(m->stamps_x.data(), sx, m->d.NX * 4);
+  memcpy(m->stamps_y.data(), sy, m->d.NY * 4);
+  memcpy(m->stamps_z.data(), sz, m->d.NZ * 4);
+  sdm_status rc = upload_stamps(m);
+  if (rc != SDM_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return SDM_OK;
+}
+
+sdm_status sdm_dump_state(sdm_map *m, float *px, float *py, float *pz, float *w, uint16_t *ts, uint16_t *track,
+                          uint8_t *label, uint8_t *status, uint8_t *forget, uint16_t *owner) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  const size_t n = (size_t)m->d.v_count * m->d.S;
+  if (px || py || pz || forget) {
+    float *tx, *ty, *tz;
+    uint8_t *tf;
+    HIP_TRY(dev_alloc(&tx, n));
+    HIP_TRY(dev_alloc(&ty, n));
+    HIP_TRY(dev_alloc(&tz, n));
+    HIP_TRY(dev_alloc(&tf, n));
+    launch_unpack_pos4(m->st.pos4, tx, ty, tz, tf, n, s);
+    if (px) HIP_TRY(hipMemcpyAsync(px, tx, n * 4, hipMemcpyDeviceToHost, s));
+    if (py) HIP_TRY(hipMemcpyAsync(py, ty, n * 4, hipMemcpyDeviceToHost, s));
+    if (pz) HIP_TRY(hipMemcpyAsync(pz, tz, n * 4, hipMemcpyDeviceToHost, s));
+    if (forget) HIP_TRY(hipMemcpyAsync(forget, tf, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(tx);
+    (void)hipFree(ty);
+    (void)hipFree(tz);
+    (void)hipFree(tf);
+  }
+  if (w) HIP_TRY(hipMemcpyAsync(w, m->st.w, n * 4, hipMemcpyDeviceToHost, s));
+  if (ts) HIP_TRY(hipMemcpyAsync(ts, m->st.ts, n * 2, hipMemcpyDeviceToHost, s));
+  if (track) HIP_TRY(hipMemcpyAsync(track, m->st.track, n * 2, hipMemcpyDeviceToHost, s));
+  if (label) HIP_TRY(hipMemcpyAsync(label, m->st.label, n, hipMemcpyDeviceToHost, s));
+  if (status) HIP_TRY(hipMemcpyAsync(status, m->st.status, n, hipMemcpyDeviceToHost, s));
+  if (owner) HIP_TRY(hipMemcpyAsync(owner, m->st.owner, n * 2, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return SDM_OK;
+}
+
+sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const float *pz, const float *w,
+                          const uint16_t *ts, const uint16_t *track, const uint8_t *label, const uint8_t *status,
+                          const uint8_t *forget, const uint16_t *owner) {
+  if (!m || !px || !py || !pz || !w || !ts || !track || !label || !status || !forget) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  const size_t n = (size_t)m->d.v_count * m->d.S;
+  float *tx, *ty, *tz;
+  uint8_t *tf;
+  HIP_TRY(dev_alloc(&tx, n));
+  HIP_TRY(dev_alloc(&ty, n));
+  HIP_TRY(dev_alloc(&tz, n));
+  HIP_TRY(dev_alloc(&tf, n));
+  HIP_TRY(hipMemcpyAsync(tx, px, n * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ty, py, n * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(tz, pz, n * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(tf, forget, n, hipMemcpyHostToDevice, s));
+  launch_pack_pos4(m->st.pos4, tx, ty, tz, tf, n, s);
+  HIP_TRY(hipMemcpyAsync(m->st.w, w, n * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(m->st.ts, ts, n * 2, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(m->st.track, track, n * 2, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(m->st.label, label, n, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(m->st.status, status, n, hipMemcpyHostToDevice, s));
+  if (owner) HIP_TRY(hipMemcpyAsync(m->st.owner, owner, n * 2, hipMemcpyHostToDevice, s));
+  else HIP_TRY(hipMemsetAsync(m->st.owner, 0xFF, n * 2, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  (void)hipFree(tx);
+  (void)hipFree(ty);
+  (void)hipFree(tz);
+  (void)hipFree(tf);
+  return SDM_OK;
+}
+
+sdm_status sdm_get_ck_kappa(sdm_map *m, float *out) {
+  if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMemcpyAsync(out, m->sc.ck_kappa, (size_t)m->d.W * m->d.H * 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return SDM_OK;
+}
+sdm_status sdm_get_bin_counts(sdm_map *m, uint32_t *out) {
+  if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMemcpyAsync(out, m->sc.bin_count, (size_t)m->d.W * m->d.H * 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return SDM_OK;
+}
+sdm_status sdm_get_bins(sdm_map *m, uint32_t *out, int64_t cap, int64_t *n_out) {
+  if (!m || !n_out) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  Counters c;
+  HIP_TRY(hipMemcpyAsync(&c, m->sc.cnt, sizeof(c), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  *n_out = c.n_vis;
+  int64_t ncopy = std::min<int64_t>(std::min<int64_t>(c.n_vis, cap), m->sc.cap_vis);
+  if (ncopy > 0 && out) HIP_TRY(hipMemcpy(out, m->sc.bin_idx, (size_t)ncopy * 4, hipMemcpyDeviceToHost));
+  return SDM_OK;
+}
+sdm_status sdm_get_extrinsic(sdm_map *m, float *out16) {
+  if (!m || !out16) return SDM_ERR_INVALID_ARGUMENT;
+  memcpy(out16, m->f.E, 64);
+  return SDM_OK;
+}
+
+// Roofline helper for bench.py: the occupancy sweep alone, `iters` launches on the map's stream,
+// bracketed by HIP events on that stream.
+sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms) {
+  if (!m || !avg_ms || iters <= 0) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a));
+  HIP_TRY(hipEventCreate(&b));
+  launch_occupancy(m->d, m->flt, m->st, m->stream);  // warm-up
+  HIP_TRY(hipEventRecord(a, m->stream));
+  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->flt, m->st, m->stream);
+  HIP_TRY(hipEventRecord(b, m->stream));
+  HIP_TRY(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  *avg_ms = ms / iters;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return SDM_OK;
+}
+
+// ---- unit-test hooks for the primitives -------------------------------------------------------
+sdm_status sdm_test_scan(const uint32_t *in, uint32_t *out, int64_t n) {
+  if (!in || !out || n <= 0) return SDM_ERR_INVALID_ARGUMENT;
+  uint32_t *din, *dout, *scr;
+  HIP_TRY(dev_alloc(&din, (size_t)n));
+  HIP_TRY(dev_alloc(&dout, (size_t)n));
+  HIP_TRY(dev_alloc(&scr, scan_scratch_elems((size_t)n) + 16));
+  HIP_TRY(hipMemcpy(din, in, (size_t)n * 4, hipMemcpyHostToDevice));
+  exclusive_scan_u32(din, dout, (size_t)n, scr, nullptr);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(din);
+  (void)hipFree(dout);
+  (void)hipFree(scr);
+  return SDM_OK;
+}
+
+sdm_status sdm_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
+                               int64_t n, int32_t nbits) {
+  if (!keys_in || !vals_in || !keys_out || !vals_out || n <= 0 || nbits <= 0 || nbits > 32) return SDM_ERR_INVALID_ARGUMENT;
+  uint32_t *ka, *va, *kb, *vb, *scr;
+  HIP_TRY(dev_alloc(&ka, (size_t)n));
+  HIP_TRY(dev_alloc(&va, (size_t)n));
+  HIP_TRY(dev_alloc(&kb, (size_t)n));
+  HIP_TRY(dev_alloc(&vb, (size_t)n));
+  HIP_TRY(dev_alloc(&scr, sort_scratch_elems((size_t)n) + 16));
+  HIP_TRY(hipMemcpy(ka, keys_in, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(va, vals_in, (size_t)n * 4, hipMemcpyHostToDevice));
+  int which = radix_sort_pairs(ka, va, kb, vb, (size_t)n, nbits, scr, nullptr);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(keys_out, which ? kb : ka, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(vals_out, which ? vb : va, (size_t)n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(ka);
+  (void)hipFree(va);
+  (void)hipFree(kb);
+  (void)hipFree(vb);
+  (void)hipFree(scr);
+  return SDM_OK;
+}
+
+}  // extern "C"

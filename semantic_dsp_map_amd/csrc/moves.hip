@@ -1,0 +1,278 @@
+// moves.hip — object-level prediction of the particle layer (gfx950).
+//
+// Reference: SemanticDSPMap::subObjectLevelUpdate collection loop + moveParticlesInSetsByTransformations
+// (semantic_dsp_map.h:588-699, mc_ring/operations.h:321-362) and ObjectSet::removeObjectByTrackID
+// (object_layer.h:414-425).
+//
+// Owner sets (ObjectParticleHashMap, object_layer.h:20-52) live on the device as a per-slot u16 shadow
+// array: slot i belongs to set(T) iff owner[i] == T.  Collecting an object's particles is therefore a
+// streaming sweep of that array with a stable multi-bin partition (ballot ranks inside a wave, LDS
+// counters across waves, one exclusive scan across blocks) — the result is every moving object's
+// particle list in ascending particle index, which is the iteration order the oracle pins for the
+// reference's std::unordered_set (DESIGN.md "pinned choices").
+#include "sdm_internal.h"
+#include "sdm_scratch.h"
+
+#pragma clang fp contract(off)
+
+namespace sdm {
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MV_ITEMS = 16;
+constexpr int MV_CHUNK = TPB * MV_ITEMS;  // slots per block
+constexpr int MV_WAVES = TPB / 64;
+
+__global__ void k_move_table(const MoveSet *ms, uint8_t *table) {
+  int k = threadIdx.x;
+  if (k < ms->n) table[ms->track[k]] = (uint8_t)k;
+}
+__global__ void k_move_table_reset(const MoveSet *ms, uint8_t *table) {
+  int k = threadIdx.x;
+  if (k < ms->n) table[ms->track[k]] = 0xFF;
+}
+
+__device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint8_t *__restrict__ table) {
+  return owner == OWNER_NONE ? (uint8_t)0xFF : table[owner];
+}
+
+// pass 1: per-block, per-object member counts.  cnt[obj * n_blocks + block]
+__global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__ owner, size_t n_slots,
+                                                    const uint8_t *__restrict__ table, uint32_t *__restrict__ cnt,
+                                                    uint32_t n_blocks, int n_obj) {
+  __shared__ uint32_t c[MAX_MOVE_OBJECTS];
+  if (threadIdx.x < MAX_MOVE_OBJECTS) c[threadIdx.x] = 0;
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * MV_CHUNK;
+#pragma unroll 4
+  for (int r = 0; r < MV_ITEMS; ++r) {
+    size_t i = base + (size_t)r * TPB + threadIdx.x;
+    if (i < n_slots) {
+      uint8_t o = obj_of(owner[i], table);
+      if (o != 0xFF) atomicAdd(&c[o], 1u);
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * n_blocks + blockIdx.x] = c[threadIdx.x];
+}
+
+// pass 2 (after the exclusive scan of cnt): stable scatter of the member indices.
+__global__ __launch_bounds__(TPB) void k_move_scatter(const uint16_t *__restrict__ owner, size_t n_slots, size_t slot_base,
+                                                      const uint8_t *__restrict__ table, const uint32_t *__restrict__ offs,
+                                                      uint32_t n_blocks, int n_obj, uint32_t *__restrict__ mv_src,
+                                                      uint32_t cap, Counters *cnt) {
+  __shared__ uint32_t obj_base[MAX_MOVE_OBJECTS];
+  __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
+  __shared__ uint32_t block_total;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) block_total = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < n_obj) {
+    uint32_t o0 = offs[(size_t)threadIdx.x * n_blocks + blockIdx.x];
+    uint32_t o1 = offs[(size_t)threadIdx.x * n_blocks + blockIdx.x + 1];  // next block (or next object's first block)
+    obj_base[threadIdx.x] = o0;
+    if (o1 != o0) atomicAdd(&block_total, o1 - o0);
+  }
+  __syncthreads();
+  if (block_total == 0) return;  // no member of any moving object in this chunk
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  size_t base = (size_t)blockIdx.x * MV_CHUNK;
+  for (int r = 0; r < MV_ITEMS; ++r) {
+    if (threadIdx.x < MAX_MOVE_OBJECTS) {
+#pragma unroll
+      for (int w = 0; w < MV_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+    }
+    __syncthreads();
+    size_t i = base + (size_t)r * TPB + threadIdx.x;
+    uint8_t o = 0xFF;
+    if (i < n_slots) o = obj_of(owner[i], table);
+    bool valid = o != 0xFF;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      bool bit = (o >> b) & 1u;
+      uint64_t m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
+    if (valid && rank_in_wave == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
+    __syncthreads();
+    if (valid) {
+      uint32_t off = obj_base[o] + rank_in_wave;
+#pragma unroll
+      for (int w = 0; w < MV_WAVES; ++w)
+        if (w < wid) off += wave_cnt[w][o];
+      if (off < cap) mv_src[off] = (uint32_t)(slot_base + i);
+      else cnt->overflow = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x < MAX_MOVE_OBJECTS) {
+      uint32_t add = 0;
+#pragma unroll
+      for (int w = 0; w < MV_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
+      obj_base[threadIdx.x] += add;
+    }
+    __syncthreads();
+  }
+}
+
+// phase 1 of moveParticlesInSetsByTransformations (operations.h:331-349): copy, transform + table noise,
+// delete the original.  e = rank of the particle in (object order, ascending index); the noise cursor
+// advances by three per particle in exactly that order.
+__global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter flt, const MoveSet *ms, State st, Scratch sc,
+                                                        const uint32_t *__restrict__ offs, uint32_t n_blocks, int n_obj) {
+  const uint32_t total = offs[(size_t)n_obj * n_blocks];
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    sc.cnt->n_moved = total;
+    *sc.mv_total = total < sc.cap_move ? total : sc.cap_move;
+  }
+  if (sc.cnt->overflow) return;
+  const size_t slot_base = (size_t)d.v_begin << d.p_n;
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total && e < sc.cap_move; e += stride) {
+    int obj = 0;
+    for (int k = 1; k < n_obj; ++k)
+      if (e >= offs[(size_t)k * n_blocks]) obj = k;
+    const uint32_t src = sc.mv_src[e];
+    const size_t li = (size_t)src - slot_base;
+    const float4 p = st.pos4[li];
+    const float *T = ms->T[obj];
+    float nx = row4(T + 0, p.x, p.y, p.z);
+    float ny = row4(T + 4, p.x, p.y, p.z);
+    float nz = row4(T + 8, p.x, p.y, p.z);
+    long long draw = (long long)sc.cur->move_cursor + 3ll * e;
+    nx = nx + st.noise[(draw + 1) % flt.noise_n];
+    ny = ny + st.noise[(draw + 2) % flt.noise_n];
+    nz = nz + st.noise[(draw + 3) % flt.noise_n];
+    sc.mv_pos[e] = make_float4(nx, ny, nz, p.w);
+    sc.mv_w[e] = st.w[li];
+    sc.mv_ts[e] = st.ts[li];
+    sc.mv_track[e] = st.track[li];
+    sc.mv_label[e] = st.label[li];
+    sc.mv_status[e] = st.status[li];
+    sc.mv_owner[e] = ms->track[obj];
+    st.status[li] = ST_INVALID;  // deleteParticleByIndex
+    st.owner[li] = OWNER_NONE;   // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
+    uint32_t rx, ry, rz;
+    uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
+    uint32_t key = d.V;
+    if (v != INVALID_INDEX && rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) key = v;
+    sc.bkey_a[e] = key;
+    sc.bval_a[e] = e;
+  }
+}
+
+__global__ void k_move_cursor(Filter flt, Scratch sc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long long c = (long long)sc.cur->move_cursor + 3ll * (long long)sc.cnt->n_moved;
+  sc.cur->move_cursor = (int32_t)(c % flt.noise_n);
+}
+
+// phase 2 (operations.h:351-361): re-insert the copies, first vacant slot, in (object, index) order.
+// Sorted by target voxel (stable), one thread replays each voxel's segment.
+template <int S>
+__global__ __launch_bounds__(TPB) void k_move_replay(Dims d, State st, Scratch sc, const uint32_t *__restrict__ skey,
+                                                     const uint32_t *__restrict__ sval) {
+  if (sc.cnt->overflow) return;
+  const uint32_t total = *sc.mv_total;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const uint32_t v = skey[t];
+  if (v >= d.V) return;
+  if (t > 0 && skey[t - 1] == v) return;
+  uint32_t rx, ry, rz;
+  voxel_to_ring(d, v, rx, ry, rz);
+  uint32_t a = st.stamps_x[rx], b = st.stamps_y[ry], c = st.stamps_z[rz];
+  uint32_t smax = a > b ? a : b;
+  smax = smax > c ? smax : c;
+  const size_t base = (size_t)(v - d.v_begin) * S;
+  uint8_t stv[S];
+  uint16_t tsv[S];
+  __builtin_memcpy(stv, st.status + base, S);
+  __builtin_memcpy(tsv, st.ts + base, 2 * S);
+  uint32_t n_ok = 0;
+  for (uint32_t u = t; u < total && skey[u] == v; ++u) {
+    const uint32_t e = sval[u];
+    int slot = -1;
+#pragma unroll
+    for (int i = S - 1; i >= 1; --i)
+      if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) slot = i;
+    if (slot < 0) continue;  // voxel full: the copy is dropped (operations.h:357)
+    const uint8_t cs = sc.mv_status[e];
+    const uint16_t cts = sc.mv_ts[e];
+    st.pos4[base + slot] = sc.mv_pos[e];
+    st.w[base + slot] = sc.mv_w[e];
+    st.ts[base + slot] = cts;
+    st.track[base + slot] = sc.mv_track[e];
+    st.label[base + slot] = sc.mv_label[e];
+    st.status[base + slot] = cs;
+    st.owner[base + slot] = sc.mv_owner[e];  // new index joins the object's set
+#pragma unroll
+    for (int i = 1; i < S; ++i)
+      if (i == slot) {
+        stv[i] = cs;
+        tsv[i] = cts;
+      }
+    ++n_ok;
+  }
+  if (n_ok) atomicAdd(&sc.cnt->n_move_reinserted, n_ok);
+}
+
+// removeObjectByTrackID (object_layer.h:414-425): every index of the set -> INVALID, set erased.
+__global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const uint16_t *__restrict__ tracks, int n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n_slots; i += stride) {
+    uint16_t o = st.owner[i];
+    if (o == OWNER_NONE) continue;
+    for (int k = 0; k < n; ++k)
+      if (tracks[k] == o) {
+        st.status[i] = ST_INVALID;
+        st.owner[i] = OWNER_NONE;
+        break;
+      }
+  }
+}
+
+inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
+
+}  // namespace
+
+size_t move_blocks(const Dims &d) { return ((size_t)d.v_count * d.S + MV_CHUNK - 1) / MV_CHUNK; }
+
+void launch_moves(const Dims &d, const Frame &f, const Filter &flt, const MoveSet *ms_dev, int n_obj, const State &st,
+                  const Scratch &sc, hipStream_t s) {
+  if (n_obj <= 0) return;
+  const size_t n_slots = (size_t)d.v_count * d.S;
+  const size_t slot_base = (size_t)d.v_begin << d.p_n;
+  const uint32_t n_blocks = (uint32_t)move_blocks(d);
+  const size_t n_cnt = (size_t)n_obj * n_blocks + 1;
+  hipLaunchKernelGGL(k_move_table, dim3(1), dim3(MAX_MOVE_OBJECTS), 0, s, ms_dev, sc.track_to_obj);
+  hipMemsetAsync(sc.mv_cnt + (n_cnt - 1), 0, 4, s);
+  hipLaunchKernelGGL(k_move_count, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, sc.track_to_obj, sc.mv_cnt, n_blocks, n_obj);
+  exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch, s);
+  hipLaunchKernelGGL(k_move_scatter, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, slot_base, sc.track_to_obj, sc.mv_cnt,
+                     n_blocks, n_obj, sc.mv_src, sc.cap_move, sc.cnt);
+  hipLaunchKernelGGL(k_move_table_reset, dim3(1), dim3(MAX_MOVE_OBJECTS), 0, s, ms_dev, sc.track_to_obj);
+  hipLaunchKernelGGL(k_move_transform, dim3(1024), dim3(TPB), 0, s, d, f, flt, ms_dev, st, sc, sc.mv_cnt, n_blocks, n_obj);
+  hipLaunchKernelGGL(k_move_cursor, dim3(1), dim3(64), 0, s, flt, sc);
+  int nbits = d.x_n + d.y_n + d.z_n + 1;
+  int which = radix_sort_pairs(sc.bkey_a, sc.bval_a, sc.bkey_b, sc.bval_b, sc.cap_move, nbits, sc.sort_scratch, s, sc.mv_total);
+  const uint32_t *skey = which ? sc.bkey_b : sc.bkey_a;
+  const uint32_t *sval = which ? sc.bval_b : sc.bval_a;
+  dim3 grid(blocks_for(sc.cap_move));
+  switch (d.p_n) {
+    case 1: hipLaunchKernelGGL(k_move_replay<2>, grid, dim3(TPB), 0, s, d, st, sc, skey, sval); break;
+    case 2: hipLaunchKernelGGL(k_move_replay<4>, grid, dim3(TPB), 0, s, d, st, sc, skey, sval); break;
+    case 3: hipLaunchKernelGGL(k_move_replay<8>, grid, dim3(TPB), 0, s, d, st, sc, skey, sval); break;
+    default: hipLaunchKernelGGL(k_move_replay<16>, grid, dim3(TPB), 0, s, d, st, sc, skey, sval); break;
+  }
+}
+
+void launch_remove(const Dims &d, const State &st, const uint16_t *tracks_dev, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_remove, dim3(4096), dim3(TPB), 0, s, st, (size_t)d.v_count * d.S, tracks_dev, n);
+}
+
+}  // namespace sdm

@@ -1,0 +1,227 @@
+// primitives.hip — hand-written gfx950 building blocks: exclusive scan and stable LSD radix sort.
+//
+// Both are written for 64-wide wavefronts (ballot masks are 64 bit, wave reductions
+// use 64-lane shuffles) and are deterministic: no atomics decide an output position.
+// The sort is what turns the reference's strictly sequential "first vacant slot"
+// insertion order (mc_ring/operations.h:790-796, semantic_dsp_map.h:778-800) into
+// per-voxel segments that keep their original order (stability) and can be replayed
+// voxel-parallel.
+#include "sdm_internal.h"
+
+namespace sdm {
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t n = __shfl_up(v, off, 64);
+    if (lane >= off) v += n;
+  }
+  return v;
+}
+
+// exclusive scan across the 256 threads of a block of one value per thread; returns the block total in *total
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *total) {
+  __shared__ uint32_t wave_sums[SCAN_THREADS / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t inc = wave_inclusive_scan(v);
+  if (lane == 63) wave_sums[wid] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_THREADS / 64; ++i) {
+    uint32_t s = wave_sums[i];
+    if (i < wid) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// pass 1: per-tile totals
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const uint32_t *__restrict__ in, uint32_t *__restrict__ sums,
+                                                               size_t n) {
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    size_t k = base + i;
+    if (k < n) s += in[k];
+  }
+  uint32_t total;
+  block_exclusive_scan(s, &total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// pass 2: one block turns the tile totals into exclusive offsets (any count, running carry)
+__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_inplace(uint32_t *__restrict__ sums, size_t m) {
+  uint32_t carry = 0;
+  for (size_t start = 0; start < m; start += SCAN_TILE) {
+    size_t base = start + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+      size_t k = base + i;
+      v[i] = k < m ? sums[k] : 0u;
+      s += v[i];
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(s, &total) + carry;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+      size_t k = base + i;
+      if (k < m) sums[k] = ex;
+      ex += v[i];
+    }
+    carry += total;
+  }
+}
+
+// pass 3: scan inside each tile and add the tile offset
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                           const uint32_t *__restrict__ sums, size_t n) {
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    size_t k = base + i;
+    v[i] = k < n ? in[k] : 0u;
+    s += v[i];
+  }
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan(s, &total) + sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    size_t k = base + i;
+    if (k < n) out[k] = ex;
+    ex += v[i];
+  }
+}
+
+// ---------------------------------------------------------------- radix sort
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 2048 keys per block
+constexpr int RS_WAVES = RS_THREADS / 64;
+
+// histogram of one 8-bit digit per tile; layout hist[digit * n_tiles + tile] so that one
+// exclusive scan over the whole array yields the global scatter offsets.
+__global__ __launch_bounds__(RS_THREADS) void rs_histogram(const uint32_t *__restrict__ keys, uint32_t *__restrict__ hist,
+                                                           size_t n, int shift, uint32_t n_tiles,
+                                                           const uint32_t *__restrict__ n_dev) {
+  __shared__ uint32_t h[256];
+  if (n_dev) n = *n_dev < n ? (size_t)*n_dev : n;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    size_t k = base + (size_t)r * RS_THREADS + threadIdx.x;
+    if (k < n) atomicAdd(&h[(keys[k] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// stable scatter: elements of a tile are visited in index order (round-major, then thread);
+// the rank of an element among equal digits is (earlier rounds) + (earlier waves of this round)
+// + (lower lanes of this wave), the last from a ballot-built peer mask.
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint32_t *__restrict__ keys_in,
+                                                         const uint32_t *__restrict__ vals_in,
+                                                         uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                         const uint32_t *__restrict__ offsets, size_t n, int shift,
+                                                         uint32_t n_tiles, const uint32_t *__restrict__ n_dev) {
+  __shared__ uint32_t digit_base[256];
+  if (n_dev) n = *n_dev < n ? (size_t)*n_dev : n;
+  if ((size_t)blockIdx.x * RS_TILE >= n) return;
+  __shared__ uint32_t wave_cnt[RS_WAVES][256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  digit_base[threadIdx.x] = offsets[(size_t)threadIdx.x * n_tiles + blockIdx.x];
+  size_t base = (size_t)blockIdx.x * RS_TILE;
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < RS_ITEMS; ++r) {
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    size_t k = base + (size_t)r * RS_THREADS + threadIdx.x;
+    bool valid = k < n;
+    uint32_t key = valid ? keys_in[k] : 0u;
+    uint32_t val = valid ? vals_in[k] : 0u;
+    uint32_t digit = (key >> shift) & 255u;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      bool bit = (digit >> b) & 1u;
+      uint64_t m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
+    if (valid && rank_in_wave == 0) wave_cnt[wid][digit] = (uint32_t)__popcll(peers);
+    __syncthreads();
+    if (valid) {
+      uint32_t off = digit_base[digit] + rank_in_wave;
+#pragma unroll
+      for (int w = 0; w < RS_WAVES; ++w)
+        if (w < wid) off += wave_cnt[w][digit];
+      keys_out[off] = key;
+      vals_out[off] = val;
+    }
+    __syncthreads();
+    {
+      uint32_t add = 0;
+#pragma unroll
+      for (int w = 0; w < RS_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
+      digit_base[threadIdx.x] += add;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+size_t scan_scratch_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
+
+void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch, hipStream_t s) {
+  if (n == 0) return;
+  size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, scratch, n);
+  hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(SCAN_THREADS), 0, s, scratch, tiles);
+  hipLaunchKernelGGL(scan_tiles, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, out, scratch, n);
+}
+
+size_t sort_scratch_elems(size_t n) {
+  size_t tiles = (n + RS_TILE - 1) / RS_TILE;
+  size_t hist = 256 * tiles;
+  return hist + scan_scratch_elems(hist);
+}
+
+int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, size_t n, int nbits,
+                     uint32_t *scratch, hipStream_t s, const uint32_t *n_dev) {
+  if (n == 0) return 0;
+  size_t tiles = (n + RS_TILE - 1) / RS_TILE;
+  size_t hist_n = 256 * tiles;
+  uint32_t *hist = scratch;
+  uint32_t *scan_scratch = scratch + hist_n;
+  int which = 0;
+  for (int shift = 0; shift < nbits; shift += 8) {
+    uint32_t *kin = which ? keys_b : keys_a, *vin = which ? vals_b : vals_a;
+    uint32_t *kout = which ? keys_a : keys_b, *vout = which ? vals_a : vals_b;
+    hipLaunchKernelGGL(rs_histogram, dim3((unsigned)tiles), dim3(RS_THREADS), 0, s, kin, hist, n, shift, (uint32_t)tiles, n_dev);
+    exclusive_scan_u32(hist, hist, hist_n, scan_scratch, s);
+    hipLaunchKernelGGL(rs_scatter, dim3((unsigned)tiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, hist, n, shift,
+                       (uint32_t)tiles, n_dev);
+    which ^= 1;
+  }
+  return which;
+}
+
+}  // namespace sdm

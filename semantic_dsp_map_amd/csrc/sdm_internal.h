@@ -1,0 +1,200 @@
+// sdm_internal.h — shared declarations of libsdm_hip (not part of the C ABI).
+//
+// Data layout in HBM (SoA over particle slots, index = voxel << p_n | slot, the
+// reference's particle index, mc_ring/operations.h:370,788):
+//   pos4   float4  x, y, z, forget_count (as uint bits)      16 B
+//   w      float   weight                                      4 B
+//   ts     u16     time stamp (slot 0 = the voxel's time particle)
+//   track  u16, label u8, status u8
+//   owner  u16     track id of the owner set holding this index, 0xFFFF = none
+// plus per-voxel results (8 B) and the three per-axis slab stamp arrays.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sdm.h"
+
+#pragma clang fp contract(off)
+
+namespace sdm {
+
+constexpr uint32_t INVALID_INDEX = 0xffffffffu;  // INVALID_PARTICLE_INDEX, operations.h:35
+constexpr uint16_t OWNER_NONE = 0xFFFF;
+constexpr int PDF_NUM = 20000;                     // GAUSSIAN_PDF_NUM, basic_algorithms.h:378
+#define SDM_OCC_INIT_WEIGHT 0.05f                  // C_PARTICLE_OCC_INIT_WEIGHT, settings.h:147
+#define SDM_MIN_RIGHT_PDF 0.1f                     // c_min_rightly_updated_pdf, settings.h:149
+
+// Particle_Status, mc_ring/buffer.h:43-50
+enum : uint8_t { ST_INVALID = 0, ST_UPDATED = 1, ST_REGULAR_BORN = 2, ST_GUESSED_BORN = 3, ST_COPIED = 4, ST_TIMEPTC = 5 };
+
+// Everything a kernel needs to know about the grid and the camera (passed by value).
+struct Dims {
+  int x_n, y_n, z_n, p_n;
+  uint32_t NX, NY, NZ, S;
+  uint32_t V;            // voxels of the whole map
+  uint32_t v_begin;      // first storage voxel index owned by this shard
+  uint32_t v_count;      // voxels owned by this shard (Z-slab in ring-index space)
+  uint32_t rz_begin, rz_count;
+  float voxel_size, recip;
+  float pmin[3], pmax[3];
+  int W, H;
+  float fx, fy, cx, cy;
+  float dmin, dmax;
+  float tanx, tany;
+  float occl_coeff;      // g_depth_error_stddev_at_one_meter + 1.f, operations.h:1387
+  int window_half;
+  int max_movable;
+};
+
+// Ring-buffer state of the current frame (mc_ring/buffer.h:97-120) + frame scalars.
+struct Frame {
+  int eq[3];
+  float center[3];
+  uint32_t gts;          // global_time_stamp
+  float E[16];           // extrinsic, row-major
+  int bb0[3], bb1[3];    // conservative map-index bounding box of the frustum, [bb0, bb1) in voxels
+  int start_v[3];        // BFS start vertex
+  int start_ok;          // start vertex inside the vertex grid
+};
+
+// Filter parameters in device-friendly form.
+struct Filter {
+  float p_detect, noise_number, occ_threshold, id_transition;
+  float forget[8];       // getForgettingFactor(count) for count 0..7
+  int independent;
+  int consider_depth_noise;
+  int nb;                // births per valid pixel actually generated
+  int use_rng;           // births draw from the noise table
+  int noise_n;           // table length
+};
+
+// Device-side counters / flags of one frame (zeroed at frame start, except cursors).
+struct Counters {
+  uint32_t n_vis;
+  uint32_t n_birth_success;
+  uint32_t n_birth_attempts;
+  uint32_t n_resampled;
+  uint32_t n_moved;
+  uint32_t n_move_reinserted;
+  uint32_t n_frustum_voxels;
+  uint32_t n_occupied;
+  uint32_t n_free;
+  uint32_t flood_changed[8];
+  uint32_t flood_rounds;
+  uint32_t start_in_frustum;
+  uint32_t overflow;
+  uint32_t n_valid_px;
+  uint32_t pad[8];
+};
+struct Cursors {
+  int32_t birth_cursor;
+  int32_t move_cursor;
+};
+
+struct State {
+  float4 *pos4 = nullptr;
+  float *w = nullptr;
+  uint16_t *ts = nullptr;
+  uint16_t *track = nullptr;
+  uint8_t *label = nullptr;
+  uint8_t *status = nullptr;
+  uint16_t *owner = nullptr;
+  sdm_voxel_result *res = nullptr;
+  uint32_t *stamps_x = nullptr, *stamps_y = nullptr, *stamps_z = nullptr;
+  float *pdf = nullptr;
+  float *noise = nullptr;
+};
+
+// ---- device helpers ------------------------------------------------------------------
+// PINNED: 4x4 row-major times [x y z 1] evaluated ((m0*x + m1*y) + m2*z) + m3
+__host__ __device__ __forceinline__ float row4(const float *r, float x, float y, float z) {
+  return ((r[0] * x + r[1] * y) + r[2] * z) + r[3];
+}
+
+// operations.h:1037-1070 (single +-N correction)
+__host__ __device__ __forceinline__ uint32_t axis_correct(int idx, uint32_t n) {
+  if (idx < 0) return (uint32_t)(idx + (int)n);
+  if (idx >= (int)n) return (uint32_t)(idx - (int)n);
+  return (uint32_t)idx;
+}
+
+// operations.h:890-923 row-major storage index
+__host__ __device__ __forceinline__ uint32_t ring_to_voxel(const Dims &d, uint32_t rx, uint32_t ry, uint32_t rz) {
+  return (((rz << d.y_n) | ry) << d.x_n) | rx;
+}
+__host__ __device__ __forceinline__ void voxel_to_ring(const Dims &d, uint32_t v, uint32_t &rx, uint32_t &ry, uint32_t &rz) {
+  rx = v & (d.NX - 1);
+  ry = (v >> d.x_n) & (d.NY - 1);
+  rz = (v >> (d.x_n + d.y_n)) & (d.NZ - 1);
+}
+
+// PINNED float -> index cast (operations.h:867-869): (-1,0) truncates to 0 and is accepted.
+__host__ __device__ __forceinline__ bool float_to_idx(float f, uint32_t n, uint32_t &out) {
+  if (!(f > -1.0f && f < (float)n)) return false;
+  out = (uint32_t)(int32_t)f;
+  return out < n;
+}
+
+// operations.h:849-883: global position -> storage voxel index (INVALID_INDEX if outside the map)
+__host__ __device__ __forceinline__ uint32_t global_pos_to_voxel(const Dims &d, const Frame &f, float px, float py,
+                                                                 float pz, uint32_t &rx, uint32_t &ry, uint32_t &rz) {
+  float mx = px - f.center[0], my = py - f.center[1], mz = pz - f.center[2];
+  uint32_t ix = 0, iy = 0, iz = 0;
+  bool ok = float_to_idx((mx - d.pmin[0]) * d.recip, d.NX, ix);
+  ok = float_to_idx((my - d.pmin[1]) * d.recip, d.NY, iy) && ok;
+  ok = float_to_idx((mz - d.pmin[2]) * d.recip, d.NZ, iz) && ok;
+  if (!ok) return INVALID_INDEX;
+  rx = axis_correct((int)ix + f.eq[0], d.NX);
+  ry = axis_correct((int)iy + f.eq[1], d.NY);
+  rz = axis_correct((int)iz + f.eq[2], d.NZ);
+  return ring_to_voxel(d, rx, ry, rz);
+}
+
+// operations.h:1267-1290 (PINNED: K*p/z as (fx*x + cx*z)/z, (fy*y + cy*z)/z)
+__device__ __forceinline__ bool project_to_image(const Dims &d, const Frame &f, float px, float py, float pz, int &row,
+                                                 int &col, float &cam_z) {
+  float x = row4(f.E + 0, px, py, pz);
+  float y = row4(f.E + 4, px, py, pz);
+  float z = row4(f.E + 8, px, py, pz);
+  if (z < d.dmin || z > d.dmax) return false;
+  float u = (d.fx * x + d.cx * z) / z;
+  float v = (d.fy * y + d.cy * z) / z;
+  row = (int)v;
+  col = (int)u;
+  if (row < 0 || row >= d.H || col < 0 || col >= d.W) return false;
+  cam_z = z;
+  return true;
+}
+
+// operations.h:1240-1258
+__device__ __forceinline__ bool point_in_frustum(const Dims &d, const Frame &f, float px, float py, float pz) {
+  float x = row4(f.E + 0, px, py, pz);
+  float y = row4(f.E + 4, px, py, pz);
+  float z = row4(f.E + 8, px, py, pz);
+  if (z < d.dmin || z > d.dmax) return false;
+  if (fabsf(x) > z * d.tanx) return false;
+  if (fabsf(y) > z * d.tany) return false;
+  return true;
+}
+
+// basic_algorithms.h:417-422 (PINNED: NaN -> 1e-9f)
+__device__ __forceinline__ float query_pdf(const float *__restrict__ pdf, float x, float mu, float sigma) {
+  float c = (x - mu) / sigma;
+  if (!(c <= 9.9f && c >= -9.9f)) return 1e-9f;
+  return pdf[(int)(c * 1000 + 10000)];
+}
+
+// ---- primitives (primitives.hip) ------------------------------------------------------
+// exclusive prefix sum of n uint32; in == out allowed. scratch must hold scan_scratch_elems(n) uint32.
+size_t scan_scratch_elems(size_t n);
+void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch, hipStream_t s);
+// stable LSD radix sort of (key,val) pairs on key bits [0,nbits). Result ends in (keys_a, vals_a) if the returned
+// value is 0, in (keys_b, vals_b) if 1. scratch must hold sort_scratch_elems(n) uint32.  If n_dev is not null the
+// element count is min(*n_dev, n) read on the device (n is then the capacity the launch is sized for).
+size_t sort_scratch_elems(size_t n);
+int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, size_t n, int nbits,
+                     uint32_t *scratch, hipStream_t s, const uint32_t *n_dev = nullptr);
+
+void launch_clear(const Dims &d, const State &st, hipStream_t s);
+
+}  // namespace sdm

@@ -1,0 +1,79 @@
+// sdm_scratch.h — per-frame device work buffers and the stage launchers (internal).
+#pragma once
+#include "sdm_internal.h"
+
+namespace sdm {
+
+// Raster order of the birth loop (semantic_dsp_map.h:778-800): pass p = 3*row_start + col_start,
+// off[p] = first sequence number of the pass, cols[p] = visited columns per row in the pass.
+struct BirthOrder {
+  int off[10];
+  int cols[9];
+};
+
+struct Scratch {
+  // frustum vertex bitsets, one line of wpl 64-bit words per (y,z)
+  uint64_t *vmask = nullptr, *reach = nullptr;
+  int wpl = 0;
+  // inputs of the current frame (device)
+  const float *depth = nullptr;
+  const sdm_labeled_point *cloud = nullptr;
+  // per-pixel bins
+  uint32_t *bin_count = nullptr, *bin_start = nullptr;
+  uint32_t *vis_pix = nullptr, *vis_idx = nullptr, *vis_pib = nullptr;
+  uint32_t cap_vis = 0;
+  // visible particles in bin order
+  uint32_t *bin_idx = nullptr, *vpix = nullptr;
+  float *vx = nullptr, *vy = nullptr, *vz = nullptr, *vw = nullptr;
+  uint16_t *vtrack = nullptr;
+  uint8_t *vforget = nullptr;
+  float *ck_kappa = nullptr;
+  // births
+  uint32_t *b_valid = nullptr, *b_rank = nullptr;
+  uint32_t *bkey_a = nullptr, *bval_a = nullptr, *bkey_b = nullptr, *bval_b = nullptr;
+  float4 *bpos = nullptr;
+  // object moves
+  uint32_t *mv_src = nullptr;      // source particle index of every moved particle, (object, index) order
+  uint32_t *mv_cnt = nullptr;      // per-block per-object counts / offsets
+  uint32_t *mv_total = nullptr;    // per-object totals + exclusive offsets
+  float4 *mv_pos = nullptr;        // copies: position (+forget bits)
+  float *mv_w = nullptr;
+  uint16_t *mv_ts = nullptr, *mv_track = nullptr, *mv_owner = nullptr;
+  uint8_t *mv_label = nullptr, *mv_status = nullptr;
+  uint32_t cap_move = 0;
+  uint8_t *track_to_obj = nullptr; // 65536 entries: moving-object rank of a track id, 0xFF = not moving
+  // generic
+  uint32_t *scan_scratch = nullptr, *sort_scratch = nullptr;
+  Counters *cnt = nullptr;
+  Cursors *cur = nullptr;
+};
+
+void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s);
+void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int flood_rounds, hipStream_t s);
+void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, hipStream_t s);
+void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s);
+void launch_weight(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
+void launch_births(const Dims &d, const Frame &f, const Filter &flt, const BirthOrder &bo, const State &st,
+                   const Scratch &sc, hipStream_t s);
+void launch_count_live(const Dims &d, const State &st, unsigned long long *out, hipStream_t s);
+void launch_count_owner(const Dims &d, const State &st, uint16_t track, unsigned long long *out, hipStream_t s);
+void launch_pack_pos4(float4 *pos4, const float *px, const float *py, const float *pz, const uint8_t *forget, size_t n,
+                      hipStream_t s);
+void launch_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s);
+void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t *flags, uint32_t *offs,
+                        uint32_t *scan_scratch, sdm_point *out, uint32_t cap, int want_free, const float sub[3],
+                        hipStream_t s);
+
+// object moves / removals (moves.hip)
+constexpr int MAX_MOVE_OBJECTS = 64;
+struct MoveSet {
+  int n;
+  float T[MAX_MOVE_OBJECTS][12];  // rows 0..2 of the 4x4 (row-major)
+  uint16_t track[MAX_MOVE_OBJECTS];
+};
+size_t move_blocks(const Dims &d);
+void launch_moves(const Dims &d, const Frame &f, const Filter &flt, const MoveSet *ms_dev, int n_obj, const State &st,
+                  const Scratch &sc, hipStream_t s);
+void launch_remove(const Dims &d, const State &st, const uint16_t *tracks_dev, int n, hipStream_t s);
+
+}  // namespace sdm

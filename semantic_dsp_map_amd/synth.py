@@ -1,0 +1,254 @@
+"""Synthetic depth + segmentation frames for tests and bench.py.
+
+There is no dataset in the image (the reference's rosbags are external
+downloads), so frames are ray-cast from a small analytic street scene:
+ground plane, two side walls, static boxes and constant-velocity "car" boxes.
+The output has exactly the layout the hot path consumes: a float32 depth
+image (metres, camera-frame z) and a LabeledPoint[H][W] image
+(reference include/utils/data_base.h:78-92), plus the camera pose and the list
+of per-object 4x4 motions the object layer would hand to the particle update
+(reference include/semantic_dsp_map.h:673-693).
+
+World frame: x right, y down, z forward (camera frame at identity pose).
+Pure numpy; deterministic for a given seed.
+"""
+import math
+
+import numpy as np
+
+LABELED_POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("sigma", "<f4"),
+                          ("track_id", "<u2"), ("label_id", "u1"), ("is_valid", "u1")])
+OBJECT_MOVE = np.dtype([("track_id", "<i4"), ("T", "<f4", (16,))])
+
+# label ids / static instance ids of the reference's cfg/object_info.csv
+LABEL_ROAD, TRACK_ROAD = 8, 65528
+LABEL_BUILDING, TRACK_BUILDING = 7, 65529
+LABEL_POLE, TRACK_POLE = 12, 65524
+LABEL_TREE, TRACK_TREE = 5, 65531
+LABEL_VEGETATION, TRACK_VEGETATION = 6, 65530
+LABEL_CAR = 15
+MAX_MOVABLE_TRACK = 65522  # min static instance id (Misc = 65523) - 1, object_info_handler.h:49-69,84
+
+# ---------------------------------------------------------------- presets
+# grid / camera presets: BASELINE.json configs C1..C5
+_KITTI360 = dict(fx=552.554261, fy=552.554261, cx=682.049453, cy=238.769549, width=1408, height=376,
+                 depth_min=0.3, depth_max=30.0, voxel_size=0.15, window_half=5)        # settings.h:32-52
+_ZED2_BOOST = dict(fx=0.5 * 527.8191528320312, fy=0.5 * 527.8191528320312, cx=0.5 * 633.9357299804688,
+                   cy=0.5 * 366.3338623046875, width=640, height=360, depth_min=0.3, depth_max=15.0,
+                   voxel_size=0.15, window_half=3)                                      # settings.h:101-141
+_VKITTI2 = dict(fx=725.0087, fy=725.0087, cx=620.5, cy=187.0, width=1242, height=375,
+                depth_min=0.3, depth_max=30.0, voxel_size=0.2, window_half=5)          # settings.h:79-98
+
+CONFIGS = {
+    "C1": dict(x_n=6, y_n=6, z_n=6, p_n=3, max_movable_track=MAX_MOVABLE_TRACK, **_KITTI360),
+    "C2": dict(x_n=7, y_n=7, z_n=7, p_n=2, max_movable_track=MAX_MOVABLE_TRACK, **_ZED2_BOOST),
+    "C3": dict(x_n=8, y_n=8, z_n=8, p_n=3, max_movable_track=MAX_MOVABLE_TRACK, **_VKITTI2),
+    "C4": dict(x_n=8, y_n=8, z_n=8, p_n=3, max_movable_track=MAX_MOVABLE_TRACK, **_VKITTI2),
+    "C5": dict(x_n=9, y_n=9, z_n=9, p_n=3, max_movable_track=MAX_MOVABLE_TRACK, **_VKITTI2),
+    # small configurations for fast parity tests
+    "T0": dict(x_n=5, y_n=5, z_n=5, p_n=3, max_movable_track=MAX_MOVABLE_TRACK,
+               fx=80.0, fy=80.0, cx=64.0, cy=40.0, width=128, height=80, depth_min=0.3, depth_max=12.0,
+               voxel_size=0.4, window_half=3),
+    "T1": dict(x_n=6, y_n=5, z_n=6, p_n=2, max_movable_track=MAX_MOVABLE_TRACK,
+               fx=120.0, fy=120.0, cx=96.0, cy=54.0, width=192, height=108, depth_min=0.3, depth_max=15.0,
+               voxel_size=0.3, window_half=5),
+}
+
+# parameter presets: reference cfg/options_*.yaml
+PARAMS = {
+    "kitti360": dict(detection_probability=0.6, noise_number=0.6, nb_ptc_num_per_point=1, occupancy_threshold=0.1,
+                     max_obersevation_lost_time=10, forgetting_rate=0.5, max_forget_count=3,
+                     match_score_threshold=0.6, id_transition_probability=0.2, if_consider_depth_noise=1,
+                     if_use_independent_filter=1, depth_noise_first_order=0.01, depth_noise_zero_order=0.1),
+    "zed2": dict(detection_probability=0.8, noise_number=0.2, nb_ptc_num_per_point=1, occupancy_threshold=0.15,
+                 max_obersevation_lost_time=20, forgetting_rate=1.0, max_forget_count=5,
+                 match_score_threshold=0.6, id_transition_probability=0.5, if_consider_depth_noise=1,
+                 if_use_independent_filter=0, depth_noise_first_order=0.02, depth_noise_zero_order=0.3),
+    "vkitti2": dict(detection_probability=0.98, noise_number=0.001, nb_ptc_num_per_point=1, occupancy_threshold=0.5,
+                    max_obersevation_lost_time=5, forgetting_rate=1.0, max_forget_count=3,
+                    match_score_threshold=0.6, id_transition_probability=0.2, if_consider_depth_noise=1,
+                    if_use_independent_filter=0, depth_noise_first_order=0.01, depth_noise_zero_order=0.2),
+    # exercises the Gaussian-noise birth path (nb > 1) and the no-noise birth path
+    "noisy3": dict(detection_probability=0.95, noise_number=0.1, nb_ptc_num_per_point=3, occupancy_threshold=0.2,
+                   max_obersevation_lost_time=5, forgetting_rate=1.0, max_forget_count=5,
+                   match_score_threshold=0.3, id_transition_probability=0.1, if_consider_depth_noise=1,
+                   if_use_independent_filter=0, depth_noise_first_order=0.01, depth_noise_zero_order=0.1),
+    "nodepthnoise": dict(detection_probability=1.0, noise_number=0.001, nb_ptc_num_per_point=3,
+                         occupancy_threshold=0.1, max_obersevation_lost_time=10, forgetting_rate=1.0,
+                         max_forget_count=5, match_score_threshold=0.3, id_transition_probability=0.1,
+                         if_consider_depth_noise=0, if_use_independent_filter=0, depth_noise_first_order=0.0,
+                         depth_noise_zero_order=0.1),
+}
+CONFIG_PARAMS = {"C1": "kitti360", "C2": "zed2", "C3": "vkitti2", "C4": "vkitti2", "C5": "vkitti2",
+                 "T0": "vkitti2", "T1": "zed2"}
+
+
+def noise_table(seed=20250217, n=1000000, stddev=0.05):
+    """Host-side stand-in for the reference's gaussian_randoms table (basic_algorithms.h:394-402).
+    On the GPU box the table is generated by rocRAND inside the library and read back; this numpy
+    table is used for CPU-only tests."""
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(n) * stddev).astype(np.float32)
+
+
+def yaw_quat(theta):
+    """(w, x, y, z) of a rotation by theta about the y (down) axis."""
+    return np.array([math.cos(theta / 2), 0.0, math.sin(theta / 2), 0.0], np.float64)
+
+
+def quat_to_R(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], np.float64)
+
+
+class Scene:
+    """Street scene scaled to the map extent of a configuration."""
+
+    def __init__(self, cfg, n_static=24, n_dynamic=4, seed=7, speed=0.3, yaw_rate_deg=1.0,
+                 invalid_fraction=0.0, dyn_speed=(0.2, 1.0)):
+        self.cfg = dict(cfg)
+        self.rng = np.random.default_rng(seed)
+        self.seed = seed
+        half = 0.5 * (1 << min(cfg["x_n"], cfg["z_n"])) * cfg["voxel_size"]
+        self.half = half
+        self.ground_y = min(1.6, 0.35 * (1 << cfg["y_n"]) * cfg["voxel_size"])
+        self.wall_x = min(8.0, 0.8 * half)
+        self.wall_top = -min(6.0, 0.45 * (1 << cfg["y_n"]) * cfg["voxel_size"])
+        self.speed = speed
+        self.yaw_rate = math.radians(yaw_rate_deg)
+        self.invalid_fraction = invalid_fraction
+        zmax = max(2.0 * half, 6.0)
+        r = self.rng
+        boxes, labels, tracks = [], [], []
+        static_kinds = [(LABEL_POLE, TRACK_POLE, (0.3, 3.0, 0.3)), (LABEL_TREE, TRACK_TREE, (1.5, 4.0, 1.5)),
+                        (LABEL_VEGETATION, TRACK_VEGETATION, (2.0, 1.0, 2.0)),
+                        (LABEL_BUILDING, TRACK_BUILDING, (3.0, 5.0, 3.0))]
+        for k in range(n_static):
+            lab, trk, (sx, sy, sz) = static_kinds[k % len(static_kinds)]
+            s = min(1.0, half / 12.0)
+            sx, sy, sz = sx * s, min(sy * s, self.ground_y - self.wall_top), sz * s
+            cx = r.uniform(-0.85 * self.wall_x, 0.85 * self.wall_x)
+            cz = r.uniform(1.5, zmax)
+            if abs(cx) < 1.2 * s + sx / 2:  # keep the driving lane free
+                cx = math.copysign(1.2 * s + sx / 2 + 0.2, cx if cx != 0 else 1.0)
+            boxes.append([cx - sx / 2, self.ground_y - sy, cz - sz / 2, cx + sx / 2, self.ground_y, cz + sz / 2])
+            labels.append(lab)
+            tracks.append(trk)
+        self.static_boxes = np.array(boxes, np.float64).reshape(-1, 6)
+        self.static_labels = np.array(labels, np.uint8)
+        self.static_tracks = np.array(tracks, np.uint16)
+        dyn, vel = [], []
+        for k in range(n_dynamic):
+            s = min(1.0, half / 12.0)
+            sx, sy, sz = 1.8 * s, 1.5 * s, 4.0 * s
+            lane = (-1) ** k * (1.2 * s + sx / 2 + 0.3)
+            cz = r.uniform(3.0 * s + 1.0, max(0.9 * half, 4.0))
+            dyn.append([lane - sx / 2, self.ground_y - sy, cz - sz / 2, lane + sx / 2, self.ground_y, cz + sz / 2])
+            v = r.uniform(*dyn_speed) * s
+            vel.append([0.0, 0.0, v if k % 2 == 0 else -0.5 * v])
+        self.dyn_boxes0 = np.array(dyn, np.float64).reshape(-1, 6)
+        self.dyn_vel = np.array(vel, np.float64).reshape(-1, 3)
+        self.dyn_tracks = np.arange(1, n_dynamic + 1, dtype=np.uint16)
+
+    # ------------------------------------------------------------ trajectory
+    def pose(self, t):
+        theta = self.yaw_rate * t
+        pos = np.array([0.05 * t * self.speed, 0.0, self.speed * t], np.float64)
+        return pos, yaw_quat(theta)
+
+    def dyn_boxes(self, t):
+        b = self.dyn_boxes0.copy()
+        if len(b):
+            d = self.dyn_vel * t
+            b[:, 0:3] += d
+            b[:, 3:6] += d
+        return b
+
+    def moves(self, t):
+        """Motions from frame t-1 to t of the dynamic objects (pure translations)."""
+        out = np.zeros(len(self.dyn_tracks) if t > 0 else 0, OBJECT_MOVE)
+        for k in range(len(out)):
+            T = np.eye(4, dtype=np.float64)
+            T[0:3, 3] = self.dyn_vel[k]
+            out[k]["track_id"] = int(self.dyn_tracks[k])
+            out[k]["T"] = T.astype(np.float32).reshape(16)
+        return out
+
+    # -------------------------------------------------------------- render
+    def render(self, t, params):
+        """Returns depth (H,W) f32, cloud (H*W,) LABELED_POINT, cam_pos (3,) f32, cam_q (4,) f32."""
+        c = self.cfg
+        W, H = c["width"], c["height"]
+        pos, q = self.pose(t)
+        R = quat_to_R(q)
+        jj, ii = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+        dc = np.stack([(jj - c["cx"]) / c["fx"], (ii - c["cy"]) / c["fy"], np.ones_like(jj)], -1).reshape(-1, 3)
+        dw = dc @ R.T
+        n = dw.shape[0]
+        best_t = np.full(n, 1000.0)
+        best_label = np.zeros(n, np.uint8)
+        best_track = np.full(n, 65535, np.uint16)
+
+        def take(tt, ok, label, track):
+            nonlocal best_t
+            m = ok & (tt > 1e-6) & (tt < best_t)
+            best_t = np.where(m, tt, best_t)
+            best_label[m] = label
+            best_track[m] = track
+
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tg = (self.ground_y - pos[1]) / dw[:, 1]
+            take(tg, dw[:, 1] > 1e-9, LABEL_ROAD, TRACK_ROAD)
+            for sx in (-self.wall_x, self.wall_x):
+                tw = (sx - pos[0]) / dw[:, 0]
+                hy = pos[1] + tw * dw[:, 1]
+                take(tw, (np.abs(dw[:, 0]) > 1e-9) & (hy >= self.wall_top) & (hy <= self.ground_y),
+                     LABEL_BUILDING, TRACK_BUILDING)
+            boxes = [(self.static_boxes, self.static_labels, self.static_tracks),
+                     (self.dyn_boxes(t), np.full(len(self.dyn_tracks), LABEL_CAR, np.uint8), self.dyn_tracks)]
+            inv = 1.0 / dw
+            for bx, labs, trks in boxes:
+                for k in range(len(bx)):
+                    t0 = (bx[k, 0:3] - pos) * inv
+                    t1 = (bx[k, 3:6] - pos) * inv
+                    tn = np.nanmax(np.minimum(t0, t1), axis=1)
+                    tf = np.nanmin(np.maximum(t0, t1), axis=1)
+                    take(tn, (tn <= tf) & (tf > 0), labs[k], trks[k])
+
+        depth = best_t.astype(np.float32)  # camera-frame z == ray parameter (dc.z == 1)
+        if self.invalid_fraction > 0:
+            r = np.random.default_rng(self.seed * 1000003 + t)
+            bad = r.random(n) < self.invalid_fraction
+            depth = np.where(bad, np.float32(np.nan), depth)
+        valid = (~np.isnan(depth)) & (depth >= np.float32(c["depth_min"])) & (depth <= np.float32(c["depth_max"]))
+        p = pos[None, :] + best_t[:, None] * dw
+        cloud = np.zeros(n, LABELED_POINT)
+        cloud["x"] = np.where(valid, p[:, 0], 0.0).astype(np.float32)
+        cloud["y"] = np.where(valid, p[:, 1], 0.0).astype(np.float32)
+        cloud["z"] = np.where(valid, p[:, 2], 0.0).astype(np.float32)
+        zero = np.float32(params["depth_noise_zero_order"])
+        first = np.float32(params["depth_noise_first_order"])
+        if params["if_consider_depth_noise"]:
+            sig = zero + first * np.where(valid, depth, np.float32(0))  # pointcloud_tools.h:284-286
+        else:
+            sig = np.full(n, np.float32(0.1))                          # pointcloud_tools.h:288
+        # PINNED: sigma of an invalid pixel is uninitialised in the reference; zero-order term here
+        cloud["sigma"] = np.where(valid, sig, zero if params["if_consider_depth_noise"] else np.float32(0.1))
+        cloud["track_id"] = np.where(valid, best_track, 0)
+        cloud["label_id"] = np.where(valid, best_label, 0)
+        cloud["is_valid"] = valid.astype(np.uint8)
+        return depth.reshape(H, W), cloud, pos.astype(np.float32), q.astype(np.float32)
+
+
+def make_frames(cfg_name, n_frames, params_name=None, seed=7, **scene_kw):
+    """Convenience: list of (depth, cloud, cam_pos, cam_q, moves) for a named configuration."""
+    cfg = CONFIGS[cfg_name]
+    params = PARAMS[params_name or CONFIG_PARAMS[cfg_name]]
+    sc = Scene(cfg, seed=seed, **scene_kw)
+    frames = []
+    for t in range(n_frames):
+        depth, cloud, pos, q = sc.render(t, params)
+        frames.append((depth, cloud, pos, q, sc.moves(t)))
+    return cfg, params, frames
