@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py — whole-frame throughput of the particle-grid update hot path on MI355X.
+
+Metric (BASELINE.json): Mvoxels updated / s = voxels of the map / frame time of the hot path
+(one "step" = one subObjectLevelUpdate-equivalent frame: ego shift, object moves, visibility/binning,
+SMC-PHD weight update, births + resampling, occupancy/semantic sweep), inputs resident in HBM.
+
+  N = 1 : BASELINE config C3 — 256^3 voxels, 8 slots/voxel, ~2M live particles, 1242x375 VKITTI2 camera,
+          dynamic objects (4x4 transforms), cfg/options_virtual_kitti2.yaml parameters.
+  N > 1 : weak scaling, 2^24 voxels and ~2M particles per GPU (…C5 = 512^3 / 16M particles at N = 8),
+          Z-slab shards, one process per GPU, all-gather of the partial ck images over RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task description), with two extra objects:
+  roofline     — occupancy/semantic sweep kernel: algorithmic bytes (80 B/voxel at 8 slots)
+                 / HIP-event time on the stream it runs on, against the 8 TB/s HBM peak.
+  cpu_baseline — the CPU oracle (literal single-thread restatement of the reference, kind "port") timed on
+                 the same workload on this box's host cores (bounded sample), rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_BPS = 8.0e12  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--particles", type=int, default=2000000, help="live particles per GPU after prefill")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from semantic_dsp_map_amd import binding, sharded, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libsdm_hip has no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    base = synth.CONFIGS[args.config]
+    cfg = sharded.weak_scaled_config(base, world)
+    params = synth.PARAMS[synth.CONFIG_PARAMS[args.config]]
+    V = 1 << (cfg["x_n"] + cfg["y_n"] + cfg["z_n"])
+    S = 1 << cfg["p_n"]
+    n_frames = args.warmup + args.steps
+
+    # ---- synthetic frames (same on every rank), uploaded to HBM before the timed region
+    scene = synth.Scene(cfg, n_static=48, n_dynamic=6, seed=7)
+    t0 = time.time()
+    frames = []
+    for t in range(n_frames):
+        depth, cloud, pos, q = scene.render(t, params)
+        d_depth = torch.from_numpy(depth.reshape(-1)).to(dev)
+        d_cloud = torch.from_numpy(cloud.view(np.uint8).reshape(-1)).to(dev)
+        frames.append((depth, cloud, pos, q, scene.moves(t), d_depth, d_cloud))
+    t_render = time.time() - t0
+
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        eng = sharded.HipEngine(cfg, params, rank, world, local_rank)
+        m = eng.map
+        # noise table: rocRAND on the device, read back so that the CPU baseline uses the same floats
+        m.generate_noise_table(seed=20250217)
+        noise = m.download_noise_table()
+        st, ring, n_pre = synth.prefill_state(cfg, scene, args.particles, shard_rank=rank, shard_count=world)
+        m.load_state(st)
+        m.set_ring_state(ring)
+        drv = sharded.ShardedDriver(eng, rank, world, dist)
+
+        def run(lo, hi):
+            for t in range(lo, hi):
+                depth, cloud, pos, q, moves, d_depth, d_cloud = frames[t]
+                drv.update(d_depth.data_ptr(), d_cloud.data_ptr(), pos, q, moves)
+
+        run(0, args.warmup)
+        m.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.warmup, n_frames)
+        m.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+
+        stats = m.stats(count_live=True)
+        live = stats["live_particles"]
+        if dist is not None:
+            lt = torch.tensor([live, stats["n_visible"]], dtype=torch.int64, device=dev)
+            dist.all_reduce(lt)
+            live, n_vis = int(lt[0].item()), int(lt[1].item())
+        else:
+            n_vis = stats["n_visible"]
+
+        # per-stage GPU times of one more frame (not part of the timed region)
+        stage_ms = None
+        if world == 1:
+            m.set_profiling(True)
+            depth, cloud, pos, q = scene.render(n_frames, params)
+            m.update(depth, cloud, pos, q, scene.moves(n_frames), sync=True)
+            stage_ms = m.stats()["stage_ms"]
+            m.set_profiling(False)
+
+        # ---- roofline of the dominant streaming kernel (occupancy / semantic sweep), HIP events on its stream
+        sweep_ms = m.time_occupancy_sweep(iters=50)
+    ms_per_step = dt * 1e3 / args.steps
+    value = V / (dt / args.steps) / 1e6  # Mvoxels / s, whole map (all shards)
+    bytes_per_voxel = (S - 1) * 10 + 2 + 8  # read (S-1)*(w4+ts2+track2+label1+status1)+2, write 8
+    alg_bytes = (V // world) * bytes_per_voxel
+    achieved = alg_bytes / (sweep_ms * 1e-3)
+    roofline = {"kernel": "k_occupancy<%d>" % S, "bound": "hbm", "achieved": round(achieved / 1e9, 1),
+                "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BPS, 4),
+                "traffic": None, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(sweep_ms, 5)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_frames > 0:
+        cpu = cpu_baseline(cfg, params, noise, frames, st, ring, args.cpu_frames, V)
+
+    if rank == 0:
+        out = {
+            "metric": "Mvoxels updated/sec (256^3 grid, 2M particles, VKITTI2 camera; whole hot-path frame)",
+            "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %dx%dx%d voxels, %d slots/voxel, %dx%d image, window %d, %s params, "
+                                   "6 dynamic objects, %d live particles, %d visible/frame"
+                                   % (args.config if world == 1 else "%s weak-scaled x%d" % (args.config, world),
+                                      1 << cfg["x_n"], 1 << cfg["y_n"], 1 << cfg["z_n"], S, cfg["width"], cfg["height"],
+                                      cfg["window_half"], synth.CONFIG_PARAMS[args.config], live, n_vis),
+                       "voxels": V, "live_particles": live, "visible_particles": n_vis,
+                       "parallelism": "zslab%d" % world, "inputs": "depth + LabeledPoint image resident in HBM",
+                       "render_s": round(t_render, 1)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if stage_ms is not None:
+            out["stage_ms"] = {k: round(stage_ms[i], 4) for i, k in
+                               enumerate(["", "ego", "move", "remove", "visibility", "weight", "birth", "occupancy"]) if k}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, params, noise, frames, st, ring, n_frames, V):
+    """The oracle in its literal order (bin_order 0 = the reference's BFS push order), one thread, same
+    prefilled map and same frames: 2 warm-up + n_frames timed frames (about 10-20 s of CPU work)."""
+    from oracle import oracle as orc
+    o = orc.OracleMap(dict(cfg, bin_order=0), params, noise)
+    o.load_state(st)
+    o.set_ring_state(ring)
+    warm = 2
+    times = []
+    stages = np.zeros(8)
+    for t in range(min(warm + n_frames, len(frames))):
+        depth, cloud, pos, q, moves = frames[t][:5]
+        t0 = time.perf_counter()
+        o.update(depth, cloud, pos, q, moves)
+        dt = time.perf_counter() - t0
+        if t >= warm:
+            times.append(dt)
+            stages += np.array(o.stats()["stage_ms"])
+    med = float(np.median(times))
+    return {"value": round(V / med / 1e6, 2), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same workload after %d warm-up frames, median %.1f ms/frame (min %.1f); "
+                      "g++ -O3 -march=native -ffp-contract=off, 1 thread of %d host cores"
+                      % (len(times), warm, med * 1e3, min(times) * 1e3, os.cpu_count()),
+            "ms_per_frame": round(med * 1e3, 2),
+            "stage_ms": {k: round(stages[i] / len(times), 2) for i, k in
+                         enumerate(["", "ego", "move", "remove", "visibility", "weight", "birth", "occupancy"]) if k}}
+
+
+if __name__ == "__main__":
+    main()

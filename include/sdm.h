@@ -197,8 +197,14 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
                             uint32_t flags, int32_t stop_after, const float **ck_part_dev);
 sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_parts, uint32_t flags,
                              int32_t stop_after);
-/* the HIP stream (hipStream_t) all work of this map is enqueued on */
+/* the HIP stream (hipStream_t) all work of this map is enqueued on; sdm_set_stream moves the map onto a
+ * caller-owned stream (e.g. the one RCCL collectives are issued on, so that no host sync is needed between
+ * sdm_update_begin, the all-gather and sdm_update_finish); NULL restores the map's own stream. */
 sdm_status sdm_stream(sdm_map *m, void **stream_out);
+sdm_status sdm_set_stream(sdm_map *m, void *hip_stream);
+/* caller-provided device buffer (H*W floats) that sdm_update_begin writes this shard's partial ck image to
+ * (e.g. a slice of the all-gather send buffer); NULL restores the internal buffer. */
+sdm_status sdm_set_ck_buffer(sdm_map *m, float *dev_buffer);
 
 /* Wait for all enqueued work of this map; surfaces deferred device-side errors. */
 sdm_status sdm_synchronize(sdm_map *m);

@@ -96,6 +96,8 @@ def load_library():
         "sdm_update_begin": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32, C.POINTER(vp)],
         "sdm_update_finish": [vp, vp, i32, u32, i32],
         "sdm_stream": [vp, C.POINTER(vp)],
+        "sdm_set_stream": [vp, vp],
+        "sdm_set_ck_buffer": [vp, vp],
         "sdm_synchronize": [vp],
         "sdm_get_voxels": [vp, vp],
         "sdm_get_occupied": [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), i32],
@@ -245,6 +247,12 @@ class SdmMap:
         s = C.c_void_p()
         _check(self.L, self.L.sdm_stream(self.h, C.byref(s)), "sdm_stream")
         return s.value or 0
+
+    def set_stream(self, hip_stream):
+        _check(self.L, self.L.sdm_set_stream(self.h, _ptr(int(hip_stream)) if hip_stream else None), "sdm_set_stream")
+
+    def set_ck_buffer(self, dev_ptr):
+        _check(self.L, self.L.sdm_set_ck_buffer(self.h, _ptr(int(dev_ptr)) if dev_ptr else None), "sdm_set_ck_buffer")
 
     def synchronize(self):
         _check(self.L, self.L.sdm_synchronize(self.h), "sdm_synchronize")

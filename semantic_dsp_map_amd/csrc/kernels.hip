@@ -697,6 +697,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
     const uint16_t track = (uint16_t)(tl & 0xffffu);
     const uint8_t label = (uint8_t)((tl >> 16) & 0xffu);
     bool inserted = false;
+    bool changed = false;  // did this birth change the voxel (insert or triggered resample)?
 #pragma unroll
     for (int attempt = 0; attempt < 2; ++attempt) {
       int slot = -1;
@@ -719,6 +720,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
             tsv[i] = (uint16_t)f.gts;
           }
         inserted = true;
+        changed = true;
         ++n_success;
         break;
       }
@@ -727,6 +729,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
       if (attempt == 1 || resampled || checked) break;
       if (resample_voxel<S>(d, st, base, stv)) {
         resampled = true;
+        changed = true;
         atomicAdd(&sc.cnt->n_resampled, 1u);
       } else {
         checked = true;
@@ -737,12 +740,15 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
       // semantic_dsp_map.h:1165-1170: after every add, resample until it has triggered once
       if (resample_voxel<S>(d, st, base, stv)) {
         resampled = true;
+        changed = true;
         atomicAdd(&sc.cnt->n_resampled, 1u);
       } else {
         checked = true;
       }
     }
-    if (!inserted && (resampled || checked)) break;  // fixed point: later births of this voxel change nothing
+    // fixed point: the voxel is full, its one resample per frame is used up (or cannot trigger, since births
+    // never add UPDATED particles), and this birth changed nothing -> no later birth of this voxel can either
+    if (!changed && (resampled || checked)) break;
   }
   if (n_success) atomicAdd(&sc.cnt->n_birth_success, n_success);
 }

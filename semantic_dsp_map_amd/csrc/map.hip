@@ -56,6 +56,8 @@ struct sdm_map {
   State st{};
   Scratch sc{};
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  float *ck_user = nullptr;
   int device = 0;
 
   // host ring-buffer state (mc_ring/buffer.h:97-120)
@@ -415,7 +417,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->prm.depth_noise_first_order = 0.f;
   m->prm.depth_noise_zero_order = 0.1f;
 
-  HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+  m->stream = m->own_stream;
   const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t hw = (size_t)d.W * d.H;
   sdm_status rc;
@@ -520,7 +523,7 @@ sdm_status sdm_destroy(sdm_map *m) {
     if (p) (void)hipFree(p);
   if (m->ev_valid)
     for (int i = 0; i < 9; ++i) (void)hipEventDestroy(m->ev[i]);
-  if (m->stream) (void)hipStreamDestroy(m->stream);
+  if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   delete m;
   return SDM_OK;
 }
@@ -668,8 +671,9 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
   if (done(4)) return SDM_OK;
 
   // U2 pass 1: this shard's ck partial sums
-  launch_ck(d, m->flt, m->st, m->sc, m->d_ck_part, s);
-  if (ck_part_dev) *ck_part_dev = m->d_ck_part;
+  float *ck_dst = m->ck_user ? m->ck_user : m->d_ck_part;
+  launch_ck(d, m->flt, m->st, m->sc, ck_dst, s);
+  if (ck_part_dev) *ck_part_dev = ck_dst;
   return SDM_OK;
 }
 
@@ -688,7 +692,8 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
       m->stage_ran[stage] = true;
     }
   };
-  launch_ck_finish(d, m->flt, m->sc, ck_parts_dev ? ck_parts_dev : m->d_ck_part, ck_parts_dev ? n_parts : 1, s);
+  const float *own = m->ck_user ? m->ck_user : m->d_ck_part;
+  launch_ck_finish(d, m->flt, m->sc, ck_parts_dev ? ck_parts_dev : own, ck_parts_dev ? n_parts : 1, s);
   launch_weight(d, m->f, m->flt, m->st, m->sc, s);
   mark(5);
   if (done(5)) return SDM_OK;
@@ -714,6 +719,20 @@ sdm_status sdm_synchronize(sdm_map *m) {
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return check_counters(m, nullptr);
+}
+
+sdm_status sdm_set_stream(sdm_map *m, void *hip_stream) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  m->stream = hip_stream ? (hipStream_t)hip_stream : m->own_stream;
+  return SDM_OK;
+}
+
+sdm_status sdm_set_ck_buffer(sdm_map *m, float *dev_buffer) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  m->ck_user = dev_buffer;
+  return SDM_OK;
 }
 
 sdm_status sdm_stream(sdm_map *m, void **stream_out) {

@@ -252,3 +252,61 @@ def make_frames(cfg_name, n_frames, params_name=None, seed=7, **scene_kw):
         depth, cloud, pos, q = sc.render(t, params)
         frames.append((depth, cloud, pos, q, sc.moves(t)))
     return cfg, params, frames
+
+
+STATE_FIELDS = [("px", np.float32), ("py", np.float32), ("pz", np.float32), ("w", np.float32),
+                ("ts", np.uint16), ("track", np.uint16), ("label", np.uint8), ("status", np.uint8),
+                ("forget", np.uint8), ("owner", np.uint16)]
+
+
+def prefill_state(cfg, scene, n_particles, seed=11, shard_rank=0, shard_count=1):
+    """A map state (SoA dump format of sdm_load_state) holding ~n_particles live particles.
+
+    The street scene only ever shows a few 10^4 surface voxels to the camera, far fewer than the
+    "2M particles" BASELINE.json quotes its metric on, so the benchmark map is topped up with particles
+    in the space the camera cannot see into: below the ground plane and behind the side walls.  They
+    are ordinary UPDATED particles (time stamp 1, the map then starts at global_time_stamp 1): the
+    visibility stage has to load, project and occlusion-test those inside the frustum box every frame,
+    the occupancy sweep fuses them, and the ring shift expires them as the ego moves — exactly the work a
+    long-running map carries.  Ring state must be the initial one (no shift yet).
+    With shard_count > 1 only the Z-slab of shard_rank is generated (arrays of V/shard_count * S slots)."""
+    rng = np.random.default_rng(seed + 7919 * shard_rank)
+    x_n, y_n, z_n, p_n = cfg["x_n"], cfg["y_n"], cfg["z_n"], cfg["p_n"]
+    NX, NY, NZ, S = 1 << x_n, 1 << y_n, 1 << z_n, 1 << p_n
+    size = np.float32(cfg["voxel_size"])
+    NZl = NZ // shard_count
+    z0 = NZl * shard_rank
+    Vl = NX * NY * NZl
+    pmin = [-(N >> 1) * size for N in (NX, NY, NZ)]
+    gy = int(np.ceil((scene.ground_y + 0.5 - float(pmin[1])) / float(size)))
+    wx_lo = int(np.floor((-scene.wall_x - 0.5 - float(pmin[0])) / float(size)))
+    wx_hi = int(np.ceil((scene.wall_x + 0.5 - float(pmin[0])) / float(size)))
+    mx = np.arange(NX)
+    my = np.arange(NY)
+    hidden = np.zeros((NZl, NY, NX), bool)
+    hidden[:, my >= gy, :] = True
+    hidden[:, :, (mx < wx_lo) | (mx > wx_hi)] = True
+    cand = np.flatnonzero(hidden.ravel())
+    del hidden
+    n_vox = min(len(cand), max(n_particles // (S - 1), 1))
+    vox = np.sort(rng.choice(cand, n_vox, replace=False)).astype(np.int64)   # local voxel index
+    del cand
+    st = {k: np.zeros(Vl * S, dt) for k, dt in STATE_FIELDS}
+    st["owner"][:] = 0xFFFF
+    st["status"].reshape(Vl, S)[:, 0] = 5                     # TIMEPTC
+    vx, vy, vz = vox & (NX - 1), (vox >> x_n) & (NY - 1), (vox >> (x_n + y_n)) + z0
+    under = vy >= gy
+    for s in range(1, S):
+        idx = vox * S + s
+        st["px"][idx] = (vx.astype(np.float32) + rng.random(n_vox, np.float32)) * size + pmin[0]
+        st["py"][idx] = (vy.astype(np.float32) + rng.random(n_vox, np.float32)) * size + pmin[1]
+        st["pz"][idx] = (vz.astype(np.float32) + rng.random(n_vox, np.float32)) * size + pmin[2]
+        st["w"][idx] = (0.08 + 0.5 * rng.random(n_vox, np.float32)).astype(np.float32)
+        st["ts"][idx] = 1
+        st["track"][idx] = np.where(under, TRACK_ROAD, TRACK_BUILDING)
+        st["label"][idx] = np.where(under, LABEL_ROAD, LABEL_BUILDING)
+        st["status"][idx] = 1                                 # UPDATED
+    st["ts"][vox * S] = 1                                     # the voxel has been observed
+    ring = {"global_time_stamp": 1, "moved_steps": [0, 0, 0], "eq_steps": [0, 0, 0],
+            "map_center": [0.0, 0.0, 0.0], "last_pos": [0.0, 0.0, 0.0], "birth_cursor": 0, "move_cursor": 0}
+    return st, ring, n_vox * (S - 1)
