@@ -185,7 +185,8 @@ class Scene:
         R = quat_to_R(q)
         jj, ii = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
         dc = np.stack([(jj - c["cx"]) / c["fx"], (ii - c["cy"]) / c["fy"], np.ones_like(jj)], -1).reshape(-1, 3)
-        dw = dc @ R.T
+        # explicit products (no BLAS) so that frames are bit-reproducible on every host
+        dw = np.stack([dc[:, 0] * R[a, 0] + dc[:, 1] * R[a, 1] + dc[:, 2] * R[a, 2] for a in range(3)], -1)
         n = dw.shape[0]
         best_t = np.full(n, 1000.0)
         best_label = np.zeros(n, np.uint8)

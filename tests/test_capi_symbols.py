@@ -1,0 +1,68 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads without a GPU and exports every
+function include/sdm.h declares; struct layouts seen by ctypes match the header."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from semantic_dsp_map_amd import binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "sdm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    if not os.path.exists(binding.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = C.CDLL(binding.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, "declared in include/sdm.h but not exported: %s" % missing
+
+
+def test_binding_covers_the_header():
+    L = binding.load_library()
+    for n in declared_functions():
+        assert getattr(L, n) is not None
+
+
+def test_struct_layouts():
+    assert C.sizeof(binding.Config) == 80
+    assert C.sizeof(binding.Params) == 52
+    assert C.sizeof(binding.RingState) == 60
+    assert binding.LABELED_POINT.itemsize == 20 and binding.VOXEL_RESULT.itemsize == 8
+    assert binding.OBJECT_MOVE.itemsize == 68 and binding.POINT.itemsize == 16
+
+
+def test_no_cpu_path():
+    """Without a GPU the library must refuse to create a map instead of falling back."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    from tests import kat_cases as kc
+    with pytest.raises(binding.SdmError) as e:
+        binding.SdmMap(kc.K0, kc.PARAMS)
+    assert "SDM_ERR_NO_DEVICE" in str(e.value) or "SDM_ERR_HIP" in str(e.value)
+
+
+def test_product_package_does_not_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing in the product package may import, include, link or run it."""
+    pkg = os.path.join(ROOT, "semantic_dsp_map_amd")
+    pat = re.compile(r"(^\s*(from|import)\s+oracle\b)|(#include\s*[\"<][^\">]*oracle)|(oracle[/\\])|(libsdm_oracle)|(cpu_ref)", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), "%s references the oracle" % f
