@@ -224,6 +224,8 @@ sdm_status sdm_object_particle_count(sdm_map *m, int32_t track_id, int64_t *coun
 /* ---- introspection / checkpoint (tests, fixtures; SURVEY.md §5 checkpoint row) */
 sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live);
 sdm_status sdm_set_profiling(sdm_map *m, int32_t on);
+/* test hook: always run the generic 3-D frustum flood instead of the line-graph flood (both are exact) */
+sdm_status sdm_debug_force_generic_flood(sdm_map *m, int32_t on);
 sdm_status sdm_get_ring_state(sdm_map *m, sdm_ring_state *out);
 sdm_status sdm_set_ring_state(sdm_map *m, const sdm_ring_state *in);
 sdm_status sdm_get_stamps(sdm_map *m, uint32_t *sx, uint32_t *sy, uint32_t *sz);

@@ -106,6 +106,7 @@ def load_library():
         "sdm_object_particle_count": [vp, i32, C.POINTER(i64)],
         "sdm_get_stats": [vp, C.POINTER(Stats), i32],
         "sdm_set_profiling": [vp, i32],
+        "sdm_debug_force_generic_flood": [vp, i32],
         "sdm_get_ring_state": [vp, C.POINTER(RingState)],
         "sdm_set_ring_state": [vp, C.POINTER(RingState)],
         "sdm_get_stamps": [vp, vp, vp, vp],
@@ -284,6 +285,9 @@ class SdmMap:
 
     def set_profiling(self, on=True):
         _check(self.L, self.L.sdm_set_profiling(self.h, 1 if on else 0), "sdm_set_profiling")
+
+    def force_generic_flood(self, on=True):
+        _check(self.L, self.L.sdm_debug_force_generic_flood(self.h, 1 if on else 0), "sdm_debug_force_generic_flood")
 
     def ring_state(self):
         r = RingState()

@@ -149,20 +149,33 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
 }
 
 // ------------------------------------------------------------------------------------ A6
-// Frustum vertex mask (isPointInFrustum of every grid vertex in the conservative bounding box,
-// mc_ring/operations.h:1338-1340).  One wave per 64 vertices along x; ballot packs the bits.
-__global__ __launch_bounds__(TPB) void k_vertex_mask(Dims d, Frame f, uint64_t *__restrict__ M, int wpl, uint32_t n_words) {
-  uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (gw >= n_words) return;
-  const int lane = threadIdx.x & 63;
+// The reference reaches the voxels it updates by a BFS over 6-connected in-frustum grid VERTICES starting at the
+// vertex under the point 1 m in front of the camera (mc_ring/operations.h:1312-1456).  The set it reaches is the
+// connected component of that vertex among the in-frustum vertices.  Here:
+//   1. k_vertex_mask    in-frustum bit of every vertex of the conservative frustum box, 64 per wave (ballot);
+//   2. k_line_info      per x-line: non-empty?, its bits one contiguous run ("simple")?, does it share an x with the
+//                       next line in y / in z? -> three small bitmaps over (y,z);
+//   3. k_flood2d        when every line is simple, a line is reached as a whole or not at all, so the component is a
+//                       flood fill over LINES in the (y,z) plane: one workgroup, reach bitmap in LDS, word-parallel
+//                       fills along y, carry sweeps along z, until nothing changes;
+//   4. k_reach_expand   R = reached line ? M : 0;
+//   5. k_flood_generic  only if some line was not simple (float rounding exactly on a frustum plane): the plain 3-D
+//                       bit flood, one workgroup, exact for any mask.
+// Both paths are compared with the oracle's literal BFS in the parity tests.
+
+// Frustum vertex mask (isPointInFrustum, operations.h:1240-1258, 1338-1340): one wave per 64 vertices along x.
+__global__ __launch_bounds__(TPB) void k_vertex_mask(Dims d, Frame f, uint64_t *__restrict__ M, int wpl) {
   const int VY = d.NY + 1;
+  const int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
+  uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (gw >= (uint32_t)ny * nz * wpl) return;
+  const int lane = threadIdx.x & 63;
   int xw = gw % wpl;
-  int line = gw / wpl;
-  int y = line % VY, z = line / VY;
+  int l = gw / wpl;
+  int y = f.bb0[1] + l % ny, z = f.bb0[2] + l / ny;
   int x = xw * 64 + lane;
   bool in = false;
-  if (x >= f.bb0[0] && x <= f.bb1[0] && y >= f.bb0[1] && y <= f.bb1[1] && z >= f.bb0[2] && z <= f.bb1[2] &&
-      x <= (int)d.NX) {
+  if (x >= f.bb0[0] && x <= f.bb1[0]) {
     // vertex position: idx * size + (map_center + map_min), operations.h:1304,1338
     float gx = (float)x * d.voxel_size + (f.center[0] + d.pmin[0]);
     float gy = (float)y * d.voxel_size + (f.center[1] + d.pmin[1]);
@@ -170,126 +183,262 @@ __global__ __launch_bounds__(TPB) void k_vertex_mask(Dims d, Frame f, uint64_t *
     in = point_in_frustum(d, f, gx, gy, gz);
   }
   uint64_t mask = __ballot(in);
-  if (lane == 0) M[gw] = mask;
+  if (lane == 0) M[((size_t)z * VY + y) * wpl + xw] = mask;
 }
 
-// seed of the BFS (operations.h:1312-1324): the start vertex is reached iff it is inside the frustum
-__global__ void k_flood_seed(Dims d, Frame f, const uint64_t *__restrict__ M, uint64_t *__restrict__ R, int wpl,
-                             Counters *cnt) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (!f.start_ok) return;
+constexpr int MAX_WPL = 9;  // 513 vertices along an axis at most (x_n, y_n <= 9)
+
+// per-line summary bitmaps over (y,z); one wave per 64 lines along y, ballot-packed.  wy = words per z row.
+__global__ __launch_bounds__(TPB) void k_line_info(Dims d, Frame f, const uint64_t *__restrict__ M, int wpl, int wy,
+                                                   uint64_t *__restrict__ NE, uint64_t *__restrict__ EY,
+                                                   uint64_t *__restrict__ EZ, Counters *cnt) {
   const int VY = d.NY + 1;
-  size_t word = ((size_t)f.start_v[2] * VY + f.start_v[1]) * wpl + (f.start_v[0] >> 6);
-  uint64_t bit = 1ull << (f.start_v[0] & 63);
-  if (M[word] & bit) {
-    R[word] = bit;
-    cnt->start_in_frustum = 1;
+  const int yw0 = f.bb0[1] >> 6, yw1 = f.bb1[1] >> 6;
+  const int nyw = yw1 - yw0 + 1, nz = f.bb1[2] - f.bb0[2] + 1;
+  uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (gw >= (uint32_t)nyw * nz) return;
+  const int lane = threadIdx.x & 63;
+  const int yw = yw0 + gw % nyw, z = f.bb0[2] + gw / nyw;
+  const int y = yw * 64 + lane;
+  bool ne = false, ey = false, ez = false, complex_line = false;
+  if (y >= f.bb0[1] && y <= f.bb1[1]) {
+    const uint64_t *m = M + ((size_t)z * VY + y) * wpl;
+    const bool has_y = y + 1 <= f.bb1[1], has_z = z + 1 <= f.bb1[2];
+    const uint64_t *my = m + wpl, *mz = m + (size_t)VY * wpl;
+    uint32_t rises = 0;
+    uint64_t prev_msb = 0;
+    for (int i = 0; i < wpl; ++i) {
+      uint64_t w = m[i];
+      ne = ne || w != 0;
+      rises += (uint32_t)__popcll(w & ~((w << 1) | prev_msb));
+      prev_msb = w >> 63;
+      if (has_y && (w & my[i])) ey = true;
+      if (has_z && (w & mz[i])) ez = true;
+    }
+    complex_line = rises > 1;
+  }
+  uint64_t bne = __ballot(ne), bey = __ballot(ey), bez = __ballot(ez), bc = __ballot(complex_line);
+  if (lane == 0) {
+    size_t o = (size_t)z * wy + yw;
+    NE[o] = bne;
+    EY[o] = bey;
+    EZ[o] = bez;
+    if (bc) cnt->flood_complex = 1;
   }
 }
 
+__device__ __forceinline__ uint64_t fill_up64(uint64_t g, uint64_t p) {  // bit y may be entered from y-1 iff p[y]
+  g |= p & (g << 1);  p &= (p << 1);
+  g |= p & (g << 2);  p &= (p << 2);
+  g |= p & (g << 4);  p &= (p << 4);
+  g |= p & (g << 8);  p &= (p << 8);
+  g |= p & (g << 16); p &= (p << 16);
+  g |= p & (g << 32);
+  return g;
+}
+__device__ __forceinline__ uint64_t fill_down64(uint64_t g, uint64_t p) {  // bit y may be entered from y+1 iff p[y]
+  g |= p & (g >> 1);  p &= (p >> 1);
+  g |= p & (g >> 2);  p &= (p >> 2);
+  g |= p & (g >> 4);  p &= (p >> 4);
+  g |= p & (g >> 8);  p &= (p >> 8);
+  g |= p & (g >> 16); p &= (p >> 16);
+  g |= p & (g >> 32);
+  return g;
+}
 // occluded (Kogge-Stone) fill of g through the set bits of p, both directions inside one word
 __device__ __forceinline__ uint64_t fill64(uint64_t g, uint64_t p) {
   g &= p;
-  uint64_t gu = g, pu = p;
-  gu |= pu & (gu << 1);  pu &= (pu << 1);
-  gu |= pu & (gu << 2);  pu &= (pu << 2);
-  gu |= pu & (gu << 4);  pu &= (pu << 4);
-  gu |= pu & (gu << 8);  pu &= (pu << 8);
-  gu |= pu & (gu << 16); pu &= (pu << 16);
-  gu |= pu & (gu << 32);
-  uint64_t gd = g, pd = p;
-  gd |= pd & (gd >> 1);  pd &= (pd >> 1);
-  gd |= pd & (gd >> 2);  pd &= (pd >> 2);
-  gd |= pd & (gd >> 4);  pd &= (pd >> 4);
-  gd |= pd & (gd >> 8);  pd &= (pd >> 8);
-  gd |= pd & (gd >> 16); pd &= (pd >> 16);
-  gd |= pd & (gd >> 32);
-  return gu | gd;
+  return fill_up64(g, p) | fill_down64(g, p);
 }
 
-constexpr int MAX_WPL = 9;  // 513 vertices along x at most (x_n <= 9)
-
-// The BFS over 6-connected in-frustum vertices (operations.h:1327-1456) reaches exactly the connected
-// component of the start vertex.  It is computed here as a bit-parallel flood: line fills along x,
-// carry sweeps along y and z, repeated until a whole round changes nothing.
-__global__ __launch_bounds__(TPB) void k_flood_x(Dims d, Frame f, const uint64_t *__restrict__ M, uint64_t *__restrict__ R,
-                                                 int wpl, int round, Counters *cnt) {
-  if (round > 0 && cnt->flood_changed[round - 1] == 0) return;
+// Flood over lines in the (y,z) plane.  One workgroup; r (reached lines, bit y of word [z][yw]) lives in LDS.
+__global__ __launch_bounds__(TPB) void k_flood2d(Dims d, Frame f, const uint64_t *__restrict__ M, int wpl, int wy,
+                                                 const uint64_t *__restrict__ EY, const uint64_t *__restrict__ EZ,
+                                                 uint64_t *__restrict__ R2D, Counters *cnt) {
+  extern __shared__ uint64_t r[];  // [nz][nyw]
+  __shared__ uint32_t changed;
   const int VY = d.NY + 1;
-  int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ny * nz) return;
-  int y = f.bb0[1] + t % ny, z = f.bb0[2] + t / ny;
-  size_t base = ((size_t)z * VY + y) * wpl;
-  uint64_t r[MAX_WPL], m[MAX_WPL];
-  uint64_t any = 0;
-  for (int i = 0; i < wpl; ++i) {
-    r[i] = R[base + i];
-    any |= r[i];
+  const int yw0 = f.bb0[1] >> 6, yw1 = f.bb1[1] >> 6;
+  const int nyw = yw1 - yw0 + 1, nz = f.bb1[2] - f.bb0[2] + 1, z0 = f.bb0[2];
+  for (int i = threadIdx.x; i < nz * nyw; i += blockDim.x) r[i] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0 && f.start_ok) {
+    // seed: the start vertex is reached iff it lies inside the frustum (operations.h:1324-1340)
+    const int sx = f.start_v[0], sy = f.start_v[1], sz = f.start_v[2];
+    if (sy >= f.bb0[1] && sy <= f.bb1[1] && sz >= f.bb0[2] && sz <= f.bb1[2] && sx >= f.bb0[0] && sx <= f.bb1[0]) {
+      uint64_t w = M[((size_t)sz * VY + sy) * wpl + (sx >> 6)];
+      if ((w >> (sx & 63)) & 1ull) {
+        r[(sz - z0) * nyw + ((sy >> 6) - yw0)] = 1ull << (sy & 63);
+        cnt->start_in_frustum = 1;
+      }
+    }
   }
-  if (!any) return;
-  for (int i = 0; i < wpl; ++i) m[i] = M[base + i];
-  bool changed = false;
-  uint64_t carry = 0;
-  for (int i = 0; i < wpl; ++i) {  // upward across words
-    uint64_t g = fill64(r[i] | (carry ? 1ull : 0ull), m[i]);
-    carry = g >> 63;
-    if (g != r[i]) changed = true;
-    r[i] = g;
+  __syncthreads();
+  uint32_t rounds = 0;
+  for (; rounds < 256; ++rounds) {
+    if (threadIdx.x == 0) changed = 0;
+    __syncthreads();
+    // fill along y inside every z row; edge bit y joins lines y and y+1
+    for (int row = threadIdx.x; row < nz; row += blockDim.x) {
+      uint64_t *rr = r + row * nyw;
+      const uint64_t *e = EY + (size_t)(z0 + row) * wy + yw0;
+      uint64_t any = 0;
+      for (int i = 0; i < nyw; ++i) any |= rr[i];
+      if (!any) continue;
+      bool ch = false;
+      uint64_t carry = 0;
+      for (int i = 0; i < nyw; ++i) {  // upward
+        uint64_t ew = e[i];
+        uint64_t g = fill_up64(rr[i] | carry, ew << 1);
+        carry = (g >> 63) & (ew >> 63);
+        if (g != rr[i]) { rr[i] = g; ch = true; }
+      }
+      carry = 0;
+      for (int i = nyw - 1; i >= 0; --i) {  // downward
+        uint64_t ew = e[i];
+        uint64_t g = fill_down64(rr[i] | (carry << 63), ew);
+        carry = (i > 0) ? ((g & 1ull) & (e[i - 1] >> 63)) : 0ull;
+        if (g != rr[i]) { rr[i] = g; ch = true; }
+      }
+      if (ch) changed = 1;
+    }
+    __syncthreads();
+    // carry sweeps along z, one thread per y word; edge bit y of row z joins (y,z) and (y,z+1)
+    for (int c = threadIdx.x; c < nyw; c += blockDim.x) {
+      bool ch = false;
+      uint64_t carry = 0;
+#pragma unroll 4
+      for (int z = 0; z < nz; ++z) {
+        uint64_t old = r[z * nyw + c];
+        uint64_t g = old;
+        if (z > 0) g |= carry & EZ[(size_t)(z0 + z - 1) * wy + yw0 + c];
+        if (g != old) { r[z * nyw + c] = g; ch = true; }
+        carry = g;
+      }
+      carry = 0;
+#pragma unroll 4
+      for (int z = nz - 1; z >= 0; --z) {
+        uint64_t old = r[z * nyw + c];
+        uint64_t g = old | (carry & EZ[(size_t)(z0 + z) * wy + yw0 + c]);
+        if (g != old) { r[z * nyw + c] = g; ch = true; }
+        carry = g;
+      }
+      if (ch) changed = 1;
+    }
+    __syncthreads();
+    if (!changed) break;
+    __syncthreads();
   }
-  carry = 0;
-  for (int i = wpl - 1; i >= 0; --i) {  // downward across words
-    uint64_t g = fill64(r[i] | (carry ? (1ull << 63) : 0ull), m[i]);
-    carry = g & 1ull;
-    if (g != r[i]) changed = true;
-    r[i] = g;
-  }
-  if (changed) {
-    for (int i = 0; i < wpl; ++i) R[base + i] = r[i];
-    cnt->flood_changed[round] = 1;
-  }
+  for (int i = threadIdx.x; i < nz * nyw; i += blockDim.x) R2D[(size_t)(z0 + i / nyw) * wy + yw0 + i % nyw] = r[i];
+  if (threadIdx.x == 0) cnt->flood_rounds = rounds;
 }
 
-// axis: 1 = sweep along y (threads over z,xw), 2 = sweep along z (threads over y,xw)
-__global__ __launch_bounds__(TPB) void k_flood_sweep(Dims d, Frame f, const uint64_t *__restrict__ M,
-                                                     uint64_t *__restrict__ R, int wpl, int axis, int round, Counters *cnt) {
-  if (round > 0 && cnt->flood_changed[round - 1] == 0) return;
+// R = reached line ? M : 0 for every word of the frustum box
+__global__ __launch_bounds__(TPB) void k_reach_expand(Dims d, Frame f, const uint64_t *__restrict__ M,
+                                                      uint64_t *__restrict__ R, int wpl, int wy,
+                                                      const uint64_t *__restrict__ R2D) {
   const int VY = d.NY + 1;
-  int xw0 = f.bb0[0] >> 6, xw1 = f.bb1[0] >> 6;
-  int nxw = xw1 - xw0 + 1;
-  int other = axis == 1 ? 2 : 1;
-  int no = f.bb1[other] - f.bb0[other] + 1;
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nxw * no) return;
-  int xw = xw0 + t % nxw;
-  int o = f.bb0[other] + t / nxw;
-  int a0 = f.bb0[axis], a1 = f.bb1[axis];
-  size_t stride = axis == 1 ? (size_t)wpl : (size_t)VY * wpl;
-  size_t base = (axis == 1 ? (size_t)o * VY * wpl : (size_t)o * wpl) + xw;
-  bool changed = false;
-  uint64_t carry = 0;
-  for (int a = a0; a <= a1; ++a) {
-    size_t idx = base + (size_t)a * stride;
-    uint64_t r = R[idx];
-    uint64_t nr = r | (carry & M[idx]);
-    if (nr != r) {
-      R[idx] = nr;
-      changed = true;
-    }
-    carry = nr;
+  const int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint32_t)ny * nz * wpl) return;
+  int xw = t % wpl;
+  int l = t / wpl;
+  int y = f.bb0[1] + l % ny, z = f.bb0[2] + l / ny;
+  bool reached = (R2D[(size_t)z * wy + (y >> 6)] >> (y & 63)) & 1ull;
+  size_t o = ((size_t)z * VY + y) * wpl + xw;
+  R[o] = reached ? M[o] : 0ull;
+}
+
+// Exact 3-D bit flood for arbitrary masks (fallback, one workgroup): line fills along x, carry sweeps along y and z,
+// repeated until a whole round changes nothing.
+__global__ __launch_bounds__(1024) void k_flood_generic(Dims d, Frame f, const uint64_t *__restrict__ M,
+                                                        uint64_t *__restrict__ R, int wpl, int force, Counters *cnt) {
+  if (!force && !cnt->flood_complex) return;
+  __shared__ uint32_t changed;
+  const int VY = d.NY + 1;
+  const int y0 = f.bb0[1], z0 = f.bb0[2];
+  const int ny = f.bb1[1] - y0 + 1, nz = f.bb1[2] - z0 + 1;
+  const int xw0 = f.bb0[0] >> 6, nxw = (f.bb1[0] >> 6) - xw0 + 1;
+  for (int t = threadIdx.x; t < ny * nz * wpl; t += blockDim.x) {
+    int l = t / wpl;
+    R[((size_t)(z0 + l / ny) * VY + (y0 + l % ny)) * wpl + t % wpl] = 0ull;
   }
-  carry = 0;
-  for (int a = a1; a >= a0; --a) {
-    size_t idx = base + (size_t)a * stride;
-    uint64_t r = R[idx];
-    uint64_t nr = r | (carry & M[idx]);
-    if (nr != r) {
-      R[idx] = nr;
-      changed = true;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cnt->start_in_frustum = 0;
+    const int sx = f.start_v[0], sy = f.start_v[1], sz = f.start_v[2];
+    if (f.start_ok && sy >= y0 && sy <= f.bb1[1] && sz >= z0 && sz <= f.bb1[2] && sx >= f.bb0[0] && sx <= f.bb1[0]) {
+      size_t word = ((size_t)sz * VY + sy) * wpl + (sx >> 6);
+      uint64_t bit = 1ull << (sx & 63);
+      if (M[word] & bit) {
+        R[word] = bit;
+        cnt->start_in_frustum = 1;
+      }
     }
-    carry = nr;
   }
-  if (changed) cnt->flood_changed[round] = 1;
+  __syncthreads();
+  uint32_t rounds = 0;
+  for (; rounds < 1024; ++rounds) {
+    if (threadIdx.x == 0) changed = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < ny * nz; t += blockDim.x) {  // x fills
+      size_t base = ((size_t)(z0 + t / ny) * VY + (y0 + t % ny)) * wpl;
+      uint64_t r[MAX_WPL], m[MAX_WPL];
+      uint64_t any = 0;
+      for (int i = 0; i < wpl; ++i) { r[i] = R[base + i]; any |= r[i]; }
+      if (!any) continue;
+      for (int i = 0; i < wpl; ++i) m[i] = M[base + i];
+      bool ch = false;
+      uint64_t carry = 0;
+      for (int i = 0; i < wpl; ++i) {
+        uint64_t g = fill64(r[i] | (carry ? 1ull : 0ull), m[i]);
+        carry = g >> 63;
+        if (g != r[i]) ch = true;
+        r[i] = g;
+      }
+      carry = 0;
+      for (int i = wpl - 1; i >= 0; --i) {
+        uint64_t g = fill64(r[i] | (carry ? (1ull << 63) : 0ull), m[i]);
+        carry = g & 1ull;
+        if (g != r[i]) ch = true;
+        r[i] = g;
+      }
+      if (ch) {
+        for (int i = 0; i < wpl; ++i) R[base + i] = r[i];
+        changed = 1;
+      }
+    }
+    __syncthreads();
+    for (int axis = 1; axis <= 2; ++axis) {  // carry sweeps along y, then z
+      const int no = axis == 1 ? nz : ny, na = axis == 1 ? ny : nz;
+      const int o0 = axis == 1 ? z0 : y0, a0 = axis == 1 ? y0 : z0;
+      const size_t stride = axis == 1 ? (size_t)wpl : (size_t)VY * wpl;
+      for (int t = threadIdx.x; t < nxw * no; t += blockDim.x) {
+        const int xw = xw0 + t % nxw, o = o0 + t / nxw;
+        const size_t base = (axis == 1 ? (size_t)o * VY * wpl : (size_t)o * wpl) + xw;
+        bool ch = false;
+        uint64_t carry = 0;
+        for (int a = a0; a < a0 + na; ++a) {
+          size_t idx = base + (size_t)a * stride;
+          uint64_t rr = R[idx], nr = rr | (carry & M[idx]);
+          if (nr != rr) { R[idx] = nr; ch = true; }
+          carry = nr;
+        }
+        carry = 0;
+        for (int a = a0 + na - 1; a >= a0; --a) {
+          size_t idx = base + (size_t)a * stride;
+          uint64_t rr = R[idx], nr = rr | (carry & M[idx]);
+          if (nr != rr) { R[idx] = nr; ch = true; }
+          carry = nr;
+        }
+        if (ch) changed = 1;
+      }
+      __syncthreads();
+    }
+    if (!changed) break;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt->flood_rounds = rounds;
 }
 
 __device__ __forceinline__ bool vbit(const uint64_t *__restrict__ R, size_t line_base, int x) {
@@ -321,7 +470,8 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, S
   uint32_t ry = axis_correct(ay + f.eq[1], d.NY);
   uint32_t rz = axis_correct(az + f.eq[2], d.NZ);
   if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) return;  // another shard's slab
-  atomicAdd(&sc.cnt->n_frustum_voxels, 1u);
+  const uint32_t shard = blockIdx.x & (VIS_SHARDS - 1);
+  atomicAdd(&sc.cnt->fv_shard[shard], 1u);
   uint32_t v = ring_to_voxel(d, rx, ry, rz);
   uint32_t lv = v - d.v_begin;
   const uint32_t smax = stamp_max(st, rx, ry, rz);
@@ -354,9 +504,11 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, S
       if (cam_z > dpt * d.occl_coeff) continue;  // occluded (operations.h:1397-1400)
       observed = true;
       uint32_t pix = (uint32_t)(row * d.W + col);
-      uint32_t k = atomicAdd(&sc.cnt->n_vis, 1u);
+      const uint32_t cap_sub = sc.cap_vis / VIS_SHARDS;
+      uint32_t k = atomicAdd(&sc.cnt->vis_shard[shard], 1u);
       uint32_t pib = atomicAdd(&sc.bin_count[pix], 1u);
-      if (k < sc.cap_vis) {
+      if (k < cap_sub) {
+        k += shard * cap_sub;
         sc.vis_pix[k] = pix;
         sc.vis_idx[k] = (uint32_t)(((size_t)v << d.p_n) + i);
         sc.vis_pib[k] = pib;
@@ -381,13 +533,19 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, S
   }
 }
 
-// counting sort of the visible particles by pixel: scatter into the scanned bin ranges
-__global__ __launch_bounds__(TPB) void k_bin_fill(Scratch sc) {
+// counting sort of the visible particles by pixel: scatter into the scanned bin ranges.
+// blockIdx.y = shard of the work list; the total (last entry of the scanned counts) becomes n_vis.
+__global__ __launch_bounds__(TPB) void k_bin_fill(Scratch sc, uint32_t hw) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sc.cnt->n_vis = sc.bin_start[hw];
   if (sc.cnt->overflow) return;
-  uint32_t n = sc.cnt->n_vis;
+  const uint32_t cap_sub = sc.cap_vis / VIS_SHARDS;
+  const uint32_t shard = blockIdx.y;
+  uint32_t n = sc.cnt->vis_shard[shard];
+  if (n > cap_sub) n = cap_sub;
+  const uint32_t base = shard * cap_sub;
   uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
-    sc.bin_idx[sc.bin_start[sc.vis_pix[k]] + sc.vis_pib[k]] = sc.vis_idx[k];
+    sc.bin_idx[sc.bin_start[sc.vis_pix[base + k]] + sc.vis_pib[base + k]] = sc.vis_idx[base + k];
 }
 
 __device__ __forceinline__ void sift_down(uint32_t *a, uint32_t start, uint32_t end) {
@@ -712,7 +870,10 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
         st.track[base + slot] = track;
         st.label[base + slot] = label;
         st.status[base + slot] = ST_REGULAR_BORN;
-        if ((int)track <= d.max_movable) st.owner[base + slot] = track;  // addParticleToObj
+        if ((int)track <= d.max_movable) {  // addParticleToObj
+          st.owner[base + slot] = track;
+          st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
+        }
 #pragma unroll
         for (int i = 1; i < S; ++i)
           if (i == slot) {
@@ -848,6 +1009,7 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s) {
   hipMemsetAsync(st.track, 0, n * sizeof(uint16_t), s);
   hipMemsetAsync(st.label, 0, n, s);
   hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
+  hipMemsetAsync(st.owner_flag, 0, (n + OWNER_CHUNK - 1) / OWNER_CHUNK, s);
   hipMemsetAsync(st.res, 0, (size_t)d.v_count * sizeof(sdm_voxel_result), s);
   hipLaunchKernelGGL(k_clear_status, dim3(4096), dim3(TPB), 0, s, st.status, (uint32_t)n, d.S - 1);
 }
@@ -865,22 +1027,18 @@ void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStre
   SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st);
 }
 
-void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int flood_rounds, hipStream_t s) {
-  const int VY = d.NY + 1, VZ = d.NZ + 1;
-  const uint32_t n_words = (uint32_t)VZ * VY * sc.wpl;
-  hipMemsetAsync(sc.reach, 0, (size_t)n_words * 8, s);
+void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int force_generic, hipStream_t s) {
   hipMemsetAsync(sc.bin_count, 0, ((size_t)d.W * d.H + 1) * 4, s);
-  hipLaunchKernelGGL(k_vertex_mask, dim3(blocks_for((size_t)n_words * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl, n_words);
-  hipLaunchKernelGGL(k_flood_seed, dim3(1), dim3(64), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, sc.cnt);
-  int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
-  int nxw = (f.bb1[0] >> 6) - (f.bb0[0] >> 6) + 1;
-  if (ny > 0 && nz > 0 && nxw > 0) {
-    for (int r = 0; r < flood_rounds; ++r) {
-      hipLaunchKernelGGL(k_flood_x, dim3(blocks_for((size_t)ny * nz)), dim3(TPB), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, r, sc.cnt);
-      hipLaunchKernelGGL(k_flood_sweep, dim3(blocks_for((size_t)nxw * nz)), dim3(TPB), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, 1, r, sc.cnt);
-      hipLaunchKernelGGL(k_flood_sweep, dim3(blocks_for((size_t)nxw * ny)), dim3(TPB), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, 2, r, sc.cnt);
-    }
-  }
+  const int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
+  const int nyw = (f.bb1[1] >> 6) - (f.bb0[1] >> 6) + 1;
+  const size_t n_words = (size_t)ny * nz * sc.wpl;
+  hipLaunchKernelGGL(k_vertex_mask, dim3(blocks_for(n_words * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl);
+  hipLaunchKernelGGL(k_line_info, dim3(blocks_for((size_t)nyw * nz * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ne,
+                     sc.line_ey, sc.line_ez, sc.cnt);
+  hipLaunchKernelGGL(k_flood2d, dim3(1), dim3(TPB), (size_t)nz * nyw * 8, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ey, sc.line_ez,
+                     sc.line_reach, sc.cnt);
+  hipLaunchKernelGGL(k_reach_expand, dim3(blocks_for(n_words)), dim3(TPB), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, sc.wy, sc.line_reach);
+  hipLaunchKernelGGL(k_flood_generic, dim3(1), dim3(1024), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, force_generic, sc.cnt);
   int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];
   if (bx > 0 && by > 0 && bz > 0) {
     dim3 grid(blocks_for((size_t)bx * by * bz));
@@ -888,7 +1046,7 @@ void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scr
   }
   // bins: scan the per-pixel counts, scatter, canonical order + gather
   exclusive_scan_u32(sc.bin_count, sc.bin_start, (size_t)d.W * d.H + 1, sc.scan_scratch, s);
-  hipLaunchKernelGGL(k_bin_fill, dim3(2048), dim3(TPB), 0, s, sc);
+  hipLaunchKernelGGL(k_bin_fill, dim3(16, VIS_SHARDS), dim3(TPB), 0, s, sc, (uint32_t)(d.W * d.H));
   hipLaunchKernelGGL(k_bin_sort_gather, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, st, sc);
 }
 

@@ -82,7 +82,7 @@ struct sdm_map {
   int nb_alloc = 0;
   size_t sort_cap = 0;
   int noise_n = 0;
-  int flood_rounds = 5;
+  int force_generic_flood = 0;
 
   bool profiling = false;
   hipEvent_t ev[9]{};
@@ -325,11 +325,10 @@ sdm_status check_counters(sdm_map *m, Counters *out) {
     set_error("capacity", __FILE__, __LINE__, "visible-particle or move list overflowed (raise sdm_config.max_visible)");
     return SDM_ERR_CAPACITY;
   }
-  for (int r = 0; r < 8; ++r)
-    if (r == m->flood_rounds - 1 && c.flood_changed[r]) {
-      set_error("flood", __FILE__, __LINE__, "frustum flood fill still changing in its last round");
-      return SDM_ERR_NOT_CONVERGED;
-    }
+  if (c.flood_rounds >= 256 && !c.flood_complex) {
+    set_error("flood", __FILE__, __LINE__, "frustum flood fill did not converge");
+    return SDM_ERR_NOT_CONVERGED;
+  }
   return SDM_OK;
 }
 
@@ -346,7 +345,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   *out = nullptr;
   // runSystemChecking (mc_ring/operations.h:54-64)
   if (cfg->x_n + cfg->y_n + cfg->z_n + cfg->p_n > 31 || cfg->x_n < 2 || cfg->y_n < 2 || cfg->z_n < 2 || cfg->p_n < 1 ||
-      cfg->p_n > 4 || cfg->x_n > 9 || cfg->width <= 0 || cfg->height <= 0 || !(cfg->voxel_size > 0.f) ||
+      cfg->p_n > 4 || cfg->x_n > 9 || cfg->y_n > 9 || cfg->z_n > 9 || cfg->width <= 0 || cfg->height <= 0 || !(cfg->voxel_size > 0.f) ||
       cfg->window_half < 0) {
     set_error("sdm_create", __FILE__, __LINE__, "invalid configuration");
     return SDM_ERR_INVALID_ARGUMENT;
@@ -431,6 +430,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(m->st.label, n_slots);
   A(m->st.status, n_slots);
   A(m->st.owner, n_slots);
+  A(m->st.owner_flag, (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK);
   A(m->st.res, d.v_count);
   A(m->st.stamps_x, d.NX);
   A(m->st.stamps_y, d.NY);
@@ -449,11 +449,20 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   const size_t n_words = (size_t)(d.NZ + 1) * (d.NY + 1) * sc.wpl;
   A(sc.vmask, n_words);
   A(sc.reach, n_words);
+  sc.wy = (int)((d.NY + 1 + 63) / 64);
+  const size_t n_line_words = (size_t)(d.NZ + 1) * sc.wy;
+  A(sc.line_ne, n_line_words);
+  A(sc.line_ey, n_line_words);
+  A(sc.line_ez, n_line_words);
+  A(sc.line_reach, n_line_words);
   A(m->d_depth, hw);
   A(m->d_cloud, hw);
   A(sc.bin_count, hw + 1);
   A(sc.bin_start, hw + 1);
-  size_t cap_vis = cfg->max_visible > 0 ? (size_t)cfg->max_visible : std::min<size_t>(n_slots, (size_t)16 << 20);
+  // per-shard capacity is cap_vis / VIS_SHARDS; small maps get head-room for one block's worth of slots per shard
+  size_t cap_vis = cfg->max_visible > 0 ? (size_t)cfg->max_visible
+                                        : std::min<size_t>(n_slots + (size_t)VIS_SHARDS * 256 * d.S, (size_t)16 << 20);
+  cap_vis = (cap_vis + VIS_SHARDS - 1) / VIS_SHARDS * VIS_SHARDS;
   cap_vis = std::min<size_t>(cap_vis, 0xffffff00u);
   sc.cap_vis = (uint32_t)cap_vis;
   A(sc.vis_pix, cap_vis);
@@ -666,7 +675,7 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
   if (done(3)) return SDM_OK;
 
   // U1: visibility + binning (semantic_dsp_map.h:749)
-  launch_visibility(d, m->f, m->st, m->sc, m->flood_rounds, s);
+  launch_visibility(d, m->f, m->st, m->sc, m->force_generic_flood, s);
   mark(4);
   if (done(4)) return SDM_OK;
 
@@ -809,10 +818,9 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
   out->n_resampled_voxels = c.n_resampled;
   out->n_moved = c.n_moved;
   out->n_move_reinserted = c.n_move_reinserted;
-  out->n_frustum_voxels = c.n_frustum_voxels;
+  for (uint32_t k = 0; k < VIS_SHARDS; ++k) out->n_frustum_voxels += c.fv_shard[k];
   out->bfs_start_in_frustum = c.start_in_frustum;
-  for (int r = 0; r < 8; ++r)
-    if (c.flood_changed[r]) out->flood_rounds = r + 1;
+  out->flood_rounds = c.flood_rounds;
   if (m->profiling) {
     int prev = 0;
     for (int sidx = 1; sidx <= 7; ++sidx) {
@@ -839,6 +847,12 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
     out->n_occupied = (int64_t)nocc;
   }
   return rc;
+}
+
+sdm_status sdm_debug_force_generic_flood(sdm_map *m, int32_t on) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  m->force_generic_flood = on ? 1 : 0;
+  return SDM_OK;
 }
 
 sdm_status sdm_set_profiling(sdm_map *m, int32_t on) {
@@ -960,6 +974,7 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
   HIP_TRY(hipMemcpyAsync(m->st.status, status, n, hipMemcpyHostToDevice, s));
   if (owner) HIP_TRY(hipMemcpyAsync(m->st.owner, owner, n * 2, hipMemcpyHostToDevice, s));
   else HIP_TRY(hipMemsetAsync(m->st.owner, 0xFF, n * 2, s));
+  launch_owner_flags(m->d, m->st, s);
   HIP_TRY(hipStreamSynchronize(s));
   (void)hipFree(tx);
   (void)hipFree(ty);

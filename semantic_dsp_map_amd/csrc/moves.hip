@@ -23,6 +23,7 @@ constexpr int TPB = 256;
 constexpr int MV_ITEMS = 16;
 constexpr int MV_CHUNK = TPB * MV_ITEMS;  // slots per block
 constexpr int MV_WAVES = TPB / 64;
+static_assert(MV_CHUNK == (int)OWNER_CHUNK, "one move-sweep block per owner_flag byte");
 
 __global__ void k_move_table(const MoveSet *ms, uint8_t *table) {
   int k = threadIdx.x;
@@ -37,24 +38,34 @@ __device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint8_t *__restr
   return owner == OWNER_NONE ? (uint8_t)0xFF : table[owner];
 }
 
-// pass 1: per-block, per-object member counts.  cnt[obj * n_blocks + block]
+// pass 1: per-block, per-object member counts.  cnt[obj * n_blocks + block].  Chunks whose owner_flag is clear
+// are not read at all; a flagged chunk that turns out to hold no owner any more clears its flag.
 __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__ owner, size_t n_slots,
                                                     const uint8_t *__restrict__ table, uint32_t *__restrict__ cnt,
-                                                    uint32_t n_blocks, int n_obj) {
+                                                    uint32_t n_blocks, int n_obj, uint8_t *__restrict__ owner_flag) {
   __shared__ uint32_t c[MAX_MOVE_OBJECTS];
+  __shared__ uint32_t any_owner;
+  if (owner_flag[blockIdx.x] == 0) {
+    if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * n_blocks + blockIdx.x] = 0;
+    return;
+  }
   if (threadIdx.x < MAX_MOVE_OBJECTS) c[threadIdx.x] = 0;
+  if (threadIdx.x == 0) any_owner = 0;
   __syncthreads();
   size_t base = (size_t)blockIdx.x * MV_CHUNK;
 #pragma unroll 4
   for (int r = 0; r < MV_ITEMS; ++r) {
     size_t i = base + (size_t)r * TPB + threadIdx.x;
     if (i < n_slots) {
-      uint8_t o = obj_of(owner[i], table);
+      uint16_t ow = owner[i];
+      if (ow != OWNER_NONE) any_owner = 1;
+      uint8_t o = obj_of(ow, table);
       if (o != 0xFF) atomicAdd(&c[o], 1u);
     }
   }
   __syncthreads();
   if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * n_blocks + blockIdx.x] = c[threadIdx.x];
+  if (threadIdx.x == 0 && any_owner == 0) owner_flag[blockIdx.x] = 0;
 }
 
 // pass 2 (after the exclusive scan of cnt): stable scatter of the member indices.
@@ -208,6 +219,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, State st, Scratch s
     st.label[base + slot] = sc.mv_label[e];
     st.status[base + slot] = cs;
     st.owner[base + slot] = sc.mv_owner[e];  // new index joins the object's set
+    st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
 #pragma unroll
     for (int i = 1; i < S; ++i)
       if (i == slot) {
@@ -221,9 +233,11 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, State st, Scratch s
 
 // removeObjectByTrackID (object_layer.h:414-425): every index of the set -> INVALID, set erased.
 __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const uint16_t *__restrict__ tracks, int n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n_slots; i += stride) {
+  if (st.owner_flag[blockIdx.x] == 0) return;  // one block per OWNER_CHUNK slots
+  size_t i = (size_t)blockIdx.x * OWNER_CHUNK + threadIdx.x;
+  size_t end = (size_t)(blockIdx.x + 1) * OWNER_CHUNK;
+  if (end > n_slots) end = n_slots;
+  for (; i < end; i += blockDim.x) {
     uint16_t o = st.owner[i];
     if (o == OWNER_NONE) continue;
     for (int k = 0; k < n; ++k)
@@ -235,9 +249,31 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
   }
 }
 
+// after sdm_load_state: recompute the chunk flags from the owner array
+__global__ __launch_bounds__(TPB) void k_owner_flags(const uint16_t *__restrict__ owner, size_t n_slots,
+                                                     uint8_t *__restrict__ owner_flag) {
+  __shared__ uint32_t any_owner;
+  if (threadIdx.x == 0) any_owner = 0;
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * OWNER_CHUNK + threadIdx.x;
+  size_t end = (size_t)(blockIdx.x + 1) * OWNER_CHUNK;
+  if (end > n_slots) end = n_slots;
+  bool a = false;
+  for (; i < end; i += blockDim.x) a = a || owner[i] != OWNER_NONE;
+  if (a) any_owner = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) owner_flag[blockIdx.x] = any_owner ? 1 : 0;
+}
+
 inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
 
 }  // namespace
+
+void launch_owner_flags(const Dims &d, const State &st, hipStream_t s) {
+  const size_t n_slots = (size_t)d.v_count * d.S;
+  hipLaunchKernelGGL(k_owner_flags, dim3((unsigned)((n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK)), dim3(TPB), 0, s, st.owner, n_slots,
+                     st.owner_flag);
+}
 
 size_t move_blocks(const Dims &d) { return ((size_t)d.v_count * d.S + MV_CHUNK - 1) / MV_CHUNK; }
 
@@ -250,7 +286,8 @@ void launch_moves(const Dims &d, const Frame &f, const Filter &flt, const MoveSe
   const size_t n_cnt = (size_t)n_obj * n_blocks + 1;
   hipLaunchKernelGGL(k_move_table, dim3(1), dim3(MAX_MOVE_OBJECTS), 0, s, ms_dev, sc.track_to_obj);
   hipMemsetAsync(sc.mv_cnt + (n_cnt - 1), 0, 4, s);
-  hipLaunchKernelGGL(k_move_count, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, sc.track_to_obj, sc.mv_cnt, n_blocks, n_obj);
+  hipLaunchKernelGGL(k_move_count, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, sc.track_to_obj, sc.mv_cnt, n_blocks, n_obj,
+                     st.owner_flag);
   exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch, s);
   hipLaunchKernelGGL(k_move_scatter, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, slot_base, sc.track_to_obj, sc.mv_cnt,
                      n_blocks, n_obj, sc.mv_src, sc.cap_move, sc.cnt);
@@ -272,7 +309,8 @@ void launch_moves(const Dims &d, const Frame &f, const Filter &flt, const MoveSe
 
 void launch_remove(const Dims &d, const State &st, const uint16_t *tracks_dev, int n, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_remove, dim3(4096), dim3(TPB), 0, s, st, (size_t)d.v_count * d.S, tracks_dev, n);
+  const size_t n_slots = (size_t)d.v_count * d.S;
+  hipLaunchKernelGGL(k_remove, dim3((unsigned)((n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK)), dim3(TPB), 0, s, st, n_slots, tracks_dev, n);
 }
 
 }  // namespace sdm

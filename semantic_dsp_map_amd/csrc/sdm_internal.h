@@ -79,13 +79,20 @@ struct Counters {
   uint32_t n_frustum_voxels;
   uint32_t n_occupied;
   uint32_t n_free;
-  uint32_t flood_changed[8];
+  uint32_t flood_complex;  // some x-line of the frustum mask is not one contiguous run
+  uint32_t flood_pad[7];
   uint32_t flood_rounds;
   uint32_t start_in_frustum;
   uint32_t overflow;
   uint32_t n_valid_px;
   uint32_t pad[8];
+  // Same-address atomics retire at ~12 ns each on MI355X, so counters that every wave bumps are sharded
+  // by block index; the per-shard visible-particle counters also index per-shard regions of the work list.
+  uint32_t vis_shard[64];
+  uint32_t fv_shard[64];
 };
+constexpr uint32_t VIS_SHARDS = 64;
+constexpr uint32_t OWNER_CHUNK = 4096;  // slots per owner_flag byte (= slots per block of the move sweep)
 struct Cursors {
   int32_t birth_cursor;
   int32_t move_cursor;
@@ -99,6 +106,9 @@ struct State {
   uint8_t *label = nullptr;
   uint8_t *status = nullptr;
   uint16_t *owner = nullptr;
+  // one byte per OWNER_CHUNK consecutive slots: 1 if any slot of the chunk may have an owner.  Lets the object-move
+  // and removal sweeps skip the (vast) part of the map no dynamic object ever touched.
+  uint8_t *owner_flag = nullptr;
   sdm_voxel_result *res = nullptr;
   uint32_t *stamps_x = nullptr, *stamps_y = nullptr, *stamps_z = nullptr;
   float *pdf = nullptr;

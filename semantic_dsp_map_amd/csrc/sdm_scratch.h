@@ -15,6 +15,9 @@ struct Scratch {
   // frustum vertex bitsets, one line of wpl 64-bit words per (y,z)
   uint64_t *vmask = nullptr, *reach = nullptr;
   int wpl = 0;
+  // per-line bitmaps over (y,z), wy 64-bit words per z row: non-empty, overlaps next line in y / z, reached
+  uint64_t *line_ne = nullptr, *line_ey = nullptr, *line_ez = nullptr, *line_reach = nullptr;
+  int wy = 0;
   // inputs of the current frame (device)
   const float *depth = nullptr;
   const sdm_labeled_point *cloud = nullptr;
@@ -49,7 +52,7 @@ struct Scratch {
 };
 
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s);
-void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int flood_rounds, hipStream_t s);
+void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int force_generic, hipStream_t s);
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, hipStream_t s);
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s);
 void launch_weight(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
@@ -72,6 +75,7 @@ struct MoveSet {
   uint16_t track[MAX_MOVE_OBJECTS];
 };
 size_t move_blocks(const Dims &d);
+void launch_owner_flags(const Dims &d, const State &st, hipStream_t s);
 void launch_moves(const Dims &d, const Frame &f, const Filter &flt, const MoveSet *ms_dev, int n_obj, const State &st,
                   const Scratch &sc, hipStream_t s);
 void launch_remove(const Dims &d, const State &st, const uint16_t *tracks_dev, int n, hipStream_t s);

@@ -307,7 +307,9 @@ def prefill_state(cfg, scene, n_particles, seed=11, shard_rank=0, shard_count=1)
         st["track"][idx] = np.where(under, TRACK_ROAD, TRACK_BUILDING)
         st["label"][idx] = np.where(under, LABEL_ROAD, LABEL_BUILDING)
         st["status"][idx] = 1                                 # UPDATED
-    st["ts"][vox * S] = 1                                     # the voxel has been observed
+    # every voxel of the map has been observed at frame 1 (a long-running map has seen its whole volume): the
+    # occupancy sweep then has to read every slot of every voxel instead of skipping never-seen voxels
+    st["ts"][0::S] = 1
     ring = {"global_time_stamp": 1, "moved_steps": [0, 0, 0], "eq_steps": [0, 0, 0],
             "map_center": [0.0, 0.0, 0.0], "last_pos": [0.0, 0.0, 0.0], "birth_cursor": 0, "move_cursor": 0}
     return st, ring, n_vox * (S - 1)

@@ -184,3 +184,19 @@ def test_c3_full_size_two_frames():
     v = g.voxels()
     assert np.all((v["occ"] == 1) == (v["wsum"] > np.float32(params["occupancy_threshold"])))
     g.close()
+
+
+def test_generic_flood_fallback_matches_oracle():
+    """The frustum flood has two exact implementations (line-graph flood, and the plain 3-D bit flood used when a
+    mask line is not one run).  Force the fallback and compare with the oracle's literal BFS result."""
+    cfg, params, frames = synth.make_frames("T1", 5, "zed2", n_dynamic=2, yaw_rate_deg=4.0)
+    o, g = pu.make_pair(cfg, params, noise())
+    g.force_generic_flood(True)
+    S = 1 << cfg["p_n"]
+    for t, (depth, cloud, pos, q, moves) in enumerate(frames):
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves, sync=True)
+        rep = pu.compare_maps(o, g, S, check_bins=True, tag="frame %d: " % t)
+        assert not rep, "\n".join(rep)
+        assert o.stats()["n_frustum_voxels"] == g.stats()["n_frustum_voxels"]
+    g.close()
