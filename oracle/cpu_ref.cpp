@@ -620,7 +620,8 @@ struct oracle_map {
     const bool indep = prm.if_use_independent_filter != 0;
     const int slabs = cfg.ck_slabs > 1 ? cfg.ck_slabs : 1;
     const uint32_t slab_len = NZ / slabs;
-    std::vector<float> partial(slabs);
+    std::vector<float> partial(slabs), row_partial(slabs);
+    const bool canonical = cfg.bin_order == 1 || slabs > 1;
     for (int i = 0; i < H; ++i) {
       for (int j = 0; j < W; ++j) {
         const oracle_labeled_point &o = cloud[size_t(i) * W + j];
@@ -629,6 +630,10 @@ struct oracle_map {
         float ck_this_pixel = 0.f;
         if (slabs > 1) std::fill(partial.begin(), partial.end(), 0.f);
         for (int m = -h; m <= h; ++m) {
+          // canonical mode: every window row is summed on its own and the row sums are added in row order
+          // (the GPU evaluates the rows in parallel); literal mode: one running sum like the reference.
+          float row_sum = 0.f;
+          if (slabs > 1) std::fill(row_partial.begin(), row_partial.end(), 0.f);
           for (int n = -h; n <= h; ++n) {
             int ni = i + m, nj = j + n;
             if (ni < 0 || ni >= H || nj < 0 || nj >= W) continue;
@@ -649,12 +654,19 @@ struct oracle_map {
                 }
                 if (slabs > 1) {
                   uint32_t rz = (bin[l] >> cfg.p_n) >> (cfg.x_n + cfg.y_n);
-                  partial[rz / slab_len] += particle->weight * gk;
+                  row_partial[rz / slab_len] += particle->weight * gk;
+                } else if (canonical) {
+                  row_sum += particle->weight * gk;
                 } else {
                   ck_this_pixel += particle->weight * gk;
                 }
               }
             }
+          }
+          if (slabs > 1) {
+            for (int g = 0; g < slabs; ++g) partial[g] += row_partial[g];
+          } else if (canonical) {
+            ck_this_pixel += row_sum;
           }
         }
         if (slabs > 1) {
@@ -675,6 +687,7 @@ struct oracle_map {
           float acc = 0.f;
           bool updated_with_right_id = false;
           for (int m = -h; m <= h; ++m) {
+            float row_acc = 0.f;  // canonical mode: per-row partial sums, see pass 1
             for (int n = -h; n <= h; ++n) {
               int ni = i + m, nj = j + n;
               if (ni < 0 || ni >= H || nj < 0 || nj >= W) continue;
@@ -694,8 +707,10 @@ struct oracle_map {
                 }
                 gk *= getForgettingFactor(particle->forget_count);
               }
-              acc += gk / ck_kappa[size_t(ni) * W + nj];
+              if (canonical) row_acc += gk / ck_kappa[size_t(ni) * W + nj];
+              else acc += gk / ck_kappa[size_t(ni) * W + nj];
             }
+            if (canonical) acc += row_acc;
           }
           particle->weight *= (acc * prm.detection_probability + 1.f - prm.detection_probability);
           particle->status = UPDATED;

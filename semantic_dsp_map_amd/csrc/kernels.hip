@@ -47,6 +47,13 @@ __global__ __launch_bounds__(TPB) void k_clear_status(uint8_t *__restrict__ stat
   for (; i < n_slots; i += stride) status[i] = (i & slot_mask) == 0 ? (uint8_t)ST_TIMEPTC : (uint8_t)ST_INVALID;
 }
 
+// start of frame: zero the per-frame counters and the per-pixel bin counts (one launch instead of two memsets)
+__global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__restrict__ bin_count, uint32_t n_bins) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < sizeof(Counters) / 4) reinterpret_cast<uint32_t *>(cnt)[i] = 0;
+  for (; i < n_bins; i += gridDim.x * blockDim.x) bin_count[i] = 0;
+}
+
 // ------------------------------------------------------------------------------------ A10
 // getOccupancyResult -> determineIfVoxelOccupied -> calculateWeightAndSemanticsInVoxel
 // (semantic_dsp_map.h:1239-1257, mc_ring/operations.h:623-639, 390-448).
@@ -457,13 +464,21 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, S
   int ay = f.bb0[1] + (int)((t / bx) % by);
   int az = f.bb0[2] + (int)(t / ((uint32_t)bx * by));
   const int VY = d.NY + 1;
+  // a voxel is handled iff one of its 8 corner vertices was reached by the flood.  Simple masks: vertex reached =
+  // in-frustum bit & its x-line reached; complex masks: the generic flood wrote the reached bits to sc.reach.
+  const bool generic = sc.force_generic || sc.cnt->flood_complex;
   bool reached = false;
 #pragma unroll
   for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-      size_t lb = ((size_t)(az + dz) * VY + (ay + dy)) * sc.wpl;
-      reached = reached || vbit(sc.reach, lb, ax) || vbit(sc.reach, lb, ax + 1);
+      const int y = ay + dy, z = az + dz;
+      size_t lb = ((size_t)z * VY + y) * sc.wpl;
+      if (generic) {
+        reached = reached || vbit(sc.reach, lb, ax) || vbit(sc.reach, lb, ax + 1);
+      } else if ((sc.line_reach[(size_t)z * sc.wy + (y >> 6)] >> (y & 63)) & 1ull) {
+        reached = reached || vbit(sc.vmask, lb, ax) || vbit(sc.vmask, lb, ax + 1);
+      }
     }
   if (!reached) return;
   uint32_t rx = axis_correct(ax + f.eq[0], d.NX);
@@ -609,43 +624,60 @@ __global__ __launch_bounds__(TPB) void k_bin_sort_gather(Dims d, State st, Scrat
 }
 
 // ------------------------------------------------------------------------------------ A7
-// SemanticDSPMap::updateParticles pass 1 (semantic_dsp_map.h:973-1037): ck + kappa per valid pixel.
-// One thread per pixel accumulates in the reference's order (window rows, columns, bin order).
-__global__ __launch_bounds__(TPB) void k_ck(Dims d, Filter flt, State st, Scratch sc, float *__restrict__ ck_out) {
-  if (sc.cnt->overflow) return;
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.W * d.H) return;
-  const sdm_labeled_point o = sc.cloud[p];
-  if (!o.is_valid) return;
-  const int i = p / d.W, j = p % d.W;
+// SemanticDSPMap::updateParticles (semantic_dsp_map.h:960-1121), the SMC-PHD weight update.  Not HBM-bound: every
+// particle-pixel pair of a (2h+1)^2 window costs three IEEE divisions and three LUT reads.  The work is split per
+// WINDOW ROW so that the long serial chains of the CPU loops become 2h+1 short ones: a 16x16 workgroup holds 16
+// pixels (pass 1) or 16 particles (pass 2) times up to 16 window rows; every thread accumulates its row in the
+// reference's order, then the row sums are added in row order.  (Canonical summation order, DESIGN.md: the value is
+// identical on the oracle's canonical mode and differs from the reference's single running sum only in rounding.)
+constexpr int A7_ROWS = 16;   // >= 2*window_half+1
+constexpr int A7_ITEMS = 16;  // pixels / particles per workgroup
+
+// pass 1 (semantic_dsp_map.h:973-1037): ck of every valid pixel.  finish != 0 also applies ck*P_d + kappa (:1035).
+__global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, State st, Scratch sc,
+                                                          float *__restrict__ ck_out, int finish) {
+  __shared__ float rowsum[A7_ITEMS][A7_ROWS];
+  const int r = threadIdx.x, it = threadIdx.y;
+  const int p = blockIdx.x * A7_ITEMS + it;
   const int h = d.window_half;
-  const float sigma = o.sigma;
-  const float *__restrict__ pdf = st.pdf;
-  float ck = 0.f;
-  int j0 = j - h < 0 ? 0 : j - h;
-  int j1 = j + h >= d.W ? d.W - 1 : j + h;
-  for (int m = -h; m <= h; ++m) {
-    int ni = i + m;
-    if (ni < 0 || ni >= d.H) continue;
-    uint32_t s = sc.bin_start[ni * d.W + j0];
-    uint32_t e = sc.bin_start[ni * d.W + j1 + 1];
-    for (uint32_t k = s; k < e; ++k) {
-      uint16_t ptrack = sc.vtrack[k];
-      if (flt.independent && ptrack != o.track_id) continue;
-      float gk = query_pdf(pdf, sc.vx[k], o.x, sigma) * query_pdf(pdf, sc.vy[k], o.y, sigma) *
-                 query_pdf(pdf, sc.vz[k], o.z, sigma);
-      if (!flt.independent) {
-        gk *= flt.forget[sc.vforget[k] & 7];
-        if (ptrack != o.track_id) gk *= flt.id_transition;
+  float acc = 0.f;
+  bool valid_px = false;
+  if (!sc.cnt->overflow && p < d.W * d.H && r <= 2 * h) {
+    const sdm_labeled_point o = sc.cloud[p];
+    valid_px = o.is_valid != 0;
+    const int i = p / d.W, j = p % d.W;
+    const int ni = i + r - h;
+    if (valid_px && ni >= 0 && ni < d.H) {
+      const int j0 = j - h < 0 ? 0 : j - h;
+      const int j1 = j + h >= d.W ? d.W - 1 : j + h;
+      const uint32_t s = sc.bin_start[ni * d.W + j0];
+      const uint32_t e = sc.bin_start[ni * d.W + j1 + 1];
+      const float *__restrict__ pdf = st.pdf;
+      const float sigma = o.sigma;
+      for (uint32_t k = s; k < e; ++k) {
+        const uint16_t ptrack = sc.vtrack[k];
+        if (flt.independent && ptrack != o.track_id) continue;
+        float gk = query_pdf(pdf, sc.vx[k], o.x, sigma) * query_pdf(pdf, sc.vy[k], o.y, sigma) *
+                   query_pdf(pdf, sc.vz[k], o.z, sigma);
+        if (!flt.independent) {
+          gk *= flt.forget[sc.vforget[k] & 7];
+          if (ptrack != o.track_id) gk *= flt.id_transition;
+        }
+        acc += sc.vw[k] * gk;
       }
-      ck += sc.vw[k] * gk;
     }
   }
-  ck_out[p] = ck;
+  rowsum[it][r] = acc;
+  __syncthreads();
+  if (r == 0 && valid_px) {
+    float ck = 0.f;
+    for (int m = 0; m <= 2 * h; ++m) ck += rowsum[it][m];
+    if (finish) sc.ck_kappa[p] = ck * flt.p_detect + flt.noise_number;
+    else ck_out[p] = ck;
+  }
 }
 
-// ck_kappa = ck * P_d + noise_number (semantic_dsp_map.h:1035); ck_parts > 1: sum of per-slab partial
-// images in slab order (multi-GPU path)
+// ck_kappa from the per-slab partial images, summed in slab order (multi-GPU path)
 __global__ __launch_bounds__(TPB) void k_ck_finish(Dims d, Filter flt, Scratch sc, const float *__restrict__ parts,
                                                    int n_parts) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -653,65 +685,79 @@ __global__ __launch_bounds__(TPB) void k_ck_finish(Dims d, Filter flt, Scratch s
   if (!sc.cloud[p].is_valid) return;
   float ck = 0.f;
   size_t hw = (size_t)d.W * d.H;
-  if (n_parts == 1) ck = parts[p];
-  else
-    for (int g = 0; g < n_parts; ++g) ck += parts[(size_t)g * hw + p];
+  for (int g = 0; g < n_parts; ++g) ck += parts[(size_t)g * hw + p];
   sc.ck_kappa[p] = ck * flt.p_detect + flt.noise_number;
 }
 
-// pass 2 (semantic_dsp_map.h:1041-1119): one thread per binned particle.
-__global__ __launch_bounds__(TPB) void k_weight(Dims d, Frame f, Filter flt, State st, Scratch sc) {
+// pass 2 (semantic_dsp_map.h:1041-1119): 16 binned particles x window rows per workgroup.
+__global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Frame f, Filter flt, State st, Scratch sc) {
+  __shared__ float rowsum[A7_ITEMS][A7_ROWS];
+  __shared__ int rowflag[A7_ITEMS][A7_ROWS];
   if (sc.cnt->overflow) return;
   const uint32_t n = sc.cnt->n_vis;
-  const float *__restrict__ pdf = st.pdf;
+  const int r = threadIdx.x, it = threadIdx.y;
   const int h = d.window_half;
+  const float *__restrict__ pdf = st.pdf;
   const size_t slot_base = (size_t)d.v_begin << d.p_n;
-  uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-    const uint32_t p = sc.vpix[k];
-    const int i = p / d.W, j = p % d.W;
-    const float sigma = sc.cloud[p].sigma;  // sigma of the particle's own pixel (semantic_dsp_map.h:1047)
-    const float x = sc.vx[k], y = sc.vy[k], z = sc.vz[k];
-    const uint16_t ptrack = sc.vtrack[k];
-    const uint32_t fc = sc.vforget[k];
-    const float ff = flt.forget[fc & 7];
+  for (uint32_t k0 = blockIdx.x * A7_ITEMS; k0 < n; k0 += gridDim.x * A7_ITEMS) {
+    const uint32_t k = k0 + it;
     float acc = 0.f;
-    bool right_id = false;
-    for (int m = -h; m <= h; ++m) {
-      int ni = i + m;
-      if (ni < 0 || ni >= d.H) continue;
-      for (int nn = -h; nn <= h; ++nn) {
-        int nj = j + nn;
-        if (nj < 0 || nj >= d.W) continue;
-        const int q = ni * d.W + nj;
-        const sdm_labeled_point o = sc.cloud[q];
-        if (!o.is_valid) continue;
-        if (flt.independent && o.track_id != ptrack) continue;
-        float gk = query_pdf(pdf, x, o.x, sigma) * query_pdf(pdf, y, o.y, sigma) * query_pdf(pdf, z, o.z, sigma);
-        if (!flt.independent) {
-          if (ptrack != o.track_id) {
-            gk *= flt.id_transition;
-          } else {
-            if (gk > SDM_MIN_RIGHT_PDF) right_id = true;
+    int right = 0;
+    uint32_t p = 0;
+    if (k < n) p = sc.vpix[k];
+    if (k < n && r <= 2 * h) {
+      const int i = p / d.W, j = p % d.W;
+      const int ni = i + r - h;
+      if (ni >= 0 && ni < d.H) {
+        const float sigma = sc.cloud[p].sigma;  // sigma of the particle's own pixel (semantic_dsp_map.h:1047)
+        const float x = sc.vx[k], y = sc.vy[k], z = sc.vz[k];
+        const uint16_t ptrack = sc.vtrack[k];
+        const float ff = flt.forget[sc.vforget[k] & 7];
+        for (int nn = -h; nn <= h; ++nn) {
+          const int nj = j + nn;
+          if (nj < 0 || nj >= d.W) continue;
+          const int q = ni * d.W + nj;
+          const sdm_labeled_point o = sc.cloud[q];
+          if (!o.is_valid) continue;
+          if (flt.independent && o.track_id != ptrack) continue;
+          float gk = query_pdf(pdf, x, o.x, sigma) * query_pdf(pdf, y, o.y, sigma) * query_pdf(pdf, z, o.z, sigma);
+          if (!flt.independent) {
+            if (ptrack != o.track_id) {
+              gk *= flt.id_transition;
+            } else {
+              if (gk > SDM_MIN_RIGHT_PDF) right = 1;
+            }
+            gk *= ff;
           }
-          gk *= ff;
+          acc += gk / sc.ck_kappa[q];
         }
-        acc += gk / sc.ck_kappa[q];
       }
     }
-    const size_t li = (size_t)sc.bin_idx[k] - slot_base;
-    float wnew = sc.vw[k] * (acc * flt.p_detect + 1.f - flt.p_detect);
-    st.w[li] = wnew;
-    st.status[li] = ST_UPDATED;
-    st.ts[li] = (uint16_t)f.gts;
-    if (!flt.independent) {
-      uint32_t nf = right_id ? 0u : (fc < 5u ? fc + 1u : fc);
-      if (nf != fc) {
-        float4 q4 = st.pos4[li];
-        q4.w = __uint_as_float(nf);
-        st.pos4[li] = q4;
+    rowsum[it][r] = acc;
+    rowflag[it][r] = right;
+    __syncthreads();
+    if (r == 0 && k < n) {
+      float a = 0.f;
+      int right_id = 0;
+      for (int m = 0; m <= 2 * h; ++m) {
+        a += rowsum[it][m];
+        right_id |= rowflag[it][m];
+      }
+      const size_t li = (size_t)sc.bin_idx[k] - slot_base;
+      const uint32_t fc = sc.vforget[k];
+      st.w[li] = sc.vw[k] * (a * flt.p_detect + 1.f - flt.p_detect);
+      st.status[li] = ST_UPDATED;
+      st.ts[li] = (uint16_t)f.gts;
+      if (!flt.independent) {
+        uint32_t nf = right_id ? 0u : (fc < 5u ? fc + 1u : fc);
+        if (nf != fc) {
+          float4 q4 = st.pos4[li];
+          q4.w = __uint_as_float(nf);
+          st.pos4[li] = q4;
+        }
       }
     }
+    __syncthreads();
   }
 }
 
@@ -1027,8 +1073,11 @@ void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStre
   SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st);
 }
 
+void launch_frame_begin(const Dims &d, const Scratch &sc, hipStream_t s) {
+  hipLaunchKernelGGL(k_frame_begin, dim3(512), dim3(TPB), 0, s, sc.cnt, sc.bin_count, (uint32_t)(d.W * d.H + 1));
+}
+
 void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int force_generic, hipStream_t s) {
-  hipMemsetAsync(sc.bin_count, 0, ((size_t)d.W * d.H + 1) * 4, s);
   const int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
   const int nyw = (f.bb1[1] >> 6) - (f.bb0[1] >> 6) + 1;
   const size_t n_words = (size_t)ny * nz * sc.wpl;
@@ -1037,7 +1086,6 @@ void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scr
                      sc.line_ey, sc.line_ez, sc.cnt);
   hipLaunchKernelGGL(k_flood2d, dim3(1), dim3(TPB), (size_t)nz * nyw * 8, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ey, sc.line_ez,
                      sc.line_reach, sc.cnt);
-  hipLaunchKernelGGL(k_reach_expand, dim3(blocks_for(n_words)), dim3(TPB), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, sc.wy, sc.line_reach);
   hipLaunchKernelGGL(k_flood_generic, dim3(1), dim3(1024), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, force_generic, sc.cnt);
   int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];
   if (bx > 0 && by > 0 && bz > 0) {
@@ -1050,24 +1098,26 @@ void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scr
   hipLaunchKernelGGL(k_bin_sort_gather, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, st, sc);
 }
 
-void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_ck, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, st, sc, ck_out);
+void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s) {
+  hipLaunchKernelGGL(k_ck, dim3(blocks_for((size_t)d.W * d.H, A7_ITEMS)), dim3(A7_ROWS, A7_ITEMS), 0, s, d, flt, st, sc, ck_out, finish);
 }
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s) {
   hipLaunchKernelGGL(k_ck_finish, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, parts, n_parts);
 }
 void launch_weight(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s) {
-  hipLaunchKernelGGL(k_weight, dim3(4096), dim3(TPB), 0, s, d, f, flt, st, sc);
+  hipLaunchKernelGGL(k_weight, dim3(16384), dim3(A7_ROWS, A7_ITEMS), 0, s, d, f, flt, st, sc);
 }
 
 void launch_births(const Dims &d, const Frame &f, const Filter &flt, const BirthOrder &bo, const State &st,
                    const Scratch &sc, hipStream_t s) {
   const size_t hw = (size_t)d.W * d.H;
   const size_t total = hw * flt.nb;
-  hipLaunchKernelGGL(k_birth_flags, dim3(blocks_for(hw)), dim3(TPB), 0, s, d, bo, sc);
-  exclusive_scan_u32(sc.b_valid, sc.b_rank, hw, sc.scan_scratch, s);
+  if (flt.use_rng) {  // the exclusive rank among valid pixels only feeds the noise-table cursor
+    hipLaunchKernelGGL(k_birth_flags, dim3(blocks_for(hw)), dim3(TPB), 0, s, d, bo, sc);
+    exclusive_scan_u32(sc.b_valid, sc.b_rank, hw, sc.scan_scratch, s);
+  }
   hipLaunchKernelGGL(k_birth_candidates, dim3(blocks_for(total)), dim3(TPB), 0, s, d, f, flt, bo, st, sc);
-  hipLaunchKernelGGL(k_birth_cursor, dim3(1), dim3(64), 0, s, d, flt, sc);
+  if (flt.use_rng) hipLaunchKernelGGL(k_birth_cursor, dim3(1), dim3(64), 0, s, d, flt, sc);
   int nbits = d.x_n + d.y_n + d.z_n + 1;
   int which = radix_sort_pairs(sc.bkey_a, sc.bval_a, sc.bkey_b, sc.bval_b, total, nbits, sc.sort_scratch, s);
   const uint32_t *skey = which ? sc.bkey_b : sc.bkey_a;

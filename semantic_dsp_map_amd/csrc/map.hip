@@ -58,6 +58,7 @@ struct sdm_map {
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
   float *ck_user = nullptr;
+  bool fused_ck = false;  // single-GPU sdm_update: pass 1 writes ck+kappa directly
   int device = 0;
 
   // host ring-buffer state (mc_ring/buffer.h:97-120)
@@ -346,7 +347,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   // runSystemChecking (mc_ring/operations.h:54-64)
   if (cfg->x_n + cfg->y_n + cfg->z_n + cfg->p_n > 31 || cfg->x_n < 2 || cfg->y_n < 2 || cfg->z_n < 2 || cfg->p_n < 1 ||
       cfg->p_n > 4 || cfg->x_n > 9 || cfg->y_n > 9 || cfg->z_n > 9 || cfg->width <= 0 || cfg->height <= 0 || !(cfg->voxel_size > 0.f) ||
-      cfg->window_half < 0) {
+      cfg->window_half < 0 || cfg->window_half > 7) {
     set_error("sdm_create", __FILE__, __LINE__, "invalid configuration");
     return SDM_ERR_INVALID_ARGUMENT;
   }
@@ -627,7 +628,7 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
 
   m->global_time_stamp += 1;  // semantic_dsp_map.h:173
   mark(0);
-  HIP_TRY(hipMemsetAsync(m->sc.cnt, 0, sizeof(Counters), s));
+  launch_frame_begin(d, m->sc, s);
   if (flags & SDM_INPUT_ON_DEVICE) {
     m->sc.depth = depth;
     m->sc.cloud = cloud;
@@ -675,13 +676,14 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
   if (done(3)) return SDM_OK;
 
   // U1: visibility + binning (semantic_dsp_map.h:749)
+  m->sc.force_generic = m->force_generic_flood;
   launch_visibility(d, m->f, m->st, m->sc, m->force_generic_flood, s);
   mark(4);
   if (done(4)) return SDM_OK;
 
   // U2 pass 1: this shard's ck partial sums
   float *ck_dst = m->ck_user ? m->ck_user : m->d_ck_part;
-  launch_ck(d, m->flt, m->st, m->sc, ck_dst, s);
+  launch_ck(d, m->flt, m->st, m->sc, ck_dst, m->fused_ck ? 1 : 0, s);
   if (ck_part_dev) *ck_part_dev = ck_dst;
   return SDM_OK;
 }
@@ -702,7 +704,7 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
     }
   };
   const float *own = m->ck_user ? m->ck_user : m->d_ck_part;
-  launch_ck_finish(d, m->flt, m->sc, ck_parts_dev ? ck_parts_dev : own, ck_parts_dev ? n_parts : 1, s);
+  if (!m->fused_ck) launch_ck_finish(d, m->flt, m->sc, ck_parts_dev ? ck_parts_dev : own, ck_parts_dev ? n_parts : 1, s);
   launch_weight(d, m->f, m->flt, m->st, m->sc, s);
   mark(5);
   if (done(5)) return SDM_OK;
@@ -717,10 +719,13 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
 sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
                       const float cam_q[4], const sdm_object_move *moves, int32_t n_moves, const int32_t *remove_tracks,
                       int32_t n_remove, uint32_t flags, int32_t stop_after) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  m->fused_ck = true;
   sdm_status rc = sdm_update_begin(m, depth, cloud, cam_pos, cam_q, moves, n_moves, remove_tracks, n_remove, flags,
                                    stop_after, nullptr);
-  if (rc != SDM_OK) return rc;
-  return sdm_update_finish(m, nullptr, 1, flags, stop_after);
+  if (rc == SDM_OK) rc = sdm_update_finish(m, nullptr, 1, flags, stop_after);
+  m->fused_ck = false;
+  return rc;
 }
 
 sdm_status sdm_synchronize(sdm_map *m) {

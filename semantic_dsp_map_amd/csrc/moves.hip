@@ -25,31 +25,31 @@ constexpr int MV_CHUNK = TPB * MV_ITEMS;  // slots per block
 constexpr int MV_WAVES = TPB / 64;
 static_assert(MV_CHUNK == (int)OWNER_CHUNK, "one move-sweep block per owner_flag byte");
 
-__global__ void k_move_table(const MoveSet *ms, uint8_t *table) {
-  int k = threadIdx.x;
-  if (k < ms->n) table[ms->track[k]] = (uint8_t)k;
-}
-__global__ void k_move_table_reset(const MoveSet *ms, uint8_t *table) {
-  int k = threadIdx.x;
-  if (k < ms->n) table[ms->track[k]] = 0xFF;
-}
-
-__device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint8_t *__restrict__ table) {
-  return owner == OWNER_NONE ? (uint8_t)0xFF : table[owner];
+// rank of the moving object that owns a slot (0xFF if none): the <= 64 moving track ids sit in LDS
+__device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint16_t *tracks, int n_obj) {
+  if (owner == OWNER_NONE) return 0xFF;
+  uint8_t o = 0xFF;
+  for (int k = 0; k < n_obj; ++k)
+    if (tracks[k] == owner) o = (uint8_t)k;
+  return o;
 }
 
 // pass 1: per-block, per-object member counts.  cnt[obj * n_blocks + block].  Chunks whose owner_flag is clear
 // are not read at all; a flagged chunk that turns out to hold no owner any more clears its flag.
 __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__ owner, size_t n_slots,
-                                                    const uint8_t *__restrict__ table, uint32_t *__restrict__ cnt,
+                                                    const MoveSet *__restrict__ ms, uint32_t *__restrict__ cnt,
                                                     uint32_t n_blocks, int n_obj, uint8_t *__restrict__ owner_flag) {
   __shared__ uint32_t c[MAX_MOVE_OBJECTS];
+  __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
   __shared__ uint32_t any_owner;
   if (owner_flag[blockIdx.x] == 0) {
     if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * n_blocks + blockIdx.x] = 0;
     return;
   }
-  if (threadIdx.x < MAX_MOVE_OBJECTS) c[threadIdx.x] = 0;
+  if (threadIdx.x < MAX_MOVE_OBJECTS) {
+    c[threadIdx.x] = 0;
+    tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms->track[threadIdx.x] : OWNER_NONE;
+  }
   if (threadIdx.x == 0) any_owner = 0;
   __syncthreads();
   size_t base = (size_t)blockIdx.x * MV_CHUNK;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__
     if (i < n_slots) {
       uint16_t ow = owner[i];
       if (ow != OWNER_NONE) any_owner = 1;
-      uint8_t o = obj_of(ow, table);
+      uint8_t o = obj_of(ow, tracks, n_obj);
       if (o != 0xFF) atomicAdd(&c[o], 1u);
     }
   }
@@ -70,14 +70,16 @@ __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__
 
 // pass 2 (after the exclusive scan of cnt): stable scatter of the member indices.
 __global__ __launch_bounds__(TPB) void k_move_scatter(const uint16_t *__restrict__ owner, size_t n_slots, size_t slot_base,
-                                                      const uint8_t *__restrict__ table, const uint32_t *__restrict__ offs,
+                                                      const MoveSet *__restrict__ ms, const uint32_t *__restrict__ offs,
                                                       uint32_t n_blocks, int n_obj, uint32_t *__restrict__ mv_src,
                                                       uint32_t cap, Counters *cnt) {
   __shared__ uint32_t obj_base[MAX_MOVE_OBJECTS];
+  __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
   __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
   __shared__ uint32_t block_total;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) block_total = 0;
+  if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms->track[threadIdx.x] : OWNER_NONE;
   __syncthreads();
   if ((int)threadIdx.x < n_obj) {
     uint32_t o0 = offs[(size_t)threadIdx.x * n_blocks + blockIdx.x];
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(TPB) void k_move_scatter(const uint16_t *__restrict
     __syncthreads();
     size_t i = base + (size_t)r * TPB + threadIdx.x;
     uint8_t o = 0xFF;
-    if (i < n_slots) o = obj_of(owner[i], table);
+    if (i < n_slots) o = obj_of(owner[i], tracks, n_obj);
     bool valid = o != 0xFF;
     uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -174,17 +176,16 @@ __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter 
   }
 }
 
-__global__ void k_move_cursor(Filter flt, Scratch sc) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  long long c = (long long)sc.cur->move_cursor + 3ll * (long long)sc.cnt->n_moved;
-  sc.cur->move_cursor = (int32_t)(c % flt.noise_n);
-}
-
 // phase 2 (operations.h:351-361): re-insert the copies, first vacant slot, in (object, index) order.
 // Sorted by target voxel (stable), one thread replays each voxel's segment.
 template <int S>
-__global__ __launch_bounds__(TPB) void k_move_replay(Dims d, State st, Scratch sc, const uint32_t *__restrict__ skey,
-                                                     const uint32_t *__restrict__ sval) {
+__global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State st, Scratch sc,
+                                                     const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // the table cursor of RingBufferOperations::gaussian_random_calculator_ advanced by three per moved particle
+    long long c = (long long)sc.cur->move_cursor + 3ll * (long long)sc.cnt->n_moved;
+    sc.cur->move_cursor = (int32_t)(c % flt.noise_n);
+  }
   if (sc.cnt->overflow) return;
   const uint32_t total = *sc.mv_total;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,26 +285,23 @@ void launch_moves(const Dims &d, const Frame &f, const Filter &flt, const MoveSe
   const size_t slot_base = (size_t)d.v_begin << d.p_n;
   const uint32_t n_blocks = (uint32_t)move_blocks(d);
   const size_t n_cnt = (size_t)n_obj * n_blocks + 1;
-  hipLaunchKernelGGL(k_move_table, dim3(1), dim3(MAX_MOVE_OBJECTS), 0, s, ms_dev, sc.track_to_obj);
   hipMemsetAsync(sc.mv_cnt + (n_cnt - 1), 0, 4, s);
-  hipLaunchKernelGGL(k_move_count, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, sc.track_to_obj, sc.mv_cnt, n_blocks, n_obj,
+  hipLaunchKernelGGL(k_move_count, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, ms_dev, sc.mv_cnt, n_blocks, n_obj,
                      st.owner_flag);
   exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch, s);
-  hipLaunchKernelGGL(k_move_scatter, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, slot_base, sc.track_to_obj, sc.mv_cnt,
+  hipLaunchKernelGGL(k_move_scatter, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, slot_base, ms_dev, sc.mv_cnt,
                      n_blocks, n_obj, sc.mv_src, sc.cap_move, sc.cnt);
-  hipLaunchKernelGGL(k_move_table_reset, dim3(1), dim3(MAX_MOVE_OBJECTS), 0, s, ms_dev, sc.track_to_obj);
   hipLaunchKernelGGL(k_move_transform, dim3(1024), dim3(TPB), 0, s, d, f, flt, ms_dev, st, sc, sc.mv_cnt, n_blocks, n_obj);
-  hipLaunchKernelGGL(k_move_cursor, dim3(1), dim3(64), 0, s, flt, sc);
   int nbits = d.x_n + d.y_n + d.z_n + 1;
   int which = radix_sort_pairs(sc.bkey_a, sc.bval_a, sc.bkey_b, sc.bval_b, sc.cap_move, nbits, sc.sort_scratch, s, sc.mv_total);
   const uint32_t *skey = which ? sc.bkey_b : sc.bkey_a;
   const uint32_t *sval = which ? sc.bval_b : sc.bval_a;
   dim3 grid(blocks_for(sc.cap_move));
   switch (d.p_n) {
-    case 1: hipLaunchKernelGGL(k_move_replay<2>, grid, dim3(TPB), 0, s, d, st, sc, skey, sval); break;
-    case 2: hipLaunchKernelGGL(k_move_replay<4>, grid, dim3(TPB), 0, s, d, st, sc, skey, sval); break;
-    case 3: hipLaunchKernelGGL(k_move_replay<8>, grid, dim3(TPB), 0, s, d, st, sc, skey, sval); break;
-    default: hipLaunchKernelGGL(k_move_replay<16>, grid, dim3(TPB), 0, s, d, st, sc, skey, sval); break;
+    case 1: hipLaunchKernelGGL(k_move_replay<2>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
+    case 2: hipLaunchKernelGGL(k_move_replay<4>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
+    case 3: hipLaunchKernelGGL(k_move_replay<8>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
+    default: hipLaunchKernelGGL(k_move_replay<16>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
   }
 }
 

@@ -60,34 +60,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const uint32_t *_
   if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-// pass 2: one block turns the tile totals into exclusive offsets (any count, running carry)
-__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_inplace(uint32_t *__restrict__ sums, size_t m) {
-  uint32_t carry = 0;
-  for (size_t start = 0; start < m; start += SCAN_TILE) {
-    size_t base = start + (size_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-      size_t k = base + i;
-      v[i] = k < m ? sums[k] : 0u;
-      s += v[i];
-    }
-    uint32_t total;
-    uint32_t ex = block_exclusive_scan(s, &total) + carry;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-      size_t k = base + i;
-      if (k < m) sums[k] = ex;
-      ex += v[i];
-    }
-    carry += total;
-  }
-}
-
-// pass 3: scan inside each tile and add the tile offset
+// pass 2: every block first reduces the totals of all preceding tiles (a few thousand values at most, read
+// by 256 threads), then scans its own tile.  Two launches per scan instead of three.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                            const uint32_t *__restrict__ sums, size_t n) {
+  uint32_t pre = 0;
+  for (uint32_t t = threadIdx.x; t < blockIdx.x; t += SCAN_THREADS) pre += sums[t];
+  uint32_t tile_offset;
+  block_exclusive_scan(pre, &tile_offset);
   size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS];
   uint32_t s = 0;
@@ -98,7 +78,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const uint32_t *__res
     s += v[i];
   }
   uint32_t total;
-  uint32_t ex = block_exclusive_scan(s, &total) + sums[blockIdx.x];
+  uint32_t ex = block_exclusive_scan(s, &total) + tile_offset;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
     size_t k = base + i;
@@ -112,24 +92,32 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 8;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 2048 keys per block
 constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_BITS = 9;                      // 25-bit voxel keys sort in 3 passes
+constexpr int RS_RADIX = 1 << RS_BITS;          // 512
+constexpr int RS_DPT = RS_RADIX / RS_THREADS;   // digits per thread when a block walks the digit table
 
-// histogram of one 8-bit digit per tile; layout hist[digit * n_tiles + tile] so that one
-// exclusive scan over the whole array yields the global scatter offsets.
+// histogram of one digit per tile; layout hist[digit * n_tiles + tile] so that one exclusive scan over the
+// whole array yields the global scatter offsets.
 __global__ __launch_bounds__(RS_THREADS) void rs_histogram(const uint32_t *__restrict__ keys, uint32_t *__restrict__ hist,
                                                            size_t n, int shift, uint32_t n_tiles,
                                                            const uint32_t *__restrict__ n_dev) {
-  __shared__ uint32_t h[256];
+  __shared__ uint32_t h[RS_RADIX];
   if (n_dev) n = *n_dev < n ? (size_t)*n_dev : n;
-  h[threadIdx.x] = 0;
+#pragma unroll
+  for (int q = 0; q < RS_DPT; ++q) h[threadIdx.x + q * RS_THREADS] = 0;
   __syncthreads();
   size_t base = (size_t)blockIdx.x * RS_TILE;
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; ++r) {
     size_t k = base + (size_t)r * RS_THREADS + threadIdx.x;
-    if (k < n) atomicAdd(&h[(keys[k] >> shift) & 255u], 1u);
+    if (k < n) atomicAdd(&h[(keys[k] >> shift) & (RS_RADIX - 1)], 1u);
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+#pragma unroll
+  for (int q = 0; q < RS_DPT; ++q) {
+    int dg = threadIdx.x + q * RS_THREADS;
+    hist[(size_t)dg * n_tiles + blockIdx.x] = h[dg];
+  }
 }
 
 // stable scatter: elements of a tile are visited in index order (round-major, then thread);
@@ -140,26 +128,32 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint32_t *__restr
                                                          uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                          const uint32_t *__restrict__ offsets, size_t n, int shift,
                                                          uint32_t n_tiles, const uint32_t *__restrict__ n_dev) {
-  __shared__ uint32_t digit_base[256];
+  __shared__ uint32_t digit_base[RS_RADIX];
+  __shared__ uint32_t wave_cnt[RS_WAVES][RS_RADIX];
   if (n_dev) n = *n_dev < n ? (size_t)*n_dev : n;
   if ((size_t)blockIdx.x * RS_TILE >= n) return;
-  __shared__ uint32_t wave_cnt[RS_WAVES][256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  digit_base[threadIdx.x] = offsets[(size_t)threadIdx.x * n_tiles + blockIdx.x];
+#pragma unroll
+  for (int q = 0; q < RS_DPT; ++q) {
+    int dg = threadIdx.x + q * RS_THREADS;
+    digit_base[dg] = offsets[(size_t)dg * n_tiles + blockIdx.x];
+  }
   size_t base = (size_t)blockIdx.x * RS_TILE;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int r = 0; r < RS_ITEMS; ++r) {
 #pragma unroll
-    for (int w = 0; w < RS_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+    for (int w = 0; w < RS_WAVES; ++w)
+#pragma unroll
+      for (int q = 0; q < RS_DPT; ++q) wave_cnt[w][threadIdx.x + q * RS_THREADS] = 0;
     __syncthreads();
     size_t k = base + (size_t)r * RS_THREADS + threadIdx.x;
     bool valid = k < n;
     uint32_t key = valid ? keys_in[k] : 0u;
     uint32_t val = valid ? vals_in[k] : 0u;
-    uint32_t digit = (key >> shift) & 255u;
+    uint32_t digit = (key >> shift) & (RS_RADIX - 1);
     uint64_t peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < RS_BITS; ++b) {
       bool bit = (digit >> b) & 1u;
       uint64_t m = __ballot(bit);
       peers &= bit ? m : ~m;
@@ -176,11 +170,13 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint32_t *__restr
       vals_out[off] = val;
     }
     __syncthreads();
-    {
+#pragma unroll
+    for (int q = 0; q < RS_DPT; ++q) {
+      int dg = threadIdx.x + q * RS_THREADS;
       uint32_t add = 0;
 #pragma unroll
-      for (int w = 0; w < RS_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
-      digit_base[threadIdx.x] += add;
+      for (int w = 0; w < RS_WAVES; ++w) add += wave_cnt[w][dg];
+      digit_base[dg] += add;
     }
     __syncthreads();
   }
@@ -194,13 +190,12 @@ void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *s
   if (n == 0) return;
   size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, scratch, n);
-  hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(SCAN_THREADS), 0, s, scratch, tiles);
   hipLaunchKernelGGL(scan_tiles, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, out, scratch, n);
 }
 
 size_t sort_scratch_elems(size_t n) {
   size_t tiles = (n + RS_TILE - 1) / RS_TILE;
-  size_t hist = 256 * tiles;
+  size_t hist = (size_t)RS_RADIX * tiles;
   return hist + scan_scratch_elems(hist);
 }
 
@@ -208,11 +203,11 @@ int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint3
                      uint32_t *scratch, hipStream_t s, const uint32_t *n_dev) {
   if (n == 0) return 0;
   size_t tiles = (n + RS_TILE - 1) / RS_TILE;
-  size_t hist_n = 256 * tiles;
+  size_t hist_n = (size_t)RS_RADIX * tiles;
   uint32_t *hist = scratch;
   uint32_t *scan_scratch = scratch + hist_n;
   int which = 0;
-  for (int shift = 0; shift < nbits; shift += 8) {
+  for (int shift = 0; shift < nbits; shift += RS_BITS) {
     uint32_t *kin = which ? keys_b : keys_a, *vin = which ? vals_b : vals_a;
     uint32_t *kout = which ? keys_a : keys_b, *vout = which ? vals_a : vals_b;
     hipLaunchKernelGGL(rs_histogram, dim3((unsigned)tiles), dim3(RS_THREADS), 0, s, kin, hist, n, shift, (uint32_t)tiles, n_dev);

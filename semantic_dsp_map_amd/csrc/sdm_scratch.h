@@ -18,6 +18,7 @@ struct Scratch {
   // per-line bitmaps over (y,z), wy 64-bit words per z row: non-empty, overlaps next line in y / z, reached
   uint64_t *line_ne = nullptr, *line_ey = nullptr, *line_ez = nullptr, *line_reach = nullptr;
   int wy = 0;
+  int force_generic = 0;
   // inputs of the current frame (device)
   const float *depth = nullptr;
   const sdm_labeled_point *cloud = nullptr;
@@ -51,9 +52,10 @@ struct Scratch {
   Cursors *cur = nullptr;
 };
 
+void launch_frame_begin(const Dims &d, const Scratch &sc, hipStream_t s);
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s);
 void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int force_generic, hipStream_t s);
-void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, hipStream_t s);
+void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s);
 void launch_weight(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
 void launch_births(const Dims &d, const Frame &f, const Filter &flt, const BirthOrder &bo, const State &st,
