@@ -33,6 +33,9 @@ class HipEngine:
         self.map.update_begin(depth_ptr, cloud_ptr, pos, q, moves, remove_tracks, on_device=on_device)
         return self.part
 
+    def update(self, depth_ptr, cloud_ptr, pos, q, moves=None, remove_tracks=None, on_device=True):
+        self.map.update(depth_ptr, cloud_ptr, pos, q, moves, remove_tracks, on_device=on_device)
+
     def finish(self, gathered, n_parts):
         self.map.update_finish(gathered.data_ptr() if n_parts > 1 else None, n_parts)
 
@@ -49,6 +52,8 @@ class ShardedDriver:
             raise ValueError("world > 1 needs a torch.distributed module")
 
     def update(self, *frame, **kw):
+        if self.world == 1 and hasattr(self.engine, "update"):
+            return self.engine.update(*frame, **kw)   # no exchange: the fused single-GPU frame
         part = self.engine.begin(*frame, **kw)
         if self.world > 1:
             # all_gather_into_tensor: rank r's image lands at [r*HW, (r+1)*HW) = slab order
