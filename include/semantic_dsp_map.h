@@ -1,0 +1,431 @@
+/**
+ * semantic_dsp_map.h — the reference's `class SemanticDSPMap` (public API verbatim, reference
+ * include/semantic_dsp_map.h:21-251) on top of libsdm_hip (include/sdm.h).
+ *
+ * Drop-in for the particle-update path only: everything the reference does inside
+ * subObjectLevelUpdate (semantic_dsp_map.h:576-955) runs on the MI355X behind sdm_update(); what stays on the
+ * host is what the reference also does outside that function:
+ *   - track-id reallocation (semantic_dsp_map.h:179-186),
+ *   - the object layer (objectLevelUpdate, :306-566): NOT re-implemented here.  Plug the reference's own
+ *     ObjectSet logic in through SdmObjectLayer (INTEGRATION.md shows the 20-line glue); without one the map runs
+ *     like the reference with g_consider_instance == false,
+ *   - generateLabeledPointCloud (utils/pointcloud_tools.h:88-310), restated below for the non-BOOST, non-ZED
+ *     presets (the ZED2 bounding-box filter and the BOOST resize are not ported yet),
+ *   - colouring of the emitted cloud (semantic_dsp_map.h:1274-1331).  Not ported: the HSV "V x 0.7" dimming of
+ *     voxels outside the view frustum (:1333-1351, one OpenCV cvtColor round trip per voxel in the reference).
+ *
+ * Compile-time grid/camera constants of settings/settings.h become SdmGridPreset; pick one with
+ * setGridPreset() before the first update() (default: the reference's SETTING 2, VIRTUAL_KITTI2).
+ *
+ * Needs Eigen3, OpenCV and PCL headers like the reference does.  They are not available in the build image of this
+ * repository, where this file is only compile-checked against minimal stand-in headers (tests/mock_includes).
+ */
+#pragma once
+
+#include <Eigen/Dense>
+#include <opencv2/opencv.hpp>
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <iostream>
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "sdm.h"
+
+#ifndef SDM_HAVE_REFERENCE_TRACKING_TYPES
+/// utils/data_base.h:25-31
+struct BBox2D {
+  int x1, y1, x2, y2;
+};
+/// utils/tracking_result_handler.h:15-26 (the mask_kpts_msgs input format, docs/custom_files.md:16-45)
+struct MaskKpts {
+  int track_id;
+  std::string label;
+  std::vector<Eigen::Vector3d> kpts_current;
+  std::vector<Eigen::Vector3d> kpts_previous;
+  cv::Mat mask;
+  BBox2D bbox;
+};
+#endif
+
+/// settings/settings.h:32-141 as data
+struct SdmGridPreset {
+  int x_n, y_n, z_n, p_n;
+  float voxel_size, fx, fy, cx, cy;
+  int width, height;
+  float depth_min, depth_max;
+  int window_half;
+  bool consider_instance;
+  static SdmGridPreset Kitti360() { return {8, 8, 8, 3, 0.15f, 552.554261f, 552.554261f, 682.049453f, 238.769549f, 1408, 376, 0.3f, 30.f, 5, false}; }
+  static SdmGridPreset Coda() { return {8, 8, 7, 2, 0.15f, 569.8286f, 565.4818f, 439.2660f, 360.5810f, 960, 540, 0.3f, 10.f, 5, true}; }
+  static SdmGridPreset VirtualKitti2() { return {8, 7, 8, 3, 0.2f, 725.0087f, 725.0087f, 620.5f, 187.f, 1242, 375, 0.3f, 30.f, 5, true}; }
+};
+
+/// What the particle layer needs from the object layer each frame (semantic_dsp_map.h:588-736).
+struct SdmObjectLayer {
+  virtual ~SdmObjectLayer() {}
+  /// objectLevelUpdate (semantic_dsp_map.h:306-566)
+  virtual void update(const std::vector<MaskKpts> &ins_seg_result, const Eigen::Vector3d &camera_position,
+                      const Eigen::Quaterniond &camera_orientation, double time_stamp) = 0;
+  /// objects to move this frame, in a deterministic order (ascending track id), and objects to wipe
+  virtual void collect(uint32_t global_time_stamp, int max_obersevation_lost_time, std::vector<sdm_object_move> &moves,
+                       std::vector<int32_t> &remove_tracks) = 0;
+  virtual void clear() = 0;
+};
+
+class SemanticDSPMap {
+ public:
+  /// semantic_dsp_map.h:25-67
+  SemanticDSPMap()
+      : map_(nullptr), object_layer_(nullptr), preset_(SdmGridPreset::VirtualKitti2()), device_(0),
+        global_time_stamp_(0), visualize_with_zero_center_(false), if_out_evaluation_format_(false) {
+    params_.detection_probability = 0.95f;
+    params_.noise_number = 0.1f;
+    params_.nb_ptc_num_per_point = 3;
+    params_.occupancy_threshold = 0.2f;
+    params_.max_obersevation_lost_time = 5;
+    params_.forgetting_rate = 1.0f;
+    params_.max_forget_count = 5;
+    params_.match_score_threshold = 0.3f;
+    params_.id_transition_probability = 0.1f;
+    params_.if_consider_depth_noise = 0;
+    params_.if_use_independent_filter = 0;
+    params_.depth_noise_first_order = 0.0f;
+    params_.depth_noise_zero_order = 0.1f;
+    for (int i = 0; i < 256; ++i) color_map_int_256_.push_back(i);
+    // semantic_dsp_map.h:45-48 shuffles with an unseeded generator; a fixed LCG permutation keeps runs reproducible
+    uint32_t s = 12345u;
+    for (int i = 255; i > 0; --i) {
+      s = s * 1664525u + 1013904223u;
+      std::swap(color_map_int_256_[i], color_map_int_256_[(s >> 8) % (i + 1)]);
+    }
+    for (int i = 0; i < 256; ++i) {  // jet map, semantic_dsp_map.h:50-63
+      Eigen::Vector3i c;
+      if (i < 64) c << 0, 0, i * 4;
+      else if (i < 128) c << 0, (i - 64) * 4, 255;
+      else if (i < 192) c << (i - 128) * 4, 255, 255 - (i - 128) * 4;
+      else c << 255, 255 - (i - 192) * 4, 0;
+      color_map_jet_256_.push_back(c);
+    }
+    defaultLabelTables();
+  }
+  ~SemanticDSPMap() {
+    if (map_) sdm_destroy(map_);
+  }
+  SemanticDSPMap(const SemanticDSPMap &) = delete;
+  SemanticDSPMap &operator=(const SemanticDSPMap &) = delete;
+
+  // ---- additions (the reference fixes these at compile time / inside the class) ----
+  void setGridPreset(const SdmGridPreset &p) { preset_ = p; }
+  void setDevice(int hip_device) { device_ = hip_device; }
+  void setObjectLayer(SdmObjectLayer *layer) { object_layer_ = layer; }
+  /// label tables of utils/object_info_handler.h:28-91 (CSV): label name -> label id, static label -> instance id
+  void setLabelTables(const std::map<std::string, int> &label_ids, const std::map<std::string, int> &static_instance_ids) {
+    label_id_.clear();
+    static_instance_to_label_.clear();
+    for (auto &kv : label_ids) label_id_[kv.first] = kv.second;
+    int min_static = 65536;
+    for (auto &kv : static_instance_ids) {
+      static_instance_to_label_[kv.second] = label_id_[kv.first];
+      min_static = std::min(min_static, kv.second);
+    }
+    max_movable_track_ = min_static - 1;  // object_info_handler.h:84
+  }
+
+  // ---- the reference's public interface ----
+  /// semantic_dsp_map.h:74-81
+  void clear() {
+    if (map_) check(sdm_clear(map_), "sdm_clear");
+    if (object_layer_) object_layer_->clear();
+    global_time_stamp_ = 0;
+  }
+  /// semantic_dsp_map.h:85-88 (template matching is dead code in the shipped node)
+  void setTemplatePath(std::string) {}
+  /// semantic_dsp_map.h:101-115
+  void setMapParameters(float detection_probability, float noise_number, int nb_ptc_num_per_point, float occupancy_threshold,
+                        int max_obersevation_lost_time, float forgetting_rate = 1.f, int max_forget_count = 5,
+                        float match_score_threshold = 0.5, float id_transition_probability = 0.1) {
+    params_.detection_probability = detection_probability;
+    params_.noise_number = noise_number;
+    params_.nb_ptc_num_per_point = nb_ptc_num_per_point;
+    params_.occupancy_threshold = occupancy_threshold;
+    params_.max_obersevation_lost_time = max_obersevation_lost_time;
+    params_.forgetting_rate = forgetting_rate;
+    params_.max_forget_count = max_forget_count;
+    params_.match_score_threshold = match_score_threshold;
+    params_.id_transition_probability = id_transition_probability;
+    std::cout << "max_obersevation_lost_time_ = " << max_obersevation_lost_time << std::endl;
+    std::cout << "id_transition_probability_ = " << id_transition_probability << std::endl;
+    pushParams();
+  }
+  /// semantic_dsp_map.h:121-125
+  void setMapOptions(bool if_consider_depth_noise, bool if_use_independent_filter) {
+    params_.if_consider_depth_noise = if_consider_depth_noise ? 1 : 0;
+    params_.if_use_independent_filter = if_use_independent_filter ? 1 : 0;
+    pushParams();
+  }
+  /// semantic_dsp_map.h:130-134
+  void setVisualizeOptions(bool visualize_with_zero_center, bool if_out_evaluation_format) {
+    visualize_with_zero_center_ = visualize_with_zero_center;
+    if_out_evaluation_format_ = if_out_evaluation_format;
+  }
+  /// semantic_dsp_map.h:142-148 (consumed by the object layer)
+  void setBeyesianMovementParameters(double distance_threshold, double probability_threshold, double increment, double decrement) {
+    beyesian_[0] = distance_threshold;
+    beyesian_[1] = probability_threshold;
+    beyesian_[2] = increment;
+    beyesian_[3] = decrement;
+  }
+  const double *beyesianMovementParameters() const { return beyesian_; }
+  /// semantic_dsp_map.h:153-156
+  void setOccupancyThreshold(float threshold) {
+    params_.occupancy_threshold = threshold;
+    pushParams();
+  }
+  /// semantic_dsp_map.h:161-166
+  void setDepthNoiseModelParameters(float first_order, float zero_order) {
+    params_.depth_noise_first_order = first_order;
+    params_.depth_noise_zero_order = zero_order;
+    std::cout << "Noise model is " << first_order << " * distance + " << zero_order << std::endl;
+  }
+
+  /// semantic_dsp_map.h:170-251.  Like the reference: no return code, diagnostics on stderr, output clouds are
+  /// appended to and neither cleared nor given width/height.
+  void update(cv::Mat &depth_value_mat, std::vector<MaskKpts> &ins_seg_result, Eigen::Vector3d &camera_position,
+              Eigen::Quaterniond &camera_orientation, pcl::PointCloud<pcl::PointXYZRGB>::Ptr &occupied_point_cloud,
+              pcl::PointCloud<pcl::PointXYZRGB>::Ptr &freespace_point_cloud, bool if_get_freespace = false,
+              double time_stamp_double = 0.0) {
+    ensureMap();
+    global_time_stamp_ += 1;
+    for (size_t i = 0; i < ins_seg_result.size(); ++i) {  // :179-186
+      if (ins_seg_result[i].label != "static" && ins_seg_result[i].track_id > max_movable_track_) {
+        std::cout << "Reach the maximum movable object instance id. ID reallocated." << std::endl;
+        ins_seg_result[i].track_id = ins_seg_result[i].track_id % max_movable_track_;
+      }
+    }
+    std::vector<sdm_object_move> moves;
+    std::vector<int32_t> removals;
+    if (preset_.consider_instance && object_layer_) {  // :189-191
+      object_layer_->update(ins_seg_result, camera_position, camera_orientation, time_stamp_double);
+      object_layer_->collect(global_time_stamp_, params_.max_obersevation_lost_time, moves, removals);
+    }
+    if (generateLabeledPointCloud(depth_value_mat, ins_seg_result, camera_position, camera_orientation) != 0) return;
+
+    const Eigen::Vector3f pf = camera_position.cast<float>();  // :584
+    const float cam_pos[3] = {pf.x(), pf.y(), pf.z()};
+    const Eigen::Quaternionf qf = camera_orientation.cast<float>();  // :745
+    const float cam_q[4] = {qf.w(), qf.x(), qf.y(), qf.z()};
+    if (!check(sdm_update(map_, depth_.data(), cloud_.data(), cam_pos, cam_q, moves.empty() ? nullptr : moves.data(),
+                          (int32_t)moves.size(), removals.empty() ? nullptr : removals.data(), (int32_t)removals.size(), 0,
+                          SDM_STAGE_ALL),
+               "sdm_update"))
+      return;
+    emit(occupied_point_cloud, false, cam_pos);
+    if (if_get_freespace) emit(freespace_point_cloud, true, cam_pos);
+  }
+
+  sdm_map *handle() { return map_; }
+
+ private:
+  sdm_map *map_;
+  SdmObjectLayer *object_layer_;
+  SdmGridPreset preset_;
+  sdm_params params_;
+  int device_;
+  uint32_t global_time_stamp_;
+  bool visualize_with_zero_center_, if_out_evaluation_format_;
+  double beyesian_[4] = {0.1, 0.69, 0.1, 0.15};
+  int max_movable_track_ = 65523;  // utils/data_base.h:196
+  std::vector<int> color_map_int_256_;
+  std::vector<Eigen::Vector3i> color_map_jet_256_;
+  std::unordered_map<std::string, int> label_id_;          // g_label_id_map_default
+  std::unordered_map<int, int> static_instance_to_label_;   // g_instance_id_to_label_map_default -> label id
+  std::unordered_map<int, cv::Vec3b> label_color_;          // g_label_color_map_default (BGR)
+  std::vector<float> depth_;
+  std::vector<sdm_labeled_point> cloud_;
+  std::vector<sdm_point> points_;
+
+  bool check(sdm_status s, const char *what) {
+    if (s == SDM_OK) return true;
+    std::cerr << what << " failed: " << sdm_last_error() << std::endl;  // the reference reports on stdout/stderr and carries on
+    return false;
+  }
+  void pushParams() {
+    if (map_) check(sdm_set_params(map_, &params_), "sdm_set_params");
+  }
+  void ensureMap() {
+    if (map_) return;
+    sdm_config c{};
+    c.x_n = preset_.x_n;
+    c.y_n = preset_.y_n;
+    c.z_n = preset_.z_n;
+    c.p_n = preset_.p_n;
+    c.voxel_size = preset_.voxel_size;
+    c.fx = preset_.fx;
+    c.fy = preset_.fy;
+    c.cx = preset_.cx;
+    c.cy = preset_.cy;
+    c.width = preset_.width;
+    c.height = preset_.height;
+    c.depth_min = preset_.depth_min;
+    c.depth_max = preset_.depth_max;
+    c.window_half = preset_.window_half;
+    c.max_movable_track = max_movable_track_;
+    c.device = device_;
+    c.shard_rank = 0;
+    c.shard_count = 1;
+    if (sdm_create(&c, &map_) != SDM_OK) throw std::runtime_error(std::string("sdm_create: ") + sdm_last_error());
+    // prediction_stddev_ = 0.05 table of 1,000,000 draws (semantic_dsp_map.h:40,66; basic_algorithms.h:394-402)
+    check(sdm_generate_noise_table(map_, 20250217ull, 1000000, 0.05f), "sdm_generate_noise_table");
+    pushParams();
+    depth_.resize((size_t)c.width * c.height);
+    cloud_.resize((size_t)c.width * c.height);
+  }
+
+  void defaultLabelTables() {  // utils/data_base.h:108-232
+    const char *names[] = {"Background", "Terrain", "Sky", "Tree", "Vegetation", "Building", "Road", "GuardRail",
+                           "TrafficSign", "TrafficLight", "Pole", "Misc", "Truck", "Car", "Person"};
+    const int ids[] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+    for (int i = 0; i < 15; ++i) label_id_[names[i]] = ids[i];
+    for (int i = 0; i < 12; ++i) static_instance_to_label_[65535 - i] = ids[i];
+    const int bgr[15][4] = {{0, 0, 0, 0},      {2, 200, 0, 210},  {3, 255, 200, 90}, {4, 0, 199, 0},    {5, 0, 240, 90},
+                            {6, 140, 140, 140}, {7, 100, 60, 100}, {8, 255, 100, 250}, {9, 0, 255, 255},  {10, 0, 200, 200},
+                            {11, 0, 130, 255},  {12, 80, 80, 80},  {13, 60, 60, 160},  {14, 80, 127, 255}, {15, 139, 139, 0}};
+    for (auto &c : bgr) label_color_[c[0]] = cv::Vec3b((uchar)c[1], (uchar)c[2], (uchar)c[3]);
+    max_movable_track_ = 65523;
+  }
+
+  /// PointCloudTools::generateLabeledPointCloud (utils/pointcloud_tools.h:88-310), general (non-BOOST, non-ZED) path.
+  int generateLabeledPointCloud(const cv::Mat &depth, const std::vector<MaskKpts> &seg, const Eigen::Vector3d &cam_p,
+                                const Eigen::Quaterniond &cam_q) {
+    if (depth.empty()) {
+      std::cerr << "Error: depth image is empty." << std::endl;
+      return -1;
+    }
+    const int W = preset_.width, H = preset_.height;
+    if (depth.cols != W || depth.rows != H) {
+      std::cerr << "Error: depth image size does not match the grid preset." << std::endl;
+      return -1;
+    }
+    const Eigen::Matrix3d R = cam_q.toRotationMatrix();
+    Eigen::Matrix3d K;
+    K << preset_.fx, 0, preset_.cx, 0, preset_.fy, preset_.cy, 0, 0, 1;
+    const Eigen::Matrix3d Kinv = K.inverse();
+    std::vector<uint16_t> track_mask((size_t)W * H, 65535);  // :147-156
+    std::unordered_map<int, int> track_to_label;
+    for (const auto &s : seg) {  // static mask first, :121-143
+      if (s.label != "static") continue;
+      for (int j = 0; j < s.mask.rows && j < H; ++j)
+        for (int k = 0; k < s.mask.cols && k < W; ++k) {
+          const int pixel_label = (int)s.mask.at<uchar>(j, k) + 1;  // :137-138
+          int inst = 65535;
+          for (const auto &kv : static_instance_to_label_)
+            if (kv.second == pixel_label) inst = kv.first;
+          track_mask[(size_t)j * W + k] = (uint16_t)inst;
+        }
+      break;
+    }
+    if (preset_.consider_instance) {  // :163-213
+      for (const auto &s : seg) {
+        if (s.label == "static") continue;
+        auto it = label_id_.find(s.label);
+        track_to_label[s.track_id] = it == label_id_.end() ? 0 : it->second;
+        for (int j = 0; j < s.mask.rows && j < H; ++j)
+          for (int k = 0; k < s.mask.cols && k < W; ++k)
+            if (s.mask.at<uchar>(j, k) > 0) track_mask[(size_t)j * W + k] = (uint16_t)s.track_id;
+      }
+    }
+    for (int i = 0; i < H; ++i)
+      for (int j = 0; j < W; ++j) {  // :218-304
+        const size_t p = (size_t)i * W + j;
+        const float d = depth.at<float>(i, j);
+        depth_[p] = d;
+        sdm_labeled_point &o = cloud_[p];
+        if (std::isnan(d) || d < preset_.depth_min || d > preset_.depth_max) {
+          o = sdm_labeled_point{0.f, 0.f, 0.f, params_.if_consider_depth_noise ? params_.depth_noise_zero_order : 0.1f, 0, 0, 0};
+          continue;
+        }
+        Eigen::Vector3d pt = Kinv * Eigen::Vector3d(j, i, 1) * (double)d;  // :243
+        pt = R * pt + cam_p;                                             // :247
+        const uint16_t inst = track_mask[p];
+        int label = 0;
+        if ((int)inst > max_movable_track_) {  // :277-283
+          auto it = static_instance_to_label_.find(inst);
+          label = it == static_instance_to_label_.end() ? 0 : it->second;
+        } else {
+          label = track_to_label[inst];
+        }
+        o.x = (float)pt.x();
+        o.y = (float)pt.y();
+        o.z = (float)pt.z();
+        o.sigma = params_.if_consider_depth_noise ? params_.depth_noise_zero_order + params_.depth_noise_first_order * d : 0.1f;
+        o.track_id = inst;
+        o.label_id = (uint8_t)label;
+        o.is_valid = 1;
+      }
+    return 0;
+  }
+
+  /// getOccupancyResult output side (semantic_dsp_map.h:1258-1376): positions come compacted from the GPU,
+  /// colouring follows the reference's rules.
+  void emit(pcl::PointCloud<pcl::PointXYZRGB>::Ptr &out, bool free_space, const float cam_pos[3]) {
+    size_t n = 0;
+    const size_t cap = (size_t)1 << (preset_.x_n + preset_.y_n + preset_.z_n);
+    if (points_.size() < 1024) points_.resize(1024);
+    auto get = free_space ? sdm_get_freespace : sdm_get_occupied;
+    if (!check(get(map_, points_.data(), points_.size(), &n, visualize_with_zero_center_ ? 1 : 0), "sdm_get_occupied")) return;
+    if (n > points_.size()) {
+      points_.resize(std::min(n, cap));
+      if (!check(get(map_, points_.data(), points_.size(), &n, visualize_with_zero_center_ ? 1 : 0), "sdm_get_occupied")) return;
+    }
+    const int background = label_id_["Background"];
+    for (size_t k = 0; k < n && k < points_.size(); ++k) {
+      const sdm_point &v = points_[k];
+      pcl::PointXYZRGB pt;
+      pt.x = v.x;
+      pt.y = v.y;
+      pt.z = v.z;
+      if (free_space) {  // :1371-1373
+        pt.r = 0;
+        pt.g = 255;
+        pt.b = 0;
+        out->points.push_back(pt);
+        continue;
+      }
+      if (v.occ == 1) {
+        if (v.label == background) {  // :1277-1294
+          const int ci = std::min(std::max(static_cast<int>((-pt.z + 2.f) * 51.2f), 0), 255);
+          pt.r = (uint8_t)color_map_jet_256_[ci](0);
+          pt.g = (uint8_t)color_map_jet_256_[ci](1);
+          pt.b = (uint8_t)color_map_jet_256_[ci](2);
+          if (if_out_evaluation_format_) pt.r = pt.g = pt.b = 0;
+        } else if ((int)v.track > max_movable_track_ || !preset_.consider_instance) {  // :1297-1309
+          const cv::Vec3b c = label_color_.count(v.label) ? label_color_[v.label] : cv::Vec3b(0, 0, 0);
+          pt.r = c[2];
+          pt.g = c[1];
+          pt.b = c[0];
+        } else if (if_out_evaluation_format_) {  // :1311-1316
+          pt.r = v.label;
+          pt.g = (uint8_t)(v.track >> 8);
+          pt.b = (uint8_t)(v.track & 0xFF);
+        } else {  // :1317-1319 (the reference indexes a 256-entry table with the 16-bit track id; clamped here)
+          pt.r = 160;
+          pt.g = (uint8_t)color_map_int_256_[v.track & 0xFF];
+          pt.b = (uint8_t)color_map_int_256_[v.label];
+        }
+      } else {  // guessed occupied, :1325-1331
+        pt.r = pt.g = pt.b = 255;
+      }
+      (void)cam_pos;
+      out->points.push_back(pt);
+    }
+  }
+};

@@ -1,0 +1,56 @@
+// Drives include/semantic_dsp_map.h (the reference's class API) the way src/mapping.cpp does: setters, then
+// update(depth, masks, pose, clouds) per frame.  Built against tests/mock_includes (no Eigen/OpenCV/PCL in the image)
+// and linked with libsdm_hip.so.  Exit code 0 = the occupied cloud of a flat wall came back as expected.
+#include <cstdio>
+
+#include "semantic_dsp_map.h"
+
+int main(int argc, char **argv) {
+  const bool run = argc > 1;  // without an argument: construction + setters only (CPU box: there is no device)
+  SemanticDSPMap map;
+  SdmGridPreset p = SdmGridPreset::VirtualKitti2();
+  p.x_n = p.y_n = p.z_n = 5;
+  p.voxel_size = 0.4f;
+  p.width = 128;
+  p.height = 80;
+  p.fx = p.fy = 80.f;
+  p.cx = 64.f;
+  p.cy = 40.f;
+  p.depth_max = 12.f;
+  p.window_half = 3;
+  map.setGridPreset(p);
+  map.setMapParameters(0.98f, 0.001f, 1, 0.5f, 5, 1.0f, 3, 0.6f, 0.2f);  // cfg/options_virtual_kitti2.yaml
+  map.setMapOptions(true, false);
+  map.setVisualizeOptions(false, true);
+  map.setBeyesianMovementParameters(0.1, 0.75, 0.2, 0.1);
+  map.setDepthNoiseModelParameters(0.01f, 0.2f);
+  if (!run) {
+    std::printf("adapter constructed\n");
+    return 0;
+  }
+  cv::Mat depth(p.height, p.width, 4);
+  for (int i = 0; i < p.height; ++i)
+    for (int j = 0; j < p.width; ++j) depth.at<float>(i, j) = 3.0f;  // a wall 3 m ahead
+  MaskKpts st;
+  st.track_id = 65535;
+  st.label = "static";
+  st.mask = cv::Mat(p.height, p.width, 1);
+  for (int i = 0; i < p.height; ++i)
+    for (int j = 0; j < p.width; ++j) st.mask.at<uchar>(i, j) = 5;  // pixel value + 1 = label 6 (Building)
+  std::vector<MaskKpts> seg{st};
+  Eigen::Vector3d pos(0, 0, 0);
+  Eigen::Quaterniond q(1, 0, 0, 0);
+  size_t n_occ = 0;
+  for (int t = 0; t < 4; ++t) {
+    pcl::PointCloud<pcl::PointXYZRGB>::Ptr occ(new pcl::PointCloud<pcl::PointXYZRGB>), fr(new pcl::PointCloud<pcl::PointXYZRGB>);
+    map.update(depth, seg, pos, q, occ, fr, true, 0.1 * t);
+    n_occ = occ->size();
+    std::printf("frame %d: %zu occupied, %zu free voxels\n", t, occ->size(), fr->size());
+    for (auto &pt : occ->points)
+      if (pt.z < 2.7f || pt.z > 3.5f) {
+        std::printf("occupied voxel away from the wall: z = %f\n", pt.z);
+        return 2;
+      }
+  }
+  return n_occ > 50 ? 0 : 1;
+}

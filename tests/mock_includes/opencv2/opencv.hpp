@@ -1,0 +1,22 @@
+// Minimal stand-in for cv::Mat / cv::Vec3b as used by include/semantic_dsp_map.h (TEST INFRASTRUCTURE, see Eigen/Dense).
+#pragma once
+#include <cstdint>
+#include <vector>
+typedef unsigned char uchar;
+namespace cv {
+struct Vec3b {
+  uchar v[3];
+  Vec3b() : v{0, 0, 0} {}
+  Vec3b(uchar a, uchar b, uchar c) : v{a, b, c} {}
+  uchar operator[](int i) const { return v[i]; }
+};
+struct Mat {
+  int rows = 0, cols = 0, elem = 1;
+  std::vector<unsigned char> buf;
+  Mat() {}
+  Mat(int r, int c, int elem_size) : rows(r), cols(c), elem(elem_size), buf((size_t)r * c * elem_size) {}
+  bool empty() const { return rows == 0 || cols == 0; }
+  template <typename T> T &at(int r, int c) { return *reinterpret_cast<T *>(&buf[((size_t)r * cols + c) * sizeof(T)]); }
+  template <typename T> const T &at(int r, int c) const { return *reinterpret_cast<const T *>(&buf[((size_t)r * cols + c) * sizeof(T)]); }
+};
+}  // namespace cv
