@@ -197,6 +197,23 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
                             uint32_t flags, int32_t stop_after, const float **ck_part_dev);
 sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_parts, uint32_t flags,
                              int32_t stop_after);
+/* sdm_update_begin itself in three steps, for sharded maps whose moving objects cross slab borders
+ * (moveParticlesInSetsByTransformations, mc_ring/operations.h:321-362, needs the other shards twice):
+ *   sdm_frame_start   -> all-gather of the per-object member counts (SDM_HALO_OBJ int32 per shard)
+ *   sdm_frame_moves   -> all-gather of the export buffers (copies whose target voxel lies in another slab)
+ *   sdm_frame_predict -> all-gather of the partial ck images -> sdm_update_finish
+ * The exchange buffers are device memory owned by the caller and registered once with sdm_set_halo_buffers. */
+#define SDM_HALO_OBJ 64
+#define SDM_HALO_RECORD_BYTES 36
+#define SDM_HALO_HEADER_BYTES 16
+sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_point *cloud,
+                           const float cam_pos[3], const float cam_q[4],
+                           const sdm_object_move *moves, int32_t n_moves,
+                           const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after);
+sdm_status sdm_frame_moves(sdm_map *m);
+sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev);
+sdm_status sdm_set_halo_buffers(sdm_map *m, int32_t *counts_local, const int32_t *counts_all, void *send,
+                                const void *recv_all, int32_t cap_records);
 /* the HIP stream (hipStream_t) all work of this map is enqueued on; sdm_set_stream moves the map onto a
  * caller-owned stream (e.g. the one RCCL collectives are issued on, so that no host sync is needed between
  * sdm_update_begin, the all-gather and sdm_update_finish); NULL restores the map's own stream. */

@@ -95,6 +95,10 @@ def load_library():
         "sdm_update": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32],
         "sdm_update_begin": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32, C.POINTER(vp)],
         "sdm_update_finish": [vp, vp, i32, u32, i32],
+        "sdm_frame_start": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32],
+        "sdm_frame_moves": [vp],
+        "sdm_frame_predict": [vp, C.POINTER(vp)],
+        "sdm_set_halo_buffers": [vp, vp, vp, vp, vp, i32],
         "sdm_stream": [vp, C.POINTER(vp)],
         "sdm_set_stream": [vp, vp],
         "sdm_set_ck_buffer": [vp, vp],
@@ -239,6 +243,24 @@ class SdmMap:
         ck = C.c_void_p()
         _check(self.L, self.L.sdm_update_begin(self.h, *args, fl, st, C.byref(ck)), "sdm_update_begin")
         return ck.value
+
+    def frame_start(self, depth, cloud, cam_pos, cam_q, moves=None, remove_tracks=None, stop_after="all", on_device=False, flags=0):
+        keep, args = self._frame_args(depth, cloud, cam_pos, cam_q, moves, remove_tracks, on_device)
+        fl = flags | (INPUT_ON_DEVICE if on_device else 0)
+        st = STAGES[stop_after] if isinstance(stop_after, str) else stop_after
+        _check(self.L, self.L.sdm_frame_start(self.h, *args, fl, st), "sdm_frame_start")
+
+    def frame_moves(self):
+        _check(self.L, self.L.sdm_frame_moves(self.h), "sdm_frame_moves")
+
+    def frame_predict(self):
+        ck = C.c_void_p()
+        _check(self.L, self.L.sdm_frame_predict(self.h, C.byref(ck)), "sdm_frame_predict")
+        return ck.value
+
+    def set_halo_buffers(self, counts_local, counts_all, send, recv_all, cap_records):
+        _check(self.L, self.L.sdm_set_halo_buffers(self.h, _ptr(int(counts_local)), _ptr(int(counts_all)), _ptr(int(send)),
+                                                    _ptr(int(recv_all)), cap_records), "sdm_set_halo_buffers")
 
     def update_finish(self, ck_parts_dev=None, n_parts=1, stop_after="all", flags=0):
         st = STAGES[stop_after] if isinstance(stop_after, str) else stop_after

@@ -59,6 +59,12 @@ struct sdm_map {
   hipStream_t own_stream = nullptr;
   float *ck_user = nullptr;
   bool fused_ck = false;  // single-GPU sdm_update: pass 1 writes ck+kappa directly
+  int32_t stop_after = 0;
+  uint32_t frame_flags = 0;
+  int n_moves = 0, n_remove = 0;
+  int32_t *d_counts_local = nullptr;
+  int32_t *counts_local_user = nullptr;
+  const int32_t *counts_all_user = nullptr;
   int device = 0;
 
   // host ring-buffer state (mc_ring/buffer.h:97-120)
@@ -484,6 +490,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   sc.cap_move = (uint32_t)std::min<size_t>(n_slots, (size_t)1 << 20);
   A(sc.mv_src, sc.cap_move);
   A(sc.mv_total, 4);
+  A(sc.mv_ebase, MAX_MOVE_OBJECTS);
+  A(m->d_counts_local, HALO_OBJ);
   const size_t mv_cnt_n = (size_t)MAX_MOVE_OBJECTS * move_blocks(d) + 1;
   A(sc.mv_cnt, mv_cnt_n);
   A(sc.mv_pos, sc.cap_move);
@@ -604,12 +612,18 @@ sdm_status sdm_download_pdf_table(sdm_map *m, float *table, int32_t n) {
 }
 
 // ---- the frame ---------------------------------------------------------------------------------
-// First half of subObjectLevelUpdate (semantic_dsp_map.h:576-764): prediction, visibility/binning and
-// this shard's partial ck image.  ck_part_dev receives the device pointer of that image (H*W floats).
-sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
-                            const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
-                            const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after,
-                            const float **ck_part_dev) {
+// The first half of subObjectLevelUpdate (semantic_dsp_map.h:576-764) in three steps, cut where a Z-slab sharded map
+// needs data from the other shards:
+//   sdm_frame_start    ego shift; every moving object's local members are collected, per-object counts published
+//                      [exchange 1: all-gather of the count rows, HALO_OBJ ints per shard]
+//   sdm_frame_moves    global ranks, transform + noise, originals deleted, slab-crossing copies exported
+//                      [exchange 2: all-gather of the export buffers]
+//   sdm_frame_predict  import, ordered re-insertion, removals, visibility/binning, this shard's partial ck image
+//                      [exchange 3: all-gather of the partial ck images]  -> sdm_update_finish
+// sdm_update_begin = the three steps back to back (single shard, or a frame without object moves).
+sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
+                           const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
+                           const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after) {
   if (!m || !depth || !cloud || !cam_pos || !cam_q || n_moves < 0 || n_remove < 0 || (n_moves && !moves) ||
       (n_remove && !remove_tracks) || n_moves > MAX_MOVE_OBJECTS || n_remove > 1024)
     return SDM_ERR_INVALID_ARGUMENT;
@@ -617,6 +631,10 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
   hipStream_t s = m->stream;
   const Dims &d = m->d;
   const size_t hw = (size_t)d.W * d.H;
+  m->stop_after = stop_after;
+  m->frame_flags = flags;
+  m->n_moves = 0;
+  m->n_remove = 0;
   auto done = [&](int stage) { return stop_after != 0 && stop_after <= stage; };
   for (int i = 0; i < 9; ++i) m->stage_ran[i] = false;
   auto mark = [&](int stage) {
@@ -650,7 +668,7 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
   mark(1);
   if (done(1)) return SDM_OK;
 
-  // P2: object moves (semantic_dsp_map.h:588-699)
+  // P2 (first part): collect the moving objects' particles (semantic_dsp_map.h:588-693)
   if (n_moves > 0) {
     MoveSet ms;
     memset(&ms, 0, sizeof(ms));
@@ -660,18 +678,58 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
       memcpy(ms.T[k], moves[k].T, 12 * sizeof(float));
     }
     HIP_TRY(hipMemcpyAsync(m->d_moveset, &ms, sizeof(ms), hipMemcpyHostToDevice, s));
-    launch_moves(d, m->f, m->flt, m->d_moveset, n_moves, m->st, m->sc, s);
+    m->n_moves = n_moves;
+    launch_moves_count(d, m->d_moveset, n_moves, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, s);
   }
-  mark(2);
-  if (done(2)) return SDM_OK;
-
-  // P3: removals (semantic_dsp_map.h:702-736)
   if (n_remove > 0) {
     std::vector<uint16_t> tr(n_remove);
     for (int k = 0; k < n_remove; ++k) tr[k] = (uint16_t)remove_tracks[k];
     HIP_TRY(hipMemcpyAsync(m->d_remove, tr.data(), n_remove * 2, hipMemcpyHostToDevice, s));
-    launch_remove(d, m->st, m->d_remove, n_remove, s);
+    m->n_remove = n_remove;
   }
+  return SDM_OK;
+}
+
+sdm_status sdm_frame_moves(sdm_map *m) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  if (m->stop_after != 0 && m->stop_after <= SDM_STAGE_EGO) return SDM_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  const int world = m->cfg.shard_count, rank = m->cfg.shard_rank;
+  if (m->n_moves > 0) {
+    // without gathered counts (single shard, or the caller skipped exchange 1) the local counts are the global ones
+    const int32_t *counts_all = m->counts_all_user;
+    int w = world, r = rank;
+    if (!counts_all) {
+      counts_all = m->counts_local_user ? m->counts_local_user : m->d_counts_local;
+      w = 1;
+      r = 0;
+    }
+    launch_moves_transform(m->d, m->f, m->flt, m->d_moveset, m->n_moves, m->st, m->sc, counts_all, w, r, m->stream);
+  }
+  return SDM_OK;
+}
+
+sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  const int stop_after = m->stop_after;
+  if (stop_after != 0 && stop_after <= SDM_STAGE_EGO) return SDM_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  const Dims &d = m->d;
+  auto done = [&](int stage) { return stop_after != 0 && stop_after <= stage; };
+  auto mark = [&](int stage) {
+    if (m->profiling) {
+      (void)hipEventRecord(m->ev[stage], s);
+      m->stage_ran[stage] = true;
+    }
+  };
+  // P2 (second part): re-insert the moved copies in the reference's order (operations.h:351-361)
+  launch_moves_finish(d, m->flt, m->n_moves, m->st, m->sc, m->counts_all_user ? m->cfg.shard_count : 1, m->cfg.shard_rank, s);
+  mark(2);
+  if (done(2)) return SDM_OK;
+
+  // P3: removals (semantic_dsp_map.h:702-736)
+  if (m->n_remove > 0) launch_remove(d, m->st, m->d_remove, m->n_remove, s);
   mark(3);
   if (done(3)) return SDM_OK;
 
@@ -685,6 +743,36 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
   float *ck_dst = m->ck_user ? m->ck_user : m->d_ck_part;
   launch_ck(d, m->flt, m->st, m->sc, ck_dst, m->fused_ck ? 1 : 0, s);
   if (ck_part_dev) *ck_part_dev = ck_dst;
+  return SDM_OK;
+}
+
+sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
+                            const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
+                            const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after,
+                            const float **ck_part_dev) {
+  sdm_status rc = sdm_frame_start(m, depth, cloud, cam_pos, cam_q, moves, n_moves, remove_tracks, n_remove, flags, stop_after);
+  if (rc != SDM_OK) return rc;
+  // no exchange between the steps: moved particles that leave this shard's slab are dropped (exact for one shard)
+  const int32_t *keep_all = m->counts_all_user;
+  m->counts_all_user = nullptr;
+  rc = sdm_frame_moves(m);
+  if (rc == SDM_OK) rc = sdm_frame_predict(m, ck_part_dev);
+  m->counts_all_user = keep_all;
+  return rc;
+}
+
+// buffers of the two move exchanges (all device pointers, caller-owned):
+//   counts_local  HALO_OBJ int32 written by sdm_frame_start      counts_all  shard_count x HALO_OBJ, gathered
+//   send          16-byte header + cap_records x 36 B, written by sdm_frame_moves
+//   recv_all      shard_count such buffers in shard order, gathered, read by sdm_frame_predict
+sdm_status sdm_set_halo_buffers(sdm_map *m, int32_t *counts_local, const int32_t *counts_all, void *send, const void *recv_all,
+                                int32_t cap_records) {
+  if (!m || cap_records < 0) return SDM_ERR_INVALID_ARGUMENT;
+  m->counts_local_user = counts_local;
+  m->counts_all_user = counts_all;
+  m->sc.halo_send = (unsigned char *)send;
+  m->sc.halo_recv = (const unsigned char *)recv_all;
+  m->sc.halo_cap = (uint32_t)cap_records;
   return SDM_OK;
 }
 

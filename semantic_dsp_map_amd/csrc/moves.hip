@@ -130,24 +130,74 @@ __global__ __launch_bounds__(TPB) void k_move_scatter(const uint16_t *__restrict
   }
 }
 
+// ---- global ranks across Z-slab shards ------------------------------------------------------------------
+// The noise-table cursor and the re-insertion order of the reference run over (object order, ascending particle
+// index).  With the map split into Z slabs (ring-z = high index bits) that order is: object, then shard, then local
+// index.  Every shard publishes its per-object member counts (HALO_OBJ ints), the counts of all shards are gathered,
+// and the global rank of the j-th local member of object k on shard r is
+//     e = sum_{k'<k} sum_r' C[r'][k']  +  sum_{r'<r} C[r'][k]  +  j.
+// Moved copies are stored at index e, so a stable sort by target voxel keeps the reference's order without knowing
+// where a copy came from.  A copy whose target voxel belongs to another slab is exported as a 36-byte record.
+struct HaloRecord {
+  float x, y, z;
+  uint32_t forget_bits;
+  float w;
+  uint32_t voxel;
+  uint32_t e;
+  uint32_t ts_track;            // ts | track << 16
+  uint32_t owner_label_status;  // owner | label << 16 | status << 24
+};
+static_assert(sizeof(HaloRecord) == HALO_RECORD_BYTES, "halo record layout");
+
+__global__ void k_move_local_counts(const uint32_t *__restrict__ offs, uint32_t n_blocks, int n_obj, int32_t *counts_local) {
+  int k = threadIdx.x;
+  if (k >= HALO_OBJ) return;
+  counts_local[k] = k < n_obj ? (int32_t)(offs[(size_t)(k + 1) * n_blocks] - offs[(size_t)k * n_blocks]) : 0;
+}
+
+// one thread: e_base[k], total; also resets the export counter
+__global__ void k_move_bases(const int32_t *__restrict__ counts_all, int world, int rank, int n_obj, Scratch sc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t run = 0;
+  for (int k = 0; k < n_obj; ++k) {
+    uint32_t below = 0, all = 0;
+    for (int r = 0; r < world; ++r) {
+      uint32_t c = (uint32_t)counts_all[r * HALO_OBJ + k];
+      if (r < rank) below += c;
+      all += c;
+    }
+    sc.mv_ebase[k] = run + below;
+    run += all;
+  }
+  sc.cnt->n_moved = run;
+  *sc.mv_total = run < sc.cap_move ? run : sc.cap_move;
+  if (run > sc.cap_move) sc.cnt->overflow = 1;
+  if (sc.halo_send) *reinterpret_cast<uint32_t *>(sc.halo_send) = 0;
+}
+
+__global__ __launch_bounds__(TPB) void k_move_init_keys(Dims d, Scratch sc) {
+  const uint32_t total = *sc.mv_total;
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    sc.bkey_a[e] = d.V;  // "not mine": sorts behind every real voxel and is skipped by the replay
+    sc.bval_a[e] = e;
+  }
+}
+
 // phase 1 of moveParticlesInSetsByTransformations (operations.h:331-349): copy, transform + table noise,
-// delete the original.  e = rank of the particle in (object order, ascending index); the noise cursor
-// advances by three per particle in exactly that order.
+// delete the original.  The noise cursor advances by three per particle in global rank order.
 __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter flt, const MoveSet *ms, State st, Scratch sc,
                                                         const uint32_t *__restrict__ offs, uint32_t n_blocks, int n_obj) {
-  const uint32_t total = offs[(size_t)n_obj * n_blocks];
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    sc.cnt->n_moved = total;
-    *sc.mv_total = total < sc.cap_move ? total : sc.cap_move;
-  }
   if (sc.cnt->overflow) return;
+  const uint32_t local_total = offs[(size_t)n_obj * n_blocks];
   const size_t slot_base = (size_t)d.v_begin << d.p_n;
   uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total && e < sc.cap_move; e += stride) {
+  for (uint32_t le = blockIdx.x * blockDim.x + threadIdx.x; le < local_total; le += stride) {
     int obj = 0;
     for (int k = 1; k < n_obj; ++k)
-      if (e >= offs[(size_t)k * n_blocks]) obj = k;
-    const uint32_t src = sc.mv_src[e];
+      if (le >= offs[(size_t)k * n_blocks]) obj = k;
+    const uint32_t e = sc.mv_ebase[obj] + (le - offs[(size_t)obj * n_blocks]);
+    const uint32_t src = sc.mv_src[le];
     const size_t li = (size_t)src - slot_base;
     const float4 p = st.pos4[li];
     const float *T = ms->T[obj];
@@ -158,21 +208,69 @@ __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter 
     nx = nx + st.noise[(draw + 1) % flt.noise_n];
     ny = ny + st.noise[(draw + 2) % flt.noise_n];
     nz = nz + st.noise[(draw + 3) % flt.noise_n];
-    sc.mv_pos[e] = make_float4(nx, ny, nz, p.w);
-    sc.mv_w[e] = st.w[li];
-    sc.mv_ts[e] = st.ts[li];
-    sc.mv_track[e] = st.track[li];
-    sc.mv_label[e] = st.label[li];
-    sc.mv_status[e] = st.status[li];
-    sc.mv_owner[e] = ms->track[obj];
+    const float pw = st.w[li];
+    const uint16_t pts = st.ts[li], ptrack = st.track[li];
+    const uint8_t plabel = st.label[li], pstatus = st.status[li];
+    const uint16_t powner = ms->track[obj];
     st.status[li] = ST_INVALID;  // deleteParticleByIndex
     st.owner[li] = OWNER_NONE;   // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
     uint32_t rx, ry, rz;
     uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
-    uint32_t key = d.V;
-    if (v != INVALID_INDEX && rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) key = v;
-    sc.bkey_a[e] = key;
-    sc.bval_a[e] = e;
+    if (v == INVALID_INDEX) continue;  // left the map: dropped (operations.h:799-802)
+    if (rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) {
+      if (e >= sc.cap_move) continue;
+      sc.mv_pos[e] = make_float4(nx, ny, nz, p.w);
+      sc.mv_w[e] = pw;
+      sc.mv_ts[e] = pts;
+      sc.mv_track[e] = ptrack;
+      sc.mv_label[e] = plabel;
+      sc.mv_status[e] = pstatus;
+      sc.mv_owner[e] = powner;
+      sc.bkey_a[e] = v;
+    } else if (sc.halo_send) {  // crosses into another slab: export
+      uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(sc.halo_send), 1u);
+      if (k < sc.halo_cap) {
+        HaloRecord r;
+        r.x = nx;
+        r.y = ny;
+        r.z = nz;
+        r.forget_bits = __float_as_uint(p.w);
+        r.w = pw;
+        r.voxel = v;
+        r.e = e;
+        r.ts_track = (uint32_t)pts | ((uint32_t)ptrack << 16);
+        r.owner_label_status = (uint32_t)powner | ((uint32_t)plabel << 16) | ((uint32_t)pstatus << 24);
+        reinterpret_cast<HaloRecord *>(sc.halo_send + HALO_HEADER_BYTES)[k] = r;
+      } else {
+        sc.cnt->overflow = 1;
+      }
+    }
+  }
+}
+
+// import the records other shards exported into this slab (blockIdx.y = source shard)
+__global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int world, int rank) {
+  const int src = blockIdx.y;
+  if (src == rank || src >= world) return;
+  const unsigned char *buf = sc.halo_recv + (size_t)src * (HALO_HEADER_BYTES + (size_t)sc.halo_cap * HALO_RECORD_BYTES);
+  uint32_t n = *reinterpret_cast<const uint32_t *>(buf);
+  if (n > sc.halo_cap) n = sc.halo_cap;
+  const HaloRecord *rec = reinterpret_cast<const HaloRecord *>(buf + HALO_HEADER_BYTES);
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    const HaloRecord r = rec[k];
+    uint32_t rz = (r.voxel >> (d.x_n + d.y_n)) & (d.NZ - 1);
+    if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) continue;
+    const uint32_t e = r.e;
+    if (e >= sc.cap_move) continue;
+    sc.mv_pos[e] = make_float4(r.x, r.y, r.z, __uint_as_float(r.forget_bits));
+    sc.mv_w[e] = r.w;
+    sc.mv_ts[e] = (uint16_t)(r.ts_track & 0xffffu);
+    sc.mv_track[e] = (uint16_t)(r.ts_track >> 16);
+    sc.mv_owner[e] = (uint16_t)(r.owner_label_status & 0xffffu);
+    sc.mv_label[e] = (uint8_t)((r.owner_label_status >> 16) & 0xffu);
+    sc.mv_status[e] = (uint8_t)(r.owner_label_status >> 24);
+    sc.bkey_a[e] = r.voxel;
   }
 }
 
@@ -278,8 +376,9 @@ void launch_owner_flags(const Dims &d, const State &st, hipStream_t s) {
 
 size_t move_blocks(const Dims &d) { return ((size_t)d.v_count * d.S + MV_CHUNK - 1) / MV_CHUNK; }
 
-void launch_moves(const Dims &d, const Frame &f, const Filter &flt, const MoveSet *ms_dev, int n_obj, const State &st,
-                  const Scratch &sc, hipStream_t s) {
+// step 1: collect every moving object's members (ascending index) and publish the per-object counts
+void launch_moves_count(const Dims &d, const MoveSet *ms_dev, int n_obj, const State &st, const Scratch &sc, int32_t *counts_local,
+                        hipStream_t s) {
   if (n_obj <= 0) return;
   const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t slot_base = (size_t)d.v_begin << d.p_n;
@@ -291,7 +390,24 @@ void launch_moves(const Dims &d, const Frame &f, const Filter &flt, const MoveSe
   exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch, s);
   hipLaunchKernelGGL(k_move_scatter, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, slot_base, ms_dev, sc.mv_cnt,
                      n_blocks, n_obj, sc.mv_src, sc.cap_move, sc.cnt);
+  hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, n_blocks, n_obj, counts_local);
+}
+
+// step 2 (after the counts of all shards are known): global ranks, transform, export of slab-crossing copies
+void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet *ms_dev, int n_obj, const State &st,
+                            const Scratch &sc, const int32_t *counts_all, int world, int rank, hipStream_t s) {
+  if (n_obj <= 0) return;
+  const uint32_t n_blocks = (uint32_t)move_blocks(d);
+  hipLaunchKernelGGL(k_move_bases, dim3(1), dim3(64), 0, s, counts_all, world, rank, n_obj, sc);
+  hipLaunchKernelGGL(k_move_init_keys, dim3(256), dim3(TPB), 0, s, d, sc);
   hipLaunchKernelGGL(k_move_transform, dim3(1024), dim3(TPB), 0, s, d, f, flt, ms_dev, st, sc, sc.mv_cnt, n_blocks, n_obj);
+}
+
+// step 3 (after the export buffers of all shards are gathered): import, stable sort by voxel, ordered replay
+void launch_moves_finish(const Dims &d, const Filter &flt, int n_obj, const State &st, const Scratch &sc, int world, int rank,
+                         hipStream_t s) {
+  if (n_obj <= 0) return;
+  if (world > 1 && sc.halo_recv) hipLaunchKernelGGL(k_move_import, dim3(64, world), dim3(TPB), 0, s, d, sc, world, rank);
   int nbits = d.x_n + d.y_n + d.z_n + 1;
   int which = radix_sort_pairs(sc.bkey_a, sc.bval_a, sc.bkey_b, sc.bval_b, sc.cap_move, nbits, sc.sort_scratch, s, sc.mv_total);
   const uint32_t *skey = which ? sc.bkey_b : sc.bkey_a;

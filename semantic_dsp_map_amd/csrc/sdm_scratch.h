@@ -45,6 +45,11 @@ struct Scratch {
   uint16_t *mv_ts = nullptr, *mv_track = nullptr, *mv_owner = nullptr;
   uint8_t *mv_label = nullptr, *mv_status = nullptr;
   uint32_t cap_move = 0;
+  uint32_t *mv_ebase = nullptr;    // global rank of each moving object's first local member
+  // slab-crossing copies: [u32 count, pad to 16 B][records]; recv = one such buffer per shard, shard order
+  unsigned char *halo_send = nullptr;
+  const unsigned char *halo_recv = nullptr;
+  uint32_t halo_cap = 0;
   uint8_t *track_to_obj = nullptr; // 65536 entries: moving-object rank of a track id, 0xFF = not moving
   // generic
   uint32_t *scan_scratch = nullptr, *sort_scratch = nullptr;
@@ -71,6 +76,9 @@ void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t
 
 // object moves / removals (moves.hip)
 constexpr int MAX_MOVE_OBJECTS = 64;
+constexpr int HALO_OBJ = 64;              // ints per shard in the gathered count matrix (>= MAX_MOVE_OBJECTS)
+constexpr int HALO_RECORD_BYTES = 36;
+constexpr int HALO_HEADER_BYTES = 16;
 struct MoveSet {
   int n;
   float T[MAX_MOVE_OBJECTS][12];  // rows 0..2 of the 4x4 (row-major)
@@ -78,8 +86,12 @@ struct MoveSet {
 };
 size_t move_blocks(const Dims &d);
 void launch_owner_flags(const Dims &d, const State &st, hipStream_t s);
-void launch_moves(const Dims &d, const Frame &f, const Filter &flt, const MoveSet *ms_dev, int n_obj, const State &st,
-                  const Scratch &sc, hipStream_t s);
+void launch_moves_count(const Dims &d, const MoveSet *ms_dev, int n_obj, const State &st, const Scratch &sc, int32_t *counts_local,
+                        hipStream_t s);
+void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet *ms_dev, int n_obj, const State &st,
+                            const Scratch &sc, const int32_t *counts_all, int world, int rank, hipStream_t s);
+void launch_moves_finish(const Dims &d, const Filter &flt, int n_obj, const State &st, const Scratch &sc, int world, int rank,
+                         hipStream_t s);
 void launch_remove(const Dims &d, const State &st, const uint16_t *tracks_dev, int n, hipStream_t s);
 
 }  // namespace sdm
