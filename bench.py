@@ -42,26 +42,22 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
-    import torch
     from semantic_dsp_map_amd import binding, sharded, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, args.gpus))
     dist = None
     if world > 1:
+        # torch.distributed is plumbing only: gloo (CPU) for the rendezvous, barriers and the max over ranks.
+        # The data-path collectives are RCCL calls inside libsdm_hip on the system HIP runtime.
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: libsdm_hip has no CPU path")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     base = synth.CONFIGS[args.config]
     cfg = sharded.weak_scaled_config(base, world)
@@ -70,73 +66,67 @@ def main():
     S = 1 << cfg["p_n"]
     n_frames = args.warmup + args.steps
 
+    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist)
+    m = eng.map
+    # noise table: rocRAND on the device, read back so that the CPU baseline uses the same floats
+    m.generate_noise_table(seed=20250217)
+    noise = m.download_noise_table()
+
     # ---- synthetic frames (same on every rank), uploaded to HBM before the timed region
     scene = synth.Scene(cfg, n_static=48, n_dynamic=6, seed=7)
     t0 = time.time()
     frames = []
     for t in range(n_frames):
         depth, cloud, pos, q = scene.render(t, params)
-        d_depth = torch.from_numpy(depth.reshape(-1)).to(dev)
-        d_cloud = torch.from_numpy(cloud.view(np.uint8).reshape(-1)).to(dev)
-        frames.append((depth, cloud, pos, q, scene.moves(t), d_depth, d_cloud))
+        frames.append((depth, cloud, pos, q, scene.moves(t), m.device_put(depth), m.device_put(cloud)))
     t_render = time.time() - t0
 
-    side = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(side):
-        eng = sharded.HipEngine(cfg, params, rank, world, local_rank)
-        m = eng.map
-        # noise table: rocRAND on the device, read back so that the CPU baseline uses the same floats
-        m.generate_noise_table(seed=20250217)
-        noise = m.download_noise_table()
-        st, ring, n_pre = synth.prefill_state(cfg, scene, args.particles, shard_rank=rank, shard_count=world)
-        m.load_state(st)
-        m.set_ring_state(ring)
-        drv = sharded.ShardedDriver(eng, rank, world, dist)
+    st, ring, n_pre = synth.prefill_state(cfg, scene, args.particles, shard_rank=rank, shard_count=world)
+    m.load_state(st)
+    m.set_ring_state(ring)
 
-        def run(lo, hi):
-            for t in range(lo, hi):
-                depth, cloud, pos, q, moves, d_depth, d_cloud = frames[t]
-                drv.update(d_depth.data_ptr(), d_cloud.data_ptr(), pos, q, moves)
+    def run(lo, hi):
+        for t in range(lo, hi):
+            depth, cloud, pos, q, moves, d_depth, d_cloud = frames[t]
+            eng.update(d_depth, d_cloud, pos, q, moves)
 
-        run(0, args.warmup)
+    def fence():
         m.synchronize()
-        torch.cuda.synchronize()
+        m.device_synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(args.warmup, n_frames)
-        m.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
 
-        stats = m.stats(count_live=True)
-        live = stats["live_particles"]
-        if dist is not None:
-            lt = torch.tensor([live, stats["n_visible"]], dtype=torch.int64, device=dev)
-            dist.all_reduce(lt)
-            live, n_vis = int(lt[0].item()), int(lt[1].item())
-        else:
-            n_vis = stats["n_visible"]
+    run(0, args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(args.warmup, n_frames)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
 
-        # per-stage GPU times of one more frame (not part of the timed region)
-        stage_ms = None
-        if world == 1:
-            m.set_profiling(True)
-            depth, cloud, pos, q = scene.render(n_frames, params)
-            m.update(depth, cloud, pos, q, scene.moves(n_frames), sync=True)
-            stage_ms = m.stats()["stage_ms"]
-            m.set_profiling(False)
+    stats = m.stats(count_live=True)
+    live, n_vis = stats["live_particles"], stats["n_visible"]
+    if dist is not None:
+        lt = torch.tensor([live, n_vis], dtype=torch.int64)
+        dist.all_reduce(lt)
+        live, n_vis = int(lt[0].item()), int(lt[1].item())
 
-        # ---- roofline of the dominant streaming kernel (occupancy / semantic sweep), HIP events on its stream
-        sweep_ms = m.time_occupancy_sweep(iters=50)
+    # per-stage GPU times of one more frame (not part of the timed region)
+    stage_ms = None
+    if world == 1:
+        m.set_profiling(True)
+        depth, cloud, pos, q = scene.render(n_frames, params)
+        dd, dc = m.device_put(depth), m.device_put(cloud)
+        m.update(dd, dc, pos, q, scene.moves(n_frames), on_device=True, sync=True)
+        stage_ms = m.stats()["stage_ms"]
+        m.set_profiling(False)
+
+    # ---- roofline of the dominant streaming kernel (occupancy / semantic sweep), HIP events on its stream
+    sweep_ms = m.time_occupancy_sweep(iters=50)
     ms_per_step = dt * 1e3 / args.steps
     value = V / (dt / args.steps) / 1e6  # Mvoxels / s, whole map (all shards)
     bytes_per_voxel = (S - 1) * 10 + 2 + 8  # read (S-1)*(w4+ts2+track2+label1+status1)+2, write 8

@@ -223,6 +223,23 @@ sdm_status sdm_set_stream(sdm_map *m, void *hip_stream);
  * (e.g. a slice of the all-gather send buffer); NULL restores the internal buffer. */
 sdm_status sdm_set_ck_buffer(sdm_map *m, float *dev_buffer);
 
+/* ---- native multi-GPU path: RCCL over xGMI, one process per GPU.  Rank 0 draws an id, the caller hands it to
+ * every rank (any out-of-band channel), every rank calls sdm_comm_init on its shard map (collective), then
+ * sdm_update_sharded runs whole frames: the three all-gathers above are issued on the map's stream. */
+sdm_status sdm_comm_unique_id(uint8_t out[128]);
+sdm_status sdm_comm_init(sdm_map *m, const uint8_t id[128], int32_t halo_cap_records);
+sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_point *cloud,
+                              const float cam_pos[3], const float cam_q[4],
+                              const sdm_object_move *moves, int32_t n_moves,
+                              const int32_t *remove_tracks, int32_t n_remove, uint32_t flags);
+
+/* ---- plain device buffers (for frames kept resident in HBM, see SDM_INPUT_ON_DEVICE) */
+sdm_status sdm_device_alloc(sdm_map *m, size_t bytes, void **out);
+sdm_status sdm_device_free(sdm_map *m, void *p);
+sdm_status sdm_device_upload(sdm_map *m, void *dst_dev, const void *src_host, size_t bytes);
+sdm_status sdm_device_download(sdm_map *m, void *dst_host, const void *src_dev, size_t bytes);
+sdm_status sdm_device_synchronize(sdm_map *m);
+
 /* Wait for all enqueued work of this map; surfaces deferred device-side errors. */
 sdm_status sdm_synchronize(sdm_map *m);
 

@@ -99,6 +99,14 @@ def load_library():
         "sdm_frame_moves": [vp],
         "sdm_frame_predict": [vp, C.POINTER(vp)],
         "sdm_set_halo_buffers": [vp, vp, vp, vp, vp, i32],
+        "sdm_comm_unique_id": [vp],
+        "sdm_comm_init": [vp, vp, i32],
+        "sdm_update_sharded": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32],
+        "sdm_device_alloc": [vp, C.c_size_t, C.POINTER(vp)],
+        "sdm_device_free": [vp, vp],
+        "sdm_device_upload": [vp, vp, vp, C.c_size_t],
+        "sdm_device_download": [vp, vp, vp, C.c_size_t],
+        "sdm_device_synchronize": [vp],
         "sdm_stream": [vp, C.POINTER(vp)],
         "sdm_set_stream": [vp, vp],
         "sdm_set_ck_buffer": [vp, vp],
@@ -262,6 +270,42 @@ class SdmMap:
         _check(self.L, self.L.sdm_set_halo_buffers(self.h, _ptr(int(counts_local)), _ptr(int(counts_all)), _ptr(int(send)),
                                                     _ptr(int(recv_all)), cap_records), "sdm_set_halo_buffers")
 
+    def comm_init(self, id_bytes, halo_cap=0):
+        buf = np.frombuffer(bytes(id_bytes), np.uint8).copy()
+        assert buf.size == 128
+        _check(self.L, self.L.sdm_comm_init(self.h, _ptr(buf), halo_cap), "sdm_comm_init")
+
+    def update_sharded(self, depth, cloud, cam_pos, cam_q, moves=None, remove_tracks=None, on_device=False, flags=0):
+        keep, args = self._frame_args(depth, cloud, cam_pos, cam_q, moves, remove_tracks, on_device)
+        fl = flags | (INPUT_ON_DEVICE if on_device else 0)
+        _check(self.L, self.L.sdm_update_sharded(self.h, *args, fl), "sdm_update_sharded")
+
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        _check(self.L, self.L.sdm_device_alloc(self.h, nbytes, C.byref(p)), "sdm_device_alloc")
+        return p.value
+
+    def device_free(self, ptr):
+        _check(self.L, self.L.sdm_device_free(self.h, _ptr(int(ptr))), "sdm_device_free")
+
+    def device_upload(self, ptr, array):
+        a = np.ascontiguousarray(array)
+        _check(self.L, self.L.sdm_device_upload(self.h, _ptr(int(ptr)), _ptr(a), a.nbytes), "sdm_device_upload")
+
+    def device_put(self, array):
+        a = np.ascontiguousarray(array)
+        p = self.device_alloc(a.nbytes)
+        self.device_upload(p, a)
+        return p
+
+    def device_download(self, ptr, nbytes, dtype=np.uint8):
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype)
+        _check(self.L, self.L.sdm_device_download(self.h, _ptr(out), _ptr(int(ptr)), out.nbytes), "sdm_device_download")
+        return out
+
+    def device_synchronize(self):
+        _check(self.L, self.L.sdm_device_synchronize(self.h), "sdm_device_synchronize")
+
     def update_finish(self, ck_parts_dev=None, n_parts=1, stop_after="all", flags=0):
         st = STAGES[stop_after] if isinstance(stop_after, str) else stop_after
         _check(self.L, self.L.sdm_update_finish(self.h, _ptr(ck_parts_dev), n_parts, flags, st), "sdm_update_finish")
@@ -378,6 +422,14 @@ class SdmMap:
         ms = C.c_float()
         _check(self.L, self.L.sdm_time_occupancy_sweep(self.h, iters, C.byref(ms)), "sdm_time_occupancy_sweep")
         return ms.value
+
+
+def comm_unique_id():
+    """128-byte RCCL id drawn on this process (rank 0 broadcasts it to the other ranks)."""
+    L = load_library()
+    buf = np.zeros(128, np.uint8)
+    _check(L, L.sdm_comm_unique_id(_ptr(buf)), "sdm_comm_unique_id")
+    return buf.tobytes()
 
 
 def test_scan(a):

@@ -3,6 +3,7 @@
 // Host work per frame is O(axis length): the ego-centre ring shift of the reference moves no particle
 // data, it only stamps the slabs that were recycled (mc_ring/operations.h:68-96, 1111-1191); everything
 // else is enqueued on one HIP stream with no host synchronisation inside a frame.
+#include <rccl/rccl.h>
 #include <rocrand/rocrand.h>
 
 #include <algorithm>
@@ -63,6 +64,12 @@ struct sdm_map {
   uint32_t frame_flags = 0;
   int n_moves = 0, n_remove = 0;
   int32_t *d_counts_local = nullptr;
+  // native RCCL path (sdm_comm_init): communicator + exchange buffers owned by the map
+  ncclComm_t comm = nullptr;
+  int32_t *d_counts_all = nullptr;
+  unsigned char *d_halo_send = nullptr, *d_halo_recv = nullptr;
+  float *d_ck_all = nullptr;
+  uint32_t halo_cap_own = 0;
   int32_t *counts_local_user = nullptr;
   const int32_t *counts_all_user = nullptr;
   int device = 0;
@@ -539,6 +546,10 @@ sdm_status sdm_destroy(sdm_map *m) {
   void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points};
   for (void *p : extra)
     if (p) (void)hipFree(p);
+  if (m->comm) (void)ncclCommDestroy(m->comm);
+  void *comm_bufs[] = {m->d_counts_all, m->d_halo_send, m->d_halo_recv, m->d_ck_all};
+  for (void *p : comm_bufs)
+    if (p) (void)hipFree(p);
   if (m->ev_valid)
     for (int i = 0; i < 9; ++i) (void)hipEventDestroy(m->ev[i]);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
@@ -840,6 +851,105 @@ sdm_status sdm_set_ck_buffer(sdm_map *m, float *dev_buffer) {
 sdm_status sdm_stream(sdm_map *m, void **stream_out) {
   if (!m || !stream_out) return SDM_ERR_INVALID_ARGUMENT;
   *stream_out = (void *)m->stream;
+  return SDM_OK;
+}
+
+// ---- multi-GPU: RCCL over xGMI, one process per GPU ---------------------------------------------
+// The reference is one process and one thread; these collectives are new.  Rendezvous (handing the
+// 128-byte id of rank 0 to the other ranks) is the caller's business (bench.py uses torch.distributed/gloo for it).
+#define NCCL_TRY(expr)                                                       \
+  do {                                                                       \
+    ncclResult_t r_ = (expr);                                                \
+    if (r_ != ncclSuccess) {                                                 \
+      set_error(#expr, __FILE__, __LINE__, ncclGetErrorString(r_));          \
+      return SDM_ERR_COMM;                                                   \
+    }                                                                        \
+  } while (0)
+
+sdm_status sdm_comm_unique_id(uint8_t out[128]) {
+  if (!out) return SDM_ERR_INVALID_ARGUMENT;
+  static_assert(NCCL_UNIQUE_ID_BYTES == 128, "id size");
+  ncclUniqueId id;
+  NCCL_TRY(ncclGetUniqueId(&id));
+  memcpy(out, id.internal, 128);
+  return SDM_OK;
+}
+
+sdm_status sdm_comm_init(sdm_map *m, const uint8_t id_bytes[128], int32_t halo_cap_records) {
+  if (!m || !id_bytes || halo_cap_records < 0 || m->comm) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  const int world = m->cfg.shard_count, rank = m->cfg.shard_rank;
+  ncclUniqueId id;
+  memcpy(id.internal, id_bytes, 128);
+  NCCL_TRY(ncclCommInitRank(&m->comm, world, id, rank));
+  const size_t hw = (size_t)m->d.W * m->d.H;
+  m->halo_cap_own = halo_cap_records > 0 ? (uint32_t)halo_cap_records : 16384u;
+  const size_t hb = HALO_HEADER_BYTES + (size_t)m->halo_cap_own * HALO_RECORD_BYTES;
+  HIP_TRY(dev_alloc(&m->d_counts_all, (size_t)world * HALO_OBJ));
+  HIP_TRY(dev_alloc(&m->d_halo_send, hb));
+  HIP_TRY(dev_alloc(&m->d_halo_recv, (size_t)world * hb));
+  HIP_TRY(dev_alloc(&m->d_ck_all, (size_t)world * hw));
+  HIP_TRY(hipMemsetAsync(m->d_halo_send, 0, hb, m->stream));
+  HIP_TRY(hipMemsetAsync(m->d_halo_recv, 0, (size_t)world * hb, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return sdm_set_halo_buffers(m, m->d_counts_local, m->d_counts_all, m->d_halo_send, m->d_halo_recv, (int32_t)m->halo_cap_own);
+}
+
+// One frame of a sharded map with all exchanges done here: start -> all-gather(counts) -> moves ->
+// all-gather(exports) -> predict -> all-gather(ck images) -> finish, everything on the map's stream.
+sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
+                              const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
+                              const int32_t *remove_tracks, int32_t n_remove, uint32_t flags) {
+  if (!m || !m->comm) return SDM_ERR_INVALID_ARGUMENT;
+  const int world = m->cfg.shard_count;
+  const size_t hw = (size_t)m->d.W * m->d.H;
+  sdm_status rc = sdm_frame_start(m, depth, cloud, cam_pos, cam_q, moves, n_moves, remove_tracks, n_remove, flags, 0);
+  if (rc != SDM_OK) return rc;
+  if (n_moves > 0) NCCL_TRY(ncclAllGather(m->d_counts_local, m->d_counts_all, HALO_OBJ, ncclInt32, m->comm, m->stream));
+  rc = sdm_frame_moves(m);
+  if (rc != SDM_OK) return rc;
+  if (n_moves > 0) {
+    const size_t hb = HALO_HEADER_BYTES + (size_t)m->halo_cap_own * HALO_RECORD_BYTES;
+    NCCL_TRY(ncclAllGather(m->d_halo_send, m->d_halo_recv, hb, ncclUint8, m->comm, m->stream));
+  }
+  const float *part = nullptr;
+  rc = sdm_frame_predict(m, &part);
+  if (rc != SDM_OK) return rc;
+  NCCL_TRY(ncclAllGather(part, m->d_ck_all, hw, ncclFloat32, m->comm, m->stream));
+  return sdm_update_finish(m, m->d_ck_all, world, flags, 0);
+}
+
+// ---- plain device buffers for callers that keep their frames resident in HBM (SDM_INPUT_ON_DEVICE) ----
+sdm_status sdm_device_alloc(sdm_map *m, size_t bytes, void **out) {
+  if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+  return SDM_OK;
+}
+sdm_status sdm_device_free(sdm_map *m, void *p) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipFree(p));
+  return SDM_OK;
+}
+sdm_status sdm_device_upload(sdm_map *m, void *dst_dev, const void *src_host, size_t bytes) {
+  if (!m || !dst_dev || !src_host) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return SDM_OK;
+}
+sdm_status sdm_device_download(sdm_map *m, void *dst_host, const void *src_dev, size_t bytes) {
+  if (!m || !dst_host || !src_dev) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return SDM_OK;
+}
+sdm_status sdm_device_synchronize(sdm_map *m) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipDeviceSynchronize());
   return SDM_OK;
 }
 
