@@ -91,6 +91,8 @@ def main():
             eng.update(d_depth, d_cloud, pos, q, moves)
 
     def fence():
+        # hipStreamSynchronize + hipDeviceSynchronize on the HIP runtime libsdm_hip runs on.  (torch bundles a second
+        # HIP runtime; torch.cuda.synchronize() would not see this library's streams, so it is not used.)
         m.synchronize()
         m.device_synchronize()
         if dist is not None:
@@ -134,7 +136,7 @@ def main():
     achieved = alg_bytes / (sweep_ms * 1e-3)
     roofline = {"kernel": "k_occupancy<%d>" % S, "bound": "hbm", "achieved": round(achieved / 1e9, 1),
                 "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BPS, 4),
-                "traffic": None, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(sweep_ms, 5)}
+                "traffic": pmc_traffic(S, V // world), "bytes_per_launch": alg_bytes, "avg_launch_ms": round(sweep_ms, 5)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_frames > 0:
@@ -163,6 +165,20 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(S, voxels):
+    """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per
+    MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r01c_sweep_pmc.json); None if they were taken on a
+    different kernel shape.  PMC counters cannot be read from inside this process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01c_sweep_pmc.json")) as f:
+            p = json.load(f)
+        if p["kernel"] == "k_occupancy<%d>" % S and p["algorithmic_bytes_per_launch"] == voxels * ((S - 1) * 10 + 10):
+            return int(p["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(cfg, params, noise, frames, st, ring, n_frames, V):

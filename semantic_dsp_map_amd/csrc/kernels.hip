@@ -19,17 +19,42 @@ namespace {
 
 constexpr int TPB = 256;
 
+// Whole-voxel fetch: all S slots of one SoA array with the widest aligned vector loads (16 B pieces).  The copy goes
+// through a plain vector type so that the compiler cannot narrow it to the bytes it happens to use (slot 0 of
+// most arrays is dead, which otherwise splits a 32-byte row into dword/dwordx3 pieces).
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 template <typename T, int N>
 __device__ __forceinline__ void load_vec(T (&dst)[N], const T *src) {
   constexpr int B = (int)sizeof(T) * N;
-  constexpr int A = B > 16 ? 16 : B;
-  __builtin_memcpy(dst, __builtin_assume_aligned(src, A), B);
+  if constexpr (B >= 16) {
+    const v4u *p = reinterpret_cast<const v4u *>(src);
+    v4u tmp[B / 16];
+#pragma unroll
+    for (int i = 0; i < B / 16; ++i) tmp[i] = __builtin_nontemporal_load(p + i);
+    __builtin_memcpy(dst, tmp, B);
+  } else if constexpr (B == 8) {
+    v2u tmp = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(src));
+    __builtin_memcpy(dst, &tmp, 8);
+  } else if constexpr (B == 4) {
+    uint32_t tmp = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(src));
+    __builtin_memcpy(dst, &tmp, 4);
+  } else {
+    uint16_t tmp = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(src));
+    __builtin_memcpy(dst, &tmp, 2);
+  }
 }
 template <typename T, int N>
 __device__ __forceinline__ void store_vec(T *dst, const T (&src)[N]) {
   constexpr int B = (int)sizeof(T) * N;
   constexpr int A = B > 16 ? 16 : B;
   __builtin_memcpy(__builtin_assume_aligned(dst, A), src, B);
+}
+
+__device__ __forceinline__ void store_result(sdm_voxel_result *dst, const sdm_voxel_result &r) {
+  v2u v;
+  __builtin_memcpy(&v, &r, 8);
+  __builtin_nontemporal_store(v, reinterpret_cast<v2u *>(dst));  // written once, read by the next stage only
 }
 
 __device__ __forceinline__ uint32_t stamp_max(const State &st, uint32_t rx, uint32_t ry, uint32_t rz) {
@@ -78,7 +103,7 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
   if (t0 == 0 || t0 < smax) {  // isVoxelValid, operations.h:824-837
     out.wsum = -1.f;
     out.occ = -1;
-    st.res[lv] = out;
+    store_result(st.res + lv, out);
     return;
   }
   uint8_t stv[S];
@@ -150,7 +175,7 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
   if (weight_sum > occ_threshold) out.occ = 1;
   else if (guessed >= SDM_OCC_INIT_WEIGHT) out.occ = 2;
   else out.occ = 0;
-  st.res[lv] = out;
+  store_result(st.res + lv, out);
   if (dirty_w) store_vec(st.w + base, wv);
   if (dirty_s) store_vec(st.status + base, stv);
 }

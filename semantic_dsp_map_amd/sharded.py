@@ -53,7 +53,18 @@ class NativeShardedMap:
         if world > 1:
             if dist is None:
                 raise ValueError("world > 1 needs a torch.distributed module for the rendezvous")
-            self.map.comm_init(broadcast_unique_id(dist, rank), halo_cap)
+            uid = broadcast_unique_id(dist, rank)
+            # RCCL prints a version banner on stdout at communicator creation; keep stdout clean for the caller's JSON
+            import os
+            import sys
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                self.map.comm_init(uid, halo_cap)
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
 
     def update(self, depth, cloud, pos, q, moves=None, remove_tracks=None, on_device=True):
         if self.world == 1:
