@@ -287,12 +287,18 @@ __device__ __forceinline__ uint64_t fill64(uint64_t g, uint64_t p) {
 __global__ __launch_bounds__(TPB) void k_flood2d(Dims d, Frame f, const uint64_t *__restrict__ M, int wpl, int wy,
                                                  const uint64_t *__restrict__ EY, const uint64_t *__restrict__ EZ,
                                                  uint64_t *__restrict__ R2D, Counters *cnt) {
-  extern __shared__ uint64_t r[];  // [nz][nyw]
+  extern __shared__ uint64_t lds[];  // r, ey, ez: [nz][nyw] each
   __shared__ uint32_t changed;
   const int VY = d.NY + 1;
   const int yw0 = f.bb0[1] >> 6, yw1 = f.bb1[1] >> 6;
   const int nyw = yw1 - yw0 + 1, nz = f.bb1[2] - f.bb0[2] + 1, z0 = f.bb0[2];
-  for (int i = threadIdx.x; i < nz * nyw; i += blockDim.x) r[i] = 0;
+  uint64_t *r = lds, *ey = lds + nz * nyw, *ez = lds + 2 * nz * nyw;
+  for (int i = threadIdx.x; i < nz * nyw; i += blockDim.x) {
+    r[i] = 0;
+    const size_t g = (size_t)(z0 + i / nyw) * wy + yw0 + i % nyw;
+    ey[i] = EY[g];
+    ez[i] = EZ[g];
+  }
   __syncthreads();
   if (threadIdx.x == 0 && f.start_ok) {
     // seed: the start vertex is reached iff it lies inside the frustum (operations.h:1324-1340)
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(TPB) void k_flood2d(Dims d, Frame f, const uint64_t
     // fill along y inside every z row; edge bit y joins lines y and y+1
     for (int row = threadIdx.x; row < nz; row += blockDim.x) {
       uint64_t *rr = r + row * nyw;
-      const uint64_t *e = EY + (size_t)(z0 + row) * wy + yw0;
+      const uint64_t *e = ey + row * nyw;
       uint64_t any = 0;
       for (int i = 0; i < nyw; ++i) any |= rr[i];
       if (!any) continue;
@@ -339,19 +345,19 @@ __global__ __launch_bounds__(TPB) void k_flood2d(Dims d, Frame f, const uint64_t
     for (int c = threadIdx.x; c < nyw; c += blockDim.x) {
       bool ch = false;
       uint64_t carry = 0;
-#pragma unroll 4
+#pragma unroll 8
       for (int z = 0; z < nz; ++z) {
         uint64_t old = r[z * nyw + c];
         uint64_t g = old;
-        if (z > 0) g |= carry & EZ[(size_t)(z0 + z - 1) * wy + yw0 + c];
+        if (z > 0) g |= carry & ez[(z - 1) * nyw + c];
         if (g != old) { r[z * nyw + c] = g; ch = true; }
         carry = g;
       }
       carry = 0;
-#pragma unroll 4
+#pragma unroll 8
       for (int z = nz - 1; z >= 0; --z) {
         uint64_t old = r[z * nyw + c];
-        uint64_t g = old | (carry & EZ[(size_t)(z0 + z) * wy + yw0 + c]);
+        uint64_t g = old | (carry & ez[z * nyw + c]);
         if (g != old) { r[z * nyw + c] = g; ch = true; }
         carry = g;
       }
@@ -1102,16 +1108,26 @@ void launch_frame_begin(const Dims &d, const Scratch &sc, hipStream_t s) {
   hipLaunchKernelGGL(k_frame_begin, dim3(512), dim3(TPB), 0, s, sc.cnt, sc.bin_count, (uint32_t)(d.W * d.H + 1));
 }
 
-void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int force_generic, hipStream_t s) {
+// The frustum reach set depends on the camera pose only, not on the map: it runs on a side stream next to the
+// object moves.
+void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_generic, hipStream_t s) {
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_flood2d), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    lds_attr_set = true;
+  }
   const int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
   const int nyw = (f.bb1[1] >> 6) - (f.bb0[1] >> 6) + 1;
   const size_t n_words = (size_t)ny * nz * sc.wpl;
   hipLaunchKernelGGL(k_vertex_mask, dim3(blocks_for(n_words * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl);
   hipLaunchKernelGGL(k_line_info, dim3(blocks_for((size_t)nyw * nz * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ne,
                      sc.line_ey, sc.line_ez, sc.cnt);
-  hipLaunchKernelGGL(k_flood2d, dim3(1), dim3(TPB), (size_t)nz * nyw * 8, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ey, sc.line_ez,
+  hipLaunchKernelGGL(k_flood2d, dim3(1), dim3(TPB), (size_t)nz * nyw * 8 * 3, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ey, sc.line_ez,
                      sc.line_reach, sc.cnt);
   hipLaunchKernelGGL(k_flood_generic, dim3(1), dim3(1024), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, force_generic, sc.cnt);
+}
+
+void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, hipStream_t s) {
   int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];
   if (bx > 0 && by > 0 && bz > 0) {
     dim3 grid(blocks_for((size_t)bx * by * bz));
@@ -1133,18 +1149,25 @@ void launch_weight(const Dims &d, const Frame &f, const Filter &flt, const State
   hipLaunchKernelGGL(k_weight, dim3(16384), dim3(A7_ROWS, A7_ITEMS), 0, s, d, f, flt, st, sc);
 }
 
-void launch_births(const Dims &d, const Frame &f, const Filter &flt, const BirthOrder &bo, const State &st,
-                   const Scratch &sc, hipStream_t s) {
+// Birth candidates and their stable sort by target voxel depend on the input cloud only: side stream.
+// Returns which double buffer holds the sorted list.
+int launch_birth_prepare(const Dims &d, const Frame &f, const Filter &flt, const BirthOrder &bo, const State &st,
+                         const Scratch &sc, hipStream_t s) {
   const size_t hw = (size_t)d.W * d.H;
   const size_t total = hw * flt.nb;
   if (flt.use_rng) {  // the exclusive rank among valid pixels only feeds the noise-table cursor
     hipLaunchKernelGGL(k_birth_flags, dim3(blocks_for(hw)), dim3(TPB), 0, s, d, bo, sc);
-    exclusive_scan_u32(sc.b_valid, sc.b_rank, hw, sc.scan_scratch, s);
+    exclusive_scan_u32(sc.b_valid, sc.b_rank, hw, sc.scan_scratch_b, s);
   }
   hipLaunchKernelGGL(k_birth_candidates, dim3(blocks_for(total)), dim3(TPB), 0, s, d, f, flt, bo, st, sc);
   if (flt.use_rng) hipLaunchKernelGGL(k_birth_cursor, dim3(1), dim3(64), 0, s, d, flt, sc);
   int nbits = d.x_n + d.y_n + d.z_n + 1;
-  int which = radix_sort_pairs(sc.bkey_a, sc.bval_a, sc.bkey_b, sc.bval_b, total, nbits, sc.sort_scratch, s);
+  return radix_sort_pairs(sc.bkey_a, sc.bval_a, sc.bkey_b, sc.bval_b, total, nbits, sc.sort_scratch, s);
+}
+
+void launch_birth_replay(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, int which,
+                         hipStream_t s) {
+  const size_t total = (size_t)d.W * d.H * flt.nb;
   const uint32_t *skey = which ? sc.bkey_b : sc.bkey_a;
   const uint32_t *sval = which ? sc.bval_b : sc.bval_a;
   dim3 grid(blocks_for(total));

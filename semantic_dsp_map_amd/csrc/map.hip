@@ -58,6 +58,12 @@ struct sdm_map {
   Scratch sc{};
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
+  // side streams: the frustum reach set (pose only) and the birth candidates + sort (input cloud only) do not depend
+  // on the map state, so they run next to the object-move chain and join the main stream through events
+  hipStream_t s_frustum = nullptr, s_birth = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_frustum = nullptr, ev_birth = nullptr;
+  int birth_which = 0;
+  bool side_pending = false;
   float *ck_user = nullptr;
   bool fused_ck = false;  // single-GPU sdm_update: pass 1 writes ck+kappa directly
   int32_t stop_after = 0;
@@ -165,7 +171,7 @@ sdm_status ensure_birth_buffers(sdm_map *m) {
   const size_t hw = (size_t)m->d.W * m->d.H;
   const int nb = std::max(m->flt.nb, 1);
   if (nb <= m->nb_alloc) return SDM_OK;
-  size_t need = std::max(hw * nb, (size_t)m->sc.cap_move);
+  size_t need = hw * nb;
   auto re = [&](auto **p, size_t n) -> hipError_t {
     if (*p) (void)hipFree(*p);
     return dev_alloc(p, n);
@@ -332,6 +338,8 @@ void host_initialize(sdm_map *m) {
 
 sdm_status check_counters(sdm_map *m, Counters *out) {
   Counters c;
+  HIP_TRY(hipStreamSynchronize(m->s_frustum));
+  HIP_TRY(hipStreamSynchronize(m->s_birth));
   HIP_TRY(hipMemcpyAsync(&c, m->sc.cnt, sizeof(Counters), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (out) *out = c;
@@ -432,6 +440,11 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
 
   HIP_TRY(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
   m->stream = m->own_stream;
+  HIP_TRY(hipStreamCreateWithFlags(&m->s_frustum, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&m->s_birth, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_begin, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_frustum, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_birth, hipEventDisableTiming));
   const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t hw = (size_t)d.W * d.H;
   sdm_status rc;
@@ -512,6 +525,12 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   HIP_TRY(hipMemsetAsync(sc.track_to_obj, 0xFF, 65536, m->stream));
   size_t scan_need = std::max({scan_scratch_elems(hw + 1), scan_scratch_elems(mv_cnt_n), scan_scratch_elems((size_t)d.v_count + 1)});
   A(sc.scan_scratch, scan_need + 16);
+  A(sc.scan_scratch_b, scan_scratch_elems(hw + 1) + 16);
+  A(sc.mkey_a, sc.cap_move);
+  A(sc.mval_a, sc.cap_move);
+  A(sc.mkey_b, sc.cap_move);
+  A(sc.mval_b, sc.cap_move);
+  A(sc.msort_scratch, sort_scratch_elems(sc.cap_move) + 16);
   A(sc.cnt, 1);
   A(sc.cur, 1);
   HIP_TRY(hipMemsetAsync(sc.cnt, 0, sizeof(Counters), m->stream));
@@ -552,6 +571,13 @@ sdm_status sdm_destroy(sdm_map *m) {
     if (p) (void)hipFree(p);
   if (m->ev_valid)
     for (int i = 0; i < 9; ++i) (void)hipEventDestroy(m->ev[i]);
+  if (m->s_frustum) (void)hipStreamSynchronize(m->s_frustum);
+  if (m->s_birth) (void)hipStreamSynchronize(m->s_birth);
+  if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
+  if (m->ev_frustum) (void)hipEventDestroy(m->ev_frustum);
+  if (m->ev_birth) (void)hipEventDestroy(m->ev_birth);
+  if (m->s_frustum) (void)hipStreamDestroy(m->s_frustum);
+  if (m->s_birth) (void)hipStreamDestroy(m->s_birth);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   delete m;
   return SDM_OK;
@@ -679,6 +705,22 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
   mark(1);
   if (done(1)) return SDM_OK;
 
+  // fork: everything that only needs this frame's inputs and pose starts now on the side streams
+  HIP_TRY(hipEventRecord(m->ev_begin, s));
+  m->side_pending = false;
+  if (!done(3)) {
+    HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->ev_begin, 0));
+    m->sc.force_generic = m->force_generic_flood;
+    launch_frustum(d, m->f, m->sc, m->force_generic_flood, m->s_frustum);
+    HIP_TRY(hipEventRecord(m->ev_frustum, m->s_frustum));
+    m->side_pending = true;
+  }
+  if (!done(5)) {
+    HIP_TRY(hipStreamWaitEvent(m->s_birth, m->ev_begin, 0));
+    m->birth_which = launch_birth_prepare(d, m->f, m->flt, m->bo, m->st, m->sc, m->s_birth);
+    HIP_TRY(hipEventRecord(m->ev_birth, m->s_birth));
+  }
+
   // P2 (first part): collect the moving objects' particles (semantic_dsp_map.h:588-693)
   if (n_moves > 0) {
     MoveSet ms;
@@ -744,9 +786,9 @@ sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev) {
   mark(3);
   if (done(3)) return SDM_OK;
 
-  // U1: visibility + binning (semantic_dsp_map.h:749)
-  m->sc.force_generic = m->force_generic_flood;
-  launch_visibility(d, m->f, m->st, m->sc, m->force_generic_flood, s);
+  // U1: visibility + binning (semantic_dsp_map.h:749); join the frustum stream first
+  HIP_TRY(hipStreamWaitEvent(s, m->ev_frustum, 0));
+  launch_visibility(d, m->f, m->st, m->sc, s);
   mark(4);
   if (done(4)) return SDM_OK;
 
@@ -807,7 +849,8 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
   launch_weight(d, m->f, m->flt, m->st, m->sc, s);
   mark(5);
   if (done(5)) return SDM_OK;
-  launch_births(d, m->f, m->flt, m->bo, m->st, m->sc, s);
+  HIP_TRY(hipStreamWaitEvent(s, m->ev_birth, 0));  // join the birth-candidate stream
+  launch_birth_replay(d, m->f, m->flt, m->st, m->sc, m->birth_which, s);
   mark(6);
   if (done(6)) return SDM_OK;
   if (!(flags & SDM_SKIP_OCCUPANCY)) launch_occupancy(d, m->flt, m->st, s);
@@ -830,6 +873,8 @@ sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *c
 sdm_status sdm_synchronize(sdm_map *m) {
   if (!m) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->s_frustum));
+  HIP_TRY(hipStreamSynchronize(m->s_birth));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return check_counters(m, nullptr);
 }

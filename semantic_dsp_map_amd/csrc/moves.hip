@@ -179,8 +179,8 @@ __global__ __launch_bounds__(TPB) void k_move_init_keys(Dims d, Scratch sc) {
   const uint32_t total = *sc.mv_total;
   uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    sc.bkey_a[e] = d.V;  // "not mine": sorts behind every real voxel and is skipped by the replay
-    sc.bval_a[e] = e;
+    sc.mkey_a[e] = d.V;  // "not mine": sorts behind every real voxel and is skipped by the replay
+    sc.mval_a[e] = e;
   }
 }
 
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter 
       sc.mv_label[e] = plabel;
       sc.mv_status[e] = pstatus;
       sc.mv_owner[e] = powner;
-      sc.bkey_a[e] = v;
+      sc.mkey_a[e] = v;
     } else if (sc.halo_send) {  // crosses into another slab: export
       uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(sc.halo_send), 1u);
       if (k < sc.halo_cap) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int wor
     sc.mv_owner[e] = (uint16_t)(r.owner_label_status & 0xffffu);
     sc.mv_label[e] = (uint8_t)((r.owner_label_status >> 16) & 0xffu);
     sc.mv_status[e] = (uint8_t)(r.owner_label_status >> 24);
-    sc.bkey_a[e] = r.voxel;
+    sc.mkey_a[e] = r.voxel;
   }
 }
 
@@ -409,9 +409,9 @@ void launch_moves_finish(const Dims &d, const Filter &flt, int n_obj, const Stat
   if (n_obj <= 0) return;
   if (world > 1 && sc.halo_recv) hipLaunchKernelGGL(k_move_import, dim3(64, world), dim3(TPB), 0, s, d, sc, world, rank);
   int nbits = d.x_n + d.y_n + d.z_n + 1;
-  int which = radix_sort_pairs(sc.bkey_a, sc.bval_a, sc.bkey_b, sc.bval_b, sc.cap_move, nbits, sc.sort_scratch, s, sc.mv_total);
-  const uint32_t *skey = which ? sc.bkey_b : sc.bkey_a;
-  const uint32_t *sval = which ? sc.bval_b : sc.bval_a;
+  int which = radix_sort_pairs(sc.mkey_a, sc.mval_a, sc.mkey_b, sc.mval_b, sc.cap_move, nbits, sc.msort_scratch, s, sc.mv_total);
+  const uint32_t *skey = which ? sc.mkey_b : sc.mkey_a;
+  const uint32_t *sval = which ? sc.mval_b : sc.mval_a;
   dim3 grid(blocks_for(sc.cap_move));
   switch (d.p_n) {
     case 1: hipLaunchKernelGGL(k_move_replay<2>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;

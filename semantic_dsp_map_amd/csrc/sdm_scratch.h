@@ -53,18 +53,24 @@ struct Scratch {
   uint8_t *track_to_obj = nullptr; // 65536 entries: moving-object rank of a track id, 0xFF = not moving
   // generic
   uint32_t *scan_scratch = nullptr, *sort_scratch = nullptr;
+  uint32_t *scan_scratch_b = nullptr;   // births run on their own stream
+  // sort double buffers of the move re-insertion (the birth sort runs concurrently on another stream)
+  uint32_t *mkey_a = nullptr, *mval_a = nullptr, *mkey_b = nullptr, *mval_b = nullptr, *msort_scratch = nullptr;
   Counters *cnt = nullptr;
   Cursors *cur = nullptr;
 };
 
 void launch_frame_begin(const Dims &d, const Scratch &sc, hipStream_t s);
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s);
-void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int force_generic, hipStream_t s);
+void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_generic, hipStream_t s);
+void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, hipStream_t s);
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s);
 void launch_weight(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
-void launch_births(const Dims &d, const Frame &f, const Filter &flt, const BirthOrder &bo, const State &st,
-                   const Scratch &sc, hipStream_t s);
+int launch_birth_prepare(const Dims &d, const Frame &f, const Filter &flt, const BirthOrder &bo, const State &st,
+                         const Scratch &sc, hipStream_t s);
+void launch_birth_replay(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, int which,
+                         hipStream_t s);
 void launch_count_live(const Dims &d, const State &st, unsigned long long *out, hipStream_t s);
 void launch_count_owner(const Dims &d, const State &st, uint16_t track, unsigned long long *out, hipStream_t s);
 void launch_pack_pos4(float4 *pos4, const float *px, const float *py, const float *pz, const uint8_t *forget, size_t n,
