@@ -507,13 +507,15 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(m->d_ck_part, hw);
   A(sc.b_valid, hw + 1);
   A(sc.b_rank, hw + 1);
-  sc.cap_move = (uint32_t)std::min<size_t>(n_slots, (size_t)1 << 20);
+  sc.cap_move = (uint32_t)std::min<size_t>(n_slots, (size_t)1 << 18);  // moved particles per frame (objects hold <= ~1e5)
   A(sc.mv_src, sc.cap_move);
   A(sc.mv_total, 4);
   A(sc.mv_ebase, MAX_MOVE_OBJECTS);
   A(m->d_counts_local, HALO_OBJ);
-  const size_t mv_cnt_n = (size_t)MAX_MOVE_OBJECTS * move_blocks(d) + 1;
+  const size_t mv_cnt_n = move_count_elems();
   A(sc.mv_cnt, mv_cnt_n);
+  A(sc.mv_list, 8192);
+  A(sc.mv_nlist, 4);
   A(sc.mv_pos, sc.cap_move);
   A(sc.mv_w, sc.cap_move);
   A(sc.mv_ts, sc.cap_move);

@@ -24,6 +24,7 @@ constexpr int MV_ITEMS = 16;
 constexpr int MV_CHUNK = TPB * MV_ITEMS;  // slots per block
 constexpr int MV_WAVES = TPB / 64;
 static_assert(MV_CHUNK == (int)OWNER_CHUNK, "one move-sweep block per owner_flag byte");
+constexpr uint32_t MV_LIST_CAP = 8192;  // flagged chunks handled per frame (= 33 M slots with an owner nearby)
 
 // rank of the moving object that owns a slot (0xFF if none): the <= 64 moving track ids sit in LDS
 __device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint16_t *tracks, int n_obj) {
@@ -34,99 +35,140 @@ __device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint16_t *tracks
   return o;
 }
 
-// pass 1: per-block, per-object member counts.  cnt[obj * n_blocks + block].  Chunks whose owner_flag is clear
-// are not read at all; a flagged chunk that turns out to hold no owner any more clears its flag.
+// pass 0: ascending list of the chunks whose owner_flag is set (one workgroup, ballot compaction).  Dynamic objects
+// touch a few hundred of the map's tens of thousands of chunks; everything after this works on the list only.
+__global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *__restrict__ owner_flag, uint32_t n_flags,
+                                                      uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Counters *cnt) {
+  __shared__ uint32_t wave_cnt[16];
+  __shared__ uint32_t running;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_flags; base += 1024) {
+    uint32_t i = base + threadIdx.x;
+    bool f = i < n_flags && owner_flag[i] != 0;
+    uint64_t m = __ballot(f);
+    if (lane == 0) wave_cnt[wid] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = running;
+    for (int w = 0; w < wid; ++w) off += wave_cnt[w];
+    if (f) {
+      uint32_t pos = off + (uint32_t)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+      if (pos < MV_LIST_CAP) list[pos] = i;
+      else cnt->overflow = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < 16; ++w) t += wave_cnt[w];
+      running += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_list = running < MV_LIST_CAP ? running : MV_LIST_CAP;
+}
+
+// pass 1: per-chunk, per-object member counts.  cnt[obj * MV_LIST_CAP + list position].  A flagged chunk that turns out
+// to hold no owner any more clears its flag.
 __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__ owner, size_t n_slots,
-                                                    const MoveSet *__restrict__ ms, uint32_t *__restrict__ cnt,
-                                                    uint32_t n_blocks, int n_obj, uint8_t *__restrict__ owner_flag) {
+                                                    const MoveSet *__restrict__ ms, uint32_t *__restrict__ cnt, int n_obj,
+                                                    uint8_t *__restrict__ owner_flag, const uint32_t *__restrict__ list,
+                                                    const uint32_t *__restrict__ n_list) {
   __shared__ uint32_t c[MAX_MOVE_OBJECTS];
   __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
   __shared__ uint32_t any_owner;
-  if (owner_flag[blockIdx.x] == 0) {
-    if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * n_blocks + blockIdx.x] = 0;
-    return;
-  }
-  if (threadIdx.x < MAX_MOVE_OBJECTS) {
-    c[threadIdx.x] = 0;
-    tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms->track[threadIdx.x] : OWNER_NONE;
-  }
-  if (threadIdx.x == 0) any_owner = 0;
-  __syncthreads();
-  size_t base = (size_t)blockIdx.x * MV_CHUNK;
-#pragma unroll 4
-  for (int r = 0; r < MV_ITEMS; ++r) {
-    size_t i = base + (size_t)r * TPB + threadIdx.x;
-    if (i < n_slots) {
-      uint16_t ow = owner[i];
-      if (ow != OWNER_NONE) any_owner = 1;
-      uint8_t o = obj_of(ow, tracks, n_obj);
-      if (o != 0xFF) atomicAdd(&c[o], 1u);
+  const uint32_t n = *n_list;
+  if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms->track[threadIdx.x] : OWNER_NONE;
+  for (uint32_t pos = blockIdx.x; pos < MV_LIST_CAP; pos += gridDim.x) {
+    if (pos >= n) {  // unused tail of the count matrix
+      if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * MV_LIST_CAP + pos] = 0;
+      continue;
     }
+    __syncthreads();
+    if (threadIdx.x < MAX_MOVE_OBJECTS) c[threadIdx.x] = 0;
+    if (threadIdx.x == 0) any_owner = 0;
+    __syncthreads();
+    const uint32_t chunk = list[pos];
+    size_t base = (size_t)chunk * MV_CHUNK;
+#pragma unroll 4
+    for (int r = 0; r < MV_ITEMS; ++r) {
+      size_t i = base + (size_t)r * TPB + threadIdx.x;
+      if (i < n_slots) {
+        uint16_t ow = owner[i];
+        if (ow != OWNER_NONE) any_owner = 1;
+        uint8_t o = obj_of(ow, tracks, n_obj);
+        if (o != 0xFF) atomicAdd(&c[o], 1u);
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * MV_LIST_CAP + pos] = c[threadIdx.x];
+    if (threadIdx.x == 0 && any_owner == 0) owner_flag[chunk] = 0;
   }
-  __syncthreads();
-  if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * n_blocks + blockIdx.x] = c[threadIdx.x];
-  if (threadIdx.x == 0 && any_owner == 0) owner_flag[blockIdx.x] = 0;
 }
 
 // pass 2 (after the exclusive scan of cnt): stable scatter of the member indices.
 __global__ __launch_bounds__(TPB) void k_move_scatter(const uint16_t *__restrict__ owner, size_t n_slots, size_t slot_base,
                                                       const MoveSet *__restrict__ ms, const uint32_t *__restrict__ offs,
-                                                      uint32_t n_blocks, int n_obj, uint32_t *__restrict__ mv_src,
-                                                      uint32_t cap, Counters *cnt) {
+                                                      int n_obj, uint32_t *__restrict__ mv_src, uint32_t cap, Counters *cnt,
+                                                      const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list) {
   __shared__ uint32_t obj_base[MAX_MOVE_OBJECTS];
   __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
   __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
   __shared__ uint32_t block_total;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (threadIdx.x == 0) block_total = 0;
+  const uint32_t n = *n_list;
   if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms->track[threadIdx.x] : OWNER_NONE;
-  __syncthreads();
-  if ((int)threadIdx.x < n_obj) {
-    uint32_t o0 = offs[(size_t)threadIdx.x * n_blocks + blockIdx.x];
-    uint32_t o1 = offs[(size_t)threadIdx.x * n_blocks + blockIdx.x + 1];  // next block (or next object's first block)
-    obj_base[threadIdx.x] = o0;
-    if (o1 != o0) atomicAdd(&block_total, o1 - o0);
-  }
-  __syncthreads();
-  if (block_total == 0) return;  // no member of any moving object in this chunk
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  size_t base = (size_t)blockIdx.x * MV_CHUNK;
-  for (int r = 0; r < MV_ITEMS; ++r) {
-    if (threadIdx.x < MAX_MOVE_OBJECTS) {
-#pragma unroll
-      for (int w = 0; w < MV_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+  for (uint32_t pos = blockIdx.x; pos < n; pos += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x == 0) block_total = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < n_obj) {
+      uint32_t o0 = offs[(size_t)threadIdx.x * MV_LIST_CAP + pos];
+      uint32_t o1 = offs[(size_t)threadIdx.x * MV_LIST_CAP + pos + 1];  // next position (or next object's first)
+      obj_base[threadIdx.x] = o0;
+      if (o1 != o0) atomicAdd(&block_total, o1 - o0);
     }
     __syncthreads();
-    size_t i = base + (size_t)r * TPB + threadIdx.x;
-    uint8_t o = 0xFF;
-    if (i < n_slots) o = obj_of(owner[i], tracks, n_obj);
-    bool valid = o != 0xFF;
-    uint64_t peers = __ballot(valid);
+    if (block_total == 0) continue;  // no member of any moving object in this chunk
+    size_t base = (size_t)list[pos] * MV_CHUNK;
+    for (int r = 0; r < MV_ITEMS; ++r) {
+      if (threadIdx.x < MAX_MOVE_OBJECTS) {
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      bool bit = (o >> b) & 1u;
-      uint64_t m = __ballot(bit);
-      peers &= bit ? m : ~m;
-    }
-    uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
-    if (valid && rank_in_wave == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
-    __syncthreads();
-    if (valid) {
-      uint32_t off = obj_base[o] + rank_in_wave;
+        for (int w = 0; w < MV_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+      }
+      __syncthreads();
+      size_t i = base + (size_t)r * TPB + threadIdx.x;
+      uint8_t o = 0xFF;
+      if (i < n_slots) o = obj_of(owner[i], tracks, n_obj);
+      bool valid = o != 0xFF;
+      uint64_t peers = __ballot(valid);
 #pragma unroll
-      for (int w = 0; w < MV_WAVES; ++w)
-        if (w < wid) off += wave_cnt[w][o];
-      if (off < cap) mv_src[off] = (uint32_t)(slot_base + i);
-      else cnt->overflow = 1;
-    }
-    __syncthreads();
-    if (threadIdx.x < MAX_MOVE_OBJECTS) {
-      uint32_t add = 0;
+      for (int b = 0; b < 6; ++b) {
+        bool bit = (o >> b) & 1u;
+        uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+      }
+      uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
+      if (valid && rank_in_wave == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
+      __syncthreads();
+      if (valid) {
+        uint32_t off = obj_base[o] + rank_in_wave;
 #pragma unroll
-      for (int w = 0; w < MV_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
-      obj_base[threadIdx.x] += add;
+        for (int w = 0; w < MV_WAVES; ++w)
+          if (w < wid) off += wave_cnt[w][o];
+        if (off < cap) mv_src[off] = (uint32_t)(slot_base + i);
+        else cnt->overflow = 1;
+      }
+      __syncthreads();
+      if (threadIdx.x < MAX_MOVE_OBJECTS) {
+        uint32_t add = 0;
+#pragma unroll
+        for (int w = 0; w < MV_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
+        obj_base[threadIdx.x] += add;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
@@ -149,10 +191,10 @@ struct HaloRecord {
 };
 static_assert(sizeof(HaloRecord) == HALO_RECORD_BYTES, "halo record layout");
 
-__global__ void k_move_local_counts(const uint32_t *__restrict__ offs, uint32_t n_blocks, int n_obj, int32_t *counts_local) {
+__global__ void k_move_local_counts(const uint32_t *__restrict__ offs, int n_obj, int32_t *counts_local) {
   int k = threadIdx.x;
   if (k >= HALO_OBJ) return;
-  counts_local[k] = k < n_obj ? (int32_t)(offs[(size_t)(k + 1) * n_blocks] - offs[(size_t)k * n_blocks]) : 0;
+  counts_local[k] = k < n_obj ? (int32_t)(offs[(size_t)(k + 1) * MV_LIST_CAP] - offs[(size_t)k * MV_LIST_CAP]) : 0;
 }
 
 // one thread: e_base[k], total; also resets the export counter
@@ -187,8 +229,9 @@ __global__ __launch_bounds__(TPB) void k_move_init_keys(Dims d, Scratch sc) {
 // phase 1 of moveParticlesInSetsByTransformations (operations.h:331-349): copy, transform + table noise,
 // delete the original.  The noise cursor advances by three per particle in global rank order.
 __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter flt, const MoveSet *ms, State st, Scratch sc,
-                                                        const uint32_t *__restrict__ offs, uint32_t n_blocks, int n_obj) {
+                                                        const uint32_t *__restrict__ offs, int n_obj, int write_all_keys) {
   if (sc.cnt->overflow) return;
+  const uint32_t n_blocks = MV_LIST_CAP;
   const uint32_t local_total = offs[(size_t)n_obj * n_blocks];
   const size_t slot_base = (size_t)d.v_begin << d.p_n;
   uint32_t stride = gridDim.x * blockDim.x;
@@ -216,6 +259,10 @@ __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter 
     st.owner[li] = OWNER_NONE;   // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
     uint32_t rx, ry, rz;
     uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
+    if (write_all_keys && e < sc.cap_move) {  // single shard: every rank is written here, no separate key init pass
+      sc.mkey_a[e] = d.V;
+      sc.mval_a[e] = e;
+    }
     if (v == INVALID_INDEX) continue;  // left the map: dropped (operations.h:799-802)
     if (rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) {
       if (e >= sc.cap_move) continue;
@@ -375,6 +422,7 @@ void launch_owner_flags(const Dims &d, const State &st, hipStream_t s) {
 }
 
 size_t move_blocks(const Dims &d) { return ((size_t)d.v_count * d.S + MV_CHUNK - 1) / MV_CHUNK; }
+size_t move_count_elems() { return (size_t)MAX_MOVE_OBJECTS * MV_LIST_CAP + 1; }
 
 // step 1: collect every moving object's members (ascending index) and publish the per-object counts
 void launch_moves_count(const Dims &d, const MoveSet *ms_dev, int n_obj, const State &st, const Scratch &sc, int32_t *counts_local,
@@ -382,25 +430,25 @@ void launch_moves_count(const Dims &d, const MoveSet *ms_dev, int n_obj, const S
   if (n_obj <= 0) return;
   const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t slot_base = (size_t)d.v_begin << d.p_n;
-  const uint32_t n_blocks = (uint32_t)move_blocks(d);
-  const size_t n_cnt = (size_t)n_obj * n_blocks + 1;
+  const size_t n_cnt = (size_t)n_obj * MV_LIST_CAP + 1;
+  hipLaunchKernelGGL(k_move_chunks, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cnt);
   hipMemsetAsync(sc.mv_cnt + (n_cnt - 1), 0, 4, s);
-  hipLaunchKernelGGL(k_move_count, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, ms_dev, sc.mv_cnt, n_blocks, n_obj,
-                     st.owner_flag);
+  hipLaunchKernelGGL(k_move_count, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, ms_dev, sc.mv_cnt, n_obj, st.owner_flag, sc.mv_list,
+                     sc.mv_nlist);
   exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch, s);
-  hipLaunchKernelGGL(k_move_scatter, dim3(n_blocks), dim3(TPB), 0, s, st.owner, n_slots, slot_base, ms_dev, sc.mv_cnt,
-                     n_blocks, n_obj, sc.mv_src, sc.cap_move, sc.cnt);
-  hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, n_blocks, n_obj, counts_local);
+  hipLaunchKernelGGL(k_move_scatter, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, slot_base, ms_dev, sc.mv_cnt, n_obj, sc.mv_src,
+                     sc.cap_move, sc.cnt, sc.mv_list, sc.mv_nlist);
+  hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, n_obj, counts_local);
 }
 
 // step 2 (after the counts of all shards are known): global ranks, transform, export of slab-crossing copies
 void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet *ms_dev, int n_obj, const State &st,
                             const Scratch &sc, const int32_t *counts_all, int world, int rank, hipStream_t s) {
   if (n_obj <= 0) return;
-  const uint32_t n_blocks = (uint32_t)move_blocks(d);
   hipLaunchKernelGGL(k_move_bases, dim3(1), dim3(64), 0, s, counts_all, world, rank, n_obj, sc);
-  hipLaunchKernelGGL(k_move_init_keys, dim3(256), dim3(TPB), 0, s, d, sc);
-  hipLaunchKernelGGL(k_move_transform, dim3(1024), dim3(TPB), 0, s, d, f, flt, ms_dev, st, sc, sc.mv_cnt, n_blocks, n_obj);
+  // with several shards most ranks of the global list belong to other shards: they must read "not mine"
+  if (world > 1) hipLaunchKernelGGL(k_move_init_keys, dim3(256), dim3(TPB), 0, s, d, sc);
+  hipLaunchKernelGGL(k_move_transform, dim3(256), dim3(TPB), 0, s, d, f, flt, ms_dev, st, sc, sc.mv_cnt, n_obj, world > 1 ? 0 : 1);
 }
 
 // step 3 (after the export buffers of all shards are gathered): import, stable sort by voxel, ordered replay

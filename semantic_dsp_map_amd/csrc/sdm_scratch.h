@@ -38,7 +38,8 @@ struct Scratch {
   float4 *bpos = nullptr;
   // object moves
   uint32_t *mv_src = nullptr;      // source particle index of every moved particle, (object, index) order
-  uint32_t *mv_cnt = nullptr;      // per-block per-object counts / offsets
+  uint32_t *mv_cnt = nullptr;      // per-chunk per-object counts / offsets
+  uint32_t *mv_list = nullptr, *mv_nlist = nullptr;  // ascending list of chunks that may hold owned slots
   uint32_t *mv_total = nullptr;    // per-object totals + exclusive offsets
   float4 *mv_pos = nullptr;        // copies: position (+forget bits)
   float *mv_w = nullptr;
@@ -91,6 +92,7 @@ struct MoveSet {
   uint16_t track[MAX_MOVE_OBJECTS];
 };
 size_t move_blocks(const Dims &d);
+size_t move_count_elems();
 void launch_owner_flags(const Dims &d, const State &st, hipStream_t s);
 void launch_moves_count(const Dims &d, const MoveSet *ms_dev, int n_obj, const State &st, const Scratch &sc, int32_t *counts_local,
                         hipStream_t s);
