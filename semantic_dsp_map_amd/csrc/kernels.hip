@@ -287,12 +287,12 @@ __device__ __forceinline__ uint64_t fill64(uint64_t g, uint64_t p) {
 __global__ __launch_bounds__(TPB) void k_flood2d(Dims d, Frame f, const uint64_t *__restrict__ M, int wpl, int wy,
                                                  const uint64_t *__restrict__ EY, const uint64_t *__restrict__ EZ,
                                                  uint64_t *__restrict__ R2D, Counters *cnt) {
-  extern __shared__ uint64_t lds[];  // r, ey, ez: [nz][nyw] each
+  extern __shared__ uint64_t lds[];  // r, ey, ez, pp: [nz][nyw] each
   __shared__ uint32_t changed;
   const int VY = d.NY + 1;
   const int yw0 = f.bb0[1] >> 6, yw1 = f.bb1[1] >> 6;
   const int nyw = yw1 - yw0 + 1, nz = f.bb1[2] - f.bb0[2] + 1, z0 = f.bb0[2];
-  uint64_t *r = lds, *ey = lds + nz * nyw, *ez = lds + 2 * nz * nyw;
+  uint64_t *r = lds, *ey = lds + nz * nyw, *ez = lds + 2 * nz * nyw, *pp = lds + 3 * nz * nyw;
   for (int i = threadIdx.x; i < nz * nyw; i += blockDim.x) {
     r[i] = 0;
     const size_t g = (size_t)(z0 + i / nyw) * wy + yw0 + i % nyw;
@@ -341,27 +341,50 @@ __global__ __launch_bounds__(TPB) void k_flood2d(Dims d, Frame f, const uint64_t
       if (ch) changed = 1;
     }
     __syncthreads();
-    // carry sweeps along z, one thread per y word; edge bit y of row z joins (y,z) and (y,z+1)
-    for (int c = threadIdx.x; c < nyw; c += blockDim.x) {
-      bool ch = false;
-      uint64_t carry = 0;
-#pragma unroll 8
-      for (int z = 0; z < nz; ++z) {
-        uint64_t old = r[z * nyw + c];
-        uint64_t g = old;
-        if (z > 0) g |= carry & ez[(z - 1) * nyw + c];
-        if (g != old) { r[z * nyw + c] = g; ch = true; }
-        carry = g;
+    // propagation along z as a parallel prefix (generate = r, propagate = edge to the neighbour row), log2(nz) steps
+    // in each direction; every thread owns the (row, word) entries i = tid, tid + 256, ...
+    for (int dir = 0; dir < 2; ++dir) {
+      for (int i = threadIdx.x; i < nz * nyw; i += blockDim.x) {
+        const int z = i / nyw;
+        // up: row z is entered from z-1 through edge row z-1; down: from z+1 through edge row z
+        pp[i] = dir == 0 ? (z > 0 ? ez[i - nyw] : 0ull) : (z < nz - 1 ? ez[i] : 0ull);
       }
-      carry = 0;
-#pragma unroll 8
-      for (int z = nz - 1; z >= 0; --z) {
-        uint64_t old = r[z * nyw + c];
-        uint64_t g = old | (carry & ez[z * nyw + c]);
-        if (g != old) { r[z * nyw + c] = g; ch = true; }
-        carry = g;
+      __syncthreads();
+      for (int dist = 1; dist < nz; dist <<= 1) {
+        uint64_t gn[3], pn[3];  // neighbour values of this thread's (at most 3) entries; nz*nyw <= 513*9 > 3*256 -> loop
+        for (int base = 0; base < nz * nyw; base += 3 * (int)blockDim.x) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const int i = base + q * (int)blockDim.x + (int)threadIdx.x;
+            gn[q] = 0;
+            pn[q] = 0;
+            if (i < nz * nyw) {
+              const int z = i / nyw;
+              const int zn = dir == 0 ? z - dist : z + dist;
+              if (zn >= 0 && zn < nz) {
+                const int in = i + (zn - z) * nyw;
+                gn[q] = r[in];
+                pn[q] = pp[in];
+              }
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const int i = base + q * (int)blockDim.x + (int)threadIdx.x;
+            if (i < nz * nyw) {
+              const uint64_t p = pp[i], old = r[i];
+              const uint64_t g = old | (p & gn[q]);
+              if (g != old) {
+                r[i] = g;
+                changed = 1;
+              }
+              pp[i] = p & pn[q];
+            }
+          }
+          __syncthreads();
+        }
       }
-      if (ch) changed = 1;
     }
     __syncthreads();
     if (!changed) break;
@@ -1113,7 +1136,7 @@ void launch_frame_begin(const Dims &d, const Scratch &sc, hipStream_t s) {
 void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_generic, hipStream_t s) {
   static bool lds_attr_set = false;
   if (!lds_attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_flood2d), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_flood2d), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     lds_attr_set = true;
   }
   const int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
@@ -1122,7 +1145,7 @@ void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_
   hipLaunchKernelGGL(k_vertex_mask, dim3(blocks_for(n_words * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl);
   hipLaunchKernelGGL(k_line_info, dim3(blocks_for((size_t)nyw * nz * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ne,
                      sc.line_ey, sc.line_ez, sc.cnt);
-  hipLaunchKernelGGL(k_flood2d, dim3(1), dim3(TPB), (size_t)nz * nyw * 8 * 3, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ey, sc.line_ez,
+  hipLaunchKernelGGL(k_flood2d, dim3(1), dim3(TPB), (size_t)nz * nyw * 8 * 4, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ey, sc.line_ez,
                      sc.line_reach, sc.cnt);
   hipLaunchKernelGGL(k_flood_generic, dim3(1), dim3(1024), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, force_generic, sc.cnt);
 }

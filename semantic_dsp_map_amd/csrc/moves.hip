@@ -35,32 +35,58 @@ __device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint16_t *tracks
   return o;
 }
 
-// pass 0: ascending list of the chunks whose owner_flag is set (one workgroup, ballot compaction).  Dynamic objects
-// touch a few hundred of the map's tens of thousands of chunks; everything after this works on the list only.
+// pass 0: ascending list of the chunks whose owner_flag is set (one workgroup; each thread takes 32 consecutive
+// flag bytes, one block-wide scan of the per-thread counts per 32 K flags).  Dynamic objects touch a few hundred of
+// the map's tens of thousands of chunks; everything after this works on the list only.
 __global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *__restrict__ owner_flag, uint32_t n_flags,
                                                       uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Counters *cnt) {
-  __shared__ uint32_t wave_cnt[16];
+  __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t running;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) running = 0;
   __syncthreads();
-  for (uint32_t base = 0; base < n_flags; base += 1024) {
-    uint32_t i = base + threadIdx.x;
-    bool f = i < n_flags && owner_flag[i] != 0;
-    uint64_t m = __ballot(f);
-    if (lane == 0) wave_cnt[wid] = (uint32_t)__popcll(m);
+  constexpr uint32_t PER = 32;
+  for (uint32_t tile = 0; tile < n_flags; tile += 1024 * PER) {
+    const uint32_t first = tile + threadIdx.x * PER;
+    uint32_t mask = 0;  // bit j: flag first + j is set
+    if (first + PER <= n_flags && ((size_t)(owner_flag + first) & 15) == 0) {
+      const uint4 a = *reinterpret_cast<const uint4 *>(owner_flag + first);
+      const uint4 b4 = *reinterpret_cast<const uint4 *>(owner_flag + first + 16);
+      const uint32_t w[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((w[q] >> (8 * j)) & 0xffu) mask |= 1u << (4 * q + j);
+    } else {
+      for (uint32_t j = 0; j < PER; ++j)
+        if (first + j < n_flags && owner_flag[first + j]) mask |= 1u << j;
+    }
+    const uint32_t c = (uint32_t)__popc(mask);
+    // block exclusive scan of c
+    uint32_t inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t nb = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += nb;
+    }
+    if (lane == 63) wave_tot[wid] = inc;
     __syncthreads();
-    uint32_t off = running;
-    for (int w = 0; w < wid; ++w) off += wave_cnt[w];
-    if (f) {
-      uint32_t pos = off + (uint32_t)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-      if (pos < MV_LIST_CAP) list[pos] = i;
+    uint32_t base = running;
+    for (int w2 = 0; w2 < wid; ++w2) base += wave_tot[w2];
+    uint32_t pos = base + inc - c;
+    uint32_t mm = mask;
+    while (mm) {
+      const int j = __ffs((int)mm) - 1;
+      mm &= mm - 1;
+      if (pos < MV_LIST_CAP) list[pos] = first + (uint32_t)j;
       else cnt->overflow = 1;
+      ++pos;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t t = 0;
-      for (int w = 0; w < 16; ++w) t += wave_cnt[w];
+      for (int w2 = 0; w2 < 16; ++w2) t += wave_tot[w2];
       running += t;
     }
     __syncthreads();
