@@ -73,9 +73,15 @@ __global__ __launch_bounds__(TPB) void k_clear_status(uint8_t *__restrict__ stat
 }
 
 // start of frame: zero the per-frame counters and the per-pixel bin counts (one launch instead of two memsets)
-__global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__restrict__ bin_count, uint32_t n_bins) {
+__global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__restrict__ bin_count, uint32_t n_bins,
+                                                      State st, StampUpdates su) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < sizeof(Counters) / 4) reinterpret_cast<uint32_t *>(cnt)[i] = 0;
+  if (i < (uint32_t)su.n) {  // this frame's recycled slabs (no host-to-device copy of the stamp arrays)
+    const uint32_t e = su.entry[i], axis = e >> 12, idx = e & 0xfffu;
+    uint32_t *arr = axis == 0 ? st.stamps_x : (axis == 1 ? st.stamps_y : st.stamps_z);
+    arr[idx] = su.value;
+  }
   for (; i < n_bins; i += gridDim.x * blockDim.x) bin_count[i] = 0;
 }
 
@@ -1127,8 +1133,8 @@ void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStre
   SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st);
 }
 
-void launch_frame_begin(const Dims &d, const Scratch &sc, hipStream_t s) {
-  hipLaunchKernelGGL(k_frame_begin, dim3(512), dim3(TPB), 0, s, sc.cnt, sc.bin_count, (uint32_t)(d.W * d.H + 1));
+void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s) {
+  hipLaunchKernelGGL(k_frame_begin, dim3(512), dim3(TPB), 0, s, sc.cnt, sc.bin_count, (uint32_t)(d.W * d.H + 1), st, su);
 }
 
 // The frustum reach set depends on the camera pose only, not on the map: it runs on a side stream next to the

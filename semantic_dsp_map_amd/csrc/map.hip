@@ -88,6 +88,9 @@ struct sdm_map {
   float forgetting_function[5]{};
   bool forgetting_initialized = false;
   float cam_R[9]{}, cam_p[3]{};
+  StampUpdates stamp_updates{};
+  bool stamps_dirty = true;  // device copy of the stamp arrays needs a full upload
+  MoveSet moveset{};
 
   // owned device buffers for inputs
   float *d_depth = nullptr;
@@ -199,11 +202,16 @@ void update_ring_index_params(sdm_map *m) {
   for (int a = 0; a < 3; ++a) {
     const int new_moved = steps[a] - m->moved_steps[a];
     const int n = (int)N[a];
+    auto stamp = [&](uint32_t idx) {
+      (*st[a])[idx] = m->global_time_stamp;
+      StampUpdates &su = m->stamp_updates;
+      if (su.n < MAX_STAMP_UPDATES) su.entry[su.n++] = (uint16_t)((a << 12) | idx);
+      else m->stamps_dirty = true;  // too many for the kernel-argument list: fall back to a full upload
+    };
     if (new_moved > 0) {
-      for (int i = 0; i < new_moved; ++i) (*st[a])[axis_correct(i + m->eq_steps[a], N[a])] = m->global_time_stamp;
+      for (int i = 0; i < new_moved; ++i) stamp(axis_correct(i + m->eq_steps[a], N[a]));
     } else if (new_moved < 0) {
-      for (int i = 0; i < -new_moved; ++i)
-        (*st[a])[axis_correct(n - 1 - i + m->eq_steps[a], N[a])] = m->global_time_stamp;
+      for (int i = 0; i < -new_moved; ++i) stamp(axis_correct(n - 1 - i + m->eq_steps[a], N[a]));
     }
   }
   for (int a = 0; a < 3; ++a) {
@@ -323,6 +331,7 @@ void sync_frame_scalars(sdm_map *m) {
 }
 
 sdm_status upload_stamps(sdm_map *m) {
+  m->stamps_dirty = false;
   HIP_TRY(hipMemcpyAsync(m->st.stamps_x, m->stamps_x.data(), m->d.NX * 4, hipMemcpyHostToDevice, m->stream));
   HIP_TRY(hipMemcpyAsync(m->st.stamps_y, m->stamps_y.data(), m->d.NY * 4, hipMemcpyHostToDevice, m->stream));
   HIP_TRY(hipMemcpyAsync(m->st.stamps_z, m->stamps_z.data(), m->d.NZ * 4, hipMemcpyHostToDevice, m->stream));
@@ -685,7 +694,18 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
 
   m->global_time_stamp += 1;  // semantic_dsp_map.h:173
   mark(0);
-  launch_frame_begin(d, m->sc, s);
+  // P1: ego-centre ring shift (semantic_dsp_map.h:584-585); the recycled slabs' stamps ride along with the
+  // frame-begin kernel as kernel arguments
+  m->stamp_updates.n = 0;
+  m->stamp_updates.value = m->global_time_stamp;
+  update_ego_center(m, cam_pos);
+  sync_frame_scalars(m);
+  sdm_status rc = SDM_OK;
+  if (m->stamps_dirty) {
+    if ((rc = upload_stamps(m)) != SDM_OK) return rc;
+    m->stamp_updates.n = 0;
+  }
+  launch_frame_begin(d, m->st, m->sc, m->stamp_updates, s);
   if (flags & SDM_INPUT_ON_DEVICE) {
     m->sc.depth = depth;
     m->sc.cloud = cloud;
@@ -695,11 +715,6 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
     m->sc.depth = m->d_depth;
     m->sc.cloud = m->d_cloud;
   }
-  // P1: ego-centre ring shift (semantic_dsp_map.h:584-585)
-  update_ego_center(m, cam_pos);
-  sync_frame_scalars(m);
-  sdm_status rc = upload_stamps(m);
-  if (rc != SDM_OK) return rc;
   refresh_filter(m);
   m->forgetting_initialized = true;  // the reference freezes its forgetting table at the first update
   compute_extrinsic(m, cam_pos, cam_q);
@@ -725,16 +740,15 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
 
   // P2 (first part): collect the moving objects' particles (semantic_dsp_map.h:588-693)
   if (n_moves > 0) {
-    MoveSet ms;
+    MoveSet &ms = m->moveset;
     memset(&ms, 0, sizeof(ms));
     ms.n = n_moves;
     for (int k = 0; k < n_moves; ++k) {
       ms.track[k] = (uint16_t)moves[k].track_id;
       memcpy(ms.T[k], moves[k].T, 12 * sizeof(float));
     }
-    HIP_TRY(hipMemcpyAsync(m->d_moveset, &ms, sizeof(ms), hipMemcpyHostToDevice, s));
     m->n_moves = n_moves;
-    launch_moves_count(d, m->d_moveset, n_moves, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, s);
+    launch_moves_count(d, ms, n_moves, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, s);
   }
   if (n_remove > 0) {
     std::vector<uint16_t> tr(n_remove);
@@ -759,7 +773,7 @@ sdm_status sdm_frame_moves(sdm_map *m) {
       w = 1;
       r = 0;
     }
-    launch_moves_transform(m->d, m->f, m->flt, m->d_moveset, m->n_moves, m->st, m->sc, counts_all, w, r, m->stream);
+    launch_moves_transform(m->d, m->f, m->flt, m->moveset, m->n_moves, m->st, m->sc, counts_all, w, r, m->stream);
   }
   return SDM_OK;
 }

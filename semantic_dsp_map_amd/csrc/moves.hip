@@ -39,7 +39,8 @@ __device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint16_t *tracks
 // flag bytes, one block-wide scan of the per-thread counts per 32 K flags).  Dynamic objects touch a few hundred of
 // the map's tens of thousands of chunks; everything after this works on the list only.
 __global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *__restrict__ owner_flag, uint32_t n_flags,
-                                                      uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Counters *cnt) {
+                                                      uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Counters *cnt,
+                                                      uint32_t *__restrict__ cnt_tail) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t running;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -91,20 +92,23 @@ __global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *__restrict_
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *n_list = running < MV_LIST_CAP ? running : MV_LIST_CAP;
+  if (threadIdx.x == 0) {
+    *n_list = running < MV_LIST_CAP ? running : MV_LIST_CAP;
+    *cnt_tail = 0;  // terminator of the count matrix (becomes the grand total after the scan)
+  }
 }
 
 // pass 1: per-chunk, per-object member counts.  cnt[obj * MV_LIST_CAP + list position].  A flagged chunk that turns out
 // to hold no owner any more clears its flag.
 __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__ owner, size_t n_slots,
-                                                    const MoveSet *__restrict__ ms, uint32_t *__restrict__ cnt, int n_obj,
+                                                    const MoveSet ms, uint32_t *__restrict__ cnt, int n_obj,
                                                     uint8_t *__restrict__ owner_flag, const uint32_t *__restrict__ list,
                                                     const uint32_t *__restrict__ n_list) {
   __shared__ uint32_t c[MAX_MOVE_OBJECTS];
   __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
   __shared__ uint32_t any_owner;
   const uint32_t n = *n_list;
-  if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms->track[threadIdx.x] : OWNER_NONE;
+  if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms.track[threadIdx.x] : OWNER_NONE;
   for (uint32_t pos = blockIdx.x; pos < MV_LIST_CAP; pos += gridDim.x) {
     if (pos >= n) {  // unused tail of the count matrix
       if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * MV_LIST_CAP + pos] = 0;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__
 
 // pass 2 (after the exclusive scan of cnt): stable scatter of the member indices.
 __global__ __launch_bounds__(TPB) void k_move_scatter(const uint16_t *__restrict__ owner, size_t n_slots, size_t slot_base,
-                                                      const MoveSet *__restrict__ ms, const uint32_t *__restrict__ offs,
+                                                      const MoveSet ms, const uint32_t *__restrict__ offs,
                                                       int n_obj, uint32_t *__restrict__ mv_src, uint32_t cap, Counters *cnt,
                                                       const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list) {
   __shared__ uint32_t obj_base[MAX_MOVE_OBJECTS];
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(TPB) void k_move_scatter(const uint16_t *__restrict
   __shared__ uint32_t block_total;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t n = *n_list;
-  if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms->track[threadIdx.x] : OWNER_NONE;
+  if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms.track[threadIdx.x] : OWNER_NONE;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (uint32_t pos = blockIdx.x; pos < n; pos += gridDim.x) {
     __syncthreads();
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(TPB) void k_move_init_keys(Dims d, Scratch sc) {
 
 // phase 1 of moveParticlesInSetsByTransformations (operations.h:331-349): copy, transform + table noise,
 // delete the original.  The noise cursor advances by three per particle in global rank order.
-__global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter flt, const MoveSet *ms, State st, Scratch sc,
+__global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter flt, const MoveSet ms, State st, Scratch sc,
                                                         const uint32_t *__restrict__ offs, int n_obj, int write_all_keys) {
   if (sc.cnt->overflow) return;
   const uint32_t n_blocks = MV_LIST_CAP;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter 
     const uint32_t src = sc.mv_src[le];
     const size_t li = (size_t)src - slot_base;
     const float4 p = st.pos4[li];
-    const float *T = ms->T[obj];
+    const float *T = ms.T[obj];
     float nx = row4(T + 0, p.x, p.y, p.z);
     float ny = row4(T + 4, p.x, p.y, p.z);
     float nz = row4(T + 8, p.x, p.y, p.z);
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter 
     const float pw = st.w[li];
     const uint16_t pts = st.ts[li], ptrack = st.track[li];
     const uint8_t plabel = st.label[li], pstatus = st.status[li];
-    const uint16_t powner = ms->track[obj];
+    const uint16_t powner = ms.track[obj];
     st.status[li] = ST_INVALID;  // deleteParticleByIndex
     st.owner[li] = OWNER_NONE;   // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
     uint32_t rx, ry, rz;
@@ -451,14 +455,14 @@ size_t move_blocks(const Dims &d) { return ((size_t)d.v_count * d.S + MV_CHUNK -
 size_t move_count_elems() { return (size_t)MAX_MOVE_OBJECTS * MV_LIST_CAP + 1; }
 
 // step 1: collect every moving object's members (ascending index) and publish the per-object counts
-void launch_moves_count(const Dims &d, const MoveSet *ms_dev, int n_obj, const State &st, const Scratch &sc, int32_t *counts_local,
+void launch_moves_count(const Dims &d, const MoveSet &ms_dev, int n_obj, const State &st, const Scratch &sc, int32_t *counts_local,
                         hipStream_t s) {
   if (n_obj <= 0) return;
   const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t slot_base = (size_t)d.v_begin << d.p_n;
   const size_t n_cnt = (size_t)n_obj * MV_LIST_CAP + 1;
-  hipLaunchKernelGGL(k_move_chunks, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cnt);
-  hipMemsetAsync(sc.mv_cnt + (n_cnt - 1), 0, 4, s);
+  hipLaunchKernelGGL(k_move_chunks, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cnt,
+                     sc.mv_cnt + (n_cnt - 1));
   hipLaunchKernelGGL(k_move_count, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, ms_dev, sc.mv_cnt, n_obj, st.owner_flag, sc.mv_list,
                      sc.mv_nlist);
   exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch, s);
@@ -468,7 +472,7 @@ void launch_moves_count(const Dims &d, const MoveSet *ms_dev, int n_obj, const S
 }
 
 // step 2 (after the counts of all shards are known): global ranks, transform, export of slab-crossing copies
-void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet *ms_dev, int n_obj, const State &st,
+void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms_dev, int n_obj, const State &st,
                             const Scratch &sc, const int32_t *counts_all, int world, int rank, hipStream_t s) {
   if (n_obj <= 0) return;
   hipLaunchKernelGGL(k_move_bases, dim3(1), dim3(64), 0, s, counts_all, world, rank, n_obj, sc);

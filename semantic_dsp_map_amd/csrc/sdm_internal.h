@@ -93,6 +93,14 @@ struct Counters {
 };
 constexpr uint32_t VIS_SHARDS = 64;
 constexpr uint32_t OWNER_CHUNK = 4096;  // slots per owner_flag byte (= slots per block of the move sweep)
+// Slab stamps written by this frame's ring shift (mc_ring/operations.h:1131-1181), applied on the device by the
+// frame-begin kernel; all stamps of one frame carry the same value (the frame's global_time_stamp).
+constexpr int MAX_STAMP_UPDATES = 96;
+struct StampUpdates {
+  int n;
+  uint32_t value;
+  uint16_t entry[MAX_STAMP_UPDATES];  // axis << 12 | ring index
+};
 struct Cursors {
   int32_t birth_cursor;
   int32_t move_cursor;

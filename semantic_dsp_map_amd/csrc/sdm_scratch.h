@@ -61,7 +61,7 @@ struct Scratch {
   Cursors *cur = nullptr;
 };
 
-void launch_frame_begin(const Dims &d, const Scratch &sc, hipStream_t s);
+void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s);
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s);
 void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_generic, hipStream_t s);
 void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, hipStream_t s);
@@ -82,7 +82,7 @@ void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t
                         hipStream_t s);
 
 // object moves / removals (moves.hip)
-constexpr int MAX_MOVE_OBJECTS = 64;
+constexpr int MAX_MOVE_OBJECTS = 48;  // keeps the by-value MoveSet kernel argument under the 4 KB kernarg limit
 constexpr int HALO_OBJ = 64;              // ints per shard in the gathered count matrix (>= MAX_MOVE_OBJECTS)
 constexpr int HALO_RECORD_BYTES = 36;
 constexpr int HALO_HEADER_BYTES = 16;
@@ -94,9 +94,9 @@ struct MoveSet {
 size_t move_blocks(const Dims &d);
 size_t move_count_elems();
 void launch_owner_flags(const Dims &d, const State &st, hipStream_t s);
-void launch_moves_count(const Dims &d, const MoveSet *ms_dev, int n_obj, const State &st, const Scratch &sc, int32_t *counts_local,
+void launch_moves_count(const Dims &d, const MoveSet &ms, int n_obj, const State &st, const Scratch &sc, int32_t *counts_local,
                         hipStream_t s);
-void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet *ms_dev, int n_obj, const State &st,
+void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms, int n_obj, const State &st,
                             const Scratch &sc, const int32_t *counts_all, int world, int rank, hipStream_t s);
 void launch_moves_finish(const Dims &d, const Filter &flt, int n_obj, const State &st, const Scratch &sc, int world, int rank,
                          hipStream_t s);
