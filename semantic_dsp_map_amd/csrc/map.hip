@@ -60,8 +60,9 @@ struct sdm_map {
   hipStream_t own_stream = nullptr;
   // side streams: the frustum reach set (pose only) and the birth candidates + sort (input cloud only) do not depend
   // on the map state, so they run next to the object-move chain and join the main stream through events
-  hipStream_t s_frustum = nullptr, s_birth = nullptr;
-  hipEvent_t ev_begin = nullptr, ev_frustum = nullptr, ev_birth = nullptr;
+  hipStream_t s_frustum = nullptr, s_birth = nullptr, s_occ = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_frustum = nullptr, ev_birth = nullptr, ev_predicted = nullptr, ev_occ = nullptr;
+  bool occ_early = false;  // the outside-the-frustum-box part of the occupancy sweep is in flight on s_occ
   int birth_which = 0;
   bool side_pending = false;
   float *ck_user = nullptr;
@@ -185,6 +186,7 @@ sdm_status ensure_birth_buffers(sdm_map *m) {
   HIP_TRY(re(&m->sc.bkey_b, need));
   HIP_TRY(re(&m->sc.bval_b, need));
   HIP_TRY(re(&m->sc.bpos, hw * nb));
+  HIP_TRY(re(&m->sc.occ_fix, hw * nb));
   HIP_TRY(re(&m->sc.sort_scratch, sort_scratch_elems(need)));
   m->nb_alloc = nb;
   m->sort_cap = need;
@@ -349,6 +351,7 @@ sdm_status check_counters(sdm_map *m, Counters *out) {
   Counters c;
   HIP_TRY(hipStreamSynchronize(m->s_frustum));
   HIP_TRY(hipStreamSynchronize(m->s_birth));
+  HIP_TRY(hipStreamSynchronize(m->s_occ));
   HIP_TRY(hipMemcpyAsync(&c, m->sc.cnt, sizeof(Counters), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (out) *out = c;
@@ -454,6 +457,9 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   HIP_TRY(hipEventCreateWithFlags(&m->ev_begin, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_frustum, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_birth, hipEventDisableTiming));
+  HIP_TRY(hipStreamCreateWithFlags(&m->s_occ, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_predicted, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_occ, hipEventDisableTiming));
   const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t hw = (size_t)d.W * d.H;
   sdm_status rc;
@@ -573,7 +579,7 @@ sdm_status sdm_destroy(sdm_map *m) {
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
   for (void *p : m->allocs) (void)hipFree(p);
-  void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points};
+  void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points, m->sc.occ_fix};
   for (void *p : extra)
     if (p) (void)hipFree(p);
   if (m->comm) (void)ncclCommDestroy(m->comm);
@@ -584,6 +590,10 @@ sdm_status sdm_destroy(sdm_map *m) {
     for (int i = 0; i < 9; ++i) (void)hipEventDestroy(m->ev[i]);
   if (m->s_frustum) (void)hipStreamSynchronize(m->s_frustum);
   if (m->s_birth) (void)hipStreamSynchronize(m->s_birth);
+  if (m->s_occ) (void)hipStreamSynchronize(m->s_occ);
+  if (m->ev_predicted) (void)hipEventDestroy(m->ev_predicted);
+  if (m->ev_occ) (void)hipEventDestroy(m->ev_occ);
+  if (m->s_occ) (void)hipStreamDestroy(m->s_occ);
   if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
   if (m->ev_frustum) (void)hipEventDestroy(m->ev_frustum);
   if (m->ev_birth) (void)hipEventDestroy(m->ev_birth);
@@ -802,6 +812,18 @@ sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev) {
   mark(3);
   if (done(3)) return SDM_OK;
 
+  // O1, early part (semantic_dsp_map.h:910): visibility, weight update and births only touch voxels inside the frustum
+  // index box, so the sweep over everything OUTSIDE the box starts now on its own stream and fills the bandwidth the
+  // latency-bound stages below leave idle.  Only for complete frames (it mutates weights/status like the reference).
+  m->occ_early = false;
+  if (stop_after == 0 && !(m->frame_flags & SDM_SKIP_OCCUPANCY)) {
+    HIP_TRY(hipEventRecord(m->ev_predicted, s));
+    HIP_TRY(hipStreamWaitEvent(m->s_occ, m->ev_predicted, 0));
+    launch_occupancy(d, m->f, m->flt, m->st, 1, m->s_occ);
+    HIP_TRY(hipEventRecord(m->ev_occ, m->s_occ));
+    m->occ_early = true;
+  }
+
   // U1: visibility + binning (semantic_dsp_map.h:749); join the frustum stream first
   HIP_TRY(hipStreamWaitEvent(s, m->ev_frustum, 0));
   launch_visibility(d, m->f, m->st, m->sc, s);
@@ -866,10 +888,16 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
   mark(5);
   if (done(5)) return SDM_OK;
   HIP_TRY(hipStreamWaitEvent(s, m->ev_birth, 0));  // join the birth-candidate stream
+  // births may (rarely, with noise) land outside the box: they must not race with the outside sweep
+  if (m->occ_early) HIP_TRY(hipStreamWaitEvent(s, m->ev_occ, 0));
   launch_birth_replay(d, m->f, m->flt, m->st, m->sc, m->birth_which, s);
   mark(6);
   if (done(6)) return SDM_OK;
-  if (!(flags & SDM_SKIP_OCCUPANCY)) launch_occupancy(d, m->flt, m->st, s);
+  if (!(flags & SDM_SKIP_OCCUPANCY)) {
+    if (m->occ_early) launch_occupancy_inside(d, m->f, m->flt, m->st, m->sc, s);  // the box + listed stragglers
+    else launch_occupancy(d, m->f, m->flt, m->st, 0, s);
+  }
+  m->occ_early = false;
   mark(7);
   return SDM_OK;
 }
@@ -891,6 +919,7 @@ sdm_status sdm_synchronize(sdm_map *m) {
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->s_frustum));
   HIP_TRY(hipStreamSynchronize(m->s_birth));
+  HIP_TRY(hipStreamSynchronize(m->s_occ));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return check_counters(m, nullptr);
 }
@@ -1286,9 +1315,9 @@ sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms) {
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a));
   HIP_TRY(hipEventCreate(&b));
-  launch_occupancy(m->d, m->flt, m->st, m->stream);  // warm-up
+  launch_occupancy(m->d, m->f, m->flt, m->st, 0, m->stream);  // warm-up
   HIP_TRY(hipEventRecord(a, m->stream));
-  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->flt, m->st, m->stream);
+  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->f, m->flt, m->st, 0, m->stream);
   HIP_TRY(hipEventRecord(b, m->stream));
   HIP_TRY(hipEventSynchronize(b));
   float ms = 0.f;

@@ -52,6 +52,7 @@ struct Scratch {
   const unsigned char *halo_recv = nullptr;
   uint32_t halo_cap = 0;
   uint8_t *track_to_obj = nullptr; // 65536 entries: moving-object rank of a track id, 0xFF = not moving
+  uint32_t *occ_fix = nullptr;     // voxels outside the frustum box touched by births (see k_occupancy_inside)
   // generic
   uint32_t *scan_scratch = nullptr, *sort_scratch = nullptr;
   uint32_t *scan_scratch_b = nullptr;   // births run on their own stream
@@ -62,7 +63,8 @@ struct Scratch {
 };
 
 void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s);
-void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s);
+void launch_occupancy(const Dims &d, const Frame &f, const Filter &flt, const State &st, int mode, hipStream_t s);
+void launch_occupancy_inside(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
 void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_generic, hipStream_t s);
 void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, hipStream_t s);
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
