@@ -90,11 +90,13 @@ __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__
 // (semantic_dsp_map.h:1239-1257, mc_ring/operations.h:623-639, 390-448).
 // One thread per voxel; all S slots of the voxel are fetched with wide loads (SoA arrays are
 // voxel-contiguous), the 8-byte result is one store.  HBM-bound: 80 B/voxel at S=8.
-// read_only: the early sweep must not write slot state (other kernels of the frame are running); a voxel that needs a
-// clamp or a cull is reported through the return value and left for the late pass.
 template <int S>
-__device__ __forceinline__ bool occupancy_voxel(const Dims &d, float occ_threshold, State &st, uint32_t lv, uint32_t rx,
-                                                uint32_t ry, uint32_t rz, bool read_only) {
+__global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, State st) {
+  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;  // local voxel of this shard
+  if (lv >= d.v_count) return;
+  uint32_t v = d.v_begin + lv;
+  uint32_t rx, ry, rz;
+  voxel_to_ring(d, v, rx, ry, rz);
   const uint32_t smax = stamp_max(st, rx, ry, rz);
   const size_t base = (size_t)lv * S;
 
@@ -108,7 +110,7 @@ __device__ __forceinline__ bool occupancy_voxel(const Dims &d, float occ_thresho
     out.wsum = -1.f;
     out.occ = -1;
     store_result(st.res + lv, out);
-    return false;
+    return;
   }
   uint8_t stv[S];
   float wv[S];
@@ -179,61 +181,9 @@ __device__ __forceinline__ bool occupancy_voxel(const Dims &d, float occ_thresho
   if (weight_sum > occ_threshold) out.occ = 1;
   else if (guessed >= SDM_OCC_INIT_WEIGHT) out.occ = 2;
   else out.occ = 0;
-  if (read_only && (dirty_w || dirty_s)) return true;  // needs mutation: deferred
   store_result(st.res + lv, out);
   if (dirty_w) store_vec(st.w + base, wv);
   if (dirty_s) store_vec(st.status + base, stv);
-  return false;
-}
-
-// The sweep in three flavours.  ALL: every voxel of the shard (stand-alone sweep, roofline measurement).
-// OUTSIDE / INSIDE the frustum index box: visibility, weight update and (bar rare noisy births, see the fix-up list)
-// births only touch voxels inside the box, so the big OUTSIDE part of the sweep runs on a side stream next to those
-// latency-bound stages and only the INSIDE part (plus the listed stragglers) waits for them.
-enum { OCC_ALL = 0, OCC_OUTSIDE = 1 };
-
-template <int S>
-__global__ __launch_bounds__(TPB) void k_occupancy(Dims d, Frame f, float occ_threshold, State st, Scratch sc, int mode) {
-  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;  // local voxel of this shard
-  if (lv >= d.v_count) return;
-  uint32_t v = d.v_begin + lv;
-  uint32_t rx, ry, rz;
-  voxel_to_ring(d, v, rx, ry, rz);
-  if (mode == OCC_OUTSIDE) {
-    // ring index -> map index (operations.h:1022-1033) -> inside the frustum box?
-    const int mx = (int)axis_correct((int)rx - f.eq[0], d.NX), my = (int)axis_correct((int)ry - f.eq[1], d.NY),
-              mz = (int)axis_correct((int)rz - f.eq[2], d.NZ);
-    if (mx >= f.bb0[0] && mx < f.bb1[0] && my >= f.bb0[1] && my < f.bb1[1] && mz >= f.bb0[2] && mz < f.bb1[2]) return;
-    if (occupancy_voxel<S>(d, occ_threshold, st, lv, rx, ry, rz, true)) occ_list_voxel(d, f, sc, v);
-    return;
-  }
-  occupancy_voxel<S>(d, occ_threshold, st, lv, rx, ry, rz, false);
-}
-
-// voxels inside the frustum box (thread mapping of k_visibility), then the fix-up list: voxels outside the box that
-// a birth touched after the OUTSIDE sweep had already passed
-template <int S>
-__global__ __launch_bounds__(TPB) void k_occupancy_inside(Dims d, Frame f, float occ_threshold, State st, Scratch sc,
-                                                          uint32_t box_blocks) {
-  if (blockIdx.x < box_blocks) {
-    const int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bx <= 0 || by <= 0 || bz <= 0 || t >= (uint32_t)bx * by * bz) return;
-    const int ax = f.bb0[0] + (int)(t % bx), ay = f.bb0[1] + (int)((t / bx) % by), az = f.bb0[2] + (int)(t / ((uint32_t)bx * by));
-    const uint32_t rx = axis_correct(ax + f.eq[0], d.NX), ry = axis_correct(ay + f.eq[1], d.NY), rz = axis_correct(az + f.eq[2], d.NZ);
-    if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) return;
-    occupancy_voxel<S>(d, occ_threshold, st, ring_to_voxel(d, rx, ry, rz) - d.v_begin, rx, ry, rz, false);
-    return;
-  }
-  uint32_t n = sc.cnt->n_occ_fix;
-  if (n > sc.occ_fix_cap) n = sc.occ_fix_cap;
-  const uint32_t stride = (gridDim.x - box_blocks) * blockDim.x;
-  for (uint32_t k = (blockIdx.x - box_blocks) * blockDim.x + threadIdx.x; k < n; k += stride) {
-    const uint32_t v = sc.occ_fix[k];
-    uint32_t rx, ry, rz;
-    voxel_to_ring(d, v, rx, ry, rz);
-    occupancy_voxel<S>(d, occ_threshold, st, v - d.v_begin, rx, ry, rz, false);
-  }
 }
 
 // ------------------------------------------------------------------------------------ A6
@@ -1005,7 +955,6 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
   load_vec(tsv, st.ts + base);
   bool resampled = false, checked = false;
   uint32_t n_success = 0;
-  occ_list_voxel(d, f, sc, v);  // a (noisy) birth outside the frustum box: the early occupancy sweep may have passed it
   for (uint32_t u = t; u < total && skey[u] == v; ++u) {
     const float4 bp = sc.bpos[sval[u]];
     const uint32_t tl = __float_as_uint(bp.w);
@@ -1179,15 +1128,9 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s) {
     default: hipLaunchKernelGGL(kernel<16>, grid, dim3(TPB), 0, s, __VA_ARGS__); break;            \
   }
 
-void launch_occupancy(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, int mode, hipStream_t s) {
+void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s) {
   dim3 grid(blocks_for(d.v_count));
-  SDM_DISPATCH_S(k_occupancy, grid, s, d, f, flt.occ_threshold, st, sc, mode);
-}
-void launch_occupancy_inside(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s) {
-  const int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];
-  const uint32_t box_blocks = (bx > 0 && by > 0 && bz > 0) ? blocks_for((size_t)bx * by * bz) : 0u;
-  dim3 grid(box_blocks + 64);  // the last 64 blocks walk the fix-up list (grid-stride, any length)
-  SDM_DISPATCH_S(k_occupancy_inside, grid, s, d, f, flt.occ_threshold, st, sc, box_blocks);
+  SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st);
 }
 
 void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s) {

@@ -60,9 +60,8 @@ struct sdm_map {
   hipStream_t own_stream = nullptr;
   // side streams: the frustum reach set (pose only) and the birth candidates + sort (input cloud only) do not depend
   // on the map state, so they run next to the object-move chain and join the main stream through events
-  hipStream_t s_frustum = nullptr, s_birth = nullptr, s_occ = nullptr;
-  hipEvent_t ev_begin = nullptr, ev_frustum = nullptr, ev_birth = nullptr, ev_predicted = nullptr, ev_occ = nullptr;
-  bool occ_early = false;  // the outside-the-frustum-box part of the occupancy sweep is in flight on s_occ
+  hipStream_t s_frustum = nullptr, s_birth = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_frustum = nullptr, ev_birth = nullptr;
   int birth_which = 0;
   bool side_pending = false;
   float *ck_user = nullptr;
@@ -350,7 +349,6 @@ sdm_status check_counters(sdm_map *m, Counters *out) {
   Counters c;
   HIP_TRY(hipStreamSynchronize(m->s_frustum));
   HIP_TRY(hipStreamSynchronize(m->s_birth));
-  HIP_TRY(hipStreamSynchronize(m->s_occ));
   HIP_TRY(hipMemcpyAsync(&c, m->sc.cnt, sizeof(Counters), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (out) *out = c;
@@ -449,20 +447,13 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->prm.depth_noise_first_order = 0.f;
   m->prm.depth_noise_zero_order = 0.1f;
 
-  // the main stream carries the latency-bound dependency chain: highest priority; the bulk occupancy sweep that runs
-  // beside it gets the lowest, so that it only takes the CU slots the chain leaves free
-  int prio_least = 0, prio_greatest = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-  HIP_TRY(hipStreamCreateWithPriority(&m->own_stream, hipStreamNonBlocking, prio_greatest));
+  HIP_TRY(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
   m->stream = m->own_stream;
-  HIP_TRY(hipStreamCreateWithPriority(&m->s_frustum, hipStreamNonBlocking, prio_greatest));
-  HIP_TRY(hipStreamCreateWithPriority(&m->s_birth, hipStreamNonBlocking, prio_greatest));
+  HIP_TRY(hipStreamCreateWithFlags(&m->s_frustum, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&m->s_birth, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_begin, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_frustum, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_birth, hipEventDisableTiming));
-  HIP_TRY(hipStreamCreateWithPriority(&m->s_occ, hipStreamNonBlocking, prio_least));
-  HIP_TRY(hipEventCreateWithFlags(&m->ev_predicted, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&m->ev_occ, hipEventDisableTiming));
   const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t hw = (size_t)d.W * d.H;
   sdm_status rc;
@@ -553,10 +544,6 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.msort_scratch, sort_scratch_elems(sc.cap_move) + 16);
   A(sc.cnt, 1);
   A(sc.cur, 1);
-  sc.occ_fix_cap = (uint32_t)std::min<size_t>(d.v_count, (size_t)4 << 20);
-  A(sc.occ_fix, sc.occ_fix_cap);
-  A(sc.fix_stamp, d.v_count);
-  HIP_TRY(hipMemsetAsync(sc.fix_stamp, 0xFF, (size_t)d.v_count * 4, m->stream));
   HIP_TRY(hipMemsetAsync(sc.cnt, 0, sizeof(Counters), m->stream));
   HIP_TRY(hipMemsetAsync(sc.cur, 0, sizeof(Cursors), m->stream));
   A(m->d_moveset, 1);
@@ -597,10 +584,6 @@ sdm_status sdm_destroy(sdm_map *m) {
     for (int i = 0; i < 9; ++i) (void)hipEventDestroy(m->ev[i]);
   if (m->s_frustum) (void)hipStreamSynchronize(m->s_frustum);
   if (m->s_birth) (void)hipStreamSynchronize(m->s_birth);
-  if (m->s_occ) (void)hipStreamSynchronize(m->s_occ);
-  if (m->ev_predicted) (void)hipEventDestroy(m->ev_predicted);
-  if (m->ev_occ) (void)hipEventDestroy(m->ev_occ);
-  if (m->s_occ) (void)hipStreamDestroy(m->s_occ);
   if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
   if (m->ev_frustum) (void)hipEventDestroy(m->ev_frustum);
   if (m->ev_birth) (void)hipEventDestroy(m->ev_birth);
@@ -616,7 +599,6 @@ sdm_status sdm_destroy(sdm_map *m) {
 sdm_status sdm_clear(sdm_map *m) {
   if (!m) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
-  HIP_TRY(hipMemsetAsync(m->sc.fix_stamp, 0xFF, (size_t)m->d.v_count * 4, m->stream));
   host_initialize(m);
   launch_clear(m->d, m->st, m->stream);
   return upload_stamps(m);
@@ -743,20 +725,6 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
   // fork: everything that only needs this frame's inputs and pose starts now on the side streams
   HIP_TRY(hipEventRecord(m->ev_begin, s));
   m->side_pending = false;
-  // O1, early part (semantic_dsp_map.h:910).  Moves, removals, visibility, weight update and births change only (a) voxels
-  // inside the frustum index box and (b) a few voxels outside it, which the kernels that touch them put on a fix-up
-  // list.  So the sweep over everything OUTSIDE the box starts right away on its own stream, read-only (a voxel that
-  // needs a clamp or cull is listed instead), hidden behind the launch-bound move chain; the late pass sweeps the box
-  // and the list.  Only for complete frames.
-  m->occ_early = false;
-  m->sc.occ_listing = 0;
-  if (stop_after == 0 && !(flags & SDM_SKIP_OCCUPANCY)) {
-    m->sc.occ_listing = 1;
-    HIP_TRY(hipStreamWaitEvent(m->s_occ, m->ev_begin, 0));
-    launch_occupancy(d, m->f, m->flt, m->st, m->sc, 1, m->s_occ);
-    HIP_TRY(hipEventRecord(m->ev_occ, m->s_occ));
-    m->occ_early = true;
-  }
   if (!done(3)) {
     HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->ev_begin, 0));
     m->sc.force_generic = m->force_generic_flood;
@@ -825,12 +793,12 @@ sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev) {
     }
   };
   // P2 (second part): re-insert the moved copies in the reference's order (operations.h:351-361)
-  launch_moves_finish(d, m->f, m->flt, m->n_moves, m->st, m->sc, m->counts_all_user ? m->cfg.shard_count : 1, m->cfg.shard_rank, s);
+  launch_moves_finish(d, m->flt, m->n_moves, m->st, m->sc, m->counts_all_user ? m->cfg.shard_count : 1, m->cfg.shard_rank, s);
   mark(2);
   if (done(2)) return SDM_OK;
 
   // P3: removals (semantic_dsp_map.h:702-736)
-  if (m->n_remove > 0) launch_remove(d, m->f, m->st, m->sc, m->d_remove, m->n_remove, s);
+  if (m->n_remove > 0) launch_remove(d, m->st, m->d_remove, m->n_remove, s);
   mark(3);
   if (done(3)) return SDM_OK;
 
@@ -901,15 +869,7 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
   launch_birth_replay(d, m->f, m->flt, m->st, m->sc, m->birth_which, s);
   mark(6);
   if (done(6)) return SDM_OK;
-  if (!(flags & SDM_SKIP_OCCUPANCY)) {
-    if (m->occ_early) {
-      HIP_TRY(hipStreamWaitEvent(s, m->ev_occ, 0));  // the late pass must write its results after the early one
-      launch_occupancy_inside(d, m->f, m->flt, m->st, m->sc, s);  // the box + the fix-up list
-    } else {
-      launch_occupancy(d, m->f, m->flt, m->st, m->sc, 0, s);
-    }
-  }
-  m->occ_early = false;
+  if (!(flags & SDM_SKIP_OCCUPANCY)) launch_occupancy(d, m->flt, m->st, s);
   mark(7);
   return SDM_OK;
 }
@@ -931,7 +891,6 @@ sdm_status sdm_synchronize(sdm_map *m) {
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->s_frustum));
   HIP_TRY(hipStreamSynchronize(m->s_birth));
-  HIP_TRY(hipStreamSynchronize(m->s_occ));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return check_counters(m, nullptr);
 }
@@ -1195,7 +1154,6 @@ sdm_status sdm_set_ring_state(sdm_map *m, const sdm_ring_state *o) {
     m->last_pos[a] = o->last_pos[a];
   }
   Cursors c{o->birth_cursor, o->move_cursor};
-  HIP_TRY(hipMemsetAsync(m->sc.fix_stamp, 0xFF, (size_t)m->d.v_count * 4, m->stream));  // frame stamps may repeat
   HIP_TRY(hipMemcpyAsync(m->sc.cur, &c, sizeof(c), hipMemcpyHostToDevice, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   sync_frame_scalars(m);
@@ -1328,9 +1286,9 @@ sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms) {
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a));
   HIP_TRY(hipEventCreate(&b));
-  launch_occupancy(m->d, m->f, m->flt, m->st, m->sc, 0, m->stream);  // warm-up
+  launch_occupancy(m->d, m->flt, m->st, m->stream);  // warm-up
   HIP_TRY(hipEventRecord(a, m->stream));
-  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->f, m->flt, m->st, m->sc, 0, m->stream);
+  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->flt, m->st, m->stream);
   HIP_TRY(hipEventRecord(b, m->stream));
   HIP_TRY(hipEventSynchronize(b));
   float ms = 0.f;

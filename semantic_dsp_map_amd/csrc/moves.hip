@@ -287,7 +287,6 @@ __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter 
     const uint16_t powner = ms.track[obj];
     st.status[li] = ST_INVALID;  // deleteParticleByIndex
     st.owner[li] = OWNER_NONE;   // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
-    occ_list_voxel(d, f, sc, src >> d.p_n);
     uint32_t rx, ry, rz;
     uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
     if (write_all_keys && e < sc.cap_move) {  // single shard: every rank is written here, no separate key init pass
@@ -355,7 +354,7 @@ __global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int wor
 // phase 2 (operations.h:351-361): re-insert the copies, first vacant slot, in (object, index) order.
 // Sorted by target voxel (stable), one thread replays each voxel's segment.
 template <int S>
-__global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Frame f, Filter flt, State st, Scratch sc,
+__global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State st, Scratch sc,
                                                      const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // the table cursor of RingBufferOperations::gaussian_random_calculator_ advanced by three per moved particle
@@ -405,15 +404,11 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Frame f, Filter flt
       }
     ++n_ok;
   }
-  if (n_ok) {
-    atomicAdd(&sc.cnt->n_move_reinserted, n_ok);
-    occ_list_voxel(d, f, sc, v);
-  }
+  if (n_ok) atomicAdd(&sc.cnt->n_move_reinserted, n_ok);
 }
 
 // removeObjectByTrackID (object_layer.h:414-425): every index of the set -> INVALID, set erased.
-__global__ __launch_bounds__(TPB) void k_remove(Dims d, Frame f, State st, Scratch sc, size_t n_slots,
-                                                const uint16_t *__restrict__ tracks, int n) {
+__global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const uint16_t *__restrict__ tracks, int n) {
   if (st.owner_flag[blockIdx.x] == 0) return;  // one block per OWNER_CHUNK slots
   size_t i = (size_t)blockIdx.x * OWNER_CHUNK + threadIdx.x;
   size_t end = (size_t)(blockIdx.x + 1) * OWNER_CHUNK;
@@ -425,7 +420,6 @@ __global__ __launch_bounds__(TPB) void k_remove(Dims d, Frame f, State st, Scrat
       if (tracks[k] == o) {
         st.status[i] = ST_INVALID;
         st.owner[i] = OWNER_NONE;
-        occ_list_voxel(d, f, sc, d.v_begin + (uint32_t)(i >> d.p_n));
         break;
       }
   }
@@ -488,7 +482,7 @@ void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, co
 }
 
 // step 3 (after the export buffers of all shards are gathered): import, stable sort by voxel, ordered replay
-void launch_moves_finish(const Dims &d, const Frame &f, const Filter &flt, int n_obj, const State &st, const Scratch &sc, int world, int rank,
+void launch_moves_finish(const Dims &d, const Filter &flt, int n_obj, const State &st, const Scratch &sc, int world, int rank,
                          hipStream_t s) {
   if (n_obj <= 0) return;
   if (world > 1 && sc.halo_recv) hipLaunchKernelGGL(k_move_import, dim3(64, world), dim3(TPB), 0, s, d, sc, world, rank);
@@ -498,17 +492,17 @@ void launch_moves_finish(const Dims &d, const Frame &f, const Filter &flt, int n
   const uint32_t *sval = which ? sc.mval_b : sc.mval_a;
   dim3 grid(blocks_for(sc.cap_move));
   switch (d.p_n) {
-    case 1: hipLaunchKernelGGL(k_move_replay<2>, grid, dim3(TPB), 0, s, d, f, flt, st, sc, skey, sval); break;
-    case 2: hipLaunchKernelGGL(k_move_replay<4>, grid, dim3(TPB), 0, s, d, f, flt, st, sc, skey, sval); break;
-    case 3: hipLaunchKernelGGL(k_move_replay<8>, grid, dim3(TPB), 0, s, d, f, flt, st, sc, skey, sval); break;
-    default: hipLaunchKernelGGL(k_move_replay<16>, grid, dim3(TPB), 0, s, d, f, flt, st, sc, skey, sval); break;
+    case 1: hipLaunchKernelGGL(k_move_replay<2>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
+    case 2: hipLaunchKernelGGL(k_move_replay<4>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
+    case 3: hipLaunchKernelGGL(k_move_replay<8>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
+    default: hipLaunchKernelGGL(k_move_replay<16>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
   }
 }
 
-void launch_remove(const Dims &d, const Frame &f, const State &st, const Scratch &sc, const uint16_t *tracks_dev, int n, hipStream_t s) {
+void launch_remove(const Dims &d, const State &st, const uint16_t *tracks_dev, int n, hipStream_t s) {
   if (n <= 0) return;
   const size_t n_slots = (size_t)d.v_count * d.S;
-  hipLaunchKernelGGL(k_remove, dim3((unsigned)((n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK)), dim3(TPB), 0, s, d, f, st, sc, n_slots, tracks_dev, n);
+  hipLaunchKernelGGL(k_remove, dim3((unsigned)((n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK)), dim3(TPB), 0, s, st, n_slots, tracks_dev, n);
 }
 
 }  // namespace sdm

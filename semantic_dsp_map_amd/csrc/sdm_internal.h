@@ -85,8 +85,7 @@ struct Counters {
   uint32_t start_in_frustum;
   uint32_t overflow;
   uint32_t n_valid_px;
-  uint32_t n_occ_fix;  // births that landed outside the frustum box this frame
-  uint32_t pad[7];
+  uint32_t pad[8];
   // Same-address atomics retire at ~12 ns each on MI355X, so counters that every wave bumps are sharded
   // by block index; the per-shard visible-particle counters also index per-shard regions of the work list.
   uint32_t vis_shard[64];

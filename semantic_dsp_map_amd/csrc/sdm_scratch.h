@@ -52,13 +52,6 @@ struct Scratch {
   const unsigned char *halo_recv = nullptr;
   uint32_t halo_cap = 0;
   uint8_t *track_to_obj = nullptr; // 65536 entries: moving-object rank of a track id, 0xFF = not moving
-  // Occupancy fix-up list: voxels OUTSIDE the frustum box whose slots changed during this frame (moves, removals,
-  // noisy births) or that the read-only early sweep found in need of a clamp/cull.  fix_stamp[v] == frame stamp marks
-  // a voxel as already listed (no clearing between frames).  occ_listing: the early sweep is active this frame.
-  uint32_t *occ_fix = nullptr;
-  uint32_t *fix_stamp = nullptr;
-  uint32_t occ_fix_cap = 0;
-  int occ_listing = 0;
   // generic
   uint32_t *scan_scratch = nullptr, *sort_scratch = nullptr;
   uint32_t *scan_scratch_b = nullptr;   // births run on their own stream
@@ -68,23 +61,8 @@ struct Scratch {
   Cursors *cur = nullptr;
 };
 
-// append voxel v (global storage index) to the occupancy fix-up list, once per frame, if it lies outside the frustum box
-__device__ __forceinline__ void occ_list_voxel(const Dims &d, const Frame &f, const Scratch &sc, uint32_t v) {
-  if (!sc.occ_listing) return;
-  uint32_t rx, ry, rz;
-  voxel_to_ring(d, v, rx, ry, rz);
-  const int mx = (int)axis_correct((int)rx - f.eq[0], d.NX), my = (int)axis_correct((int)ry - f.eq[1], d.NY),
-            mz = (int)axis_correct((int)rz - f.eq[2], d.NZ);
-  if (mx >= f.bb0[0] && mx < f.bb1[0] && my >= f.bb0[1] && my < f.bb1[1] && mz >= f.bb0[2] && mz < f.bb1[2]) return;
-  if (atomicExch(&sc.fix_stamp[v - d.v_begin], f.gts) == f.gts) return;  // already listed this frame
-  uint32_t k = atomicAdd(&sc.cnt->n_occ_fix, 1u);
-  if (k < sc.occ_fix_cap) sc.occ_fix[k] = v;
-  else sc.cnt->overflow = 1;
-}
-
 void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s);
-void launch_occupancy(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, int mode, hipStream_t s);
-void launch_occupancy_inside(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
+void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s);
 void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_generic, hipStream_t s);
 void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, hipStream_t s);
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
@@ -120,8 +98,8 @@ void launch_moves_count(const Dims &d, const MoveSet &ms, int n_obj, const State
                         hipStream_t s);
 void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms, int n_obj, const State &st,
                             const Scratch &sc, const int32_t *counts_all, int world, int rank, hipStream_t s);
-void launch_moves_finish(const Dims &d, const Frame &f, const Filter &flt, int n_obj, const State &st, const Scratch &sc, int world, int rank,
+void launch_moves_finish(const Dims &d, const Filter &flt, int n_obj, const State &st, const Scratch &sc, int world, int rank,
                          hipStream_t s);
-void launch_remove(const Dims &d, const Frame &f, const State &st, const Scratch &sc, const uint16_t *tracks_dev, int n, hipStream_t s);
+void launch_remove(const Dims &d, const State &st, const uint16_t *tracks_dev, int n, hipStream_t s);
 
 }  // namespace sdm
