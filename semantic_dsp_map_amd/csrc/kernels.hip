@@ -673,12 +673,8 @@ __global__ __launch_bounds__(TPB) void k_bin_sort_gather(Dims d, State st, Scrat
   for (uint32_t i = 0; i < n; ++i) {
     size_t li = (size_t)a[i] - slot_base;
     float4 q = st.pos4[li];
-    sc.vx[s + i] = q.x;
-    sc.vy[s + i] = q.y;
-    sc.vz[s + i] = q.z;
-    sc.vw[s + i] = st.w[li];
-    sc.vtrack[s + i] = st.track[li];
-    sc.vforget[s + i] = (uint8_t)(__float_as_uint(q.w) & 0xffu);
+    sc.vp4[s + i] = make_float4(q.x, q.y, q.z, st.w[li]);
+    sc.vtf[s + i] = (uint32_t)st.track[li] | ((__float_as_uint(q.w) & 0xffu) << 16);
     sc.vpix[s + i] = p;
   }
 }
@@ -715,25 +711,37 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, St
       const float *__restrict__ pdf = st.pdf;
       const float sigma = o.sigma;
       for (uint32_t k = s; k < e; ++k) {
-        const uint16_t ptrack = sc.vtrack[k];
+        const float4 pv = sc.vp4[k];
+        const uint32_t tf = sc.vtf[k];
+        const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
         if (flt.independent && ptrack != o.track_id) continue;
-        float gk = query_pdf(pdf, sc.vx[k], o.x, sigma) * query_pdf(pdf, sc.vy[k], o.y, sigma) *
-                   query_pdf(pdf, sc.vz[k], o.z, sigma);
+        float gk = query_pdf(pdf, pv.x, o.x, sigma) * query_pdf(pdf, pv.y, o.y, sigma) * query_pdf(pdf, pv.z, o.z, sigma);
         if (!flt.independent) {
-          gk *= flt.forget[sc.vforget[k] & 7];
+          gk *= flt.forget[(tf >> 16) & 7];
           if (ptrack != o.track_id) gk *= flt.id_transition;
         }
-        acc += sc.vw[k] * gk;
+        acc += pv.w * gk;
       }
     }
   }
   rowsum[it][r] = acc;
   __syncthreads();
-  if (r == 0 && valid_px) {
-    float ck = 0.f;
-    for (int m = 0; m <= 2 * h; ++m) ck += rowsum[it][m];
-    if (finish) sc.ck_kappa[p] = ck * flt.p_detect + flt.noise_number;
-    else ck_out[p] = ck;
+  if (r == 0 && p < d.W * d.H) {
+    if (valid_px) {
+      float ck = 0.f;
+      for (int m = 0; m <= 2 * h; ++m) ck += rowsum[it][m];
+      if (finish) {
+        const float ckk = ck * flt.p_detect + flt.noise_number;
+        const sdm_labeled_point o = sc.cloud[p];
+        sc.ck_kappa[p] = ckk;
+        sc.pix4[p] = make_float4(o.x, o.y, o.z, ckk);
+        sc.pixt[p] = (uint32_t)o.track_id | (1u << 16);
+      } else {
+        ck_out[p] = ck;
+      }
+    } else if (finish) {
+      sc.pixt[p] = 0;  // invalid pixel: skipped by pass 2
+    }
   }
 }
 
@@ -742,11 +750,18 @@ __global__ __launch_bounds__(TPB) void k_ck_finish(Dims d, Filter flt, Scratch s
                                                    int n_parts) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.W * d.H) return;
-  if (!sc.cloud[p].is_valid) return;
+  const sdm_labeled_point o = sc.cloud[p];
+  if (!o.is_valid) {
+    sc.pixt[p] = 0;
+    return;
+  }
   float ck = 0.f;
   size_t hw = (size_t)d.W * d.H;
   for (int g = 0; g < n_parts; ++g) ck += parts[(size_t)g * hw + p];
-  sc.ck_kappa[p] = ck * flt.p_detect + flt.noise_number;
+  const float ckk = ck * flt.p_detect + flt.noise_number;
+  sc.ck_kappa[p] = ckk;
+  sc.pix4[p] = make_float4(o.x, o.y, o.z, ckk);
+  sc.pixt[p] = (uint32_t)o.track_id | (1u << 16);
 }
 
 // pass 2 (semantic_dsp_map.h:1041-1119): 16 binned particles x window rows per workgroup.
@@ -770,26 +785,29 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Frame f, F
       const int ni = i + r - h;
       if (ni >= 0 && ni < d.H) {
         const float sigma = sc.cloud[p].sigma;  // sigma of the particle's own pixel (semantic_dsp_map.h:1047)
-        const float x = sc.vx[k], y = sc.vy[k], z = sc.vz[k];
-        const uint16_t ptrack = sc.vtrack[k];
-        const float ff = flt.forget[sc.vforget[k] & 7];
+        const float4 pv = sc.vp4[k];
+        const uint32_t tf = sc.vtf[k];
+        const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
+        const float ff = flt.forget[(tf >> 16) & 7];
         for (int nn = -h; nn <= h; ++nn) {
           const int nj = j + nn;
           if (nj < 0 || nj >= d.W) continue;
           const int q = ni * d.W + nj;
-          const sdm_labeled_point o = sc.cloud[q];
-          if (!o.is_valid) continue;
-          if (flt.independent && o.track_id != ptrack) continue;
-          float gk = query_pdf(pdf, x, o.x, sigma) * query_pdf(pdf, y, o.y, sigma) * query_pdf(pdf, z, o.z, sigma);
+          const uint32_t ot = sc.pixt[q];
+          if (!(ot >> 16)) continue;  // invalid pixel
+          const uint16_t otrack = (uint16_t)(ot & 0xffffu);
+          if (flt.independent && otrack != ptrack) continue;
+          const float4 o = sc.pix4[q];  // x, y, z, ck+kappa
+          float gk = query_pdf(pdf, pv.x, o.x, sigma) * query_pdf(pdf, pv.y, o.y, sigma) * query_pdf(pdf, pv.z, o.z, sigma);
           if (!flt.independent) {
-            if (ptrack != o.track_id) {
+            if (ptrack != otrack) {
               gk *= flt.id_transition;
             } else {
               if (gk > SDM_MIN_RIGHT_PDF) right = 1;
             }
             gk *= ff;
           }
-          acc += gk / sc.ck_kappa[q];
+          acc += gk / o.w;
         }
       }
     }
@@ -804,8 +822,8 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Frame f, F
         right_id |= rowflag[it][m];
       }
       const size_t li = (size_t)sc.bin_idx[k] - slot_base;
-      const uint32_t fc = sc.vforget[k];
-      st.w[li] = sc.vw[k] * (a * flt.p_detect + 1.f - flt.p_detect);
+      const uint32_t fc = (sc.vtf[k] >> 16) & 0xffu;
+      st.w[li] = sc.vp4[k].w * (a * flt.p_detect + 1.f - flt.p_detect);
       st.status[li] = ST_UPDATED;
       st.ts[li] = (uint16_t)f.gts;
       if (!flt.independent) {

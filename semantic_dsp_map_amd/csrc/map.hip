@@ -506,12 +506,10 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.vis_pib, cap_vis);
   A(sc.bin_idx, cap_vis);
   A(sc.vpix, cap_vis);
-  A(sc.vx, cap_vis);
-  A(sc.vy, cap_vis);
-  A(sc.vz, cap_vis);
-  A(sc.vw, cap_vis);
-  A(sc.vtrack, cap_vis);
-  A(sc.vforget, cap_vis);
+  A(sc.vp4, cap_vis);
+  A(sc.vtf, cap_vis);
+  A(sc.pix4, hw);
+  A(sc.pixt, hw);
   A(sc.ck_kappa, hw);
   A(m->d_ck_part, hw);
   A(sc.b_valid, hw + 1);

@@ -28,9 +28,11 @@ struct Scratch {
   uint32_t cap_vis = 0;
   // visible particles in bin order
   uint32_t *bin_idx = nullptr, *vpix = nullptr;
-  float *vx = nullptr, *vy = nullptr, *vz = nullptr, *vw = nullptr;
-  uint16_t *vtrack = nullptr;
-  uint8_t *vforget = nullptr;
+  float4 *vp4 = nullptr;     // x, y, z, weight
+  uint32_t *vtf = nullptr;   // track | forget_count << 16
+  // per pixel, packed for pass 2 of the weight update: {x, y, z, ck+kappa} and track | is_valid << 16
+  float4 *pix4 = nullptr;
+  uint32_t *pixt = nullptr;
   float *ck_kappa = nullptr;
   // births
   uint32_t *b_valid = nullptr, *b_rank = nullptr;
