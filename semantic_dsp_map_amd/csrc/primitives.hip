@@ -148,15 +148,25 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint32_t *__restr
     // base[digit] = (all keys with a smaller digit) + (keys with this digit in earlier tiles) itself.
     static_assert(RS_DPT == 2, "two digits per thread");
     uint32_t below[2] = {0, 0}, total[2] = {0, 0};
-    for (uint32_t t = 0; t < n_tiles; ++t) {
-      const uint32_t h0 = offsets[(size_t)t * RS_RADIX + threadIdx.x];
-      const uint32_t h1 = offsets[(size_t)t * RS_RADIX + RS_THREADS + threadIdx.x];
-      if (t < blockIdx.x) {
-        below[0] += h0;
-        below[1] += h1;
+    // 8 tiles per step: 16 independent loads in flight per thread (a serial loop here is pure L2 latency)
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 8) {
+      uint32_t h0[8], h1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t t = t0 + u;
+        const bool ok = t < n_tiles;
+        h0[u] = ok ? offsets[(size_t)t * RS_RADIX + threadIdx.x] : 0u;
+        h1[u] = ok ? offsets[(size_t)t * RS_RADIX + RS_THREADS + threadIdx.x] : 0u;
       }
-      total[0] += h0;
-      total[1] += h1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (t0 + u < blockIdx.x) {
+          below[0] += h0[u];
+          below[1] += h1[u];
+        }
+        total[0] += h0[u];
+        total[1] += h1[u];
+      }
     }
     uint32_t carry = 0;
 #pragma unroll
