@@ -228,13 +228,16 @@ __global__ void k_move_local_counts(const uint32_t *__restrict__ offs, int n_obj
 }
 
 // one thread: e_base[k], total; also resets the export counter
-__global__ void k_move_bases(const int32_t *__restrict__ counts_all, int world, int rank, int n_obj, Scratch sc) {
+__global__ void k_move_bases(const int32_t *__restrict__ counts_all, int world, int rank, int n_obj, Scratch sc,
+                             const uint32_t *__restrict__ offs) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   uint32_t run = 0;
   for (int k = 0; k < n_obj; ++k) {
     uint32_t below = 0, all = 0;
     for (int r = 0; r < world; ++r) {
-      uint32_t c = (uint32_t)counts_all[r * HALO_OBJ + k];
+      // single shard: the count row is read straight from the scanned count matrix
+      uint32_t c = counts_all ? (uint32_t)counts_all[r * HALO_OBJ + k]
+                              : offs[(size_t)(k + 1) * MV_LIST_CAP] - offs[(size_t)k * MV_LIST_CAP];
       if (r < rank) below += c;
       all += c;
     }
@@ -468,14 +471,15 @@ void launch_moves_count(const Dims &d, const MoveSet &ms_dev, int n_obj, const S
   exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch, s);
   hipLaunchKernelGGL(k_move_scatter, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, slot_base, ms_dev, sc.mv_cnt, n_obj, sc.mv_src,
                      sc.cap_move, sc.cnt, sc.mv_list, sc.mv_nlist);
-  hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, n_obj, counts_local);
+  // the per-object counts are only needed as a separate row when they are exchanged between shards
+  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, n_obj, counts_local);
 }
 
 // step 2 (after the counts of all shards are known): global ranks, transform, export of slab-crossing copies
 void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms_dev, int n_obj, const State &st,
                             const Scratch &sc, const int32_t *counts_all, int world, int rank, hipStream_t s) {
   if (n_obj <= 0) return;
-  hipLaunchKernelGGL(k_move_bases, dim3(1), dim3(64), 0, s, counts_all, world, rank, n_obj, sc);
+  hipLaunchKernelGGL(k_move_bases, dim3(1), dim3(64), 0, s, d.v_count != d.V ? counts_all : nullptr, world, rank, n_obj, sc, sc.mv_cnt);
   // with several shards most ranks of the global list belong to other shards: they must read "not mine"
   if (world > 1) hipLaunchKernelGGL(k_move_init_keys, dim3(256), dim3(TPB), 0, s, d, sc);
   hipLaunchKernelGGL(k_move_transform, dim3(256), dim3(TPB), 0, s, d, f, flt, ms_dev, st, sc, sc.mv_cnt, n_obj, world > 1 ? 0 : 1);

@@ -95,13 +95,12 @@ constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_BITS = 9;                      // 25-bit voxel keys sort in 3 passes
 constexpr int RS_RADIX = 1 << RS_BITS;          // 512
 constexpr int RS_DPT = RS_RADIX / RS_THREADS;   // digits per thread when a block walks the digit table
-constexpr size_t RS_SELF_TILES = 320;           // up to 655 K keys: scatter blocks compute their own offsets
 
 // histogram of one digit per tile; layout hist[digit * n_tiles + tile] so that one exclusive scan over the
 // whole array yields the global scatter offsets.
 __global__ __launch_bounds__(RS_THREADS) void rs_histogram(const uint32_t *__restrict__ keys, uint32_t *__restrict__ hist,
                                                            size_t n, int shift, uint32_t n_tiles,
-                                                           const uint32_t *__restrict__ n_dev, int tile_major) {
+                                                           const uint32_t *__restrict__ n_dev) {
   __shared__ uint32_t h[RS_RADIX];
   if (n_dev) n = *n_dev < n ? (size_t)*n_dev : n;
 #pragma unroll
@@ -117,8 +116,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_histogram(const uint32_t *__res
 #pragma unroll
   for (int q = 0; q < RS_DPT; ++q) {
     int dg = threadIdx.x + q * RS_THREADS;
-    if (tile_major) hist[(size_t)blockIdx.x * RS_RADIX + dg] = h[dg];
-    else hist[(size_t)dg * n_tiles + blockIdx.x] = h[dg];
+    hist[(size_t)dg * n_tiles + blockIdx.x] = h[dg];
   }
 }
 
@@ -129,66 +127,16 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint32_t *__restr
                                                          const uint32_t *__restrict__ vals_in,
                                                          uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                          const uint32_t *__restrict__ offsets, size_t n, int shift,
-                                                         uint32_t n_tiles, const uint32_t *__restrict__ n_dev,
-                                                         int self_offsets) {
+                                                         uint32_t n_tiles, const uint32_t *__restrict__ n_dev) {
   __shared__ uint32_t digit_base[RS_RADIX];
   __shared__ uint32_t wave_cnt[RS_WAVES][RS_RADIX];
-  __shared__ uint32_t wave_tot[RS_WAVES];
   if (n_dev) n = *n_dev < n ? (size_t)*n_dev : n;
   if ((size_t)blockIdx.x * RS_TILE >= n) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (!self_offsets) {
 #pragma unroll
-    for (int q = 0; q < RS_DPT; ++q) {
-      int dg = threadIdx.x + q * RS_THREADS;
-      digit_base[dg] = offsets[(size_t)dg * n_tiles + blockIdx.x];
-    }
-  } else {
-    // Few tiles: skip the separate scan launches.  `offsets` is the raw tile-major histogram; this block derives
-    // base[digit] = (all keys with a smaller digit) + (keys with this digit in earlier tiles) itself.
-    static_assert(RS_DPT == 2, "two digits per thread");
-    uint32_t below[2] = {0, 0}, total[2] = {0, 0};
-    // 8 tiles per step: 16 independent loads in flight per thread (a serial loop here is pure L2 latency)
-    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 8) {
-      uint32_t h0[8], h1[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const uint32_t t = t0 + u;
-        const bool ok = t < n_tiles;
-        h0[u] = ok ? offsets[(size_t)t * RS_RADIX + threadIdx.x] : 0u;
-        h1[u] = ok ? offsets[(size_t)t * RS_RADIX + RS_THREADS + threadIdx.x] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (t0 + u < blockIdx.x) {
-          below[0] += h0[u];
-          below[1] += h1[u];
-        }
-        total[0] += h0[u];
-        total[1] += h1[u];
-      }
-    }
-    uint32_t carry = 0;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {  // digits q*256 + tid, in digit order
-      uint32_t inc = total[q];
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        uint32_t nb = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += nb;
-      }
-      if (lane == 63) wave_tot[wid] = inc;
-      __syncthreads();
-      uint32_t pre = carry, all = 0;
-#pragma unroll
-      for (int w = 0; w < RS_WAVES; ++w) {
-        if (w < wid) pre += wave_tot[w];
-        all += wave_tot[w];
-      }
-      digit_base[q * RS_THREADS + threadIdx.x] = pre + inc - total[q] + below[q];
-      carry += all;
-      __syncthreads();
-    }
+  for (int q = 0; q < RS_DPT; ++q) {
+    int dg = threadIdx.x + q * RS_THREADS;
+    digit_base[dg] = offsets[(size_t)dg * n_tiles + blockIdx.x];
   }
   size_t base = (size_t)blockIdx.x * RS_TILE;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -262,12 +210,10 @@ int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint3
   for (int shift = 0; shift < nbits; shift += RS_BITS) {
     uint32_t *kin = which ? keys_b : keys_a, *vin = which ? vals_b : vals_a;
     uint32_t *kout = which ? keys_a : keys_b, *vout = which ? vals_a : vals_b;
-    // up to RS_SELF_TILES tiles every scatter block sums the tile histograms itself: 2 launches per pass, not 4
-    const int self = tiles <= RS_SELF_TILES ? 1 : 0;
-    hipLaunchKernelGGL(rs_histogram, dim3((unsigned)tiles), dim3(RS_THREADS), 0, s, kin, hist, n, shift, (uint32_t)tiles, n_dev, self);
-    if (!self) exclusive_scan_u32(hist, hist, hist_n, scan_scratch, s);
+    hipLaunchKernelGGL(rs_histogram, dim3((unsigned)tiles), dim3(RS_THREADS), 0, s, kin, hist, n, shift, (uint32_t)tiles, n_dev);
+    exclusive_scan_u32(hist, hist, hist_n, scan_scratch, s);
     hipLaunchKernelGGL(rs_scatter, dim3((unsigned)tiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, hist, n, shift,
-                       (uint32_t)tiles, n_dev, self);
+                       (uint32_t)tiles, n_dev);
     which ^= 1;
   }
   return which;
