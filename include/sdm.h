@@ -112,6 +112,7 @@ typedef struct {
 /* sdm_update flags */
 #define SDM_INPUT_ON_DEVICE 0x1u /* depth / cloud are device pointers already resident in HBM */
 #define SDM_SKIP_OCCUPANCY 0x2u  /* do not run the occupancy sweep (debug)                     */
+#define SDM_NO_INSTANCES 0x4u    /* sdm_update_raw: ignore the object masks (g_consider_instance == false, settings.h:49) */
 
 /* stage ids (also indices of sdm_stats.stage_ms): the reference's own stage timers,
  * semantic_dsp_map.h:916-921 */
@@ -183,6 +184,28 @@ sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *c
                       const sdm_object_move *moves, int32_t n_moves,
                       const int32_t *remove_tracks, int32_t n_remove,
                       uint32_t flags, int32_t stop_after);
+
+/* ---- the step right before the path, PointCloudTools::generateLabeledPointCloud
+ * (utils/pointcloud_tools.h:88-310, general non-BOOST / non-ZED2 path), on the device.  Instead of the 20-byte
+ * LabeledPoint image the caller hands over what the reference's update() receives: the depth image, the "static" MONO8
+ * mask (pixel value + 1 = label id, :137-138; NULL = every pixel Background/65535, :147-156) and one MONO8 mask per
+ * movable object (> 0 = object, later entries override earlier ones, :163-213), plus the camera pose in double
+ * (the reference back-projects in double and casts to float, :243-249, 298-300).
+ * label_to_static_instance[256]: instance id of a static label id (g_label_to_instance_id_map_default), 65535 for
+ * label ids without one.  Every mask is H*W bytes, host memory (or device memory with SDM_INPUT_ON_DEVICE). */
+typedef struct {
+  int32_t track_id;    /* <= max_movable_track */
+  int32_t label_id;    /* g_label_id_map_default[label] */
+  const uint8_t *mask; /* H*W, > 0 = object */
+} sdm_instance_mask;
+sdm_status sdm_update_raw(sdm_map *m, const float *depth, const uint8_t *static_mask,
+                          const uint16_t label_to_static_instance[256],
+                          const sdm_instance_mask *objects, int32_t n_objects,
+                          const double cam_pos[3], const double cam_q[4],
+                          const sdm_object_move *moves, int32_t n_moves,
+                          const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after);
+/* the LabeledPoint image sdm_update_raw generated for the last frame (H*W entries), for cross-checks */
+sdm_status sdm_get_labeled_cloud(sdm_map *m, sdm_labeled_point *out);
 
 /* The same frame split at its one cross-shard dependency: sdm_update_begin runs the
  * prediction, visibility/binning and this shard's partial ck image (pass 1 of updateParticles,

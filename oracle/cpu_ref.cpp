@@ -1116,6 +1116,79 @@ int64_t oracle_get_bins(oracle_map *m, uint32_t *out, int64_t cap) {
 void oracle_get_extrinsic(oracle_map *m, float *out16) { memcpy(out16, m->extrinsic, 64); }
 void oracle_get_pdf_table(oracle_map *m, float *out) { memcpy(out, m->pdf.data(), m->pdf.size() * 4); }
 
+// utils/pointcloud_tools.h:88-310.  PINNED: K^-1 = (1/fx, -cx/fx, 1/fy, -cy/fy) in double (the reference inverts K
+// with Eigen), K^-1*(j,i,1) = (ifx*j + icx, ify*i + icy, 1), R from Eigen's toRotationMatrix formula in double,
+// camera-to-global = ((r0*x + r1*y) + r2*z) + t; fields of invalid points (uninitialised in the reference) are zero
+// with sigma = zero-order term.
+void oracle_generate_cloud(oracle_map *m, const float *depth, const uint8_t *static_mask, const uint16_t *label_to_inst,
+                           const int32_t *obj_track, const int32_t *obj_label, const uint8_t *obj_masks, int32_t n_objects,
+                           const double cam_pos[3], const double cam_q[4], int32_t consider_instance,
+                           oracle_labeled_point *out) {
+  const oracle_config &c = m->cfg;
+  const int W = c.width, H = c.height;
+  const size_t hw = (size_t)W * H;
+  const double w = cam_q[0], x = cam_q[1], y = cam_q[2], z = cam_q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  const double R[9] = {1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx,
+                       txz - twy,         tyz + twx, 1.0 - (txx + tyy)};
+  const double ifx = 1.0 / (double)c.fx, icx = -(double)c.cx / (double)c.fx;
+  const double ify = 1.0 / (double)c.fy, icy = -(double)c.cy / (double)c.fy;
+  const double dmin = (double)c.depth_min, dmax = (double)c.depth_max;
+  for (int i = 0; i < H; ++i)
+    for (int j = 0; j < W; ++j) {
+      const size_t p = (size_t)i * W + j;
+      const float dv = depth[p];
+      oracle_labeled_point o;
+      if (std::isnan(dv) || (double)dv < dmin || (double)dv > dmax) {
+        o.x = o.y = o.z = 0.f;
+        o.sigma = m->prm.if_consider_depth_noise ? m->prm.depth_noise_zero_order : 0.1f;
+        o.track_id = 0;
+        o.label_id = 0;
+        o.is_valid = 0;
+        out[p] = o;
+        continue;
+      }
+      uint32_t inst = 65535u;
+      int label = 0;
+      bool from_object = false;
+      if (static_mask) {
+        uint32_t pixel_label = (uint32_t)static_mask[p] + 1u;  // :137-138
+        inst = label_to_inst[pixel_label > 255u ? 255u : pixel_label];
+      }
+      if (consider_instance)
+        for (int k = 0; k < n_objects; ++k)
+          if (obj_masks[(size_t)k * hw + p] > 0) {  // :196-207
+            inst = (uint32_t)obj_track[k];
+            label = obj_label[k];
+            from_object = true;
+          }
+      if ((int)inst > c.max_movable_track) {  // :277-283
+        label = 0;
+        if (static_mask)
+          for (int l = 0; l < 256; ++l)
+            if (label_to_inst[l] == inst) {
+              label = l;
+              break;
+            }
+      } else if (!from_object) {
+        label = 0;
+      }
+      const double px = (ifx * (double)j + icx) * (double)dv;  // :243
+      const double py = (ify * (double)i + icy) * (double)dv;
+      const double pz = (double)dv;
+      o.x = (float)(((R[0] * px + R[1] * py) + R[2] * pz) + cam_pos[0]);  // :247, 298-300
+      o.y = (float)(((R[3] * px + R[4] * py) + R[5] * pz) + cam_pos[1]);
+      o.z = (float)(((R[6] * px + R[7] * py) + R[8] * pz) + cam_pos[2]);
+      o.sigma = m->prm.if_consider_depth_noise ? m->prm.depth_noise_zero_order + m->prm.depth_noise_first_order * dv : 0.1f;
+      o.track_id = (uint16_t)inst;
+      o.label_id = (uint8_t)label;
+      o.is_valid = 1;
+      out[p] = o;
+    }
+}
+
 uint32_t oracle_pos_to_voxel(oracle_map *m, float x, float y, float z) {
   uint32_t v, rx, ry, rz;
   m->globalPosToVoxel(x, y, z, v, rx, ry, rz);

@@ -153,6 +153,13 @@ void oracle_get_extrinsic(oracle_map *m, float *out16);
 /* standard_gaussian_pdf, 20000 floats (basic_algorithms.h:405-407) */
 void oracle_get_pdf_table(oracle_map *m, float *out);
 
+/* PointCloudTools::generateLabeledPointCloud (utils/pointcloud_tools.h:88-310), general (non-BOOST, non-ZED2) path.
+ * static_mask may be NULL; obj_masks = n_objects consecutive H*W masks; label_to_inst[256]. */
+void oracle_generate_cloud(oracle_map *m, const float *depth, const uint8_t *static_mask, const uint16_t *label_to_inst,
+                           const int32_t *obj_track, const int32_t *obj_label, const uint8_t *obj_masks, int32_t n_objects,
+                           const double cam_pos[3], const double cam_q[4], int32_t consider_instance,
+                           oracle_labeled_point *out);
+
 /* helpers exposed for known-answer tests */
 uint32_t oracle_pos_to_voxel(oracle_map *m, float x, float y, float z); /* 0xffffffff if outside */
 void oracle_voxel_to_pos(oracle_map *m, uint32_t voxel, float out[3]);  /* global min corner */

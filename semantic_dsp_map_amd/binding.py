@@ -52,6 +52,10 @@ class Params(C.Structure):
                 ("depth_noise_first_order", C.c_float), ("depth_noise_zero_order", C.c_float)]
 
 
+class InstanceMask(C.Structure):
+    _fields_ = [("track_id", C.c_int32), ("label_id", C.c_int32), ("mask", C.c_void_p)]
+
+
 class RingState(C.Structure):
     _fields_ = [("global_time_stamp", C.c_uint32), ("moved_steps", C.c_int32 * 3), ("eq_steps", C.c_int32 * 3),
                 ("map_center", C.c_float * 3), ("last_pos", C.c_float * 3),
@@ -93,6 +97,8 @@ def load_library():
         "sdm_download_noise_table": [vp, vp, i32],
         "sdm_download_pdf_table": [vp, vp, i32],
         "sdm_update": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32],
+        "sdm_update_raw": [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, i32, u32, i32],
+        "sdm_get_labeled_cloud": [vp, vp],
         "sdm_update_begin": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32, C.POINTER(vp)],
         "sdm_update_finish": [vp, vp, i32, u32, i32],
         "sdm_frame_start": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32],
@@ -242,6 +248,33 @@ class SdmMap:
         _check(self.L, self.L.sdm_update(self.h, *args, fl, st), "sdm_update")
         if sync:
             self.synchronize()
+
+    def update_raw(self, depth, static_mask, label_to_inst, objects, cam_pos, cam_q, moves=None, remove_tracks=None,
+                   stop_after="all", flags=0, sync=False):
+        """SURVEY row N1 on the device.  objects: list of (track_id, label_id, mask HxW uint8); pose in double."""
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        sm = None if static_mask is None else np.ascontiguousarray(static_mask, dtype=np.uint8)
+        tab = np.ascontiguousarray(label_to_inst, dtype=np.uint16)
+        assert tab.size == 256
+        masks = [np.ascontiguousarray(o[2], dtype=np.uint8) for o in objects]
+        arr = (InstanceMask * max(len(objects), 1))()
+        for k, o in enumerate(objects):
+            arr[k].track_id, arr[k].label_id, arr[k].mask = int(o[0]), int(o[1]), masks[k].ctypes.data
+        pos = np.ascontiguousarray(cam_pos, dtype=np.float64)
+        q = np.ascontiguousarray(cam_q, dtype=np.float64)
+        mv = np.ascontiguousarray(moves if moves is not None else np.zeros(0, OBJECT_MOVE), dtype=OBJECT_MOVE)
+        rm = np.ascontiguousarray(remove_tracks if remove_tracks is not None else [], dtype=np.int32)
+        st = STAGES[stop_after] if isinstance(stop_after, str) else stop_after
+        _check(self.L, self.L.sdm_update_raw(self.h, _ptr(depth), _ptr(sm), _ptr(tab), C.cast(arr, C.c_void_p), len(objects),
+                                             _ptr(pos), _ptr(q), _ptr(mv) if mv.size else None, mv.size,
+                                             _ptr(rm) if rm.size else None, rm.size, flags, st), "sdm_update_raw")
+        if sync:
+            self.synchronize()
+
+    def labeled_cloud(self):
+        out = np.empty(self.W * self.H, LABELED_POINT)
+        _check(self.L, self.L.sdm_get_labeled_cloud(self.h, _ptr(out)), "sdm_get_labeled_cloud")
+        return out
 
     def update_begin(self, depth, cloud, cam_pos, cam_q, moves=None, remove_tracks=None, stop_after="all",
                      on_device=False, flags=0):

@@ -1038,6 +1038,80 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
   if (n_success) atomicAdd(&sc.cnt->n_birth_success, n_success);
 }
 
+// ------------------------------------------------------------------------------------ N1
+// PointCloudTools::generateLabeledPointCloud (utils/pointcloud_tools.h:88-310), general path: merge the masks into a
+// track-id image, back-project every valid depth pixel in double, cast to float, attach label and sigma.
+// PINNED: K^-1 is (1/fx, -cx/fx, 1/fy, -cy/fy) in double; K^-1*(j,i,1) = (ifx*j + icx, ify*i + icy, 1);
+// camera-to-global = ((r0*x + r1*y) + r2*z) + t with Eigen's toRotationMatrix formula in double.
+struct CloudArgs {
+  double R[9], t[3];
+  double ifx, icx, ify, icy;
+  double dmin, dmax;
+  float sigma0, sigma1;
+  int consider_depth_noise, consider_instance, n_objects, has_static;
+  int track[MAX_CLOUD_OBJECTS], label[MAX_CLOUD_OBJECTS];
+};
+
+__global__ __launch_bounds__(TPB) void k_labeled_cloud(Dims d, CloudArgs a, const float *__restrict__ depth,
+                                                       const uint8_t *__restrict__ static_mask,
+                                                       const uint16_t *__restrict__ label_to_inst,
+                                                       const uint8_t *__restrict__ obj_masks,
+                                                       sdm_labeled_point *__restrict__ cloud) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int hw = d.W * d.H;
+  if (p >= hw) return;
+  const int i = p / d.W, j = p % d.W;
+  const float dv = depth[p];
+  sdm_labeled_point o;
+  if (isnan(dv) || (double)dv < a.dmin || (double)dv > a.dmax) {  // :228
+    // PINNED: the reference leaves the fields of an invalid point uninitialised
+    o.x = o.y = o.z = 0.f;
+    o.sigma = a.consider_depth_noise ? a.sigma0 : 0.1f;
+    o.track_id = 0;
+    o.label_id = 0;
+    o.is_valid = 0;
+    cloud[p] = o;
+    return;
+  }
+  // track id image: static mask first (:121-156), then every movable object's mask in order (:163-213)
+  uint32_t inst = 65535u;
+  int label = 0;
+  bool from_object = false;
+  if (a.has_static) inst = label_to_inst[(uint32_t)static_mask[p] + 1u > 255u ? 255u : (uint32_t)static_mask[p] + 1u];
+  if (a.consider_instance)
+    for (int k = 0; k < a.n_objects; ++k)
+      if (obj_masks[(size_t)k * hw + p] > 0) {
+        inst = (uint32_t)a.track[k];
+        label = a.label[k];
+        from_object = true;
+      }
+  if ((int)inst > d.max_movable) {  // :277-283: static instance -> its label
+    label = 0;
+    if (a.has_static)
+      for (int l = 0; l < 256; ++l)
+        if (label_to_inst[l] == inst) {
+          label = l;
+          break;
+        }
+  } else if (!from_object) {
+    label = 0;  // movable id that came out of the static mask table: track_to_label_id_map default (:282)
+  }
+  const double x = (a.ifx * (double)j + a.icx) * (double)dv;  // :243
+  const double y = (a.ify * (double)i + a.icy) * (double)dv;
+  const double z = (double)dv;
+  const double gx = ((a.R[0] * x + a.R[1] * y) + a.R[2] * z) + a.t[0];  // :247
+  const double gy = ((a.R[3] * x + a.R[4] * y) + a.R[5] * z) + a.t[1];
+  const double gz = ((a.R[6] * x + a.R[7] * y) + a.R[8] * z) + a.t[2];
+  o.x = (float)gx;
+  o.y = (float)gy;
+  o.z = (float)gz;
+  o.sigma = a.consider_depth_noise ? a.sigma0 + a.sigma1 * dv : 0.1f;  // :284-289
+  o.track_id = (uint16_t)inst;
+  o.label_id = (uint8_t)label;
+  o.is_valid = 1;
+  cloud[p] = o;
+}
+
 // ------------------------------------------------------------------------------------ utilities
 __global__ __launch_bounds__(TPB) void k_count_live(Dims d, State st, unsigned long long *out) {
   uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1219,6 +1293,15 @@ void launch_birth_replay(const Dims &d, const Frame &f, const Filter &flt, const
   const uint32_t *sval = which ? sc.bval_b : sc.bval_a;
   dim3 grid(blocks_for(total));
   SDM_DISPATCH_S(k_birth_replay, grid, s, d, f, flt, st, sc, skey, sval, (uint32_t)total);
+}
+
+void launch_labeled_cloud(const Dims &d, const CloudArgsHost &h, const float *depth, const uint8_t *static_mask,
+                          const uint16_t *label_to_inst, const uint8_t *obj_masks, sdm_labeled_point *cloud, hipStream_t s) {
+  CloudArgs a;
+  static_assert(sizeof(CloudArgs) == sizeof(CloudArgsHost), "CloudArgs layout");
+  __builtin_memcpy(&a, &h, sizeof(a));
+  hipLaunchKernelGGL(k_labeled_cloud, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, a, depth, static_mask, label_to_inst,
+                     obj_masks, cloud);
 }
 
 void launch_count_live(const Dims &d, const State &st, unsigned long long *out, hipStream_t s) {

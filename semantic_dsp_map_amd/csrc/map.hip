@@ -96,6 +96,10 @@ struct sdm_map {
   float *d_depth = nullptr;
   sdm_labeled_point *d_cloud = nullptr;
   float *d_ck_part = nullptr;
+  // N1 inputs: static mask, label->instance table, object masks (grown on demand)
+  uint8_t *d_static_mask = nullptr, *d_obj_masks = nullptr;
+  uint16_t *d_label_to_inst = nullptr;
+  int obj_masks_cap = 0;
   MoveSet *d_moveset = nullptr;
   uint16_t *d_remove = nullptr;
   unsigned long long *d_u64 = nullptr;
@@ -512,6 +516,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.pixt, hw);
   A(sc.ck_kappa, hw);
   A(m->d_ck_part, hw);
+  A(m->d_static_mask, hw);
+  A(m->d_label_to_inst, 256);
   A(sc.b_valid, hw + 1);
   A(sc.b_rank, hw + 1);
   sc.cap_move = (uint32_t)std::min<size_t>(n_slots, (size_t)1 << 18);  // moved particles per frame (objects hold <= ~1e5)
@@ -571,7 +577,7 @@ sdm_status sdm_destroy(sdm_map *m) {
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
   for (void *p : m->allocs) (void)hipFree(p);
-  void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points};
+  void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points, m->d_obj_masks};
   for (void *p : extra)
     if (p) (void)hipFree(p);
   if (m->comm) (void)ncclCommDestroy(m->comm);
@@ -882,6 +888,88 @@ sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *c
   if (rc == SDM_OK) rc = sdm_update_finish(m, nullptr, 1, flags, stop_after);
   m->fused_ck = false;
   return rc;
+}
+
+// SURVEY.md row N1 on the device: masks + depth -> LabeledPoint image, then the usual frame on device-resident inputs.
+sdm_status sdm_update_raw(sdm_map *m, const float *depth, const uint8_t *static_mask, const uint16_t label_to_static_instance[256],
+                          const sdm_instance_mask *objects, int32_t n_objects, const double cam_pos[3], const double cam_q[4],
+                          const sdm_object_move *moves, int32_t n_moves, const int32_t *remove_tracks, int32_t n_remove,
+                          uint32_t flags, int32_t stop_after) {
+  if (!m || !depth || !cam_pos || !cam_q || n_objects < 0 || n_objects > MAX_CLOUD_OBJECTS || (n_objects && !objects) ||
+      (static_mask && !label_to_static_instance))
+    return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  const Dims &d = m->d;
+  const size_t hw = (size_t)d.W * d.H;
+  const bool on_dev = (flags & SDM_INPUT_ON_DEVICE) != 0;
+  const hipMemcpyKind kind = on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (n_objects > m->obj_masks_cap) {
+    HIP_TRY(hipStreamSynchronize(s));
+    if (m->d_obj_masks) HIP_TRY(hipFree(m->d_obj_masks));
+    m->d_obj_masks = nullptr;
+    HIP_TRY(dev_alloc(&m->d_obj_masks, hw * n_objects));
+    m->obj_masks_cap = n_objects;
+  }
+  const float *depth_dev = depth;
+  if (!on_dev) {
+    HIP_TRY(hipMemcpyAsync(m->d_depth, depth, hw * sizeof(float), hipMemcpyHostToDevice, s));
+    depth_dev = m->d_depth;
+  }
+  if (static_mask) {
+    HIP_TRY(hipMemcpyAsync(m->d_static_mask, static_mask, hw, kind, s));
+    HIP_TRY(hipMemcpyAsync(m->d_label_to_inst, label_to_static_instance, 512, hipMemcpyHostToDevice, s));
+  }
+  CloudArgsHost a;
+  memset(&a, 0, sizeof(a));
+  for (int k = 0; k < n_objects; ++k) {
+    if (!objects[k].mask) return SDM_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipMemcpyAsync(m->d_obj_masks + hw * k, objects[k].mask, hw, kind, s));
+    a.track[k] = objects[k].track_id;
+    a.label[k] = objects[k].label_id;
+  }
+  // Eigen's Quaternion::toRotationMatrix in double (pointcloud_tools.h:107-110)
+  {
+    const double w = cam_q[0], x = cam_q[1], y = cam_q[2], z = cam_q[3];
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    a.R[0] = 1.0 - (tyy + tzz);
+    a.R[1] = txy - twz;
+    a.R[2] = txz + twy;
+    a.R[3] = txy + twz;
+    a.R[4] = 1.0 - (txx + tzz);
+    a.R[5] = tyz - twx;
+    a.R[6] = txz - twy;
+    a.R[7] = tyz + twx;
+    a.R[8] = 1.0 - (txx + tyy);
+  }
+  for (int k = 0; k < 3; ++k) a.t[k] = cam_pos[k];
+  a.ifx = 1.0 / (double)d.fx;
+  a.icx = -(double)d.cx / (double)d.fx;
+  a.ify = 1.0 / (double)d.fy;
+  a.icy = -(double)d.cy / (double)d.fy;
+  a.dmin = (double)d.dmin;
+  a.dmax = (double)d.dmax;
+  a.sigma0 = m->prm.depth_noise_zero_order;
+  a.sigma1 = m->prm.depth_noise_first_order;
+  a.consider_depth_noise = m->prm.if_consider_depth_noise ? 1 : 0;
+  a.consider_instance = (flags & SDM_NO_INSTANCES) ? 0 : 1;
+  a.n_objects = n_objects;
+  a.has_static = static_mask ? 1 : 0;
+  launch_labeled_cloud(d, a, depth_dev, m->d_static_mask, m->d_label_to_inst, m->d_obj_masks, m->d_cloud, s);
+  const float posf[3] = {(float)cam_pos[0], (float)cam_pos[1], (float)cam_pos[2]};       // semantic_dsp_map.h:584
+  const float qf[4] = {(float)cam_q[0], (float)cam_q[1], (float)cam_q[2], (float)cam_q[3]};  // :745
+  return sdm_update(m, depth_dev, m->d_cloud, posf, qf, moves, n_moves, remove_tracks, n_remove, flags | SDM_INPUT_ON_DEVICE,
+                    stop_after);
+}
+
+sdm_status sdm_get_labeled_cloud(sdm_map *m, sdm_labeled_point *out) {
+  if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMemcpyAsync(out, m->sc.cloud, (size_t)m->d.W * m->d.H * sizeof(sdm_labeled_point), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return SDM_OK;
 }
 
 sdm_status sdm_synchronize(sdm_map *m) {

@@ -63,6 +63,19 @@ struct Scratch {
   Cursors *cur = nullptr;
 };
 
+// N1: arguments of the labeled-point-cloud kernel (same layout as the kernel-side struct)
+constexpr int MAX_CLOUD_OBJECTS = 64;
+struct CloudArgsHost {
+  double R[9], t[3];
+  double ifx, icx, ify, icy;
+  double dmin, dmax;
+  float sigma0, sigma1;
+  int consider_depth_noise, consider_instance, n_objects, has_static;
+  int track[MAX_CLOUD_OBJECTS], label[MAX_CLOUD_OBJECTS];
+};
+void launch_labeled_cloud(const Dims &d, const CloudArgsHost &h, const float *depth, const uint8_t *static_mask,
+                          const uint16_t *label_to_inst, const uint8_t *obj_masks, sdm_labeled_point *cloud, hipStream_t s);
+
 void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s);
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s);
 void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_generic, hipStream_t s);

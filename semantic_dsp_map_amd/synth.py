@@ -243,6 +243,31 @@ class Scene:
         return depth.reshape(H, W), cloud, pos.astype(np.float32), q.astype(np.float32)
 
 
+# label id -> static instance id of the reference's cfg/object_info.csv (65535 where a label has none)
+LABEL_TO_STATIC_INSTANCE = np.full(256, 65535, np.uint16)
+for _l, _i in {0: 65535, 3: 65533, 4: 65532, 5: 65531, 6: 65530, 7: 65529, 8: 65528, 9: 65527, 10: 65526, 11: 65525,
+               12: 65524, 13: 65523}.items():
+    LABEL_TO_STATIC_INSTANCE[_l] = _i
+
+
+def raw_inputs(cfg, cloud, scene):
+    """The inputs the reference's update() receives for the same frame (mask_kpts_msgs semantics,
+    docs/custom_files.md:16-45): a "static" MONO8 mask whose pixel value + 1 is the label id, and one MONO8 mask per
+    movable object.  Derived from a rendered LabeledPoint image; pixels of movable objects show Road in the static
+    mask (something static has to be there)."""
+    H, W = cfg["height"], cfg["width"]
+    lab = cloud["label_id"].astype(np.int32)
+    trk = cloud["track_id"].astype(np.int32)
+    movable = (trk <= cfg["max_movable_track"]) & (cloud["is_valid"] > 0)
+    static_label = np.where(movable | (cloud["is_valid"] == 0), LABEL_ROAD, lab)
+    static_mask = (static_label - 1).astype(np.uint8).reshape(H, W)
+    objects = []
+    for t in scene.dyn_tracks:
+        m = (movable & (trk == int(t))).astype(np.uint8).reshape(H, W)
+        objects.append((int(t), LABEL_CAR, m))
+    return static_mask, objects
+
+
 def make_frames(cfg_name, n_frames, params_name=None, seed=7, **scene_kw):
     """Convenience: list of (depth, cloud, cam_pos, cam_q, moves) for a named configuration."""
     cfg = CONFIGS[cfg_name]
