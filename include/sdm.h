@@ -269,9 +269,16 @@ sdm_status sdm_synchronize(sdm_map *m);
 /* ---- results (getOccupancyResult, semantic_dsp_map.h:1239-1383) */
 /* all voxels in storage order; out has 2^(x_n+y_n+z_n) entries (this shard's slab if sharded) */
 sdm_status sdm_get_voxels(sdm_map *m, sdm_voxel_result *out);
-/* compacted list of voxels with occ > 0 (occupied) or occ == 0 (free) in increasing storage index */
-sdm_status sdm_get_occupied(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t zero_center);
-sdm_status sdm_get_freespace(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t zero_center);
+/* compacted list of voxels with occ > 0 (occupied) or occ == 0 (free) in increasing storage index.
+ * flags: SDM_POINTS_ZERO_CENTER subtracts the camera position (visualize_with_zero_center_, semantic_dsp_map.h:1263-1271);
+ * SDM_POINTS_MARK_FOV adds SDM_OCC_OUT_OF_FOV to sdm_point.occ of voxels whose global position fails
+ * checkIfPointInFrustum against the last frame's extrinsic (the test that selects the HSV dimming,
+ * semantic_dsp_map.h:1339-1342). */
+#define SDM_POINTS_ZERO_CENTER 0x1
+#define SDM_POINTS_MARK_FOV 0x2
+#define SDM_OCC_OUT_OF_FOV 0x40
+sdm_status sdm_get_occupied(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t flags);
+sdm_status sdm_get_freespace(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t flags);
 /* device pointer to the per-voxel result array (valid until the next update) */
 sdm_status sdm_voxels_device_ptr(sdm_map *m, const sdm_voxel_result **out);
 

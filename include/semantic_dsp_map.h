@@ -9,10 +9,12 @@
  *   - the object layer (objectLevelUpdate, :306-566): NOT re-implemented here.  Plug the reference's own
  *     ObjectSet logic in through SdmObjectLayer (INTEGRATION.md shows the 20-line glue); without one the map runs
  *     like the reference with g_consider_instance == false,
- *   - generateLabeledPointCloud (utils/pointcloud_tools.h:88-310), restated below for the non-BOOST, non-ZED
- *     presets (the ZED2 bounding-box filter and the BOOST resize are not ported yet),
- *   - colouring of the emitted cloud (semantic_dsp_map.h:1274-1331).  Not ported: the HSV "V x 0.7" dimming of
- *     voxels outside the view frustum (:1333-1351, one OpenCV cvtColor round trip per voxel in the reference).
+ *   - packing of the depth image and the MONO8 masks for sdm_update_raw(), which runs generateLabeledPointCloud
+ *     (utils/pointcloud_tools.h:88-310) on the device for the non-BOOST, non-ZED presets (the ZED2
+ *     bounding-box filter and the BOOST resize are not ported yet),
+ *   - colouring of the emitted cloud (semantic_dsp_map.h:1274-1351): the colour rules and OpenCV's RGB<->HSV round
+ *     trip stay host code (one batched cvtColor instead of the reference's two per voxel); the in-view test that
+ *     selects the "V x 0.7" dimming comes from the device with each point (SDM_POINTS_MARK_FOV, row N2).
  *
  * Compile-time grid/camera constants of settings/settings.h become SdmGridPreset; pick one with
  * setGridPreset() before the first update() (default: the reference's SETTING 2, VIRTUAL_KITTI2).
@@ -138,6 +140,7 @@ class SemanticDSPMap {
       min_static = std::min(min_static, kv.second);
     }
     max_movable_track_ = min_static - 1;  // object_info_handler.h:84
+    rebuildLabelToInstance();
   }
 
   // ---- the reference's public interface ----
@@ -217,16 +220,20 @@ class SemanticDSPMap {
       object_layer_->update(ins_seg_result, camera_position, camera_orientation, time_stamp_double);
       object_layer_->collect(global_time_stamp_, params_.max_obersevation_lost_time, moves, removals);
     }
-    if (generateLabeledPointCloud(depth_value_mat, ins_seg_result, camera_position, camera_orientation) != 0) return;
+    if (packRawInputs(depth_value_mat, ins_seg_result) != 0) return;
 
-    const Eigen::Vector3f pf = camera_position.cast<float>();  // :584
+    // pose in double for the back-projection (pointcloud_tools.h:243-247); the library casts it to float for the
+    // map update like the reference does (semantic_dsp_map.h:584, 745)
+    const double cam_pos_d[3] = {camera_position.x(), camera_position.y(), camera_position.z()};
+    const double cam_q_d[4] = {camera_orientation.w(), camera_orientation.x(), camera_orientation.y(), camera_orientation.z()};
+    const Eigen::Vector3f pf = camera_position.cast<float>();
     const float cam_pos[3] = {pf.x(), pf.y(), pf.z()};
-    const Eigen::Quaternionf qf = camera_orientation.cast<float>();  // :745
-    const float cam_q[4] = {qf.w(), qf.x(), qf.y(), qf.z()};
-    if (!check(sdm_update(map_, depth_.data(), cloud_.data(), cam_pos, cam_q, moves.empty() ? nullptr : moves.data(),
-                          (int32_t)moves.size(), removals.empty() ? nullptr : removals.data(), (int32_t)removals.size(), 0,
-                          SDM_STAGE_ALL),
-               "sdm_update"))
+    if (!check(sdm_update_raw(map_, depth_.data(), have_static_ ? static_mask_.data() : nullptr, label_to_inst_,
+                              objects_.empty() ? nullptr : objects_.data(), (int32_t)objects_.size(), cam_pos_d, cam_q_d,
+                              moves.empty() ? nullptr : moves.data(), (int32_t)moves.size(),
+                              removals.empty() ? nullptr : removals.data(), (int32_t)removals.size(),
+                              preset_.consider_instance ? 0u : SDM_NO_INSTANCES, SDM_STAGE_ALL),
+               "sdm_update_raw"))
       return;
     emit(occupied_point_cloud, false, cam_pos);
     if (if_get_freespace) emit(freespace_point_cloud, true, cam_pos);
@@ -250,7 +257,10 @@ class SemanticDSPMap {
   std::unordered_map<int, int> static_instance_to_label_;   // g_instance_id_to_label_map_default -> label id
   std::unordered_map<int, cv::Vec3b> label_color_;          // g_label_color_map_default (BGR)
   std::vector<float> depth_;
-  std::vector<sdm_labeled_point> cloud_;
+  std::vector<uint8_t> static_mask_, object_masks_;
+  std::vector<sdm_instance_mask> objects_;
+  uint16_t label_to_inst_[256];  // g_label_to_instance_id_map_default as a table (65535 = Background's instance)
+  bool have_static_ = false;
   std::vector<sdm_point> points_;
 
   bool check(sdm_status s, const char *what) {
@@ -287,7 +297,12 @@ class SemanticDSPMap {
     check(sdm_generate_noise_table(map_, 20250217ull, 1000000, 0.05f), "sdm_generate_noise_table");
     pushParams();
     depth_.resize((size_t)c.width * c.height);
-    cloud_.resize((size_t)c.width * c.height);
+    static_mask_.resize((size_t)c.width * c.height);
+  }
+  void rebuildLabelToInstance() {
+    for (int l = 0; l < 256; ++l) label_to_inst_[l] = 65535;
+    for (const auto &kv : static_instance_to_label_)
+      if (kv.second >= 0 && kv.second < 256) label_to_inst_[kv.second] = (uint16_t)kv.first;
   }
 
   void defaultLabelTables() {  // utils/data_base.h:108-232
@@ -301,11 +316,13 @@ class SemanticDSPMap {
                             {11, 0, 130, 255},  {12, 80, 80, 80},  {13, 60, 60, 160},  {14, 80, 127, 255}, {15, 139, 139, 0}};
     for (auto &c : bgr) label_color_[c[0]] = cv::Vec3b((uchar)c[1], (uchar)c[2], (uchar)c[3]);
     max_movable_track_ = 65523;
+    rebuildLabelToInstance();
   }
 
-  /// PointCloudTools::generateLabeledPointCloud (utils/pointcloud_tools.h:88-310), general (non-BOOST, non-ZED) path.
-  int generateLabeledPointCloud(const cv::Mat &depth, const std::vector<MaskKpts> &seg, const Eigen::Vector3d &cam_p,
-                                const Eigen::Quaterniond &cam_q) {
+  /// Host half of PointCloudTools::generateLabeledPointCloud (utils/pointcloud_tools.h:88-213): validate the depth
+  /// image and lay the MONO8 masks out as dense H x W buffers; the per-pixel work (:218-304) is the device kernel
+  /// behind sdm_update_raw.
+  int packRawInputs(const cv::Mat &depth, const std::vector<MaskKpts> &seg) {
     if (depth.empty()) {
       std::cerr << "Error: depth image is empty." << std::endl;
       return -1;
@@ -315,62 +332,39 @@ class SemanticDSPMap {
       std::cerr << "Error: depth image size does not match the grid preset." << std::endl;
       return -1;
     }
-    const Eigen::Matrix3d R = cam_q.toRotationMatrix();
-    Eigen::Matrix3d K;
-    K << preset_.fx, 0, preset_.cx, 0, preset_.fy, preset_.cy, 0, 0, 1;
-    const Eigen::Matrix3d Kinv = K.inverse();
-    std::vector<uint16_t> track_mask((size_t)W * H, 65535);  // :147-156
-    std::unordered_map<int, int> track_to_label;
-    for (const auto &s : seg) {  // static mask first, :121-143
+    const size_t hw = (size_t)W * H;
+    for (int i = 0; i < H; ++i)
+      for (int j = 0; j < W; ++j) depth_[(size_t)i * W + j] = depth.at<float>(i, j);
+    have_static_ = false;
+    for (const auto &s : seg) {  // :121-143, the first "static" entry
       if (s.label != "static") continue;
+      std::fill(static_mask_.begin(), static_mask_.end(), (uint8_t)255);  // uncovered pixels: no label -> Background's instance
       for (int j = 0; j < s.mask.rows && j < H; ++j)
-        for (int k = 0; k < s.mask.cols && k < W; ++k) {
-          const int pixel_label = (int)s.mask.at<uchar>(j, k) + 1;  // :137-138
-          int inst = 65535;
-          for (const auto &kv : static_instance_to_label_)
-            if (kv.second == pixel_label) inst = kv.first;
-          track_mask[(size_t)j * W + k] = (uint16_t)inst;
-        }
+        for (int k = 0; k < s.mask.cols && k < W; ++k) static_mask_[(size_t)j * W + k] = s.mask.at<uchar>(j, k);
+      have_static_ = true;
       break;
     }
-    if (preset_.consider_instance) {  // :163-213
+    objects_.clear();
+    size_t n_obj = 0;
+    if (preset_.consider_instance)
+      for (const auto &s : seg) n_obj += s.label != "static";
+    object_masks_.assign(n_obj * hw, 0);
+    if (preset_.consider_instance) {  // :163-213, later masks override earlier ones
+      size_t k_obj = 0;
       for (const auto &s : seg) {
         if (s.label == "static") continue;
-        auto it = label_id_.find(s.label);
-        track_to_label[s.track_id] = it == label_id_.end() ? 0 : it->second;
+        uint8_t *dst = object_masks_.data() + k_obj * hw;
         for (int j = 0; j < s.mask.rows && j < H; ++j)
-          for (int k = 0; k < s.mask.cols && k < W; ++k)
-            if (s.mask.at<uchar>(j, k) > 0) track_mask[(size_t)j * W + k] = (uint16_t)s.track_id;
+          for (int k = 0; k < s.mask.cols && k < W; ++k) dst[(size_t)j * W + k] = s.mask.at<uchar>(j, k);
+        auto it = label_id_.find(s.label);
+        sdm_instance_mask o;
+        o.track_id = s.track_id;
+        o.label_id = it == label_id_.end() ? 0 : it->second;
+        o.mask = dst;
+        objects_.push_back(o);
+        ++k_obj;
       }
     }
-    for (int i = 0; i < H; ++i)
-      for (int j = 0; j < W; ++j) {  // :218-304
-        const size_t p = (size_t)i * W + j;
-        const float d = depth.at<float>(i, j);
-        depth_[p] = d;
-        sdm_labeled_point &o = cloud_[p];
-        if (std::isnan(d) || d < preset_.depth_min || d > preset_.depth_max) {
-          o = sdm_labeled_point{0.f, 0.f, 0.f, params_.if_consider_depth_noise ? params_.depth_noise_zero_order : 0.1f, 0, 0, 0};
-          continue;
-        }
-        Eigen::Vector3d pt = Kinv * Eigen::Vector3d(j, i, 1) * (double)d;  // :243
-        pt = R * pt + cam_p;                                             // :247
-        const uint16_t inst = track_mask[p];
-        int label = 0;
-        if ((int)inst > max_movable_track_) {  // :277-283
-          auto it = static_instance_to_label_.find(inst);
-          label = it == static_instance_to_label_.end() ? 0 : it->second;
-        } else {
-          label = track_to_label[inst];
-        }
-        o.x = (float)pt.x();
-        o.y = (float)pt.y();
-        o.z = (float)pt.z();
-        o.sigma = params_.if_consider_depth_noise ? params_.depth_noise_zero_order + params_.depth_noise_first_order * d : 0.1f;
-        o.track_id = inst;
-        o.label_id = (uint8_t)label;
-        o.is_valid = 1;
-      }
     return 0;
   }
 
@@ -381,11 +375,13 @@ class SemanticDSPMap {
     const size_t cap = (size_t)1 << (preset_.x_n + preset_.y_n + preset_.z_n);
     if (points_.size() < 1024) points_.resize(1024);
     auto get = free_space ? sdm_get_freespace : sdm_get_occupied;
-    if (!check(get(map_, points_.data(), points_.size(), &n, visualize_with_zero_center_ ? 1 : 0), "sdm_get_occupied")) return;
+    const int32_t flags = (visualize_with_zero_center_ ? SDM_POINTS_ZERO_CENTER : 0) | (free_space ? 0 : SDM_POINTS_MARK_FOV);
+    if (!check(get(map_, points_.data(), points_.size(), &n, flags), "sdm_get_occupied")) return;
     if (n > points_.size()) {
       points_.resize(std::min(n, cap));
-      if (!check(get(map_, points_.data(), points_.size(), &n, visualize_with_zero_center_ ? 1 : 0), "sdm_get_occupied")) return;
+      if (!check(get(map_, points_.data(), points_.size(), &n, flags), "sdm_get_occupied")) return;
     }
+    const size_t first_new = out->points.size();
     const int background = label_id_["Background"];
     for (size_t k = 0; k < n && k < points_.size(); ++k) {
       const sdm_point &v = points_[k];
@@ -400,7 +396,8 @@ class SemanticDSPMap {
         out->points.push_back(pt);
         continue;
       }
-      if (v.occ == 1) {
+      const int occ = v.occ & ~SDM_OCC_OUT_OF_FOV;
+      if (occ == 1) {
         if (v.label == background) {  // :1277-1294
           const int ci = std::min(std::max(static_cast<int>((-pt.z + 2.f) * 51.2f), 0), 255);
           pt.r = (uint8_t)color_map_jet_256_[ci](0);
@@ -426,6 +423,30 @@ class SemanticDSPMap {
       }
       (void)cam_pos;
       out->points.push_back(pt);
+    }
+    if (free_space || if_out_evaluation_format_) return;
+    // :1333-1351: every occupied point goes RGB -> HSV -> RGB through OpenCV's 8-bit conversion (not an identity),
+    // with V x 0.7 for voxels outside the camera frustum.  One n x 1 image instead of two 1 x 1 images per voxel.
+    const int n_new = (int)(out->points.size() - first_new);
+    if (n_new == 0) return;
+    cv::Mat rgb(n_new, 1, CV_8UC3), hsv, rgb2;
+    for (int k = 0; k < n_new; ++k) {
+      const pcl::PointXYZRGB &pt = out->points[first_new + k];
+      rgb.at<cv::Vec3b>(k, 0) = cv::Vec3b(pt.r, pt.g, pt.b);
+    }
+    cv::cvtColor(rgb, hsv, cv::COLOR_RGB2HSV);
+    for (int k = 0; k < n_new; ++k)
+      if (points_[k].occ & SDM_OCC_OUT_OF_FOV) {
+        cv::Vec3b &c = hsv.at<cv::Vec3b>(k, 0);
+        c[2] *= 0.7f;  // :1342
+      }
+    cv::cvtColor(hsv, rgb2, cv::COLOR_HSV2RGB);
+    for (int k = 0; k < n_new; ++k) {
+      pcl::PointXYZRGB &pt = out->points[first_new + k];
+      const cv::Vec3b c = rgb2.at<cv::Vec3b>(k, 0);
+      pt.r = c[0];
+      pt.g = c[1];
+      pt.b = c[2];
     }
   }
 };

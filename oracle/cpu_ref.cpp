@@ -1189,6 +1189,7 @@ void oracle_generate_cloud(oracle_map *m, const float *depth, const uint8_t *sta
     }
 }
 
+int32_t oracle_point_in_frustum(oracle_map *m, float x, float y, float z) { return m->isPointInFrustum(x, y, z) ? 1 : 0; }
 uint32_t oracle_pos_to_voxel(oracle_map *m, float x, float y, float z) {
   uint32_t v, rx, ry, rz;
   m->globalPosToVoxel(x, y, z, v, rx, ry, rz);

@@ -163,6 +163,7 @@ void oracle_generate_cloud(oracle_map *m, const float *depth, const uint8_t *sta
 /* helpers exposed for known-answer tests */
 uint32_t oracle_pos_to_voxel(oracle_map *m, float x, float y, float z); /* 0xffffffff if outside */
 void oracle_voxel_to_pos(oracle_map *m, uint32_t voxel, float out[3]);  /* global min corner */
+int32_t oracle_point_in_frustum(oracle_map *m, float x, float y, float z); /* operations.h:1240-1258, last frame's extrinsic */
 float oracle_query_pdf(oracle_map *m, float x, float mu, float sigma);
 float oracle_forgetting_factor(oracle_map *m, int32_t forget_count);
 uint32_t oracle_add_particle(oracle_map *m, float x, float y, float z, uint8_t label, uint16_t track);

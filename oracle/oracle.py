@@ -113,6 +113,8 @@ def lib():
         L.oracle_get_bins.argtypes = [vp, vp, C.c_int64]
         L.oracle_get_extrinsic.argtypes = [vp, vp]
         L.oracle_get_pdf_table.argtypes = [vp, vp]
+        L.oracle_point_in_frustum.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+        L.oracle_point_in_frustum.restype = C.c_int32
         L.oracle_generate_cloud.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, C.c_int32, vp]
         L.oracle_pos_to_voxel.restype = C.c_uint32
         L.oracle_pos_to_voxel.argtypes = [vp, C.c_float, C.c_float, C.c_float]
@@ -278,6 +280,9 @@ class OracleMap:
         self.L.oracle_generate_cloud(self.h, _ptr(depth), _ptr(sm), _ptr(tab), _ptr(tr), _ptr(lb), _ptr(masks), len(objects),
                                      _ptr(pos), _ptr(q), 1 if consider_instance else 0, _ptr(out))
         return out
+
+    def point_in_frustum(self, x, y, z):
+        return bool(self.L.oracle_point_in_frustum(self.h, float(x), float(y), float(z)))
 
     def pdf_table(self):
         out = np.empty(20000, np.float32)

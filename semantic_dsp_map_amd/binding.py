@@ -362,12 +362,13 @@ class SdmMap:
         _check(self.L, self.L.sdm_get_voxels(self.h, _ptr(out)), "sdm_get_voxels")
         return out
 
-    def occupied(self, cap=None, zero_center=False, free=False):
+    def occupied(self, cap=None, zero_center=False, free=False, mark_fov=False):
         cap = cap or self.v_count
         out = np.empty(cap, POINT)
         n = C.c_size_t()
         fn = self.L.sdm_get_freespace if free else self.L.sdm_get_occupied
-        _check(self.L, fn(self.h, _ptr(out), cap, C.byref(n), 1 if zero_center else 0), "sdm_get_occupied")
+        _check(self.L, fn(self.h, _ptr(out), cap, C.byref(n), (1 if zero_center else 0) | (2 if mark_fov else 0)),
+               "sdm_get_occupied")
         return out[:min(n.value, cap)], n.value
 
     def object_particle_count(self, track):

@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(TPB) void k_flag_results(Dims d, State st, uint32_t
 }
 __global__ __launch_bounds__(TPB) void k_emit_points(Dims d, Frame f, State st, const uint32_t *flags,
                                                      const uint32_t *offs, sdm_point *out, uint32_t cap, float sub_x,
-                                                     float sub_y, float sub_z) {
+                                                     float sub_y, float sub_z, int mark_fov) {
   uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
   if (lv >= d.v_count || !flags[lv]) return;
   uint32_t o = offs[lv];
@@ -1191,6 +1191,8 @@ __global__ __launch_bounds__(TPB) void k_emit_points(Dims d, Frame f, State st, 
   pt.track = r.track;
   pt.label = r.label;
   pt.occ = r.occ;
+  // semantic_dsp_map.h:1339-1342: the uncentred voxel position against the frame's frustum
+  if (mark_fov && !point_in_frustum(d, f, x, y, z)) pt.occ = (int8_t)(pt.occ | SDM_OCC_OUT_OF_FOV);
   out[o] = pt;
 }
 
@@ -1321,12 +1323,12 @@ void launch_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uin
 }
 void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t *flags, uint32_t *offs,
                         uint32_t *scan_scratch, sdm_point *out, uint32_t cap, int want_free, const float sub[3],
-                        hipStream_t s) {
+                        int mark_fov, hipStream_t s) {
   hipLaunchKernelGGL(k_flag_results, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st, flags, want_free);
   hipMemsetAsync(flags + d.v_count, 0, 4, s);
   exclusive_scan_u32(flags, offs, (size_t)d.v_count + 1, scan_scratch, s);
   hipLaunchKernelGGL(k_emit_points, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, f, st, flags, offs, out, cap, sub[0],
-                     sub[1], sub[2]);
+                     sub[1], sub[2], mark_fov);
 }
 
 }  // namespace sdm

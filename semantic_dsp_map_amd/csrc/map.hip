@@ -1109,7 +1109,7 @@ sdm_status sdm_get_voxels(sdm_map *m, sdm_voxel_result *out) {
   return SDM_OK;
 }
 
-static sdm_status get_points(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int zero_center, int want_free) {
+static sdm_status get_points(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int flags, int want_free) {
   if (!m || !n_out || (cap && !out)) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
   if (cap > m->points_cap) {
@@ -1120,10 +1120,11 @@ static sdm_status get_points(sdm_map *m, sdm_point *out, size_t cap, size_t *n_o
   }
   // visualize_with_zero_center: subtract the camera position (semantic_dsp_map.h:1263-1271)
   float sub[3] = {0.f, 0.f, 0.f};
-  if (zero_center)
+  if (flags & SDM_POINTS_ZERO_CENTER)
     for (int a = 0; a < 3; ++a) sub[a] = m->cam_p[a];
   uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0xffffffffu);
-  launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->sc.scan_scratch, m->d_points, cap32, want_free, sub, m->stream);
+  launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->sc.scan_scratch, m->d_points, cap32, want_free, sub,
+                     (flags & SDM_POINTS_MARK_FOV) ? 1 : 0, m->stream);
   uint32_t total = 0;
   HIP_TRY(hipMemcpyAsync(&total, m->d_offs + m->d.v_count, 4, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1132,11 +1133,11 @@ static sdm_status get_points(sdm_map *m, sdm_point *out, size_t cap, size_t *n_o
   if (ncopy) HIP_TRY(hipMemcpy(out, m->d_points, ncopy * sizeof(sdm_point), hipMemcpyDeviceToHost));
   return SDM_OK;
 }
-sdm_status sdm_get_occupied(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t zero_center) {
-  return get_points(m, out, cap, n_out, zero_center, 0);
+sdm_status sdm_get_occupied(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t flags) {
+  return get_points(m, out, cap, n_out, flags, 0);
 }
-sdm_status sdm_get_freespace(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t zero_center) {
-  return get_points(m, out, cap, n_out, zero_center, 1);
+sdm_status sdm_get_freespace(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t flags) {
+  return get_points(m, out, cap, n_out, flags, 1);
 }
 sdm_status sdm_voxels_device_ptr(sdm_map *m, const sdm_voxel_result **out) {
   if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
@@ -1189,7 +1190,7 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
     size_t nocc = 0;
     // occupied voxel count from the result array
     const float zero3[3] = {0.f, 0.f, 0.f};
-    launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->sc.scan_scratch, m->d_points, 0, 0, zero3, m->stream);
+    launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->sc.scan_scratch, m->d_points, 0, 0, zero3, 0, m->stream);
     uint32_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, m->d_offs + m->d.v_count, 4, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));

@@ -94,7 +94,7 @@ void launch_pack_pos4(float4 *pos4, const float *px, const float *py, const floa
 void launch_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s);
 void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t *flags, uint32_t *offs,
                         uint32_t *scan_scratch, sdm_point *out, uint32_t cap, int want_free, const float sub[3],
-                        hipStream_t s);
+                        int mark_fov, hipStream_t s);
 
 // object moves / removals (moves.hip)
 constexpr int MAX_MOVE_OBJECTS = 48;  // keeps the by-value MoveSet kernel argument under the 4 KB kernarg limit

@@ -2,6 +2,9 @@
 #pragma once
 #include <cstdint>
 #include <vector>
+#ifndef CV_8UC3
+#define CV_8UC3 3  /* stand-in: element size */
+#endif
 typedef unsigned char uchar;
 namespace cv {
 struct Vec3b {
@@ -9,7 +12,9 @@ struct Vec3b {
   Vec3b() : v{0, 0, 0} {}
   Vec3b(uchar a, uchar b, uchar c) : v{a, b, c} {}
   uchar operator[](int i) const { return v[i]; }
+  uchar &operator[](int i) { return v[i]; }
 };
+enum { COLOR_RGB2HSV = 41, COLOR_HSV2RGB = 55 };
 struct Mat {
   int rows = 0, cols = 0, elem = 1;
   std::vector<unsigned char> buf;
@@ -19,4 +24,6 @@ struct Mat {
   template <typename T> T &at(int r, int c) { return *reinterpret_cast<T *>(&buf[((size_t)r * cols + c) * sizeof(T)]); }
   template <typename T> const T &at(int r, int c) const { return *reinterpret_cast<const T *>(&buf[((size_t)r * cols + c) * sizeof(T)]); }
 };
+// stand-in: a plain copy (the real conversion is OpenCV's; only the adapter's call sequence is compile-checked here)
+inline void cvtColor(const Mat &src, Mat &dst, int) { dst = src; }
 }  // namespace cv

@@ -109,6 +109,13 @@ def test_multiframe_parity_free_running(cfg_name, params_name, n_frames, scene_k
     pos_want = np.stack([o.voxel_to_pos(int(v)) for v in want_idx[:64]]) if len(want_idx) else np.zeros((0, 3), np.float32)
     got = np.stack([occ["x"], occ["y"], occ["z"]], -1)[:64]
     assert np.array_equal(pu.bits(pos_want.astype(np.float32)), pu.bits(got))
+    # the in-view test that selects the HSV dimming of the emitted colour (semantic_dsp_map.h:1339-1342)
+    occ2, _ = g.occupied(mark_fov=True)
+    assert np.array_equal(occ2["occ"] & 0x3f, occ["occ"])
+    step = max(1, len(occ2) // 512)
+    for k in range(0, len(occ2), step):
+        inside = o.point_in_frustum(occ2["x"][k], occ2["y"][k], occ2["z"][k])
+        assert bool(occ2["occ"][k] & 0x40) == (not inside), k
     g.close()
 
 
