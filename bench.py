@@ -102,6 +102,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     run(args.warmup, n_frames)
+    t_enqueue = time.perf_counter() - t0  # host time to issue the frames (the GPU runs behind it)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -155,7 +156,8 @@ def main():
                                       cfg["window_half"], synth.CONFIG_PARAMS[args.config], live, n_vis),
                        "voxels": V, "live_particles": live, "visible_particles": n_vis,
                        "parallelism": "zslab%d" % world, "inputs": "depth + LabeledPoint image resident in HBM",
-                       "render_s": round(t_render, 1)},
+                       "render_s": round(t_render, 1),
+                       "host_enqueue_ms_per_step": round(t_enqueue * 1e3 / args.steps, 4)},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -515,50 +515,51 @@ __device__ __forceinline__ bool vbit(const uint64_t *__restrict__ R, size_t line
 // Per-voxel body of getIdxOfVisibleParitlces (operations.h:1344-1436): every voxel that shares a reached
 // in-frustum vertex is handled exactly once (order does not matter: all effects are voxel-local except the
 // per-pixel bins, whose order is made canonical afterwards).
+// Dependent memory steps are kept few: (1) the status row and the depth under the "imaginary particle" of an empty
+// voxel - nine reached voxels in ten are empty and stop there, without touching the stamp row; (2) stamp row and slab
+// stamps; (3) positions of all live slots; (4) the depth pixel under each; (5) all bin-counter atomics and one
+// work-list reservation per voxel.
 template <int S>
-__global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, Scratch sc) {
-  int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];  // voxel box [bb0,bb1)
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bx <= 0 || by <= 0 || bz <= 0 || t >= (uint32_t)bx * by * bz) return;
-  int ax = f.bb0[0] + (int)(t % bx);
-  int ay = f.bb0[1] + (int)((t / bx) % by);
-  int az = f.bb0[2] + (int)(t / ((uint32_t)bx * by));
-  const int VY = d.NY + 1;
-  // a voxel is handled iff one of its 8 corner vertices was reached by the flood.  Simple masks: vertex reached =
-  // in-frustum bit & its x-line reached; complex masks: the generic flood wrote the reached bits to sc.reach.
-  const bool generic = sc.force_generic || sc.cnt->flood_complex;
-  bool reached = false;
-#pragma unroll
-  for (int dz = 0; dz < 2; ++dz)
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-      const int y = ay + dy, z = az + dz;
-      size_t lb = ((size_t)z * VY + y) * sc.wpl;
-      if (generic) {
-        reached = reached || vbit(sc.reach, lb, ax) || vbit(sc.reach, lb, ax + 1);
-      } else if ((sc.line_reach[(size_t)z * sc.wy + (y >> 6)] >> (y & 63)) & 1ull) {
-        reached = reached || vbit(sc.vmask, lb, ax) || vbit(sc.vmask, lb, ax + 1);
-      }
-    }
-  if (!reached) return;
-  uint32_t rx = axis_correct(ax + f.eq[0], d.NX);
-  uint32_t ry = axis_correct(ay + f.eq[1], d.NY);
-  uint32_t rz = axis_correct(az + f.eq[2], d.NZ);
-  if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) return;  // another shard's slab
+__device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int ax,
+                                                 int ay, int az) {
+  const uint32_t rx = axis_correct(ax + f.eq[0], d.NX);
+  const uint32_t ry = axis_correct(ay + f.eq[1], d.NY);
+  const uint32_t rz = axis_correct(az + f.eq[2], d.NZ);
   const uint32_t shard = blockIdx.x & (VIS_SHARDS - 1);
   atomicAdd(&sc.cnt->fv_shard[shard], 1u);
-  uint32_t v = ring_to_voxel(d, rx, ry, rz);
-  uint32_t lv = v - d.v_begin;
-  const uint32_t smax = stamp_max(st, rx, ry, rz);
+  const uint32_t v = ring_to_voxel(d, rx, ry, rz);
+  const uint32_t lv = v - d.v_begin;
   const size_t base = (size_t)lv * S;
   uint8_t stv[S];
-  uint16_t tsv[S];
   load_vec(stv, st.status + base);
+  // imaginary particle at the voxel's min corner, mapXYZIdxToGlobalPose (operations.h:986-991, 1418-1431)
+  float im_depth = 0.f, im_z = 0.f;
+  bool im_ok;
+  {
+    float ix = (float)(uint32_t)ax * d.voxel_size + d.pmin[0] + f.center[0];
+    float iy = (float)(uint32_t)ay * d.voxel_size + d.pmin[1] + f.center[1];
+    float iz = (float)(uint32_t)az * d.voxel_size + d.pmin[2] + f.center[2];
+    int row, col;
+    im_ok = project_to_image(d, f, ix, iy, iz, row, col, im_z);
+    if (im_ok) im_depth = sc.depth[(size_t)row * d.W + col];
+  }
+  bool any = false;
+#pragma unroll
+  for (int i = 1; i < S; ++i) any = any || stv[i] != ST_INVALID;
+  if (!any) {
+    if (im_ok && im_z <= im_depth) st.ts[base] = (uint16_t)f.gts;
+    return;
+  }
+  const uint32_t smax = stamp_max(st, rx, ry, rz);
+  uint16_t tsv[S];
   load_vec(tsv, st.ts + base);
   bool dirty = false, observed = false;
   int valid_n = 0;
+  bool live[S];
+  float4 pos[S];
 #pragma unroll
   for (int i = 1; i < S; ++i) {
+    live[i] = false;
     if (stv[i] == ST_INVALID) continue;
     if ((uint32_t)tsv[i] < smax) {  // outdated: delete (operations.h:1374-1378)
       stv[i] = ST_INVALID;
@@ -566,45 +567,153 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, S
       continue;
     }
     valid_n++;
-    float4 p = st.pos4[base + i];
+    live[i] = true;
+    pos[i] = st.pos4[base + i];
+  }
+  int pixv[S];
+  float camz[S], dptv[S];
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    pixv[i] = -1;
+    if (!live[i]) continue;
     int row, col;
-    float cam_z;
-    if (project_to_image(d, f, p.x, p.y, p.z, row, col, cam_z)) {
-      float dpt = sc.depth[(size_t)row * d.W + col];
-      if (dpt > d.dmax) {  // nothing measurable along this ray: free (operations.h:1389-1395)
-        st.w[base + i] = SDM_OCC_INIT_WEIGHT;
-        observed = true;
-        continue;
-      }
-      if (cam_z > dpt * d.occl_coeff) continue;  // occluded (operations.h:1397-1400)
+    if (project_to_image(d, f, pos[i].x, pos[i].y, pos[i].z, row, col, camz[i])) {
+      pixv[i] = row * d.W + col;
+      dptv[i] = sc.depth[pixv[i]];
+    }
+  }
+  bool vis[S];
+  uint32_t pib[S], nv = 0;
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    vis[i] = false;
+    if (!live[i] || pixv[i] < 0) continue;
+    const float dpt = dptv[i];
+    if (dpt > d.dmax) {  // nothing measurable along this ray: free (operations.h:1389-1395)
+      st.w[base + i] = SDM_OCC_INIT_WEIGHT;
       observed = true;
-      uint32_t pix = (uint32_t)(row * d.W + col);
-      const uint32_t cap_sub = sc.cap_vis / VIS_SHARDS;
-      uint32_t k = atomicAdd(&sc.cnt->vis_shard[shard], 1u);
-      uint32_t pib = atomicAdd(&sc.bin_count[pix], 1u);
-      if (k < cap_sub) {
-        k += shard * cap_sub;
-        sc.vis_pix[k] = pix;
-        sc.vis_idx[k] = (uint32_t)(((size_t)v << d.p_n) + i);
-        sc.vis_pib[k] = pib;
-      } else {
-        sc.cnt->overflow = 1;
-      }
+      continue;
+    }
+    if (camz[i] > dpt * d.occl_coeff) continue;  // occluded (operations.h:1397-1400)
+    observed = true;
+    vis[i] = true;
+    nv++;
+  }
+#pragma unroll
+  for (int i = 1; i < S; ++i)
+    if (vis[i]) pib[i] = atomicAdd(&sc.bin_count[pixv[i]], 1u);
+  if (nv) {
+    const uint32_t cap_sub = sc.cap_vis / VIS_SHARDS;
+    uint32_t k = atomicAdd(&sc.cnt->vis_shard[shard], nv);
+    if (k + nv <= cap_sub) {
+      k += shard * cap_sub;
+#pragma unroll
+      for (int i = 1; i < S; ++i)
+        if (vis[i]) {
+          sc.vis_pix[k] = (uint32_t)pixv[i];
+          sc.vis_idx[k] = (uint32_t)(((size_t)v << d.p_n) + i);
+          sc.vis_pib[k] = pib[i];
+          ++k;
+        }
+    } else {
+      sc.cnt->overflow = 1;
     }
   }
   if (dirty) store_vec(st.status + base, stv);
   if (observed) {
     st.ts[base] = (uint16_t)f.gts;
   } else if (valid_n == 0) {
-    // imaginary particle at the voxel's min corner, mapXYZIdxToGlobalPose (operations.h:986-991, 1418-1431)
-    float ix = (float)(uint32_t)ax * d.voxel_size + d.pmin[0] + f.center[0];
-    float iy = (float)(uint32_t)ay * d.voxel_size + d.pmin[1] + f.center[1];
-    float iz = (float)(uint32_t)az * d.voxel_size + d.pmin[2] + f.center[2];
-    int row, col;
-    float cam_z;
-    if (project_to_image(d, f, ix, iy, iz, row, col, cam_z)) {
-      if (cam_z <= sc.depth[(size_t)row * d.W + col]) st.ts[base] = (uint16_t)f.gts;
+    if (im_ok && im_z <= im_depth) st.ts[base] = (uint16_t)f.gts;
+  }
+}
+
+// Two phases per workgroup.  Only about a third of the voxels of the frustum's index box were reached, and testing
+// them one by one costs a dozen bit-test loads each.  So the candidates are taken 64 at a time: a "word" is the 64
+// voxels along x whose lower corner vertices share one 64-bit word of the vertex bitmaps.  A voxel is handled iff one
+// of its 8 corner vertices was reached by the flood: per vertex line (4 per voxel row) that is word | word >> 1 (the
+// upper-x corner; bit 0 of the next word shifts in).  Simple masks: vertex reached = in-frustum bit & its x-line
+// reached; complex masks: the generic flood wrote the reached bits to sc.reach.  VIS_WORDS words per workgroup; their
+// set bits are then dealt out to the lanes, so the loads that go to HBM are issued by full waves.
+constexpr int VIS_WORDS = 16;
+
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, uint32_t n) {  // position of the n-th (0-based) set bit
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const uint32_t c = (uint32_t)__popcll(m & ((1ull << w) - 1ull));
+    if (n >= c) {
+      n -= c;
+      m >>= w;
+      pos += w;
     }
+  }
+  return pos;
+}
+
+template <int S>
+__global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, Scratch sc) {
+  __shared__ unsigned long long wmask[VIS_WORDS];
+  __shared__ uint32_t woff[VIS_WORDS + 1];
+  const int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];  // voxel box [bb0,bb1)
+  if (bx <= 0 || by <= 0 || bz <= 0) return;
+  const int wlo = f.bb0[0] >> 6, nwx = ((f.bb1[0] - 1) >> 6) - wlo + 1;
+  const uint32_t n_words = (uint32_t)nwx * by * bz;
+  const uint32_t g0 = blockIdx.x * VIS_WORDS;
+  if (threadIdx.x < VIS_WORDS) {
+    const uint32_t g = g0 + threadIdx.x;
+    unsigned long long m = 0;
+    if (g < n_words) {
+      const int wi = wlo + (int)(g % nwx);
+      const int ay = f.bb0[1] + (int)((g / nwx) % by);
+      const int az = f.bb0[2] + (int)(g / ((uint32_t)nwx * by));
+      const uint32_t rz = axis_correct(az + f.eq[2], d.NZ);
+      if (rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) {  // else: another shard's slab
+        const bool generic = sc.force_generic || sc.cnt->flood_complex;
+        const uint64_t *__restrict__ bits = generic ? sc.reach : sc.vmask;
+        const int VY = d.NY + 1;
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            const int y = ay + dy, z = az + dz;
+            const size_t lb = ((size_t)z * VY + y) * sc.wpl;
+            const bool line_ok = generic || ((sc.line_reach[(size_t)z * sc.wy + (y >> 6)] >> (y & 63)) & 1ull);
+            const unsigned long long w0 = bits[lb + wi];
+            const unsigned long long w1 = wi + 1 < (int)sc.wpl ? bits[lb + wi + 1] : 0ull;
+            if (line_ok) m |= w0 | (w0 >> 1) | (w1 << 63);
+          }
+        // voxels of the box only
+        const int x0 = wi << 6;
+        const int lo = f.bb0[0] > x0 ? f.bb0[0] - x0 : 0;
+        const int hi = f.bb1[0] - x0 < 64 ? f.bb1[0] - x0 : 64;  // exclusive
+        unsigned long long keep = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+        keep &= ~((1ull << lo) - 1ull);
+        m &= keep;
+      }
+    }
+    wmask[threadIdx.x] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < VIS_WORDS; ++w) {
+      woff[w] = run;
+      run += (uint32_t)__popcll(wmask[w]);
+    }
+    woff[VIS_WORDS] = run;
+  }
+  __syncthreads();
+  const uint32_t nl = woff[VIS_WORDS];
+  for (uint32_t li = threadIdx.x; li < nl; li += TPB) {
+    int w = 0;
+#pragma unroll
+    for (int k = 1; k < VIS_WORDS; ++k) w += woff[k] <= li ? 1 : 0;
+    const uint32_t g = g0 + w;
+    const int ax = ((wlo + (int)(g % nwx)) << 6) + nth_set_bit(wmask[w], li - woff[w]);
+    const int ay = f.bb0[1] + (int)((g / nwx) % by);
+    const int az = f.bb0[2] + (int)(g / ((uint32_t)nwx * by));
+    visibility_voxel<S>(d, f, st, sc, ax, ay, az);
   }
 }
 
@@ -690,58 +799,206 @@ constexpr int A7_ROWS = 16;   // >= 2*window_half+1
 constexpr int A7_ITEMS = 16;  // pixels / particles per workgroup
 
 // pass 1 (semantic_dsp_map.h:973-1037): ck of every valid pixel.  finish != 0 also applies ck*P_d + kappa (:1035).
-__global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, State st, Scratch sc,
-                                                          float *__restrict__ ck_out, int finish) {
-  __shared__ float rowsum[A7_ITEMS][A7_ROWS];
-  const int r = threadIdx.x, it = threadIdx.y;
-  const int p = blockIdx.x * A7_ITEMS + it;
+// Visible particles are far fewer than pixels (C3: ~27 K against 466 K) and clustered: half the windows are empty,
+// the median window holds one particle, the 99th percentile 124.  So the pixels are split: k_ck_light (one thread per
+// pixel) finishes every pixel whose window holds at most CK_LIGHT_MAX particles and lists the others; k_ck_heavy
+// spreads each listed pixel over its window rows.  Both add a row's terms in bin order and the row sums in row
+// order (canonical order) - the value does not depend on which kernel produced it.
+constexpr uint32_t CK_LIGHT_MAX = 4;
+
+__device__ __forceinline__ float ck_term(const Filter &flt, const float *__restrict__ pdf, const float4 pv, const uint32_t tf,
+                                         const sdm_labeled_point &o, bool &skip) {
+  const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
+  skip = flt.independent && ptrack != o.track_id;
+  float gk = query_pdf(pdf, pv.x, o.x, o.sigma) * query_pdf(pdf, pv.y, o.y, o.sigma) * query_pdf(pdf, pv.z, o.z, o.sigma);
+  if (!flt.independent) {
+    gk *= flt.forget[(tf >> 16) & 7];
+    if (ptrack != o.track_id) gk *= flt.id_transition;
+  }
+  return pv.w * gk;
+}
+
+__device__ __forceinline__ void ck_store(const Filter &flt, const Scratch &sc, float *__restrict__ ck_out, int finish, int p,
+                                         const sdm_labeled_point &o, float ck) {
+  if (finish) {
+    const float ckk = ck * flt.p_detect + flt.noise_number;
+    sc.ck_kappa[p] = ckk;
+    sc.pix4[p] = make_float4(o.x, o.y, o.z, ckk);
+    sc.pixt[p] = (uint32_t)o.track_id | (1u << 16);
+  } else {
+    ck_out[p] = ck;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_ck_light(Dims d, Filter flt, State st, Scratch sc, float *__restrict__ ck_out,
+                                                  int finish) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.W * d.H) return;
+  const sdm_labeled_point o = sc.cloud[p];
+  if (!o.is_valid) {
+    if (finish) sc.pixt[p] = 0;  // invalid pixel: skipped by pass 2
+    return;
+  }
   const int h = d.window_half;
-  float acc = 0.f;
-  bool valid_px = false;
-  if (!sc.cnt->overflow && p < d.W * d.H && r <= 2 * h) {
-    const sdm_labeled_point o = sc.cloud[p];
-    valid_px = o.is_valid != 0;
-    const int i = p / d.W, j = p % d.W;
-    const int ni = i + r - h;
-    if (valid_px && ni >= 0 && ni < d.H) {
-      const int j0 = j - h < 0 ? 0 : j - h;
-      const int j1 = j + h >= d.W ? d.W - 1 : j + h;
-      const uint32_t s = sc.bin_start[ni * d.W + j0];
-      const uint32_t e = sc.bin_start[ni * d.W + j1 + 1];
-      const float *__restrict__ pdf = st.pdf;
-      const float sigma = o.sigma;
-      for (uint32_t k = s; k < e; ++k) {
-        const float4 pv = sc.vp4[k];
-        const uint32_t tf = sc.vtf[k];
-        const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
-        if (flt.independent && ptrack != o.track_id) continue;
-        float gk = query_pdf(pdf, pv.x, o.x, sigma) * query_pdf(pdf, pv.y, o.y, sigma) * query_pdf(pdf, pv.z, o.z, sigma);
-        if (!flt.independent) {
-          gk *= flt.forget[(tf >> 16) & 7];
-          if (ptrack != o.track_id) gk *= flt.id_transition;
-        }
-        acc += pv.w * gk;
+  const int i = p / d.W, j = p - i * d.W;
+  uint32_t ss[A7_ROWS], ee[A7_ROWS], total = 0;
+  if (!sc.cnt->overflow) {
+    const int j0 = j - h < 0 ? 0 : j - h;
+    const int j1 = j + h >= d.W ? d.W - 1 : j + h;
+#pragma unroll
+    for (int r = 0; r < A7_ROWS; ++r) {
+      const int ni = i + r - h;
+      ss[r] = ee[r] = 0;
+      if (r <= 2 * h && ni >= 0 && ni < d.H) {
+        ss[r] = sc.bin_start[ni * d.W + j0];
+        ee[r] = sc.bin_start[ni * d.W + j1 + 1];
       }
+      total += ee[r] - ss[r];
     }
   }
-  rowsum[it][r] = acc;
-  __syncthreads();
-  if (r == 0 && p < d.W * d.H) {
-    if (valid_px) {
+  if (total > CK_LIGHT_MAX) {
+    const uint32_t shard = blockIdx.x & (VIS_SHARDS - 1);
+    const uint32_t k = atomicAdd(&sc.cnt->heavy_shard[shard], 1u);
+    sc.ck_heavy[shard * sc.cap_heavy + k] = (uint32_t)p;  // cap_heavy covers every pixel a shard's blocks can hold
+    return;
+  }
+  float ck = 0.f;
+  if (total) {
+    const float *__restrict__ pdf = st.pdf;
+#pragma unroll
+    for (int r = 0; r < A7_ROWS; ++r) {
+      if (ss[r] == ee[r]) continue;  // an empty row adds +0
+      float acc = 0.f;
+      for (uint32_t k = ss[r]; k < ee[r]; ++k) {
+        bool skip;
+        const float t = ck_term(flt, pdf, sc.vp4[k], sc.vtf[k], o, skip);
+        if (!skip) acc += t;
+      }
+      ck += acc;
+    }
+  }
+  ck_store(flt, sc, ck_out, finish, p, o, ck);
+}
+
+// 16 listed pixels per workgroup round, blockIdx.y = shard of the list.  Window sizes are very uneven (9 .. ~300
+// particles), so the particle-pixel terms of the 16 pixels are flattened (pixel, row, bin order) and dealt out evenly
+// to the 256 lanes - each computes a contiguous chunk of terms into LDS - and then lane (pixel, row) adds its row's
+// terms in bin order; the row sums are added in row order.  More terms than the LDS buffer holds: several passes,
+// the running row sums stay in registers.
+constexpr uint32_t CK_TERM_CAP = 4096;
+
+__global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter flt, State st, Scratch sc,
+                                                                float *__restrict__ ck_out, int finish) {
+  __shared__ float rowsum[A7_ITEMS][A7_ROWS];
+  __shared__ uint32_t rowoff[A7_ITEMS * A7_ROWS + 1];  // exclusive prefix of the row lengths, flattened (pixel, row)
+  __shared__ uint32_t rowbeg[A7_ITEMS * A7_ROWS];      // first bin entry of the row
+  __shared__ float opx[A7_ITEMS][4];                   // x, y, z, sigma of the pixel's point
+  __shared__ uint32_t otrk[A7_ITEMS];
+  __shared__ float term[CK_TERM_CAP];
+  const int r = threadIdx.x, it = threadIdx.y;
+  const int lane = it * A7_ROWS + r;
+  const int h = d.window_half;
+  const uint32_t shard = blockIdx.y;
+  const uint32_t n = sc.cnt->heavy_shard[shard];
+  const float *__restrict__ pdf = st.pdf;
+  for (uint32_t q0 = blockIdx.x * A7_ITEMS; q0 < n; q0 += gridDim.x * A7_ITEMS) {
+    const uint32_t q = q0 + it;
+    int p = 0;
+    uint32_t s = 0, e = 0;
+    sdm_labeled_point o;
+    if (q < n) {
+      p = (int)sc.ck_heavy[shard * sc.cap_heavy + q];
+      o = sc.cloud[p];
+      const int i = p / d.W, j = p - i * d.W;
+      const int ni = i + r - h;
+      if (r <= 2 * h && ni >= 0 && ni < d.H) {
+        const int j0 = j - h < 0 ? 0 : j - h;
+        const int j1 = j + h >= d.W ? d.W - 1 : j + h;
+        s = sc.bin_start[ni * d.W + j0];
+        e = sc.bin_start[ni * d.W + j1 + 1];
+      }
+      if (r == 0) {
+        opx[it][0] = o.x;
+        opx[it][1] = o.y;
+        opx[it][2] = o.z;
+        opx[it][3] = o.sigma;
+        otrk[it] = o.track_id;
+      }
+    }
+    rowbeg[lane] = s;
+    rowoff[lane] = e - s;
+    __syncthreads();
+    if (lane < 64) {  // exclusive prefix over the 256 row lengths by one wave: 4 per lane + wave scan
+      uint32_t v[4], sum = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = rowoff[lane * 4 + u];
+        sum += v[u];
+      }
+      uint32_t inc = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+      }
+      uint32_t run = inc - sum;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        rowoff[lane * 4 + u] = run;
+        run += v[u];
+      }
+      if (lane == 63) rowoff[A7_ITEMS * A7_ROWS] = inc;
+    }
+    __syncthreads();
+    const uint32_t total = rowoff[A7_ITEMS * A7_ROWS];
+    const uint32_t my_a = rowoff[lane], my_b = rowoff[lane + 1];
+    float acc = 0.f;
+    for (uint32_t base = 0; base < total; base += CK_TERM_CAP) {
+      const uint32_t cnt = total - base < CK_TERM_CAP ? total - base : CK_TERM_CAP;
+      const uint32_t chunk = (cnt + 255u) / 256u;
+      uint32_t g = base + (uint32_t)lane * chunk;
+      const uint32_t g_end = g + chunk < base + cnt ? g + chunk : base + cnt;
+      if (g < g_end) {
+        // row that holds term g: largest index with rowoff[idx] <= g (rows of length 0 share an offset with their
+        // successor and are stepped over)
+        int lo = 0, hi = A7_ITEMS * A7_ROWS;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (rowoff[mid] <= g) lo = mid; else hi = mid;
+        }
+        int row = lo;
+        while (rowoff[row + 1] <= g) ++row;
+        for (; g < g_end; ++g) {
+          while (rowoff[row + 1] <= g) ++row;
+          const int px = row / A7_ROWS;
+          const uint32_t k = rowbeg[row] + (g - rowoff[row]);
+          sdm_labeled_point oo;
+          oo.x = opx[px][0];
+          oo.y = opx[px][1];
+          oo.z = opx[px][2];
+          oo.sigma = opx[px][3];
+          oo.track_id = (uint16_t)otrk[px];
+          bool skip;
+          const float t = ck_term(flt, pdf, sc.vp4[k], sc.vtf[k], oo, skip);
+          term[g - base] = skip ? -0.f : t;  // x + (-0) == x for every x: a skipped term leaves the sum untouched
+        }
+      }
+      __syncthreads();
+      {
+        const uint32_t a = my_a > base ? my_a : base;
+        const uint32_t b = my_b < base + cnt ? my_b : base + cnt;
+        for (uint32_t t = a; t < b; ++t) acc += term[t - base];
+      }
+      __syncthreads();
+    }
+    rowsum[it][r] = acc;
+    __syncthreads();
+    if (r == 0 && q < n) {
       float ck = 0.f;
       for (int m = 0; m <= 2 * h; ++m) ck += rowsum[it][m];
-      if (finish) {
-        const float ckk = ck * flt.p_detect + flt.noise_number;
-        const sdm_labeled_point o = sc.cloud[p];
-        sc.ck_kappa[p] = ckk;
-        sc.pix4[p] = make_float4(o.x, o.y, o.z, ckk);
-        sc.pixt[p] = (uint32_t)o.track_id | (1u << 16);
-      } else {
-        ck_out[p] = ck;
-      }
-    } else if (finish) {
-      sc.pixt[p] = 0;  // invalid pixel: skipped by pass 2
+      ck_store(flt, sc, ck_out, finish, p, o, ck);
     }
+    __syncthreads();
   }
 }
 
@@ -789,25 +1046,36 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Frame f, F
         const uint32_t tf = sc.vtf[k];
         const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
         const float ff = flt.forget[(tf >> 16) & 7];
-        for (int nn = -h; nn <= h; ++nn) {
-          const int nj = j + nn;
-          if (nj < 0 || nj >= d.W) continue;
-          const int q = ni * d.W + nj;
-          const uint32_t ot = sc.pixt[q];
-          if (!(ot >> 16)) continue;  // invalid pixel
-          const uint16_t otrack = (uint16_t)(ot & 0xffffu);
-          if (flt.independent && otrack != ptrack) continue;
-          const float4 o = sc.pix4[q];  // x, y, z, ck+kappa
-          float gk = query_pdf(pdf, pv.x, o.x, sigma) * query_pdf(pdf, pv.y, o.y, sigma) * query_pdf(pdf, pv.z, o.z, sigma);
-          if (!flt.independent) {
-            if (ptrack != otrack) {
-              gk *= flt.id_transition;
-            } else {
-              if (gk > SDM_MIN_RIGHT_PDF) right = 1;
-            }
-            gk *= ff;
+        // the loads of a window row are issued eight pixels at a time; the adds stay in column order
+        for (int n0 = -h; n0 <= h; n0 += 8) {
+          uint32_t ot[8];
+          float4 o[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int nj = j + n0 + u;
+            ot[u] = 0;
+            if (n0 + u <= h && nj >= 0 && nj < d.W) ot[u] = sc.pixt[ni * d.W + nj];
           }
-          acc += gk / o.w;
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (ot[u] >> 16) o[u] = sc.pix4[ni * d.W + j + n0 + u];  // x, y, z, ck+kappa
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (!(ot[u] >> 16)) continue;  // outside the window / image, or an invalid pixel
+            const uint16_t otrack = (uint16_t)(ot[u] & 0xffffu);
+            if (flt.independent && otrack != ptrack) continue;
+            float gk = query_pdf(pdf, pv.x, o[u].x, sigma) * query_pdf(pdf, pv.y, o[u].y, sigma) *
+                       query_pdf(pdf, pv.z, o[u].z, sigma);
+            if (!flt.independent) {
+              if (ptrack != otrack) {
+                gk *= flt.id_transition;
+              } else {
+                if (gk > SDM_MIN_RIGHT_PDF) right = 1;
+              }
+              gk *= ff;
+            }
+            acc += gk / o[u].w;
+          }
         }
       }
     }
@@ -1253,7 +1521,8 @@ void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_
 void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, hipStream_t s) {
   int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];
   if (bx > 0 && by > 0 && bz > 0) {
-    dim3 grid(blocks_for((size_t)bx * by * bz));
+    const int nwx = ((f.bb1[0] - 1) >> 6) - (f.bb0[0] >> 6) + 1;
+    dim3 grid(blocks_for((size_t)nwx * by * bz, VIS_WORDS));
     SDM_DISPATCH_S(k_visibility, grid, s, d, f, st, sc);
   }
   // bins: scan the per-pixel counts, scatter, canonical order + gather
@@ -1263,7 +1532,8 @@ void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scr
 }
 
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s) {
-  hipLaunchKernelGGL(k_ck, dim3(blocks_for((size_t)d.W * d.H, A7_ITEMS)), dim3(A7_ROWS, A7_ITEMS), 0, s, d, flt, st, sc, ck_out, finish);
+  hipLaunchKernelGGL(k_ck_light, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, st, sc, ck_out, finish);
+  hipLaunchKernelGGL(k_ck_heavy, dim3(64, VIS_SHARDS), dim3(A7_ROWS, A7_ITEMS), 0, s, d, flt, st, sc, ck_out, finish);
 }
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s) {
   hipLaunchKernelGGL(k_ck_finish, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, parts, n_parts);

@@ -515,6 +515,9 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.pix4, hw);
   A(sc.pixt, hw);
   A(sc.ck_kappa, hw);
+  // pixels reach the heavy list from blocks of TPB consecutive pixels, shard = block & 63
+  sc.cap_heavy = (uint32_t)(((hw + 255) / 256 + VIS_SHARDS - 1) / VIS_SHARDS * 256);
+  A(sc.ck_heavy, (size_t)sc.cap_heavy * VIS_SHARDS);
   A(m->d_ck_part, hw);
   A(m->d_static_mask, hw);
   A(m->d_label_to_inst, 256);

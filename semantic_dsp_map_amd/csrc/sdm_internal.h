@@ -90,6 +90,7 @@ struct Counters {
   // by block index; the per-shard visible-particle counters also index per-shard regions of the work list.
   uint32_t vis_shard[64];
   uint32_t fv_shard[64];
+  uint32_t heavy_shard[64];  // weight-update pass 1: pixels handed to the row-parallel kernel
 };
 constexpr uint32_t VIS_SHARDS = 64;
 constexpr uint32_t OWNER_CHUNK = 4096;  // slots per owner_flag byte (= slots per block of the move sweep)

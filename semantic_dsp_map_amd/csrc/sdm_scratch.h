@@ -34,6 +34,8 @@ struct Scratch {
   float4 *pix4 = nullptr;
   uint32_t *pixt = nullptr;
   float *ck_kappa = nullptr;
+  uint32_t *ck_heavy = nullptr;  // sharded list of pixels with long windows (cap_heavy entries per shard)
+  uint32_t cap_heavy = 0;
   // births
   uint32_t *b_valid = nullptr, *b_rank = nullptr;
   uint32_t *bkey_a = nullptr, *bval_a = nullptr, *bkey_b = nullptr, *bval_b = nullptr;
