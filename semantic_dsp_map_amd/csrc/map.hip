@@ -544,11 +544,11 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   size_t scan_need = std::max({scan_scratch_elems(hw + 1), scan_scratch_elems(mv_cnt_n), scan_scratch_elems((size_t)d.v_count + 1)});
   A(sc.scan_scratch, scan_need + 16);
   A(sc.scan_scratch_b, scan_scratch_elems(hw + 1) + 16);
-  A(sc.mkey_a, sc.cap_move);
-  A(sc.mval_a, sc.cap_move);
-  A(sc.mkey_b, sc.cap_move);
-  A(sc.mval_b, sc.cap_move);
-  A(sc.msort_scratch, sort_scratch_elems(sc.cap_move) + 16);
+  A(sc.mv_head, d.v_count);
+  HIP_TRY(hipMemset(sc.mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t)));  // MV_NIL; the replay leaves it that way
+  A(sc.mv_next, sc.cap_move);
+  A(sc.mv_vox, sc.cap_move);
+  A(sc.mv_vlist, sc.cap_move);
   A(sc.cnt, 1);
   A(sc.cur, 1);
   HIP_TRY(hipMemsetAsync(sc.cnt, 0, sizeof(Counters), m->stream));
@@ -607,6 +607,7 @@ sdm_status sdm_clear(sdm_map *m) {
   if (!m) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
   host_initialize(m);
+  HIP_TRY(hipMemsetAsync(m->sc.mv_head, 0xff, (size_t)m->d.v_count * sizeof(uint32_t), m->stream));
   launch_clear(m->d, m->st, m->stream);
   return upload_stamps(m);
 }
@@ -733,16 +734,18 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
   HIP_TRY(hipEventRecord(m->ev_begin, s));
   m->side_pending = false;
   if (!done(3)) {
-    HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->ev_begin, 0));
+    hipStream_t sf = getenv("SDM_SIDE") ? s : m->s_frustum;  // TEMP experiment
+    HIP_TRY(hipStreamWaitEvent(sf, m->ev_begin, 0));
     m->sc.force_generic = m->force_generic_flood;
-    launch_frustum(d, m->f, m->sc, m->force_generic_flood, m->s_frustum);
-    HIP_TRY(hipEventRecord(m->ev_frustum, m->s_frustum));
+    launch_frustum(d, m->f, m->sc, m->force_generic_flood, sf);
+    HIP_TRY(hipEventRecord(m->ev_frustum, sf));
     m->side_pending = true;
   }
   if (!done(5)) {
-    HIP_TRY(hipStreamWaitEvent(m->s_birth, m->ev_begin, 0));
-    m->birth_which = launch_birth_prepare(d, m->f, m->flt, m->bo, m->st, m->sc, m->s_birth);
-    HIP_TRY(hipEventRecord(m->ev_birth, m->s_birth));
+    hipStream_t sb = getenv("SDM_SIDE") ? s : m->s_birth;  // TEMP experiment
+    HIP_TRY(hipStreamWaitEvent(sb, m->ev_begin, 0));
+    m->birth_which = launch_birth_prepare(d, m->f, m->flt, m->bo, m->st, m->sc, sb);
+    HIP_TRY(hipEventRecord(m->ev_birth, sb));
   }
 
   // P2 (first part): collect the moving objects' particles (semantic_dsp_map.h:588-693)

@@ -250,19 +250,22 @@ __global__ void k_move_bases(const int32_t *__restrict__ counts_all, int world, 
   if (sc.halo_send) *reinterpret_cast<uint32_t *>(sc.halo_send) = 0;
 }
 
-__global__ __launch_bounds__(TPB) void k_move_init_keys(Dims d, Scratch sc) {
-  const uint32_t total = *sc.mv_total;
-  uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    sc.mkey_a[e] = d.V;  // "not mine": sorts behind every real voxel and is skipped by the replay
-    sc.mval_a[e] = e;
-  }
+constexpr uint32_t MV_NIL = 0xffffffffu;
+
+// A moved copy of global rank e joins the list of its target voxel (push-front; the replay restores rank order).
+// The copy that finds the list idle also enters the voxel in this frame's work list.
+__device__ __forceinline__ void move_link(const Dims &d, const Scratch &sc, uint32_t v, uint32_t e) {
+  const uint32_t lv = v - d.v_begin;
+  sc.mv_vox[e] = lv;
+  const uint32_t prev = atomicExch(&sc.mv_head[lv], e);
+  sc.mv_next[e] = prev;
+  if (prev == MV_NIL) sc.mv_vlist[atomicAdd(&sc.cnt->n_move_voxels, 1u)] = lv;
 }
 
 // phase 1 of moveParticlesInSetsByTransformations (operations.h:331-349): copy, transform + table noise,
 // delete the original.  The noise cursor advances by three per particle in global rank order.
 __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter flt, const MoveSet ms, State st, Scratch sc,
-                                                        const uint32_t *__restrict__ offs, int n_obj, int write_all_keys) {
+                                                        const uint32_t *__restrict__ offs, int n_obj) {
   if (sc.cnt->overflow) return;
   const uint32_t n_blocks = MV_LIST_CAP;
   const uint32_t local_total = offs[(size_t)n_obj * n_blocks];
@@ -292,10 +295,6 @@ __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter 
     st.owner[li] = OWNER_NONE;   // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
     uint32_t rx, ry, rz;
     uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
-    if (write_all_keys && e < sc.cap_move) {  // single shard: every rank is written here, no separate key init pass
-      sc.mkey_a[e] = d.V;
-      sc.mval_a[e] = e;
-    }
     if (v == INVALID_INDEX) continue;  // left the map: dropped (operations.h:799-802)
     if (rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) {
       if (e >= sc.cap_move) continue;
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter 
       sc.mv_label[e] = plabel;
       sc.mv_status[e] = pstatus;
       sc.mv_owner[e] = powner;
-      sc.mkey_a[e] = v;
+      move_link(d, sc, v, e);
     } else if (sc.halo_send) {  // crosses into another slab: export
       uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(sc.halo_send), 1u);
       if (k < sc.halo_cap) {
@@ -350,64 +349,93 @@ __global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int wor
     sc.mv_owner[e] = (uint16_t)(r.owner_label_status & 0xffffu);
     sc.mv_label[e] = (uint8_t)((r.owner_label_status >> 16) & 0xffu);
     sc.mv_status[e] = (uint8_t)(r.owner_label_status >> 24);
-    sc.mkey_a[e] = r.voxel;
+    move_link(d, sc, r.voxel, e);
   }
 }
 
-// phase 2 (operations.h:351-361): re-insert the copies, first vacant slot, in (object, index) order.
-// Sorted by target voxel (stable), one thread replays each voxel's segment.
+// phase 2 (operations.h:351-361): re-insert the copies, first vacant slot, in (object, index) order = ascending global
+// rank.  One thread per target voxel: it walks the voxel's list, picks the next S-1 ranks in ascending order, replays
+// them, and repeats while the voxel still has a vacant slot (a copy whose own stamp is older than the slab's leaves
+// its slot vacant, so a list can be longer than the voxel; once the voxel is full every later copy is dropped,
+// operations.h:357).  The list head is left idle again.
 template <int S>
-__global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State st, Scratch sc,
-                                                     const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval) {
+__global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State st, Scratch sc) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // the table cursor of RingBufferOperations::gaussian_random_calculator_ advanced by three per moved particle
     long long c = (long long)sc.cur->move_cursor + 3ll * (long long)sc.cnt->n_moved;
     sc.cur->move_cursor = (int32_t)(c % flt.noise_n);
   }
-  if (sc.cnt->overflow) return;
-  const uint32_t total = *sc.mv_total;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const uint32_t v = skey[t];
-  if (v >= d.V) return;
-  if (t > 0 && skey[t - 1] == v) return;
-  uint32_t rx, ry, rz;
-  voxel_to_ring(d, v, rx, ry, rz);
-  uint32_t a = st.stamps_x[rx], b = st.stamps_y[ry], c = st.stamps_z[rz];
-  uint32_t smax = a > b ? a : b;
-  smax = smax > c ? smax : c;
-  const size_t base = (size_t)(v - d.v_begin) * S;
-  uint8_t stv[S];
-  uint16_t tsv[S];
-  __builtin_memcpy(stv, st.status + base, S);
-  __builtin_memcpy(tsv, st.ts + base, 2 * S);
-  uint32_t n_ok = 0;
-  for (uint32_t u = t; u < total && skey[u] == v; ++u) {
-    const uint32_t e = sval[u];
-    int slot = -1;
+  const uint32_t n_vox = sc.cnt->n_move_voxels;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_vox; t += stride) {
+    const uint32_t lv = sc.mv_vlist[t];
+    const uint32_t head = sc.mv_head[lv];
+    sc.mv_head[lv] = MV_NIL;
+    if (sc.cnt->overflow) continue;
+    const uint32_t v = d.v_begin + lv;
+    uint32_t rx, ry, rz;
+    voxel_to_ring(d, v, rx, ry, rz);
+    uint32_t a = st.stamps_x[rx], b = st.stamps_y[ry], c = st.stamps_z[rz];
+    uint32_t smax = a > b ? a : b;
+    smax = smax > c ? smax : c;
+    const size_t base = (size_t)lv * S;
+    uint8_t stv[S];
+    uint16_t tsv[S];
+    __builtin_memcpy(stv, st.status + base, S);
+    __builtin_memcpy(tsv, st.ts + base, 2 * S);
+    uint32_t n_ok = 0;
+    bool more = true, full = false;
+    long long last = -1;  // largest rank replayed so far
+    while (more && !full) {
+      uint32_t best[S - 1];  // the S-1 smallest ranks above `last`, ascending
 #pragma unroll
-    for (int i = S - 1; i >= 1; --i)
-      if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) slot = i;
-    if (slot < 0) continue;  // voxel full: the copy is dropped (operations.h:357)
-    const uint8_t cs = sc.mv_status[e];
-    const uint16_t cts = sc.mv_ts[e];
-    st.pos4[base + slot] = sc.mv_pos[e];
-    st.w[base + slot] = sc.mv_w[e];
-    st.ts[base + slot] = cts;
-    st.track[base + slot] = sc.mv_track[e];
-    st.label[base + slot] = sc.mv_label[e];
-    st.status[base + slot] = cs;
-    st.owner[base + slot] = sc.mv_owner[e];  // new index joins the object's set
-    st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
+      for (int i = 0; i < S - 1; ++i) best[i] = MV_NIL;
+      for (uint32_t cur = head; cur != MV_NIL; cur = sc.mv_next[cur]) {
+        if ((long long)cur <= last) continue;
+        uint32_t x = cur;
 #pragma unroll
-    for (int i = 1; i < S; ++i)
-      if (i == slot) {
-        stv[i] = cs;
-        tsv[i] = cts;
+        for (int i = 0; i < S - 1; ++i)
+          if (x < best[i]) {
+            const uint32_t y = best[i];
+            best[i] = x;
+            x = y;
+          }
       }
-    ++n_ok;
+      more = best[S - 2] != MV_NIL;  // a full batch: there may be further ranks
+#pragma unroll
+      for (int u = 0; u < S - 1; ++u) {
+        const uint32_t e = best[u];
+        if (e == MV_NIL || full) break;
+        last = e;
+        int slot = -1;
+#pragma unroll
+        for (int i = S - 1; i >= 1; --i)
+          if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) slot = i;
+        if (slot < 0) {  // voxel full: this copy and all later ones are dropped (operations.h:357)
+          full = true;
+          break;
+        }
+        const uint8_t cs = sc.mv_status[e];
+        const uint16_t cts = sc.mv_ts[e];
+        st.pos4[base + slot] = sc.mv_pos[e];
+        st.w[base + slot] = sc.mv_w[e];
+        st.ts[base + slot] = cts;
+        st.track[base + slot] = sc.mv_track[e];
+        st.label[base + slot] = sc.mv_label[e];
+        st.status[base + slot] = cs;
+        st.owner[base + slot] = sc.mv_owner[e];  // new index joins the object's set
+        st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
+#pragma unroll
+        for (int i = 1; i < S; ++i)
+          if (i == slot) {
+            stv[i] = cs;
+            tsv[i] = cts;
+          }
+        ++n_ok;
+      }
+    }
+    if (n_ok) atomicAdd(&sc.cnt->n_move_reinserted, n_ok);
   }
-  if (n_ok) atomicAdd(&sc.cnt->n_move_reinserted, n_ok);
 }
 
 // removeObjectByTrackID (object_layer.h:414-425): every index of the set -> INVALID, set erased.
@@ -480,26 +508,20 @@ void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, co
                             const Scratch &sc, const int32_t *counts_all, int world, int rank, hipStream_t s) {
   if (n_obj <= 0) return;
   hipLaunchKernelGGL(k_move_bases, dim3(1), dim3(64), 0, s, d.v_count != d.V ? counts_all : nullptr, world, rank, n_obj, sc, sc.mv_cnt);
-  // with several shards most ranks of the global list belong to other shards: they must read "not mine"
-  if (world > 1) hipLaunchKernelGGL(k_move_init_keys, dim3(256), dim3(TPB), 0, s, d, sc);
-  hipLaunchKernelGGL(k_move_transform, dim3(256), dim3(TPB), 0, s, d, f, flt, ms_dev, st, sc, sc.mv_cnt, n_obj, world > 1 ? 0 : 1);
+  hipLaunchKernelGGL(k_move_transform, dim3(256), dim3(TPB), 0, s, d, f, flt, ms_dev, st, sc, sc.mv_cnt, n_obj);
 }
 
-// step 3 (after the export buffers of all shards are gathered): import, stable sort by voxel, ordered replay
+// step 3 (after the export buffers of all shards are gathered): import, ordered replay per target voxel
 void launch_moves_finish(const Dims &d, const Filter &flt, int n_obj, const State &st, const Scratch &sc, int world, int rank,
                          hipStream_t s) {
   if (n_obj <= 0) return;
   if (world > 1 && sc.halo_recv) hipLaunchKernelGGL(k_move_import, dim3(64, world), dim3(TPB), 0, s, d, sc, world, rank);
-  int nbits = d.x_n + d.y_n + d.z_n + 1;
-  int which = radix_sort_pairs(sc.mkey_a, sc.mval_a, sc.mkey_b, sc.mval_b, sc.cap_move, nbits, sc.msort_scratch, s, sc.mv_total);
-  const uint32_t *skey = which ? sc.mkey_b : sc.mkey_a;
-  const uint32_t *sval = which ? sc.mval_b : sc.mval_a;
-  dim3 grid(blocks_for(sc.cap_move));
+  dim3 grid(256);
   switch (d.p_n) {
-    case 1: hipLaunchKernelGGL(k_move_replay<2>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
-    case 2: hipLaunchKernelGGL(k_move_replay<4>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
-    case 3: hipLaunchKernelGGL(k_move_replay<8>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
-    default: hipLaunchKernelGGL(k_move_replay<16>, grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval); break;
+    case 1: hipLaunchKernelGGL(k_move_replay<2>, grid, dim3(TPB), 0, s, d, flt, st, sc); break;
+    case 2: hipLaunchKernelGGL(k_move_replay<4>, grid, dim3(TPB), 0, s, d, flt, st, sc); break;
+    case 3: hipLaunchKernelGGL(k_move_replay<8>, grid, dim3(TPB), 0, s, d, flt, st, sc); break;
+    default: hipLaunchKernelGGL(k_move_replay<16>, grid, dim3(TPB), 0, s, d, flt, st, sc); break;
   }
 }
 

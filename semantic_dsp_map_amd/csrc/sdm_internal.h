@@ -85,7 +85,8 @@ struct Counters {
   uint32_t start_in_frustum;
   uint32_t overflow;
   uint32_t n_valid_px;
-  uint32_t pad[8];
+  uint32_t n_move_voxels;  // voxels that receive at least one moved copy this frame
+  uint32_t pad[7];
   // Same-address atomics retire at ~12 ns each on MI355X, so counters that every wave bumps are sharded
   // by block index; the per-shard visible-particle counters also index per-shard regions of the work list.
   uint32_t vis_shard[64];

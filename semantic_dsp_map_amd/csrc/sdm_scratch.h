@@ -60,7 +60,9 @@ struct Scratch {
   uint32_t *scan_scratch = nullptr, *sort_scratch = nullptr;
   uint32_t *scan_scratch_b = nullptr;   // births run on their own stream
   // sort double buffers of the move re-insertion (the birth sort runs concurrently on another stream)
-  uint32_t *mkey_a = nullptr, *mval_a = nullptr, *mkey_b = nullptr, *mval_b = nullptr, *msort_scratch = nullptr;
+  // re-insertion of the moved copies: per target voxel a linked list of copy ranks (mv_head, one entry per voxel of the
+  // shard, MV_NIL when idle; mv_next per rank) and the list of voxels that got a list this frame
+  uint32_t *mv_head = nullptr, *mv_next = nullptr, *mv_vox = nullptr, *mv_vlist = nullptr;
   Counters *cnt = nullptr;
   Cursors *cur = nullptr;
 };
