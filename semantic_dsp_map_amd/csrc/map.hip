@@ -524,9 +524,6 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.b_valid, hw + 1);
   A(sc.b_rank, hw + 1);
   sc.cap_move = (uint32_t)std::min<size_t>(n_slots, (size_t)1 << 18);  // moved particles per frame (objects hold <= ~1e5)
-  A(sc.mv_src, sc.cap_move);
-  A(sc.mv_total, 4);
-  A(sc.mv_ebase, MAX_MOVE_OBJECTS);
   A(m->d_counts_local, HALO_OBJ);
   const size_t mv_cnt_n = move_count_elems();
   A(sc.mv_cnt, mv_cnt_n);
@@ -547,7 +544,6 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.mv_head, d.v_count);
   HIP_TRY(hipMemset(sc.mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t)));  // MV_NIL; the replay leaves it that way
   A(sc.mv_next, sc.cap_move);
-  A(sc.mv_vox, sc.cap_move);
   A(sc.mv_vlist, sc.cap_move);
   A(sc.cnt, 1);
   A(sc.cur, 1);

@@ -136,72 +136,6 @@ __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__
   }
 }
 
-// pass 2 (after the exclusive scan of cnt): stable scatter of the member indices.
-__global__ __launch_bounds__(TPB) void k_move_scatter(const uint16_t *__restrict__ owner, size_t n_slots, size_t slot_base,
-                                                      const MoveSet ms, const uint32_t *__restrict__ offs,
-                                                      int n_obj, uint32_t *__restrict__ mv_src, uint32_t cap, Counters *cnt,
-                                                      const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list) {
-  __shared__ uint32_t obj_base[MAX_MOVE_OBJECTS];
-  __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
-  __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
-  __shared__ uint32_t block_total;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const uint32_t n = *n_list;
-  if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms.track[threadIdx.x] : OWNER_NONE;
-  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (uint32_t pos = blockIdx.x; pos < n; pos += gridDim.x) {
-    __syncthreads();
-    if (threadIdx.x == 0) block_total = 0;
-    __syncthreads();
-    if ((int)threadIdx.x < n_obj) {
-      uint32_t o0 = offs[(size_t)threadIdx.x * MV_LIST_CAP + pos];
-      uint32_t o1 = offs[(size_t)threadIdx.x * MV_LIST_CAP + pos + 1];  // next position (or next object's first)
-      obj_base[threadIdx.x] = o0;
-      if (o1 != o0) atomicAdd(&block_total, o1 - o0);
-    }
-    __syncthreads();
-    if (block_total == 0) continue;  // no member of any moving object in this chunk
-    size_t base = (size_t)list[pos] * MV_CHUNK;
-    for (int r = 0; r < MV_ITEMS; ++r) {
-      if (threadIdx.x < MAX_MOVE_OBJECTS) {
-#pragma unroll
-        for (int w = 0; w < MV_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
-      }
-      __syncthreads();
-      size_t i = base + (size_t)r * TPB + threadIdx.x;
-      uint8_t o = 0xFF;
-      if (i < n_slots) o = obj_of(owner[i], tracks, n_obj);
-      bool valid = o != 0xFF;
-      uint64_t peers = __ballot(valid);
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        bool bit = (o >> b) & 1u;
-        uint64_t m = __ballot(bit);
-        peers &= bit ? m : ~m;
-      }
-      uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
-      if (valid && rank_in_wave == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
-      __syncthreads();
-      if (valid) {
-        uint32_t off = obj_base[o] + rank_in_wave;
-#pragma unroll
-        for (int w = 0; w < MV_WAVES; ++w)
-          if (w < wid) off += wave_cnt[w][o];
-        if (off < cap) mv_src[off] = (uint32_t)(slot_base + i);
-        else cnt->overflow = 1;
-      }
-      __syncthreads();
-      if (threadIdx.x < MAX_MOVE_OBJECTS) {
-        uint32_t add = 0;
-#pragma unroll
-        for (int w = 0; w < MV_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
-        obj_base[threadIdx.x] += add;
-      }
-      __syncthreads();
-    }
-  }
-}
-
 // ---- global ranks across Z-slab shards ------------------------------------------------------------------
 // The noise-table cursor and the re-insertion order of the reference run over (object order, ascending particle
 // index).  With the map split into Z slabs (ring-z = high index bits) that order is: object, then shard, then local
@@ -221,33 +155,11 @@ struct HaloRecord {
 };
 static_assert(sizeof(HaloRecord) == HALO_RECORD_BYTES, "halo record layout");
 
-__global__ void k_move_local_counts(const uint32_t *__restrict__ offs, int n_obj, int32_t *counts_local) {
+__global__ void k_move_local_counts(const uint32_t *__restrict__ offs, int n_obj, int32_t *counts_local, Scratch sc) {
   int k = threadIdx.x;
+  if (k == 0 && sc.halo_send) *reinterpret_cast<uint32_t *>(sc.halo_send) = 0;  // this frame's export counter
   if (k >= HALO_OBJ) return;
   counts_local[k] = k < n_obj ? (int32_t)(offs[(size_t)(k + 1) * MV_LIST_CAP] - offs[(size_t)k * MV_LIST_CAP]) : 0;
-}
-
-// one thread: e_base[k], total; also resets the export counter
-__global__ void k_move_bases(const int32_t *__restrict__ counts_all, int world, int rank, int n_obj, Scratch sc,
-                             const uint32_t *__restrict__ offs) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  uint32_t run = 0;
-  for (int k = 0; k < n_obj; ++k) {
-    uint32_t below = 0, all = 0;
-    for (int r = 0; r < world; ++r) {
-      // single shard: the count row is read straight from the scanned count matrix
-      uint32_t c = counts_all ? (uint32_t)counts_all[r * HALO_OBJ + k]
-                              : offs[(size_t)(k + 1) * MV_LIST_CAP] - offs[(size_t)k * MV_LIST_CAP];
-      if (r < rank) below += c;
-      all += c;
-    }
-    sc.mv_ebase[k] = run + below;
-    run += all;
-  }
-  sc.cnt->n_moved = run;
-  *sc.mv_total = run < sc.cap_move ? run : sc.cap_move;
-  if (run > sc.cap_move) sc.cnt->overflow = 1;
-  if (sc.halo_send) *reinterpret_cast<uint32_t *>(sc.halo_send) = 0;
 }
 
 constexpr uint32_t MV_NIL = 0xffffffffu;
@@ -256,73 +168,153 @@ constexpr uint32_t MV_NIL = 0xffffffffu;
 // The copy that finds the list idle also enters the voxel in this frame's work list.
 __device__ __forceinline__ void move_link(const Dims &d, const Scratch &sc, uint32_t v, uint32_t e) {
   const uint32_t lv = v - d.v_begin;
-  sc.mv_vox[e] = lv;
   const uint32_t prev = atomicExch(&sc.mv_head[lv], e);
   sc.mv_next[e] = prev;
   if (prev == MV_NIL) sc.mv_vlist[atomicAdd(&sc.cnt->n_move_voxels, 1u)] = lv;
 }
 
-// phase 1 of moveParticlesInSetsByTransformations (operations.h:331-349): copy, transform + table noise,
-// delete the original.  The noise cursor advances by three per particle in global rank order.
-__global__ __launch_bounds__(TPB) void k_move_transform(Dims d, Frame f, Filter flt, const MoveSet ms, State st, Scratch sc,
-                                                        const uint32_t *__restrict__ offs, int n_obj) {
-  if (sc.cnt->overflow) return;
-  const uint32_t n_blocks = MV_LIST_CAP;
-  const uint32_t local_total = offs[(size_t)n_obj * n_blocks];
+// one member of moving object `obj`, global rank e, local slot li
+__device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms, const State &st,
+                                         const Scratch &sc, int obj, uint32_t e, size_t li) {
+  const float4 p = st.pos4[li];
+  const float *T = ms.T[obj];
+  float nx = row4(T + 0, p.x, p.y, p.z);
+  float ny = row4(T + 4, p.x, p.y, p.z);
+  float nz = row4(T + 8, p.x, p.y, p.z);
+  long long draw = (long long)sc.cur->move_cursor + 3ll * e;
+  nx = nx + st.noise[(draw + 1) % flt.noise_n];
+  ny = ny + st.noise[(draw + 2) % flt.noise_n];
+  nz = nz + st.noise[(draw + 3) % flt.noise_n];
+  const float pw = st.w[li];
+  const uint16_t pts = st.ts[li], ptrack = st.track[li];
+  const uint8_t plabel = st.label[li], pstatus = st.status[li];
+  const uint16_t powner = ms.track[obj];
+  st.status[li] = ST_INVALID;  // deleteParticleByIndex
+  st.owner[li] = OWNER_NONE;   // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
+  uint32_t rx, ry, rz;
+  uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
+  if (v == INVALID_INDEX) return;  // left the map: dropped (operations.h:799-802)
+  if (rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) {
+    if (e >= sc.cap_move) return;
+    sc.mv_pos[e] = make_float4(nx, ny, nz, p.w);
+    sc.mv_w[e] = pw;
+    sc.mv_ts[e] = pts;
+    sc.mv_track[e] = ptrack;
+    sc.mv_label[e] = plabel;
+    sc.mv_status[e] = pstatus;
+    sc.mv_owner[e] = powner;
+    move_link(d, sc, v, e);
+  } else if (sc.halo_send) {  // crosses into another slab: export
+    uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(sc.halo_send), 1u);
+    if (k < sc.halo_cap) {
+      HaloRecord r;
+      r.x = nx;
+      r.y = ny;
+      r.z = nz;
+      r.forget_bits = __float_as_uint(p.w);
+      r.w = pw;
+      r.voxel = v;
+      r.e = e;
+      r.ts_track = (uint32_t)pts | ((uint32_t)ptrack << 16);
+      r.owner_label_status = (uint32_t)powner | ((uint32_t)plabel << 16) | ((uint32_t)pstatus << 24);
+      reinterpret_cast<HaloRecord *>(sc.halo_send + HALO_HEADER_BYTES)[k] = r;
+    } else {
+      sc.cnt->overflow = 1;
+    }
+  }
+}
+
+// phase 1 of moveParticlesInSetsByTransformations (operations.h:331-349): copy, transform + table noise, delete the
+// original.  One workgroup per flagged chunk: the members of every moving object are ranked in ascending index order
+// (ballot ranks inside a wave, wave counts through LDS, chunk offsets from the scanned count matrix), which gives each
+// its global rank e = rank among all members of all moving objects in (object, shard, index) order.  The noise
+// cursor advances by three per particle in that order; the copy joins its target voxel's list or is exported.
+__global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt, const MoveSet ms, State st, Scratch sc,
+                                                    const uint32_t *__restrict__ offs, int n_obj,
+                                                    const int32_t *__restrict__ counts_all, int world, int rank) {
+  __shared__ uint32_t obj_base[MAX_MOVE_OBJECTS];  // global rank of the object's next member in this chunk
+  __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
+  __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
+  __shared__ uint32_t e_shift[MAX_MOVE_OBJECTS];   // global rank of the object's first local member - its local offset
+  __shared__ uint32_t block_total;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const uint32_t n = *sc.mv_nlist;
+  const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t slot_base = (size_t)d.v_begin << d.p_n;
-  uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t le = blockIdx.x * blockDim.x + threadIdx.x; le < local_total; le += stride) {
-    int obj = 0;
-    for (int k = 1; k < n_obj; ++k)
-      if (le >= offs[(size_t)k * n_blocks]) obj = k;
-    const uint32_t e = sc.mv_ebase[obj] + (le - offs[(size_t)obj * n_blocks]);
-    const uint32_t src = sc.mv_src[le];
-    const size_t li = (size_t)src - slot_base;
-    const float4 p = st.pos4[li];
-    const float *T = ms.T[obj];
-    float nx = row4(T + 0, p.x, p.y, p.z);
-    float ny = row4(T + 4, p.x, p.y, p.z);
-    float nz = row4(T + 8, p.x, p.y, p.z);
-    long long draw = (long long)sc.cur->move_cursor + 3ll * e;
-    nx = nx + st.noise[(draw + 1) % flt.noise_n];
-    ny = ny + st.noise[(draw + 2) % flt.noise_n];
-    nz = nz + st.noise[(draw + 3) % flt.noise_n];
-    const float pw = st.w[li];
-    const uint16_t pts = st.ts[li], ptrack = st.track[li];
-    const uint8_t plabel = st.label[li], pstatus = st.status[li];
-    const uint16_t powner = ms.track[obj];
-    st.status[li] = ST_INVALID;  // deleteParticleByIndex
-    st.owner[li] = OWNER_NONE;   // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
-    uint32_t rx, ry, rz;
-    uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
-    if (v == INVALID_INDEX) continue;  // left the map: dropped (operations.h:799-802)
-    if (rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) {
-      if (e >= sc.cap_move) continue;
-      sc.mv_pos[e] = make_float4(nx, ny, nz, p.w);
-      sc.mv_w[e] = pw;
-      sc.mv_ts[e] = pts;
-      sc.mv_track[e] = ptrack;
-      sc.mv_label[e] = plabel;
-      sc.mv_status[e] = pstatus;
-      sc.mv_owner[e] = powner;
-      move_link(d, sc, v, e);
-    } else if (sc.halo_send) {  // crosses into another slab: export
-      uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(sc.halo_send), 1u);
-      if (k < sc.halo_cap) {
-        HaloRecord r;
-        r.x = nx;
-        r.y = ny;
-        r.z = nz;
-        r.forget_bits = __float_as_uint(p.w);
-        r.w = pw;
-        r.voxel = v;
-        r.e = e;
-        r.ts_track = (uint32_t)pts | ((uint32_t)ptrack << 16);
-        r.owner_label_status = (uint32_t)powner | ((uint32_t)plabel << 16) | ((uint32_t)pstatus << 24);
-        reinterpret_cast<HaloRecord *>(sc.halo_send + HALO_HEADER_BYTES)[k] = r;
-      } else {
-        sc.cnt->overflow = 1;
+  if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms.track[threadIdx.x] : OWNER_NONE;
+  if ((int)threadIdx.x < n_obj) {
+    // e = sum_{k'<k} sum_r' C[r'][k'] + sum_{r'<rank} C[r'][k] + j.  Single shard: the scanned count matrix already
+    // is that prefix (shift 0).
+    uint32_t shift = 0;
+    if (counts_all) {
+      uint32_t run = 0;
+      for (int k = 0; k < (int)threadIdx.x; ++k)
+        for (int r = 0; r < world; ++r) run += (uint32_t)counts_all[r * HALO_OBJ + k];
+      for (int r = 0; r < rank; ++r) run += (uint32_t)counts_all[r * HALO_OBJ + threadIdx.x];
+      shift = run - offs[(size_t)threadIdx.x * MV_LIST_CAP];
+    }
+    e_shift[threadIdx.x] = shift;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    uint32_t total = 0;
+    if (counts_all) {
+      for (int k = 0; k < n_obj; ++k)
+        for (int r = 0; r < world; ++r) total += (uint32_t)counts_all[r * HALO_OBJ + k];
+    } else {
+      total = offs[(size_t)n_obj * MV_LIST_CAP];
+    }
+    sc.cnt->n_moved = total;
+    if (total > sc.cap_move) sc.cnt->overflow = 1;
+  }
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (uint32_t pos = blockIdx.x; pos < n; pos += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x == 0) block_total = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < n_obj) {
+      uint32_t o0 = offs[(size_t)threadIdx.x * MV_LIST_CAP + pos];
+      uint32_t o1 = offs[(size_t)threadIdx.x * MV_LIST_CAP + pos + 1];  // next position (or next object's first)
+      obj_base[threadIdx.x] = o0 + e_shift[threadIdx.x];
+      if (o1 != o0) atomicAdd(&block_total, o1 - o0);
+    }
+    __syncthreads();
+    if (block_total == 0) continue;  // no member of any moving object in this chunk
+    const size_t base = (size_t)sc.mv_list[pos] * MV_CHUNK;
+    for (int r = 0; r < MV_ITEMS; ++r) {
+      if (threadIdx.x < MAX_MOVE_OBJECTS) {
+#pragma unroll
+        for (int w = 0; w < MV_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
       }
+      __syncthreads();
+      const size_t li = base + (size_t)r * TPB + threadIdx.x;
+      uint8_t o = 0xFF;
+      if (li < n_slots) o = obj_of(st.owner[li], tracks, n_obj);
+      const bool valid = o != 0xFF;
+      uint64_t peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        bool bit = (o >> b) & 1u;
+        uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+      }
+      const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
+      if (valid && rank_in_wave == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
+      __syncthreads();
+      if (valid) {
+        uint32_t e = obj_base[o] + rank_in_wave;
+#pragma unroll
+        for (int w = 0; w < MV_WAVES; ++w)
+          if (w < wid) e += wave_cnt[w][o];
+        move_one(d, f, flt, ms, st, sc, (int)o, e, li);
+      }
+      __syncthreads();
+      if (threadIdx.x < MAX_MOVE_OBJECTS) {
+        uint32_t add = 0;
+#pragma unroll
+        for (int w = 0; w < MV_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
+        obj_base[threadIdx.x] += add;
+      }
+      __syncthreads();
     }
   }
 }
@@ -497,18 +489,16 @@ void launch_moves_count(const Dims &d, const MoveSet &ms_dev, int n_obj, const S
   hipLaunchKernelGGL(k_move_count, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, ms_dev, sc.mv_cnt, n_obj, st.owner_flag, sc.mv_list,
                      sc.mv_nlist);
   exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch, s);
-  hipLaunchKernelGGL(k_move_scatter, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, slot_base, ms_dev, sc.mv_cnt, n_obj, sc.mv_src,
-                     sc.cap_move, sc.cnt, sc.mv_list, sc.mv_nlist);
   // the per-object counts are only needed as a separate row when they are exchanged between shards
-  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, n_obj, counts_local);
+  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, n_obj, counts_local, sc);
 }
 
 // step 2 (after the counts of all shards are known): global ranks, transform, export of slab-crossing copies
 void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms_dev, int n_obj, const State &st,
                             const Scratch &sc, const int32_t *counts_all, int world, int rank, hipStream_t s) {
   if (n_obj <= 0) return;
-  hipLaunchKernelGGL(k_move_bases, dim3(1), dim3(64), 0, s, d.v_count != d.V ? counts_all : nullptr, world, rank, n_obj, sc, sc.mv_cnt);
-  hipLaunchKernelGGL(k_move_transform, dim3(256), dim3(TPB), 0, s, d, f, flt, ms_dev, st, sc, sc.mv_cnt, n_obj);
+  hipLaunchKernelGGL(k_move_apply, dim3(1024), dim3(TPB), 0, s, d, f, flt, ms_dev, st, sc, sc.mv_cnt, n_obj,
+                     d.v_count != d.V ? counts_all : nullptr, world, rank);
 }
 
 // step 3 (after the export buffers of all shards are gathered): import, ordered replay per target voxel

@@ -41,16 +41,13 @@ struct Scratch {
   uint32_t *bkey_a = nullptr, *bval_a = nullptr, *bkey_b = nullptr, *bval_b = nullptr;
   float4 *bpos = nullptr;
   // object moves
-  uint32_t *mv_src = nullptr;      // source particle index of every moved particle, (object, index) order
   uint32_t *mv_cnt = nullptr;      // per-chunk per-object counts / offsets
   uint32_t *mv_list = nullptr, *mv_nlist = nullptr;  // ascending list of chunks that may hold owned slots
-  uint32_t *mv_total = nullptr;    // per-object totals + exclusive offsets
   float4 *mv_pos = nullptr;        // copies: position (+forget bits)
   float *mv_w = nullptr;
   uint16_t *mv_ts = nullptr, *mv_track = nullptr, *mv_owner = nullptr;
   uint8_t *mv_label = nullptr, *mv_status = nullptr;
   uint32_t cap_move = 0;
-  uint32_t *mv_ebase = nullptr;    // global rank of each moving object's first local member
   // slab-crossing copies: [u32 count, pad to 16 B][records]; recv = one such buffer per shard, shard order
   unsigned char *halo_send = nullptr;
   const unsigned char *halo_recv = nullptr;
@@ -62,7 +59,7 @@ struct Scratch {
   // sort double buffers of the move re-insertion (the birth sort runs concurrently on another stream)
   // re-insertion of the moved copies: per target voxel a linked list of copy ranks (mv_head, one entry per voxel of the
   // shard, MV_NIL when idle; mv_next per rank) and the list of voxels that got a list this frame
-  uint32_t *mv_head = nullptr, *mv_next = nullptr, *mv_vox = nullptr, *mv_vlist = nullptr;
+  uint32_t *mv_head = nullptr, *mv_next = nullptr, *mv_vlist = nullptr;
   Counters *cnt = nullptr;
   Cursors *cur = nullptr;
 };
