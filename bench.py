@@ -112,7 +112,7 @@ def main():
         dt = float(tt.item())
 
     stats = m.stats(count_live=True)
-    live, n_vis = stats["live_particles"], stats["n_visible"]
+    live, n_vis, live_vox_local = stats["live_particles"], stats["n_visible"], stats["live_voxels"]
     if dist is not None:
         lt = torch.tensor([live, n_vis], dtype=torch.int64)
         dist.all_reduce(lt)
@@ -132,12 +132,16 @@ def main():
     sweep_ms = m.time_occupancy_sweep(iters=50)
     ms_per_step = dt * 1e3 / args.steps
     value = V / (dt / args.steps) / 1e6  # Mvoxels / s, whole map (all shards)
-    bytes_per_voxel = (S - 1) * 10 + 2 + 8  # read (S-1)*(w4+ts2+track2+label1+status1)+2, write 8
-    alg_bytes = (V // world) * bytes_per_voxel
+    # Algorithmic bytes of one sweep: every voxel costs its stamp row (2S), status row (S) and the 8-byte
+    # result; the weight, track and label rows (7S) are needed only for observed voxels that hold a live slot.
+    # (SURVEY.md 8d's dense figure, 80 B/voxel at S = 8, is the case "every voxel holds a particle".)
+    alg_bytes = (V // world) * (3 * S + 8) + live_vox_local * 7 * S
     achieved = alg_bytes / (sweep_ms * 1e-3)
     roofline = {"kernel": "k_occupancy<%d>" % S, "bound": "hbm", "achieved": round(achieved / 1e9, 1),
                 "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BPS, 4),
-                "traffic": pmc_traffic(S, V // world), "bytes_per_launch": alg_bytes, "avg_launch_ms": round(sweep_ms, 5)}
+                "traffic": pmc_traffic(S, V // world, live_vox_local), "bytes_per_launch": alg_bytes,
+                "avg_launch_ms": round(sweep_ms, 5), "voxels": V // world, "voxels_with_live_slots": live_vox_local,
+                "dense_bytes_per_launch": (V // world) * (10 * S + 8)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_frames > 0:
@@ -169,14 +173,16 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(S, voxels):
+def pmc_traffic(S, voxels, live_voxels):
     """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per
-    MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r01c_sweep_pmc.json); None if they were taken on a
-    different kernel shape.  PMC counters cannot be read from inside this process."""
+    MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r01e_sweep_pmc.json); None if they were taken on a
+    different kernel shape or a map whose live-voxel count is more than 10 % off.  PMC counters cannot be read from
+    inside this process."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01c_sweep_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01e_sweep_pmc.json")) as f:
             p = json.load(f)
-        if p["kernel"] == "k_occupancy<%d>" % S and p["algorithmic_bytes_per_launch"] == voxels * ((S - 1) * 10 + 10):
+        if (p["kernel"] == "k_occupancy<%d>" % S and p["voxels"] == voxels
+                and abs(p["voxels_with_live_slots"] - live_voxels) <= 0.1 * max(live_voxels, 1)):
             return int(p["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass

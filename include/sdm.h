@@ -149,6 +149,7 @@ typedef struct {
   int64_t n_occupied;
   int64_t flood_rounds;
   int64_t bfs_start_in_frustum;
+  int64_t live_voxels;      /* observed voxels holding a live slot (count_live=1): the ones the sweep fetches in full */
   double stage_ms[8];       /* GPU time per stage of the last update when profiling is on */
 } sdm_stats;
 

@@ -88,35 +88,22 @@ __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__
 // ------------------------------------------------------------------------------------ A10
 // getOccupancyResult -> determineIfVoxelOccupied -> calculateWeightAndSemanticsInVoxel
 // (semantic_dsp_map.h:1239-1257, mc_ring/operations.h:623-639, 390-448).
-// One thread per voxel; all S slots of the voxel are fetched with wide loads (SoA arrays are
-// voxel-contiguous), the 8-byte result is one store.  HBM-bound: 80 B/voxel at S=8.
+// One thread per voxel; the slot rows of a voxel are fetched with wide loads (SoA arrays are voxel-contiguous), the
+// 8-byte result is one store.  HBM-bound.  Every voxel costs its stamp row, status row and result (2S + S + 8 =
+// 32 B at S = 8); weight, track and label rows (7S = 56 B) are only fetched for voxels that hold a live slot - in a
+// map that is mostly free space or never observed that is a small minority.
+// A voxel that holds a live slot: weight sum, clamp / cull write-backs and the track vote
+// (calculateWeightAndSemanticsInVoxel, operations.h:390-448).
 template <int S>
-__global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, State st) {
-  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;  // local voxel of this shard
-  if (lv >= d.v_count) return;
-  uint32_t v = d.v_begin + lv;
-  uint32_t rx, ry, rz;
-  voxel_to_ring(d, v, rx, ry, rz);
-  const uint32_t smax = stamp_max(st, rx, ry, rz);
+__device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_threshold, uint32_t lv, uint32_t smax,
+                                                     const uint16_t (&tsv)[S], uint8_t (&stv)[S]) {
   const size_t base = (size_t)lv * S;
-
-  uint16_t tsv[S];
-  load_vec(tsv, st.ts + base);
   sdm_voxel_result out;
   out.track = 0;
   out.label = 0;
-  const uint32_t t0 = tsv[0];
-  if (t0 == 0 || t0 < smax) {  // isVoxelValid, operations.h:824-837
-    out.wsum = -1.f;
-    out.occ = -1;
-    store_result(st.res + lv, out);
-    return;
-  }
-  uint8_t stv[S];
   float wv[S];
   uint16_t trk[S];
   uint8_t lab[S];
-  load_vec(stv, st.status + base);
   load_vec(wv, st.w + base);
   load_vec(trk, st.track + base);
   load_vec(lab, st.label + base);
@@ -184,6 +171,75 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
   store_result(st.res + lv, out);
   if (dirty_w) store_vec(st.w + base, wv);
   if (dirty_s) store_vec(st.status + base, stv);
+}
+
+// Two phases per workgroup of TPB * OCC_VPT voxels.  Phase 1 streams the stamp and status rows (OCC_VPT voxels per
+// thread, all rows requested before the first is looked at) and finishes every voxel that is not observed or holds
+// no live slot - the vast majority in a map that is mostly free or unseen space.  Voxels with live slots are listed
+// in LDS and handled in phase 2 with all lanes busy: their vote loops and extra row loads would otherwise run with a
+// few lanes of every wave that happens to touch a surface.
+constexpr int OCC_VPT = 4;
+
+template <int S>
+__global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, State st) {
+  __shared__ uint16_t live_list[TPB * OCC_VPT];
+  __shared__ uint32_t n_live;
+  const uint32_t blk0 = blockIdx.x * (TPB * OCC_VPT);
+  if (threadIdx.x == 0) n_live = 0;
+  uint16_t tsv[OCC_VPT][S];
+  uint8_t stv[OCC_VPT][S];
+  uint32_t smax[OCC_VPT];
+#pragma unroll
+  for (int u = 0; u < OCC_VPT; ++u) {
+    const uint32_t lv = blk0 + u * TPB + threadIdx.x;
+    if (lv >= d.v_count) continue;
+    const size_t base = (size_t)lv * S;
+    load_vec(tsv[u], st.ts + base);
+    load_vec(stv[u], st.status + base);
+    uint32_t rx, ry, rz;
+    voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+    smax[u] = stamp_max(st, rx, ry, rz);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < OCC_VPT; ++u) {
+    const uint32_t lv = blk0 + u * TPB + threadIdx.x;
+    if (lv >= d.v_count) continue;
+    sdm_voxel_result out;
+    out.track = 0;
+    out.label = 0;
+    const uint32_t t0 = tsv[u][0];
+    if (t0 == 0 || t0 < smax[u]) {  // isVoxelValid, operations.h:824-837
+      out.wsum = -1.f;
+      out.occ = -1;
+      store_result(st.res + lv, out);
+      continue;
+    }
+    bool any_live = false;
+#pragma unroll
+    for (int i = 1; i < S; ++i)  // isParticleVacant, operations.h:810-816
+      any_live = any_live || !(stv[u][i] == ST_INVALID || (uint32_t)tsv[u][i] < smax[u]);
+    if (!any_live) {  // nothing contributes: weight sum 0, no vote, nothing to clamp or cull
+      out.wsum = 0.f;
+      out.occ = 0.f > occ_threshold ? 1 : 0;
+      store_result(st.res + lv, out);
+      continue;
+    }
+    live_list[atomicAdd(&n_live, 1u)] = (uint16_t)(u * TPB + threadIdx.x);
+  }
+  __syncthreads();
+  const uint32_t nl = n_live;
+  for (uint32_t k = threadIdx.x; k < nl; k += TPB) {
+    const uint32_t lv = blk0 + live_list[k];
+    const size_t base = (size_t)lv * S;
+    uint16_t ts1[S];
+    uint8_t st1[S];
+    load_vec(ts1, st.ts + base);  // second touch: L2
+    load_vec(st1, st.status + base);
+    uint32_t rx, ry, rz;
+    voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+    occupancy_live_voxel<S>(st, occ_threshold, lv, stamp_max(st, rx, ry, rz), ts1, st1);
+  }
 }
 
 // ------------------------------------------------------------------------------------ A6
@@ -1383,7 +1439,7 @@ __global__ __launch_bounds__(TPB) void k_labeled_cloud(Dims d, CloudArgs a, cons
 // ------------------------------------------------------------------------------------ utilities
 __global__ __launch_bounds__(TPB) void k_count_live(Dims d, State st, unsigned long long *out) {
   uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t c = 0;
+  uint32_t c = 0, cv = 0;
   if (lv < d.v_count) {
     uint32_t v = d.v_begin + lv, rx, ry, rz;
     voxel_to_ring(d, v, rx, ry, rz);
@@ -1391,9 +1447,15 @@ __global__ __launch_bounds__(TPB) void k_count_live(Dims d, State st, unsigned l
     size_t base = (size_t)lv * d.S;
     for (uint32_t i = 1; i < d.S; ++i)
       if (st.status[base + i] != ST_INVALID && (uint32_t)st.ts[base + i] >= smax) c++;
+    // bits 36..: voxels that pass isVoxelValid and hold a live slot (the ones the sweep fetches in full)
+    const uint32_t t0 = st.ts[base];
+    if (c && t0 != 0 && t0 >= smax) cv = 1;
   }
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+  for (int off = 32; off > 0; off >>= 1) {
+    c += __shfl_down(c, off, 64);
+    cv += __shfl_down(cv, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c | ((unsigned long long)cv << 36));
 }
 
 __global__ __launch_bounds__(TPB) void k_count_owner(Dims d, State st, uint16_t track, unsigned long long *out) {
@@ -1491,7 +1553,7 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s) {
   }
 
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s) {
-  dim3 grid(blocks_for(d.v_count));
+  dim3 grid(blocks_for(d.v_count, TPB * OCC_VPT));
   SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st);
 }
 

@@ -1188,7 +1188,8 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
     unsigned long long n = 0;
     HIP_TRY(hipMemcpyAsync(&n, m->d_u64, 8, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    out->live_particles = (int64_t)n;
+    out->live_particles = (int64_t)(n & ((1ull << 36) - 1));
+    out->live_voxels = (int64_t)(n >> 36);
     size_t nocc = 0;
     // occupied voxel count from the result array
     const float zero3[3] = {0.f, 0.f, 0.f};

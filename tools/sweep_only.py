@@ -18,4 +18,5 @@ st, ring, n = synth.prefill_state(cfg, scene, 2000000)
 m.load_state(st)
 m.set_ring_state(ring)
 ms = m.time_occupancy_sweep(iters=int(sys.argv[1]) if len(sys.argv) > 1 else 10)
-print("sweep avg ms", ms, "live prefill", n)
+stt = m.stats(count_live=True)
+print("sweep avg ms", ms, "live prefill", n, "live_voxels", stt["live_voxels"], "live_particles", stt["live_particles"])
