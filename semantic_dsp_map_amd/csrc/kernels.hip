@@ -173,11 +173,12 @@ __device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_
   if (dirty_s) store_vec(st.status + base, stv);
 }
 
-// Two phases per workgroup of TPB * OCC_VPT voxels.  Phase 1 streams the stamp and status rows (OCC_VPT voxels per
-// thread, all rows requested before the first is looked at) and finishes every voxel that is not observed or holds
-// no live slot - the vast majority in a map that is mostly free or unseen space.  Voxels with live slots are listed
-// in LDS and handled in phase 2 with all lanes busy: their vote loops and extra row loads would otherwise run with a
-// few lanes of every wave that happens to touch a surface.
+// Two phases per workgroup of TPB * OCC_VPT voxels.  Phase 1 streams the voxel stamps and the status rows (OCC_VPT
+// voxels per thread, everything requested before the first value is looked at) and finishes every voxel that is not
+// observed or whose slots are all INVALID - the vast majority in a map that is mostly free or unseen space.  The
+// others are listed in LDS and handled in phase 2 with all lanes busy: stamp row (stale slots), then weight, track
+// and label rows, vote, write-backs.  (Draining the list in a separate kernel was measured: the scattered row fetches
+// then take longer than the whole fused sweep - here they ride along with the stream.)
 constexpr int OCC_VPT = 4;
 
 template <int S>
@@ -186,16 +187,15 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
   __shared__ uint32_t n_live;
   const uint32_t blk0 = blockIdx.x * (TPB * OCC_VPT);
   if (threadIdx.x == 0) n_live = 0;
-  uint16_t tsv[OCC_VPT][S];
+  uint32_t t0v[OCC_VPT];
   uint8_t stv[OCC_VPT][S];
   uint32_t smax[OCC_VPT];
 #pragma unroll
   for (int u = 0; u < OCC_VPT; ++u) {
     const uint32_t lv = blk0 + u * TPB + threadIdx.x;
     if (lv >= d.v_count) continue;
-    const size_t base = (size_t)lv * S;
-    load_vec(tsv[u], st.ts + base);
-    load_vec(stv[u], st.status + base);
+    t0v[u] = st.vts[lv];
+    load_vec(stv[u], st.status + (size_t)lv * S);
     uint32_t rx, ry, rz;
     voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
     smax[u] = stamp_max(st, rx, ry, rz);
@@ -208,18 +208,16 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
     sdm_voxel_result out;
     out.track = 0;
     out.label = 0;
-    const uint32_t t0 = tsv[u][0];
-    if (t0 == 0 || t0 < smax[u]) {  // isVoxelValid, operations.h:824-837
+    if (t0v[u] == 0 || t0v[u] < smax[u]) {  // isVoxelValid, operations.h:824-837
       out.wsum = -1.f;
       out.occ = -1;
       store_result(st.res + lv, out);
       continue;
     }
-    bool any_live = false;
+    bool any = false;
 #pragma unroll
-    for (int i = 1; i < S; ++i)  // isParticleVacant, operations.h:810-816
-      any_live = any_live || !(stv[u][i] == ST_INVALID || (uint32_t)tsv[u][i] < smax[u]);
-    if (!any_live) {  // nothing contributes: weight sum 0, no vote, nothing to clamp or cull
+    for (int i = 1; i < S; ++i) any = any || stv[u][i] != ST_INVALID;
+    if (!any) {  // nothing contributes: weight sum 0, no vote, nothing to clamp or cull
       out.wsum = 0.f;
       out.occ = 0.f > occ_threshold ? 1 : 0;
       store_result(st.res + lv, out);
@@ -234,12 +232,37 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
     const size_t base = (size_t)lv * S;
     uint16_t ts1[S];
     uint8_t st1[S];
-    load_vec(ts1, st.ts + base);  // second touch: L2
-    load_vec(st1, st.status + base);
+    load_vec(ts1, st.ts + base);
+    load_vec(st1, st.status + base);  // second touch: L2
     uint32_t rx, ry, rz;
     voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
-    occupancy_live_voxel<S>(st, occ_threshold, lv, stamp_max(st, rx, ry, rz), ts1, st1);
+    const uint32_t sm = stamp_max(st, rx, ry, rz);
+    bool any_live = false;
+#pragma unroll
+    for (int i = 1; i < S; ++i)  // isParticleVacant, operations.h:810-816
+      any_live = any_live || !(st1[i] == ST_INVALID || (uint32_t)ts1[i] < sm);
+    if (!any_live) {  // only stale slots
+      sdm_voxel_result out;
+      out.track = 0;
+      out.label = 0;
+      out.wsum = 0.f;
+      out.occ = 0.f > occ_threshold ? 1 : 0;
+      store_result(st.res + lv, out);
+      continue;
+    }
+    occupancy_live_voxel<S>(st, occ_threshold, lv, sm, ts1, st1);
   }
+}
+
+// slot 0 of the exported stamp array carries the voxel stamp (sdm_dump_state / sdm_load_state keep the reference's
+// layout: the time particle is slot 0 of the voxel, buffer.h:57-79)
+__global__ __launch_bounds__(TPB) void k_vts_to_slot0(Dims d, State st) {
+  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lv < d.v_count) st.ts[(size_t)lv * d.S] = st.vts[lv];
+}
+__global__ __launch_bounds__(TPB) void k_vts_from_slot0(Dims d, State st) {
+  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lv < d.v_count) st.vts[lv] = st.ts[(size_t)lv * d.S];
 }
 
 // ------------------------------------------------------------------------------------ A6
@@ -603,7 +626,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
 #pragma unroll
   for (int i = 1; i < S; ++i) any = any || stv[i] != ST_INVALID;
   if (!any) {
-    if (im_ok && im_z <= im_depth) st.ts[base] = (uint16_t)f.gts;
+    if (im_ok && im_z <= im_depth) st.vts[lv] = (uint16_t)f.gts;
     return;
   }
   const uint32_t smax = stamp_max(st, rx, ry, rz);
@@ -677,9 +700,9 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   }
   if (dirty) store_vec(st.status + base, stv);
   if (observed) {
-    st.ts[base] = (uint16_t)f.gts;
+    st.vts[lv] = (uint16_t)f.gts;
   } else if (valid_n == 0) {
-    if (im_ok && im_z <= im_depth) st.ts[base] = (uint16_t)f.gts;
+    if (im_ok && im_z <= im_depth) st.vts[lv] = (uint16_t)f.gts;
   }
 }
 
@@ -1448,7 +1471,7 @@ __global__ __launch_bounds__(TPB) void k_count_live(Dims d, State st, unsigned l
     for (uint32_t i = 1; i < d.S; ++i)
       if (st.status[base + i] != ST_INVALID && (uint32_t)st.ts[base + i] >= smax) c++;
     // bits 36..: voxels that pass isVoxelValid and hold a live slot (the ones the sweep fetches in full)
-    const uint32_t t0 = st.ts[base];
+    const uint32_t t0 = st.vts[lv];
     if (c && t0 != 0 && t0 >= smax) cv = 1;
   }
   for (int off = 32; off > 0; off >>= 1) {
@@ -1536,6 +1559,7 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s) {
   hipMemsetAsync(st.pos4, 0, n * sizeof(float4), s);
   hipMemsetAsync(st.w, 0, n * sizeof(float), s);
   hipMemsetAsync(st.ts, 0, n * sizeof(uint16_t), s);
+  hipMemsetAsync(st.vts, 0, (size_t)d.v_count * sizeof(uint16_t), s);
   hipMemsetAsync(st.track, 0, n * sizeof(uint16_t), s);
   hipMemsetAsync(st.label, 0, n, s);
   hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
@@ -1636,6 +1660,11 @@ void launch_labeled_cloud(const Dims &d, const CloudArgsHost &h, const float *de
   __builtin_memcpy(&a, &h, sizeof(a));
   hipLaunchKernelGGL(k_labeled_cloud, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, a, depth, static_mask, label_to_inst,
                      obj_masks, cloud);
+}
+
+void launch_vts_sync(const Dims &d, const State &st, int to_slot0, hipStream_t s) {
+  if (to_slot0) hipLaunchKernelGGL(k_vts_to_slot0, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st);
+  else hipLaunchKernelGGL(k_vts_from_slot0, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st);
 }
 
 void launch_count_live(const Dims &d, const State &st, unsigned long long *out, hipStream_t s) {

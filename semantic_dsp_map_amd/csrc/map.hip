@@ -466,6 +466,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(m->st.pos4, n_slots);
   A(m->st.w, n_slots);
   A(m->st.ts, n_slots);
+  A(m->st.vts, d.v_count);
   A(m->st.track, n_slots);
   A(m->st.label, n_slots);
   A(m->st.status, n_slots);
@@ -1294,7 +1295,10 @@ sdm_status sdm_dump_state(sdm_map *m, float *px, float *py, float *pz, float *w,
     (void)hipFree(tf);
   }
   if (w) HIP_TRY(hipMemcpyAsync(w, m->st.w, n * 4, hipMemcpyDeviceToHost, s));
-  if (ts) HIP_TRY(hipMemcpyAsync(ts, m->st.ts, n * 2, hipMemcpyDeviceToHost, s));
+  if (ts) {
+    launch_vts_sync(m->d, m->st, 1, s);
+    HIP_TRY(hipMemcpyAsync(ts, m->st.ts, n * 2, hipMemcpyDeviceToHost, s));
+  }
   if (track) HIP_TRY(hipMemcpyAsync(track, m->st.track, n * 2, hipMemcpyDeviceToHost, s));
   if (label) HIP_TRY(hipMemcpyAsync(label, m->st.label, n, hipMemcpyDeviceToHost, s));
   if (status) HIP_TRY(hipMemcpyAsync(status, m->st.status, n, hipMemcpyDeviceToHost, s));
@@ -1323,6 +1327,7 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
   launch_pack_pos4(m->st.pos4, tx, ty, tz, tf, n, s);
   HIP_TRY(hipMemcpyAsync(m->st.w, w, n * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(m->st.ts, ts, n * 2, hipMemcpyHostToDevice, s));
+  launch_vts_sync(m->d, m->st, 0, s);
   HIP_TRY(hipMemcpyAsync(m->st.track, track, n * 2, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(m->st.label, label, n, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(m->st.status, status, n, hipMemcpyHostToDevice, s));

@@ -112,6 +112,9 @@ struct State {
   float4 *pos4 = nullptr;
   float *w = nullptr;
   uint16_t *ts = nullptr;
+  // observation stamp of every voxel = time stamp of its slot-0 "time particle" (operations.h:824-837), kept as a
+  // dense array of its own: the sweeps read it for every voxel, the slot rows only where something lives
+  uint16_t *vts = nullptr;
   uint16_t *track = nullptr;
   uint8_t *label = nullptr;
   uint8_t *status = nullptr;
