@@ -910,7 +910,7 @@ __device__ __forceinline__ void ck_store(const Filter &flt, const Scratch &sc, f
 }
 
 __global__ __launch_bounds__(TPB) void k_ck_light(Dims d, Filter flt, State st, Scratch sc, float *__restrict__ ck_out,
-                                                  int finish) {
+                                                  int finish, uint32_t light_max) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.W * d.H) return;
   const sdm_labeled_point o = sc.cloud[p];
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(TPB) void k_ck_light(Dims d, Filter flt, State st, 
       total += ee[r] - ss[r];
     }
   }
-  if (total > CK_LIGHT_MAX) {
+  if (total > light_max) {
     const uint32_t shard = blockIdx.x & (VIS_SHARDS - 1);
     const uint32_t k = atomicAdd(&sc.cnt->heavy_shard[shard], 1u);
     sc.ck_heavy[shard * sc.cap_heavy + k] = (uint32_t)p;  // cap_heavy covers every pixel a shard's blocks can hold
@@ -1034,32 +1034,45 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
     float acc = 0.f;
     for (uint32_t base = 0; base < total; base += CK_TERM_CAP) {
       const uint32_t cnt = total - base < CK_TERM_CAP ? total - base : CK_TERM_CAP;
-      const uint32_t chunk = (cnt + 255u) / 256u;
-      uint32_t g = base + (uint32_t)lane * chunk;
-      const uint32_t g_end = g + chunk < base + cnt ? g + chunk : base + cnt;
-      if (g < g_end) {
-        // row that holds term g: largest index with rowoff[idx] <= g (rows of length 0 share an offset with their
-        // successor and are stepped over)
-        int lo = 0, hi = A7_ITEMS * A7_ROWS;
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (rowoff[mid] <= g) lo = mid; else hi = mid;
+      // lane l computes terms base + l, base + l + 256, ...; four at a time, so that the loads of four
+      // independent terms are in flight together (a lane's terms are otherwise a chain of dependent loads)
+      for (uint32_t g0 = base + (uint32_t)lane; g0 < base + cnt; g0 += 4u * 256u) {
+        float4 pv[4];
+        uint32_t tf[4];
+        int px[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t g = g0 + (uint32_t)u * 256u;
+          on[u] = g < base + cnt;
+          px[u] = 0;
+          if (on[u]) {
+            // row that holds term g: largest index with rowoff[idx] <= g (rows of length 0 share an offset with
+            // their successor and are never selected)
+            int lo = 0, hi = A7_ITEMS * A7_ROWS;
+#pragma unroll
+            for (int step = 0; step < 8; ++step) {
+              const int mid = (lo + hi) >> 1;
+              if (rowoff[mid] <= g) lo = mid; else hi = mid;
+            }
+            const uint32_t k = rowbeg[lo] + (g - rowoff[lo]);
+            px[u] = lo / A7_ROWS;
+            pv[u] = sc.vp4[k];
+            tf[u] = sc.vtf[k];
+          }
         }
-        int row = lo;
-        while (rowoff[row + 1] <= g) ++row;
-        for (; g < g_end; ++g) {
-          while (rowoff[row + 1] <= g) ++row;
-          const int px = row / A7_ROWS;
-          const uint32_t k = rowbeg[row] + (g - rowoff[row]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!on[u]) continue;
           sdm_labeled_point oo;
-          oo.x = opx[px][0];
-          oo.y = opx[px][1];
-          oo.z = opx[px][2];
-          oo.sigma = opx[px][3];
-          oo.track_id = (uint16_t)otrk[px];
+          oo.x = opx[px[u]][0];
+          oo.y = opx[px[u]][1];
+          oo.z = opx[px[u]][2];
+          oo.sigma = opx[px[u]][3];
+          oo.track_id = (uint16_t)otrk[px[u]];
           bool skip;
-          const float t = ck_term(flt, pdf, sc.vp4[k], sc.vtf[k], oo, skip);
-          term[g - base] = skip ? -0.f : t;  // x + (-0) == x for every x: a skipped term leaves the sum untouched
+          const float t = ck_term(flt, pdf, pv[u], tf[u], oo, skip);
+          term[g0 + (uint32_t)u * 256u - base] = skip ? -0.f : t;  // x + (-0) == x: a skipped term leaves the sum untouched
         }
       }
       __syncthreads();
@@ -1618,7 +1631,7 @@ void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scr
 }
 
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s) {
-  hipLaunchKernelGGL(k_ck_light, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, st, sc, ck_out, finish);
+  hipLaunchKernelGGL(k_ck_light, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, st, sc, ck_out, finish, CK_LIGHT_MAX);
   hipLaunchKernelGGL(k_ck_heavy, dim3(64, VIS_SHARDS), dim3(A7_ROWS, A7_ITEMS), 0, s, d, flt, st, sc, ck_out, finish);
 }
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s) {
