@@ -1333,67 +1333,88 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
   load_vec(tsv, st.ts + base);
   bool resampled = false, checked = false;
   uint32_t n_success = 0;
-  for (uint32_t u = t; u < total && skey[u] == v; ++u) {
-    const float4 bp = sc.bpos[sval[u]];
-    const uint32_t tl = __float_as_uint(bp.w);
-    const uint16_t track = (uint16_t)(tl & 0xffffu);
-    const uint8_t label = (uint8_t)((tl >> 16) & 0xffu);
-    bool inserted = false;
-    bool changed = false;  // did this birth change the voxel (insert or triggered resample)?
+  // The candidates of a voxel are consecutive in the sorted list; eight at a time are fetched before the first is
+  // replayed (key, index, then the eight positions: two dependent loads per batch instead of per candidate).
+  bool done = false;
+  for (uint32_t u0 = t; u0 < total && !done; u0 += 8) {
+    uint32_t vs[8];
+    bool ok[8];
+    float4 bps[8];
 #pragma unroll
-    for (int attempt = 0; attempt < 2; ++attempt) {
-      int slot = -1;
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t u = u0 + j;
+      ok[j] = u < total && skey[u] == v;
+      vs[j] = ok[j] ? sval[u] : 0u;
+    }
 #pragma unroll
-      for (int i = S - 1; i >= 1; --i)
-        if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) slot = i;  // lowest vacant slot
-      if (slot > 0) {
-        // addNewParticleWithSemantics (operations.h:171-184)
-        st.pos4[base + slot] = make_float4(bp.x, bp.y, bp.z, __uint_as_float(0u));
-        st.w[base + slot] = SDM_OCC_INIT_WEIGHT;
-        st.ts[base + slot] = (uint16_t)f.gts;
-        st.track[base + slot] = track;
-        st.label[base + slot] = label;
-        st.status[base + slot] = ST_REGULAR_BORN;
-        if ((int)track <= d.max_movable) {  // addParticleToObj
-          st.owner[base + slot] = track;
-          st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
-        }
+    for (int j = 0; j < 8; ++j)
+      if (ok[j]) bps[j] = sc.bpos[vs[j]];
 #pragma unroll
-        for (int i = 1; i < S; ++i)
-          if (i == slot) {
-            stv[i] = ST_REGULAR_BORN;
-            tsv[i] = (uint16_t)f.gts;
+    for (int j = 0; j < 8; ++j) {
+      if (done) break;
+      if (!ok[j]) {  // end of this voxel's segment
+        done = true;
+        break;
+      }
+      const float4 bp = bps[j];
+      const uint32_t tl = __float_as_uint(bp.w);
+      const uint16_t track = (uint16_t)(tl & 0xffffu);
+      const uint8_t label = (uint8_t)((tl >> 16) & 0xffu);
+      bool changed = false;  // did this birth change the voxel (insert or triggered resample)?
+#pragma unroll
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        int slot = -1;
+#pragma unroll
+        for (int i = S - 1; i >= 1; --i)
+          if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) slot = i;  // lowest vacant slot
+        if (slot > 0) {
+          // addNewParticleWithSemantics (operations.h:171-184)
+          st.pos4[base + slot] = make_float4(bp.x, bp.y, bp.z, __uint_as_float(0u));
+          st.w[base + slot] = SDM_OCC_INIT_WEIGHT;
+          st.ts[base + slot] = (uint16_t)f.gts;
+          st.track[base + slot] = track;
+          st.label[base + slot] = label;
+          st.status[base + slot] = ST_REGULAR_BORN;
+          if ((int)track <= d.max_movable) {  // addParticleToObj
+            st.owner[base + slot] = track;
+            st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
           }
-        inserted = true;
-        changed = true;
-        ++n_success;
-        break;
+#pragma unroll
+          for (int i = 1; i < S; ++i)
+            if (i == slot) {
+              stv[i] = ST_REGULAR_BORN;
+              tsv[i] = (uint16_t)f.gts;
+            }
+          changed = true;
+          ++n_success;
+          break;
+        }
+        // voxel full
+        if (!flt.consider_depth_noise) break;     // no retry in the no-noise flavour
+        if (attempt == 1 || resampled || checked) break;
+        if (resample_voxel<S>(d, st, base, stv)) {
+          resampled = true;
+          changed = true;
+          atomicAdd(&sc.cnt->n_resampled, 1u);
+        } else {
+          checked = true;
+          break;
+        }
       }
-      // voxel full
-      if (!flt.consider_depth_noise) break;     // no retry in the no-noise flavour
-      if (attempt == 1 || resampled || checked) break;
-      if (resample_voxel<S>(d, st, base, stv)) {
-        resampled = true;
-        changed = true;
-        atomicAdd(&sc.cnt->n_resampled, 1u);
-      } else {
-        checked = true;
-        break;
+      if (!flt.consider_depth_noise && !resampled && !checked) {
+        // semantic_dsp_map.h:1165-1170: after every add, resample until it has triggered once
+        if (resample_voxel<S>(d, st, base, stv)) {
+          resampled = true;
+          changed = true;
+          atomicAdd(&sc.cnt->n_resampled, 1u);
+        } else {
+          checked = true;
+        }
       }
+      // fixed point: the voxel is full, its one resample per frame is used up (or cannot trigger, since births
+      // never add UPDATED particles), and this birth changed nothing -> no later birth of this voxel can either
+      if (!changed && (resampled || checked)) done = true;
     }
-    if (!flt.consider_depth_noise && !resampled && !checked) {
-      // semantic_dsp_map.h:1165-1170: after every add, resample until it has triggered once
-      if (resample_voxel<S>(d, st, base, stv)) {
-        resampled = true;
-        changed = true;
-        atomicAdd(&sc.cnt->n_resampled, 1u);
-      } else {
-        checked = true;
-      }
-    }
-    // fixed point: the voxel is full, its one resample per frame is used up (or cannot trigger, since births
-    // never add UPDATED particles), and this birth changed nothing -> no later birth of this voxel can either
-    if (!changed && (resampled || checked)) break;
   }
   if (n_success) atomicAdd(&sc.cnt->n_birth_success, n_success);
 }
