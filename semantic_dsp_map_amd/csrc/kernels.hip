@@ -1332,7 +1332,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
   load_vec(stv, st.status + base);
   load_vec(tsv, st.ts + base);
   bool resampled = false, checked = false;
-  uint32_t n_success = 0;
+  uint32_t n_success = 0, n_resamp = 0;
   // The candidates of a voxel are consecutive in the sorted list; eight at a time are fetched before the first is
   // replayed (key, index, then the eight positions: two dependent loads per batch instead of per candidate).
   bool done = false;
@@ -1395,7 +1395,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
         if (resample_voxel<S>(d, st, base, stv)) {
           resampled = true;
           changed = true;
-          atomicAdd(&sc.cnt->n_resampled, 1u);
+          n_resamp++;
         } else {
           checked = true;
           break;
@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
         if (resample_voxel<S>(d, st, base, stv)) {
           resampled = true;
           changed = true;
-          atomicAdd(&sc.cnt->n_resampled, 1u);
+          n_resamp++;
         } else {
           checked = true;
         }
@@ -1416,7 +1416,9 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
       if (!changed && (resampled || checked)) done = true;
     }
   }
-  if (n_success) atomicAdd(&sc.cnt->n_birth_success, n_success);
+  // same-address atomics retire one at a time: counters every wave bumps are sharded by block
+  if (n_success) atomicAdd(&sc.cnt->birth_shard[blockIdx.x & (VIS_SHARDS - 1)], n_success);
+  if (n_resamp) atomicAdd(&sc.cnt->resample_shard[blockIdx.x & (VIS_SHARDS - 1)], n_resamp);
 }
 
 // ------------------------------------------------------------------------------------ N1

@@ -92,6 +92,8 @@ struct Counters {
   uint32_t vis_shard[64];
   uint32_t fv_shard[64];
   uint32_t heavy_shard[64];  // weight-update pass 1: pixels handed to the row-parallel kernel
+  uint32_t birth_shard[64];     // successful births
+  uint32_t resample_shard[64];  // voxels resampled
 };
 constexpr uint32_t VIS_SHARDS = 64;
 constexpr uint32_t OWNER_CHUNK = 4096;  // slots per owner_flag byte (= slots per block of the move sweep)
