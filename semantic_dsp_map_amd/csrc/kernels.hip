@@ -104,9 +104,9 @@ __device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_
   float wv[S];
   uint16_t trk[S];
   uint8_t lab[S];
-  load_vec(wv, st.w + base);
-  load_vec(trk, st.track + base);
-  load_vec(lab, st.label + base);
+  load_vec(wv, st.w + base * REC_W);
+  load_vec(trk, st.track + base * REC_TRACK);
+  load_vec(lab, st.label + base * REC_LABEL);
 
   float weight_sum = 0.f, guessed = 0.f;
   bool vote[S];
@@ -169,7 +169,7 @@ __device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_
   else if (guessed >= SDM_OCC_INIT_WEIGHT) out.occ = 2;
   else out.occ = 0;
   store_result(st.res + lv, out);
-  if (dirty_w) store_vec(st.w + base, wv);
+  if (dirty_w) store_vec(st.w + base * REC_W, wv);
   if (dirty_s) store_vec(st.status + base, stv);
 }
 
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
     const size_t base = (size_t)lv * S;
     uint16_t ts1[S];
     uint8_t st1[S];
-    load_vec(ts1, st.ts + base);
+    load_vec(ts1, st.ts + base * REC_TS);
     load_vec(st1, st.status + base);  // second touch: L2
     uint32_t rx, ry, rz;
     voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
@@ -258,11 +258,11 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
 // layout: the time particle is slot 0 of the voxel, buffer.h:57-79)
 __global__ __launch_bounds__(TPB) void k_vts_to_slot0(Dims d, State st) {
   uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lv < d.v_count) st.ts[(size_t)lv * d.S] = st.vts[lv];
+  if (lv < d.v_count) st.ts[(size_t)lv * d.S * REC_TS] = st.vts[lv];
 }
 __global__ __launch_bounds__(TPB) void k_vts_from_slot0(Dims d, State st) {
   uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lv < d.v_count) st.vts[lv] = st.ts[(size_t)lv * d.S];
+  if (lv < d.v_count) st.vts[lv] = st.ts[(size_t)lv * d.S * REC_TS];
 }
 
 // ------------------------------------------------------------------------------------ A6
@@ -631,7 +631,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   }
   const uint32_t smax = stamp_max(st, rx, ry, rz);
   uint16_t tsv[S];
-  load_vec(tsv, st.ts + base);
+  load_vec(tsv, st.ts + base * REC_TS);
   bool dirty = false, observed = false;
   int valid_n = 0;
   bool live[S];
@@ -669,7 +669,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     if (!live[i] || pixv[i] < 0) continue;
     const float dpt = dptv[i];
     if (dpt > d.dmax) {  // nothing measurable along this ray: free (operations.h:1389-1395)
-      st.w[base + i] = SDM_OCC_INIT_WEIGHT;
+      st.w[base * REC_W + i] = SDM_OCC_INIT_WEIGHT;
       observed = true;
       continue;
     }
@@ -861,8 +861,8 @@ __global__ __launch_bounds__(TPB) void k_bin_sort_gather(Dims d, State st, Scrat
   for (uint32_t i = 0; i < n; ++i) {
     size_t li = (size_t)a[i] - slot_base;
     float4 q = st.pos4[li];
-    sc.vp4[s + i] = make_float4(q.x, q.y, q.z, st.w[li]);
-    sc.vtf[s + i] = (uint32_t)st.track[li] | ((__float_as_uint(q.w) & 0xffu) << 16);
+    sc.vp4[s + i] = make_float4(q.x, q.y, q.z, st.w[rec_index(li, d.p_n, REC_W)]);
+    sc.vtf[s + i] = (uint32_t)st.track[rec_index(li, d.p_n, REC_TRACK)] | ((__float_as_uint(q.w) & 0xffu) << 16);
     sc.vpix[s + i] = p;
   }
 }
@@ -1183,9 +1183,9 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Frame f, F
       }
       const size_t li = (size_t)sc.bin_idx[k] - slot_base;
       const uint32_t fc = (sc.vtf[k] >> 16) & 0xffu;
-      st.w[li] = sc.vp4[k].w * (a * flt.p_detect + 1.f - flt.p_detect);
+      st.w[rec_index(li, d.p_n, REC_W)] = sc.vp4[k].w * (a * flt.p_detect + 1.f - flt.p_detect);
       st.status[li] = ST_UPDATED;
-      st.ts[li] = (uint16_t)f.gts;
+      st.ts[rec_index(li, d.p_n, REC_TS)] = (uint16_t)f.gts;
       if (!flt.independent) {
         uint32_t nf = right_id ? 0u : (fc < 5u ? fc + 1u : fc);
         if (nf != fc) {
@@ -1271,7 +1271,7 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
   float weight_sum = 0.f;
   uint32_t updated = 0;
   float wv[S];
-  load_vec(wv, st.w + base);
+  load_vec(wv, st.w + base * REC_W);
 #pragma unroll
   for (int i = 1; i < S; ++i)
     if (stv[i] == ST_UPDATED) {
@@ -1286,7 +1286,7 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
       if (stv[i] == ST_UPDATED) {
         stv[i] = ST_INVALID;
         st.status[base + i] = ST_INVALID;
-        if (st.owner[base + i] == st.track[base + i]) st.owner[base + i] = OWNER_NONE;  // removeParticleFromObj
+        if (st.owner[base + i] == st.track[base * REC_TRACK + i]) st.owner[base + i] = OWNER_NONE;  // removeParticleFromObj
       }
     return true;
   }
@@ -1300,9 +1300,9 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
       if (run < thr) {
         stv[i] = ST_INVALID;
         st.status[base + i] = ST_INVALID;
-        if (st.owner[base + i] == st.track[base + i]) st.owner[base + i] = OWNER_NONE;
+        if (st.owner[base + i] == st.track[base * REC_TRACK + i]) st.owner[base + i] = OWNER_NONE;
       } else {
-        st.w[base + i] = wpp;
+        st.w[base * REC_W + i] = wpp;
         thr += wpp;
         while (run > thr) thr += wpp;
       }
@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
   uint8_t stv[S];
   uint16_t tsv[S];
   load_vec(stv, st.status + base);
-  load_vec(tsv, st.ts + base);
+  load_vec(tsv, st.ts + base * REC_TS);
   bool resampled = false, checked = false;
   uint32_t n_success = 0, n_resamp = 0;
   // The candidates of a voxel are consecutive in the sorted list; eight at a time are fetched before the first is
@@ -1370,10 +1370,10 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
         if (slot > 0) {
           // addNewParticleWithSemantics (operations.h:171-184)
           st.pos4[base + slot] = make_float4(bp.x, bp.y, bp.z, __uint_as_float(0u));
-          st.w[base + slot] = SDM_OCC_INIT_WEIGHT;
-          st.ts[base + slot] = (uint16_t)f.gts;
-          st.track[base + slot] = track;
-          st.label[base + slot] = label;
+          st.w[base * REC_W + slot] = SDM_OCC_INIT_WEIGHT;
+          st.ts[base * REC_TS + slot] = (uint16_t)f.gts;
+          st.track[base * REC_TRACK + slot] = track;
+          st.label[base * REC_LABEL + slot] = label;
           st.status[base + slot] = ST_REGULAR_BORN;
           if ((int)track <= d.max_movable) {  // addParticleToObj
             st.owner[base + slot] = track;
@@ -1505,7 +1505,7 @@ __global__ __launch_bounds__(TPB) void k_count_live(Dims d, State st, unsigned l
     uint32_t smax = stamp_max(st, rx, ry, rz);
     size_t base = (size_t)lv * d.S;
     for (uint32_t i = 1; i < d.S; ++i)
-      if (st.status[base + i] != ST_INVALID && (uint32_t)st.ts[base + i] >= smax) c++;
+      if (st.status[base + i] != ST_INVALID && (uint32_t)st.ts[base * REC_TS + i] >= smax) c++;
     // bits 36..: voxels that pass isVoxelValid and hold a live slot (the ones the sweep fetches in full)
     const uint32_t t0 = st.vts[lv];
     if (c && t0 != 0 && t0 >= smax) cv = 1;
@@ -1593,11 +1593,9 @@ inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb
 void launch_clear(const Dims &d, const State &st, hipStream_t s) {
   size_t n = (size_t)d.v_count * d.S;
   hipMemsetAsync(st.pos4, 0, n * sizeof(float4), s);
-  hipMemsetAsync(st.w, 0, n * sizeof(float), s);
-  hipMemsetAsync(st.ts, 0, n * sizeof(uint16_t), s);
+  hipMemsetAsync(st.rec, 0, n * REC_BYTES_PER_SLOT, s);
   hipMemsetAsync(st.vts, 0, (size_t)d.v_count * sizeof(uint16_t), s);
-  hipMemsetAsync(st.track, 0, n * sizeof(uint16_t), s);
-  hipMemsetAsync(st.label, 0, n, s);
+
   hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
   hipMemsetAsync(st.owner_flag, 0, (n + OWNER_CHUNK - 1) / OWNER_CHUNK, s);
   hipMemsetAsync(st.res, 0, (size_t)d.v_count * sizeof(sdm_voxel_result), s);
@@ -1696,6 +1694,36 @@ void launch_labeled_cloud(const Dims &d, const CloudArgsHost &h, const float *de
   __builtin_memcpy(&a, &h, sizeof(a));
   hipLaunchKernelGGL(k_labeled_cloud, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, a, depth, static_mask, label_to_inst,
                      obj_masks, cloud);
+}
+
+// dense slot-order arrays <-> per-voxel records (state export / import)
+__global__ __launch_bounds__(TPB) void k_rec_pack(Dims d, State st, const float *__restrict__ w, const uint16_t *__restrict__ ts,
+                                                  const uint16_t *__restrict__ track, const uint8_t *__restrict__ label, size_t n) {
+  size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= n) return;
+  st.w[rec_index(li, d.p_n, REC_W)] = w[li];
+  st.ts[rec_index(li, d.p_n, REC_TS)] = ts[li];
+  st.track[rec_index(li, d.p_n, REC_TRACK)] = track[li];
+  st.label[rec_index(li, d.p_n, REC_LABEL)] = label[li];
+}
+__global__ __launch_bounds__(TPB) void k_rec_unpack(Dims d, State st, float *__restrict__ w, uint16_t *__restrict__ ts,
+                                                    uint16_t *__restrict__ track, uint8_t *__restrict__ label, size_t n) {
+  size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= n) return;
+  w[li] = st.w[rec_index(li, d.p_n, REC_W)];
+  ts[li] = st.ts[rec_index(li, d.p_n, REC_TS)];
+  track[li] = st.track[rec_index(li, d.p_n, REC_TRACK)];
+  label[li] = st.label[rec_index(li, d.p_n, REC_LABEL)];
+}
+
+void launch_rec_pack(const Dims &d, const State &st, const float *w, const uint16_t *ts, const uint16_t *track,
+                     const uint8_t *label, hipStream_t s) {
+  const size_t n = (size_t)d.v_count * d.S;
+  hipLaunchKernelGGL(k_rec_pack, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, w, ts, track, label, n);
+}
+void launch_rec_unpack(const Dims &d, const State &st, float *w, uint16_t *ts, uint16_t *track, uint8_t *label, hipStream_t s) {
+  const size_t n = (size_t)d.v_count * d.S;
+  hipLaunchKernelGGL(k_rec_unpack, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, w, ts, track, label, n);
 }
 
 void launch_vts_sync(const Dims &d, const State &st, int to_slot0, hipStream_t s) {

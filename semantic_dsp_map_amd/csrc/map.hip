@@ -464,11 +464,12 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
 #define A(ptr, n) \
   if ((rc = alloc_tracked(m, &(ptr), (n))) != SDM_OK) return rc;
   A(m->st.pos4, n_slots);
-  A(m->st.w, n_slots);
-  A(m->st.ts, n_slots);
+  A(m->st.rec, n_slots * REC_BYTES_PER_SLOT);  // one record per voxel: w | ts | track | label (sdm_internal.h)
+  m->st.w = reinterpret_cast<float *>(m->st.rec);
+  m->st.ts = reinterpret_cast<uint16_t *>(m->st.rec + 4 * (size_t)d.S);
+  m->st.track = reinterpret_cast<uint16_t *>(m->st.rec + 6 * (size_t)d.S);
+  m->st.label = reinterpret_cast<uint8_t *>(m->st.rec + 8 * (size_t)d.S);
   A(m->st.vts, d.v_count);
-  A(m->st.track, n_slots);
-  A(m->st.label, n_slots);
   A(m->st.status, n_slots);
   A(m->st.owner, n_slots);
   A(m->st.owner_flag, (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK);
@@ -1298,13 +1299,26 @@ sdm_status sdm_dump_state(sdm_map *m, float *px, float *py, float *pz, float *w,
     (void)hipFree(tz);
     (void)hipFree(tf);
   }
-  if (w) HIP_TRY(hipMemcpyAsync(w, m->st.w, n * 4, hipMemcpyDeviceToHost, s));
-  if (ts) {
-    launch_vts_sync(m->d, m->st, 1, s);
-    HIP_TRY(hipMemcpyAsync(ts, m->st.ts, n * 2, hipMemcpyDeviceToHost, s));
+  if (w || ts || track || label) {  // record fields -> the reference's slot order, through dense temporaries
+    float *tw;
+    uint16_t *tts, *ttr;
+    uint8_t *tl;
+    HIP_TRY(dev_alloc(&tw, n));
+    HIP_TRY(dev_alloc(&tts, n));
+    HIP_TRY(dev_alloc(&ttr, n));
+    HIP_TRY(dev_alloc(&tl, n));
+    launch_vts_sync(m->d, m->st, 1, s);  // slot 0 of the exported stamp row carries the voxel stamp
+    launch_rec_unpack(m->d, m->st, tw, tts, ttr, tl, s);
+    if (w) HIP_TRY(hipMemcpyAsync(w, tw, n * 4, hipMemcpyDeviceToHost, s));
+    if (ts) HIP_TRY(hipMemcpyAsync(ts, tts, n * 2, hipMemcpyDeviceToHost, s));
+    if (track) HIP_TRY(hipMemcpyAsync(track, ttr, n * 2, hipMemcpyDeviceToHost, s));
+    if (label) HIP_TRY(hipMemcpyAsync(label, tl, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(tw);
+    (void)hipFree(tts);
+    (void)hipFree(ttr);
+    (void)hipFree(tl);
   }
-  if (track) HIP_TRY(hipMemcpyAsync(track, m->st.track, n * 2, hipMemcpyDeviceToHost, s));
-  if (label) HIP_TRY(hipMemcpyAsync(label, m->st.label, n, hipMemcpyDeviceToHost, s));
   if (status) HIP_TRY(hipMemcpyAsync(status, m->st.status, n, hipMemcpyDeviceToHost, s));
   if (owner) HIP_TRY(hipMemcpyAsync(owner, m->st.owner, n * 2, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1329,11 +1343,26 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
   HIP_TRY(hipMemcpyAsync(tz, pz, n * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(tf, forget, n, hipMemcpyHostToDevice, s));
   launch_pack_pos4(m->st.pos4, tx, ty, tz, tf, n, s);
-  HIP_TRY(hipMemcpyAsync(m->st.w, w, n * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(m->st.ts, ts, n * 2, hipMemcpyHostToDevice, s));
-  launch_vts_sync(m->d, m->st, 0, s);
-  HIP_TRY(hipMemcpyAsync(m->st.track, track, n * 2, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(m->st.label, label, n, hipMemcpyHostToDevice, s));
+  {
+    float *tw;
+    uint16_t *tts, *ttr;
+    uint8_t *tl;
+    HIP_TRY(dev_alloc(&tw, n));
+    HIP_TRY(dev_alloc(&tts, n));
+    HIP_TRY(dev_alloc(&ttr, n));
+    HIP_TRY(dev_alloc(&tl, n));
+    HIP_TRY(hipMemcpyAsync(tw, w, n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(tts, ts, n * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ttr, track, n * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(tl, label, n, hipMemcpyHostToDevice, s));
+    launch_rec_pack(m->d, m->st, tw, tts, ttr, tl, s);
+    launch_vts_sync(m->d, m->st, 0, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(tw);
+    (void)hipFree(tts);
+    (void)hipFree(ttr);
+    (void)hipFree(tl);
+  }
   HIP_TRY(hipMemcpyAsync(m->st.status, status, n, hipMemcpyHostToDevice, s));
   if (owner) HIP_TRY(hipMemcpyAsync(m->st.owner, owner, n * 2, hipMemcpyHostToDevice, s));
   else HIP_TRY(hipMemsetAsync(m->st.owner, 0xFF, n * 2, s));

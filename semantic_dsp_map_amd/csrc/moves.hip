@@ -185,9 +185,9 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
   nx = nx + st.noise[(draw + 1) % flt.noise_n];
   ny = ny + st.noise[(draw + 2) % flt.noise_n];
   nz = nz + st.noise[(draw + 3) % flt.noise_n];
-  const float pw = st.w[li];
-  const uint16_t pts = st.ts[li], ptrack = st.track[li];
-  const uint8_t plabel = st.label[li], pstatus = st.status[li];
+  const float pw = st.w[rec_index(li, d.p_n, REC_W)];
+  const uint16_t pts = st.ts[rec_index(li, d.p_n, REC_TS)], ptrack = st.track[rec_index(li, d.p_n, REC_TRACK)];
+  const uint8_t plabel = st.label[rec_index(li, d.p_n, REC_LABEL)], pstatus = st.status[li];
   const uint16_t powner = ms.track[obj];
   st.status[li] = ST_INVALID;  // deleteParticleByIndex
   st.owner[li] = OWNER_NONE;   // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
     uint8_t stv[S];
     uint16_t tsv[S];
     __builtin_memcpy(stv, st.status + base, S);
-    __builtin_memcpy(tsv, st.ts + base, 2 * S);
+    __builtin_memcpy(tsv, st.ts + base * REC_TS, 2 * S);
     uint32_t n_ok = 0;
     bool more = true, full = false;
     long long last = -1;  // largest rank replayed so far
@@ -410,10 +410,10 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
         const uint8_t cs = sc.mv_status[e];
         const uint16_t cts = sc.mv_ts[e];
         st.pos4[base + slot] = sc.mv_pos[e];
-        st.w[base + slot] = sc.mv_w[e];
-        st.ts[base + slot] = cts;
-        st.track[base + slot] = sc.mv_track[e];
-        st.label[base + slot] = sc.mv_label[e];
+        st.w[base * REC_W + slot] = sc.mv_w[e];
+        st.ts[base * REC_TS + slot] = cts;
+        st.track[base * REC_TRACK + slot] = sc.mv_track[e];
+        st.label[base * REC_LABEL + slot] = sc.mv_label[e];
         st.status[base + slot] = cs;
         st.owner[base + slot] = sc.mv_owner[e];  // new index joins the object's set
         st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;

@@ -110,8 +110,17 @@ struct Cursors {
   int32_t move_cursor;
 };
 
+// Slot attributes that are only touched where a particle lives - weight, time stamp, track id, label - share one
+// record of 16*S bytes per voxel (128 B at S = 8: one cache line): [w: 4S | ts: 2S | track: 2S | label: S | pad 7S].
+// State::w / ts / track / label point at the first voxel's field; the index of slot i of local voxel lv is
+//   w[lv*S*REC_W + i], ts[lv*S*REC_TS + i], track[lv*S*REC_TRACK + i], label[lv*S*REC_LABEL + i].
+// Status, the per-voxel stamp, owner and position are streamed by whole-map sweeps and stay dense arrays.
+constexpr size_t REC_BYTES_PER_SLOT = 16;
+constexpr size_t REC_W = 4, REC_TS = 8, REC_TRACK = 8, REC_LABEL = 16;
+
 struct State {
   float4 *pos4 = nullptr;
+  unsigned char *rec = nullptr;  // v_count records of 16*S bytes
   float *w = nullptr;
   uint16_t *ts = nullptr;
   // observation stamp of every voxel = time stamp of its slot-0 "time particle" (operations.h:824-837), kept as a
@@ -129,6 +138,11 @@ struct State {
   float *pdf = nullptr;
   float *noise = nullptr;
 };
+
+// field index of global-slot-order index li = lv << p_n | slot (see the record layout above)
+__host__ __device__ __forceinline__ size_t rec_index(size_t li, int p_n, size_t mult) {
+  return ((li >> p_n) << p_n) * mult + (li & (((size_t)1 << p_n) - 1));
+}
 
 // ---- device helpers ------------------------------------------------------------------
 // PINNED: 4x4 row-major times [x y z 1] evaluated ((m0*x + m1*y) + m2*z) + m3
