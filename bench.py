@@ -132,11 +132,10 @@ def main():
     sweep_ms = m.time_occupancy_sweep(iters=50)
     ms_per_step = dt * 1e3 / args.steps
     value = V / (dt / args.steps) / 1e6  # Mvoxels / s, whole map (all shards)
-    # Algorithmic bytes of one sweep: every voxel costs its 2-byte observation stamp, its status row (S)
-    # and the 8-byte result; the slot stamp, weight, track and label rows (9S) are needed only for observed voxels that
-    # hold a live slot.  (SURVEY.md 8d's dense figure, 80 B/voxel at S = 8, is the case "every voxel holds a
-    # particle".)
-    alg_bytes = (V // world) * (2 + S + 8) + live_vox_local * 9 * S
+    # Algorithmic bytes of one sweep: every voxel costs its 2-byte observation stamp, 1-byte "something
+    # here" flag and the 8-byte result; status row and record (S + 9S) are needed only for observed voxels that hold
+    # a live slot.  (SURVEY.md 8d's dense figure, 80 B/voxel at S = 8, is the case "every voxel holds a particle".)
+    alg_bytes = (V // world) * (2 + 1 + 8) + live_vox_local * 10 * S
     achieved = alg_bytes / (sweep_ms * 1e-3)
     roofline = {"kernel": "k_occupancy<%d>" % S, "bound": "hbm", "achieved": round(achieved / 1e9, 1),
                 "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BPS, 4),

@@ -96,17 +96,12 @@ __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__
 // (calculateWeightAndSemanticsInVoxel, operations.h:390-448).
 template <int S>
 __device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_threshold, uint32_t lv, uint32_t smax,
-                                                     const uint16_t (&tsv)[S], uint8_t (&stv)[S]) {
+                                                     const uint16_t (&tsv)[S], uint8_t (&stv)[S], float (&wv)[S],
+                                                     const uint16_t (&trk)[S], const uint8_t (&lab)[S]) {
   const size_t base = (size_t)lv * S;
   sdm_voxel_result out;
   out.track = 0;
   out.label = 0;
-  float wv[S];
-  uint16_t trk[S];
-  uint8_t lab[S];
-  load_vec(wv, st.w + base * REC_W);
-  load_vec(trk, st.track + base * REC_TRACK);
-  load_vec(lab, st.label + base * REC_LABEL);
 
   float weight_sum = 0.f, guessed = 0.f;
   bool vote[S];
@@ -170,14 +165,20 @@ __device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_
   else out.occ = 0;
   store_result(st.res + lv, out);
   if (dirty_w) store_vec(st.w + base * REC_W, wv);
-  if (dirty_s) store_vec(st.status + base, stv);
+  if (dirty_s) {
+    store_vec(st.status + base, stv);
+    bool any = false;  // the cull may have emptied the voxel
+#pragma unroll
+    for (int i = 1; i < S; ++i) any = any || stv[i] != ST_INVALID;
+    if (!any) st.vflag[lv] = 0;
+  }
 }
 
-// Two phases per workgroup of TPB * OCC_VPT voxels.  Phase 1 streams the voxel stamps and the status rows (OCC_VPT
-// voxels per thread, everything requested before the first value is looked at) and finishes every voxel that is not
-// observed or whose slots are all INVALID - the vast majority in a map that is mostly free or unseen space.  The
-// others are listed in LDS and handled in phase 2 with all lanes busy: stamp row (stale slots), then weight, track
-// and label rows, vote, write-backs.  (Draining the list in a separate kernel was measured: the scattered row fetches
+// Two phases per workgroup of TPB * OCC_VPT voxels.  Phase 1 streams the voxel stamps and the "something here" bytes
+// (OCC_VPT voxels per thread, everything requested before the first value is looked at) and finishes every voxel that
+// is not observed or empty - the vast majority in a map that is mostly free or unseen space - from 3 bytes.  The others
+// are listed in LDS and handled in phase 2 with all lanes busy: status row, the voxel's record (slot stamps, weights,
+// tracks, labels), vote, write-backs.  (Draining the list in a separate kernel was measured: the scattered fetches
 // then take longer than the whole fused sweep - here they ride along with the stream.)
 constexpr int OCC_VPT = 4;
 
@@ -187,15 +188,13 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
   __shared__ uint32_t n_live;
   const uint32_t blk0 = blockIdx.x * (TPB * OCC_VPT);
   if (threadIdx.x == 0) n_live = 0;
-  uint32_t t0v[OCC_VPT];
-  uint8_t stv[OCC_VPT][S];
-  uint32_t smax[OCC_VPT];
+  uint32_t t0v[OCC_VPT], flag[OCC_VPT], smax[OCC_VPT];
 #pragma unroll
   for (int u = 0; u < OCC_VPT; ++u) {
     const uint32_t lv = blk0 + u * TPB + threadIdx.x;
     if (lv >= d.v_count) continue;
     t0v[u] = st.vts[lv];
-    load_vec(stv[u], st.status + (size_t)lv * S);
+    flag[u] = st.vflag[lv];
     uint32_t rx, ry, rz;
     voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
     smax[u] = stamp_max(st, rx, ry, rz);
@@ -214,10 +213,7 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
       store_result(st.res + lv, out);
       continue;
     }
-    bool any = false;
-#pragma unroll
-    for (int i = 1; i < S; ++i) any = any || stv[u][i] != ST_INVALID;
-    if (!any) {  // nothing contributes: weight sum 0, no vote, nothing to clamp or cull
+    if (!flag[u]) {  // every slot INVALID: weight sum 0, no vote, nothing to clamp or cull
       out.wsum = 0.f;
       out.occ = 0.f > occ_threshold ? 1 : 0;
       store_result(st.res + lv, out);
@@ -230,27 +226,34 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
   for (uint32_t k = threadIdx.x; k < nl; k += TPB) {
     const uint32_t lv = blk0 + live_list[k];
     const size_t base = (size_t)lv * S;
-    uint16_t ts1[S];
-    uint8_t st1[S];
+    uint16_t ts1[S], trk[S];
+    uint8_t st1[S], lab[S];
+    float wv[S];
+    load_vec(st1, st.status + base);
+    load_vec(wv, st.w + base * REC_W);  // the whole record (one line at S = 8) in one go
     load_vec(ts1, st.ts + base * REC_TS);
-    load_vec(st1, st.status + base);  // second touch: L2
+    load_vec(trk, st.track + base * REC_TRACK);
+    load_vec(lab, st.label + base * REC_LABEL);
     uint32_t rx, ry, rz;
     voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
     const uint32_t sm = stamp_max(st, rx, ry, rz);
-    bool any_live = false;
+    bool any_live = false, any = false;
 #pragma unroll
-    for (int i = 1; i < S; ++i)  // isParticleVacant, operations.h:810-816
+    for (int i = 1; i < S; ++i) {  // isParticleVacant, operations.h:810-816
+      any = any || st1[i] != ST_INVALID;
       any_live = any_live || !(st1[i] == ST_INVALID || (uint32_t)ts1[i] < sm);
-    if (!any_live) {  // only stale slots
+    }
+    if (!any_live) {  // deleted since it was flagged, or only stale slots
       sdm_voxel_result out;
       out.track = 0;
       out.label = 0;
       out.wsum = 0.f;
       out.occ = 0.f > occ_threshold ? 1 : 0;
       store_result(st.res + lv, out);
+      if (!any) st.vflag[lv] = 0;
       continue;
     }
-    occupancy_live_voxel<S>(st, occ_threshold, lv, sm, ts1, st1);
+    occupancy_live_voxel<S>(st, occ_threshold, lv, sm, ts1, st1, wv, trk, lab);
   }
 }
 
@@ -262,7 +265,11 @@ __global__ __launch_bounds__(TPB) void k_vts_to_slot0(Dims d, State st) {
 }
 __global__ __launch_bounds__(TPB) void k_vts_from_slot0(Dims d, State st) {
   uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lv < d.v_count) st.vts[lv] = st.ts[(size_t)lv * d.S * REC_TS];
+  if (lv >= d.v_count) return;
+  st.vts[lv] = st.ts[(size_t)lv * d.S * REC_TS];
+  bool any = false;
+  for (uint32_t i = 1; i < d.S; ++i) any = any || st.status[(size_t)lv * d.S + i] != ST_INVALID;
+  st.vflag[lv] = any ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------ A6
@@ -1417,7 +1424,10 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
     }
   }
   // same-address atomics retire one at a time: counters every wave bumps are sharded by block
-  if (n_success) atomicAdd(&sc.cnt->birth_shard[blockIdx.x & (VIS_SHARDS - 1)], n_success);
+  if (n_success) {
+    st.vflag[v - d.v_begin] = 1;
+    atomicAdd(&sc.cnt->birth_shard[blockIdx.x & (VIS_SHARDS - 1)], n_success);
+  }
   if (n_resamp) atomicAdd(&sc.cnt->resample_shard[blockIdx.x & (VIS_SHARDS - 1)], n_resamp);
 }
 
@@ -1595,6 +1605,7 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s) {
   hipMemsetAsync(st.pos4, 0, n * sizeof(float4), s);
   hipMemsetAsync(st.rec, 0, n * REC_BYTES_PER_SLOT, s);
   hipMemsetAsync(st.vts, 0, (size_t)d.v_count * sizeof(uint16_t), s);
+  hipMemsetAsync(st.vflag, 0, (size_t)d.v_count, s);
 
   hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
   hipMemsetAsync(st.owner_flag, 0, (n + OWNER_CHUNK - 1) / OWNER_CHUNK, s);

@@ -470,6 +470,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->st.track = reinterpret_cast<uint16_t *>(m->st.rec + 6 * (size_t)d.S);
   m->st.label = reinterpret_cast<uint8_t *>(m->st.rec + 8 * (size_t)d.S);
   A(m->st.vts, d.v_count);
+  A(m->st.vflag, d.v_count);
   A(m->st.status, n_slots);
   A(m->st.owner, n_slots);
   A(m->st.owner_flag, (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK);
@@ -1356,7 +1357,6 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
     HIP_TRY(hipMemcpyAsync(ttr, track, n * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(tl, label, n, hipMemcpyHostToDevice, s));
     launch_rec_pack(m->d, m->st, tw, tts, ttr, tl, s);
-    launch_vts_sync(m->d, m->st, 0, s);
     HIP_TRY(hipStreamSynchronize(s));
     (void)hipFree(tw);
     (void)hipFree(tts);
@@ -1367,6 +1367,7 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
   if (owner) HIP_TRY(hipMemcpyAsync(m->st.owner, owner, n * 2, hipMemcpyHostToDevice, s));
   else HIP_TRY(hipMemsetAsync(m->st.owner, 0xFF, n * 2, s));
   launch_owner_flags(m->d, m->st, s);
+  launch_vts_sync(m->d, m->st, 0, s);  // voxel stamps from slot 0 of the stamp rows, "something here" flags from the status rows
   HIP_TRY(hipStreamSynchronize(s));
   (void)hipFree(tx);
   (void)hipFree(ty);

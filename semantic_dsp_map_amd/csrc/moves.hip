@@ -426,7 +426,10 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
         ++n_ok;
       }
     }
-    if (n_ok) atomicAdd(&sc.cnt->n_move_reinserted, n_ok);
+    if (n_ok) {
+      st.vflag[lv] = 1;
+      atomicAdd(&sc.cnt->n_move_reinserted, n_ok);
+    }
   }
 }
 

@@ -126,6 +126,10 @@ struct State {
   // observation stamp of every voxel = time stamp of its slot-0 "time particle" (operations.h:824-837), kept as a
   // dense array of its own: the sweeps read it for every voxel, the slot rows only where something lives
   uint16_t *vts = nullptr;
+  // one byte per voxel: 0 = every slot is INVALID.  Set by whatever inserts a particle (births, re-inserted moved
+  // copies, state import), refreshed exactly by the occupancy sweep; deletions leave it set (conservative).  Lets the
+  // sweep decide "nothing here" from 3 bytes per voxel without touching the status row.
+  uint8_t *vflag = nullptr;
   uint16_t *track = nullptr;
   uint8_t *label = nullptr;
   uint8_t *status = nullptr;
