@@ -312,6 +312,8 @@ sdm_status sdm_get_extrinsic(sdm_map *m, float *out16);
 /* ---- timing of single kernels for bench.py's roofline line: runs the occupancy sweep
  * `iters` times on the map's stream bracketed by HIP events, returns average ms per launch. */
 sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms);
+/* bench hook: overwrite the map with the dense case of SURVEY.md 8(d) (every slot live, every voxel observed) */
+sdm_status sdm_debug_fill_dense(sdm_map *m);
 
 /* ---- device-side unit tests of the hand-written primitives (tests/test_primitives_gpu.py) */
 sdm_status sdm_test_scan(const uint32_t *in, uint32_t *out, int64_t n);

@@ -137,6 +137,7 @@ def load_library():
         "sdm_get_bins": [vp, vp, i64, C.POINTER(i64)],
         "sdm_get_extrinsic": [vp, vp],
         "sdm_time_occupancy_sweep": [vp, i32, C.POINTER(C.c_float)],
+        "sdm_debug_fill_dense": [vp],
         "sdm_test_scan": [vp, vp, i64],
         "sdm_test_sort_pairs": [vp, vp, vp, vp, i64, i32],
     }
@@ -452,6 +453,9 @@ class SdmMap:
         out = np.empty(16, np.float32)
         _check(self.L, self.L.sdm_get_extrinsic(self.h, _ptr(out)), "sdm_get_extrinsic")
         return out.reshape(4, 4)
+
+    def fill_dense(self):
+        _check(self.L, self.L.sdm_debug_fill_dense(self.h), "sdm_debug_fill_dense")
 
     def time_occupancy_sweep(self, iters=20):
         ms = C.c_float()

@@ -1737,6 +1737,34 @@ void launch_rec_unpack(const Dims &d, const State &st, float *w, uint16_t *ts, u
   hipLaunchKernelGGL(k_rec_unpack, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, w, ts, track, label, n);
 }
 
+// bench hook: every slot of every voxel holds a live particle with pseudo-random weight / track / label, every voxel is
+// observed - the dense case of SURVEY.md 8(d) for the occupancy sweep.
+__global__ __launch_bounds__(TPB) void k_fill_dense(Dims d, State st, uint32_t stamp) {
+  size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)d.v_count * d.S;
+  if (li >= n) return;
+  const uint32_t i = (uint32_t)(li & (d.S - 1));
+  const size_t lv = li >> d.p_n;
+  uint32_t h = (uint32_t)li * 2654435761u;
+  h ^= h >> 15;
+  h *= 2246822519u;
+  h ^= h >> 13;
+  st.status[li] = i == 0 ? (uint8_t)ST_TIMEPTC : (uint8_t)((h & 7u) == 0 ? ST_REGULAR_BORN : ST_UPDATED);
+  st.w[rec_index(li, d.p_n, REC_W)] = 0.06f + (float)(h >> 20) * (0.3f / 4096.f);
+  st.ts[rec_index(li, d.p_n, REC_TS)] = (uint16_t)stamp;
+  st.track[rec_index(li, d.p_n, REC_TRACK)] = (uint16_t)(65524u + ((h >> 8) & 7u));
+  st.label[rec_index(li, d.p_n, REC_LABEL)] = (uint8_t)(5u + ((h >> 8) & 7u));
+  st.owner[li] = OWNER_NONE;
+  if (i == 0) {
+    st.vts[lv] = (uint16_t)stamp;
+    st.vflag[lv] = 1;
+  }
+}
+void launch_fill_dense(const Dims &d, const State &st, uint32_t stamp, hipStream_t s) {
+  const size_t n = (size_t)d.v_count * d.S;
+  hipLaunchKernelGGL(k_fill_dense, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, stamp);
+}
+
 void launch_vts_sync(const Dims &d, const State &st, int to_slot0, hipStream_t s) {
   if (to_slot0) hipLaunchKernelGGL(k_vts_to_slot0, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st);
   else hipLaunchKernelGGL(k_vts_from_slot0, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st);

@@ -532,13 +532,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.mv_cnt, mv_cnt_n);
   A(sc.mv_list, 8192);
   A(sc.mv_nlist, 4);
-  A(sc.mv_pos, sc.cap_move);
-  A(sc.mv_w, sc.cap_move);
-  A(sc.mv_ts, sc.cap_move);
-  A(sc.mv_track, sc.cap_move);
-  A(sc.mv_owner, sc.cap_move);
-  A(sc.mv_label, sc.cap_move);
-  A(sc.mv_status, sc.cap_move);
+  A(sc.mv_copy, sc.cap_move);
   A(sc.track_to_obj, 65536);
   HIP_TRY(hipMemsetAsync(sc.track_to_obj, 0xFF, 65536, m->stream));
   size_t scan_need = std::max({scan_scratch_elems(hw + 1), scan_scratch_elems(mv_cnt_n), scan_scratch_elems((size_t)d.v_count + 1)});
@@ -1425,6 +1419,15 @@ sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms) {
   *avg_ms = ms / iters;
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
+  return SDM_OK;
+}
+
+// Bench hook: overwrite the map with the dense case (every slot live, every voxel observed).
+sdm_status sdm_debug_fill_dense(sdm_map *m) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  launch_fill_dense(m->d, m->st, m->global_time_stamp ? m->global_time_stamp : 1u, m->stream);
+  HIP_TRY(hipStreamSynchronize(m->stream));
   return SDM_OK;
 }
 

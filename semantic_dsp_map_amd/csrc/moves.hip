@@ -196,13 +196,19 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
   if (v == INVALID_INDEX) return;  // left the map: dropped (operations.h:799-802)
   if (rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) {
     if (e >= sc.cap_move) return;
-    sc.mv_pos[e] = make_float4(nx, ny, nz, p.w);
-    sc.mv_w[e] = pw;
-    sc.mv_ts[e] = pts;
-    sc.mv_track[e] = ptrack;
-    sc.mv_label[e] = plabel;
-    sc.mv_status[e] = pstatus;
-    sc.mv_owner[e] = powner;
+    MoveCopy c;
+    c.x = nx;
+    c.y = ny;
+    c.z = nz;
+    c.forget_bits = __float_as_uint(p.w);
+    c.w = pw;
+    c.ts = pts;
+    c.track = ptrack;
+    c.owner = powner;
+    c.label = plabel;
+    c.status = pstatus;
+    c.pad = 0;
+    sc.mv_copy[e] = c;
     move_link(d, sc, v, e);
   } else if (sc.halo_send) {  // crosses into another slab: export
     uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(sc.halo_send), 1u);
@@ -334,13 +340,19 @@ __global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int wor
     if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) continue;
     const uint32_t e = r.e;
     if (e >= sc.cap_move) continue;
-    sc.mv_pos[e] = make_float4(r.x, r.y, r.z, __uint_as_float(r.forget_bits));
-    sc.mv_w[e] = r.w;
-    sc.mv_ts[e] = (uint16_t)(r.ts_track & 0xffffu);
-    sc.mv_track[e] = (uint16_t)(r.ts_track >> 16);
-    sc.mv_owner[e] = (uint16_t)(r.owner_label_status & 0xffffu);
-    sc.mv_label[e] = (uint8_t)((r.owner_label_status >> 16) & 0xffu);
-    sc.mv_status[e] = (uint8_t)(r.owner_label_status >> 24);
+    MoveCopy c;
+    c.x = r.x;
+    c.y = r.y;
+    c.z = r.z;
+    c.forget_bits = r.forget_bits;
+    c.w = r.w;
+    c.ts = (uint16_t)(r.ts_track & 0xffffu);
+    c.track = (uint16_t)(r.ts_track >> 16);
+    c.owner = (uint16_t)(r.owner_label_status & 0xffffu);
+    c.label = (uint8_t)((r.owner_label_status >> 16) & 0xffu);
+    c.status = (uint8_t)(r.owner_label_status >> 24);
+    c.pad = 0;
+    sc.mv_copy[e] = c;
     move_link(d, sc, r.voxel, e);
   }
 }
@@ -407,15 +419,16 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
           full = true;
           break;
         }
-        const uint8_t cs = sc.mv_status[e];
-        const uint16_t cts = sc.mv_ts[e];
-        st.pos4[base + slot] = sc.mv_pos[e];
-        st.w[base * REC_W + slot] = sc.mv_w[e];
+        const MoveCopy c = sc.mv_copy[e];
+        const uint8_t cs = c.status;
+        const uint16_t cts = c.ts;
+        st.pos4[base + slot] = make_float4(c.x, c.y, c.z, __uint_as_float(c.forget_bits));
+        st.w[base * REC_W + slot] = c.w;
         st.ts[base * REC_TS + slot] = cts;
-        st.track[base * REC_TRACK + slot] = sc.mv_track[e];
-        st.label[base * REC_LABEL + slot] = sc.mv_label[e];
+        st.track[base * REC_TRACK + slot] = c.track;
+        st.label[base * REC_LABEL + slot] = c.label;
         st.status[base + slot] = cs;
-        st.owner[base + slot] = sc.mv_owner[e];  // new index joins the object's set
+        st.owner[base + slot] = c.owner;  // new index joins the object's set
         st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
 #pragma unroll
         for (int i = 1; i < S; ++i)

@@ -11,6 +11,17 @@ struct BirthOrder {
   int cols[9];
 };
 
+// one moved copy of a particle on its way to its new voxel (operations.h:339-349)
+struct MoveCopy {
+  float x, y, z;
+  uint32_t forget_bits;
+  float w;
+  uint16_t ts, track, owner;
+  uint8_t label, status;
+  uint32_t pad;
+};
+static_assert(sizeof(MoveCopy) == 32, "MoveCopy layout");
+
 struct Scratch {
   // frustum vertex bitsets, one line of wpl 64-bit words per (y,z)
   uint64_t *vmask = nullptr, *reach = nullptr;
@@ -43,10 +54,7 @@ struct Scratch {
   // object moves
   uint32_t *mv_cnt = nullptr;      // per-chunk per-object counts / offsets
   uint32_t *mv_list = nullptr, *mv_nlist = nullptr;  // ascending list of chunks that may hold owned slots
-  float4 *mv_pos = nullptr;        // copies: position (+forget bits)
-  float *mv_w = nullptr;
-  uint16_t *mv_ts = nullptr, *mv_track = nullptr, *mv_owner = nullptr;
-  uint8_t *mv_label = nullptr, *mv_status = nullptr;
+  MoveCopy *mv_copy = nullptr;     // the moved copies, indexed by global rank (32 B each: two 16-byte accesses)
   uint32_t cap_move = 0;
   // slab-crossing copies: [u32 count, pad to 16 B][records]; recv = one such buffer per shard, shard order
   unsigned char *halo_send = nullptr;
@@ -97,6 +105,7 @@ void launch_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uin
 void launch_rec_pack(const Dims &d, const State &st, const float *w, const uint16_t *ts, const uint16_t *track,
                      const uint8_t *label, hipStream_t s);
 void launch_rec_unpack(const Dims &d, const State &st, float *w, uint16_t *ts, uint16_t *track, uint8_t *label, hipStream_t s);
+void launch_fill_dense(const Dims &d, const State &st, uint32_t stamp, hipStream_t s);
 void launch_vts_sync(const Dims &d, const State &st, int to_slot0, hipStream_t s);
 void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t *flags, uint32_t *offs,
                         uint32_t *scan_scratch, sdm_point *out, uint32_t cap, int want_free, const float sub[3],
