@@ -120,3 +120,44 @@ def test_native_rccl_single_rank():
     assert np.array_equal(a.voxels(), b.voxels())
     a.close()
     b.close()
+
+
+def test_gloo_rendezvous_then_rccl_in_one_process():
+    """The order bench.py uses at N > 1: torch + a gloo process group first (CPU only), then libsdm_hip, the RCCL id
+    through sharded.broadcast_unique_id, sdm_comm_init and sharded frames.  Run in a fresh interpreter: torch brings
+    its own HIP runtime into the process and must not disturb the one the library runs on."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29541")
+import torch
+import torch.distributed as dist
+dist.init_process_group("gloo", rank=0, world_size=1)
+import numpy as np
+from semantic_dsp_map_amd import binding, sharded, synth
+cfg, params, frames = synth.make_frames("T0", 3, "vkitti2", n_dynamic=2)
+noise = synth.noise_table()
+uid = sharded.broadcast_unique_id(dist, 0)
+assert len(uid) == 128 and any(uid)
+a = binding.SdmMap(cfg, params, noise)
+b = binding.SdmMap(cfg, params, noise)
+b.comm_init(uid, 1024)
+for depth, cloud, pos, q, moves in frames:
+    a.update(depth, cloud, pos, q, moves, sync=True)
+    b.update_sharded(depth, cloud, pos, q, moves)
+    b.synchronize()
+dist.barrier()
+t = torch.tensor([1.5], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert np.array_equal(a.voxels(), b.voxels())
+assert not torch.cuda.is_initialized()
+dist.destroy_process_group()
+print("OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
