@@ -338,3 +338,48 @@ def prefill_state(cfg, scene, n_particles, seed=11, shard_rank=0, shard_count=1)
     ring = {"global_time_stamp": 1, "moved_steps": [0, 0, 0], "eq_steps": [0, 0, 0],
             "map_center": [0.0, 0.0, 0.0], "last_pos": [0.0, 0.0, 0.0], "birth_cursor": 0, "move_cursor": 0}
     return st, ring, n_vox * (S - 1)
+
+
+def write_clip(path, cfg_name, n_frames, params_name=None, seed=7, noise=None, **scene_kw):
+    """Dump a synthetic clip in the format tools/replay/replay.cpp reads (ROS-free replay): per frame
+    the inputs the reference's update() receives - depth, "static" MONO8 mask, one MONO8 mask per movable object, the
+    double pose - plus the object motions its object layer would have produced.  Returns what was written, so that a
+    test can push the same frames through the Python binding."""
+    import struct
+    from . import binding
+    cfg = CONFIGS[cfg_name]
+    params = PARAMS[params_name or CONFIG_PARAMS[cfg_name]]
+    noise = noise_table() if noise is None else np.ascontiguousarray(noise, np.float32)
+    sc = Scene(cfg, seed=seed, **scene_kw)
+    c = binding.Config()
+    for k, _ in binding.Config._fields_:
+        setattr(c, k, cfg.get(k, 0) if k not in ("shard_count",) else 1)
+    c.max_movable_track = cfg["max_movable_track"]
+    p = binding.Params()
+    for k, _ in binding.Params._fields_:
+        setattr(p, k, params[k])
+    frames = []
+    with open(path, "wb") as f:
+        f.write(b"SDMCLIP1")
+        f.write(bytes(c))
+        f.write(bytes(p))
+        f.write(struct.pack("<I", noise.size))
+        f.write(noise.tobytes())
+        f.write(LABEL_TO_STATIC_INSTANCE.astype("<u2").tobytes())
+        f.write(struct.pack("<I", n_frames))
+        for t in range(n_frames):
+            depth, cloud, pos, q = sc.render(t, params)
+            static_mask, objects = raw_inputs(cfg, cloud, sc)
+            pos64, q64 = sc.pose(t)
+            moves = np.ascontiguousarray(sc.moves(t), dtype=binding.OBJECT_MOVE)
+            f.write(np.asarray(pos64, "<f8").tobytes())
+            f.write(np.asarray(q64, "<f8").tobytes())
+            f.write(struct.pack("<III", 1, len(objects), moves.size))
+            f.write(np.ascontiguousarray(depth, "<f4").tobytes())
+            f.write(np.ascontiguousarray(static_mask, np.uint8).tobytes())
+            for trk, lab, mask in objects:
+                f.write(struct.pack("<ii", trk, lab))
+                f.write(np.ascontiguousarray(mask, np.uint8).tobytes())
+            f.write(moves.tobytes())
+            frames.append((depth, static_mask, objects, pos64, q64, moves))
+    return cfg, params, noise, frames
