@@ -205,6 +205,27 @@ sdm_status sdm_update_raw(sdm_map *m, const float *depth, const uint8_t *static_
                           const double cam_pos[3], const double cam_q[4],
                           const sdm_object_move *moves, int32_t n_moves,
                           const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after);
+/* Preset-specific parts of generateLabeledPointCloud:
+ *  - BOOST mode (settings.h:26, 137-143): depth and masks arrive at src_width x src_height and are reduced by `rescale`
+ *    with the reference's nearest-neighbour manualResize (pointcloud_tools.h:1104-1133); int(src * rescale) must equal
+ *    the configured width / height.  src_width = 0: inputs already have the configured size.
+ *  - ZED2 (SETTING 3): pixels whose track id is sky_instance are invalid (:236-242); object_bbox (n_objects x 6
+ *    doubles: min x, max x, min y, max y, min z, max z of the object's current key points +- 1 m, global frame,
+ *    :174-196) turns points of a movable instance that lie outside their object's box into Background (:254-272).
+ *    sky_instance < 0 / object_bbox NULL: off. */
+typedef struct {
+  int32_t src_width, src_height;
+  float rescale;
+  int32_t sky_instance;
+  const double *object_bbox;
+} sdm_raw_options;
+sdm_status sdm_update_raw_ex(sdm_map *m, const float *depth, const uint8_t *static_mask,
+                             const uint16_t label_to_static_instance[256],
+                             const sdm_instance_mask *objects, int32_t n_objects,
+                             const double cam_pos[3], const double cam_q[4],
+                             const sdm_object_move *moves, int32_t n_moves,
+                             const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after,
+                             const sdm_raw_options *opt);
 /* the LabeledPoint image sdm_update_raw generated for the last frame (H*W entries), for cross-checks */
 sdm_status sdm_get_labeled_cloud(sdm_map *m, sdm_labeled_point *out);
 

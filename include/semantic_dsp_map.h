@@ -9,9 +9,10 @@
  *   - the object layer (objectLevelUpdate, :306-566): NOT re-implemented here.  Plug the reference's own
  *     ObjectSet logic in through SdmObjectLayer (INTEGRATION.md shows the 20-line glue); without one the map runs
  *     like the reference with g_consider_instance == false,
- *   - packing of the depth image and the MONO8 masks for sdm_update_raw(), which runs generateLabeledPointCloud
- *     (utils/pointcloud_tools.h:88-310) on the device for the non-BOOST, non-ZED presets (the ZED2
- *     bounding-box filter and the BOOST resize are not ported yet),
+ *   - packing of the depth image and the MONO8 masks for sdm_update_raw_ex(), which runs generateLabeledPointCloud
+ *     (utils/pointcloud_tools.h:88-310) on the device, including the BOOST-mode manualResize and
+ *     the ZED2 sky / bounding-box filters (SdmGridPreset::Zed2Boost); the per-object boxes are computed here from the
+ *     key points,
  *   - colouring of the emitted cloud (semantic_dsp_map.h:1274-1351): the colour rules and OpenCV's RGB<->HSV round
  *     trip stay host code (one batched cvtColor instead of the reference's two per voxel); the in-view test that
  *     selects the "V x 0.7" dimming comes from the device with each point (SDM_POINTS_MARK_FOV, row N2).
@@ -33,6 +34,7 @@
 #include <cmath>
 #include <cstdint>
 #include <iostream>
+#include <limits>
 #include <map>
 #include <set>
 #include <stdexcept>
@@ -66,9 +68,26 @@ struct SdmGridPreset {
   float depth_min, depth_max;
   int window_half;
   bool consider_instance;
+  /// BOOST_MODE (settings.h:26, 137-143): inputs arrive at src_width x src_height and are reduced by `rescale`
+  /// (manualResize); width/height and the intrinsics above are the reduced ones.  src_width = 0: no BOOST mode.
+  int src_width = 0, src_height = 0;
+  float rescale = 1.f;
+  /// SETTING 3 (ZED2): sky pixels are dropped and every movable object's points are clipped to the box of its
+  /// current key points +- 1 m (pointcloud_tools.h:174-196, 236-242, 254-272)
+  bool zed2_filters = false;
   static SdmGridPreset Kitti360() { return {8, 8, 8, 3, 0.15f, 552.554261f, 552.554261f, 682.049453f, 238.769549f, 1408, 376, 0.3f, 30.f, 5, false}; }
   static SdmGridPreset Coda() { return {8, 8, 7, 2, 0.15f, 569.8286f, 565.4818f, 439.2660f, 360.5810f, 960, 540, 0.3f, 10.f, 5, true}; }
   static SdmGridPreset VirtualKitti2() { return {8, 7, 8, 3, 0.2f, 725.0087f, 725.0087f, 620.5f, 187.f, 1242, 375, 0.3f, 30.f, 5, true}; }
+  /// SETTING 3 with BOOST_MODE 1, the reference's ZED2 configuration (settings.h:24-27, 100-119, 137-143, semantic_dsp_map.h:964-970)
+  static SdmGridPreset Zed2Boost() {
+    SdmGridPreset p{7, 5, 7, 2, 0.15f, 0.5f * 527.8191528320312f, 0.5f * 527.8191528320312f, 0.5f * 633.9357299804688f,
+                    0.5f * 366.3338623046875f, 640, 360, 0.3f, 15.f, 3, true};
+    p.src_width = 1280;
+    p.src_height = 720;
+    p.rescale = 0.5f;
+    p.zed2_filters = true;
+    return p;
+  }
 };
 
 /// What the particle layer needs from the object layer each frame (semantic_dsp_map.h:588-736).
@@ -228,12 +247,22 @@ class SemanticDSPMap {
     const double cam_q_d[4] = {camera_orientation.w(), camera_orientation.x(), camera_orientation.y(), camera_orientation.z()};
     const Eigen::Vector3f pf = camera_position.cast<float>();
     const float cam_pos[3] = {pf.x(), pf.y(), pf.z()};
-    if (!check(sdm_update_raw(map_, depth_.data(), have_static_ ? static_mask_.data() : nullptr, label_to_inst_,
-                              objects_.empty() ? nullptr : objects_.data(), (int32_t)objects_.size(), cam_pos_d, cam_q_d,
-                              moves.empty() ? nullptr : moves.data(), (int32_t)moves.size(),
-                              removals.empty() ? nullptr : removals.data(), (int32_t)removals.size(),
-                              preset_.consider_instance ? 0u : SDM_NO_INSTANCES, SDM_STAGE_ALL),
-               "sdm_update_raw"))
+    sdm_raw_options opt;
+    opt.src_width = preset_.src_width;
+    opt.src_height = preset_.src_height;
+    opt.rescale = preset_.rescale;
+    opt.sky_instance = -1;
+    if (preset_.zed2_filters && label_id_.count("Sky")) {  // g_label_to_instance_id_map_default["Sky"]
+      const int sky_label = label_id_["Sky"];
+      if (sky_label >= 0 && sky_label < 256) opt.sky_instance = label_to_inst_[sky_label];
+    }
+    opt.object_bbox = preset_.zed2_filters && !boxes_.empty() ? boxes_.data() : nullptr;
+    if (!check(sdm_update_raw_ex(map_, depth_.data(), have_static_ ? static_mask_.data() : nullptr, label_to_inst_,
+                                 objects_.empty() ? nullptr : objects_.data(), (int32_t)objects_.size(), cam_pos_d, cam_q_d,
+                                 moves.empty() ? nullptr : moves.data(), (int32_t)moves.size(),
+                                 removals.empty() ? nullptr : removals.data(), (int32_t)removals.size(),
+                                 preset_.consider_instance ? 0u : SDM_NO_INSTANCES, SDM_STAGE_ALL, &opt),
+               "sdm_update_raw_ex"))
       return;
     emit(occupied_point_cloud, false, cam_pos);
     if (if_get_freespace) emit(freespace_point_cloud, true, cam_pos);
@@ -259,6 +288,7 @@ class SemanticDSPMap {
   std::vector<float> depth_;
   std::vector<uint8_t> static_mask_, object_masks_;
   std::vector<sdm_instance_mask> objects_;
+  std::vector<double> boxes_;  // ZED2: per object min x, max x, min y, max y, min z, max z
   uint16_t label_to_inst_[256];  // g_label_to_instance_id_map_default as a table (65535 = Background's instance)
   bool have_static_ = false;
   std::vector<sdm_point> points_;
@@ -327,12 +357,18 @@ class SemanticDSPMap {
       std::cerr << "Error: depth image is empty." << std::endl;
       return -1;
     }
-    const int W = preset_.width, H = preset_.height;
+    // BOOST mode: the images keep the sensor's size here, the library reduces them (manualResize) on the device
+    const int W = preset_.src_width > 0 ? preset_.src_width : preset_.width;
+    const int H = preset_.src_width > 0 ? preset_.src_height : preset_.height;
     if (depth.cols != W || depth.rows != H) {
       std::cerr << "Error: depth image size does not match the grid preset." << std::endl;
       return -1;
     }
     const size_t hw = (size_t)W * H;
+    if (depth_.size() != hw) {
+      depth_.resize(hw);
+      static_mask_.resize(hw);
+    }
     for (int i = 0; i < H; ++i)
       for (int j = 0; j < W; ++j) depth_[(size_t)i * W + j] = depth.at<float>(i, j);
     have_static_ = false;
@@ -345,6 +381,7 @@ class SemanticDSPMap {
       break;
     }
     objects_.clear();
+    boxes_.clear();
     size_t n_obj = 0;
     if (preset_.consider_instance)
       for (const auto &s : seg) n_obj += s.label != "static";
@@ -362,6 +399,20 @@ class SemanticDSPMap {
         o.label_id = it == label_id_.end() ? 0 : it->second;
         o.mask = dst;
         objects_.push_back(o);
+        if (preset_.zed2_filters) {  // pointcloud_tools.h:174-196 (max starts at the smallest positive double there)
+          double lo[3] = {std::numeric_limits<double>::max(), std::numeric_limits<double>::max(), std::numeric_limits<double>::max()};
+          double hi[3] = {std::numeric_limits<double>::min(), std::numeric_limits<double>::min(), std::numeric_limits<double>::min()};
+          for (const auto &kpt : s.kpts_current)
+            for (int a = 0; a < 3; ++a) {
+              if (kpt(a) < lo[a]) lo[a] = kpt(a);
+              if (kpt(a) > hi[a]) hi[a] = kpt(a);
+            }
+          const double margin = 1.0;
+          for (int a = 0; a < 3; ++a) {
+            boxes_.push_back(lo[a] - margin);
+            boxes_.push_back(hi[a] + margin);
+          }
+        }
         ++k_obj;
       }
     }

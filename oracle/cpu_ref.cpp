@@ -995,6 +995,19 @@ struct oracle_map {
 };
 
 // ------------------------------------------------------------------ C ABI
+// utils/pointcloud_tools.h:1104-1133
+template <typename T>
+static void manual_resize(const T *src, int src_w, int src_h, T *dst, int dst_w, int dst_h, float scale) {
+  const float scale_inv = 1.f / scale;
+  for (int i = 0; i < dst_h; ++i)
+    for (int j = 0; j < dst_w; ++j) {
+      int si = static_cast<int>(i * scale_inv), sj = static_cast<int>(j * scale_inv);
+      si = std::min(si, src_h - 1);
+      sj = std::min(sj, src_w - 1);
+      dst[(size_t)i * dst_w + j] = src[(size_t)si * src_w + sj];
+    }
+}
+
 extern "C" {
 
 oracle_map *oracle_create(const oracle_config *cfg) {
@@ -1119,14 +1132,35 @@ void oracle_get_pdf_table(oracle_map *m, float *out) { memcpy(out, m->pdf.data()
 // utils/pointcloud_tools.h:88-310.  PINNED: K^-1 = (1/fx, -cx/fx, 1/fy, -cy/fy) in double (the reference inverts K
 // with Eigen), K^-1*(j,i,1) = (ifx*j + icx, ify*i + icy, 1), R from Eigen's toRotationMatrix formula in double,
 // camera-to-global = ((r0*x + r1*y) + r2*z) + t; fields of invalid points (uninitialised in the reference) are zero
-// with sigma = zero-order term.
-void oracle_generate_cloud(oracle_map *m, const float *depth, const uint8_t *static_mask, const uint16_t *label_to_inst,
-                           const int32_t *obj_track, const int32_t *obj_label, const uint8_t *obj_masks, int32_t n_objects,
-                           const double cam_pos[3], const double cam_q[4], int32_t consider_instance,
-                           oracle_labeled_point *out) {
+// with sigma = zero-order term; sigma of a point the ZED2 box filter turns into Background (unset in the reference) is
+// the noise model's.
+void oracle_generate_cloud_ex(oracle_map *m, const float *depth_in, const uint8_t *static_in, const uint16_t *label_to_inst,
+                              const int32_t *obj_track, const int32_t *obj_label, const uint8_t *obj_in, int32_t n_objects,
+                              const double cam_pos[3], const double cam_q[4], int32_t consider_instance,
+                              int32_t src_width, int32_t src_height, float rescale, int32_t sky_instance,
+                              const double *object_bbox, oracle_labeled_point *out, float *depth_out) {
   const oracle_config &c = m->cfg;
   const int W = c.width, H = c.height;
   const size_t hw = (size_t)W * H;
+  std::vector<float> depth_r;
+  std::vector<uint8_t> static_r, obj_r;
+  const float *depth = depth_in;
+  const uint8_t *static_mask = static_in, *obj_masks = obj_in;
+  if (src_width > 0) {  // BOOST mode (:98-102, 126-130, 172-176)
+    const size_t shw = (size_t)src_width * src_height;
+    depth_r.resize(hw);
+    manual_resize(depth_in, src_width, src_height, depth_r.data(), W, H, rescale);
+    depth = depth_r.data();
+    if (static_in) {
+      static_r.resize(hw);
+      manual_resize(static_in, src_width, src_height, static_r.data(), W, H, rescale);
+      static_mask = static_r.data();
+    }
+    obj_r.resize(hw * (size_t)std::max(n_objects, 1));
+    for (int k = 0; k < n_objects; ++k) manual_resize(obj_in + shw * k, src_width, src_height, obj_r.data() + hw * k, W, H, rescale);
+    obj_masks = obj_r.data();
+  }
+  if (depth_out) memcpy(depth_out, depth, hw * sizeof(float));
   const double w = cam_q[0], x = cam_q[1], y = cam_q[2], z = cam_q[3];
   const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
   const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x;
@@ -1136,18 +1170,15 @@ void oracle_generate_cloud(oracle_map *m, const float *depth, const uint8_t *sta
   const double ifx = 1.0 / (double)c.fx, icx = -(double)c.cx / (double)c.fx;
   const double ify = 1.0 / (double)c.fy, icy = -(double)c.cy / (double)c.fy;
   const double dmin = (double)c.depth_min, dmax = (double)c.depth_max;
+  const float sigma_invalid = m->prm.if_consider_depth_noise ? m->prm.depth_noise_zero_order : 0.1f;
   for (int i = 0; i < H; ++i)
     for (int j = 0; j < W; ++j) {
       const size_t p = (size_t)i * W + j;
       const float dv = depth[p];
       oracle_labeled_point o;
+      const oracle_labeled_point invalid = {0.f, 0.f, 0.f, sigma_invalid, 0, 0, 0};
       if (std::isnan(dv) || (double)dv < dmin || (double)dv > dmax) {
-        o.x = o.y = o.z = 0.f;
-        o.sigma = m->prm.if_consider_depth_noise ? m->prm.depth_noise_zero_order : 0.1f;
-        o.track_id = 0;
-        o.label_id = 0;
-        o.is_valid = 0;
-        out[p] = o;
+        out[p] = invalid;
         continue;
       }
       uint32_t inst = 65535u;
@@ -1164,6 +1195,34 @@ void oracle_generate_cloud(oracle_map *m, const float *depth, const uint8_t *sta
             label = obj_label[k];
             from_object = true;
           }
+      if (sky_instance >= 0 && inst == (uint32_t)sky_instance) {  // :236-242
+        out[p] = invalid;
+        continue;
+      }
+      const double px = (ifx * (double)j + icx) * (double)dv;  // :243
+      const double py = (ify * (double)i + icy) * (double)dv;
+      const double pz = (double)dv;
+      const double gx = ((R[0] * px + R[1] * py) + R[2] * pz) + cam_pos[0];  // :247
+      const double gy = ((R[3] * px + R[4] * py) + R[5] * pz) + cam_pos[1];
+      const double gz = ((R[6] * px + R[7] * py) + R[8] * pz) + cam_pos[2];
+      const float sigma = m->prm.if_consider_depth_noise ? m->prm.depth_noise_zero_order + m->prm.depth_noise_first_order * dv : 0.1f;
+      if (object_bbox && consider_instance && (int)inst < c.max_movable_track) {  // :254-272
+        double b[6] = {0, 0, 0, 0, 0, 0};  // std::map default for a track id without an object
+        for (int k = 0; k < n_objects; ++k)
+          if ((uint32_t)obj_track[k] == inst)
+            for (int q = 0; q < 6; ++q) b[q] = object_bbox[k * 6 + q];
+        if (gx < b[0] || gx > b[1] || gy < b[2] || gy > b[3] || gz < b[4] || gz > b[5]) {
+          o.x = (float)gx;
+          o.y = (float)gy;
+          o.z = (float)gz;
+          o.sigma = sigma;
+          o.track_id = 65535;
+          o.label_id = 0;
+          o.is_valid = 1;
+          out[p] = o;
+          continue;
+        }
+      }
       if ((int)inst > c.max_movable_track) {  // :277-283
         label = 0;
         if (static_mask)
@@ -1175,18 +1234,23 @@ void oracle_generate_cloud(oracle_map *m, const float *depth, const uint8_t *sta
       } else if (!from_object) {
         label = 0;
       }
-      const double px = (ifx * (double)j + icx) * (double)dv;  // :243
-      const double py = (ify * (double)i + icy) * (double)dv;
-      const double pz = (double)dv;
-      o.x = (float)(((R[0] * px + R[1] * py) + R[2] * pz) + cam_pos[0]);  // :247, 298-300
-      o.y = (float)(((R[3] * px + R[4] * py) + R[5] * pz) + cam_pos[1]);
-      o.z = (float)(((R[6] * px + R[7] * py) + R[8] * pz) + cam_pos[2]);
-      o.sigma = m->prm.if_consider_depth_noise ? m->prm.depth_noise_zero_order + m->prm.depth_noise_first_order * dv : 0.1f;
+      o.x = (float)gx;  // :298-300
+      o.y = (float)gy;
+      o.z = (float)gz;
+      o.sigma = sigma;
       o.track_id = (uint16_t)inst;
       o.label_id = (uint8_t)label;
       o.is_valid = 1;
       out[p] = o;
     }
+}
+
+void oracle_generate_cloud(oracle_map *m, const float *depth, const uint8_t *static_mask, const uint16_t *label_to_inst,
+                           const int32_t *obj_track, const int32_t *obj_label, const uint8_t *obj_masks, int32_t n_objects,
+                           const double cam_pos[3], const double cam_q[4], int32_t consider_instance,
+                           oracle_labeled_point *out) {
+  oracle_generate_cloud_ex(m, depth, static_mask, label_to_inst, obj_track, obj_label, obj_masks, n_objects, cam_pos, cam_q,
+                           consider_instance, 0, 0, 1.f, -1, nullptr, out, nullptr);
 }
 
 int32_t oracle_point_in_frustum(oracle_map *m, float x, float y, float z) { return m->isPointInFrustum(x, y, z) ? 1 : 0; }

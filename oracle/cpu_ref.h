@@ -160,6 +160,15 @@ void oracle_generate_cloud(oracle_map *m, const float *depth, const uint8_t *sta
                            const double cam_pos[3], const double cam_q[4], int32_t consider_instance,
                            oracle_labeled_point *out);
 
+/* The preset-specific parts (BOOST-mode manualResize, pointcloud_tools.h:1104-1133; ZED2 sky exclusion and per-object
+ * box filter, :174-196, 236-242, 254-272).  src_width = 0: no resize; sky_instance < 0 / object_bbox NULL: off.
+ * Inputs are src_width x src_height when resizing.  depth_out (H*W, may be NULL) receives the resized depth image. */
+void oracle_generate_cloud_ex(oracle_map *m, const float *depth, const uint8_t *static_mask, const uint16_t *label_to_inst,
+                              const int32_t *obj_track, const int32_t *obj_label, const uint8_t *obj_masks, int32_t n_objects,
+                              const double cam_pos[3], const double cam_q[4], int32_t consider_instance,
+                              int32_t src_width, int32_t src_height, float rescale, int32_t sky_instance,
+                              const double *object_bbox, oracle_labeled_point *out, float *depth_out);
+
 /* helpers exposed for known-answer tests */
 uint32_t oracle_pos_to_voxel(oracle_map *m, float x, float y, float z); /* 0xffffffff if outside */
 void oracle_voxel_to_pos(oracle_map *m, uint32_t voxel, float out[3]);  /* global min corner */

@@ -116,6 +116,8 @@ def lib():
         L.oracle_point_in_frustum.argtypes = [vp, C.c_float, C.c_float, C.c_float]
         L.oracle_point_in_frustum.restype = C.c_int32
         L.oracle_generate_cloud.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, C.c_int32, vp]
+        L.oracle_generate_cloud_ex.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, C.c_int32,
+                                               C.c_float, C.c_int32, vp, vp, vp]
         L.oracle_pos_to_voxel.restype = C.c_uint32
         L.oracle_pos_to_voxel.argtypes = [vp, C.c_float, C.c_float, C.c_float]
         L.oracle_voxel_to_pos.argtypes = [vp, C.c_uint32, vp]
@@ -263,6 +265,29 @@ class OracleMap:
         out = np.empty(16, np.float32)
         self.L.oracle_get_extrinsic(self.h, _ptr(out))
         return out.reshape(4, 4)
+
+    def generate_cloud_ex(self, depth, static_mask, label_to_inst, objects, cam_pos, cam_q, consider_instance=True,
+                          src_size=None, rescale=1.0, sky_instance=-1, object_bbox=None):
+        """generate_cloud with the preset-specific parts: BOOST-mode inputs of src_size = (width, height) reduced by
+        `rescale`, ZED2 sky exclusion and per-object boxes (n_objects x 6 doubles).  Returns (cloud, resized depth)."""
+        hw = self.W * self.H
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        sm = None if static_mask is None else np.ascontiguousarray(static_mask, dtype=np.uint8)
+        tab = np.ascontiguousarray(label_to_inst, dtype=np.uint16)
+        tr = np.array([o[0] for o in objects], np.int32)
+        lb = np.array([o[1] for o in objects], np.int32)
+        masks = np.ascontiguousarray(np.concatenate([np.asarray(o[2], np.uint8).reshape(-1) for o in objects])
+                                     if objects else np.zeros(1, np.uint8))
+        pos = np.ascontiguousarray(cam_pos, dtype=np.float64)
+        q = np.ascontiguousarray(cam_q, dtype=np.float64)
+        bb = None if object_bbox is None else np.ascontiguousarray(object_bbox, dtype=np.float64)
+        out = np.zeros(hw, LABELED_POINT)
+        dout = np.zeros(hw, np.float32)
+        sw, sh = src_size if src_size else (0, 0)
+        self.L.oracle_generate_cloud_ex(self.h, _ptr(depth), _ptr(sm), _ptr(tab), _ptr(tr), _ptr(lb), _ptr(masks), len(objects),
+                                        _ptr(pos), _ptr(q), 1 if consider_instance else 0, sw, sh, float(rescale),
+                                        int(sky_instance), _ptr(bb), _ptr(out), _ptr(dout))
+        return out, dout
 
     def generate_cloud(self, depth, static_mask, label_to_inst, objects, cam_pos, cam_q, consider_instance=True):
         """objects: list of (track_id, label_id, mask HxW uint8).  Returns the LabeledPoint image."""

@@ -56,6 +56,11 @@ class InstanceMask(C.Structure):
     _fields_ = [("track_id", C.c_int32), ("label_id", C.c_int32), ("mask", C.c_void_p)]
 
 
+class RawOptions(C.Structure):
+    _fields_ = [("src_width", C.c_int32), ("src_height", C.c_int32), ("rescale", C.c_float), ("sky_instance", C.c_int32),
+                ("object_bbox", C.c_void_p)]
+
+
 class RingState(C.Structure):
     _fields_ = [("global_time_stamp", C.c_uint32), ("moved_steps", C.c_int32 * 3), ("eq_steps", C.c_int32 * 3),
                 ("map_center", C.c_float * 3), ("last_pos", C.c_float * 3),
@@ -99,6 +104,7 @@ def load_library():
         "sdm_download_pdf_table": [vp, vp, i32],
         "sdm_update": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32],
         "sdm_update_raw": [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, i32, u32, i32],
+        "sdm_update_raw_ex": [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, i32, u32, i32, vp],
         "sdm_get_labeled_cloud": [vp, vp],
         "sdm_update_begin": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32, C.POINTER(vp)],
         "sdm_update_finish": [vp, vp, i32, u32, i32],
@@ -252,7 +258,7 @@ class SdmMap:
             self.synchronize()
 
     def update_raw(self, depth, static_mask, label_to_inst, objects, cam_pos, cam_q, moves=None, remove_tracks=None,
-                   stop_after="all", flags=0, sync=False):
+                   stop_after="all", flags=0, sync=False, src_size=None, rescale=1.0, sky_instance=-1, object_bbox=None):
         """SURVEY row N1 on the device.  objects: list of (track_id, label_id, mask HxW uint8); pose in double."""
         depth = np.ascontiguousarray(depth, dtype=np.float32)
         sm = None if static_mask is None else np.ascontiguousarray(static_mask, dtype=np.uint8)
@@ -267,9 +273,16 @@ class SdmMap:
         mv = np.ascontiguousarray(moves if moves is not None else np.zeros(0, OBJECT_MOVE), dtype=OBJECT_MOVE)
         rm = np.ascontiguousarray(remove_tracks if remove_tracks is not None else [], dtype=np.int32)
         st = STAGES[stop_after] if isinstance(stop_after, str) else stop_after
-        _check(self.L, self.L.sdm_update_raw(self.h, _ptr(depth), _ptr(sm), _ptr(tab), C.cast(arr, C.c_void_p), len(objects),
-                                             _ptr(pos), _ptr(q), _ptr(mv) if mv.size else None, mv.size,
-                                             _ptr(rm) if rm.size else None, rm.size, flags, st), "sdm_update_raw")
+        opt = RawOptions()
+        opt.src_width, opt.src_height = src_size if src_size else (0, 0)
+        opt.rescale = float(rescale)
+        opt.sky_instance = int(sky_instance)
+        bb = None if object_bbox is None else np.ascontiguousarray(object_bbox, dtype=np.float64)
+        opt.object_bbox = bb.ctypes.data if bb is not None else None
+        _check(self.L, self.L.sdm_update_raw_ex(self.h, _ptr(depth), _ptr(sm), _ptr(tab), C.cast(arr, C.c_void_p), len(objects),
+                                                _ptr(pos), _ptr(q), _ptr(mv) if mv.size else None, mv.size,
+                                                _ptr(rm) if rm.size else None, rm.size, flags, st, C.byref(opt)),
+               "sdm_update_raw_ex")
         if sync:
             self.synchronize()
 

@@ -1442,13 +1442,28 @@ struct CloudArgs {
   double dmin, dmax;
   float sigma0, sigma1;
   int consider_depth_noise, consider_instance, n_objects, has_static;
+  int sky_instance, has_bbox;
   int track[MAX_CLOUD_OBJECTS], label[MAX_CLOUD_OBJECTS];
 };
+
+// manualResize (pointcloud_tools.h:1104-1133): dst(i, j) = src(min(int(i / scale), rows - 1), min(int(j / scale), cols - 1))
+template <typename T>
+__global__ __launch_bounds__(TPB) void k_manual_resize(const T *__restrict__ src, T *__restrict__ dst, int src_w, int src_h,
+                                                       int dst_w, int dst_h, float scale_inv) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= dst_w * dst_h) return;
+  const int i = p / dst_w, j = p - i * dst_w;
+  int si = (int)((float)i * scale_inv), sj = (int)((float)j * scale_inv);
+  si = si < src_h - 1 ? si : src_h - 1;
+  sj = sj < src_w - 1 ? sj : src_w - 1;
+  dst[p] = src[(size_t)si * src_w + sj];
+}
 
 __global__ __launch_bounds__(TPB) void k_labeled_cloud(Dims d, CloudArgs a, const float *__restrict__ depth,
                                                        const uint8_t *__restrict__ static_mask,
                                                        const uint16_t *__restrict__ label_to_inst,
                                                        const uint8_t *__restrict__ obj_masks,
+                                                       const double *__restrict__ bbox,
                                                        sdm_labeled_point *__restrict__ cloud) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int hw = d.W * d.H;
@@ -1478,6 +1493,39 @@ __global__ __launch_bounds__(TPB) void k_labeled_cloud(Dims d, CloudArgs a, cons
         label = a.label[k];
         from_object = true;
       }
+  if (a.sky_instance >= 0 && inst == (uint32_t)a.sky_instance) {  // ZED2: sky pixels are invalid (:236-242)
+    o.x = o.y = o.z = 0.f;
+    o.sigma = a.consider_depth_noise ? a.sigma0 : 0.1f;
+    o.track_id = 0;
+    o.label_id = 0;
+    o.is_valid = 0;
+    cloud[p] = o;
+    return;
+  }
+  const double x = (a.ifx * (double)j + a.icx) * (double)dv;  // :243
+  const double y = (a.ify * (double)i + a.icy) * (double)dv;
+  const double z = (double)dv;
+  const double gx = ((a.R[0] * x + a.R[1] * y) + a.R[2] * z) + a.t[0];  // :247
+  const double gy = ((a.R[3] * x + a.R[4] * y) + a.R[5] * z) + a.t[1];
+  const double gz = ((a.R[6] * x + a.R[7] * y) + a.R[8] * z) + a.t[2];
+  if (a.has_bbox && a.consider_instance && (int)inst < d.max_movable) {  // ZED2 segmentation-noise filter (:254-272)
+    // track_id_*_map[instance]: the box of the last object with that track id, zeros when there is none
+    double b[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < a.n_objects; ++k)
+      if ((uint32_t)a.track[k] == inst)
+        for (int c = 0; c < 6; ++c) b[c] = bbox[k * 6 + c];
+    if (gx < b[0] || gx > b[1] || gy < b[2] || gy > b[3] || gz < b[4] || gz > b[5]) {
+      o.x = (float)gx;
+      o.y = (float)gy;
+      o.z = (float)gz;
+      o.sigma = a.consider_depth_noise ? a.sigma0 + a.sigma1 * dv : 0.1f;  // PINNED: left unset by the reference
+      o.track_id = 65535;
+      o.label_id = 0;
+      o.is_valid = 1;
+      cloud[p] = o;
+      return;
+    }
+  }
   if ((int)inst > d.max_movable) {  // :277-283: static instance -> its label
     label = 0;
     if (a.has_static)
@@ -1489,12 +1537,6 @@ __global__ __launch_bounds__(TPB) void k_labeled_cloud(Dims d, CloudArgs a, cons
   } else if (!from_object) {
     label = 0;  // movable id that came out of the static mask table: track_to_label_id_map default (:282)
   }
-  const double x = (a.ifx * (double)j + a.icx) * (double)dv;  // :243
-  const double y = (a.ify * (double)i + a.icy) * (double)dv;
-  const double z = (double)dv;
-  const double gx = ((a.R[0] * x + a.R[1] * y) + a.R[2] * z) + a.t[0];  // :247
-  const double gy = ((a.R[3] * x + a.R[4] * y) + a.R[5] * z) + a.t[1];
-  const double gz = ((a.R[6] * x + a.R[7] * y) + a.R[8] * z) + a.t[2];
   o.x = (float)gx;
   o.y = (float)gy;
   o.z = (float)gz;
@@ -1699,12 +1741,24 @@ void launch_birth_replay(const Dims &d, const Frame &f, const Filter &flt, const
 }
 
 void launch_labeled_cloud(const Dims &d, const CloudArgsHost &h, const float *depth, const uint8_t *static_mask,
-                          const uint16_t *label_to_inst, const uint8_t *obj_masks, sdm_labeled_point *cloud, hipStream_t s) {
+                          const uint16_t *label_to_inst, const uint8_t *obj_masks, const double *bbox,
+                          sdm_labeled_point *cloud, hipStream_t s) {
   CloudArgs a;
   static_assert(sizeof(CloudArgs) == sizeof(CloudArgsHost), "CloudArgs layout");
   __builtin_memcpy(&a, &h, sizeof(a));
   hipLaunchKernelGGL(k_labeled_cloud, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, a, depth, static_mask, label_to_inst,
-                     obj_masks, cloud);
+                     obj_masks, bbox, cloud);
+}
+
+void launch_manual_resize(const Dims &d, const void *src, void *dst, int src_w, int src_h, float scale, int elem_bytes,
+                          hipStream_t s) {
+  const float scale_inv = 1.f / scale;  // pointcloud_tools.h:1119
+  dim3 grid(blocks_for((size_t)d.W * d.H));
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL(k_manual_resize<float>, grid, dim3(TPB), 0, s, (const float *)src, (float *)dst, src_w, src_h, d.W, d.H, scale_inv);
+  else
+    hipLaunchKernelGGL(k_manual_resize<uint8_t>, grid, dim3(TPB), 0, s, (const uint8_t *)src, (uint8_t *)dst, src_w, src_h, d.W, d.H,
+                       scale_inv);
 }
 
 // dense slot-order arrays <-> per-voxel records (state export / import)

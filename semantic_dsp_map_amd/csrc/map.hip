@@ -100,6 +100,9 @@ struct sdm_map {
   uint8_t *d_static_mask = nullptr, *d_obj_masks = nullptr;
   uint16_t *d_label_to_inst = nullptr;
   int obj_masks_cap = 0;
+  unsigned char *d_src_stage = nullptr;  // BOOST mode: one input image at the sensor's size
+  size_t src_stage_bytes = 0;
+  double *d_bbox = nullptr;              // ZED2: per-object boxes
   MoveSet *d_moveset = nullptr;
   uint16_t *d_remove = nullptr;
   unsigned long long *d_u64 = nullptr;
@@ -524,6 +527,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(m->d_ck_part, hw);
   A(m->d_static_mask, hw);
   A(m->d_label_to_inst, 256);
+  A(m->d_bbox, 6 * MAX_CLOUD_OBJECTS);
   A(sc.b_valid, hw + 1);
   A(sc.b_rank, hw + 1);
   sc.cap_move = (uint32_t)std::min<size_t>(n_slots, (size_t)1 << 18);  // moved particles per frame (objects hold <= ~1e5)
@@ -573,7 +577,7 @@ sdm_status sdm_destroy(sdm_map *m) {
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
   for (void *p : m->allocs) (void)hipFree(p);
-  void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points, m->d_obj_masks};
+  void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points, m->d_obj_masks, m->d_src_stage};
   for (void *p : extra)
     if (p) (void)hipFree(p);
   if (m->comm) (void)ncclCommDestroy(m->comm);
@@ -894,6 +898,15 @@ sdm_status sdm_update_raw(sdm_map *m, const float *depth, const uint8_t *static_
                           const sdm_instance_mask *objects, int32_t n_objects, const double cam_pos[3], const double cam_q[4],
                           const sdm_object_move *moves, int32_t n_moves, const int32_t *remove_tracks, int32_t n_remove,
                           uint32_t flags, int32_t stop_after) {
+  return sdm_update_raw_ex(m, depth, static_mask, label_to_static_instance, objects, n_objects, cam_pos, cam_q, moves, n_moves,
+                           remove_tracks, n_remove, flags, stop_after, nullptr);
+}
+
+sdm_status sdm_update_raw_ex(sdm_map *m, const float *depth, const uint8_t *static_mask,
+                             const uint16_t label_to_static_instance[256], const sdm_instance_mask *objects, int32_t n_objects,
+                             const double cam_pos[3], const double cam_q[4], const sdm_object_move *moves, int32_t n_moves,
+                             const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after,
+                             const sdm_raw_options *opt) {
   if (!m || !depth || !cam_pos || !cam_q || n_objects < 0 || n_objects > MAX_CLOUD_OBJECTS || (n_objects && !objects) ||
       (static_mask && !label_to_static_instance))
     return SDM_ERR_INVALID_ARGUMENT;
@@ -903,6 +916,38 @@ sdm_status sdm_update_raw(sdm_map *m, const float *depth, const uint8_t *static_
   const size_t hw = (size_t)d.W * d.H;
   const bool on_dev = (flags & SDM_INPUT_ON_DEVICE) != 0;
   const hipMemcpyKind kind = on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  // BOOST mode: the inputs arrive at the sensor's size and are reduced with manualResize first
+  const bool resize = opt && opt->src_width > 0;
+  size_t src_hw = hw;
+  if (resize) {
+    if (opt->src_height <= 0 || !(opt->rescale > 0.f) || (int)((float)opt->src_height * opt->rescale) != d.H ||
+        (int)((float)opt->src_width * opt->rescale) != d.W) {
+      set_error("sdm_update_raw_ex", __FILE__, __LINE__, "int(src size * rescale) must equal the configured image size");
+      return SDM_ERR_INVALID_ARGUMENT;
+    }
+    src_hw = (size_t)opt->src_width * opt->src_height;
+    if (!on_dev && src_hw * 4 > m->src_stage_bytes) {
+      HIP_TRY(hipStreamSynchronize(s));
+      if (m->d_src_stage) HIP_TRY(hipFree(m->d_src_stage));
+      m->d_src_stage = nullptr;
+      HIP_TRY(dev_alloc(&m->d_src_stage, src_hw * 4));
+      m->src_stage_bytes = src_hw * 4;
+    }
+  }
+  // one input image -> its device buffer of the configured size
+  auto stage_in = [&](const void *src, void *dst, int elem) -> sdm_status {
+    if (!resize) {
+      HIP_TRY(hipMemcpyAsync(dst, src, hw * elem, kind, s));
+      return SDM_OK;
+    }
+    const void *src_dev = src;
+    if (!on_dev) {
+      HIP_TRY(hipMemcpyAsync(m->d_src_stage, src, src_hw * elem, hipMemcpyHostToDevice, s));
+      src_dev = m->d_src_stage;
+    }
+    launch_manual_resize(d, src_dev, dst, opt->src_width, opt->src_height, opt->rescale, elem, s);
+    return SDM_OK;
+  };
   if (n_objects > m->obj_masks_cap) {
     HIP_TRY(hipStreamSynchronize(s));
     if (m->d_obj_masks) HIP_TRY(hipFree(m->d_obj_masks));
@@ -910,23 +955,27 @@ sdm_status sdm_update_raw(sdm_map *m, const float *depth, const uint8_t *static_
     HIP_TRY(dev_alloc(&m->d_obj_masks, hw * n_objects));
     m->obj_masks_cap = n_objects;
   }
+  sdm_status rc;
   const float *depth_dev = depth;
-  if (!on_dev) {
-    HIP_TRY(hipMemcpyAsync(m->d_depth, depth, hw * sizeof(float), hipMemcpyHostToDevice, s));
+  if (!on_dev || resize) {
+    if ((rc = stage_in(depth, m->d_depth, 4)) != SDM_OK) return rc;
     depth_dev = m->d_depth;
   }
   if (static_mask) {
-    HIP_TRY(hipMemcpyAsync(m->d_static_mask, static_mask, hw, kind, s));
+    if ((rc = stage_in(static_mask, m->d_static_mask, 1)) != SDM_OK) return rc;
     HIP_TRY(hipMemcpyAsync(m->d_label_to_inst, label_to_static_instance, 512, hipMemcpyHostToDevice, s));
   }
   CloudArgsHost a;
   memset(&a, 0, sizeof(a));
   for (int k = 0; k < n_objects; ++k) {
     if (!objects[k].mask) return SDM_ERR_INVALID_ARGUMENT;
-    HIP_TRY(hipMemcpyAsync(m->d_obj_masks + hw * k, objects[k].mask, hw, kind, s));
+    if ((rc = stage_in(objects[k].mask, m->d_obj_masks + hw * k, 1)) != SDM_OK) return rc;
     a.track[k] = objects[k].track_id;
     a.label[k] = objects[k].label_id;
   }
+  a.sky_instance = opt ? opt->sky_instance : -1;
+  a.has_bbox = opt && opt->object_bbox && n_objects > 0 ? 1 : 0;
+  if (a.has_bbox) HIP_TRY(hipMemcpyAsync(m->d_bbox, opt->object_bbox, sizeof(double) * 6 * n_objects, hipMemcpyHostToDevice, s));
   // Eigen's Quaternion::toRotationMatrix in double (pointcloud_tools.h:107-110)
   {
     const double w = cam_q[0], x = cam_q[1], y = cam_q[2], z = cam_q[3];
@@ -956,7 +1005,7 @@ sdm_status sdm_update_raw(sdm_map *m, const float *depth, const uint8_t *static_
   a.consider_instance = (flags & SDM_NO_INSTANCES) ? 0 : 1;
   a.n_objects = n_objects;
   a.has_static = static_mask ? 1 : 0;
-  launch_labeled_cloud(d, a, depth_dev, m->d_static_mask, m->d_label_to_inst, m->d_obj_masks, m->d_cloud, s);
+  launch_labeled_cloud(d, a, depth_dev, m->d_static_mask, m->d_label_to_inst, m->d_obj_masks, m->d_bbox, m->d_cloud, s);
   const float posf[3] = {(float)cam_pos[0], (float)cam_pos[1], (float)cam_pos[2]};       // semantic_dsp_map.h:584
   const float qf[4] = {(float)cam_q[0], (float)cam_q[1], (float)cam_q[2], (float)cam_q[3]};  // :745
   return sdm_update(m, depth_dev, m->d_cloud, posf, qf, moves, n_moves, remove_tracks, n_remove, flags | SDM_INPUT_ON_DEVICE,

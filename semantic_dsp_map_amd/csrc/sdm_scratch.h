@@ -80,10 +80,15 @@ struct CloudArgsHost {
   double dmin, dmax;
   float sigma0, sigma1;
   int consider_depth_noise, consider_instance, n_objects, has_static;
+  int sky_instance, has_bbox;  // ZED2 preset (pointcloud_tools.h:174-196, 236-242, 254-272)
   int track[MAX_CLOUD_OBJECTS], label[MAX_CLOUD_OBJECTS];
 };
 void launch_labeled_cloud(const Dims &d, const CloudArgsHost &h, const float *depth, const uint8_t *static_mask,
-                          const uint16_t *label_to_inst, const uint8_t *obj_masks, sdm_labeled_point *cloud, hipStream_t s);
+                          const uint16_t *label_to_inst, const uint8_t *obj_masks, const double *bbox,
+                          sdm_labeled_point *cloud, hipStream_t s);
+// manualResize (pointcloud_tools.h:1104-1133): nearest-neighbour reduction of a src_w x src_h image to d.W x d.H
+void launch_manual_resize(const Dims &d, const void *src, void *dst, int src_w, int src_h, float scale, int elem_bytes,
+                          hipStream_t s);
 
 void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s);
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s);

@@ -65,3 +65,84 @@ def test_device_cloud_and_raw_frame_match_oracle(cfg_name, params_name, kw):
         rep = pu.compare_maps(o, g, S, tag="frame %d: " % t)
         assert not rep, "\n".join(rep)
     g.close()
+
+
+# ------------------------------------------------------------------ preset-specific parts (BOOST resize, ZED2 filters)
+def boost_inputs(cfg, scale=0.5, seed=3):
+    """Sensor-size inputs (2x the configured image) with recognisable content."""
+    rng = np.random.default_rng(seed)
+    W, H = cfg["width"], cfg["height"]
+    sw, sh = int(W / scale) + 1, int(H / scale) + 1          # odd sizes: int(src * scale) still gives W x H
+    assert int(sw * scale) == W and int(sh * scale) == H
+    depth = (2.0 + 6.0 * rng.random((sh, sw))).astype(np.float32)
+    depth[rng.random((sh, sw)) < 0.03] = np.nan
+    static = rng.integers(2, 12, (sh, sw)).astype(np.uint8)
+    m1 = np.zeros((sh, sw), np.uint8)
+    m1[sh // 4: sh // 2, sw // 4: sw // 2] = 255
+    m2 = np.zeros((sh, sw), np.uint8)
+    m2[sh // 3: sh // 2 + 7, sw // 3: sw // 2 + 9] = 1
+    return (sw, sh), depth, static, [(3, 14, m1), (9, 15, m2)]
+
+
+def test_manual_resize_and_zed2_filters_in_the_oracle():
+    cfg = synth.CONFIGS["T0"]
+    params = synth.PARAMS["zed2"]
+    W, H = cfg["width"], cfg["height"]
+    o = orc.OracleMap(dict(cfg, bin_order=1), params)
+    (sw, sh), depth, static, objects = boost_inputs(cfg)
+    pos, q = [0.1, -0.2, 0.3], [1.0, 0.0, 0.0, 0.0]
+    cloud, dres = o.generate_cloud_ex(depth, static, synth.LABEL_TO_STATIC_INSTANCE, objects, pos, q, src_size=(sw, sh), rescale=0.5)
+    # manualResize (pointcloud_tools.h:1104-1133): dst(i, j) = src(int(i / scale), int(j / scale)), clamped
+    si = np.minimum((np.arange(H, dtype=np.float32) * np.float32(2.0)).astype(np.int64), sh - 1)
+    sj = np.minimum((np.arange(W, dtype=np.float32) * np.float32(2.0)).astype(np.int64), sw - 1)
+    want = depth[np.ix_(si, sj)].reshape(-1)
+    assert np.array_equal(np.isnan(want), np.isnan(dres)) and np.array_equal(want[~np.isnan(want)], dres[~np.isnan(dres)])
+    # ... and the cloud is the plain generator applied to the resized images
+    objs_r = [(t, l, m[np.ix_(si, sj)]) for t, l, m in objects]
+    plain = o.generate_cloud(want.reshape(H, W), static[np.ix_(si, sj)], synth.LABEL_TO_STATIC_INSTANCE, objs_r, pos, q)
+    assert np.array_equal(plain.view(np.uint8), cloud.view(np.uint8))
+    # ZED2: sky pixels invalid; points of a movable instance outside their object's box become Background
+    sky = int(synth.LABEL_TO_STATIC_INSTANCE[4])
+    v = plain["is_valid"] > 0
+    xs = np.unique(plain["x"][v & (plain["track_id"] == 3)].astype(np.float64))
+    edge = 0.5 * (xs[len(xs) // 2] + xs[len(xs) // 2 + 1])    # between two float values: no point sits on the edge
+    box3 = [xs[0] - 1, edge, -1e9, 1e9, -1e9, 1e9]            # keeps about half of object 3
+    box9 = [-1e9, 1e9, -1e9, 1e9, -1e9, 1e9]                   # keeps all of object 9
+    z, _ = o.generate_cloud_ex(want.reshape(H, W), static[np.ix_(si, sj)], synth.LABEL_TO_STATIC_INSTANCE, objs_r, pos, q,
+                               sky_instance=sky, object_bbox=[box3, box9])
+    was_sky = v & (plain["track_id"] == sky)
+    assert was_sky.any() and not z["is_valid"][was_sky].any()
+    t3 = v & (plain["track_id"] == 3)
+    out = t3 & (plain["x"].astype(np.float64) > box3[1])
+    assert out.any() and (t3 & ~out).any()
+    assert np.all(z["track_id"][out] == 65535) and np.all(z["label_id"][out] == 0) and np.all(z["is_valid"][out] == 1)
+    assert np.array_equal(z["x"][out], plain["x"][out]) and np.array_equal(z["sigma"][out], plain["sigma"][out])
+    keep = v & ~was_sky & ~out
+    assert np.array_equal(z[keep].view(np.uint8), plain[keep].view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_device_preset_paths_match_oracle():
+    from semantic_dsp_map_amd import binding
+    cfg = synth.CONFIGS["T0"]
+    params = synth.PARAMS["zed2"]
+    W, H = cfg["width"], cfg["height"]
+    noise = synth.noise_table()
+    o = orc.OracleMap(dict(cfg, bin_order=1), params, noise)
+    g = binding.SdmMap(cfg, params, noise)
+    sky = int(synth.LABEL_TO_STATIC_INSTANCE[4])
+    for t in range(3):
+        (sw, sh), depth, static, objects = boost_inputs(cfg, seed=3 + t)
+        pos, q = np.array([0.1 * t, -0.2, 0.3]), np.array([1.0, 0.0, 0.0, 0.0])
+        boxes = [[-3.0, 0.4, -1e9, 1e9, 0.0, 6.5], [-1e9, 1e9, -0.3, 1e9, -1e9, 1e9]]
+        want, dres = o.generate_cloud_ex(depth, static, synth.LABEL_TO_STATIC_INSTANCE, objects, pos, q, src_size=(sw, sh),
+                                         rescale=0.5, sky_instance=sky, object_bbox=boxes)
+        g.update_raw(depth, static, synth.LABEL_TO_STATIC_INSTANCE, objects, pos, q, sync=True, src_size=(sw, sh), rescale=0.5,
+                     sky_instance=sky, object_bbox=boxes)
+        got = g.labeled_cloud()
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), "LabeledPoint image differs at frame %d" % t
+        assert (want["track_id"][want["is_valid"] > 0] == 65535).any()
+        o.update(dres.reshape(H, W), want, pos.astype(np.float32), q.astype(np.float32), None)
+        rep = pu.compare_maps(o, g, 1 << cfg["p_n"], tag="frame %d: " % t)
+        assert not rep, "\n".join(rep)
+    g.close()
