@@ -66,10 +66,10 @@ __device__ __forceinline__ uint32_t stamp_max(const State &st, uint32_t rx, uint
 // ------------------------------------------------------------------------------------ A13
 // RingBufferOperations::clear (mc_ring/operations.h:684-723): slot 0 = TIMEPTC, others INVALID.
 // (the zero fields are cleared with hipMemsetAsync by the launcher)
-__global__ __launch_bounds__(TPB) void k_clear_status(uint8_t *__restrict__ status, uint32_t n_slots, uint32_t slot_mask) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(TPB) void k_clear_status(uint8_t *__restrict__ status, uint32_t n_voxels, uint32_t voxel_stride) {
+  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t stride = gridDim.x * blockDim.x;
-  for (; i < n_slots; i += stride) status[i] = (i & slot_mask) == 0 ? (uint8_t)ST_TIMEPTC : (uint8_t)ST_INVALID;
+  for (; lv < n_voxels; lv += stride) status[(size_t)lv * voxel_stride] = (uint8_t)ST_TIMEPTC;  // the record was zeroed: INVALID
 }
 
 // start of frame: zero the per-frame counters and the per-pixel bin counts (one launch instead of two memsets)
@@ -166,7 +166,7 @@ __device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_
   store_result(st.res + lv, out);
   if (dirty_w) store_vec(st.w + base * REC_W, wv);
   if (dirty_s) {
-    store_vec(st.status + base, stv);
+    store_vec(st.status + base * REC_STATUS, stv);
     bool any = false;  // the cull may have emptied the voxel
 #pragma unroll
     for (int i = 1; i < S; ++i) any = any || stv[i] != ST_INVALID;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
     uint16_t ts1[S], trk[S];
     uint8_t st1[S], lab[S];
     float wv[S];
-    load_vec(st1, st.status + base);
+    load_vec(st1, st.status + base * REC_STATUS);
     load_vec(wv, st.w + base * REC_W);  // the whole record (one line at S = 8) in one go
     load_vec(ts1, st.ts + base * REC_TS);
     load_vec(trk, st.track + base * REC_TRACK);
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(TPB) void k_vts_from_slot0(Dims d, State st) {
   if (lv >= d.v_count) return;
   st.vts[lv] = st.ts[(size_t)lv * d.S * REC_TS];
   bool any = false;
-  for (uint32_t i = 1; i < d.S; ++i) any = any || st.status[(size_t)lv * d.S + i] != ST_INVALID;
+  for (uint32_t i = 1; i < d.S; ++i) any = any || st.status[(size_t)lv * d.S * REC_STATUS + i] != ST_INVALID;
   st.vflag[lv] = any ? 1 : 0;
 }
 
@@ -616,8 +616,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   const uint32_t v = ring_to_voxel(d, rx, ry, rz);
   const uint32_t lv = v - d.v_begin;
   const size_t base = (size_t)lv * S;
-  uint8_t stv[S];
-  load_vec(stv, st.status + base);
+  const uint32_t flag = st.vflag[lv];  // 0: every slot INVALID, the record is not touched
   // imaginary particle at the voxel's min corner, mapXYZIdxToGlobalPose (operations.h:986-991, 1418-1431)
   float im_depth = 0.f, im_z = 0.f;
   bool im_ok;
@@ -629,15 +628,14 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     im_ok = project_to_image(d, f, ix, iy, iz, row, col, im_z);
     if (im_ok) im_depth = sc.depth[(size_t)row * d.W + col];
   }
-  bool any = false;
-#pragma unroll
-  for (int i = 1; i < S; ++i) any = any || stv[i] != ST_INVALID;
-  if (!any) {
+  if (!flag) {
     if (im_ok && im_z <= im_depth) st.vts[lv] = (uint16_t)f.gts;
     return;
   }
   const uint32_t smax = stamp_max(st, rx, ry, rz);
+  uint8_t stv[S];
   uint16_t tsv[S];
+  load_vec(stv, st.status + base * REC_STATUS);
   load_vec(tsv, st.ts + base * REC_TS);
   bool dirty = false, observed = false;
   int valid_n = 0;
@@ -705,7 +703,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
       sc.cnt->overflow = 1;
     }
   }
-  if (dirty) store_vec(st.status + base, stv);
+  if (dirty) store_vec(st.status + base * REC_STATUS, stv);
   if (observed) {
     st.vts[lv] = (uint16_t)f.gts;
   } else if (valid_n == 0) {
@@ -1191,7 +1189,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Frame f, F
       const size_t li = (size_t)sc.bin_idx[k] - slot_base;
       const uint32_t fc = (sc.vtf[k] >> 16) & 0xffu;
       st.w[rec_index(li, d.p_n, REC_W)] = sc.vp4[k].w * (a * flt.p_detect + 1.f - flt.p_detect);
-      st.status[li] = ST_UPDATED;
+      st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_UPDATED;
       st.ts[rec_index(li, d.p_n, REC_TS)] = (uint16_t)f.gts;
       if (!flt.independent) {
         uint32_t nf = right_id ? 0u : (fc < 5u ? fc + 1u : fc);
@@ -1292,7 +1290,7 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
     for (int i = 1; i < S; ++i)
       if (stv[i] == ST_UPDATED) {
         stv[i] = ST_INVALID;
-        st.status[base + i] = ST_INVALID;
+        st.status[base * REC_STATUS + i] = ST_INVALID;
         if (st.owner[base + i] == st.track[base * REC_TRACK + i]) st.owner[base + i] = OWNER_NONE;  // removeParticleFromObj
       }
     return true;
@@ -1306,7 +1304,7 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
       run += wv[i];
       if (run < thr) {
         stv[i] = ST_INVALID;
-        st.status[base + i] = ST_INVALID;
+        st.status[base * REC_STATUS + i] = ST_INVALID;
         if (st.owner[base + i] == st.track[base * REC_TRACK + i]) st.owner[base + i] = OWNER_NONE;
       } else {
         st.w[base * REC_W + i] = wpp;
@@ -1336,7 +1334,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
   const size_t base = (size_t)(v - d.v_begin) * S;
   uint8_t stv[S];
   uint16_t tsv[S];
-  load_vec(stv, st.status + base);
+  load_vec(stv, st.status + base * REC_STATUS);
   load_vec(tsv, st.ts + base * REC_TS);
   bool resampled = false, checked = false;
   uint32_t n_success = 0, n_resamp = 0;
@@ -1381,7 +1379,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
           st.ts[base * REC_TS + slot] = (uint16_t)f.gts;
           st.track[base * REC_TRACK + slot] = track;
           st.label[base * REC_LABEL + slot] = label;
-          st.status[base + slot] = ST_REGULAR_BORN;
+          st.status[base * REC_STATUS + slot] = ST_REGULAR_BORN;
           if ((int)track <= d.max_movable) {  // addParticleToObj
             st.owner[base + slot] = track;
             st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
@@ -1557,7 +1555,7 @@ __global__ __launch_bounds__(TPB) void k_count_live(Dims d, State st, unsigned l
     uint32_t smax = stamp_max(st, rx, ry, rz);
     size_t base = (size_t)lv * d.S;
     for (uint32_t i = 1; i < d.S; ++i)
-      if (st.status[base + i] != ST_INVALID && (uint32_t)st.ts[base * REC_TS + i] >= smax) c++;
+      if (st.status[base * REC_STATUS + i] != ST_INVALID && (uint32_t)st.ts[base * REC_TS + i] >= smax) c++;
     // bits 36..: voxels that pass isVoxelValid and hold a live slot (the ones the sweep fetches in full)
     const uint32_t t0 = st.vts[lv];
     if (c && t0 != 0 && t0 >= smax) cv = 1;
@@ -1652,7 +1650,7 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s) {
   hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
   hipMemsetAsync(st.owner_flag, 0, (n + OWNER_CHUNK - 1) / OWNER_CHUNK, s);
   hipMemsetAsync(st.res, 0, (size_t)d.v_count * sizeof(sdm_voxel_result), s);
-  hipLaunchKernelGGL(k_clear_status, dim3(4096), dim3(TPB), 0, s, st.status, (uint32_t)n, d.S - 1);
+  hipLaunchKernelGGL(k_clear_status, dim3(4096), dim3(TPB), 0, s, st.status, (uint32_t)d.v_count, (uint32_t)(d.S * REC_STATUS));
 }
 
 #define SDM_DISPATCH_S(kernel, grid, s, ...)                                                      \
@@ -1763,18 +1761,22 @@ void launch_manual_resize(const Dims &d, const void *src, void *dst, int src_w, 
 
 // dense slot-order arrays <-> per-voxel records (state export / import)
 __global__ __launch_bounds__(TPB) void k_rec_pack(Dims d, State st, const float *__restrict__ w, const uint16_t *__restrict__ ts,
-                                                  const uint16_t *__restrict__ track, const uint8_t *__restrict__ label, size_t n) {
+                                                  const uint16_t *__restrict__ track, const uint8_t *__restrict__ label,
+                                                  const uint8_t *__restrict__ status, size_t n) {
   size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= n) return;
+  st.status[rec_index(li, d.p_n, REC_STATUS)] = status[li];
   st.w[rec_index(li, d.p_n, REC_W)] = w[li];
   st.ts[rec_index(li, d.p_n, REC_TS)] = ts[li];
   st.track[rec_index(li, d.p_n, REC_TRACK)] = track[li];
   st.label[rec_index(li, d.p_n, REC_LABEL)] = label[li];
 }
 __global__ __launch_bounds__(TPB) void k_rec_unpack(Dims d, State st, float *__restrict__ w, uint16_t *__restrict__ ts,
-                                                    uint16_t *__restrict__ track, uint8_t *__restrict__ label, size_t n) {
+                                                    uint16_t *__restrict__ track, uint8_t *__restrict__ label,
+                                                    uint8_t *__restrict__ status, size_t n) {
   size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= n) return;
+  status[li] = st.status[rec_index(li, d.p_n, REC_STATUS)];
   w[li] = st.w[rec_index(li, d.p_n, REC_W)];
   ts[li] = st.ts[rec_index(li, d.p_n, REC_TS)];
   track[li] = st.track[rec_index(li, d.p_n, REC_TRACK)];
@@ -1782,13 +1784,14 @@ __global__ __launch_bounds__(TPB) void k_rec_unpack(Dims d, State st, float *__r
 }
 
 void launch_rec_pack(const Dims &d, const State &st, const float *w, const uint16_t *ts, const uint16_t *track,
-                     const uint8_t *label, hipStream_t s) {
+                     const uint8_t *label, const uint8_t *status, hipStream_t s) {
   const size_t n = (size_t)d.v_count * d.S;
-  hipLaunchKernelGGL(k_rec_pack, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, w, ts, track, label, n);
+  hipLaunchKernelGGL(k_rec_pack, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, w, ts, track, label, status, n);
 }
-void launch_rec_unpack(const Dims &d, const State &st, float *w, uint16_t *ts, uint16_t *track, uint8_t *label, hipStream_t s) {
+void launch_rec_unpack(const Dims &d, const State &st, float *w, uint16_t *ts, uint16_t *track, uint8_t *label, uint8_t *status,
+                       hipStream_t s) {
   const size_t n = (size_t)d.v_count * d.S;
-  hipLaunchKernelGGL(k_rec_unpack, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, w, ts, track, label, n);
+  hipLaunchKernelGGL(k_rec_unpack, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, w, ts, track, label, status, n);
 }
 
 // bench hook: every slot of every voxel holds a live particle with pseudo-random weight / track / label, every voxel is
@@ -1803,7 +1806,7 @@ __global__ __launch_bounds__(TPB) void k_fill_dense(Dims d, State st, uint32_t s
   h ^= h >> 15;
   h *= 2246822519u;
   h ^= h >> 13;
-  st.status[li] = i == 0 ? (uint8_t)ST_TIMEPTC : (uint8_t)((h & 7u) == 0 ? ST_REGULAR_BORN : ST_UPDATED);
+  st.status[rec_index(li, d.p_n, REC_STATUS)] = i == 0 ? (uint8_t)ST_TIMEPTC : (uint8_t)((h & 7u) == 0 ? ST_REGULAR_BORN : ST_UPDATED);
   st.w[rec_index(li, d.p_n, REC_W)] = 0.06f + (float)(h >> 20) * (0.3f / 4096.f);
   st.ts[rec_index(li, d.p_n, REC_TS)] = (uint16_t)stamp;
   st.track[rec_index(li, d.p_n, REC_TRACK)] = (uint16_t)(65524u + ((h >> 8) & 7u));

@@ -472,9 +472,9 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->st.ts = reinterpret_cast<uint16_t *>(m->st.rec + 4 * (size_t)d.S);
   m->st.track = reinterpret_cast<uint16_t *>(m->st.rec + 6 * (size_t)d.S);
   m->st.label = reinterpret_cast<uint8_t *>(m->st.rec + 8 * (size_t)d.S);
+  m->st.status = m->st.rec + 9 * (size_t)d.S;
   A(m->st.vts, d.v_count);
   A(m->st.vflag, d.v_count);
-  A(m->st.status, n_slots);
   A(m->st.owner, n_slots);
   A(m->st.owner_flag, (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK);
   A(m->st.res, d.v_count);
@@ -1343,16 +1343,18 @@ sdm_status sdm_dump_state(sdm_map *m, float *px, float *py, float *pz, float *w,
     (void)hipFree(tz);
     (void)hipFree(tf);
   }
-  if (w || ts || track || label) {  // record fields -> the reference's slot order, through dense temporaries
+  if (w || ts || track || label || status) {  // record fields -> the reference's slot order, through dense temporaries
     float *tw;
     uint16_t *tts, *ttr;
-    uint8_t *tl;
+    uint8_t *tl, *tst;
     HIP_TRY(dev_alloc(&tw, n));
     HIP_TRY(dev_alloc(&tts, n));
     HIP_TRY(dev_alloc(&ttr, n));
     HIP_TRY(dev_alloc(&tl, n));
+    HIP_TRY(dev_alloc(&tst, n));
     launch_vts_sync(m->d, m->st, 1, s);  // slot 0 of the exported stamp row carries the voxel stamp
-    launch_rec_unpack(m->d, m->st, tw, tts, ttr, tl, s);
+    launch_rec_unpack(m->d, m->st, tw, tts, ttr, tl, tst, s);
+    if (status) HIP_TRY(hipMemcpyAsync(status, tst, n, hipMemcpyDeviceToHost, s));
     if (w) HIP_TRY(hipMemcpyAsync(w, tw, n * 4, hipMemcpyDeviceToHost, s));
     if (ts) HIP_TRY(hipMemcpyAsync(ts, tts, n * 2, hipMemcpyDeviceToHost, s));
     if (track) HIP_TRY(hipMemcpyAsync(track, ttr, n * 2, hipMemcpyDeviceToHost, s));
@@ -1362,8 +1364,8 @@ sdm_status sdm_dump_state(sdm_map *m, float *px, float *py, float *pz, float *w,
     (void)hipFree(tts);
     (void)hipFree(ttr);
     (void)hipFree(tl);
+    (void)hipFree(tst);
   }
-  if (status) HIP_TRY(hipMemcpyAsync(status, m->st.status, n, hipMemcpyDeviceToHost, s));
   if (owner) HIP_TRY(hipMemcpyAsync(owner, m->st.owner, n * 2, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return SDM_OK;
@@ -1390,23 +1392,25 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
   {
     float *tw;
     uint16_t *tts, *ttr;
-    uint8_t *tl;
+    uint8_t *tl, *tst;
     HIP_TRY(dev_alloc(&tw, n));
     HIP_TRY(dev_alloc(&tts, n));
     HIP_TRY(dev_alloc(&ttr, n));
     HIP_TRY(dev_alloc(&tl, n));
+    HIP_TRY(dev_alloc(&tst, n));
+    HIP_TRY(hipMemcpyAsync(tst, status, n, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(tw, w, n * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(tts, ts, n * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ttr, track, n * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(tl, label, n, hipMemcpyHostToDevice, s));
-    launch_rec_pack(m->d, m->st, tw, tts, ttr, tl, s);
+    launch_rec_pack(m->d, m->st, tw, tts, ttr, tl, tst, s);
     HIP_TRY(hipStreamSynchronize(s));
     (void)hipFree(tw);
     (void)hipFree(tts);
     (void)hipFree(ttr);
     (void)hipFree(tl);
+    (void)hipFree(tst);
   }
-  HIP_TRY(hipMemcpyAsync(m->st.status, status, n, hipMemcpyHostToDevice, s));
   if (owner) HIP_TRY(hipMemcpyAsync(m->st.owner, owner, n * 2, hipMemcpyHostToDevice, s));
   else HIP_TRY(hipMemsetAsync(m->st.owner, 0xFF, n * 2, s));
   launch_owner_flags(m->d, m->st, s);

@@ -187,9 +187,9 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
   nz = nz + st.noise[(draw + 3) % flt.noise_n];
   const float pw = st.w[rec_index(li, d.p_n, REC_W)];
   const uint16_t pts = st.ts[rec_index(li, d.p_n, REC_TS)], ptrack = st.track[rec_index(li, d.p_n, REC_TRACK)];
-  const uint8_t plabel = st.label[rec_index(li, d.p_n, REC_LABEL)], pstatus = st.status[li];
+  const uint8_t plabel = st.label[rec_index(li, d.p_n, REC_LABEL)], pstatus = st.status[rec_index(li, d.p_n, REC_STATUS)];
   const uint16_t powner = ms.track[obj];
-  st.status[li] = ST_INVALID;  // deleteParticleByIndex
+  st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_INVALID;  // deleteParticleByIndex
   st.owner[li] = OWNER_NONE;   // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
   uint32_t rx, ry, rz;
   uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
     const size_t base = (size_t)lv * S;
     uint8_t stv[S];
     uint16_t tsv[S];
-    __builtin_memcpy(stv, st.status + base, S);
+    __builtin_memcpy(stv, st.status + base * REC_STATUS, S);
     __builtin_memcpy(tsv, st.ts + base * REC_TS, 2 * S);
     uint32_t n_ok = 0;
     bool more = true, full = false;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
         st.ts[base * REC_TS + slot] = cts;
         st.track[base * REC_TRACK + slot] = c.track;
         st.label[base * REC_LABEL + slot] = c.label;
-        st.status[base + slot] = cs;
+        st.status[base * REC_STATUS + slot] = cs;
         st.owner[base + slot] = c.owner;  // new index joins the object's set
         st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
 #pragma unroll
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
 }
 
 // removeObjectByTrackID (object_layer.h:414-425): every index of the set -> INVALID, set erased.
-__global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const uint16_t *__restrict__ tracks, int n) {
+__global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const uint16_t *__restrict__ tracks, int n, int p_n) {
   if (st.owner_flag[blockIdx.x] == 0) return;  // one block per OWNER_CHUNK slots
   size_t i = (size_t)blockIdx.x * OWNER_CHUNK + threadIdx.x;
   size_t end = (size_t)(blockIdx.x + 1) * OWNER_CHUNK;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
     if (o == OWNER_NONE) continue;
     for (int k = 0; k < n; ++k)
       if (tracks[k] == o) {
-        st.status[i] = ST_INVALID;
+        st.status[rec_index(i, p_n, REC_STATUS)] = ST_INVALID;
         st.owner[i] = OWNER_NONE;
         break;
       }
@@ -534,7 +534,7 @@ void launch_moves_finish(const Dims &d, const Filter &flt, int n_obj, const Stat
 void launch_remove(const Dims &d, const State &st, const uint16_t *tracks_dev, int n, hipStream_t s) {
   if (n <= 0) return;
   const size_t n_slots = (size_t)d.v_count * d.S;
-  hipLaunchKernelGGL(k_remove, dim3((unsigned)((n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK)), dim3(TPB), 0, s, st, n_slots, tracks_dev, n);
+  hipLaunchKernelGGL(k_remove, dim3((unsigned)((n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK)), dim3(TPB), 0, s, st, n_slots, tracks_dev, n, d.p_n);
 }
 
 }  // namespace sdm

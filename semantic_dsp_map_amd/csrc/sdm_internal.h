@@ -110,13 +110,15 @@ struct Cursors {
   int32_t move_cursor;
 };
 
-// Slot attributes that are only touched where a particle lives - weight, time stamp, track id, label - share one
-// record of 16*S bytes per voxel (128 B at S = 8: one cache line): [w: 4S | ts: 2S | track: 2S | label: S | pad 7S].
-// State::w / ts / track / label point at the first voxel's field; the index of slot i of local voxel lv is
-//   w[lv*S*REC_W + i], ts[lv*S*REC_TS + i], track[lv*S*REC_TRACK + i], label[lv*S*REC_LABEL + i].
-// Status, the per-voxel stamp, owner and position are streamed by whole-map sweeps and stay dense arrays.
+// Slot attributes that are only touched where a particle lives - weight, time stamp, track id, label, status - share
+// one record of 16*S bytes per voxel (128 B at S = 8: one cache line):
+//   [w: 4S | ts: 2S | track: 2S | label: S | status: S | pad 6S].
+// State::w / ts / track / label / status point at the first voxel's field; the index of slot i of local voxel lv is
+//   w[lv*S*REC_W + i], ts[lv*S*REC_TS + i], track[lv*S*REC_TRACK + i], label[lv*S*REC_LABEL + i],
+//   status[lv*S*REC_STATUS + i].
+// What whole-map sweeps stream stays dense: the per-voxel stamp and "something here" flag, owner, positions.
 constexpr size_t REC_BYTES_PER_SLOT = 16;
-constexpr size_t REC_W = 4, REC_TS = 8, REC_TRACK = 8, REC_LABEL = 16;
+constexpr size_t REC_W = 4, REC_TS = 8, REC_TRACK = 8, REC_LABEL = 16, REC_STATUS = 16;
 
 struct State {
   float4 *pos4 = nullptr;

@@ -108,8 +108,9 @@ void launch_pack_pos4(float4 *pos4, const float *px, const float *py, const floa
 void launch_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s);
 // slot 0 of the stamp array <-> the dense voxel-stamp array (state export / import)
 void launch_rec_pack(const Dims &d, const State &st, const float *w, const uint16_t *ts, const uint16_t *track,
-                     const uint8_t *label, hipStream_t s);
-void launch_rec_unpack(const Dims &d, const State &st, float *w, uint16_t *ts, uint16_t *track, uint8_t *label, hipStream_t s);
+                     const uint8_t *label, const uint8_t *status, hipStream_t s);
+void launch_rec_unpack(const Dims &d, const State &st, float *w, uint16_t *ts, uint16_t *track, uint8_t *label, uint8_t *status,
+                       hipStream_t s);
 void launch_fill_dense(const Dims &d, const State &st, uint32_t stamp, hipStream_t s);
 void launch_vts_sync(const Dims &d, const State &st, int to_slot0, hipStream_t s);
 void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t *flags, uint32_t *offs,
