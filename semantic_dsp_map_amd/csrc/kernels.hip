@@ -687,7 +687,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     if (vis[i]) pib[i] = atomicAdd(&sc.bin_count[pixv[i]], 1u);
   if (nv) {
     const uint32_t cap_sub = sc.cap_vis / VIS_SHARDS;
-    uint32_t k = atomicAdd(&sc.cnt->vis_shard[shard], nv);
+    uint32_t k = atomicAdd(&sc.cnt->shard[shard].vis, nv);
     if (k + nv <= cap_sub) {
       k += shard * cap_sub;
 #pragma unroll
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, S
   __syncthreads();
   const uint32_t nl = woff[VIS_WORDS];
   // voxels handled (statistics): one add per workgroup - an atomic per voxel on these 64 addresses cost 26 us
-  if (threadIdx.x == 0 && nl) atomicAdd(&sc.cnt->fv_shard[blockIdx.x & (VIS_SHARDS - 1)], nl);
+  if (threadIdx.x == 0 && nl) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].fv, nl);
   for (uint32_t li = threadIdx.x; li < nl; li += TPB) {
     int w = 0;
 #pragma unroll
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(TPB) void k_bin_fill(Scratch sc, uint32_t hw) {
   if (sc.cnt->overflow) return;
   const uint32_t cap_sub = sc.cap_vis / VIS_SHARDS;
   const uint32_t shard = blockIdx.y;
-  uint32_t n = sc.cnt->vis_shard[shard];
+  uint32_t n = sc.cnt->shard[shard].vis;
   if (n > cap_sub) n = cap_sub;
   const uint32_t base = shard * cap_sub;
   uint32_t stride = gridDim.x * blockDim.x;
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(TPB) void k_ck_light(Dims d, Filter flt, State st, 
   }
   if (total > light_max) {
     const uint32_t shard = blockIdx.x & (VIS_SHARDS - 1);
-    const uint32_t k = atomicAdd(&sc.cnt->heavy_shard[shard], 1u);
+    const uint32_t k = atomicAdd(&sc.cnt->shard[shard].heavy, 1u);
     sc.ck_heavy[shard * sc.cap_heavy + k] = (uint32_t)p;  // cap_heavy covers every pixel a shard's blocks can hold
     return;
   }
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
   const int lane = it * A7_ROWS + r;
   const int h = d.window_half;
   const uint32_t shard = blockIdx.y;
-  const uint32_t n = sc.cnt->heavy_shard[shard];
+  const uint32_t n = sc.cnt->shard[shard].heavy;
   const float *__restrict__ pdf = st.pdf;
   for (uint32_t q0 = blockIdx.x * A7_ITEMS; q0 < n; q0 += gridDim.x * A7_ITEMS) {
     const uint32_t q = q0 + it;
@@ -1425,9 +1425,9 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
   // same-address atomics retire one at a time: counters every wave bumps are sharded by block
   if (n_success) {
     st.vflag[v - d.v_begin] = 1;
-    atomicAdd(&sc.cnt->birth_shard[blockIdx.x & (VIS_SHARDS - 1)], n_success);
+    atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].birth, n_success);
   }
-  if (n_resamp) atomicAdd(&sc.cnt->resample_shard[blockIdx.x & (VIS_SHARDS - 1)], n_resamp);
+  if (n_resamp) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].resample, n_resamp);
 }
 
 // ------------------------------------------------------------------------------------ N1

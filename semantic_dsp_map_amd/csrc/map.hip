@@ -1216,12 +1216,12 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
   out->n_birth_success = c.n_birth_success;
   out->n_resampled_voxels = c.n_resampled;
   for (uint32_t k = 0; k < VIS_SHARDS; ++k) {
-    out->n_birth_success += c.birth_shard[k];
-    out->n_resampled_voxels += c.resample_shard[k];
+    out->n_birth_success += c.shard[k].birth;
+    out->n_resampled_voxels += c.shard[k].resample;
   }
   out->n_moved = c.n_moved;
   out->n_move_reinserted = c.n_move_reinserted;
-  for (uint32_t k = 0; k < VIS_SHARDS; ++k) out->n_frustum_voxels += c.fv_shard[k];
+  for (uint32_t k = 0; k < VIS_SHARDS; ++k) out->n_frustum_voxels += c.shard[k].fv;
   out->bfs_start_in_frustum = c.start_in_frustum;
   out->flood_rounds = c.flood_rounds;
   if (m->profiling) {

@@ -87,14 +87,20 @@ struct Counters {
   uint32_t n_valid_px;
   uint32_t n_move_voxels;  // voxels that receive at least one moved copy this frame
   uint32_t pad[7];
-  // Same-address atomics retire at ~12 ns each on MI355X, so counters that every wave bumps are sharded
-  // by block index; the per-shard visible-particle counters also index per-shard regions of the work list.
-  uint32_t vis_shard[64];
-  uint32_t fv_shard[64];
-  uint32_t heavy_shard[64];  // weight-update pass 1: pixels handed to the row-parallel kernel
-  uint32_t birth_shard[64];     // successful births
-  uint32_t resample_shard[64];  // voxels resampled
+  // Atomics on one cache line retire one at a time (~12 ns each on MI355X) - same address or not.  Counters that
+  // every wave bumps are therefore sharded by block index, one 128-byte line per shard; the per-shard
+  // visible-particle counters also index per-shard regions of the work list.
+  struct alignas(128) ShardLine {
+    uint32_t vis;       // visible particles appended to this shard's part of the work list
+    uint32_t fv;        // frustum voxels handled
+    uint32_t heavy;     // weight-update pass 1: pixels handed to the row-parallel kernel
+    uint32_t birth;     // successful births
+    uint32_t resample;  // voxels resampled
+    uint32_t pad[27];
+  };
+  ShardLine shard[64];
 };
+static_assert(sizeof(Counters::ShardLine) == 128, "one cache line per shard");
 constexpr uint32_t VIS_SHARDS = 64;
 constexpr uint32_t OWNER_CHUNK = 4096;  // slots per owner_flag byte (= slots per block of the move sweep)
 // Slab stamps written by this frame's ring shift (mc_ring/operations.h:1131-1181), applied on the device by the
