@@ -1711,7 +1711,7 @@ void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const
   hipLaunchKernelGGL(k_ck_finish, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, parts, n_parts);
 }
 void launch_weight(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s) {
-  hipLaunchKernelGGL(k_weight, dim3(16384), dim3(A7_ROWS, A7_ITEMS), 0, s, d, f, flt, st, sc);
+  hipLaunchKernelGGL(k_weight, dim3(2048), dim3(A7_ROWS, A7_ITEMS), 0, s, d, f, flt, st, sc);
 }
 
 // Birth candidates and their stable sort by target voxel depend on the input cloud only: side stream.
