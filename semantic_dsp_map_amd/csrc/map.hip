@@ -60,7 +60,11 @@ struct sdm_map {
   hipStream_t own_stream = nullptr;
   // side streams: the frustum reach set (pose only) and the birth candidates + sort (input cloud only) do not depend
   // on the map state, so they run next to the object-move chain and join the main stream through events
-  hipStream_t s_frustum = nullptr, s_birth = nullptr;
+  hipStream_t s_frustum = nullptr, s_birth = nullptr, s_moves = nullptr;
+  // ev_state: the particles of the last frame are final (after its births, before its sweep); the next frame's
+  // member count of the moving objects starts there, next to the sweep
+  hipEvent_t ev_state = nullptr, ev_counts = nullptr;
+  bool state_event_valid = false;
   hipEvent_t ev_begin = nullptr, ev_frustum = nullptr, ev_birth = nullptr;
   int birth_which = 0;
   bool side_pending = false;
@@ -458,6 +462,9 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->stream = m->own_stream;
   HIP_TRY(hipStreamCreateWithFlags(&m->s_frustum, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&m->s_birth, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&m->s_moves, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_state, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_begin, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_frustum, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_birth, hipEventDisableTiming));
@@ -542,6 +549,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   size_t scan_need = std::max({scan_scratch_elems(hw + 1), scan_scratch_elems(mv_cnt_n), scan_scratch_elems((size_t)d.v_count + 1)});
   A(sc.scan_scratch, scan_need + 16);
   A(sc.scan_scratch_b, scan_scratch_elems(hw + 1) + 16);
+  A(sc.scan_scratch_m, scan_scratch_elems(move_count_elems()) + 16);
   A(sc.mv_head, d.v_count);
   HIP_TRY(hipMemset(sc.mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t)));  // MV_NIL; the replay leaves it that way
   A(sc.mv_next, sc.cap_move);
@@ -588,6 +596,10 @@ sdm_status sdm_destroy(sdm_map *m) {
     for (int i = 0; i < 9; ++i) (void)hipEventDestroy(m->ev[i]);
   if (m->s_frustum) (void)hipStreamSynchronize(m->s_frustum);
   if (m->s_birth) (void)hipStreamSynchronize(m->s_birth);
+  if (m->s_moves) (void)hipStreamSynchronize(m->s_moves);
+  if (m->ev_state) (void)hipEventDestroy(m->ev_state);
+  if (m->ev_counts) (void)hipEventDestroy(m->ev_counts);
+  if (m->s_moves) (void)hipStreamDestroy(m->s_moves);
   if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
   if (m->ev_frustum) (void)hipEventDestroy(m->ev_frustum);
   if (m->ev_birth) (void)hipEventDestroy(m->ev_birth);
@@ -603,6 +615,7 @@ sdm_status sdm_destroy(sdm_map *m) {
 sdm_status sdm_clear(sdm_map *m) {
   if (!m) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
+  m->state_event_valid = false;
   host_initialize(m);
   HIP_TRY(hipMemsetAsync(m->sc.mv_head, 0xff, (size_t)m->d.v_count * sizeof(uint32_t), m->stream));
   launch_clear(m->d, m->st, m->stream);
@@ -755,8 +768,16 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
       memcpy(ms.T[k], moves[k].T, 12 * sizeof(float));
     }
     m->n_moves = n_moves;
-    launch_moves_count(d, ms, n_moves, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, s);
+    // The member count only reads the owner sets, which were final when the previous frame's births were done: it runs
+    // on its own stream from that point on (next to the previous frame's sweep when frames are issued back to back)
+    // and the main stream picks its result up here.
+    if (!m->state_event_valid) HIP_TRY(hipEventRecord(m->ev_state, s));
+    HIP_TRY(hipStreamWaitEvent(m->s_moves, m->ev_state, 0));
+    launch_moves_count(d, ms, n_moves, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves);
+    HIP_TRY(hipEventRecord(m->ev_counts, m->s_moves));
+    HIP_TRY(hipStreamWaitEvent(s, m->ev_counts, 0));
   }
+  m->state_event_valid = false;  // set again when this frame's births are done
   if (n_remove > 0) {
     std::vector<uint16_t> tr(n_remove);
     for (int k = 0; k < n_remove; ++k) tr[k] = (uint16_t)remove_tracks[k];
@@ -874,6 +895,8 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
   if (done(5)) return SDM_OK;
   HIP_TRY(hipStreamWaitEvent(s, m->ev_birth, 0));  // join the birth-candidate stream
   launch_birth_replay(d, m->f, m->flt, m->st, m->sc, m->birth_which, s);
+  HIP_TRY(hipEventRecord(m->ev_state, s));
+  m->state_event_valid = true;
   mark(6);
   if (done(6)) return SDM_OK;
   if (!(flags & SDM_SKIP_OCCUPANCY)) launch_occupancy(d, m->flt, m->st, s);
@@ -1375,6 +1398,7 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
                           const uint16_t *ts, const uint16_t *track, const uint8_t *label, const uint8_t *status,
                           const uint8_t *forget, const uint16_t *owner) {
   if (!m || !px || !py || !pz || !w || !ts || !track || !label || !status || !forget) return SDM_ERR_INVALID_ARGUMENT;
+  m->state_event_valid = false;
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t s = m->stream;
   const size_t n = (size_t)m->d.v_count * m->d.S;

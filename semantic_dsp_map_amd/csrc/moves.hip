@@ -39,12 +39,15 @@ __device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint16_t *tracks
 // flag bytes, one block-wide scan of the per-thread counts per 32 K flags).  Dynamic objects touch a few hundred of
 // the map's tens of thousands of chunks; everything after this works on the list only.
 __global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *__restrict__ owner_flag, uint32_t n_flags,
-                                                      uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Counters *cnt,
+                                                      uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Cursors *cur,
                                                       uint32_t *__restrict__ cnt_tail) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t running;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (threadIdx.x == 0) running = 0;
+  if (threadIdx.x == 0) {
+    running = 0;
+    cur->move_list_overflow = 0;
+  }
   __syncthreads();
   constexpr uint32_t PER = 32;
   for (uint32_t tile = 0; tile < n_flags; tile += 1024 * PER) {
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *__restrict_
       const int j = __ffs((int)mm) - 1;
       mm &= mm - 1;
       if (pos < MV_LIST_CAP) list[pos] = first + (uint32_t)j;
-      else cnt->overflow = 1;
+      else cur->move_list_overflow = 1;
       ++pos;
     }
     __syncthreads();
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
       total = offs[(size_t)n_obj * MV_LIST_CAP];
     }
     sc.cnt->n_moved = total;
-    if (total > sc.cap_move) sc.cnt->overflow = 1;
+    if (total > sc.cap_move || sc.cur->move_list_overflow) sc.cnt->overflow = 1;
   }
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (uint32_t pos = blockIdx.x; pos < n; pos += gridDim.x) {
@@ -500,11 +503,11 @@ void launch_moves_count(const Dims &d, const MoveSet &ms_dev, int n_obj, const S
   const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t slot_base = (size_t)d.v_begin << d.p_n;
   const size_t n_cnt = (size_t)n_obj * MV_LIST_CAP + 1;
-  hipLaunchKernelGGL(k_move_chunks, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cnt,
+  hipLaunchKernelGGL(k_move_chunks, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cur,
                      sc.mv_cnt + (n_cnt - 1));
   hipLaunchKernelGGL(k_move_count, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, ms_dev, sc.mv_cnt, n_obj, st.owner_flag, sc.mv_list,
                      sc.mv_nlist);
-  exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch, s);
+  exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch_m, s);
   // the per-object counts are only needed as a separate row when they are exchanged between shards
   if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, n_obj, counts_local, sc);
 }

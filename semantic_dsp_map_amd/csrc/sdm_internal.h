@@ -114,6 +114,9 @@ struct StampUpdates {
 struct Cursors {
   int32_t birth_cursor;
   int32_t move_cursor;
+  // set by the member count of the move stage when its chunk list overflows; that count may run before the frame's
+  // counters are zeroed (it is started as soon as the previous frame's particles are final), so it cannot use them
+  uint32_t move_list_overflow;
 };
 
 // Slot attributes that are only touched where a particle lives - weight, time stamp, track id, label, status - share

@@ -64,6 +64,7 @@ struct Scratch {
   // generic
   uint32_t *scan_scratch = nullptr, *sort_scratch = nullptr;
   uint32_t *scan_scratch_b = nullptr;   // births run on their own stream
+  uint32_t *scan_scratch_m = nullptr;   // so does the member count of the move stage
   // sort double buffers of the move re-insertion (the birth sort runs concurrently on another stream)
   // re-insertion of the moved copies: per target voxel a linked list of copy ranks (mv_head, one entry per voxel of the
   // shard, MV_NIL when idle; mv_next per rank) and the list of voxels that got a list this frame
