@@ -76,7 +76,7 @@ __global__ __launch_bounds__(TPB) void k_clear_status(uint8_t *__restrict__ stat
 __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__restrict__ bin_count, uint32_t n_bins,
                                                       State st, StampUpdates su) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < sizeof(Counters) / 4) reinterpret_cast<uint32_t *>(cnt)[i] = 0;
+  if (i < offsetof(Counters, flood_complex) / 4) reinterpret_cast<uint32_t *>(cnt)[i] = 0;  // the flood flags belong to the frustum chain
   if (i < (uint32_t)su.n) {  // this frame's recycled slabs (no host-to-device copy of the stamp arrays)
     const uint32_t e = su.entry[i], axis = e >> 12, idx = e & 0xfffu;
     uint32_t *arr = axis == 0 ? st.stamps_x : (axis == 1 ? st.stamps_y : st.stamps_z);
@@ -288,7 +288,12 @@ __global__ __launch_bounds__(TPB) void k_vts_from_slot0(Dims d, State st) {
 // Both paths are compared with the oracle's literal BFS in the parity tests.
 
 // Frustum vertex mask (isPointInFrustum, operations.h:1240-1258, 1338-1340): one wave per 64 vertices along x.
-__global__ __launch_bounds__(TPB) void k_vertex_mask(Dims d, Frame f, uint64_t *__restrict__ M, int wpl) {
+__global__ __launch_bounds__(TPB) void k_vertex_mask(Dims d, Frame f, uint64_t *__restrict__ M, int wpl, Counters *cnt) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // first kernel of the frustum chain: its flags start clean
+    cnt->flood_complex = 0;
+    cnt->flood_rounds = 0;
+    cnt->start_in_frustum = 0;
+  }
   const int VY = d.NY + 1;
   const int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
   uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1682,7 +1687,7 @@ void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_
   const int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
   const int nyw = (f.bb1[1] >> 6) - (f.bb0[1] >> 6) + 1;
   const size_t n_words = (size_t)ny * nz * sc.wpl;
-  hipLaunchKernelGGL(k_vertex_mask, dim3(blocks_for(n_words * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl);
+  hipLaunchKernelGGL(k_vertex_mask, dim3(blocks_for(n_words * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl, sc.cnt);
   hipLaunchKernelGGL(k_line_info, dim3(blocks_for((size_t)nyw * nz * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ne,
                      sc.line_ey, sc.line_ez, sc.cnt);
   hipLaunchKernelGGL(k_flood2d, dim3(1), dim3(TPB), (size_t)nz * nyw * 8 * 4, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ey, sc.line_ez,

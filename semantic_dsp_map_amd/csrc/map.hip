@@ -744,18 +744,18 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
   HIP_TRY(hipEventRecord(m->ev_begin, s));
   m->side_pending = false;
   if (!done(3)) {
-    hipStream_t sf = getenv("SDM_SIDE") ? s : m->s_frustum;  // TEMP experiment
-    HIP_TRY(hipStreamWaitEvent(sf, m->ev_begin, 0));
+    // the reach set depends on the pose only; its buffers were last read by the previous frame's visibility pass, so
+    // with frames issued back to back it runs next to the previous frame's sweep
+    HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->state_event_valid ? m->ev_state : m->ev_begin, 0));
     m->sc.force_generic = m->force_generic_flood;
-    launch_frustum(d, m->f, m->sc, m->force_generic_flood, sf);
-    HIP_TRY(hipEventRecord(m->ev_frustum, sf));
+    launch_frustum(d, m->f, m->sc, m->force_generic_flood, m->s_frustum);
+    HIP_TRY(hipEventRecord(m->ev_frustum, m->s_frustum));
     m->side_pending = true;
   }
   if (!done(5)) {
-    hipStream_t sb = getenv("SDM_SIDE") ? s : m->s_birth;  // TEMP experiment
-    HIP_TRY(hipStreamWaitEvent(sb, m->ev_begin, 0));
-    m->birth_which = launch_birth_prepare(d, m->f, m->flt, m->bo, m->st, m->sc, sb);
-    HIP_TRY(hipEventRecord(m->ev_birth, sb));
+    HIP_TRY(hipStreamWaitEvent(m->s_birth, m->ev_begin, 0));
+    m->birth_which = launch_birth_prepare(d, m->f, m->flt, m->bo, m->st, m->sc, m->s_birth);
+    HIP_TRY(hipEventRecord(m->ev_birth, m->s_birth));
   }
 
   // P2 (first part): collect the moving objects' particles (semantic_dsp_map.h:588-693)

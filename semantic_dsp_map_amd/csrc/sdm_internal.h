@@ -79,10 +79,6 @@ struct Counters {
   uint32_t n_frustum_voxels;
   uint32_t n_occupied;
   uint32_t n_free;
-  uint32_t flood_complex;  // some x-line of the frustum mask is not one contiguous run
-  uint32_t flood_pad[7];
-  uint32_t flood_rounds;
-  uint32_t start_in_frustum;
   uint32_t overflow;
   uint32_t n_valid_px;
   uint32_t n_move_voxels;  // voxels that receive at least one moved copy this frame
@@ -99,6 +95,12 @@ struct Counters {
     uint32_t pad[27];
   };
   ShardLine shard[64];
+  // Written by the frustum chain, which may run ahead of the frame's k_frame_begin (it starts when the previous
+  // frame's particles are final): not zeroed with the rest, the chain's first kernel resets them.
+  uint32_t flood_complex;  // some x-line of the frustum mask is not one contiguous run
+  uint32_t flood_rounds;
+  uint32_t start_in_frustum;
+  uint32_t flood_pad[29];
 };
 static_assert(sizeof(Counters::ShardLine) == 128, "one cache line per shard");
 constexpr uint32_t VIS_SHARDS = 64;
