@@ -1,7 +1,8 @@
 // kernels.hip — the per-frame particle/voxel kernels of libsdm_hip (gfx950).
 //
 // Each kernel restates one CPU loop of the reference (file:line cited per kernel) as a
-// data-parallel pass over SoA slot arrays.  Sequential-order semantics of the reference
+// data-parallel pass over the layout of sdm_internal.h (dense per-voxel arrays for what whole-map sweeps stream,
+// one record per voxel for what only live voxels need).  Sequential-order semantics of the reference
 // (first vacant slot, 9-pass stride-3 birth raster, one resample per voxel per frame) are
 // preserved by grouping work per voxel and replaying each voxel's ordered list in one thread:
 // all state such a list touches is voxel-local.
@@ -19,7 +20,7 @@ namespace {
 
 constexpr int TPB = 256;
 
-// Whole-voxel fetch: all S slots of one SoA array with the widest aligned vector loads (16 B pieces).  The copy goes
+// Whole-voxel fetch: all S slots of one field with the widest aligned vector loads (16 B pieces).  The copy goes
 // through a plain vector type so that the compiler cannot narrow it to the bytes it happens to use (slot 0 of
 // most arrays is dead, which otherwise splits a 32-byte row into dword/dwordx3 pieces).
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -282,9 +283,9 @@ __global__ __launch_bounds__(TPB) void k_vts_from_slot0(Dims d, State st) {
 //   3. k_flood2d        when every line is simple, a line is reached as a whole or not at all, so the component is a
 //                       flood fill over LINES in the (y,z) plane: one workgroup, reach bitmap in LDS, word-parallel
 //                       fills along y, carry sweeps along z, until nothing changes;
-//   4. k_reach_expand   R = reached line ? M : 0;
-//   5. k_flood_generic  only if some line was not simple (float rounding exactly on a frustum plane): the plain 3-D
+//   4. k_flood_generic  only if some line was not simple (float rounding exactly on a frustum plane): the plain 3-D
 //                       bit flood, one workgroup, exact for any mask.
+// The visibility pass reads "reached" as (line reached & in-frustum bit) in the simple case, the flooded bits otherwise.
 // Both paths are compared with the oracle's literal BFS in the parity tests.
 
 // Frustum vertex mask (isPointInFrustum, operations.h:1240-1258, 1338-1340): one wave per 64 vertices along x.
@@ -489,22 +490,6 @@ __global__ __launch_bounds__(TPB) void k_flood2d(Dims d, Frame f, const uint64_t
   }
   for (int i = threadIdx.x; i < nz * nyw; i += blockDim.x) R2D[(size_t)(z0 + i / nyw) * wy + yw0 + i % nyw] = r[i];
   if (threadIdx.x == 0) cnt->flood_rounds = rounds;
-}
-
-// R = reached line ? M : 0 for every word of the frustum box
-__global__ __launch_bounds__(TPB) void k_reach_expand(Dims d, Frame f, const uint64_t *__restrict__ M,
-                                                      uint64_t *__restrict__ R, int wpl, int wy,
-                                                      const uint64_t *__restrict__ R2D) {
-  const int VY = d.NY + 1;
-  const int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (uint32_t)ny * nz * wpl) return;
-  int xw = t % wpl;
-  int l = t / wpl;
-  int y = f.bb0[1] + l % ny, z = f.bb0[2] + l / ny;
-  bool reached = (R2D[(size_t)z * wy + (y >> 6)] >> (y & 63)) & 1ull;
-  size_t o = ((size_t)z * VY + y) * wpl + xw;
-  R[o] = reached ? M[o] : 0ull;
 }
 
 // Exact 3-D bit flood for arbitrary masks (fallback, one workgroup): line fills along x, carry sweeps along y and z,

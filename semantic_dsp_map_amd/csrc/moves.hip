@@ -145,8 +145,8 @@ __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__
 // index.  Every shard publishes its per-object member counts (HALO_OBJ ints), the counts of all shards are gathered,
 // and the global rank of the j-th local member of object k on shard r is
 //     e = sum_{k'<k} sum_r' C[r'][k']  +  sum_{r'<r} C[r'][k]  +  j.
-// Moved copies are stored at index e, so a stable sort by target voxel keeps the reference's order without knowing
-// where a copy came from.  A copy whose target voxel belongs to another slab is exported as a 36-byte record.
+// Moved copies are stored at index e and replayed per target voxel in ascending e: the reference's order, without
+// knowing where a copy came from.  A copy whose target voxel belongs to another slab is exported as a 36-byte record.
 struct HaloRecord {
   float x, y, z;
   uint32_t forget_bits;
@@ -249,7 +249,6 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t n = *sc.mv_nlist;
   const size_t n_slots = (size_t)d.v_count * d.S;
-  const size_t slot_base = (size_t)d.v_begin << d.p_n;
   if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms.track[threadIdx.x] : OWNER_NONE;
   if ((int)threadIdx.x < n_obj) {
     // e = sum_{k'<k} sum_r' C[r'][k'] + sum_{r'<rank} C[r'][k] + j.  Single shard: the scanned count matrix already
@@ -501,7 +500,6 @@ void launch_moves_count(const Dims &d, const MoveSet &ms_dev, int n_obj, const S
                         hipStream_t s) {
   if (n_obj <= 0) return;
   const size_t n_slots = (size_t)d.v_count * d.S;
-  const size_t slot_base = (size_t)d.v_begin << d.p_n;
   const size_t n_cnt = (size_t)n_obj * MV_LIST_CAP + 1;
   hipLaunchKernelGGL(k_move_chunks, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cur,
                      sc.mv_cnt + (n_cnt - 1));

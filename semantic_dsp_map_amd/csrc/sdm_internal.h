@@ -1,13 +1,13 @@
 // sdm_internal.h — shared declarations of libsdm_hip (not part of the C ABI).
 //
-// Data layout in HBM (SoA over particle slots, index = voxel << p_n | slot, the
-// reference's particle index, mc_ring/operations.h:370,788):
-//   pos4   float4  x, y, z, forget_count (as uint bits)      16 B
-//   w      float   weight                                      4 B
-//   ts     u16     time stamp (slot 0 = the voxel's time particle)
-//   track  u16, label u8, status u8
-//   owner  u16     track id of the owner set holding this index, 0xFFFF = none
-// plus per-voxel results (8 B) and the three per-axis slab stamp arrays.
+// Data layout in HBM (particle index = voxel << p_n | slot, the reference's, mc_ring/operations.h:370,788):
+//   dense, per slot     pos4   float4  x, y, z, forget_count (as uint bits)
+//                       owner  u16     track id of the owner set holding this index, 0xFFFF = none
+//   dense, per voxel    vts    u16     observation stamp (the reference's slot-0 time particle)
+//                       vflag  u8      0 = every slot INVALID
+//                       res    8 B     result of the occupancy sweep
+//   one record per voxel (16*S bytes)  weight, time stamp, track, label, status of its S slots (see REC_* below)
+// plus the three per-axis slab stamp arrays.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
