@@ -279,6 +279,9 @@ sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_
                               const int32_t *remove_tracks, int32_t n_remove, uint32_t flags);
 
 /* ---- plain device buffers (for frames kept resident in HBM, see SDM_INPUT_ON_DEVICE) */
+/* page-locked host memory for input buffers (uploads then run at PCIe speed, beside the previous frame's kernels) */
+sdm_status sdm_host_alloc(size_t bytes, void **out);
+sdm_status sdm_host_free(void *p);
 sdm_status sdm_device_alloc(sdm_map *m, size_t bytes, void **out);
 sdm_status sdm_device_free(sdm_map *m, void *p);
 sdm_status sdm_device_upload(sdm_map *m, void *dst_dev, const void *src_host, size_t bytes);

@@ -106,6 +106,8 @@ def load_library():
         "sdm_update_raw": [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, i32, u32, i32],
         "sdm_update_raw_ex": [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, i32, u32, i32, vp],
         "sdm_get_labeled_cloud": [vp, vp],
+        "sdm_host_alloc": [C.c_size_t, C.POINTER(vp)],
+        "sdm_host_free": [vp],
         "sdm_update_begin": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32, C.POINTER(vp)],
         "sdm_update_finish": [vp, vp, i32, u32, i32],
         "sdm_frame_start": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32],

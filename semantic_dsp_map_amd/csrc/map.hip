@@ -101,12 +101,21 @@ struct sdm_map {
   sdm_labeled_point *d_cloud = nullptr;
   float *d_ck_part = nullptr;
   // N1 inputs: static mask, label->instance table, object masks (grown on demand)
-  uint8_t *d_static_mask = nullptr, *d_obj_masks = nullptr;
-  uint16_t *d_label_to_inst = nullptr;
-  int obj_masks_cap = 0;
+  // sdm_update_raw: two sets of device-side inputs, filled alternately on a copy stream, so that the upload (and
+  // BOOST-mode reduction) of a frame runs beside the previous frame's kernels
+  struct RawInputs {
+    float *depth = nullptr;
+    uint8_t *static_mask = nullptr, *obj_masks = nullptr;
+    uint16_t *label_to_inst = nullptr;
+    double *bbox = nullptr;  // ZED2: per-object boxes
+    int obj_masks_cap = 0;
+    hipEvent_t ev_free = nullptr;  // the frame that read this set has been issued up to its end
+  } raw[2];
+  int raw_next = 0;
+  hipStream_t s_copy = nullptr;
+  hipEvent_t ev_copy = nullptr;
   unsigned char *d_src_stage = nullptr;  // BOOST mode: one input image at the sensor's size
   size_t src_stage_bytes = 0;
-  double *d_bbox = nullptr;              // ZED2: per-object boxes
   MoveSet *d_moveset = nullptr;
   uint16_t *d_remove = nullptr;
   unsigned long long *d_u64 = nullptr;
@@ -532,9 +541,15 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   sc.cap_heavy = (uint32_t)(((hw + 255) / 256 + VIS_SHARDS - 1) / VIS_SHARDS * 256);
   A(sc.ck_heavy, (size_t)sc.cap_heavy * VIS_SHARDS);
   A(m->d_ck_part, hw);
-  A(m->d_static_mask, hw);
-  A(m->d_label_to_inst, 256);
-  A(m->d_bbox, 6 * MAX_CLOUD_OBJECTS);
+  for (auto &r : m->raw) {
+    A(r.depth, hw);
+    A(r.static_mask, hw);
+    A(r.label_to_inst, 256);
+    A(r.bbox, 6 * MAX_CLOUD_OBJECTS);
+    HIP_TRY(hipEventCreateWithFlags(&r.ev_free, hipEventDisableTiming));
+  }
+  HIP_TRY(hipStreamCreateWithFlags(&m->s_copy, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_copy, hipEventDisableTiming));
   A(sc.b_valid, hw + 1);
   A(sc.b_rank, hw + 1);
   sc.cap_move = (uint32_t)std::min<size_t>(n_slots, (size_t)1 << 18);  // moved particles per frame (objects hold <= ~1e5)
@@ -585,7 +600,7 @@ sdm_status sdm_destroy(sdm_map *m) {
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
   for (void *p : m->allocs) (void)hipFree(p);
-  void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points, m->d_obj_masks, m->d_src_stage};
+  void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points, m->raw[0].obj_masks, m->raw[1].obj_masks, m->d_src_stage};
   for (void *p : extra)
     if (p) (void)hipFree(p);
   if (m->comm) (void)ncclCommDestroy(m->comm);
@@ -597,6 +612,11 @@ sdm_status sdm_destroy(sdm_map *m) {
   if (m->s_frustum) (void)hipStreamSynchronize(m->s_frustum);
   if (m->s_birth) (void)hipStreamSynchronize(m->s_birth);
   if (m->s_moves) (void)hipStreamSynchronize(m->s_moves);
+  if (m->s_copy) (void)hipStreamSynchronize(m->s_copy);
+  for (auto &r : m->raw)
+    if (r.ev_free) (void)hipEventDestroy(r.ev_free);
+  if (m->ev_copy) (void)hipEventDestroy(m->ev_copy);
+  if (m->s_copy) (void)hipStreamDestroy(m->s_copy);
   if (m->ev_state) (void)hipEventDestroy(m->ev_state);
   if (m->ev_counts) (void)hipEventDestroy(m->ev_counts);
   if (m->s_moves) (void)hipStreamDestroy(m->s_moves);
@@ -957,48 +977,58 @@ sdm_status sdm_update_raw_ex(sdm_map *m, const float *depth, const uint8_t *stat
       m->src_stage_bytes = src_hw * 4;
     }
   }
+  // this frame's input set; the copy stream may fill it as soon as the frame that last read it is through
+  sdm_map::RawInputs &in = m->raw[m->raw_next];
+  m->raw_next ^= 1;
+  hipStream_t sc_ = m->s_copy;
+  HIP_TRY(hipStreamWaitEvent(sc_, in.ev_free, 0));
   // one input image -> its device buffer of the configured size
   auto stage_in = [&](const void *src, void *dst, int elem) -> sdm_status {
     if (!resize) {
-      HIP_TRY(hipMemcpyAsync(dst, src, hw * elem, kind, s));
+      HIP_TRY(hipMemcpyAsync(dst, src, hw * elem, kind, sc_));
       return SDM_OK;
     }
     const void *src_dev = src;
     if (!on_dev) {
-      HIP_TRY(hipMemcpyAsync(m->d_src_stage, src, src_hw * elem, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(m->d_src_stage, src, src_hw * elem, hipMemcpyHostToDevice, sc_));
       src_dev = m->d_src_stage;
     }
-    launch_manual_resize(d, src_dev, dst, opt->src_width, opt->src_height, opt->rescale, elem, s);
+    launch_manual_resize(d, src_dev, dst, opt->src_width, opt->src_height, opt->rescale, elem, sc_);
     return SDM_OK;
   };
-  if (n_objects > m->obj_masks_cap) {
-    HIP_TRY(hipStreamSynchronize(s));
-    if (m->d_obj_masks) HIP_TRY(hipFree(m->d_obj_masks));
-    m->d_obj_masks = nullptr;
-    HIP_TRY(dev_alloc(&m->d_obj_masks, hw * n_objects));
-    m->obj_masks_cap = n_objects;
+  if (n_objects > in.obj_masks_cap) {
+    HIP_TRY(hipStreamSynchronize(sc_));
+    if (in.obj_masks) HIP_TRY(hipFree(in.obj_masks));
+    in.obj_masks = nullptr;
+    HIP_TRY(dev_alloc(&in.obj_masks, hw * n_objects));
+    in.obj_masks_cap = n_objects;
   }
   sdm_status rc;
   const float *depth_dev = depth;
   if (!on_dev || resize) {
-    if ((rc = stage_in(depth, m->d_depth, 4)) != SDM_OK) return rc;
-    depth_dev = m->d_depth;
+    if ((rc = stage_in(depth, in.depth, 4)) != SDM_OK) return rc;
+    depth_dev = in.depth;
   }
   if (static_mask) {
-    if ((rc = stage_in(static_mask, m->d_static_mask, 1)) != SDM_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(m->d_label_to_inst, label_to_static_instance, 512, hipMemcpyHostToDevice, s));
+    if ((rc = stage_in(static_mask, in.static_mask, 1)) != SDM_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(in.label_to_inst, label_to_static_instance, 512, hipMemcpyHostToDevice, sc_));
   }
   CloudArgsHost a;
   memset(&a, 0, sizeof(a));
   for (int k = 0; k < n_objects; ++k) {
     if (!objects[k].mask) return SDM_ERR_INVALID_ARGUMENT;
-    if ((rc = stage_in(objects[k].mask, m->d_obj_masks + hw * k, 1)) != SDM_OK) return rc;
+    if ((rc = stage_in(objects[k].mask, in.obj_masks + hw * k, 1)) != SDM_OK) return rc;
     a.track[k] = objects[k].track_id;
     a.label[k] = objects[k].label_id;
   }
   a.sky_instance = opt ? opt->sky_instance : -1;
   a.has_bbox = opt && opt->object_bbox && n_objects > 0 ? 1 : 0;
-  if (a.has_bbox) HIP_TRY(hipMemcpyAsync(m->d_bbox, opt->object_bbox, sizeof(double) * 6 * n_objects, hipMemcpyHostToDevice, s));
+  if (a.has_bbox) HIP_TRY(hipMemcpyAsync(in.bbox, opt->object_bbox, sizeof(double) * 6 * n_objects, hipMemcpyHostToDevice, sc_));
+  HIP_TRY(hipEventRecord(m->ev_copy, sc_));
+  // host buffers belong to the caller again when this returns (nothing is retained): wait for the copies - the GPU is
+  // still busy with the previous frame on the main stream meanwhile
+  if (!on_dev) HIP_TRY(hipStreamSynchronize(sc_));
+  HIP_TRY(hipStreamWaitEvent(s, m->ev_copy, 0));
   // Eigen's Quaternion::toRotationMatrix in double (pointcloud_tools.h:107-110)
   {
     const double w = cam_q[0], x = cam_q[1], y = cam_q[2], z = cam_q[3];
@@ -1028,11 +1058,13 @@ sdm_status sdm_update_raw_ex(sdm_map *m, const float *depth, const uint8_t *stat
   a.consider_instance = (flags & SDM_NO_INSTANCES) ? 0 : 1;
   a.n_objects = n_objects;
   a.has_static = static_mask ? 1 : 0;
-  launch_labeled_cloud(d, a, depth_dev, m->d_static_mask, m->d_label_to_inst, m->d_obj_masks, m->d_bbox, m->d_cloud, s);
+  launch_labeled_cloud(d, a, depth_dev, in.static_mask, in.label_to_inst, in.obj_masks, in.bbox, m->d_cloud, s);
   const float posf[3] = {(float)cam_pos[0], (float)cam_pos[1], (float)cam_pos[2]};       // semantic_dsp_map.h:584
   const float qf[4] = {(float)cam_q[0], (float)cam_q[1], (float)cam_q[2], (float)cam_q[3]};  // :745
-  return sdm_update(m, depth_dev, m->d_cloud, posf, qf, moves, n_moves, remove_tracks, n_remove, flags | SDM_INPUT_ON_DEVICE,
-                    stop_after);
+  rc = sdm_update(m, depth_dev, m->d_cloud, posf, qf, moves, n_moves, remove_tracks, n_remove, flags | SDM_INPUT_ON_DEVICE,
+                  stop_after);
+  (void)hipEventRecord(in.ev_free, s);
+  return rc;
 }
 
 sdm_status sdm_get_labeled_cloud(sdm_map *m, sdm_labeled_point *out) {
@@ -1505,6 +1537,18 @@ sdm_status sdm_debug_fill_dense(sdm_map *m) {
   HIP_TRY(hipSetDevice(m->device));
   launch_fill_dense(m->d, m->st, m->global_time_stamp ? m->global_time_stamp : 1u, m->stream);
   HIP_TRY(hipStreamSynchronize(m->stream));
+  return SDM_OK;
+}
+
+// Page-locked host memory for the buffers handed to sdm_update / sdm_update_raw: uploads from it run at PCIe speed
+// and beside the kernels of the previous frame.
+sdm_status sdm_host_alloc(size_t bytes, void **out) {
+  if (!out || !bytes) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return SDM_OK;
+}
+sdm_status sdm_host_free(void *p) {
+  if (p) HIP_TRY(hipHostFree(p));
   return SDM_OK;
 }
 

@@ -6,7 +6,9 @@
 //
 //   g++ -O2 -std=c++17 -I include tools/replay/replay.cpp -o tools/replay/replay \
 //       semantic_dsp_map_amd/csrc/libsdm_hip.so -Wl,-rpath,$PWD/semantic_dsp_map_amd/csrc
-//   tools/replay/replay <clip.bin> [repeat]
+//   tools/replay/replay <clip.bin> [repeat] [pinned] [pipelined]
+//     pinned:    the frame buffers live in page-locked memory (sdm_host_alloc)
+//     pipelined: no synchronisation between frames - the upload of a frame runs beside the kernels of the previous one
 //
 // Clip file (little endian; written by semantic_dsp_map_amd/synth.py:write_clip):
 //   "SDMCLIP1" | sdm_config (80 B) | sdm_params (52 B) | u32 noise_n | f32 noise[noise_n] | u16 label_to_instance[256]
@@ -51,6 +53,11 @@ int main(int argc, char **argv) {
     return 1;
   }
   const int repeat = argc > 2 ? std::atoi(argv[2]) : 1;
+  bool pinned = false, pipelined = false;
+  for (int i = 3; i < argc; ++i) {
+    pinned = pinned || !std::strcmp(argv[i], "pinned");
+    pipelined = pipelined || !std::strcmp(argv[i], "pipelined");
+  }
   FILE *f = std::fopen(argv[1], "rb");
   if (!f) {
     std::perror(argv[1]);
@@ -96,27 +103,56 @@ int main(int argc, char **argv) {
   CHECK(sdm_create(&cfg, &m));
   CHECK(sdm_set_params(m, &prm));
   if (noise_n) CHECK(sdm_upload_noise_table(m, noise.data(), (int32_t)noise_n));
+  // page-locked copies of the per-frame buffers (what a node that owns its image buffers would allocate once)
+  struct PinnedFrame {
+    float *depth = nullptr;
+    uint8_t *static_mask = nullptr;
+    std::vector<uint8_t *> masks;
+  };
+  std::vector<PinnedFrame> pin(frames.size());
+  if (pinned)
+    for (size_t t = 0; t < frames.size(); ++t) {
+      CHECK(sdm_host_alloc(4 * hw, (void **)&pin[t].depth));
+      std::memcpy(pin[t].depth, frames[t].depth.data(), 4 * hw);
+      if (frames[t].has_static) {
+        CHECK(sdm_host_alloc(hw, (void **)&pin[t].static_mask));
+        std::memcpy(pin[t].static_mask, frames[t].static_mask.data(), hw);
+      }
+      for (auto &mk : frames[t].masks) {
+        uint8_t *p = nullptr;
+        CHECK(sdm_host_alloc(hw, (void **)&p));
+        std::memcpy(p, mk.data(), hw);
+        pin[t].masks.push_back(p);
+      }
+    }
   const size_t V = (size_t)1 << (cfg.x_n + cfg.y_n + cfg.z_n);
   std::vector<sdm_voxel_result> vox(V);
   double total_ms = 0.0;
   size_t n_updates = 0;
   for (int rep = 0; rep < repeat; ++rep) {
     if (rep) CHECK(sdm_clear(m));
+    CHECK(sdm_synchronize(m));
+    const auto r0 = std::chrono::steady_clock::now();
     for (size_t t = 0; t < frames.size(); ++t) {
       const Frame &fr = frames[t];
       std::vector<sdm_instance_mask> objs(fr.masks.size());
-      for (size_t k = 0; k < objs.size(); ++k) objs[k] = sdm_instance_mask{fr.track[k], fr.label[k], fr.masks[k].data()};
+      for (size_t k = 0; k < objs.size(); ++k)
+        objs[k] = sdm_instance_mask{fr.track[k], fr.label[k], pinned ? pin[t].masks[k] : fr.masks[k].data()};
+      const float *depth = pinned ? pin[t].depth : fr.depth.data();
+      const uint8_t *stat = !fr.has_static ? nullptr : (pinned ? pin[t].static_mask : fr.static_mask.data());
       const auto t0 = std::chrono::steady_clock::now();
-      CHECK(sdm_update_raw(m, fr.depth.data(), fr.has_static ? fr.static_mask.data() : nullptr, label_to_inst,
-                           objs.empty() ? nullptr : objs.data(), (int32_t)objs.size(), fr.pos, fr.q,
-                           fr.moves.empty() ? nullptr : fr.moves.data(), (int32_t)fr.moves.size(), nullptr, 0, 0,
+      CHECK(sdm_update_raw(m, depth, stat, label_to_inst, objs.empty() ? nullptr : objs.data(), (int32_t)objs.size(), fr.pos,
+                           fr.q, fr.moves.empty() ? nullptr : fr.moves.data(), (int32_t)fr.moves.size(), nullptr, 0, 0,
                            SDM_STAGE_ALL));
-      CHECK(sdm_synchronize(m));
-      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      total_ms += ms;
+      if (!pipelined) {
+        CHECK(sdm_synchronize(m));
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (rep == 0) std::printf("frame %zu: %.3f ms\n", t, ms);
+      }
       ++n_updates;
-      if (rep == 0) std::printf("frame %zu: %.3f ms\n", t, ms);
     }
+    CHECK(sdm_synchronize(m));
+    total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
   }
   CHECK(sdm_get_voxels(m, vox.data()));
   uint64_t h = 1469598103934665603ull;  // FNV-1a over the 8-byte results
@@ -126,7 +162,8 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 8; ++i) h = (h ^ b[i]) * 1099511628211ull;
     n_occ += r.occ > 0;
   }
-  std::printf("frames %zu  avg %.3f ms/frame (host buffers in, synchronous)  %.1f Mvoxels/s\n", n_updates, total_ms / n_updates,
+  std::printf("frames %zu  avg %.3f ms/frame (%s host buffers in, %s)  %.1f Mvoxels/s\n", n_updates, total_ms / n_updates,
+              pinned ? "page-locked" : "pageable", pipelined ? "frames issued back to back" : "synchronised after every frame",
               (double)V / (total_ms / n_updates) / 1e3);
   std::printf("occupied %zu  checksum %016llx\n", n_occ, (unsigned long long)h);
   sdm_destroy(m);
