@@ -66,7 +66,7 @@ def main():
     S = 1 << cfg["p_n"]
     n_frames = args.warmup + args.steps
 
-    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist, halo_cap=4096)
+    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist)
     m = eng.map
     # noise table: rocRAND on the device, read back so that the CPU baseline uses the same floats
     m.generate_noise_table(seed=20250217)
