@@ -1282,7 +1282,7 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
       if (stv[i] == ST_UPDATED) {
         stv[i] = ST_INVALID;
         st.status[base * REC_STATUS + i] = ST_INVALID;
-        if (st.owner[base + i] == st.track[base * REC_TRACK + i]) st.owner[base + i] = OWNER_NONE;  // removeParticleFromObj
+        owner_erase(st, base + i, st.track[base * REC_TRACK + i]);  // removeParticleFromObj
       }
     return true;
   }
@@ -1296,7 +1296,7 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
       if (run < thr) {
         stv[i] = ST_INVALID;
         st.status[base * REC_STATUS + i] = ST_INVALID;
-        if (st.owner[base + i] == st.track[base * REC_TRACK + i]) st.owner[base + i] = OWNER_NONE;
+        owner_erase(st, base + i, st.track[base * REC_TRACK + i]);
       } else {
         st.w[base * REC_W + i] = wpp;
         thr += wpp;
@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
           st.label[base * REC_LABEL + slot] = label;
           st.status[base * REC_STATUS + slot] = ST_REGULAR_BORN;
           if ((int)track <= d.max_movable) {  // addParticleToObj
-            st.owner[base + slot] = track;
+            if (!owner_insert(st, base + slot, track)) sc.cnt->overflow = 1;
             st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
           }
 #pragma unroll
@@ -1564,6 +1564,12 @@ __global__ __launch_bounds__(TPB) void k_count_owner(Dims d, State st, uint16_t 
   uint32_t c = 0;
   for (; i < n; i += (size_t)gridDim.x * blockDim.x)
     if (st.owner[i] == track) c++;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // older memberships the reference's set still holds
+    uint32_t na = st.alias[0];
+    if (na > ALIAS_CAP) na = ALIAS_CAP;
+    for (uint32_t k = 0; k < na; ++k)
+      if (st.alias[3 + 2 * k] == track) c++;
+  }
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
@@ -1639,6 +1645,7 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s) {
   hipMemsetAsync(st.vflag, 0, (size_t)d.v_count, s);
 
   hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
+  hipMemsetAsync(st.alias, 0, 8, s);  // no older memberships
   hipMemsetAsync(st.owner_flag, 0, (n + OWNER_CHUNK - 1) / OWNER_CHUNK, s);
   hipMemsetAsync(st.res, 0, (size_t)d.v_count * sizeof(sdm_voxel_result), s);
   hipLaunchKernelGGL(k_clear_status, dim3(4096), dim3(TPB), 0, s, st.status, (uint32_t)d.v_count, (uint32_t)(d.S * REC_STATUS));

@@ -493,6 +493,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(m->st.vflag, d.v_count);
   A(m->st.owner, n_slots);
   A(m->st.owner_flag, (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK);
+  A(m->st.alias, 2 + 2 * ALIAS_CAP);
+  HIP_TRY(hipMemset(m->st.alias, 0, 8));
   A(m->st.res, d.v_count);
   A(m->st.stamps_x, d.NX);
   A(m->st.stamps_y, d.NY);
@@ -1470,6 +1472,7 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
   if (owner) HIP_TRY(hipMemcpyAsync(m->st.owner, owner, n * 2, hipMemcpyHostToDevice, s));
   else HIP_TRY(hipMemsetAsync(m->st.owner, 0xFF, n * 2, s));
   launch_owner_flags(m->d, m->st, s);
+  HIP_TRY(hipMemsetAsync(m->st.alias, 0, 8, s));  // the imported owner array is all there is to the sets
   launch_vts_sync(m->d, m->st, 0, s);  // voxel stamps from slot 0 of the stamp rows, "something here" flags from the status rows
   HIP_TRY(hipStreamSynchronize(s));
   (void)hipFree(tx);

@@ -38,15 +38,37 @@ __device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint16_t *tracks
 // pass 0: ascending list of the chunks whose owner_flag is set (one workgroup; each thread takes 32 consecutive
 // flag bytes, one block-wide scan of the per-thread counts per 32 K flags).  Dynamic objects touch a few hundred of
 // the map's tens of thousands of chunks; everything after this works on the list only.
-__global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *__restrict__ owner_flag, uint32_t n_flags,
+__global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *owner_flag, uint32_t n_flags,
                                                       uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Cursors *cur,
-                                                      uint32_t *__restrict__ cnt_tail) {
+                                                      uint32_t *__restrict__ cnt_tail, uint32_t *__restrict__ alias,
+                                                      uint8_t *owner_flag_w) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t running;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) {
     running = 0;
     cur->move_list_overflow = 0;
+    // extra set memberships (State::alias): drop the deleted entries, and make sure the chunks of the live ones are
+    // on the list even if no slot of theirs has a primary owner any more
+    uint32_t na = alias[0], keep = 0;
+    if (na > ALIAS_CAP) {
+      na = ALIAS_CAP;
+      cur->move_list_overflow = 1;
+    }
+    for (uint32_t k = 0; k < na; ++k) {
+      const uint32_t idx = alias[2 + 2 * k], trk = alias[3 + 2 * k];
+      if (trk == OWNER_NONE) continue;
+      alias[2 + 2 * keep] = idx;
+      alias[3 + 2 * keep] = trk;
+      ++keep;
+      owner_flag_w[idx / OWNER_CHUNK] = 1;
+    }
+    for (uint32_t k = keep; k < na; ++k) {
+      alias[2 + 2 * k] = INVALID_INDEX;
+      alias[3 + 2 * k] = OWNER_NONE;
+    }
+    alias[0] = keep;
+    __threadfence();
   }
   __syncthreads();
   constexpr uint32_t PER = 32;
@@ -106,7 +128,7 @@ __global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *__restrict_
 __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__ owner, size_t n_slots,
                                                     const MoveSet ms, uint32_t *__restrict__ cnt, int n_obj,
                                                     uint8_t *__restrict__ owner_flag, const uint32_t *__restrict__ list,
-                                                    const uint32_t *__restrict__ n_list) {
+                                                    const uint32_t *__restrict__ n_list, const uint32_t *__restrict__ alias) {
   __shared__ uint32_t c[MAX_MOVE_OBJECTS];
   __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
   __shared__ uint32_t any_owner;
@@ -130,6 +152,16 @@ __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__
         uint16_t ow = owner[i];
         if (ow != OWNER_NONE) any_owner = 1;
         uint8_t o = obj_of(ow, tracks, n_obj);
+        if (o != 0xFF) atomicAdd(&c[o], 1u);
+      }
+    }
+    {  // older memberships the reference's sets still hold (State::alias; nearly always none)
+      const uint32_t na = alias[0] < ALIAS_CAP ? alias[0] : ALIAS_CAP;
+      for (uint32_t k = threadIdx.x; k < na; k += blockDim.x) {
+        const uint32_t idx = alias[2 + 2 * k], trk = alias[3 + 2 * k];
+        if (trk == OWNER_NONE || idx / MV_CHUNK != chunk) continue;
+        any_owner = 1;
+        const uint8_t o = obj_of((uint16_t)trk, tracks, n_obj);
         if (o != 0xFF) atomicAdd(&c[o], 1u);
       }
     }
@@ -177,8 +209,12 @@ __device__ __forceinline__ void move_link(const Dims &d, const Scratch &sc, uint
 }
 
 // one member of moving object `obj`, global rank e, local slot li
+// alias: the membership is an older one kept in State::alias (the slot's owner entry belongs to somebody else and
+// stays); copy_invalid: an object earlier in this frame's order already moved this very slot, the reference then
+// copies a particle whose status it has just set to INVALID (operations.h:339-349 run object by object).
 __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms, const State &st,
-                                         const Scratch &sc, int obj, uint32_t e, size_t li) {
+                                         const Scratch &sc, int obj, uint32_t e, size_t li, bool alias = false,
+                                         bool copy_invalid = false) {
   const float4 p = st.pos4[li];
   const float *T = ms.T[obj];
   float nx = row4(T + 0, p.x, p.y, p.z);
@@ -190,10 +226,11 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
   nz = nz + st.noise[(draw + 3) % flt.noise_n];
   const float pw = st.w[rec_index(li, d.p_n, REC_W)];
   const uint16_t pts = st.ts[rec_index(li, d.p_n, REC_TS)], ptrack = st.track[rec_index(li, d.p_n, REC_TRACK)];
-  const uint8_t plabel = st.label[rec_index(li, d.p_n, REC_LABEL)], pstatus = st.status[rec_index(li, d.p_n, REC_STATUS)];
+  const uint8_t plabel = st.label[rec_index(li, d.p_n, REC_LABEL)];
+  const uint8_t pstatus = copy_invalid ? (uint8_t)ST_INVALID : st.status[rec_index(li, d.p_n, REC_STATUS)];
   const uint16_t powner = ms.track[obj];
   st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_INVALID;  // deleteParticleByIndex
-  st.owner[li] = OWNER_NONE;   // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
+  if (!alias) st.owner[li] = OWNER_NONE;  // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
   uint32_t rx, ry, rz;
   uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
   if (v == INVALID_INDEX) return;  // left the map: dropped (operations.h:799-802)
@@ -246,6 +283,9 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
   __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
   __shared__ uint32_t e_shift[MAX_MOVE_OBJECTS];   // global rank of the object's first local member - its local offset
   __shared__ uint32_t block_total;
+  constexpr uint32_t CA_CAP = 32;
+  __shared__ uint32_t ca_idx[CA_CAP], ca_ent[CA_CAP], ca_n;
+  __shared__ uint8_t ca_obj[CA_CAP];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t n = *sc.mv_nlist;
   const size_t n_slots = (size_t)d.v_count * d.S;
@@ -287,7 +327,29 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
     }
     __syncthreads();
     if (block_total == 0) continue;  // no member of any moving object in this chunk
-    const size_t base = (size_t)sc.mv_list[pos] * MV_CHUNK;
+    const uint32_t chunk = sc.mv_list[pos];
+    const size_t base = (size_t)chunk * MV_CHUNK;
+    // older memberships of moving objects inside this chunk (State::alias): slot, object rank, entry
+    if (threadIdx.x == 0) ca_n = 0;
+    __syncthreads();
+    {
+      const uint32_t na = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
+      for (uint32_t k = threadIdx.x; k < na; k += blockDim.x) {
+        const uint32_t idx = st.alias[2 + 2 * k], trk = st.alias[3 + 2 * k];
+        if (trk == OWNER_NONE || idx / MV_CHUNK != chunk) continue;
+        const uint8_t o = obj_of((uint16_t)trk, tracks, n_obj);
+        if (o == 0xFF) continue;
+        const uint32_t c = atomicAdd(&ca_n, 1u);
+        if (c < CA_CAP) {
+          ca_idx[c] = idx;
+          ca_obj[c] = o;
+          ca_ent[c] = k;
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t n_ca = ca_n < CA_CAP ? ca_n : CA_CAP;
+    if (threadIdx.x == 0 && ca_n > CA_CAP) sc.cnt->overflow = 1;
     for (int r = 0; r < MV_ITEMS; ++r) {
       if (threadIdx.x < MAX_MOVE_OBJECTS) {
 #pragma unroll
@@ -295,25 +357,72 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
       }
       __syncthreads();
       const size_t li = base + (size_t)r * TPB + threadIdx.x;
-      uint8_t o = 0xFF;
+      uint8_t o = 0xFF, o2 = 0xFF;  // the slot's primary and (at most one) older membership among the moving objects
+      uint32_t ent2 = 0;
       if (li < n_slots) o = obj_of(st.owner[li], tracks, n_obj);
-      const bool valid = o != 0xFF;
-      uint64_t peers = __ballot(valid);
+      for (uint32_t c = 0; c < n_ca; ++c)
+        if (ca_idx[c] == (uint32_t)li) {
+          if (o2 != 0xFF) sc.cnt->overflow = 1;  // a slot in three sets at once: not handled
+          o2 = ca_obj[c];
+          ent2 = ca_ent[c];
+        }
+      const bool valid = o != 0xFF, valid2 = o2 != 0xFF;
+      uint32_t rank1 = 0, rank2 = 0;
+      if (n_ca == 0) {
+        uint64_t peers = __ballot(valid);
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        bool bit = (o >> b) & 1u;
-        uint64_t m = __ballot(bit);
-        peers &= bit ? m : ~m;
+        for (int b = 0; b < 6; ++b) {
+          bool bit = (o >> b) & 1u;
+          uint64_t m = __ballot(bit);
+          peers &= bit ? m : ~m;
+        }
+        rank1 = (uint32_t)__popcll(peers & lt_mask);
+        if (valid && rank1 == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
+      } else {
+        // members of object k in this wave = lanes whose primary OR older membership is k, in lane (= index) order
+        uint64_t b1[6], b2[6];
+        const uint64_t v1 = __ballot(valid), v2 = __ballot(valid2);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          b1[b] = __ballot((o >> b) & 1u);
+          b2[b] = __ballot((o2 >> b) & 1u);
+        }
+        auto members_of = [&](uint8_t x) {
+          uint64_t p1 = v1, p2 = v2;
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+            const bool bit = (x >> b) & 1u;
+            p1 &= bit ? b1[b] : ~b1[b];
+            p2 &= bit ? b2[b] : ~b2[b];
+          }
+          return p1 | p2;
+        };
+        if (valid) {
+          const uint64_t mm = members_of(o);
+          rank1 = (uint32_t)__popcll(mm & lt_mask);
+          if (rank1 == 0) wave_cnt[wid][o] = (uint32_t)__popcll(mm);
+        }
+        if (valid2) {
+          const uint64_t mm = members_of(o2);
+          rank2 = (uint32_t)__popcll(mm & lt_mask);
+          if (rank2 == 0) wave_cnt[wid][o2] = (uint32_t)__popcll(mm);
+        }
       }
-      const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
-      if (valid && rank_in_wave == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
       __syncthreads();
-      if (valid) {
-        uint32_t e = obj_base[o] + rank_in_wave;
+      // a slot that two moving objects hold is moved by both, in object order: the second copies a particle the first
+      // has just invalidated
+      const bool alias_first = valid2 && (!valid || o2 < o);
+#pragma unroll
+      for (int turn = 0; turn < 2; ++turn) {
+        const bool do_alias = (turn == 0) == alias_first;
+        if (do_alias ? !valid2 : !valid) continue;
+        const uint8_t ob = do_alias ? o2 : o;
+        uint32_t e = obj_base[ob] + (do_alias ? rank2 : rank1);
 #pragma unroll
         for (int w = 0; w < MV_WAVES; ++w)
-          if (w < wid) e += wave_cnt[w][o];
-        move_one(d, f, flt, ms, st, sc, (int)o, e, li);
+          if (w < wid) e += wave_cnt[w][ob];
+        move_one(d, f, flt, ms, st, sc, (int)ob, e, li, do_alias, turn == 1 && valid && valid2);
+        if (do_alias) st.alias[3 + 2 * ent2] = OWNER_NONE;  // the object's set is rebuilt from its re-inserted copies
       }
       __syncthreads();
       if (threadIdx.x < MAX_MOVE_OBJECTS) {
@@ -430,7 +539,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
         st.track[base * REC_TRACK + slot] = c.track;
         st.label[base * REC_LABEL + slot] = c.label;
         st.status[base * REC_STATUS + slot] = cs;
-        st.owner[base + slot] = c.owner;  // new index joins the object's set
+        if (!owner_insert(st, base + slot, c.owner)) sc.cnt->overflow = 1;  // new index joins the object's set
         st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
 #pragma unroll
         for (int i = 1; i < S; ++i)
@@ -450,6 +559,19 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
 
 // removeObjectByTrackID (object_layer.h:414-425): every index of the set -> INVALID, set erased.
 __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const uint16_t *__restrict__ tracks, int n, int p_n) {
+  if (blockIdx.x == 0) {  // older memberships of the removed objects (State::alias)
+    const uint32_t na = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
+    for (uint32_t k = threadIdx.x; k < na; k += blockDim.x) {
+      const uint32_t trk = st.alias[3 + 2 * k];
+      if (trk == OWNER_NONE) continue;
+      for (int q = 0; q < n; ++q)
+        if (tracks[q] == trk) {
+          st.status[rec_index(st.alias[2 + 2 * k], p_n, REC_STATUS)] = ST_INVALID;
+          st.alias[3 + 2 * k] = OWNER_NONE;
+          break;
+        }
+    }
+  }
   if (st.owner_flag[blockIdx.x] == 0) return;  // one block per OWNER_CHUNK slots
   size_t i = (size_t)blockIdx.x * OWNER_CHUNK + threadIdx.x;
   size_t end = (size_t)(blockIdx.x + 1) * OWNER_CHUNK;
@@ -502,9 +624,9 @@ void launch_moves_count(const Dims &d, const MoveSet &ms_dev, int n_obj, const S
   const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t n_cnt = (size_t)n_obj * MV_LIST_CAP + 1;
   hipLaunchKernelGGL(k_move_chunks, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cur,
-                     sc.mv_cnt + (n_cnt - 1));
+                     sc.mv_cnt + (n_cnt - 1), st.alias, st.owner_flag);
   hipLaunchKernelGGL(k_move_count, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, ms_dev, sc.mv_cnt, n_obj, st.owner_flag, sc.mv_list,
-                     sc.mv_nlist);
+                     sc.mv_nlist, st.alias);
   exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch_m, s);
   // the per-object counts are only needed as a separate row when they are exchanged between shards
   if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, n_obj, counts_local, sc);

@@ -150,11 +150,47 @@ struct State {
   // one byte per OWNER_CHUNK consecutive slots: 1 if any slot of the chunk may have an owner.  Lets the object-move
   // and removal sweeps skip the (vast) part of the map no dynamic object ever touched.
   uint8_t *owner_flag = nullptr;
+  // Extra memberships: the reference's owner sets (object_layer.h:20-52) are real sets, and a slot can sit in two of
+  // them - a stale index of object A whose slot is taken by a particle of object B stays in A's set until A moves or
+  // is removed.  owner[] holds the latest owner; every older membership that the reference still has is an entry
+  // (slot index, track) here.  alias[0] = number of entries (deleted ones carry track OWNER_NONE until the next
+  // compaction), entries from alias[2]: index, track.  Nearly always empty.
+  uint32_t *alias = nullptr;
   sdm_voxel_result *res = nullptr;
   uint32_t *stamps_x = nullptr, *stamps_y = nullptr, *stamps_z = nullptr;
   float *pdf = nullptr;
   float *noise = nullptr;
 };
+
+constexpr uint32_t ALIAS_CAP = 1024;
+
+// ObjectParticleHashMap::addParticleToObj (object_layer.h:31-33): slot li joins track's set.  li is the shard-local slot
+// index.  Returns false when the alias table is full.
+__device__ __forceinline__ bool owner_insert(const State &st, size_t li, uint16_t track) {
+  const uint16_t prev = st.owner[li];
+  st.owner[li] = track;
+  uint32_t n = st.alias[0];
+  if (n > ALIAS_CAP) n = ALIAS_CAP;
+  for (uint32_t k = 0; k < n; ++k)  // a set holds an index once
+    if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+  if (prev == OWNER_NONE || prev == track) return true;
+  const uint32_t k = atomicAdd(&st.alias[0], 1u);  // prev's set keeps the index
+  if (k >= ALIAS_CAP) return false;
+  st.alias[2 + 2 * k] = (uint32_t)li;
+  st.alias[3 + 2 * k] = prev;
+  return true;
+}
+// removeParticleFromObj (object_layer.h:35-37): slot li leaves track's set
+__device__ __forceinline__ void owner_erase(const State &st, size_t li, uint16_t track) {
+  if (st.owner[li] == track) {
+    st.owner[li] = OWNER_NONE;
+    return;
+  }
+  uint32_t n = st.alias[0];
+  if (n > ALIAS_CAP) n = ALIAS_CAP;
+  for (uint32_t k = 0; k < n; ++k)
+    if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+}
 
 // field index of global-slot-order index li = lv << p_n | slot (see the record layout above)
 __host__ __device__ __forceinline__ size_t rec_index(size_t li, int p_n, size_t mult) {
