@@ -128,3 +128,27 @@ def test_long_clip_stays_bit_exact():
     # the clip must have exercised the rare case: a slot that sits in two objects' sets at once (object_layer.h:20-52)
     assert o.stats()["alias_events"] > 0
     g.close()
+
+
+@pytest.mark.parametrize("cfg_name,params_name,kw", [
+    ("T1", "zed2", dict(n_dynamic=3, seed=4, yaw_rate_deg=3.0)),
+    ("T0", "noisy3", dict(n_dynamic=2, seed=8, yaw_rate_deg=-2.0)),
+    ("T0", "nodepthnoise", dict(n_dynamic=3, seed=13)),
+    ("T0", "kitti360", dict(n_dynamic=2, seed=17, yaw_rate_deg=1.0)),
+])
+def test_long_clips_other_presets(cfg_name, params_name, kw):
+    cfg = synth.CONFIGS[cfg_name]
+    params = synth.PARAMS[params_name]
+    sc = synth.Scene(cfg, **kw)
+    o, g = pu.make_pair(cfg, params, noise())
+    S = 1 << cfg["p_n"]
+    for t in range(100):
+        depth, cloud, pos, q = sc.render(t, params)
+        moves = sc.moves(t)
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves)
+        if t % 20 == 19:
+            g.synchronize()
+            rep = pu.compare_maps(o, g, S, tag="frame %d: " % t)
+            assert not rep, "\n".join(rep)
+    g.close()

