@@ -152,3 +152,23 @@ def test_long_clips_other_presets(cfg_name, params_name, kw):
             rep = pu.compare_maps(o, g, S, tag="frame %d: " % t)
             assert not rep, "\n".join(rep)
     g.close()
+
+
+def test_mid_size_preset_clip():
+    """C2 (the reference's ZED2 BOOST-mode grid: 128^3 x 4 slots, 640 x 360, window 3), 30 frames free-running."""
+    cfg = synth.CONFIGS["C2"]
+    params = synth.PARAMS["zed2"]
+    sc = synth.Scene(cfg, n_dynamic=3, seed=6, yaw_rate_deg=2.0)
+    o, g = pu.make_pair(cfg, params, noise())
+    S = 1 << cfg["p_n"]
+    for t in range(30):
+        depth, cloud, pos, q = sc.render(t, params)
+        moves = sc.moves(t)
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves)
+        if t % 10 == 9:
+            g.synchronize()
+            rep = pu.compare_maps(o, g, S, tag="frame %d: " % t)
+            assert not rep, "\n".join(rep)
+    assert g.stats(count_live=True)["live_particles"] > 1000
+    g.close()
