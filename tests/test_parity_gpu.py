@@ -193,6 +193,32 @@ def test_c3_full_size_two_frames():
     g.close()
 
 
+def test_c3_benchmark_state_ten_frames():
+    """The workload bench.py times - C3 prefilled with ~2 M particles, 6 moving objects - for ten frames against the
+    oracle: the dense bins of the weight update, objects of several thousand particles, a sweep over a populated map."""
+    cfg = synth.CONFIGS["C3"]
+    params = synth.PARAMS["vkitti2"]
+    scene = synth.Scene(cfg, n_static=48, n_dynamic=6, seed=7)
+    st, ring, n_pre = synth.prefill_state(cfg, scene, 2000000)
+    o, g = pu.make_pair(cfg, params, noise())
+    for m in (o, g):
+        m.load_state(st)
+        m.set_ring_state(ring)
+    S = 1 << cfg["p_n"]
+    for t in range(10):
+        depth, cloud, pos, q = scene.render(t, params)
+        moves = scene.moves(t)
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves, sync=True)
+        so, sg = o.stats(), g.stats()
+        for k in ("n_visible", "n_moved", "n_move_reinserted", "n_birth_success", "n_resampled_voxels"):
+            assert so[k] == sg[k], (t, k, so[k], sg[k])
+    assert sg["n_visible"] > 5000 and sg["n_moved"] > 1000
+    rep = pu.compare_maps(o, g, S, check_bins=True, tag="C3 prefilled: ")
+    assert not rep, "\n".join(rep)
+    g.close()
+
+
 def test_generic_flood_fallback_matches_oracle():
     """The frustum flood has two exact implementations (line-graph flood, and the plain 3-D bit flood used when a
     mask line is not one run).  Force the fallback and compare with the oracle's literal BFS result."""
