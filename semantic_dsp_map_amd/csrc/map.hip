@@ -1425,6 +1425,18 @@ sdm_status sdm_dump_state(sdm_map *m, float *px, float *py, float *pz, float *w,
   }
   if (owner) HIP_TRY(hipMemcpyAsync(owner, m->st.owner, n * 2, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (owner) {
+    // one owner per slot in the exported array: a slot that sits in several sets (State::alias) reports the largest
+    // track id, which is what walking the reference's sets in ascending track order leaves behind
+    std::vector<uint32_t> al(2 + 2 * ALIAS_CAP);
+    HIP_TRY(hipMemcpy(al.data(), m->st.alias, al.size() * 4, hipMemcpyDeviceToHost));
+    const uint32_t na = std::min<uint32_t>(al[0], ALIAS_CAP);
+    for (uint32_t k = 0; k < na; ++k) {
+      const uint32_t idx = al[2 + 2 * k], trk = al[3 + 2 * k];
+      if (trk == OWNER_NONE || idx >= n) continue;
+      if (owner[idx] == OWNER_NONE || owner[idx] < trk) owner[idx] = (uint16_t)trk;
+    }
+  }
   return SDM_OK;
 }
 

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
   __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
   __shared__ uint32_t e_shift[MAX_MOVE_OBJECTS];   // global rank of the object's first local member - its local offset
   __shared__ uint32_t block_total;
-  constexpr uint32_t CA_CAP = 32;
+  constexpr uint32_t CA_CAP = 512;
   __shared__ uint32_t ca_idx[CA_CAP], ca_ent[CA_CAP], ca_n;
   __shared__ uint8_t ca_obj[CA_CAP];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -357,72 +357,78 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
       }
       __syncthreads();
       const size_t li = base + (size_t)r * TPB + threadIdx.x;
-      uint8_t o = 0xFF, o2 = 0xFF;  // the slot's primary and (at most one) older membership among the moving objects
-      uint32_t ent2 = 0;
-      if (li < n_slots) o = obj_of(st.owner[li], tracks, n_obj);
-      for (uint32_t c = 0; c < n_ca; ++c)
-        if (ca_idx[c] == (uint32_t)li) {
-          if (o2 != 0xFF) sc.cnt->overflow = 1;  // a slot in three sets at once: not handled
-          o2 = ca_obj[c];
-          ent2 = ca_ent[c];
-        }
-      const bool valid = o != 0xFF, valid2 = o2 != 0xFF;
-      uint32_t rank1 = 0, rank2 = 0;
+      // the slot's memberships among the moving objects: mo[0] primary (owner[]), mo[1..] older ones (State::alias)
+      constexpr int MAXM = 4;
+      uint8_t mo[MAXM] = {0xFF, 0xFF, 0xFF, 0xFF};
+      uint32_t ment[MAXM] = {0, 0, 0, 0}, mrank[MAXM] = {0, 0, 0, 0};
+      if (li < n_slots) mo[0] = obj_of(st.owner[li], tracks, n_obj);
+      if (n_ca) {
+        int nm = 1;
+        for (uint32_t c = 0; c < n_ca; ++c)
+          if (ca_idx[c] == (uint32_t)li) {
+            if (nm < MAXM) {
+              mo[nm] = ca_obj[c];
+              ment[nm] = ca_ent[c];
+              ++nm;
+            } else {
+              sc.cnt->overflow = 1;  // a slot in more than four moving sets at once: not handled
+            }
+          }
+      }
       if (n_ca == 0) {
-        uint64_t peers = __ballot(valid);
+        const uint8_t o = mo[0];
+        uint64_t peers = __ballot(o != 0xFF);
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           bool bit = (o >> b) & 1u;
           uint64_t m = __ballot(bit);
           peers &= bit ? m : ~m;
         }
-        rank1 = (uint32_t)__popcll(peers & lt_mask);
-        if (valid && rank1 == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
+        mrank[0] = (uint32_t)__popcll(peers & lt_mask);
+        if (o != 0xFF && mrank[0] == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
       } else {
-        // members of object k in this wave = lanes whose primary OR older membership is k, in lane (= index) order
-        uint64_t b1[6], b2[6];
-        const uint64_t v1 = __ballot(valid), v2 = __ballot(valid2);
+        // members of object k in this wave = lanes one of whose memberships is k, in lane (= index) order
+        uint64_t bb[MAXM][6], vv[MAXM];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          b1[b] = __ballot((o >> b) & 1u);
-          b2[b] = __ballot((o2 >> b) & 1u);
+        for (int q = 0; q < MAXM; ++q) {
+          vv[q] = __ballot(mo[q] != 0xFF);
+#pragma unroll
+          for (int b = 0; b < 6; ++b) bb[q][b] = __ballot((mo[q] >> b) & 1u);
         }
-        auto members_of = [&](uint8_t x) {
-          uint64_t p1 = v1, p2 = v2;
 #pragma unroll
-          for (int b = 0; b < 6; ++b) {
-            const bool bit = (x >> b) & 1u;
-            p1 &= bit ? b1[b] : ~b1[b];
-            p2 &= bit ? b2[b] : ~b2[b];
+        for (int q = 0; q < MAXM; ++q) {
+          if (mo[q] == 0xFF) continue;
+          uint64_t mm = 0;
+#pragma unroll
+          for (int q2 = 0; q2 < MAXM; ++q2) {
+            uint64_t pq = vv[q2];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) pq &= ((mo[q] >> b) & 1u) ? bb[q2][b] : ~bb[q2][b];
+            mm |= pq;
           }
-          return p1 | p2;
-        };
-        if (valid) {
-          const uint64_t mm = members_of(o);
-          rank1 = (uint32_t)__popcll(mm & lt_mask);
-          if (rank1 == 0) wave_cnt[wid][o] = (uint32_t)__popcll(mm);
-        }
-        if (valid2) {
-          const uint64_t mm = members_of(o2);
-          rank2 = (uint32_t)__popcll(mm & lt_mask);
-          if (rank2 == 0) wave_cnt[wid][o2] = (uint32_t)__popcll(mm);
+          mrank[q] = (uint32_t)__popcll(mm & lt_mask);
+          if (mrank[q] == 0) wave_cnt[wid][mo[q]] = (uint32_t)__popcll(mm);
         }
       }
       __syncthreads();
-      // a slot that two moving objects hold is moved by both, in object order: the second copies a particle the first
-      // has just invalidated
-      const bool alias_first = valid2 && (!valid || o2 < o);
+      // a slot that several moving objects hold is moved by each of them, in object order: all but the first copy a
+      // particle that has just been invalidated
+      bool first = true;
+      for (int done_n = 0; done_n < MAXM; ++done_n) {
+        int q = -1;
 #pragma unroll
-      for (int turn = 0; turn < 2; ++turn) {
-        const bool do_alias = (turn == 0) == alias_first;
-        if (do_alias ? !valid2 : !valid) continue;
-        const uint8_t ob = do_alias ? o2 : o;
-        uint32_t e = obj_base[ob] + (do_alias ? rank2 : rank1);
+        for (int c = 0; c < MAXM; ++c)
+          if (mo[c] != 0xFF && (q < 0 || mo[c] < mo[q])) q = c;
+        if (q < 0) break;
+        const uint8_t ob = mo[q];
+        uint32_t e = obj_base[ob] + mrank[q];
 #pragma unroll
         for (int w = 0; w < MV_WAVES; ++w)
           if (w < wid) e += wave_cnt[w][ob];
-        move_one(d, f, flt, ms, st, sc, (int)ob, e, li, do_alias, turn == 1 && valid && valid2);
-        if (do_alias) st.alias[3 + 2 * ent2] = OWNER_NONE;  // the object's set is rebuilt from its re-inserted copies
+        move_one(d, f, flt, ms, st, sc, (int)ob, e, li, q != 0, !first);
+        if (q != 0) st.alias[3 + 2 * ment[q]] = OWNER_NONE;  // the object's set is rebuilt from its re-inserted copies
+        mo[q] = 0xFF;
+        first = false;
       }
       __syncthreads();
       if (threadIdx.x < MAX_MOVE_OBJECTS) {

@@ -162,7 +162,7 @@ struct State {
   float *noise = nullptr;
 };
 
-constexpr uint32_t ALIAS_CAP = 1024;
+constexpr uint32_t ALIAS_CAP = 8192;
 
 // ObjectParticleHashMap::addParticleToObj (object_layer.h:31-33): slot li joins track's set.  li is the shard-local slot
 // index.  Returns false when the alias table is full.
