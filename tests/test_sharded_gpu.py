@@ -161,3 +161,32 @@ print("OK")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("G,params_name,seed", [(2, "vkitti2", 5), (4, "noisy3", 6)])
+def test_shards_match_oracle_on_random_frames(G, params_name, seed):
+    """The seeded random frames of tests/test_fuzz_gpu.py (overlapping tracks, re-used owner slots, removals are left
+    out: the split frame entry points take none) through G Z-slab shards against the unsharded oracle, 50 frames."""
+    from tests.test_fuzz_gpu import random_frame
+    cfg = synth.CONFIGS["T0"]
+    params = synth.PARAMS[params_name]
+    rng = np.random.default_rng(seed)
+    noise = synth.noise_table()
+    o = orc.OracleMap(dict(cfg, bin_order=1, ck_slabs=G), params, noise)
+    shards = [Shard(cfg, params, noise, r, G) for r in range(G)]
+    S = 1 << cfg["p_n"]
+    pos = np.zeros(3)
+    yaw = 0.0
+    exported = 0
+    for t in range(50):
+        pos = pos + rng.normal(0, 0.35, 3) * np.array([1.0, 0.2, 1.0])
+        yaw += rng.normal(0, 0.08)
+        depth, cloud, mv, _ = random_frame(rng, cfg, params, t, pos, yaw)
+        frame = (depth, cloud, pos.astype(np.float32), synth.yaw_quat(yaw).astype(np.float32), mv)
+        o.update(*frame)
+        exported += run_frame(shards, frame)
+        if t % 10 == 9:
+            compare_union(o, shards, t, S)
+    assert exported > 0 and o.stats()["alias_events"] > 0
+    for s in shards:
+        s.m.close()
