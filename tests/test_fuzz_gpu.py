@@ -62,9 +62,10 @@ def random_frame(rng, cfg, params, t, pos, yaw):
     return depth, cloud, mv, remove
 
 
-@pytest.mark.parametrize("params_name,seed", [("vkitti2", 1), ("noisy3", 2), ("nodepthnoise", 3), ("kitti360", 4)])
-def test_random_frames_free_running(params_name, seed):
-    cfg = synth.CONFIGS["T0"]
+@pytest.mark.parametrize("params_name,seed,p_n", [("vkitti2", 1, 3), ("noisy3", 2, 3), ("nodepthnoise", 3, 3), ("kitti360", 4, 3),
+                                                  ("vkitti2", 5, 1), ("noisy3", 6, 2), ("zed2", 7, 4)])
+def test_random_frames_free_running(params_name, seed, p_n):
+    cfg = dict(synth.CONFIGS["T0"], p_n=p_n)
     params = synth.PARAMS[params_name]
     rng = np.random.default_rng(seed)
     o, g = pu.make_pair(cfg, params, synth.noise_table())
