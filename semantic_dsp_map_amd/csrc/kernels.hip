@@ -73,6 +73,18 @@ __global__ __launch_bounds__(TPB) void k_clear_status(uint8_t *__restrict__ stat
   for (; lv < n_voxels; lv += stride) status[(size_t)lv * voxel_stride] = (uint8_t)ST_TIMEPTC;  // the record was zeroed: INVALID
 }
 
+// RingBufferOperations::clear on a used map (operations.h:697-722): status, position, weight, time stamp
+__global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, size_t n) {
+  size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= n) return;
+  float4 p = st.pos4[li];
+  p.x = p.y = p.z = 0.f;  // .w carries the forget count, which clear() does not touch
+  st.pos4[li] = p;
+  st.w[rec_index(li, d.p_n, REC_W)] = 0.f;
+  st.ts[rec_index(li, d.p_n, REC_TS)] = 0;
+  st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_INVALID;  // slot 0 becomes the time particle again in k_clear_status
+}
+
 // start of frame: zero the per-frame counters and the per-pixel bin counts (one launch instead of two memsets)
 __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__restrict__ bin_count, uint32_t n_bins,
                                                       State st, StampUpdates su) {
@@ -1637,10 +1649,17 @@ inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb
 }  // namespace
 
 // ============================================================================ launchers
-void launch_clear(const Dims &d, const State &st, hipStream_t s) {
+// fresh = the buffers have never been written (sdm_create): everything to zero.  Otherwise the reference's clear()
+// (operations.h:697-722) resets status, position, weight and time stamp of every slot and leaves track id, label and
+// forget count of the dead slots as they were.
+void launch_clear(const Dims &d, const State &st, hipStream_t s, bool fresh) {
   size_t n = (size_t)d.v_count * d.S;
-  hipMemsetAsync(st.pos4, 0, n * sizeof(float4), s);
-  hipMemsetAsync(st.rec, 0, n * REC_BYTES_PER_SLOT, s);
+  if (fresh) {
+    hipMemsetAsync(st.pos4, 0, n * sizeof(float4), s);
+    hipMemsetAsync(st.rec, 0, n * REC_BYTES_PER_SLOT, s);
+  } else {
+    hipLaunchKernelGGL(k_clear_slots, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, n);
+  }
   hipMemsetAsync(st.vts, 0, (size_t)d.v_count * sizeof(uint16_t), s);
   hipMemsetAsync(st.vflag, 0, (size_t)d.v_count, s);
 

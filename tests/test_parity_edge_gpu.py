@@ -172,3 +172,27 @@ def test_mid_size_preset_clip():
             assert not rep, "\n".join(rep)
     assert g.stats(count_live=True)["live_particles"] > 1000
     g.close()
+
+
+def test_clear_in_the_middle_of_a_clip():
+    """SemanticDSPMap::clear (semantic_dsp_map.h:74-81, operations.h:684-723): particles, stamps, time stamp and object
+    sets go, the ring offset and the noise-table cursors stay."""
+    cfg = synth.CONFIGS["T0"]
+    params = synth.PARAMS["noisy3"]
+    sc = synth.Scene(cfg, n_dynamic=2, seed=12)
+    o, g = pu.make_pair(cfg, params, noise())
+    S = 1 << cfg["p_n"]
+    for t in range(10):
+        if t == 5:
+            o.clear()
+            g.clear()
+            rep = pu.compare_maps(o, g, S, check_results=False, tag="after clear: ")
+            assert not rep, "\n".join(rep)
+            assert o.ring_state() == g.ring_state()
+        depth, cloud, pos, q = sc.render(t, params)
+        moves = sc.moves(t)
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves, sync=True)
+        rep = pu.compare_maps(o, g, S, tag="frame %d: " % t)
+        assert not rep, "\n".join(rep)
+    g.close()

@@ -64,4 +64,16 @@ def test_replay_matches_binding(tmp_path):
     vox = g.voxels()
     assert int(m.group(1)) == int((vox["occ"] > 0).sum()) and int(m.group(1)) > 0
     assert int(m.group(2), 16) == fnv1a(vox.tobytes())
+    # three passes with sdm_clear in between (the ring offset and the noise cursors survive a clear, operations.h:683,
+    # so the passes differ), page-locked buffers, frames issued back to back: same as the binding doing the same
+    r2 = subprocess.run([EXE, clip, "3", "pinned", "pipelined"], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    m2 = re.search(r"occupied (\d+)\s+checksum ([0-9a-f]{16})", r2.stdout)
+    assert m2, r2.stdout
+    for rep in range(2):
+        g.clear()
+        for depth, static_mask, objects, pos64, q64, moves in frames:
+            g.update_raw(depth, static_mask, synth.LABEL_TO_STATIC_INSTANCE, objects, pos64, q64, moves)
+    g.synchronize()
+    assert int(m2.group(2), 16) == fnv1a(g.voxels().tobytes())
     g.close()
