@@ -196,3 +196,25 @@ def test_clear_in_the_middle_of_a_clip():
         rep = pu.compare_maps(o, g, S, tag="frame %d: " % t)
         assert not rep, "\n".join(rep)
     g.close()
+
+
+def test_parameters_changed_between_frames():
+    """setMapParameters / setMapOptions / setDepthNoiseModelParameters in the middle of a clip (semantic_dsp_map.h:101-166).
+    The forgetting table is built at the first update and keeps its forgetting_rate (basic_algorithms.h:32-48)."""
+    cfg = synth.CONFIGS["T0"]
+    seq = ["vkitti2", "noisy3", "kitti360", "nodepthnoise", "zed2"]
+    sc = synth.Scene(cfg, n_dynamic=2, seed=14)
+    o, g = pu.make_pair(cfg, synth.PARAMS[seq[0]], noise())
+    S = 1 << cfg["p_n"]
+    for t in range(15):
+        params = synth.PARAMS[seq[t // 3]]
+        if t % 3 == 0 and t > 0:
+            o.set_params(params)
+            g.set_params(params)
+        depth, cloud, pos, q = sc.render(t, params)
+        moves = sc.moves(t)
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves, sync=True)
+        rep = pu.compare_maps(o, g, S, tag="frame %d (%s): " % (t, seq[t // 3]))
+        assert not rep, "\n".join(rep)
+    g.close()
