@@ -218,3 +218,27 @@ def test_parameters_changed_between_frames():
         rep = pu.compare_maps(o, g, S, tag="frame %d (%s): " % (t, seq[t // 3]))
         assert not rep, "\n".join(rep)
     g.close()
+
+
+def test_time_stamp_wraps_at_16_bits():
+    """Particle time stamps are 16 bits wide (mc_ring/buffer.h:57-79), global_time_stamp and the slab stamps 32: past
+    frame 65535 the two disagree in the reference.  Whatever it does then, both implementations must do the same."""
+    cfg = synth.CONFIGS["T0"]
+    params = synth.PARAMS["vkitti2"]
+    sc = synth.Scene(cfg, n_dynamic=2, seed=15)
+    o, g = pu.make_pair(cfg, params, noise())
+    S = 1 << cfg["p_n"]
+    for t in range(14):
+        if t == 3:
+            for m in (o, g):
+                rs = m.ring_state()
+                rs["global_time_stamp"] = 65529
+                m.set_ring_state(rs)
+        depth, cloud, pos, q = sc.render(t, params)
+        moves = sc.moves(t)
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves, sync=True)
+        rep = pu.compare_maps(o, g, S, tag="frame %d: " % t)
+        assert not rep, "\n".join(rep)
+    assert g.ring_state()["global_time_stamp"] > 65536
+    g.close()
