@@ -270,6 +270,65 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
   }
 }
 
+// One round (TPB consecutive slots) of k_move_apply in a chunk that holds older set memberships (State::alias): a slot can
+// then belong to several moving objects.  mo[0] is its primary membership (owner[]), mo[1..] the older ones.
+constexpr uint32_t CA_CAP = 512;
+__device__ __forceinline__ void move_round_with_aliases(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms,
+                                                     const State &st, const Scratch &sc, size_t li, size_t n_slots, int n_obj,
+                                                     const uint16_t *tracks, const uint32_t *obj_base,
+                                                     uint32_t (*wave_cnt)[MAX_MOVE_OBJECTS], const uint32_t *ca_idx,
+                                                     const uint32_t *ca_ent, const uint8_t *ca_obj, uint32_t n_ca, uint64_t lt_mask,
+                                                     int wid) {
+  constexpr int MAXM = 4;
+  uint8_t mo[MAXM] = {0xFF, 0xFF, 0xFF, 0xFF};
+  uint32_t ment[MAXM] = {0, 0, 0, 0}, mrank[MAXM] = {0, 0, 0, 0};
+  if (li < n_slots) mo[0] = obj_of(st.owner[li], tracks, n_obj);
+  int nm = 1;
+  for (uint32_t c = 0; c < n_ca; ++c)
+    if (ca_idx[c] == (uint32_t)li) {
+      if (nm < MAXM) {
+        mo[nm] = ca_obj[c];
+        ment[nm] = ca_ent[c];
+        ++nm;
+      } else {
+        sc.cnt->overflow = 1;  // a slot in more than four moving sets at once: not handled
+      }
+    }
+  // members of object k in this wave = lanes one of whose memberships is k, in lane (= index) order.  (This path is
+  // rare; one ballot per moving object keeps it light on registers.)
+  for (int k = 0; k < n_obj; ++k) {
+    int q = -1;
+#pragma unroll
+    for (int c = 0; c < MAXM; ++c)
+      if (mo[c] == (uint8_t)k) q = c;
+    const uint64_t mm = __ballot(q >= 0);
+    if (q >= 0) {
+      mrank[q] = (uint32_t)__popcll(mm & lt_mask);
+      if (mrank[q] == 0) wave_cnt[wid][k] = (uint32_t)__popcll(mm);
+    }
+  }
+  __syncthreads();
+  // a slot that several moving objects hold is moved by each of them, in object order: all but the first copy a
+  // particle that has just been invalidated
+  bool first = true;
+  for (int done_n = 0; done_n < MAXM; ++done_n) {
+    int q = -1;
+#pragma unroll
+    for (int c = 0; c < MAXM; ++c)
+      if (mo[c] != 0xFF && (q < 0 || mo[c] < mo[q])) q = c;
+    if (q < 0) break;
+    const uint8_t ob = mo[q];
+    uint32_t e = obj_base[ob] + mrank[q];
+#pragma unroll
+    for (int w = 0; w < MV_WAVES; ++w)
+      if (w < wid) e += wave_cnt[w][ob];
+    move_one(d, f, flt, ms, st, sc, (int)ob, e, li, q != 0, !first);
+    if (q != 0) st.alias[3 + 2 * ment[q]] = OWNER_NONE;  // the object's set is rebuilt from its re-inserted copies
+    mo[q] = 0xFF;
+    first = false;
+  }
+}
+
 // phase 1 of moveParticlesInSetsByTransformations (operations.h:331-349): copy, transform + table noise, delete the
 // original.  One workgroup per flagged chunk: the members of every moving object are ranked in ascending index order
 // (ballot ranks inside a wave, wave counts through LDS, chunk offsets from the scanned count matrix), which gives each
@@ -283,7 +342,6 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
   __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
   __shared__ uint32_t e_shift[MAX_MOVE_OBJECTS];   // global rank of the object's first local member - its local offset
   __shared__ uint32_t block_total;
-  constexpr uint32_t CA_CAP = 512;
   __shared__ uint32_t ca_idx[CA_CAP], ca_ent[CA_CAP], ca_n;
   __shared__ uint8_t ca_obj[CA_CAP];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -315,6 +373,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
     if (total > sc.cap_move || sc.cur->move_list_overflow) sc.cnt->overflow = 1;
   }
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const uint32_t na_total = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
   for (uint32_t pos = blockIdx.x; pos < n; pos += gridDim.x) {
     __syncthreads();
     if (threadIdx.x == 0) block_total = 0;
@@ -330,11 +389,11 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
     const uint32_t chunk = sc.mv_list[pos];
     const size_t base = (size_t)chunk * MV_CHUNK;
     // older memberships of moving objects inside this chunk (State::alias): slot, object rank, entry
-    if (threadIdx.x == 0) ca_n = 0;
-    __syncthreads();
-    {
-      const uint32_t na = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
-      for (uint32_t k = threadIdx.x; k < na; k += blockDim.x) {
+    uint32_t n_ca = 0;
+    if (na_total) {  // (block-uniform; the table is empty in nearly every frame)
+      if (threadIdx.x == 0) ca_n = 0;
+      __syncthreads();
+      for (uint32_t k = threadIdx.x; k < na_total; k += blockDim.x) {
         const uint32_t idx = st.alias[2 + 2 * k], trk = st.alias[3 + 2 * k];
         if (trk == OWNER_NONE || idx / MV_CHUNK != chunk) continue;
         const uint8_t o = obj_of((uint16_t)trk, tracks, n_obj);
@@ -346,10 +405,10 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
           ca_ent[c] = k;
         }
       }
+      __syncthreads();
+      n_ca = ca_n < CA_CAP ? ca_n : CA_CAP;
+      if (threadIdx.x == 0 && ca_n > CA_CAP) sc.cnt->overflow = 1;
     }
-    __syncthreads();
-    const uint32_t n_ca = ca_n < CA_CAP ? ca_n : CA_CAP;
-    if (threadIdx.x == 0 && ca_n > CA_CAP) sc.cnt->overflow = 1;
     for (int r = 0; r < MV_ITEMS; ++r) {
       if (threadIdx.x < MAX_MOVE_OBJECTS) {
 #pragma unroll
@@ -357,78 +416,31 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
       }
       __syncthreads();
       const size_t li = base + (size_t)r * TPB + threadIdx.x;
-      // the slot's memberships among the moving objects: mo[0] primary (owner[]), mo[1..] older ones (State::alias)
-      constexpr int MAXM = 4;
-      uint8_t mo[MAXM] = {0xFF, 0xFF, 0xFF, 0xFF};
-      uint32_t ment[MAXM] = {0, 0, 0, 0}, mrank[MAXM] = {0, 0, 0, 0};
-      if (li < n_slots) mo[0] = obj_of(st.owner[li], tracks, n_obj);
-      if (n_ca) {
-        int nm = 1;
-        for (uint32_t c = 0; c < n_ca; ++c)
-          if (ca_idx[c] == (uint32_t)li) {
-            if (nm < MAXM) {
-              mo[nm] = ca_obj[c];
-              ment[nm] = ca_ent[c];
-              ++nm;
-            } else {
-              sc.cnt->overflow = 1;  // a slot in more than four moving sets at once: not handled
-            }
-          }
-      }
       if (n_ca == 0) {
-        const uint8_t o = mo[0];
-        uint64_t peers = __ballot(o != 0xFF);
+        // the usual case: every slot belongs to at most one moving object
+        uint8_t o = 0xFF;
+        if (li < n_slots) o = obj_of(st.owner[li], tracks, n_obj);
+        const bool valid = o != 0xFF;
+        uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           bool bit = (o >> b) & 1u;
           uint64_t m = __ballot(bit);
           peers &= bit ? m : ~m;
         }
-        mrank[0] = (uint32_t)__popcll(peers & lt_mask);
-        if (o != 0xFF && mrank[0] == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
+        const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
+        if (valid && rank_in_wave == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) {
+          uint32_t e = obj_base[o] + rank_in_wave;
+#pragma unroll
+          for (int w = 0; w < MV_WAVES; ++w)
+            if (w < wid) e += wave_cnt[w][o];
+          move_one(d, f, flt, ms, st, sc, (int)o, e, li);
+        }
       } else {
-        // members of object k in this wave = lanes one of whose memberships is k, in lane (= index) order
-        uint64_t bb[MAXM][6], vv[MAXM];
-#pragma unroll
-        for (int q = 0; q < MAXM; ++q) {
-          vv[q] = __ballot(mo[q] != 0xFF);
-#pragma unroll
-          for (int b = 0; b < 6; ++b) bb[q][b] = __ballot((mo[q] >> b) & 1u);
-        }
-#pragma unroll
-        for (int q = 0; q < MAXM; ++q) {
-          if (mo[q] == 0xFF) continue;
-          uint64_t mm = 0;
-#pragma unroll
-          for (int q2 = 0; q2 < MAXM; ++q2) {
-            uint64_t pq = vv[q2];
-#pragma unroll
-            for (int b = 0; b < 6; ++b) pq &= ((mo[q] >> b) & 1u) ? bb[q2][b] : ~bb[q2][b];
-            mm |= pq;
-          }
-          mrank[q] = (uint32_t)__popcll(mm & lt_mask);
-          if (mrank[q] == 0) wave_cnt[wid][mo[q]] = (uint32_t)__popcll(mm);
-        }
-      }
-      __syncthreads();
-      // a slot that several moving objects hold is moved by each of them, in object order: all but the first copy a
-      // particle that has just been invalidated
-      bool first = true;
-      for (int done_n = 0; done_n < MAXM; ++done_n) {
-        int q = -1;
-#pragma unroll
-        for (int c = 0; c < MAXM; ++c)
-          if (mo[c] != 0xFF && (q < 0 || mo[c] < mo[q])) q = c;
-        if (q < 0) break;
-        const uint8_t ob = mo[q];
-        uint32_t e = obj_base[ob] + mrank[q];
-#pragma unroll
-        for (int w = 0; w < MV_WAVES; ++w)
-          if (w < wid) e += wave_cnt[w][ob];
-        move_one(d, f, flt, ms, st, sc, (int)ob, e, li, q != 0, !first);
-        if (q != 0) st.alias[3 + 2 * ment[q]] = OWNER_NONE;  // the object's set is rebuilt from its re-inserted copies
-        mo[q] = 0xFF;
-        first = false;
+        move_round_with_aliases(d, f, flt, ms, st, sc, li, n_slots, n_obj, tracks, obj_base, wave_cnt, ca_idx, ca_ent, ca_obj, n_ca,
+                                lt_mask, wid);
       }
       __syncthreads();
       if (threadIdx.x < MAX_MOVE_OBJECTS) {
