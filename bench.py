@@ -175,11 +175,11 @@ def main():
 
 def pmc_traffic(S, voxels, live_voxels):
     """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per
-    MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r01g_sweep_pmc.json); None if they were taken on a
+    MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r01h_sweep_pmc.json); None if they were taken on a
     different kernel shape or a map whose live-voxel count is more than 15 % off.  PMC counters cannot be read from
     inside this process."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01g_sweep_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01h_sweep_pmc.json")) as f:
             p = json.load(f)
         if (p["kernel"] == "k_occupancy<%d>" % S and p["voxels"] == voxels
                 and abs(p["voxels_with_live_slots"] - live_voxels) <= 0.15 * max(live_voxels, 1)):
