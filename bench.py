@@ -118,30 +118,40 @@ def main():
         dist.all_reduce(lt)
         live, n_vis = int(lt[0].item()), int(lt[1].item())
 
-    # per-stage GPU times of one more frame (not part of the timed region)
-    stage_ms = None
-    if world == 1:
-        m.set_profiling(True)
-        depth, cloud, pos, q = scene.render(n_frames, params)
+    # ---- per-stage GPU times and the roofline of the dominant streaming kernel (occupancy / semantic sweep), taken on
+    # a few more frames after the timed region: HIP events on the stream the kernels run on bracket every stage
+    # (sdm_set_profiling), so "occupancy" is the in-frame duration of the sweep launch; the voxels it evaluated in full
+    # come from the library's counters.
+    n_extra = 6
+    m.set_profiling(True)
+    stage_acc = np.zeros(8)
+    sweep_live = []
+    for t in range(n_frames, n_frames + n_extra):
+        depth, cloud, pos, q = scene.render(t, params)
         dd, dc = m.device_put(depth), m.device_put(cloud)
-        m.update(dd, dc, pos, q, scene.moves(n_frames), on_device=True, sync=True)
-        stage_ms = m.stats()["stage_ms"]
-        m.set_profiling(False)
-
-    # ---- roofline of the dominant streaming kernel (occupancy / semantic sweep), HIP events on its stream
-    sweep_ms = m.time_occupancy_sweep(iters=50)
+        eng.update(dd, dc, pos, q, scene.moves(t))
+        m.synchronize()
+        stt = m.stats()
+        stage_acc += np.array(stt["stage_ms"])
+        sweep_live.append(stt["sweep_live_voxels"])
+    m.set_profiling(False)
+    stage_ms = stage_acc / n_extra
+    sweep_ms = float(stage_ms[7])
+    sweep_live_avg = float(np.mean(sweep_live))
     ms_per_step = dt * 1e3 / args.steps
     value = V / (dt / args.steps) / 1e6  # Mvoxels / s, whole map (all shards)
-    # Algorithmic bytes of one sweep: every voxel costs its 2-byte observation stamp, 1-byte "something
-    # here" flag and the 8-byte result; status row and record (S + 9S) are needed only for observed voxels that hold
-    # a live slot.  (SURVEY.md 8d's dense figure, 80 B/voxel at S = 8, is the case "every voxel holds a particle".)
-    alg_bytes = (V // world) * (2 + 1 + 8) + live_vox_local * 10 * S
+    # Algorithmic bytes of one sweep: every voxel costs its 2-byte observation stamp, 1-byte state flag and
+    # the 8-byte result; status row and record (10 S used bytes) are needed only for the voxels that were written to
+    # since the previous sweep.  (SURVEY.md 8d's dense figure, 80 B/voxel at S = 8, is the case "every voxel holds a
+    # particle and all of them changed".)
+    alg_bytes = (V // world) * (2 + 1 + 8) + sweep_live_avg * 10 * S
     achieved = alg_bytes / (sweep_ms * 1e-3)
     roofline = {"kernel": "k_occupancy<%d>" % S, "bound": "hbm", "achieved": round(achieved / 1e9, 1),
                 "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BPS, 4),
-                "traffic": pmc_traffic(S, V // world, live_vox_local), "bytes_per_launch": alg_bytes,
-                "avg_launch_ms": round(sweep_ms, 5), "voxels": V // world, "voxels_with_live_slots": live_vox_local,
-                "dense_bytes_per_launch": (V // world) * (10 * S + 8)}
+                "traffic": pmc_traffic(S, V // world, sweep_live_avg), "bytes_per_launch": int(alg_bytes),
+                "avg_launch_ms": round(sweep_ms, 5), "voxels": V // world,
+                "voxels_evaluated_in_full": int(sweep_live_avg), "voxels_with_live_slots": live_vox_local,
+                "launches_timed": n_extra, "dense_bytes_per_launch": (V // world) * (10 * S + 8)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_frames > 0:
@@ -165,7 +175,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        if stage_ms is not None:
+        if world == 1:
             out["stage_ms"] = {k: round(stage_ms[i], 4) for i, k in
                                enumerate(["", "ego", "move", "remove", "visibility", "weight", "birth", "occupancy"]) if k}
         print(json.dumps(out))
@@ -173,16 +183,16 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(S, voxels, live_voxels):
-    """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per
-    MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r01h_sweep_pmc.json); None if they were taken on a
-    different kernel shape or a map whose live-voxel count is more than 15 % off.  PMC counters cannot be read from
-    inside this process."""
+def pmc_traffic(S, voxels, evaluated):
+    """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes over this very command
+    (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r01i_sweep_pmc.json); None if they were
+    taken on a different kernel shape or with a number of fully evaluated voxels more than 25 % off.  PMC counters
+    cannot be read from inside this process."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01h_sweep_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01i_sweep_pmc.json")) as f:
             p = json.load(f)
         if (p["kernel"] == "k_occupancy<%d>" % S and p["voxels"] == voxels
-                and abs(p["voxels_with_live_slots"] - live_voxels) <= 0.15 * max(live_voxels, 1)):
+                and abs(p["voxels_evaluated_in_full"] - evaluated) <= 0.25 * max(evaluated, 1)):
             return int(p["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass

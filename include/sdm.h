@@ -149,7 +149,8 @@ typedef struct {
   int64_t n_occupied;
   int64_t flood_rounds;
   int64_t bfs_start_in_frustum;
-  int64_t live_voxels;      /* observed voxels holding a live slot (count_live=1): the ones the sweep fetches in full */
+  int64_t live_voxels;      /* observed voxels holding a live slot (count_live=1) */
+  int64_t sweep_live_voxels; /* voxels the last occupancy sweep evaluated in full: the ones written to since the sweep before */
   double stage_ms[8];       /* GPU time per stage of the last update when profiling is on */
 } sdm_stats;
 

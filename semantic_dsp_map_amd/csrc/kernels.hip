@@ -178,13 +178,17 @@ __device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_
   else out.occ = 0;
   store_result(st.res + lv, out);
   if (dirty_w) store_vec(st.w + base * REC_W, wv);
+  uint8_t flag = VF_CLEAN;
+  if (dirty_w) flag = VF_DIRTY;  // the sum above used the unclamped weights: the next evaluation differs
   if (dirty_s) {
     store_vec(st.status + base * REC_STATUS, stv);
-    bool any = false;  // the cull may have emptied the voxel
+    flag = VF_DIRTY;             // a culled slot still counted in this sum
+    bool any = false;            // the cull may have emptied the voxel
 #pragma unroll
     for (int i = 1; i < S; ++i) any = any || stv[i] != ST_INVALID;
-    if (!any) st.vflag[lv] = 0;
+    if (!any) flag = VF_EMPTY;
   }
+  st.vflag[lv] = flag;
 }
 
 // Two phases per workgroup of TPB * OCC_VPT voxels.  Phase 1 streams the voxel stamps and the "something here" bytes
@@ -196,7 +200,7 @@ __device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_
 constexpr int OCC_VPT = 4;
 
 template <int S>
-__global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, State st) {
+__global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, State st, Counters *cnt, int all_dirty) {
   __shared__ uint16_t live_list[TPB * OCC_VPT];
   __shared__ uint32_t n_live;
   const uint32_t blk0 = blockIdx.x * (TPB * OCC_VPT);
@@ -224,18 +228,21 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
       out.wsum = -1.f;
       out.occ = -1;
       store_result(st.res + lv, out);
+      if (flag[u] == VF_CLEAN) st.vflag[lv] = VF_DIRTY;  // its stored result is gone: evaluate again when it is seen again
       continue;
     }
-    if (!flag[u]) {  // every slot INVALID: weight sum 0, no vote, nothing to clamp or cull
+    if (flag[u] == VF_EMPTY) {  // every slot INVALID: weight sum 0, no vote, nothing to clamp or cull
       out.wsum = 0.f;
       out.occ = 0.f > occ_threshold ? 1 : 0;
       store_result(st.res + lv, out);
       continue;
     }
+    if (flag[u] == VF_CLEAN && !all_dirty) continue;  // nothing it holds has changed: the result of the last sweep stands
     live_list[atomicAdd(&n_live, 1u)] = (uint16_t)(u * TPB + threadIdx.x);
   }
   __syncthreads();
   const uint32_t nl = n_live;
+  if (threadIdx.x == 0 && nl) atomicAdd(&cnt->n_sweep_live, nl);
   for (uint32_t k = threadIdx.x; k < nl; k += TPB) {
     const uint32_t lv = blk0 + live_list[k];
     const size_t base = (size_t)lv * S;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
       out.wsum = 0.f;
       out.occ = 0.f > occ_threshold ? 1 : 0;
       store_result(st.res + lv, out);
-      if (!any) st.vflag[lv] = 0;
+      st.vflag[lv] = any ? VF_CLEAN : VF_EMPTY;
       continue;
     }
     occupancy_live_voxel<S>(st, occ_threshold, lv, sm, ts1, st1, wv, trk, lab);
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(TPB) void k_vts_from_slot0(Dims d, State st) {
   st.vts[lv] = st.ts[(size_t)lv * d.S * REC_TS];
   bool any = false;
   for (uint32_t i = 1; i < d.S; ++i) any = any || st.status[(size_t)lv * d.S * REC_STATUS + i] != ST_INVALID;
-  st.vflag[lv] = any ? 1 : 0;
+  st.vflag[lv] = any ? VF_DIRTY : VF_EMPTY;
 }
 
 // ------------------------------------------------------------------------------------ A6
@@ -638,7 +645,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   uint16_t tsv[S];
   load_vec(stv, st.status + base * REC_STATUS);
   load_vec(tsv, st.ts + base * REC_TS);
-  bool dirty = false, observed = false;
+  bool dirty = false, observed = false, wrote_free = false;
   int valid_n = 0;
   bool live[S];
   float4 pos[S];
@@ -676,6 +683,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     const float dpt = dptv[i];
     if (dpt > d.dmax) {  // nothing measurable along this ray: free (operations.h:1389-1395)
       st.w[base * REC_W + i] = SDM_OCC_INIT_WEIGHT;
+      wrote_free = true;
       observed = true;
       continue;
     }
@@ -705,6 +713,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     }
   }
   if (dirty) store_vec(st.status + base * REC_STATUS, stv);
+  if (dirty || wrote_free) st.vflag[lv] = VF_DIRTY;
   if (observed) {
     st.vts[lv] = (uint16_t)f.gts;
   } else if (valid_n == 0) {
@@ -1193,6 +1202,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Frame f, F
       const uint32_t fc = (sc.vtf[k] >> 16) & 0xffu;
       st.w[rec_index(li, d.p_n, REC_W)] = sc.vp4[k].w * (a * flt.p_detect + 1.f - flt.p_detect);
       st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_UPDATED;
+      st.vflag[li >> d.p_n] = VF_DIRTY;
       st.ts[rec_index(li, d.p_n, REC_TS)] = (uint16_t)f.gts;
       if (!flt.independent) {
         uint32_t nf = right_id ? 0u : (fc < 5u ? fc + 1u : fc);
@@ -1425,10 +1435,8 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
     }
   }
   // same-address atomics retire one at a time: counters every wave bumps are sharded by block
-  if (n_success) {
-    st.vflag[v - d.v_begin] = 1;
-    atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].birth, n_success);
-  }
+  if (n_success || n_resamp) st.vflag[v - d.v_begin] = VF_DIRTY;
+  if (n_success) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].birth, n_success);
   if (n_resamp) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].resample, n_resamp);
 }
 
@@ -1678,9 +1686,45 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s, bool fresh) {
     default: hipLaunchKernelGGL(kernel<16>, grid, dim3(TPB), 0, s, __VA_ARGS__); break;            \
   }
 
-void launch_occupancy(const Dims &d, const Filter &flt, const State &st, hipStream_t s) {
+void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, hipStream_t s) {
   dim3 grid(blocks_for(d.v_count, TPB * OCC_VPT));
-  SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st);
+  SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st, cnt, all_dirty);
+}
+
+// a ring shift re-stamped these slabs: what the voxels there hold has just become stale (operations.h:1131-1181), so
+// their results change although nobody wrote to them
+__global__ __launch_bounds__(TPB) void k_mark_slabs_dirty(Dims d, State st, StampUpdates su, uint32_t slab_max) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = t / slab_max, j = t - k * slab_max;  // update k, j-th voxel of its slab
+  if ((int)k >= su.n) return;
+  const uint32_t e = su.entry[k], axis = e >> 12, idx = e & 0xfffu;
+  uint32_t rx, ry, rz;
+  if (axis == 0) {
+    if (j >= d.NY * d.NZ) return;
+    rx = idx;
+    ry = j % d.NY;
+    rz = j / d.NY;
+  } else if (axis == 1) {
+    if (j >= d.NX * d.NZ) return;
+    ry = idx;
+    rx = j % d.NX;
+    rz = j / d.NX;
+  } else {
+    if (j >= d.NX * d.NY) return;
+    rz = idx;
+    rx = j % d.NX;
+    ry = j / d.NX;
+  }
+  if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) return;  // another shard's slab
+  const uint32_t lv = ring_to_voxel(d, rx, ry, rz) - d.v_begin;
+  if (st.vflag[lv] == VF_CLEAN) st.vflag[lv] = VF_DIRTY;
+}
+void launch_mark_slabs_dirty(const Dims &d, const State &st, const StampUpdates &su, hipStream_t s) {
+  if (su.n <= 0) return;
+  uint32_t slab_max = d.NY * d.NZ;
+  if (d.NX * d.NZ > slab_max) slab_max = d.NX * d.NZ;
+  if (d.NX * d.NY > slab_max) slab_max = d.NX * d.NY;
+  hipLaunchKernelGGL(k_mark_slabs_dirty, dim3(blocks_for((size_t)slab_max * su.n)), dim3(TPB), 0, s, d, st, su, slab_max);
 }
 
 void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s) {
@@ -1831,7 +1875,7 @@ __global__ __launch_bounds__(TPB) void k_fill_dense(Dims d, State st, uint32_t s
   st.owner[li] = OWNER_NONE;
   if (i == 0) {
     st.vts[lv] = (uint16_t)stamp;
-    st.vflag[lv] = 1;
+    st.vflag[lv] = VF_DIRTY;
   }
 }
 void launch_fill_dense(const Dims &d, const State &st, uint32_t stamp, hipStream_t s) {

@@ -94,6 +94,7 @@ struct sdm_map {
   float cam_R[9]{}, cam_p[3]{};
   StampUpdates stamp_updates{};
   bool stamps_dirty = true;  // device copy of the stamp arrays needs a full upload
+  bool sweep_all = true;     // the next occupancy sweep evaluates every voxel that holds something, changed or not
   MoveSet moveset{};
 
   // owned device buffers for inputs
@@ -638,6 +639,7 @@ sdm_status sdm_clear(sdm_map *m) {
   if (!m) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
   m->state_event_valid = false;
+  m->sweep_all = true;
   host_initialize(m);
   HIP_TRY(hipMemsetAsync(m->sc.mv_head, 0xff, (size_t)m->d.v_count * sizeof(uint32_t), m->stream));
   launch_clear(m->d, m->st, m->stream, false);
@@ -649,6 +651,7 @@ sdm_status sdm_set_params(sdm_map *m, const sdm_params *p) {
   if (p->nb_ptc_num_per_point < 0 || p->nb_ptc_num_per_point > 64) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
   m->prm = *p;
+  m->sweep_all = true;  // the occupancy threshold may have changed: no stored result is safe
   refresh_filter(m);
   return ensure_birth_buffers(m);
 }
@@ -742,10 +745,12 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
   sync_frame_scalars(m);
   sdm_status rc = SDM_OK;
   if (m->stamps_dirty) {
+    m->sweep_all = true;  // stamps replaced wholesale: every stored result may be stale
     if ((rc = upload_stamps(m)) != SDM_OK) return rc;
     m->stamp_updates.n = 0;
   }
   launch_frame_begin(d, m->st, m->sc, m->stamp_updates, s);
+  launch_mark_slabs_dirty(d, m->st, m->stamp_updates, s);
   if (flags & SDM_INPUT_ON_DEVICE) {
     m->sc.depth = depth;
     m->sc.cloud = cloud;
@@ -921,7 +926,10 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
   m->state_event_valid = true;
   mark(6);
   if (done(6)) return SDM_OK;
-  if (!(flags & SDM_SKIP_OCCUPANCY)) launch_occupancy(d, m->flt, m->st, s);
+  if (!(flags & SDM_SKIP_OCCUPANCY)) {
+    launch_occupancy(d, m->flt, m->st, m->sc.cnt, m->sweep_all ? 1 : 0, s);
+    m->sweep_all = false;
+  }
   mark(7);
   return SDM_OK;
 }
@@ -1280,6 +1288,7 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
   out->n_move_reinserted = c.n_move_reinserted;
   for (uint32_t k = 0; k < VIS_SHARDS; ++k) out->n_frustum_voxels += c.shard[k].fv;
   out->bfs_start_in_frustum = c.start_in_frustum;
+  out->sweep_live_voxels = c.n_sweep_live;
   out->flood_rounds = c.flood_rounds;
   if (m->profiling) {
     int prev = 0;
@@ -1341,6 +1350,7 @@ sdm_status sdm_get_ring_state(sdm_map *m, sdm_ring_state *o) {
 }
 
 sdm_status sdm_set_ring_state(sdm_map *m, const sdm_ring_state *o) {
+  if (m) m->sweep_all = true;
   if (!m || !o) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
   m->global_time_stamp = o->global_time_stamp;
@@ -1365,6 +1375,7 @@ sdm_status sdm_get_stamps(sdm_map *m, uint32_t *sx, uint32_t *sy, uint32_t *sz) 
   return SDM_OK;
 }
 sdm_status sdm_set_stamps(sdm_map *m, const uint32_t *sx, const uint32_t *sy, const uint32_t *sz) {
+  if (m) m->sweep_all = true;
   if (!m || !sx || !sy || !sz) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
   memcpy(m->stamps_x.data(), sx, m->d.NX * 4);
@@ -1444,6 +1455,7 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
                           const uint16_t *ts, const uint16_t *track, const uint8_t *label, const uint8_t *status,
                           const uint8_t *forget, const uint16_t *owner) {
   if (!m || !px || !py || !pz || !w || !ts || !track || !label || !status || !forget) return SDM_ERR_INVALID_ARGUMENT;
+  m->sweep_all = true;
   m->state_event_valid = false;
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t s = m->stream;
@@ -1533,9 +1545,9 @@ sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms) {
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a));
   HIP_TRY(hipEventCreate(&b));
-  launch_occupancy(m->d, m->flt, m->st, m->stream);  // warm-up
+  launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->stream);  // warm-up; all_dirty: the full evaluation every time
   HIP_TRY(hipEventRecord(a, m->stream));
-  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->flt, m->st, m->stream);
+  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->stream);
   HIP_TRY(hipEventRecord(b, m->stream));
   HIP_TRY(hipEventSynchronize(b));
   float ms = 0.f;

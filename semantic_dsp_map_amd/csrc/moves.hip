@@ -230,6 +230,7 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
   const uint8_t pstatus = copy_invalid ? (uint8_t)ST_INVALID : st.status[rec_index(li, d.p_n, REC_STATUS)];
   const uint16_t powner = ms.track[obj];
   st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_INVALID;  // deleteParticleByIndex
+  st.vflag[li >> d.p_n] = VF_DIRTY;
   if (!alias) st.owner[li] = OWNER_NONE;  // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
   uint32_t rx, ry, rz;
   uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
       }
     }
     if (n_ok) {
-      st.vflag[lv] = 1;
+      st.vflag[lv] = VF_DIRTY;
       atomicAdd(&sc.cnt->n_move_reinserted, n_ok);
     }
   }
@@ -585,6 +586,7 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
       for (int q = 0; q < n; ++q)
         if (tracks[q] == trk) {
           st.status[rec_index(st.alias[2 + 2 * k], p_n, REC_STATUS)] = ST_INVALID;
+          st.vflag[st.alias[2 + 2 * k] >> p_n] = VF_DIRTY;
           st.alias[3 + 2 * k] = OWNER_NONE;
           break;
         }
@@ -600,6 +602,7 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
     for (int k = 0; k < n; ++k)
       if (tracks[k] == o) {
         st.status[rec_index(i, p_n, REC_STATUS)] = ST_INVALID;
+        st.vflag[i >> p_n] = VF_DIRTY;
         st.owner[i] = OWNER_NONE;
         break;
       }

@@ -82,7 +82,8 @@ struct Counters {
   uint32_t overflow;
   uint32_t n_valid_px;
   uint32_t n_move_voxels;  // voxels that receive at least one moved copy this frame
-  uint32_t pad[7];
+  uint32_t n_sweep_live;   // voxels the occupancy sweep evaluated in full (record fetched) in its last launch
+  uint32_t pad[6];
   // Atomics on one cache line retire one at a time (~12 ns each on MI355X) - same address or not.  Counters that
   // every wave bumps are therefore sharded by block index, one 128-byte line per shard; the per-shard
   // visible-particle counters also index per-shard regions of the work list.
@@ -139,9 +140,10 @@ struct State {
   // observation stamp of every voxel = time stamp of its slot-0 "time particle" (operations.h:824-837), kept as a
   // dense array of its own: the sweeps read it for every voxel, the slot rows only where something lives
   uint16_t *vts = nullptr;
-  // one byte per voxel: 0 = every slot is INVALID.  Set by whatever inserts a particle (births, re-inserted moved
-  // copies, state import), refreshed exactly by the occupancy sweep; deletions leave it set (conservative).  Lets the
-  // sweep decide "nothing here" from 3 bytes per voxel without touching the status row.
+  // one byte per voxel: VF_EMPTY = every slot is INVALID; VF_CLEAN = the voxel holds something and nothing it holds
+  // has changed since the occupancy sweep last evaluated it (its result stands); VF_DIRTY = it holds something that
+  // was written since.  Every kernel that writes a slot, and a ring shift that re-stamps the voxel's slab, sets
+  // VF_DIRTY; the sweep sets VF_CLEAN / VF_EMPTY.  Lets the sweep finish an empty or unchanged voxel from 3 bytes.
   uint8_t *vflag = nullptr;
   uint16_t *track = nullptr;
   uint8_t *label = nullptr;
@@ -162,6 +164,7 @@ struct State {
   float *noise = nullptr;
 };
 
+enum : uint8_t { VF_EMPTY = 0, VF_CLEAN = 1, VF_DIRTY = 2 };
 constexpr uint32_t ALIAS_CAP = 8192;
 
 // ObjectParticleHashMap::addParticleToObj (object_layer.h:31-33): slot li joins track's set.  li is the shard-local slot
