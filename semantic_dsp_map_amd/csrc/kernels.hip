@@ -85,10 +85,40 @@ __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, size_t n)
   st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_INVALID;  // slot 0 becomes the time particle again in k_clear_status
 }
 
+// a ring shift re-stamped these slabs: what the voxels there hold has just become stale (operations.h:1131-1181), so
+// their results change although nobody wrote to them.  t = update k * slab_max + j-th voxel of its slab.
+__device__ __forceinline__ void mark_slab_voxel_dirty(const Dims &d, const State &st, const StampUpdates &su, uint32_t slab_max,
+                                                      uint32_t t) {
+  const uint32_t k = t / slab_max, j = t - k * slab_max;
+  if ((int)k >= su.n) return;
+  const uint32_t e = su.entry[k], axis = e >> 12, idx = e & 0xfffu;
+  uint32_t rx, ry, rz;
+  if (axis == 0) {
+    if (j >= d.NY * d.NZ) return;
+    rx = idx;
+    ry = j % d.NY;
+    rz = j / d.NY;
+  } else if (axis == 1) {
+    if (j >= d.NX * d.NZ) return;
+    ry = idx;
+    rx = j % d.NX;
+    rz = j / d.NX;
+  } else {
+    if (j >= d.NX * d.NY) return;
+    rz = idx;
+    rx = j % d.NX;
+    ry = j / d.NX;
+  }
+  if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) return;  // another shard's slab
+  const uint32_t lv = ring_to_voxel(d, rx, ry, rz) - d.v_begin;
+  if (st.vflag[lv] == VF_CLEAN) st.vflag[lv] = VF_DIRTY;
+}
+
 // start of frame: zero the per-frame counters and the per-pixel bin counts (one launch instead of two memsets)
 __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__restrict__ bin_count, uint32_t n_bins,
-                                                      State st, StampUpdates su) {
+                                                      State st, StampUpdates su, Dims d, uint32_t slab_max) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t t = i; t < slab_max * (uint32_t)su.n; t += gridDim.x * blockDim.x) mark_slab_voxel_dirty(d, st, su, slab_max, t);
   if (i < offsetof(Counters, flood_complex) / 4) reinterpret_cast<uint32_t *>(cnt)[i] = 0;  // the flood flags belong to the frustum chain
   if (i < (uint32_t)su.n) {  // this frame's recycled slabs (no host-to-device copy of the stamp arrays)
     const uint32_t e = su.entry[i], axis = e >> 12, idx = e & 0xfffu;
@@ -1691,44 +1721,12 @@ void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counter
   SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st, cnt, all_dirty);
 }
 
-// a ring shift re-stamped these slabs: what the voxels there hold has just become stale (operations.h:1131-1181), so
-// their results change although nobody wrote to them
-__global__ __launch_bounds__(TPB) void k_mark_slabs_dirty(Dims d, State st, StampUpdates su, uint32_t slab_max) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t k = t / slab_max, j = t - k * slab_max;  // update k, j-th voxel of its slab
-  if ((int)k >= su.n) return;
-  const uint32_t e = su.entry[k], axis = e >> 12, idx = e & 0xfffu;
-  uint32_t rx, ry, rz;
-  if (axis == 0) {
-    if (j >= d.NY * d.NZ) return;
-    rx = idx;
-    ry = j % d.NY;
-    rz = j / d.NY;
-  } else if (axis == 1) {
-    if (j >= d.NX * d.NZ) return;
-    ry = idx;
-    rx = j % d.NX;
-    rz = j / d.NX;
-  } else {
-    if (j >= d.NX * d.NY) return;
-    rz = idx;
-    rx = j % d.NX;
-    ry = j / d.NX;
-  }
-  if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) return;  // another shard's slab
-  const uint32_t lv = ring_to_voxel(d, rx, ry, rz) - d.v_begin;
-  if (st.vflag[lv] == VF_CLEAN) st.vflag[lv] = VF_DIRTY;
-}
-void launch_mark_slabs_dirty(const Dims &d, const State &st, const StampUpdates &su, hipStream_t s) {
-  if (su.n <= 0) return;
-  uint32_t slab_max = d.NY * d.NZ;
-  if (d.NX * d.NZ > slab_max) slab_max = d.NX * d.NZ;
-  if (d.NX * d.NY > slab_max) slab_max = d.NX * d.NY;
-  hipLaunchKernelGGL(k_mark_slabs_dirty, dim3(blocks_for((size_t)slab_max * su.n)), dim3(TPB), 0, s, d, st, su, slab_max);
-}
 
 void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s) {
-  hipLaunchKernelGGL(k_frame_begin, dim3(512), dim3(TPB), 0, s, sc.cnt, sc.bin_count, (uint32_t)(d.W * d.H + 1), st, su);
+  uint32_t slab_max = d.NY * d.NZ;  // voxels of the largest slab a ring shift can re-stamp
+  if (d.NX * d.NZ > slab_max) slab_max = d.NX * d.NZ;
+  if (d.NX * d.NY > slab_max) slab_max = d.NX * d.NY;
+  hipLaunchKernelGGL(k_frame_begin, dim3(512), dim3(TPB), 0, s, sc.cnt, sc.bin_count, (uint32_t)(d.W * d.H + 1), st, su, d, slab_max);
 }
 
 // The frustum reach set depends on the camera pose only, not on the map: it runs on a side stream next to the

@@ -750,7 +750,6 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
     m->stamp_updates.n = 0;
   }
   launch_frame_begin(d, m->st, m->sc, m->stamp_updates, s);
-  launch_mark_slabs_dirty(d, m->st, m->stamp_updates, s);
   if (flags & SDM_INPUT_ON_DEVICE) {
     m->sc.depth = depth;
     m->sc.cloud = cloud;

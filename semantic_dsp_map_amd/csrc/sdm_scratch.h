@@ -93,7 +93,6 @@ void launch_manual_resize(const Dims &d, const void *src, void *dst, int src_w, 
 
 void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s);
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, hipStream_t s);
-void launch_mark_slabs_dirty(const Dims &d, const State &st, const StampUpdates &su, hipStream_t s);
 void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_generic, hipStream_t s);
 void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, hipStream_t s);
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
