@@ -111,7 +111,8 @@ __device__ __forceinline__ void mark_slab_voxel_dirty(const Dims &d, const State
   }
   if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) return;  // another shard's slab
   const uint32_t lv = ring_to_voxel(d, rx, ry, rz) - d.v_begin;
-  if (st.vflag[lv] == VF_CLEAN) st.vflag[lv] = VF_DIRTY;
+  const uint8_t fl = st.vflag[lv];
+  if ((fl & VF_STATE) == VF_CLEAN) st.vflag[lv] = (uint8_t)(VF_DIRTY | (fl & VR_MASK));
 }
 
 // start of frame: zero the per-frame counters and the per-pixel bin counts (one launch instead of two memsets)
@@ -254,20 +255,25 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
     sdm_voxel_result out;
     out.track = 0;
     out.label = 0;
+    const uint32_t state = flag[u] & VF_STATE, held = flag[u] & VR_MASK;
     if (t0v[u] == 0 || t0v[u] < smax[u]) {  // isVoxelValid, operations.h:824-837
+      if (held == VR_UNOBSERVED && !all_dirty) continue;  // the result entry already says so
       out.wsum = -1.f;
       out.occ = -1;
       store_result(st.res + lv, out);
-      if (flag[u] == VF_CLEAN) st.vflag[lv] = VF_DIRTY;  // its stored result is gone: evaluate again when it is seen again
+      // a CLEAN voxel's stored result is gone with this: it is evaluated again when the voxel is seen again
+      st.vflag[lv] = (uint8_t)((state == VF_CLEAN ? VF_DIRTY : state) | VR_UNOBSERVED);
       continue;
     }
-    if (flag[u] == VF_EMPTY) {  // every slot INVALID: weight sum 0, no vote, nothing to clamp or cull
+    if (state == VF_EMPTY) {  // every slot INVALID: weight sum 0, no vote, nothing to clamp or cull
+      if (held == VR_EMPTY && !all_dirty) continue;
       out.wsum = 0.f;
       out.occ = 0.f > occ_threshold ? 1 : 0;
       store_result(st.res + lv, out);
+      st.vflag[lv] = (uint8_t)(VF_EMPTY | VR_EMPTY);
       continue;
     }
-    if (flag[u] == VF_CLEAN && !all_dirty) continue;  // nothing it holds has changed: the result of the last sweep stands
+    if (state == VF_CLEAN && !all_dirty) continue;  // nothing it holds has changed: the result of the last sweep stands
     live_list[atomicAdd(&n_live, 1u)] = (uint16_t)(u * TPB + threadIdx.x);
   }
   __syncthreads();
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
       out.wsum = 0.f;
       out.occ = 0.f > occ_threshold ? 1 : 0;
       store_result(st.res + lv, out);
-      st.vflag[lv] = any ? VF_CLEAN : VF_EMPTY;
+      st.vflag[lv] = (uint8_t)((any ? VF_CLEAN : VF_EMPTY) | VR_EMPTY);  // the entry holds the empty result
       continue;
     }
     occupancy_live_voxel<S>(st, occ_threshold, lv, sm, ts1, st1, wv, trk, lab);
@@ -654,7 +660,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   const uint32_t v = ring_to_voxel(d, rx, ry, rz);
   const uint32_t lv = v - d.v_begin;
   const size_t base = (size_t)lv * S;
-  const uint32_t flag = st.vflag[lv];  // 0: every slot INVALID, the record is not touched
+  const uint32_t flag = st.vflag[lv] & VF_STATE;  // VF_EMPTY: every slot INVALID, the record is not touched
   // imaginary particle at the voxel's min corner, mapXYZIdxToGlobalPose (operations.h:986-991, 1418-1431)
   float im_depth = 0.f, im_z = 0.f;
   bool im_ok;

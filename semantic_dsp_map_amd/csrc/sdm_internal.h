@@ -140,10 +140,12 @@ struct State {
   // observation stamp of every voxel = time stamp of its slot-0 "time particle" (operations.h:824-837), kept as a
   // dense array of its own: the sweeps read it for every voxel, the slot rows only where something lives
   uint16_t *vts = nullptr;
-  // one byte per voxel: VF_EMPTY = every slot is INVALID; VF_CLEAN = the voxel holds something and nothing it holds
-  // has changed since the occupancy sweep last evaluated it (its result stands); VF_DIRTY = it holds something that
-  // was written since.  Every kernel that writes a slot, and a ring shift that re-stamps the voxel's slab, sets
-  // VF_DIRTY; the sweep sets VF_CLEAN / VF_EMPTY.  Lets the sweep finish an empty or unchanged voxel from 3 bytes.
+  // one byte per voxel.  Bits 0-1: VF_EMPTY = every slot is INVALID; VF_CLEAN = the voxel holds something and nothing
+  // it holds has changed since the occupancy sweep last evaluated it (its result stands); VF_DIRTY = it holds
+  // something that was written since.  Every kernel that writes a slot, and a ring shift that re-stamps the voxel's
+  // slab, sets VF_DIRTY; the sweep sets VF_CLEAN / VF_EMPTY.  Bits 2-3, kept by the sweep: what the voxel's result
+  // entry holds right now - VR_UNOBSERVED, VR_EMPTY (the two constant results) or 0 = something else.  Together they
+  // let the sweep finish an unobserved, empty or unchanged voxel from 3 bytes read and nothing written.
   uint8_t *vflag = nullptr;
   uint16_t *track = nullptr;
   uint8_t *label = nullptr;
@@ -164,7 +166,7 @@ struct State {
   float *noise = nullptr;
 };
 
-enum : uint8_t { VF_EMPTY = 0, VF_CLEAN = 1, VF_DIRTY = 2 };
+enum : uint8_t { VF_EMPTY = 0, VF_CLEAN = 1, VF_DIRTY = 2, VF_STATE = 3, VR_UNOBSERVED = 1 << 2, VR_EMPTY = 2 << 2, VR_MASK = 3 << 2 };
 constexpr uint32_t ALIAS_CAP = 8192;
 
 // ObjectParticleHashMap::addParticleToObj (object_layer.h:31-33): slot li joins track's set.  li is the shard-local slot
