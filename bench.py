@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--particles", type=int, default=2000000, help="live particles per GPU after prefill")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-case sweep timing after the run")
     args = ap.parse_args()
 
     from semantic_dsp_map_amd import binding, sharded, synth
@@ -125,7 +126,7 @@ def main():
     n_extra = 6
     m.set_profiling(True)
     stage_acc = np.zeros(8)
-    sweep_live = []
+    sweep_live, sweep_tiles = [], []
     for t in range(n_frames, n_frames + n_extra):
         depth, cloud, pos, q = scene.render(t, params)
         dd, dc = m.device_put(depth), m.device_put(cloud)
@@ -134,28 +135,44 @@ def main():
         stt = m.stats()
         stage_acc += np.array(stt["stage_ms"])
         sweep_live.append(stt["sweep_live_voxels"])
+        sweep_tiles.append(stt["sweep_tiles"])
     m.set_profiling(False)
     stage_ms = stage_acc / n_extra
     sweep_ms = float(stage_ms[7])
     sweep_live_avg = float(np.mean(sweep_live))
+    sweep_tiles_avg = float(np.mean(sweep_tiles))
     ms_per_step = dt * 1e3 / args.steps
     value = V / (dt / args.steps) / 1e6  # Mvoxels / s, whole map (all shards)
-    # Algorithmic bytes of one sweep: every voxel costs its 2-byte observation stamp, 1-byte state flag and
-    # the 8-byte result; status row and record (10 S used bytes) are needed only for the voxels that were written to
-    # since the previous sweep.  (SURVEY.md 8d's dense figure, 80 B/voxel at S = 8, is the case "every voxel holds a
-    # particle and all of them changed".)
-    alg_bytes = (V // world) * (2 + 1 + 8) + sweep_live_avg * 10 * S
+    # Algorithmic bytes of one sweep: one byte per 2048-voxel tile; for the tiles something was written
+    # or stamped in since the previous sweep, the 2-byte observation stamp and 1-byte flag of every voxel; the record
+    # (10 S used bytes), the 8-byte result and the flag byte of the voxels that were written to.  Result entries that
+    # flip to "unobserved"/"empty" are also written (9 B each) but not counted, so `achieved` is a lower bound.
+    # (SURVEY.md 8d's dense figure, 80 B/voxel at S = 8, is the case "every voxel holds a particle and all of them
+    # changed": `dense_case` below.)
+    TILE = 2048
+    alg_bytes = (V // world) // TILE + sweep_tiles_avg * TILE * (2 + 1) + sweep_live_avg * (10 * S + 8 + 1)
     achieved = alg_bytes / (sweep_ms * 1e-3)
     roofline = {"kernel": "k_occupancy<%d>" % S, "bound": "hbm", "achieved": round(achieved / 1e9, 1),
                 "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BPS, 4),
-                "traffic": pmc_traffic(S, V // world, sweep_live_avg), "bytes_per_launch": int(alg_bytes),
+                "traffic": pmc_traffic(S, V // world, sweep_live_avg, sweep_tiles_avg), "bytes_per_launch": int(alg_bytes),
                 "avg_launch_ms": round(sweep_ms, 5), "voxels": V // world,
+                "tiles_looked_into": int(sweep_tiles_avg), "tiles": (V // world) // TILE,
                 "voxels_evaluated_in_full": int(sweep_live_avg), "voxels_with_live_slots": live_vox_local,
-                "launches_timed": n_extra, "dense_bytes_per_launch": (V // world) * (10 * S + 8)}
+                "launches_timed": n_extra}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_frames > 0:
         cpu = cpu_baseline(cfg, params, noise, frames, st, ring, args.cpu_frames, V)
+
+    if world == 1 and not args.no_dense:
+        # the same kernel on SURVEY.md 8(d)'s dense case (every slot of every voxel live, all of them to be evaluated):
+        # run last, it overwrites the map
+        m.fill_dense()
+        dense_ms = m.time_occupancy_sweep(iters=10)
+        dense_bytes = V * (2 + 1 + 8 + 10 * S)
+        roofline["dense_case"] = {"bytes_per_launch": dense_bytes, "avg_launch_ms": round(dense_ms, 5),
+                                  "achieved": round(dense_bytes / dense_ms / 1e6, 1),
+                                  "frac": round(dense_bytes / dense_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4), "launches_timed": 10}
 
     if rank == 0:
         out = {
@@ -183,16 +200,17 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(S, voxels, evaluated):
+def pmc_traffic(S, voxels, evaluated, tiles):
     """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes over this very command
-    (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r01i_sweep_pmc.json); None if they were
-    taken on a different kernel shape or with a number of fully evaluated voxels more than 25 % off.  PMC counters
+    (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r01k_sweep_pmc.json); None if they were
+    taken on a different kernel shape or with a number of fully evaluated voxels or of visited tiles more than 25 % off.  PMC counters
     cannot be read from inside this process."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01i_sweep_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01k_sweep_pmc.json")) as f:
             p = json.load(f)
         if (p["kernel"] == "k_occupancy<%d>" % S and p["voxels"] == voxels
-                and abs(p["voxels_evaluated_in_full"] - evaluated) <= 0.25 * max(evaluated, 1)):
+                and abs(p["voxels_evaluated_in_full"] - evaluated) <= 0.25 * max(evaluated, 1)
+                and abs(p["tiles_looked_into"] - tiles) <= 0.25 * max(tiles, 1)):
             return int(p["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass

@@ -151,6 +151,7 @@ typedef struct {
   int64_t bfs_start_in_frustum;
   int64_t live_voxels;      /* observed voxels holding a live slot (count_live=1) */
   int64_t sweep_live_voxels; /* voxels the last occupancy sweep evaluated in full: the ones written to since the sweep before */
+  int64_t sweep_tiles;      /* 2048-voxel tiles the last occupancy sweep looked into (something in them was written or stamped) */
   double stage_ms[8];       /* GPU time per stage of the last update when profiling is on */
 } sdm_stats;
 

@@ -72,6 +72,7 @@ class Stats(C.Structure):
                 ("n_birth_success", C.c_int64), ("n_resampled_voxels", C.c_int64), ("n_moved", C.c_int64),
                 ("n_move_reinserted", C.c_int64), ("n_frustum_voxels", C.c_int64), ("n_occupied", C.c_int64),
                 ("flood_rounds", C.c_int64), ("bfs_start_in_frustum", C.c_int64), ("live_voxels", C.c_int64), ("sweep_live_voxels", C.c_int64),
+                ("sweep_tiles", C.c_int64),
                 ("stage_ms", C.c_double * 8)]
 
 

@@ -113,6 +113,7 @@ __device__ __forceinline__ void mark_slab_voxel_dirty(const Dims &d, const State
   const uint32_t lv = ring_to_voxel(d, rx, ry, rz) - d.v_begin;
   const uint8_t fl = st.vflag[lv];
   if ((fl & VF_STATE) == VF_CLEAN) st.vflag[lv] = (uint8_t)(VF_DIRTY | (fl & VR_MASK));
+  mark_tile(st, lv);  // whatever it held, its result turns into "unobserved"
 }
 
 // start of frame: zero the per-frame counters and the per-pixel bin counts (one launch instead of two memsets)
@@ -220,6 +221,7 @@ __device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_
     if (!any) flag = VF_EMPTY;
   }
   st.vflag[lv] = flag;
+  if (flag != VF_CLEAN) mark_tile(st, lv);  // the next sweep evaluates it again resp. writes the empty result
 }
 
 // Two phases per workgroup of TPB * OCC_VPT voxels.  Phase 1 streams the voxel stamps and the "something here" bytes
@@ -228,57 +230,93 @@ __device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_
 // are listed in LDS and handled in phase 2 with all lanes busy: status row, the voxel's record (slot stamps, weights,
 // tracks, labels), vote, write-backs.  (Draining the list in a separate kernel was measured: the scattered fetches
 // then take longer than the whole fused sweep - here they ride along with the stream.)
-constexpr int OCC_VPT = 4;
+constexpr int OCC_VPT = 8;  // consecutive voxels of one thread: one 16-byte load of stamps, one 8-byte load of flags
+constexpr int OCC_GROUPS = 1;  // such groups per thread, all loaded before the first is looked at
+constexpr int OCC_TILE = TPB * OCC_VPT * OCC_GROUPS;  // voxels of one workgroup
+static_assert(OCC_TILE == (1 << TILE_SHIFT), "one workgroup per tile of State::tile_dirty");
 
 template <int S>
 __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, State st, Counters *cnt, int all_dirty) {
-  __shared__ uint16_t live_list[TPB * OCC_VPT];
+  __shared__ uint16_t live_list[OCC_TILE];
   __shared__ uint32_t n_live;
-  const uint32_t blk0 = blockIdx.x * (TPB * OCC_VPT);
+  const uint32_t blk0 = blockIdx.x * OCC_TILE;
+  // a tile nobody wrote to and no stamp changed in since the last sweep: every result entry of it stands
+  if (!all_dirty && st.tile_dirty[blockIdx.x] == 0) return;
   if (threadIdx.x == 0) n_live = 0;
-  uint32_t t0v[OCC_VPT], flag[OCC_VPT], smax[OCC_VPT];
-#pragma unroll
-  for (int u = 0; u < OCC_VPT; ++u) {
-    const uint32_t lv = blk0 + u * TPB + threadIdx.x;
-    if (lv >= d.v_count) continue;
-    t0v[u] = st.vts[lv];
-    flag[u] = st.vflag[lv];
-    uint32_t rx, ry, rz;
-    voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
-    smax[u] = stamp_max(st, rx, ry, rz);
+  __syncthreads();  // every wave has read the byte
+  if (threadIdx.x == 0) {
+    st.tile_dirty[blockIdx.x] = 0;  // phase 2 may set it again
+    atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep_tiles, 1u);
   }
-  __syncthreads();
+  {
+    uint16_t t0v[OCC_GROUPS][OCC_VPT];
+    uint8_t flag[OCC_GROUPS][OCC_VPT];
+    uint32_t sx[OCC_GROUPS][OCC_VPT], yz[OCC_GROUPS];
+    const bool rows = d.x_n >= 3;  // a group lies in one x row of the ring: one y and one z stamp, eight consecutive x stamps
 #pragma unroll
-  for (int u = 0; u < OCC_VPT; ++u) {
-    const uint32_t lv = blk0 + u * TPB + threadIdx.x;
-    if (lv >= d.v_count) continue;
-    sdm_voxel_result out;
-    out.track = 0;
-    out.label = 0;
-    const uint32_t state = flag[u] & VF_STATE, held = flag[u] & VR_MASK;
-    if (t0v[u] == 0 || t0v[u] < smax[u]) {  // isVoxelValid, operations.h:824-837
-      if (held == VR_UNOBSERVED && !all_dirty) continue;  // the result entry already says so
-      out.wsum = -1.f;
-      out.occ = -1;
-      store_result(st.res + lv, out);
-      // a CLEAN voxel's stored result is gone with this: it is evaluated again when the voxel is seen again
-      st.vflag[lv] = (uint8_t)((state == VF_CLEAN ? VF_DIRTY : state) | VR_UNOBSERVED);
-      continue;
+    for (int g = 0; g < OCC_GROUPS; ++g) {
+      const uint32_t lv0 = blk0 + (g * TPB + threadIdx.x) * OCC_VPT;  // v_count is a power of two >= 64: whole groups only
+      if (lv0 >= d.v_count) continue;
+      load_vec(t0v[g], st.vts + lv0);
+      load_vec(flag[g], st.vflag + lv0);
+      if (rows) {
+        uint32_t rx, ry, rz;
+        voxel_to_ring(d, d.v_begin + lv0, rx, ry, rz);
+        const uint32_t b = st.stamps_y[ry], c = st.stamps_z[rz];
+        yz[g] = b > c ? b : c;
+        load_vec(sx[g], st.stamps_x + rx);
+      }
     }
-    if (state == VF_EMPTY) {  // every slot INVALID: weight sum 0, no vote, nothing to clamp or cull
-      if (held == VR_EMPTY && !all_dirty) continue;
-      out.wsum = 0.f;
-      out.occ = 0.f > occ_threshold ? 1 : 0;
-      store_result(st.res + lv, out);
-      st.vflag[lv] = (uint8_t)(VF_EMPTY | VR_EMPTY);
-      continue;
+#pragma unroll
+    for (int g = 0; g < OCC_GROUPS; ++g) {
+      const uint32_t lv0 = blk0 + (g * TPB + threadIdx.x) * OCC_VPT;
+      if (lv0 >= d.v_count) continue;
+      uint8_t nflag[OCC_VPT];
+      bool flags_changed = false;
+#pragma unroll
+      for (int u = 0; u < OCC_VPT; ++u) {
+        const uint32_t lv = lv0 + u;
+        uint32_t smax;
+        if (rows) {
+          smax = sx[g][u] > yz[g] ? sx[g][u] : yz[g];
+        } else {
+          uint32_t rx, ry, rz;
+          voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+          smax = stamp_max(st, rx, ry, rz);
+        }
+        nflag[u] = flag[g][u];
+        sdm_voxel_result out;
+        out.track = 0;
+        out.label = 0;
+        const uint32_t state = flag[g][u] & VF_STATE, held = flag[g][u] & VR_MASK;
+        if (t0v[g][u] == 0 || t0v[g][u] < smax) {  // isVoxelValid, operations.h:824-837
+          if (held == VR_UNOBSERVED && !all_dirty) continue;  // the result entry already says so
+          out.wsum = -1.f;
+          out.occ = -1;
+          store_result(st.res + lv, out);
+          // a CLEAN voxel's stored result is gone with this: it is evaluated again when the voxel is seen again
+          nflag[u] = (uint8_t)((state == VF_CLEAN ? VF_DIRTY : state) | VR_UNOBSERVED);
+          flags_changed = true;
+          continue;
+        }
+        if (state == VF_EMPTY) {  // every slot INVALID: weight sum 0, no vote, nothing to clamp or cull
+          if (held == VR_EMPTY && !all_dirty) continue;
+          out.wsum = 0.f;
+          out.occ = 0.f > occ_threshold ? 1 : 0;
+          store_result(st.res + lv, out);
+          nflag[u] = (uint8_t)(VF_EMPTY | VR_EMPTY);
+          flags_changed = true;
+          continue;
+        }
+        if (state == VF_CLEAN && !all_dirty) continue;  // nothing it holds has changed: the result of the last sweep stands
+        live_list[atomicAdd(&n_live, 1u)] = (uint16_t)((g * TPB + threadIdx.x) * OCC_VPT + u);
+      }
+      if (flags_changed) store_vec(st.vflag + lv0, nflag);  // phase 2 rewrites the bytes of the listed voxels after the barrier
     }
-    if (state == VF_CLEAN && !all_dirty) continue;  // nothing it holds has changed: the result of the last sweep stands
-    live_list[atomicAdd(&n_live, 1u)] = (uint16_t)(u * TPB + threadIdx.x);
   }
   __syncthreads();
   const uint32_t nl = n_live;
-  if (threadIdx.x == 0 && nl) atomicAdd(&cnt->n_sweep_live, nl);
+  if (threadIdx.x == 0 && nl) atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep, nl);
   for (uint32_t k = threadIdx.x; k < nl; k += TPB) {
     const uint32_t lv = blk0 + live_list[k];
     const size_t base = (size_t)lv * S;
@@ -673,7 +711,10 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     if (im_ok) im_depth = sc.depth[(size_t)row * d.W + col];
   }
   if (!flag) {
-    if (im_ok && im_z <= im_depth) st.vts[lv] = (uint16_t)f.gts;
+    if (im_ok && im_z <= im_depth) {
+      st.vts[lv] = (uint16_t)f.gts;
+      mark_tile(st, lv);
+    }
     return;
   }
   const uint32_t smax = stamp_max(st, rx, ry, rz);
@@ -750,11 +791,10 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   }
   if (dirty) store_vec(st.status + base * REC_STATUS, stv);
   if (dirty || wrote_free) st.vflag[lv] = VF_DIRTY;
-  if (observed) {
-    st.vts[lv] = (uint16_t)f.gts;
-  } else if (valid_n == 0) {
-    if (im_ok && im_z <= im_depth) st.vts[lv] = (uint16_t)f.gts;
-  }
+  bool stamped = observed;
+  if (!observed && valid_n == 0) stamped = im_ok && im_z <= im_depth;
+  if (stamped) st.vts[lv] = (uint16_t)f.gts;
+  if (dirty || wrote_free || stamped) mark_tile(st, lv);
 }
 
 // Two phases per workgroup.  Only about a third of the voxels of the frustum's index box were reached, and testing
@@ -1239,6 +1279,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Frame f, F
       st.w[rec_index(li, d.p_n, REC_W)] = sc.vp4[k].w * (a * flt.p_detect + 1.f - flt.p_detect);
       st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_UPDATED;
       st.vflag[li >> d.p_n] = VF_DIRTY;
+      mark_tile(st, li >> d.p_n);
       st.ts[rec_index(li, d.p_n, REC_TS)] = (uint16_t)f.gts;
       if (!flt.independent) {
         uint32_t nf = right_id ? 0u : (fc < 5u ? fc + 1u : fc);
@@ -1471,7 +1512,10 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
     }
   }
   // same-address atomics retire one at a time: counters every wave bumps are sharded by block
-  if (n_success || n_resamp) st.vflag[v - d.v_begin] = VF_DIRTY;
+  if (n_success || n_resamp) {
+    st.vflag[v - d.v_begin] = VF_DIRTY;
+    mark_tile(st, v - d.v_begin);
+  }
   if (n_success) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].birth, n_success);
   if (n_resamp) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].resample, n_resamp);
 }
@@ -1723,7 +1767,7 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s, bool fresh) {
   }
 
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, hipStream_t s) {
-  dim3 grid(blocks_for(d.v_count, TPB * OCC_VPT));
+  dim3 grid(blocks_for(d.v_count, OCC_TILE));
   SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st, cnt, all_dirty);
 }
 

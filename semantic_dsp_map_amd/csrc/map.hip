@@ -492,6 +492,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->st.status = m->st.rec + 9 * (size_t)d.S;
   A(m->st.vts, d.v_count);
   A(m->st.vflag, d.v_count);
+  A(m->st.tile_dirty, (d.v_count >> TILE_SHIFT) + 1);
   A(m->st.owner, n_slots);
   A(m->st.owner_flag, (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK);
   A(m->st.alias, 2 + 2 * ALIAS_CAP);
@@ -766,6 +767,28 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
   mark(1);
   if (done(1)) return SDM_OK;
 
+  // The side chains are issued in the order in which they can start: the member count and the frustum chain when the
+  // previous frame's births are done, the birth candidates only after this frame's k_frame_begin.  (Under rocprofv3
+  // whatever is issued right behind the birth chain starts after it; unprofiled frame times do not depend on the
+  // order, nor on GPU_MAX_HW_QUEUES = 4 / 8 / 16, nor on folding the birth chain into one of the other side streams.)
+  // P2 (first part): collect the moving objects' particles (semantic_dsp_map.h:588-693)
+  if (n_moves > 0) {
+    MoveSet &ms = m->moveset;
+    memset(&ms, 0, sizeof(ms));
+    ms.n = n_moves;
+    for (int k = 0; k < n_moves; ++k) {
+      ms.track[k] = (uint16_t)moves[k].track_id;
+      memcpy(ms.T[k], moves[k].T, 12 * sizeof(float));
+    }
+    m->n_moves = n_moves;
+    // The member count only reads the owner sets, which were final when the previous frame's births were done: it runs
+    // on its own stream from that point on (next to the previous frame's sweep when frames are issued back to back)
+    // and the main stream picks its result up below.
+    if (!m->state_event_valid) HIP_TRY(hipEventRecord(m->ev_state, s));
+    HIP_TRY(hipStreamWaitEvent(m->s_moves, m->ev_state, 0));
+    launch_moves_count(d, ms, n_moves, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves);
+    HIP_TRY(hipEventRecord(m->ev_counts, m->s_moves));
+  }
   // fork: everything that only needs this frame's inputs and pose starts now on the side streams
   HIP_TRY(hipEventRecord(m->ev_begin, s));
   m->side_pending = false;
@@ -784,25 +807,7 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
     HIP_TRY(hipEventRecord(m->ev_birth, m->s_birth));
   }
 
-  // P2 (first part): collect the moving objects' particles (semantic_dsp_map.h:588-693)
-  if (n_moves > 0) {
-    MoveSet &ms = m->moveset;
-    memset(&ms, 0, sizeof(ms));
-    ms.n = n_moves;
-    for (int k = 0; k < n_moves; ++k) {
-      ms.track[k] = (uint16_t)moves[k].track_id;
-      memcpy(ms.T[k], moves[k].T, 12 * sizeof(float));
-    }
-    m->n_moves = n_moves;
-    // The member count only reads the owner sets, which were final when the previous frame's births were done: it runs
-    // on its own stream from that point on (next to the previous frame's sweep when frames are issued back to back)
-    // and the main stream picks its result up here.
-    if (!m->state_event_valid) HIP_TRY(hipEventRecord(m->ev_state, s));
-    HIP_TRY(hipStreamWaitEvent(m->s_moves, m->ev_state, 0));
-    launch_moves_count(d, ms, n_moves, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves);
-    HIP_TRY(hipEventRecord(m->ev_counts, m->s_moves));
-    HIP_TRY(hipStreamWaitEvent(s, m->ev_counts, 0));
-  }
+  if (n_moves > 0) HIP_TRY(hipStreamWaitEvent(s, m->ev_counts, 0));  // join: the main stream picks the counts up
   m->state_event_valid = false;  // set again when this frame's births are done
   if (n_remove > 0) {
     std::vector<uint16_t> tr(n_remove);
@@ -1287,7 +1292,10 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
   out->n_move_reinserted = c.n_move_reinserted;
   for (uint32_t k = 0; k < VIS_SHARDS; ++k) out->n_frustum_voxels += c.shard[k].fv;
   out->bfs_start_in_frustum = c.start_in_frustum;
-  out->sweep_live_voxels = c.n_sweep_live;
+  for (uint32_t k = 0; k < VIS_SHARDS; ++k) {
+    out->sweep_live_voxels += c.shard[k].sweep;
+    out->sweep_tiles += c.shard[k].sweep_tiles;
+  }
   out->flood_rounds = c.flood_rounds;
   if (m->profiling) {
     int prev = 0;

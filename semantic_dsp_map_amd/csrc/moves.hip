@@ -231,6 +231,7 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
   const uint16_t powner = ms.track[obj];
   st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_INVALID;  // deleteParticleByIndex
   st.vflag[li >> d.p_n] = VF_DIRTY;
+  mark_tile(st, li >> d.p_n);
   if (!alias) st.owner[li] = OWNER_NONE;  // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
   uint32_t rx, ry, rz;
   uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
@@ -571,6 +572,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
     }
     if (n_ok) {
       st.vflag[lv] = VF_DIRTY;
+      mark_tile(st, lv);
       atomicAdd(&sc.cnt->n_move_reinserted, n_ok);
     }
   }
@@ -587,6 +589,7 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
         if (tracks[q] == trk) {
           st.status[rec_index(st.alias[2 + 2 * k], p_n, REC_STATUS)] = ST_INVALID;
           st.vflag[st.alias[2 + 2 * k] >> p_n] = VF_DIRTY;
+          mark_tile(st, st.alias[2 + 2 * k] >> p_n);
           st.alias[3 + 2 * k] = OWNER_NONE;
           break;
         }
@@ -603,6 +606,7 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
       if (tracks[k] == o) {
         st.status[rec_index(i, p_n, REC_STATUS)] = ST_INVALID;
         st.vflag[i >> p_n] = VF_DIRTY;
+        mark_tile(st, i >> p_n);
         st.owner[i] = OWNER_NONE;
         break;
       }

@@ -82,8 +82,7 @@ struct Counters {
   uint32_t overflow;
   uint32_t n_valid_px;
   uint32_t n_move_voxels;  // voxels that receive at least one moved copy this frame
-  uint32_t n_sweep_live;   // voxels the occupancy sweep evaluated in full (record fetched) in its last launch
-  uint32_t pad[6];
+  uint32_t pad[7];
   // Atomics on one cache line retire one at a time (~12 ns each on MI355X) - same address or not.  Counters that
   // every wave bumps are therefore sharded by block index, one 128-byte line per shard; the per-shard
   // visible-particle counters also index per-shard regions of the work list.
@@ -93,7 +92,9 @@ struct Counters {
     uint32_t heavy;     // weight-update pass 1: pixels handed to the row-parallel kernel
     uint32_t birth;     // successful births
     uint32_t resample;  // voxels resampled
-    uint32_t pad[27];
+    uint32_t sweep;     // voxels the occupancy sweep evaluated in full (record fetched) in its last launch
+    uint32_t sweep_tiles;  // tiles that sweep looked into
+    uint32_t pad[25];
   };
   ShardLine shard[64];
   // Written by the frustum chain, which may run ahead of the frame's k_frame_begin (it starts when the previous
@@ -147,6 +148,7 @@ struct State {
   // entry holds right now - VR_UNOBSERVED, VR_EMPTY (the two constant results) or 0 = something else.  Together they
   // let the sweep finish an unobserved, empty or unchanged voxel from 3 bytes read and nothing written.
   uint8_t *vflag = nullptr;
+  uint8_t *tile_dirty = nullptr;  // per tile of 2^TILE_SHIFT voxels: something in it needs the sweep
   uint16_t *track = nullptr;
   uint8_t *label = nullptr;
   uint8_t *status = nullptr;
@@ -166,7 +168,11 @@ struct State {
   float *noise = nullptr;
 };
 
+// one byte per tile of 2^TILE_SHIFT voxels (State::tile_dirty): set by whoever sets VF_DIRTY on a voxel of the tile or
+// changes its observation stamp; the sweep returns at once from a tile whose byte is 0 and clears the byte otherwise
+constexpr int TILE_SHIFT = 11;
 enum : uint8_t { VF_EMPTY = 0, VF_CLEAN = 1, VF_DIRTY = 2, VF_STATE = 3, VR_UNOBSERVED = 1 << 2, VR_EMPTY = 2 << 2, VR_MASK = 3 << 2 };
+__device__ __forceinline__ void mark_tile(const State &st, size_t lv) { st.tile_dirty[lv >> TILE_SHIFT] = 1; }
 constexpr uint32_t ALIAS_CAP = 8192;
 
 // ObjectParticleHashMap::addParticleToObj (object_layer.h:31-33): slot li joins track's set.  li is the shard-local slot

@@ -7,7 +7,7 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc $c -d gpurun_out/pmc_${tag}_$c -o s -- python bench.py --no-cpu --steps 12 --warmup 4 > gpurun_out/${tag}_sweep_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc $c -d gpurun_out/pmc_${tag}_$c -o s -- python bench.py --no-cpu --no-dense --steps 20 --warmup 5 > gpurun_out/${tag}_sweep_$c.log 2>&1
   grep -E "Kernel_Name|k_occupancy" gpurun_out/pmc_${tag}_$c/s_counter_collection.csv > gpurun_out/${tag}_sweep_$c.csv
   rm -rf gpurun_out/pmc_${tag}_$c
 done
