@@ -21,8 +21,8 @@ b = json.loads(open(g + "%s_sweep_bench.json" % tag).read())
 rf = b["roofline"]
 fetch_kib, us_f, n = res["FETCH_SIZE"]
 write_kib, us_w, _ = res["WRITE_SIZE"]
-out = {"kernel": rf["kernel"], "voxels": rf["voxels"], "voxels_evaluated_in_full": rf["voxels_evaluated_in_full"],
-       "tiles": rf.get("tiles"), "tiles_looked_into": rf.get("tiles_looked_into"),
+out = {"kernel": rf["kernel"], "voxels": rf["voxels"], "voxels_evaluated_in_full": rf["layout"]["voxels_evaluated_in_full"],
+       "tiles": rf["layout"]["tiles"], "tiles_looked_into": rf["layout"]["tiles_looked_into"],
        "state": "in-frame launches of `python bench.py --no-cpu --no-dense --steps 20 --warmup 5` (C3 benchmark map), the last %d launches of the run" % last,
        "launches_averaged": n,
        "FETCH_SIZE_KiB_per_launch": round(fetch_kib, 1), "WRITE_SIZE_KiB_per_launch": round(write_kib, 1),
@@ -31,10 +31,10 @@ out = {"kernel": rf["kernel"], "voxels": rf["voxels"], "voxels_evaluated_in_full
                            "the corrected figure is an upper estimate)",
        "fetch_bytes_per_launch": int(fetch_kib * 1024 * 2), "write_bytes_per_launch": int(write_kib * 1024),
        "traffic_bytes_per_launch": int(fetch_kib * 1024 * 2 + write_kib * 1024),
-       "algorithmic_bytes_per_launch": rf["bytes_per_launch"],
+       "layout_bytes_per_launch": rf["layout"]["bytes_per_launch"], "dense_slot_bytes_per_launch": rf["bytes_per_launch"],
        "avg_kernel_us_under_pmc": round((us_f + us_w) / 2, 1),
        "commands": ["rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -- python bench.py --no-cpu --no-dense --steps 20 --warmup 5",
                     "rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -- python bench.py --no-cpu --no-dense --steps 20 --warmup 5"]}
 json.dump(out, open("profiles/%s_sweep_pmc.json" % tag, "w"), indent=1)
-print(json.dumps({k: out[k] for k in ["voxels_evaluated_in_full", "traffic_bytes_per_launch", "algorithmic_bytes_per_launch",
+print(json.dumps({k: out[k] for k in ["voxels_evaluated_in_full", "traffic_bytes_per_launch", "layout_bytes_per_launch",
                                       "avg_kernel_us_under_pmc"]}))
