@@ -175,6 +175,15 @@ def main():
     if world == 1 and not args.no_dense:
         # the same kernel on SURVEY.md 8(d)'s dense case (every slot of every voxel live, all of them to be evaluated):
         # run last, it overwrites the map
+        # first the non-incremental launch on the benchmark state: every tile, every voxel's result written, every voxel
+        # that holds a live slot evaluated (what each sweep did before the clean/dirty state, and what the first sweep
+        # after sdm_load_state / sdm_set_params does)
+        full_ms = m.time_occupancy_sweep(iters=10)
+        full_bytes = V * (2 + 1 + 8) + live_vox_local * (10 * S + 1)
+        roofline["full_evaluation"] = {"bytes_per_launch": full_bytes, "avg_launch_ms": round(full_ms, 5),
+                                       "achieved": round(full_bytes / full_ms / 1e6, 1),
+                                       "frac": round(full_bytes / full_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
+                                       "launches_timed": 10}
         m.fill_dense()
         dense_ms = m.time_occupancy_sweep(iters=10)
         dense_bytes = V * (2 + 1 + 8 + 10 * S)  # here the layout's own count: stamp, flag, result, record

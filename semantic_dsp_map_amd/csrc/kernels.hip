@@ -275,9 +275,12 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
       if (lv0 >= d.v_count) continue;
       uint8_t nflag[OCC_VPT];
       bool flags_changed = false;
+      v2u outw[OCC_VPT];       // the constant results this thread has to write ...
+      uint32_t want = 0;       // ... for these of its voxels
 #pragma unroll
       for (int u = 0; u < OCC_VPT; ++u) {
         const uint32_t lv = lv0 + u;
+        outw[u] = v2u{0u, 0u};
         uint32_t smax;
         if (rows) {
           smax = sx[g][u] > yz[g] ? sx[g][u] : yz[g];
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
           if (held == VR_UNOBSERVED && !all_dirty) continue;  // the result entry already says so
           out.wsum = -1.f;
           out.occ = -1;
-          store_result(st.res + lv, out);
+          __builtin_memcpy(&outw[u], &out, 8);
+          want |= 1u << u;
           // a CLEAN voxel's stored result is gone with this: it is evaluated again when the voxel is seen again
           nflag[u] = (uint8_t)((state == VF_CLEAN ? VF_DIRTY : state) | VR_UNOBSERVED);
           flags_changed = true;
@@ -305,7 +309,8 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
           if (held == VR_EMPTY && !all_dirty) continue;
           out.wsum = 0.f;
           out.occ = 0.f > occ_threshold ? 1 : 0;
-          store_result(st.res + lv, out);
+          __builtin_memcpy(&outw[u], &out, 8);
+          want |= 1u << u;
           nflag[u] = (uint8_t)(VF_EMPTY | VR_EMPTY);
           flags_changed = true;
           continue;
@@ -314,6 +319,16 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
         live_list[atomicAdd(&n_live, 1u)] = (uint16_t)((g * TPB + threadIdx.x) * OCC_VPT + u);
       }
       if (flags_changed) store_vec(st.vflag + lv0, nflag);  // phase 2 rewrites the bytes of the listed voxels after the barrier
+      if (want == (1u << OCC_VPT) - 1u) {  // the whole group (first sweep of a state, recycled slab rows): 64 contiguous bytes
+        v4u *dst = reinterpret_cast<v4u *>(st.res + lv0);
+#pragma unroll
+        for (int u = 0; u < OCC_VPT; u += 2)
+          __builtin_nontemporal_store(v4u{outw[u].x, outw[u].y, outw[u + 1].x, outw[u + 1].y}, dst + u / 2);
+      } else {
+#pragma unroll
+        for (int u = 0; u < OCC_VPT; ++u)
+          if (want & (1u << u)) __builtin_nontemporal_store(outw[u], reinterpret_cast<v2u *>(st.res + lv0 + u));
+      }
     }
   }
   __syncthreads();
