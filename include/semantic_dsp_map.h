@@ -37,12 +37,14 @@
 #include <limits>
 #include <map>
 #include <set>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 #include "sdm.h"
+#include "sdm_objects.h"
 
 #ifndef SDM_HAVE_REFERENCE_TRACKING_TYPES
 /// utils/data_base.h:25-31
@@ -100,6 +102,67 @@ struct SdmObjectLayer {
   virtual void collect(uint32_t global_time_stamp, int max_obersevation_lost_time, std::vector<sdm_object_move> &moves,
                        std::vector<int32_t> &remove_tracks) = 0;
   virtual void clear() = 0;
+  /// global_time_stamp after the increment at the head of update() (semantic_dsp_map.h:173), told before update()
+  virtual void setGlobalTimeStamp(uint32_t) {}
+};
+
+/// The library's own object layer (sdm_objects.h): objectLevelUpdate and the object loop of the
+/// prediction step restated on plain doubles with a seeded RANSAC sampler.  "Floating" objects (tracks that own
+/// particles but are not tracked, semantic_dsp_map.h:713-733) are not looked for: the map would have to list its owners.
+class SdmBuiltinObjectLayer : public SdmObjectLayer {
+ public:
+  SdmBuiltinObjectLayer(const sdm_objects_config &cfg, const std::unordered_map<std::string, int> &label_ids)
+      : h_(nullptr), label_ids_(label_ids), global_time_stamp_(0) {
+    if (sdm_objects_create(&cfg, &h_) != SDM_OK) throw std::invalid_argument("sdm_objects_create: bad configuration");
+  }
+  ~SdmBuiltinObjectLayer() override { sdm_objects_destroy(h_); }
+  SdmBuiltinObjectLayer(const SdmBuiltinObjectLayer &) = delete;
+  SdmBuiltinObjectLayer &operator=(const SdmBuiltinObjectLayer &) = delete;
+
+  void setGlobalTimeStamp(uint32_t t) override { global_time_stamp_ = t; }
+  void update(const std::vector<MaskKpts> &ins_seg_result, const Eigen::Vector3d &camera_position,
+              const Eigen::Quaterniond &camera_orientation, double time_stamp) override {
+    std::vector<sdm_object_observation> obs(ins_seg_result.size());
+    std::vector<std::vector<double>> cur(ins_seg_result.size()), prev(ins_seg_result.size());
+    for (size_t i = 0; i < ins_seg_result.size(); ++i) {
+      const MaskKpts &s = ins_seg_result[i];
+      for (const Eigen::Vector3d &p : s.kpts_current) cur[i].insert(cur[i].end(), {p.x(), p.y(), p.z()});
+      for (const Eigen::Vector3d &p : s.kpts_previous) prev[i].insert(prev[i].end(), {p.x(), p.y(), p.z()});
+      auto it = label_ids_.find(s.label);
+      obs[i].track_id = s.track_id;
+      obs[i].label_id = it == label_ids_.end() ? -1 : it->second;
+      obs[i].is_static = s.label == "static";
+      obs[i].n_kpts = (int32_t)s.kpts_current.size();
+      obs[i].kpts_current = cur[i].empty() ? nullptr : cur[i].data();
+      obs[i].kpts_previous = prev[i].size() == cur[i].size() && !prev[i].empty() ? prev[i].data() : nullptr;
+    }
+    const double pos[3] = {camera_position.x(), camera_position.y(), camera_position.z()};
+    const double q[4] = {camera_orientation.w(), camera_orientation.x(), camera_orientation.y(), camera_orientation.z()};
+    if (sdm_objects_update(h_, obs.empty() ? nullptr : obs.data(), (int32_t)obs.size(), pos, q, time_stamp, global_time_stamp_) != SDM_OK)
+      std::cerr << "sdm_objects_update failed" << std::endl;
+  }
+  void collect(uint32_t global_time_stamp, int max_obersevation_lost_time, std::vector<sdm_object_move> &moves,
+               std::vector<int32_t> &remove_tracks) override {
+    int32_t n_tracked = 0;
+    sdm_objects_count(h_, &n_tracked);
+    moves.resize((size_t)n_tracked);
+    remove_tracks.resize((size_t)n_tracked);
+    int32_t n_moves = 0, n_remove = 0;
+    if (sdm_objects_collect(h_, global_time_stamp, max_obersevation_lost_time, nullptr, 0, moves.data(), n_tracked, &n_moves,
+                            remove_tracks.data(), n_tracked, &n_remove) != SDM_OK) {
+      std::cerr << "sdm_objects_collect failed" << std::endl;
+      n_moves = n_remove = 0;
+    }
+    moves.resize((size_t)n_moves);
+    remove_tracks.resize((size_t)n_remove);
+  }
+  void clear() override { sdm_objects_clear(h_); }
+  sdm_objects *handle() { return h_; }
+
+ private:
+  sdm_objects *h_;
+  std::unordered_map<std::string, int> label_ids_;
+  uint32_t global_time_stamp_;
 };
 
 class SemanticDSPMap {
@@ -148,6 +211,28 @@ class SemanticDSPMap {
   void setGridPreset(const SdmGridPreset &p) { preset_ = p; }
   void setDevice(int hip_device) { device_ = hip_device; }
   void setObjectLayer(SdmObjectLayer *layer) { object_layer_ = layer; }
+  /// Use the library's object layer (sdm_objects.h).  mode = the reference's SETTING (settings.h:22); call after
+  /// setGridPreset / setLabelTables / setBeyesianMovementParameters.
+  void useBuiltinObjectLayer(int mode, uint64_t seed = 20250217ull) {
+    sdm_objects_config c;
+    c.mode = mode;
+    c.max_movable_instance_id = max_movable_track_;
+    c.movement_distance_threshold = beyesian_[0];
+    c.movement_probability_threshold = beyesian_[1];
+    c.movement_increment = beyesian_[2];
+    c.movement_decrement = beyesian_[3];
+    const int n_biggest = std::max(std::max(preset_.x_n, preset_.y_n), preset_.z_n);
+    c.map_half_size_scaled = (double)preset_.voxel_size * (double)(1 << (n_biggest - 1)) * 1.2;  // semantic_dsp_map.h:356
+    c.fx = preset_.fx;
+    c.fy = preset_.fy;
+    c.cx = preset_.cx;
+    c.cy = preset_.cy;
+    c.image_width = preset_.width;
+    c.image_height = preset_.height;
+    c.seed = seed;
+    builtin_layer_.reset(new SdmBuiltinObjectLayer(c, label_id_));
+    object_layer_ = builtin_layer_.get();
+  }
   /// label tables of utils/object_info_handler.h:28-91 (CSV): label name -> label id, static label -> instance id
   void setLabelTables(const std::map<std::string, int> &label_ids, const std::map<std::string, int> &static_instance_ids) {
     label_id_.clear();
@@ -236,6 +321,7 @@ class SemanticDSPMap {
     std::vector<sdm_object_move> moves;
     std::vector<int32_t> removals;
     if (preset_.consider_instance && object_layer_) {  // :189-191
+      object_layer_->setGlobalTimeStamp(global_time_stamp_);
       object_layer_->update(ins_seg_result, camera_position, camera_orientation, time_stamp_double);
       object_layer_->collect(global_time_stamp_, params_.max_obersevation_lost_time, moves, removals);
     }
@@ -273,6 +359,7 @@ class SemanticDSPMap {
  private:
   sdm_map *map_;
   SdmObjectLayer *object_layer_;
+  std::unique_ptr<SdmBuiltinObjectLayer> builtin_layer_;
   SdmGridPreset preset_;
   sdm_params params_;
   int device_;

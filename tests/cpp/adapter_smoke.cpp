@@ -24,7 +24,49 @@ int main(int argc, char **argv) {
   map.setVisualizeOptions(false, true);
   map.setBeyesianMovementParameters(0.1, 0.75, 0.2, 0.1);
   map.setDepthNoiseModelParameters(0.01f, 0.2f);
+  map.useBuiltinObjectLayer(SDM_OBJECTS_MODE_ZED2);
   if (!run) {
+    // the object layer is host code: drive it here through the adapter's MaskKpts conversion (no device needed)
+    sdm_objects_config oc{};
+    oc.mode = SDM_OBJECTS_MODE_ZED2;
+    oc.max_movable_instance_id = 65523;
+    oc.movement_distance_threshold = 0.1;
+    oc.movement_probability_threshold = 0.75;
+    oc.movement_increment = 0.2;
+    oc.movement_decrement = 0.1;
+    oc.map_half_size_scaled = 0.4 * 16 * 1.2;
+    oc.fx = oc.fy = 80.0;
+    oc.cx = 64.0;
+    oc.cy = 40.0;
+    oc.image_width = 128;
+    oc.image_height = 80;
+    oc.seed = 7;
+    std::unordered_map<std::string, int> labels{{"Car", 15}};
+    SdmBuiltinObjectLayer layer(oc, labels);
+    int moved_frames = 0;
+    for (int t = 0; t < 8; ++t) {
+      MaskKpts car;
+      car.track_id = 2;
+      car.label = "Car";
+      const double x = -1.0 + 0.5 * t;
+      car.kpts_current = {Eigen::Vector3d(x, 0, 5), Eigen::Vector3d(x + 0.3, 0, 5), Eigen::Vector3d(x, 0.3, 5), Eigen::Vector3d(x, 0, 5.6)};
+      MaskKpts unknown = car;
+      unknown.track_id = 3;
+      unknown.label = "Zeppelin";
+      std::vector<MaskKpts> seg{car, unknown};
+      std::vector<sdm_object_move> moves;
+      std::vector<int32_t> removals;
+      layer.setGlobalTimeStamp((uint32_t)t + 1);
+      layer.update(seg, Eigen::Vector3d(0, 0, 0), Eigen::Quaterniond(1, 0, 0, 0), 0.1 * t);
+      layer.collect((uint32_t)t + 1, 5, moves, removals);
+      if (!moves.empty()) {
+        if (moves.size() != 1 || moves[0].track_id != 2 || moves[0].T[3] < 0.45f || moves[0].T[3] > 0.55f) return 3;
+        ++moved_frames;
+      }
+      if (!removals.empty()) return 4;
+    }
+    std::printf("object layer: car moved in %d of 8 frames\n", moved_frames);
+    if (moved_frames < 3) return 5;
     std::printf("adapter constructed\n");
     return 0;
   }

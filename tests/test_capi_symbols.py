@@ -11,8 +11,8 @@ from semantic_dsp_map_amd import binding
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "sdm.h")).read()
+def declared_functions(header="sdm.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(sdm_[a-z0-9_]+)\s*\(", text)))
 
@@ -26,6 +26,20 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert len(names) >= 35
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, "declared in include/sdm.h but not exported: %s" % missing
+
+
+def test_object_layer_header_is_exported_and_bound():
+    """include/sdm_objects.h (host-side object layer): every function exported, every one reachable from Python."""
+    from semantic_dsp_map_amd import objects
+    lib = C.CDLL(binding.LIB_PATH)
+    names = declared_functions("sdm_objects.h")
+    assert len(names) == 10
+    assert not [n for n in names if not hasattr(lib, n)]
+    L = objects._lib()
+    for n in names:
+        assert getattr(L, n).argtypes is not None, n
+    assert C.sizeof(objects.ObjectsConfig) == 96 and C.sizeof(objects.Observation) == 32
+    assert C.sizeof(objects.ObjectMove) == 68 and C.sizeof(objects.ObjectInfo) == 200
 
 
 def test_binding_covers_the_header():

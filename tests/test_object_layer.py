@@ -1,0 +1,352 @@
+"""Object layer: csrc/objects.cpp through its C ABI against oracle/object_layer.py (numpy restatement
+of include/object_layer.h, semantic_dsp_map.h:304-566/588-736, basic_algorithms.h:54-195).  Host code only: runs without
+a GPU.  Floating point: the two SVDs differ (one-sided Jacobi vs LAPACK), tolerance 1e-9 absolute on matrices built from
+O(1..10) coordinates; decisions (inlier sets, moving flags, lists of moves / removals) must be identical."""
+import numpy as np
+import pytest
+
+from oracle import object_layer as ref
+from semantic_dsp_map_amd import objects as prod
+
+TOL = 1e-9
+
+
+def random_rigid(rng, max_angle=0.6, max_shift=2.0):
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    ang = rng.uniform(-max_angle, max_angle)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = rng.uniform(-max_shift, max_shift, 3)
+    return T
+
+
+def apply(T, P):
+    return P @ T[:3, :3].T + T[:3, 3]
+
+
+def base_cfg(mode, **kw):
+    cfg = dict(mode=mode, max_movable_instance_id=65000, movement_distance_threshold=0.1, movement_probability_threshold=0.75,
+               movement_increment=0.2, movement_decrement=0.1, map_half_size_scaled=0.2 * 128 * 1.2,
+               fx=725.0087, fy=725.0087, cx=620.5, cy=187.0, image_width=1242, image_height=375, seed=20250217)
+    cfg.update(kw)
+    return cfg
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 17, 200])
+def test_fit_rigid_recovers_the_transform_and_matches_oracle(n):
+    rng = np.random.default_rng(n)
+    for _ in range(20):
+        P = rng.normal(size=(n, 3)) * 3
+        T = random_rigid(rng)
+        Q = apply(T, P) + rng.normal(size=(n, 3)) * 1e-3
+        a = prod.fit_rigid(P, Q)
+        b = ref.estimate_transformation(P.T, Q.T)
+        assert np.abs(a - b).max() < TOL
+        assert abs(np.linalg.det(a[:3, :3]) - 1) < 1e-12
+        assert np.abs(a - T).max() < 2e-2
+
+
+def test_fit_rigid_degenerate_inputs():
+    rng = np.random.default_rng(5)
+    # coplanar points, mirrored target: the reflection fix must yield a proper rotation, same as the oracle
+    P = np.c_[rng.normal(size=(6, 2)), np.zeros(6)]
+    Q = P * np.array([1, 1, -1]) + np.array([0.5, 0, 0])
+    a, b = prod.fit_rigid(P, Q), ref.estimate_transformation(P.T, Q.T)
+    assert np.abs(a - b).max() < TOL and abs(np.linalg.det(a[:3, :3]) - 1) < 1e-12
+    # three points (rank 2 cross-covariance): what every RANSAC sample is
+    P = rng.normal(size=(3, 3))
+    T = random_rigid(rng)
+    a, b = prod.fit_rigid(P, apply(T, P)), ref.estimate_transformation(P.T, apply(T, P).T)
+    assert np.abs(a - b).max() < TOL and np.abs(a - T).max() < 1e-9
+    # identical point sets -> identity; a single point -> pure translation
+    a = prod.fit_rigid(P, P)
+    assert np.abs(a - np.eye(4)).max() < 1e-12
+    a = prod.fit_rigid(P[:1], P[:1] + 1.0)
+    assert np.abs(a[:3, 3] - 1.0).max() < 1e-12 and abs(np.linalg.det(a[:3, :3]) - 1) < 1e-12
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_ransac_rejects_outliers_like_the_oracle(seed):
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(8, 60))
+    P = rng.normal(size=(n, 3)) * 2
+    T = random_rigid(rng)
+    Q = apply(T, P) + rng.normal(size=(n, 3)) * 0.01
+    bad = rng.choice(n, size=n // 4, replace=False)
+    Q[bad] += rng.normal(size=(len(bad), 3)) * 3 + 2
+    for refine in (False, True):
+        a, inl_a, mse_a = prod.fit_rigid_ransac(P, Q, 100, 0.5, refine, seed=seed * 7919 + 1)
+        b, inl_b, mse_b = ref.estimate_transformation_ransac(P.T, Q.T, 100, 0.5, refine, seed=seed * 7919 + 1)
+        assert inl_a == inl_b
+        assert np.abs(a - b).max() < 1e-8
+        assert abs(mse_a - mse_b) < 1e-9
+        assert set(inl_a).isdisjoint(set(bad.tolist())) or len(set(inl_a) & set(bad.tolist())) <= 1
+    # the same seed gives the same answer, another seed may sample differently but finds the same consensus here
+    a2, inl2, _ = prod.fit_rigid_ransac(P, Q, 100, 0.5, True, seed=seed * 7919 + 1)
+    assert np.array_equal(a, a2) and inl2 == inl_a
+
+
+def test_ransac_rejects_fewer_than_three_points():
+    from semantic_dsp_map_amd.binding import SdmError
+    with pytest.raises(SdmError):
+        prod.fit_rigid_ransac(np.zeros((2, 3)), np.zeros((2, 3)))
+
+
+def box_keypoints(center, yaw, size=(1.8, 1.5, 4.2)):
+    """Four corners of a box the way a 3-D detector reports them: origin corner, +width, +height, +length."""
+    c, s = np.cos(yaw), np.sin(yaw)
+    R = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    w, h, l = size
+    local = np.array([[0, 0, 0], [w, 0, 0], [0, h, 0], [0, 0, l]], dtype=np.float64) - np.array([w / 2, h / 2, l / 2])
+    return local @ R.T + center
+
+
+def compare_layers(p, o, ids):
+    for tid in ids:
+        q = p.query(tid)
+        t = o.tracked.get(tid)
+        assert bool(q["exists"]) == (t is not None), tid
+        if t is None:
+            continue
+        assert q["observation_count"] == t.observation_count
+        assert q["observation_time_step"] == t.observation_time_step
+        assert bool(q["has_moved_flag"]) == bool(t.moved_vec)
+        assert bool(q["moving"]) == bool(t.moved_vec and t.moved_vec[0]), tid
+        assert bool(q["to_match_with_previous"]) == t.to_match_with_previous
+        assert bool(q["prediction_available"]) == t.transformations.updated
+        assert q["n_transformations"] == len(t.transformations.t_matrix_vec)
+        assert abs(q["moved_probability"] - t.moved_probability) < 1e-12
+        if t.t_matrix_vec:
+            assert np.abs(q["t_matrix"] - t.t_matrix_vec[0]).max() < 1e-8
+        if t.transformations.updated:
+            assert np.allclose(q["translation_velocity"], t.transformations.translation_velocity, atol=1e-7, equal_nan=True)
+
+
+def run_both(cfg, frames, max_lost=5, present=None):
+    """frames: list of (observations, cam_pos, cam_q, time_stamp).  Returns the per-frame (moves, removals) of the product
+    after checking them and the tracker state against the oracle."""
+    p, o = prod.ObjectLayer(cfg), ref.ObjectLayer(cfg)
+    out = []
+    ids = sorted({ob["track_id"] for f in frames for ob in f[0]})
+    for t, (obs, pos, q, ts) in enumerate(frames):
+        gts = t + 1
+        p.update(obs, pos, q, ts, gts)
+        o.update(obs, pos, q, ts, gts)
+        compare_layers(p, o, ids)
+        pres = present[t] if present else ()
+        mp, rp = p.collect(gts, max_lost, pres)
+        mo, ro = o.collect(gts, max_lost, pres)
+        assert rp == ro, (t, rp, ro)
+        assert [m[0] for m in mp] == [m[0] for m in mo], t
+        for (_, a), (_, b) in zip(mp, mo):
+            assert a.dtype == np.float32 and np.abs(a.astype(np.float64) - b.astype(np.float64)).max() < 1e-6
+        compare_layers(p, o, ids)
+        out.append((mp, rp))
+    assert p.count() == len(o.tracked)
+    p.close()
+    return out
+
+
+def test_box_mode_track_predict_lose():
+    """SETTING 3: two cars seen with box keypoints, one moves, one parks; the mover is occluded for a while (constant
+    velocity prediction), then lost (removal after max_obersevation_lost_time)."""
+    cfg = base_cfg(prod.MODE_ZED2)
+    pos, q = np.zeros(3), np.array([1.0, 0, 0, 0])
+    frames = []
+    for t in range(22):
+        obs = []
+        if t < 10:
+            obs.append(dict(track_id=3, label_id=15, is_static=False, kpts_current=box_keypoints(np.array([2.0 + 0.6 * t, 0.5, 12.0]), 0.02 * t),
+                            kpts_previous=None))
+        obs.append(dict(track_id=4, label_id=15, is_static=False, kpts_current=box_keypoints(np.array([-3.0, 0.5, 9.0]), 0.3), kpts_previous=None))
+        obs.append(dict(track_id=70000, label_id=15, is_static=False, kpts_current=box_keypoints(np.array([0, 0, 5.0]), 0), kpts_previous=None))
+        obs.append(dict(track_id=9, label_id=2, is_static=True, kpts_current=np.zeros((0, 3)), kpts_previous=None))
+        frames.append((obs, pos, q, 0.1 * t))
+    out = run_both(cfg, frames)
+    moved = [[m[0] for m in mv] for mv, _ in out]
+    assert any(3 in m for m in moved[:10]), "the moving car is never declared moving"
+    assert all(4 not in m for m in moved), "the parked car moves"
+    assert all(70000 not in m for m in moved)
+    first = next(t for t, m in enumerate(moved) if 3 in m)
+    T = next(m[1] for m in out[first][0] if m[0] == 3)
+    c_prev, c_cur = np.array([2.0 + 0.6 * (first - 1), 0.5, 12.0]), np.array([2.0 + 0.6 * first, 0.5, 12.0])
+    assert np.abs(T[:3, :3].astype(np.float64) @ c_prev + T[:3, 3] - c_cur).max() < 1e-4   # carries the box centre along
+    occluded = [t for t in range(10, 22) if 3 in moved[t]]
+    assert occluded and occluded[0] == 10                  # predicted while occluded ...
+    Tp = next(m[1] for m in out[10][0] if m[0] == 3)
+    assert np.allclose(Tp[:3, :3], np.eye(3)) and Tp[0, 3] > 0.3   # ... translation only, along the estimated velocity
+    removed = [t for t, (_, r) in enumerate(out) if 3 in r]
+    assert removed == [14]                                 # last seen at stamp 10, lost for 5 frames at stamp 15
+    assert all(3 not in m for m in moved[15:])
+
+
+def test_box_mode_out_of_view_and_far_objects():
+    cfg = base_cfg(prod.MODE_ZED2)
+    pos, q = np.zeros(3), np.array([1.0, 0, 0, 0])
+    frames = []
+    for t in range(8):
+        obs = [
+            # the last keypoint (and only it, PINNED) decides "out of view": this box sits at the image border
+            dict(track_id=1, label_id=15, is_static=False, kpts_current=box_keypoints(np.array([9.0 + 0.5 * t, 0.5, 6.0]), 0), kpts_previous=None),
+            # too far on first sight: never added
+            dict(track_id=2, label_id=15, is_static=False, kpts_current=box_keypoints(np.array([0, 0, 80.0 + t]), 0), kpts_previous=None),
+            # label not in the table: counted as observed, never added
+            dict(track_id=5, label_id=-1, is_static=False, kpts_current=box_keypoints(np.array([0, 0, 8.0]), 0), kpts_previous=None),
+            # behind the camera
+            dict(track_id=6, label_id=15, is_static=False, kpts_current=box_keypoints(np.array([1.0 + 0.5 * t, 0, -6.0]), 0), kpts_previous=None),
+        ]
+        frames.append((obs, pos, q, 0.1 * t))
+    present = [(2, 5, 6, 1)] * 8   # tracks that own particles in the map: 2 and 5 are "floating" -> wiped every frame
+    out = run_both(cfg, frames, present=present)
+    for _, r in out:
+        assert 2 in r and 5 in r and 1 not in r and 6 not in r
+
+
+@pytest.mark.parametrize("mode", [prod.MODE_CODA, prod.MODE_VKITTI2])
+def test_matched_keypoint_modes(mode):
+    """SETTING 1/2: matched keypoints, RANSAC with refinement, Bayes filter (2) or always moving (1); frames with too
+    few keypoints fall back to prediction or set the re-matching flag."""
+    rng = np.random.default_rng(3 + mode)
+    cfg = base_cfg(mode)
+    pos, q = np.zeros(3), np.array([1.0, 0, 0, 0])
+    body = rng.normal(size=(24, 3)) * np.array([1.0, 0.6, 2.0]) + np.array([3.0, 0.5, 14.0])
+    step = np.eye(4)
+    step[:3, 3] = [0.5, 0, 0.1]
+    parked = rng.normal(size=(12, 3)) + np.array([-4.0, 0.5, 10.0])
+    frames, prev = [], body.copy()
+    for t in range(20):
+        cur = apply(step, prev) + rng.normal(size=prev.shape) * 0.005
+        obs = []
+        if t in (6, 7):            # textureless frames: 3 keypoints only
+            obs.append(dict(track_id=11, label_id=15, is_static=False, kpts_current=cur[:3], kpts_previous=prev[:3]))
+        elif t < 14:
+            k = cur.copy()
+            if t == 4:             # a frame of garbage matches: transformation rejected (mse / inlier ratio)
+                k = k + rng.normal(size=k.shape) * 4
+            obs.append(dict(track_id=11, label_id=15, is_static=False, kpts_current=k, kpts_previous=prev))
+        obs.append(dict(track_id=12, label_id=15, is_static=False, kpts_current=parked + rng.normal(size=parked.shape) * 0.004,
+                        kpts_previous=parked))
+        frames.append((obs, pos, q, 0.1 * t))
+        prev = cur
+    out = run_both(cfg, frames)
+    moved = [[m[0] for m in mv] for mv, _ in out]
+    assert any(11 in m for m in moved)
+    if mode == prod.MODE_VKITTI2:
+        assert all(12 not in m for m in moved)   # Bayes filter keeps the parked car static
+    else:
+        assert any(12 in m for m in moved)       # SETTING 1: every updated object counts as moving
+    assert any(11 in r for _, r in out)          # lost after it disappears
+
+
+def test_results_do_not_depend_on_listing_order_and_replay_identically():
+    rng = np.random.default_rng(9)
+    cfg = base_cfg(prod.MODE_VKITTI2)
+    pos, q = np.zeros(3), np.array([1.0, 0, 0, 0])
+    clouds = {tid: rng.normal(size=(15, 3)) + np.array([tid * 2.0 - 8, 0.5, 12.0]) for tid in range(1, 7)}
+    frames_a, frames_b = [], []
+    for t in range(10):
+        obs = []
+        for tid, c in clouds.items():
+            shift = np.array([0.4 * (tid % 3), 0, 0.2 * (tid % 2)])
+            noise = rng.normal(size=c.shape) * 0.01
+            bad = rng.random(len(c)) < 0.2
+            cur = c + shift + noise + bad[:, None] * rng.normal(size=c.shape) * 3
+            obs.append(dict(track_id=tid, label_id=15, is_static=False, kpts_current=cur, kpts_previous=c.copy()))
+            clouds[tid] = c + shift
+        frames_a.append((obs, pos, q, 0.1 * t))
+        frames_b.append((obs[::-1], pos, q, 0.1 * t))
+    a, b, a2 = run_both(cfg, frames_a), run_both(cfg, frames_b), run_both(cfg, frames_a)
+    for (ma, ra), (mb, rb), (mc, rc) in zip(a, b, a2):
+        assert ra == rb == rc
+        assert [m[0] for m in ma] == [m[0] for m in mb] == [m[0] for m in mc]
+        for x, y, z in zip(ma, mb, mc):
+            assert np.array_equal(x[1], y[1]) and np.array_equal(x[1], z[1])
+
+
+def test_static_mode_never_moves_anything():
+    cfg = base_cfg(prod.MODE_KITTI360)
+    pos, q = np.zeros(3), np.array([1.0, 0, 0, 0])
+    frames = [([dict(track_id=1, label_id=15, is_static=False, kpts_current=box_keypoints(np.array([0.5 * t, 0.5, 8.0]), 0),
+                     kpts_previous=None)], pos, q, 0.1 * t) for t in range(8)]
+    out = run_both(cfg, frames)
+    assert all(not mv and not r for mv, r in out)
+
+
+def test_clear_and_bayes_parameters():
+    cfg = base_cfg(prod.MODE_ZED2)
+    p = prod.ObjectLayer(cfg)
+    pos, q = np.zeros(3), np.array([1.0, 0, 0, 0])
+
+    def frame(t):
+        p.update([dict(track_id=1, label_id=15, is_static=False, kpts_current=box_keypoints(np.array([0.8 * t, 0.5, 10.0]), 0),
+                       kpts_previous=None)], pos, q, 0.1 * t, t + 1)
+
+    for t in range(6):   # "moved" once the reference corner is further from its key position than the box is wide
+        frame(t)
+    assert p.count() == 1 and abs(p.query(1)["moved_probability"] - 0.9) < 1e-12 and p.query(1)["moving"] == 1
+    p.set_bayes(0.1, 0.95, 0.2, 0.1)   # semantic_dsp_map.h:142-148: a stricter threshold takes effect at the next update
+    frame(6)
+    assert p.query(1)["moving"] == 1 and p.query(1)["moved_probability"] == 1.0   # 1.1 > 0.95 decided before the clamp
+    frame(7)
+    assert p.query(1)["moving"] == 1
+    p.set_bayes(0.1, 1.5, 0.2, 0.1)
+    frame(8)
+    assert p.query(1)["moving"] == 0
+    p.clear()
+    assert p.count() == 0 and p.query(1)["exists"] == 0
+    p.close()
+
+
+def test_scene_keypoints_to_moves_to_map():
+    """End to end on the CPU: the dynamic boxes of the synthetic street scene reported as 3-D box keypoints (SETTING 3
+    style) -> object layer -> the move list of the map update.  The matrices must be the scene's true per-frame
+    motions, and a (reference-equivalent, CPU) map fed with them must end up in the same state as one fed with the
+    true motions of the same objects."""
+    from oracle import oracle as orc_mod
+    from semantic_dsp_map_amd import synth
+    from tests import kat_cases as kc
+
+    cfg = synth.CONFIGS["T0"]
+    params = synth.PARAMS["vkitti2"]
+    sc = synth.Scene(cfg, n_dynamic=3, seed=11)
+    ocfg = base_cfg(prod.MODE_ZED2, fx=cfg["fx"], fy=cfg["fy"], cx=cfg["cx"], cy=cfg["cy"], image_width=cfg["width"],
+                    image_height=cfg["height"], map_half_size_scaled=cfg["voxel_size"] * (1 << (max(cfg["x_n"], cfg["y_n"], cfg["z_n"]) - 1)) * 1.2,
+                    movement_probability_threshold=0.69, movement_increment=0.2, movement_decrement=0.1)
+    layer = prod.ObjectLayer(ocfg)
+    noise = synth.noise_table()
+    a = orc_mod.OracleMap(dict(cfg, bin_order=1), params, noise)
+    b = orc_mod.OracleMap(dict(cfg, bin_order=1), params, noise)
+    n_checked = 0
+    for t in range(12):
+        depth, cloud, pos, q = sc.render(t, params)
+        boxes = sc.dyn_boxes(t)
+        obs = []
+        for k, trk in enumerate(sc.dyn_tracks):
+            lo, hi = boxes[k, 0:3], boxes[k, 3:6]
+            kp = np.array([lo, [hi[0], lo[1], lo[2]], [lo[0], hi[1], lo[2]], [lo[0], lo[1], hi[2]]])
+            obs.append(dict(track_id=int(trk), label_id=15, is_static=False, kpts_current=kp, kpts_previous=None))
+        layer.update(obs, pos.astype(np.float64), q.astype(np.float64), 0.1 * t, t + 1)
+        moves, removals = layer.collect(t + 1, params["max_obersevation_lost_time"])
+        assert removals == []
+        truth = {int(m["track_id"]): m["T"].reshape(4, 4) for m in sc.moves(t)}
+        mv = np.zeros(len(moves), synth.OBJECT_MOVE)
+        mv_true = np.zeros(len(moves), synth.OBJECT_MOVE)
+        for i, (trk, T) in enumerate(moves):
+            assert np.abs(T - truth[trk]).max() < 2e-5, (t, trk, T, truth[trk])
+            mv[i]["track_id"], mv[i]["T"] = trk, T.reshape(16)
+            mv_true[i]["track_id"], mv_true[i]["T"] = trk, truth[trk].reshape(16)
+            n_checked += 1
+        a.update(depth, cloud, pos, q, mv)
+        b.update(depth, cloud, pos, q, mv_true)
+    assert n_checked >= 6, "no object was ever declared moving"
+    sa, sb = a.dump_state(), b.dump_state()
+    # the estimated matrices differ from the true ones in the last float bits: particle positions of moved objects may
+    # differ by that much, everything discrete must agree
+    for key in ("status", "track", "label", "ts"):
+        assert np.array_equal(sa[key], sb[key]), key
+    for key in ("px", "py", "pz"):
+        assert np.abs(sa[key] - sb[key]).max() < 1e-3, key
+    layer.close()
