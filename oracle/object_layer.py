@@ -270,7 +270,7 @@ class ObjectLayer:
                     moved_observation = 0
                     if out_of_fov:
                         success = False
-                    elif oid not in self.last_kpts:
+                    elif oid not in self.last_kpts or len(self.last_kpts[oid]) < 4:  # fewer than 4 stored: UB in the reference
                         self.last_kpts[oid], self.last_stamp[oid] = cur.copy(), ts
                         self.key_kpts[oid], self.key_stamp[oid] = cur.copy(), ts
                         success = False

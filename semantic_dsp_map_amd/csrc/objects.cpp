@@ -418,14 +418,14 @@ sdm_status update_impl(sdm_objects *h, const sdm_object_observation *obs, int32_
         moved_observation = 0;
         if (out_of_fov) {
           success = false;
-        } else if (!last.present) {  // :431-438
+        } else if (!last.present || last.pts.size() < 4) {  // :431-438; fewer than four stored keypoints (the reference
+          // would read past them): treated like none
           last = {cur, ts, true};
           h->key_kpts[id] = {cur, ts, true};
           success = false;
         } else {
-          std::vector<V3> p4(last.pts.begin(), last.pts.begin() + std::min<size_t>(4, last.pts.size()));
+          std::vector<V3> p4(last.pts.begin(), last.pts.begin() + 4);
           std::vector<V3> q4(cur.begin(), cur.begin() + 4);
-          if (p4.size() < 4) return SDM_ERR_INVALID_ARGUMENT;
           std::vector<int> inl;
           fit_rigid_ransac(p4, q4, T, inl, 2, 0.5, false, call_seed(c.seed, gts, id));
           double thr = c.movement_distance_threshold;  // :451-457

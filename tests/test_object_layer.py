@@ -350,3 +350,47 @@ def test_scene_keypoints_to_moves_to_map():
     for key in ("px", "py", "pz"):
         assert np.abs(sa[key] - sb[key]).max() < 1e-3, key
     layer.close()
+
+
+@pytest.mark.parametrize("mode,seed", [(m, s) for m in range(4) for s in range(3)])
+def test_random_clips_all_modes(mode, seed):
+    """Seeded random clips: objects appear, move, stall, vanish and come back; keypoint counts vary; some labels are
+    unknown, some ids static or beyond the movable range; the camera turns and time stamps jump.  Product and
+    restatement must agree on the full tracker state and on every output list after every call."""
+    rng = np.random.default_rng(1000 * mode + seed)
+    cfg = base_cfg(mode, movement_probability_threshold=[0.5, 0.69, 0.75][seed], seed=seed + 1)
+    n_obj = 7
+    base = {tid: rng.normal(size=(int(rng.integers(4, 14)), 3)) * np.array([1.0, 0.5, 2.0]) + np.array([rng.uniform(-8, 8), 0.5, rng.uniform(4, 22)])
+            for tid in range(1, n_obj + 1)}
+    base[n_obj] = base[n_obj] + np.array([0, 0, 60.0])          # far away on first sight
+    vel = {tid: (rng.uniform(-0.6, 0.6, 3) * np.array([1, 0, 1]) if tid % 2 else np.zeros(3)) for tid in base}
+    frames, present = [], []
+    ts = 0.0
+    for t in range(40):
+        yaw = 0.02 * t
+        q = np.array([np.cos(yaw / 2), 0, np.sin(yaw / 2), 0])
+        pos = np.array([0.05 * t, 0, 0.1 * t])
+        ts += 0.1 if t != 25 else 3.0                            # one long gap: the prediction interval is capped at 1 s
+        obs = []
+        for tid in base:
+            prev = base[tid].copy()
+            step = vel[tid] if (t // 8 + tid) % 3 else np.zeros(3)   # objects stall now and then
+            base[tid] = prev + step
+            if rng.random() < 0.25:
+                continue                                         # not detected this frame
+            n = len(prev) if rng.random() > 0.2 else int(rng.integers(1, 4))   # sometimes too few keypoints
+            cur = base[tid][:n] + rng.normal(size=(n, 3)) * 0.01
+            if rng.random() < 0.15:
+                cur = cur + rng.normal(size=cur.shape) * 2       # garbage matches
+            label = -1 if tid == 5 and t < 10 else 15
+            obs.append(dict(track_id=tid, label_id=label, is_static=False, kpts_current=cur, kpts_previous=prev[:n]))
+        obs.append(dict(track_id=70001, label_id=15, is_static=False, kpts_current=rng.normal(size=(6, 3)) + 9, kpts_previous=rng.normal(size=(6, 3)) + 9))
+        obs.append(dict(track_id=65535, label_id=3, is_static=True, kpts_current=np.zeros((0, 3)), kpts_previous=None))
+        order = rng.permutation(len(obs))
+        frames.append(([obs[i] for i in order], pos, q, ts))
+        present.append(tuple(int(x) for x in rng.choice(np.arange(1, n_obj + 3), size=3, replace=False)) if t % 7 == 3 else ())
+    out = run_both(cfg, frames, max_lost=4, present=present)
+    if mode != prod.MODE_KITTI360:
+        assert any(mv for mv, _ in out)
+    else:
+        assert not any(mv for mv, _ in out)
