@@ -12,7 +12,9 @@ SMC-PHD weight update, births + resampling, occupancy/semantic sweep), inputs re
 
 Prints ONE JSON line on rank 0 (contract in the task description), with two extra objects:
   roofline     — occupancy/semantic sweep kernel: algorithmic bytes (80 B/voxel at 8 slots)
-                 / HIP-event time on the stream it runs on, against the 8 TB/s HBM peak.
+                 / HIP-event time on the stream it runs on, against the 8 TB/s HBM peak; beside it what this
+                 layout really moves per launch (`layout`), the PMC traffic, the non-incremental launch
+                 (`full_evaluation`) and the dense case.
   cpu_baseline — the CPU oracle (literal single-thread restatement of the reference, kind "port") timed on
                  the same workload on this box's host cores (bounded sample), rank 0 at N = 1 only.
 """
@@ -25,6 +27,8 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# RCCL shares buffers between the ranks' processes through dmabuf IPC; the host driver here supports nothing else
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
