@@ -307,7 +307,6 @@ def test_scene_keypoints_to_moves_to_map():
     true motions of the same objects."""
     from oracle import oracle as orc_mod
     from semantic_dsp_map_amd import synth
-    from tests import kat_cases as kc
 
     cfg = synth.CONFIGS["T0"]
     params = synth.PARAMS["vkitti2"]
