@@ -108,11 +108,12 @@ struct SdmObjectLayer {
 
 /// The library's own object layer (sdm_objects.h): objectLevelUpdate and the object loop of the
 /// prediction step restated on plain doubles with a seeded RANSAC sampler.  "Floating" objects (tracks that own
-/// particles but are not tracked, semantic_dsp_map.h:713-733) are not looked for: the map would have to list its owners.
+/// particles but are not tracked, semantic_dsp_map.h:713-733): every movable track id that came with a mask may have
+/// particles born under it, so those ids are handed to sdm_objects_collect as "present" until they have been wiped.
 class SdmBuiltinObjectLayer : public SdmObjectLayer {
  public:
   SdmBuiltinObjectLayer(const sdm_objects_config &cfg, const std::unordered_map<std::string, int> &label_ids)
-      : h_(nullptr), label_ids_(label_ids), global_time_stamp_(0) {
+      : h_(nullptr), label_ids_(label_ids), global_time_stamp_(0), max_movable_(cfg.max_movable_instance_id) {
     if (sdm_objects_create(&cfg, &h_) != SDM_OK) throw std::invalid_argument("sdm_objects_create: bad configuration");
   }
   ~SdmBuiltinObjectLayer() override { sdm_objects_destroy(h_); }
@@ -135,6 +136,7 @@ class SdmBuiltinObjectLayer : public SdmObjectLayer {
       obs[i].n_kpts = (int32_t)s.kpts_current.size();
       obs[i].kpts_current = cur[i].empty() ? nullptr : cur[i].data();
       obs[i].kpts_previous = prev[i].size() == cur[i].size() && !prev[i].empty() ? prev[i].data() : nullptr;
+      if (!obs[i].is_static && s.track_id <= max_movable_) maybe_present_.insert(s.track_id);
     }
     const double pos[3] = {camera_position.x(), camera_position.y(), camera_position.z()};
     const double q[4] = {camera_orientation.w(), camera_orientation.x(), camera_orientation.y(), camera_orientation.z()};
@@ -145,24 +147,32 @@ class SdmBuiltinObjectLayer : public SdmObjectLayer {
                std::vector<int32_t> &remove_tracks) override {
     int32_t n_tracked = 0;
     sdm_objects_count(h_, &n_tracked);
-    moves.resize((size_t)n_tracked);
-    remove_tracks.resize((size_t)n_tracked);
+    const std::vector<int32_t> present(maybe_present_.begin(), maybe_present_.end());
+    const int32_t cap = n_tracked + (int32_t)present.size();
+    moves.resize((size_t)cap);
+    remove_tracks.resize((size_t)cap);
     int32_t n_moves = 0, n_remove = 0;
-    if (sdm_objects_collect(h_, global_time_stamp, max_obersevation_lost_time, nullptr, 0, moves.data(), n_tracked, &n_moves,
-                            remove_tracks.data(), n_tracked, &n_remove) != SDM_OK) {
+    if (sdm_objects_collect(h_, global_time_stamp, max_obersevation_lost_time, present.empty() ? nullptr : present.data(),
+                            (int32_t)present.size(), moves.data(), cap, &n_moves, remove_tracks.data(), cap, &n_remove) != SDM_OK) {
       std::cerr << "sdm_objects_collect failed" << std::endl;
       n_moves = n_remove = 0;
     }
     moves.resize((size_t)n_moves);
     remove_tracks.resize((size_t)n_remove);
+    for (int32_t id : remove_tracks) maybe_present_.erase(id);  // wiped: nothing of it is left in the map
   }
-  void clear() override { sdm_objects_clear(h_); }
+  void clear() override {
+    sdm_objects_clear(h_);
+    maybe_present_.clear();
+  }
   sdm_objects *handle() { return h_; }
 
  private:
   sdm_objects *h_;
   std::unordered_map<std::string, int> label_ids_;
   uint32_t global_time_stamp_;
+  int max_movable_;
+  std::set<int32_t> maybe_present_;
 };
 
 class SemanticDSPMap {
