@@ -1,0 +1,45 @@
+"""The bench line committed with the latest profile carries every key of the driver's contract (task description:
+bench.py contract + `roofline` + `cpu_baseline`), and the numbers in it are consistent with each other."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def latest_bench_line():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_c3.json")))
+    assert files, "no committed bench line under profiles/"
+    text = open(files[-1]).read().strip().splitlines()[-1]
+    return files[-1], json.loads(text)
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    path, d = latest_bench_line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, (path, k)
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == d["unit"]
+
+
+def test_committed_bench_line_is_self_consistent():
+    _, d = latest_bench_line()
+    voxels = d["config"]["voxels"]
+    assert abs(d["value"] - voxels / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3   # Mvoxels/s from the frame time
+    r = d["roofline"]
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-2
+    if "layout" in r:   # what the layout really moves: never more than the dense-slot figure, and the PMC traffic is near it
+        assert r["layout"]["bytes_per_launch"] <= r["bytes_per_launch"]
+        if r["traffic"] is not None:
+            assert 0.5 * r["layout"]["bytes_per_launch"] <= r["traffic"] <= 3 * r["layout"]["bytes_per_launch"]
+    assert d["value"] / d["cpu_baseline"]["value"] >= 50    # BASELINE.json: >= 50x the single-thread CPU frame time at C3
