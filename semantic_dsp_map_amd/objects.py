@@ -160,3 +160,29 @@ class ObjectLayer:
         n = C.c_int32(0)
         _check(self.L.sdm_objects_count(self.h, C.byref(n)), "sdm_objects_count")
         return n.value
+
+
+def write_keypoint_clip(path, cfg, frames, max_obersevation_lost_time=5, present=None):
+    """Dump what the tracking node hands the object layer per frame (track ids, labels, 3-D keypoints, pose, time stamp)
+    in the format tools/replay/track.cpp reads.  frames: list of (observations, cam_pos, cam_q, time_stamp) as taken by
+    ObjectLayer.update; present[t]: track ids that own particles in the map at frame t (optional)."""
+    import struct
+    c = ObjectsConfig(**{k: cfg[k] for k, _ in ObjectsConfig._fields_})
+    with open(path, "wb") as f:
+        f.write(b"SDMKPTS1")
+        f.write(bytes(c))
+        f.write(struct.pack("<iI", max_obersevation_lost_time, len(frames)))
+        for t, (obs, pos, q, ts) in enumerate(frames):
+            pres = list(present[t]) if present else []
+            f.write(_f64(pos).tobytes())
+            f.write(_f64(q).tobytes())
+            f.write(struct.pack("<dII", ts, len(obs), len(pres)))
+            f.write(np.asarray(pres, "<i4").tobytes())
+            for ob in obs:
+                cur = _f64(ob["kpts_current"]).reshape(-1, 3)
+                prev = None if ob.get("kpts_previous") is None else _f64(ob["kpts_previous"]).reshape(-1, 3)
+                has_prev = prev is not None and len(prev) == len(cur) and len(cur) > 0
+                f.write(struct.pack("<iiiii", ob["track_id"], ob["label_id"], 1 if ob["is_static"] else 0, len(cur), 1 if has_prev else 0))
+                f.write(cur.tobytes())
+                if has_prev:
+                    f.write(prev.tobytes())

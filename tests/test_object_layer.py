@@ -393,3 +393,58 @@ def test_random_clips_all_modes(mode, seed):
         assert any(mv for mv, _ in out)
     else:
         assert not any(mv for mv, _ in out)
+
+
+def test_c_driver_on_the_abi_matches_the_binding(tmp_path):
+    """tools/replay/track.cpp: a plain C++ consumer of include/sdm_objects.h (no Python, no GPU) fed with a dumped
+    keypoint clip prints the same moves (bit for bit) and removals as the ctypes binding."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "semantic_dsp_map_amd", "csrc")
+    src, exe = os.path.join(root, "tools", "replay", "track.cpp"), str(tmp_path / "track")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(root, "include"), src, "-o", exe,
+                           os.path.join(libdir, "libsdm_hip.so"), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    rng = np.random.default_rng(21)
+    cfg = base_cfg(prod.MODE_VKITTI2)
+    pos, q = np.zeros(3), np.array([1.0, 0, 0, 0])
+    clouds = {tid: rng.normal(size=(12, 3)) + np.array([tid * 3.0 - 6, 0.5, 10.0]) for tid in (1, 2, 3)}
+    frames, present = [], []
+    for t in range(14):
+        obs = []
+        for tid, c in clouds.items():
+            if tid == 2 and t > 6:
+                continue                      # vanishes: predicted, then lost
+            shift = np.array([0.5, 0, 0.1]) * (tid != 3)
+            cur = c + shift + rng.normal(size=c.shape) * 0.01
+            obs.append(dict(track_id=tid, label_id=15, is_static=False, kpts_current=cur, kpts_previous=c.copy()))
+            clouds[tid] = c + shift
+        obs.append(dict(track_id=65535, label_id=0, is_static=True, kpts_current=np.zeros((0, 3)), kpts_previous=None))
+        frames.append((obs, pos, q, 0.1 * t))
+        present.append((1, 2, 3, 40) if t == 5 else ())
+    clip = str(tmp_path / "clip.kpts")
+    prod.write_keypoint_clip(clip, cfg, frames, 5, present)
+    out = subprocess.run([exe, clip], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    got = {}
+    for line in out.stdout.splitlines():
+        w = line.split()
+        if w[0] == "frame":
+            cur = got.setdefault(int(w[1]), ([], []))
+        elif w[0] == "move":
+            cur[0].append((int(w[1]), np.array([int(x, 16) for x in w[2:]], dtype=np.uint32).view(np.float32).reshape(4, 4)))
+        elif w[0] == "wipe":
+            cur[1].append(int(w[1]))
+    layer = prod.ObjectLayer(cfg)
+    n_moves = 0
+    for t, (obs, p, qq, ts) in enumerate(frames):
+        layer.update(obs, p, qq, ts, t + 1)
+        moves, wipe = layer.collect(t + 1, 5, present[t])
+        assert wipe == got[t][1], t
+        assert [m[0] for m in moves] == [m[0] for m in got[t][0]], t
+        for a, b in zip(moves, got[t][0]):
+            assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        n_moves += len(moves)
+    assert n_moves > 10 and any(40 in w for _, w in got.values()) and any(2 in w for _, w in got.values())
+    layer.close()
+    assert subprocess.run([exe, src], capture_output=True).returncode == 2   # not a clip
