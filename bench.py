@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-case sweep timing after the run")
     args = ap.parse_args()
 
-    from semantic_dsp_map_amd import binding, sharded, synth
+    from semantic_dsp_map_amd import sharded, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -4,7 +4,6 @@ import os
 import re
 import subprocess
 
-import numpy as np
 import pytest
 
 from semantic_dsp_map_amd import synth

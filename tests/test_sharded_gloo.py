@@ -8,7 +8,6 @@ GPU in tests/test_sharded_gpu.py."""
 import os
 import socket
 
-import numpy as np
 import pytest
 
 from semantic_dsp_map_amd import sharded
