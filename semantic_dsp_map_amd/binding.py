@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsdm_hip.so")
+LIB_PATH = os.environ.get("SDM_LIB_PATH") or os.path.join(_HERE, "csrc", "libsdm_hip.so")  # override: debug builds only
 
 LABELED_POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("sigma", "<f4"),
                           ("track_id", "<u2"), ("label_id", "u1"), ("is_valid", "u1")])

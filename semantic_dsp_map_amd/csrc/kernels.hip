@@ -25,10 +25,14 @@ constexpr int TPB = 256;
 // most arrays is dead, which otherwise splits a 32-byte row into dword/dwordx3 pieces).
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-template <typename T, int N>
+// A = alignment the caller guarantees for src (record fields: rec_align(S), sdm_internal.h); below the natural
+// alignment of the widest piece (S <= 4 only) the copy is left to the compiler.
+template <int A = 16, typename T, int N>
 __device__ __forceinline__ void load_vec(T (&dst)[N], const T *src) {
   constexpr int B = (int)sizeof(T) * N;
-  if constexpr (B >= 16) {
+  if constexpr (A < (B > 16 ? 16 : B)) {
+    __builtin_memcpy(dst, __builtin_assume_aligned(src, A), B);
+  } else if constexpr (B >= 16) {
     const v4u *p = reinterpret_cast<const v4u *>(src);
     v4u tmp[B / 16];
 #pragma unroll
@@ -45,11 +49,11 @@ __device__ __forceinline__ void load_vec(T (&dst)[N], const T *src) {
     __builtin_memcpy(dst, &tmp, 2);
   }
 }
-template <typename T, int N>
+template <int A = 16, typename T, int N>
 __device__ __forceinline__ void store_vec(T *dst, const T (&src)[N]) {
   constexpr int B = (int)sizeof(T) * N;
-  constexpr int A = B > 16 ? 16 : B;
-  __builtin_memcpy(__builtin_assume_aligned(dst, A), src, B);
+  constexpr int AL = A < (B > 16 ? 16 : B) ? A : (B > 16 ? 16 : B);
+  __builtin_memcpy(__builtin_assume_aligned(dst, AL), src, B);
 }
 
 __device__ __forceinline__ void store_result(sdm_voxel_result *dst, const sdm_voxel_result &r) {
@@ -86,7 +90,11 @@ __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, size_t n)
 }
 
 // a ring shift re-stamped these slabs: what the voxels there hold has just become stale (operations.h:1131-1181), so
-// their results change although nobody wrote to them.  t = update k * slab_max + j-th voxel of its slab.
+// their results turn into "unobserved" although nobody wrote to them.  That is all the sweep would do for such a voxel
+// (isVoxelValid fails: its observation stamp is older than the new slab stamp), so it is done right here, voxel by
+// voxel, and the tile needs no mark: an x shift touches one voxel of every x row, i.e. every tile of the map, and
+// would otherwise send the next sweep through all of them.  Should the visibility pass observe the voxel again in
+// this very frame, it marks the tile itself.  t = update k * slab_max + j-th voxel of its slab.
 __device__ __forceinline__ void mark_slab_voxel_dirty(const Dims &d, const State &st, const StampUpdates &su, uint32_t slab_max,
                                                       uint32_t t) {
   const uint32_t k = t / slab_max, j = t - k * slab_max;
@@ -112,8 +120,21 @@ __device__ __forceinline__ void mark_slab_voxel_dirty(const Dims &d, const State
   if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) return;  // another shard's slab
   const uint32_t lv = ring_to_voxel(d, rx, ry, rz) - d.v_begin;
   const uint8_t fl = st.vflag[lv];
-  if ((fl & VF_STATE) == VF_CLEAN) st.vflag[lv] = (uint8_t)(VF_DIRTY | (fl & VR_MASK));
-  mark_tile(st, lv);  // whatever it held, its result turns into "unobserved"
+  const uint8_t state = fl & VF_STATE;
+  // a CLEAN voxel's stored result is gone with this: it is evaluated again when the voxel is seen again
+  const uint8_t nf = (uint8_t)((state == VF_CLEAN ? VF_DIRTY : state) | VR_UNOBSERVED);
+  if (nf != fl) st.vflag[lv] = nf;
+  if ((fl & VR_MASK) != VR_UNOBSERVED) {
+    sdm_voxel_result out;
+    out.wsum = -1.f;
+    out.track = 0;
+    out.label = 0;
+    out.occ = -1;
+    store_result(st.res + lv, out);
+  }
+#ifdef SDM_DBG_SLAB_TILE
+  mark_tile(st, lv);
+#endif
 }
 
 // start of frame: zero the per-frame counters and the per-pixel bin counts (one launch instead of two memsets)
@@ -133,202 +154,274 @@ __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__
 // ------------------------------------------------------------------------------------ A10
 // getOccupancyResult -> determineIfVoxelOccupied -> calculateWeightAndSemanticsInVoxel
 // (semantic_dsp_map.h:1239-1257, mc_ring/operations.h:623-639, 390-448).
-// One thread per voxel; the slot rows of a voxel are fetched with wide loads (SoA arrays are voxel-contiguous), the
-// 8-byte result is one store.  HBM-bound.  Every voxel costs its stamp row, status row and result (2S + S + 8 =
-// 32 B at S = 8); weight, track and label rows (7S = 56 B) are only fetched for voxels that hold a live slot - in a
-// map that is mostly free space or never observed that is a small minority.
-// A voxel that holds a live slot: weight sum, clamp / cull write-backs and the track vote
-// (calculateWeightAndSemanticsInVoxel, operations.h:390-448).
-template <int S>
-__device__ __forceinline__ void occupancy_live_voxel(const State &st, float occ_threshold, uint32_t lv, uint32_t smax,
-                                                     const uint16_t (&tsv)[S], uint8_t (&stv)[S], float (&wv)[S],
-                                                     const uint16_t (&trk)[S], const uint8_t (&lab)[S]) {
-  const size_t base = (size_t)lv * S;
-  sdm_voxel_result out;
-  out.track = 0;
-  out.label = 0;
+//
+// Two kernels share the per-voxel evaluation below:
+//   k_occupancy      the in-frame sweep: incremental (only tiles / voxels written or stamped since the last sweep),
+//                    latency-bound, kept lean so that the thousands of workgroups that leave after one byte are
+//                    dispatched quickly;
+//   k_occupancy_all  the non-incremental sweep (first sweep of a state: sdm_load_state, sdm_set_params, sdm_clear, a
+//                    wholesale stamp upload): every voxel gets its result, HBM-bound, records fetched cooperatively.
 
-  float weight_sum = 0.f, guessed = 0.f;
+// A voxel that holds something: weight sum, clamp / cull write-backs and the track vote
+// (calculateWeightAndSemanticsInVoxel, operations.h:390-448).  Written without branches - every decision is a select on
+// values all lanes compute - so that a wave whose lanes hold different slot patterns runs one instruction stream.
+// Skipped terms are added as +0.f: x + 0.f == x bit for bit for every x a sum that starts at +0.f can hold.
+// PLAIN = the caller has checked (occupancy_is_plain) that no live slot of the voxel can be clamped, culled or is a
+// guessed birth: those rules and their write-backs drop out.  The sweeps test that per wave - one special voxel sends
+// the whole wave through the general version - because the rules fire rarely and cost a third of the instructions.
+template <int S, bool PLAIN>
+__device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_threshold, uint32_t lv, uint32_t smax,
+                                                   const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv_in)[S],
+                                                   const uint16_t (&trk16)[S], const uint8_t (&lab8)[S]) {
+  float wv[S];
+  uint32_t trk[S], lab[S], stv[S];
   bool vote[S];
-  bool dirty_w = false, dirty_s = false;
-  vote[0] = false;
+  bool any = false, any_live = false, dirty_w = false, dirty_s = false;
+  float weight_sum = 0.f, guessed = 0.f;
 #pragma unroll
   for (int i = 1; i < S; ++i) {
-    vote[i] = false;
-    bool vacant = stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax;  // isParticleVacant, operations.h:810-816
-    if (!vacant) {
-      weight_sum += wv[i];
-      if (wv[i] > 1.f) {
-        wv[i] = 1.f;
-        dirty_w = true;
-      }
-      if (stv[i] == ST_GUESSED_BORN) {
-        guessed += wv[i];
-        vote[i] = true;
-      } else if (stv[i] == ST_UPDATED && wv[i] < SDM_OCC_INIT_WEIGHT) {
-        stv[i] = ST_INVALID;
-        dirty_s = true;
-      } else {
-        vote[i] = true;
-      }
+    trk[i] = trk16[i];
+    lab[i] = lab8[i];
+    stv[i] = st1[i];
+    const bool present = stv[i] != ST_INVALID;
+    const bool live = present && (uint32_t)ts1[i] >= smax;  // !isParticleVacant, operations.h:810-816
+    any = any || present;
+    any_live = any_live || live;
+    const float w = wv_in[i];
+    weight_sum += live ? w : 0.f;            // the sum takes the weight as stored ...
+    if constexpr (PLAIN) {
+      wv[i] = w;
+      vote[i] = live;
+    } else {
+      const bool clamp = live && w > 1.f;    // ... the clamp is written back (operations.h:404-407)
+      wv[i] = clamp ? 1.f : w;
+      dirty_w = dirty_w || clamp;
+      const bool guess = live && stv[i] == ST_GUESSED_BORN;
+      guessed += guess ? wv[i] : 0.f;
+      const bool cull = live && !guess && stv[i] == ST_UPDATED && wv[i] < SDM_OCC_INIT_WEIGHT;
+      stv[i] = cull ? (uint32_t)ST_INVALID : stv[i];
+      dirty_s = dirty_s || cull;
+      vote[i] = live && !cull;
     }
   }
   // std::map<track, weight> accumulated in slot order; winner = max weight, ties -> smallest track,
-  // only weights > 0 (operations.h:429-447).
+  // only weights > 0 (operations.h:429-447).  Slots that do not vote get a track id no slot can hold, so the pair loop
+  // needs no second condition; the winner's label (map assignment: the last contributor's label stays) is looked up
+  // afterwards.
+  uint32_t tv[S];
+  float wvote[S];
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    tv[i] = vote[i] ? trk[i] : 0xffffffffu - (uint32_t)i;  // distinct per slot: matches no other slot's id
+    wvote[i] = vote[i] ? wv[i] : 0.f;
+  }
   float best_w = 0.f;
-  uint32_t best_t = 0;
-  uint8_t best_l = 0;
+  uint32_t best_t = 0xffffff00u;  // matches no slot, voting or not
   bool have = false;
 #pragma unroll
   for (int i = 1; i < S; ++i) {
-    if (!vote[i]) continue;
     float tot = 0.f;
-    uint8_t l = lab[i];
 #pragma unroll
     for (int j = 1; j < S; ++j) {
-      if (vote[j] && trk[j] == trk[i]) {
-        tot += wv[j];
-        l = lab[j];  // map assignment: the last contributor's label stays
-      }
+      // (a slot always matches itself.  Sharing the 21 symmetric comparisons was tried: the compiler keeps them in
+      // SGPR pairs, runs out, and spills to VGPR lanes - more instructions than the 21 comparisons saved)
+      if (j == i) tot += wvote[j];
+      else tot += tv[j] == trk[i] ? wv[j] : 0.f;
     }
-    if (tot > 0.f) {
-      if (!have || tot > best_w || (tot == best_w && trk[i] < best_t)) {
-        have = true;
-        best_w = tot;
-        best_t = trk[i];
-        best_l = l;
-      }
-    }
+    const bool better = vote[i] && tot > 0.f && (!have || tot > best_w || (tot == best_w && trk[i] < best_t));
+    best_w = better ? tot : best_w;
+    best_t = better ? trk[i] : best_t;
+    have = have || better;
   }
-  if (have) {
-    out.track = (uint16_t)best_t;
-    out.label = best_l;
+  uint32_t best_l = 0;
+#pragma unroll
+  for (int j = 1; j < S; ++j) best_l = tv[j] == best_t ? lab[j] : best_l;
+  best_t = have ? best_t : 0u;
+  sdm_voxel_result out;
+  if (!any_live) {  // deleted since it was flagged, or only stale slots: the empty result
+    out.wsum = 0.f;
+    out.track = 0;
+    out.label = 0;
+    out.occ = 0.f > occ_threshold ? 1 : 0;
+    store_result(st.res + lv, out);
+    st.vflag[lv] = (uint8_t)((any ? VF_CLEAN : VF_EMPTY) | VR_EMPTY);  // the entry holds the empty result
+    return;
   }
   out.wsum = weight_sum;
-  if (weight_sum > occ_threshold) out.occ = 1;
-  else if (guessed >= SDM_OCC_INIT_WEIGHT) out.occ = 2;
-  else out.occ = 0;
+  out.track = (uint16_t)best_t;  // 0 / 0 without a winner (PINNED)
+  out.label = (uint8_t)best_l;
+  out.occ = weight_sum > occ_threshold ? 1 : (guessed >= SDM_OCC_INIT_WEIGHT ? 2 : 0);
   store_result(st.res + lv, out);
-  if (dirty_w) store_vec(st.w + base * REC_W, wv);
-  uint8_t flag = VF_CLEAN;
-  if (dirty_w) flag = VF_DIRTY;  // the sum above used the unclamped weights: the next evaluation differs
-  if (dirty_s) {
-    store_vec(st.status + base * REC_STATUS, stv);
-    flag = VF_DIRTY;             // a culled slot still counted in this sum
-    bool any = false;            // the cull may have emptied the voxel
+  if constexpr (PLAIN) {
+    st.vflag[lv] = VF_CLEAN;
+    return;
+  }
+  const size_t base = (size_t)lv * S;
+  if (dirty_w) {
+    float wout[S];
+    wout[0] = wv_in[0];
 #pragma unroll
-    for (int i = 1; i < S; ++i) any = any || stv[i] != ST_INVALID;
-    if (!any) flag = VF_EMPTY;
+    for (int i = 1; i < S; ++i) wout[i] = wv[i];
+    store_vec<rec_align(S)>(st.w + base * REC_W, wout);
+  }
+  uint8_t flag = dirty_w ? VF_DIRTY : VF_CLEAN;  // the sum above used the unclamped weights: the next evaluation differs
+  if (dirty_s) {
+    uint8_t sout[S];
+    sout[0] = st1[0];
+    bool left = false;  // the cull may have emptied the voxel
+#pragma unroll
+    for (int i = 1; i < S; ++i) {
+      sout[i] = (uint8_t)stv[i];
+      left = left || stv[i] != ST_INVALID;
+    }
+    store_vec<rec_align(S)>(st.status + base * REC_STATUS, sout);
+    flag = left ? VF_DIRTY : VF_EMPTY;  // a culled slot still counted in this sum
   }
   st.vflag[lv] = flag;
   if (flag != VF_CLEAN) mark_tile(st, lv);  // the next sweep evaluates it again resp. writes the empty result
 }
 
-// One workgroup per tile of 2^TILE_SHIFT voxels; a tile whose State::tile_dirty byte is 0 (nothing in it was written or
-// stamped since the last sweep) is left after one load.  Otherwise two phases.  Phase 1 streams the voxel stamps and
-// flag bytes (OCC_VPT consecutive voxels per thread, everything requested before the first value is looked at) and
-// finishes every voxel that is unobserved, empty or unchanged - the vast majority - from 3 bytes; a result entry is
-// written only when it does not already hold that constant (bits 2-3 of the flag byte).  The others are listed in LDS
-// and handled in phase 2 with all lanes busy: the voxel's record (status, slot stamps, weights, tracks, labels), vote,
-// write-backs.  (Draining the list in a separate kernel was measured: the scattered fetches then take longer than the
-// whole fused sweep.)
+// Conservative test for the PLAIN version above: true only if no slot that could be live carries a weight above 1
+// (clamp) or below the initial weight (cull candidates), and no slot at all is a guessed birth.  Stale and empty
+// slots are ignored for the weights (their weight may be anything), which costs the vacancy test the evaluation
+// repeats - still far cheaper than the rules it saves.
+template <int S>
+__device__ __forceinline__ bool occupancy_is_plain(uint32_t smax, const uint16_t (&ts1)[S], const uint8_t (&st1)[S],
+                                                   const float (&wv)[S]) {
+  float lo = SDM_OCC_INIT_WEIGHT, hi = 1.f;
+  bool guess = false;
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    const bool live = st1[i] != ST_INVALID && (uint32_t)ts1[i] >= smax;
+    const float w = live ? wv[i] : 0.5f;
+    lo = fminf(lo, w);
+    hi = fmaxf(hi, w);
+    guess = guess || st1[i] == ST_GUESSED_BORN;
+  }
+  return !guess && lo >= SDM_OCC_INIT_WEIGHT && hi <= 1.f;  // (a NaN weight fails neither test: it takes no rule either)
+}
+
+// one voxel per lane; `mine` = this lane has a voxel to evaluate (its arrays are loaded)
+template <int S>
+__device__ __forceinline__ void occupancy_evaluate_wave(const State &st, float occ_threshold, bool mine, uint32_t lv, uint32_t smax,
+                                                        const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv)[S],
+                                                        const uint16_t (&trk)[S], const uint8_t (&lab)[S]) {
+#ifdef SDM_EXP_NOPLAIN
+  const bool special = mine;
+#else
+  const bool special = mine && !occupancy_is_plain<S>(smax, ts1, st1, wv);
+#endif
+  if (__ballot(special) == 0ull) {  // wave-uniform
+    if (mine) occupancy_evaluate<S, true>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab);
+  } else {
+    if (mine) occupancy_evaluate<S, false>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab);
+  }
+}
+
+// Classification of a voxel from its observation stamp and flag byte alone: 0 = nothing to do, 1 = write the constant
+// result `out` and the flag byte `nflag`, 2 = evaluate (phase 2).  isVoxelValid: operations.h:824-837.
+__device__ __forceinline__ int occupancy_classify(uint32_t t0, uint32_t flag, uint32_t smax, float occ_threshold, int all_dirty,
+                                                  sdm_voxel_result &out, uint8_t &nflag) {
+  const uint32_t state = flag & VF_STATE, held = flag & VR_MASK;
+  out.track = 0;
+  out.label = 0;
+  if (t0 == 0 || t0 < smax) {
+    if (held == VR_UNOBSERVED && !all_dirty) return 0;  // the result entry already says so
+    out.wsum = -1.f;
+    out.occ = -1;
+    // a CLEAN voxel's stored result is gone with this: it is evaluated again when the voxel is seen again
+    nflag = (uint8_t)((state == VF_CLEAN ? VF_DIRTY : state) | VR_UNOBSERVED);
+    return 1;
+  }
+  if (state == VF_EMPTY) {  // every slot INVALID: weight sum 0, no vote, nothing to clamp or cull
+    if (held == VR_EMPTY && !all_dirty) return 0;
+    out.wsum = 0.f;
+    out.occ = 0.f > occ_threshold ? 1 : 0;
+    nflag = (uint8_t)(VF_EMPTY | VR_EMPTY);
+    return 1;
+  }
+  if (state == VF_CLEAN && !all_dirty) return 0;  // nothing it holds has changed: the result of the last sweep stands
+  return 2;
+}
+
+// In-frame sweep.  One workgroup per tile of 2^TILE_SHIFT voxels; a tile whose State::tile_dirty byte is 0 (nothing in
+// it was written or stamped since the last sweep) is left after one load.  Otherwise two phases.  Phase 1 streams the
+// voxel stamps and flag bytes (OCC_VPT consecutive voxels per thread, everything requested before the first value is
+// looked at) and finishes every voxel that is unobserved, empty or unchanged - the vast majority - from 3 bytes; a
+// result entry is written only when it does not already hold that constant (bits 2-3 of the flag byte).  The others are
+// listed in LDS and handled in phase 2 with all lanes busy: the voxel's record (status, slot stamps, weights, tracks,
+// labels), vote, write-backs.  (Draining the list in a separate kernel was measured in round 1: the scattered fetches
+// then take longer than the whole fused sweep.  Giving this kernel the cooperative record fetch of k_occupancy_all for
+// dense tiles was measured in round 2: the registers and LDS it needs cut the resident workgroups from 8 to 5 per CU
+// and the launch - 8192 workgroups of which most leave at once - went from 22 to 33 us.)
 constexpr int OCC_VPT = 8;  // consecutive voxels of one thread: one 16-byte load of stamps, one 8-byte load of flags
-constexpr int OCC_GROUPS = 1;  // such groups per thread (more were slower: 4 contiguous +5 us, 4 interleaved +9 us)
-constexpr int OCC_TILE = TPB * OCC_VPT * OCC_GROUPS;  // voxels of one workgroup
+constexpr int OCC_TILE = TPB * OCC_VPT;  // voxels of one workgroup
 static_assert(OCC_TILE == (1 << TILE_SHIFT), "one workgroup per tile of State::tile_dirty");
 
 template <int S>
-__global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, State st, Counters *cnt, int all_dirty) {
+__global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, State st, Counters *cnt) {
   __shared__ uint16_t live_list[OCC_TILE];
   __shared__ uint32_t n_live;
   const uint32_t blk0 = blockIdx.x * OCC_TILE;
   // a tile nobody wrote to and no stamp changed in since the last sweep: every result entry of it stands
-  if (!all_dirty && st.tile_dirty[blockIdx.x] == 0) return;
+  if (st.tile_dirty[blockIdx.x] == 0) return;
   if (threadIdx.x == 0) n_live = 0;
   __syncthreads();  // every wave has read the byte
   if (threadIdx.x == 0) {
     st.tile_dirty[blockIdx.x] = 0;  // phase 2 may set it again
     atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep_tiles, 1u);
   }
-  {
-    uint16_t t0v[OCC_GROUPS][OCC_VPT];
-    uint8_t flag[OCC_GROUPS][OCC_VPT];
-    uint32_t sx[OCC_GROUPS][OCC_VPT], yz[OCC_GROUPS];
+  const uint32_t lv0 = blk0 + threadIdx.x * OCC_VPT;  // v_count is a multiple of 8: whole groups only
+  if (lv0 < d.v_count) {
+    uint16_t t0v[OCC_VPT];
+    uint8_t flag[OCC_VPT];
+    uint32_t sx[OCC_VPT], yz = 0;
     const bool rows = d.x_n >= 3;  // a group lies in one x row of the ring: one y and one z stamp, eight consecutive x stamps
+    load_vec(t0v, st.vts + lv0);
+    load_vec(flag, st.vflag + lv0);
+    if (rows) {
+      uint32_t rx, ry, rz;
+      voxel_to_ring(d, d.v_begin + lv0, rx, ry, rz);
+      const uint32_t b = st.stamps_y[ry], c = st.stamps_z[rz];
+      yz = b > c ? b : c;
+      load_vec(sx, st.stamps_x + rx);
+    }
+    uint8_t nflag[OCC_VPT];
+    bool flags_changed = false;
+    v2u outw[OCC_VPT];       // the constant results this thread has to write ...
+    uint32_t want = 0;       // ... for these of its voxels
 #pragma unroll
-    for (int g = 0; g < OCC_GROUPS; ++g) {
-      const uint32_t lv0 = blk0 + (g * TPB + threadIdx.x) * OCC_VPT;  // v_count is a power of two >= 64: whole groups only
-      if (lv0 >= d.v_count) continue;
-      load_vec(t0v[g], st.vts + lv0);
-      load_vec(flag[g], st.vflag + lv0);
+    for (int u = 0; u < OCC_VPT; ++u) {
+      uint32_t smax;
       if (rows) {
+        smax = sx[u] > yz ? sx[u] : yz;
+      } else {
         uint32_t rx, ry, rz;
-        voxel_to_ring(d, d.v_begin + lv0, rx, ry, rz);
-        const uint32_t b = st.stamps_y[ry], c = st.stamps_z[rz];
-        yz[g] = b > c ? b : c;
-        load_vec(sx[g], st.stamps_x + rx);
+        voxel_to_ring(d, d.v_begin + lv0 + u, rx, ry, rz);
+        smax = stamp_max(st, rx, ry, rz);
+      }
+      nflag[u] = flag[u];
+      outw[u] = v2u{0u, 0u};
+      sdm_voxel_result out;
+      const int cls = occupancy_classify(t0v[u], flag[u], smax, occ_threshold, 0, out, nflag[u]);
+      if (cls == 1) {
+        __builtin_memcpy(&outw[u], &out, 8);
+        want |= 1u << u;
+        flags_changed = true;
+      } else if (cls == 2) {
+        live_list[atomicAdd(&n_live, 1u)] = (uint16_t)(threadIdx.x * OCC_VPT + u);
       }
     }
+    if (flags_changed) store_vec(st.vflag + lv0, nflag);  // phase 2 rewrites the bytes of the listed voxels after the barrier
+    if (want == (1u << OCC_VPT) - 1u) {  // the whole group (recycled slab rows): 64 contiguous bytes
+      v4u *dst = reinterpret_cast<v4u *>(st.res + lv0);
 #pragma unroll
-    for (int g = 0; g < OCC_GROUPS; ++g) {
-      const uint32_t lv0 = blk0 + (g * TPB + threadIdx.x) * OCC_VPT;
-      if (lv0 >= d.v_count) continue;
-      uint8_t nflag[OCC_VPT];
-      bool flags_changed = false;
-      v2u outw[OCC_VPT];       // the constant results this thread has to write ...
-      uint32_t want = 0;       // ... for these of its voxels
+      for (int u = 0; u < OCC_VPT; u += 2)
+        __builtin_nontemporal_store(v4u{outw[u].x, outw[u].y, outw[u + 1].x, outw[u + 1].y}, dst + u / 2);
+    } else {
 #pragma unroll
-      for (int u = 0; u < OCC_VPT; ++u) {
-        const uint32_t lv = lv0 + u;
-        outw[u] = v2u{0u, 0u};
-        uint32_t smax;
-        if (rows) {
-          smax = sx[g][u] > yz[g] ? sx[g][u] : yz[g];
-        } else {
-          uint32_t rx, ry, rz;
-          voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
-          smax = stamp_max(st, rx, ry, rz);
-        }
-        nflag[u] = flag[g][u];
-        sdm_voxel_result out;
-        out.track = 0;
-        out.label = 0;
-        const uint32_t state = flag[g][u] & VF_STATE, held = flag[g][u] & VR_MASK;
-        if (t0v[g][u] == 0 || t0v[g][u] < smax) {  // isVoxelValid, operations.h:824-837
-          if (held == VR_UNOBSERVED && !all_dirty) continue;  // the result entry already says so
-          out.wsum = -1.f;
-          out.occ = -1;
-          __builtin_memcpy(&outw[u], &out, 8);
-          want |= 1u << u;
-          // a CLEAN voxel's stored result is gone with this: it is evaluated again when the voxel is seen again
-          nflag[u] = (uint8_t)((state == VF_CLEAN ? VF_DIRTY : state) | VR_UNOBSERVED);
-          flags_changed = true;
-          continue;
-        }
-        if (state == VF_EMPTY) {  // every slot INVALID: weight sum 0, no vote, nothing to clamp or cull
-          if (held == VR_EMPTY && !all_dirty) continue;
-          out.wsum = 0.f;
-          out.occ = 0.f > occ_threshold ? 1 : 0;
-          __builtin_memcpy(&outw[u], &out, 8);
-          want |= 1u << u;
-          nflag[u] = (uint8_t)(VF_EMPTY | VR_EMPTY);
-          flags_changed = true;
-          continue;
-        }
-        if (state == VF_CLEAN && !all_dirty) continue;  // nothing it holds has changed: the result of the last sweep stands
-        live_list[atomicAdd(&n_live, 1u)] = (uint16_t)((g * TPB + threadIdx.x) * OCC_VPT + u);
-      }
-      if (flags_changed) store_vec(st.vflag + lv0, nflag);  // phase 2 rewrites the bytes of the listed voxels after the barrier
-      if (want == (1u << OCC_VPT) - 1u) {  // the whole group (first sweep of a state, recycled slab rows): 64 contiguous bytes
-        v4u *dst = reinterpret_cast<v4u *>(st.res + lv0);
-#pragma unroll
-        for (int u = 0; u < OCC_VPT; u += 2)
-          __builtin_nontemporal_store(v4u{outw[u].x, outw[u].y, outw[u + 1].x, outw[u + 1].y}, dst + u / 2);
-      } else {
-#pragma unroll
-        for (int u = 0; u < OCC_VPT; ++u)
-          if (want & (1u << u)) __builtin_nontemporal_store(outw[u], reinterpret_cast<v2u *>(st.res + lv0 + u));
-      }
+      for (int u = 0; u < OCC_VPT; ++u)
+        if (want & (1u << u)) __builtin_nontemporal_store(outw[u], reinterpret_cast<v2u *>(st.res + lv0 + u));
     }
   }
   __syncthreads();
@@ -340,32 +433,210 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
     uint16_t ts1[S], trk[S];
     uint8_t st1[S], lab[S];
     float wv[S];
-    load_vec(st1, st.status + base * REC_STATUS);
-    load_vec(wv, st.w + base * REC_W);  // the whole record (one line at S = 8) in one go
-    load_vec(ts1, st.ts + base * REC_TS);
-    load_vec(trk, st.track + base * REC_TRACK);
-    load_vec(lab, st.label + base * REC_LABEL);
+    load_vec<rec_align(S)>(st1, st.status + base * REC_STATUS);
+    load_vec<rec_align(S)>(wv, st.w + base * REC_W);  // the whole record (one or two lines at S = 8) in one go
+    load_vec<rec_align(S)>(ts1, st.ts + base * REC_TS);
+    load_vec<rec_align(S)>(trk, st.track + base * REC_TRACK);
+    load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
     uint32_t rx, ry, rz;
     voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
-    const uint32_t sm = stamp_max(st, rx, ry, rz);
-    bool any_live = false, any = false;
-#pragma unroll
-    for (int i = 1; i < S; ++i) {  // isParticleVacant, operations.h:810-816
-      any = any || st1[i] != ST_INVALID;
-      any_live = any_live || !(st1[i] == ST_INVALID || (uint32_t)ts1[i] < sm);
-    }
-    if (!any_live) {  // deleted since it was flagged, or only stale slots
-      sdm_voxel_result out;
-      out.track = 0;
-      out.label = 0;
-      out.wsum = 0.f;
-      out.occ = 0.f > occ_threshold ? 1 : 0;
-      store_result(st.res + lv, out);
-      st.vflag[lv] = (uint8_t)((any ? VF_CLEAN : VF_EMPTY) | VR_EMPTY);  // the entry holds the empty result
-      continue;
-    }
-    occupancy_live_voxel<S>(st, occ_threshold, lv, sm, ts1, st1, wv, trk, lab);
+    // (latency-bound here, not issue-bound: the general version only - the plain one would cost registers, i.e.
+    // resident workgroups, i.e. dispatch time of the many workgroups that leave at once)
+    occupancy_evaluate<S, false>(st, occ_threshold, lv, stamp_max(st, rx, ry, rz), ts1, st1, wv, trk, lab);
   }
+}
+
+// Non-incremental sweep: every voxel's result entry is written.  HBM-bound by construction: per voxel 2 B stamp + 1 B
+// flag read, 8 B result + 1 B flag written, and for voxels that hold something their 10*S-byte record read.
+// Chunk-centric: a wave owns OCC_CPW consecutive chunks of 64 voxels, lane = voxel, so results (8 B per lane) and flags
+// leave as contiguous rows and nothing is staged or listed; no barrier after the first.  Records: when a chunk holds
+// at least OCC_DENSE_MIN voxels to evaluate, the wave copies the chunk's 64 records - one contiguous block of 640*S
+// bytes - into LDS with lane-linear 16-byte global->LDS loads (no VGPR round trip) and every lane reads its own
+// record from there (record stride 80 B at S = 8: conflict-free ds_read_b128); a per-lane fetch of 80-byte records
+// would touch all of the block's lines with every load instruction.  Sparser chunks fetch per lane.
+constexpr int OCC_CHUNK = 64;
+constexpr int OCC_CHUNKS = OCC_TILE / OCC_CHUNK;
+constexpr int OCC_WAVES = TPB / 64;
+constexpr int OCC_CPW = OCC_CHUNKS / OCC_WAVES;  // chunks per wave
+#ifndef SDM_OCC_DENSE_MIN
+#define SDM_OCC_DENSE_MIN 12
+#endif
+constexpr uint32_t OCC_DENSE_MIN = SDM_OCC_DENSE_MIN;
+
+template <int S>
+__global__ __launch_bounds__(TPB) void k_occupancy_all(Dims d, float occ_threshold, State st, Counters *cnt) {
+  constexpr int REC = 10 * S;                    // bytes of one record
+  constexpr int PIECES = OCC_CHUNK * REC / 16;   // 16-byte pieces of one chunk of records
+  constexpr int PPL = (PIECES + 63) / 64;
+  __shared__ v4u rec_stage[OCC_WAVES][PIECES];  // one chunk of records per wave, for the lane <-> record transposition
+  __shared__ uint32_t sm_stage[OCC_WAVES][OCC_CPW][64];  // slab stamps of the wave's voxels (indexed by a run-time chunk below)
+  __shared__ uint16_t live_list[OCC_TILE];
+  __shared__ uint32_t n_live;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t blk0 = blockIdx.x * OCC_TILE;
+  if (threadIdx.x == 0) {
+    st.tile_dirty[blockIdx.x] = 0;  // the evaluation may set it again
+    n_live = 0;
+    atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep_tiles, 1u);
+  }
+  __syncthreads();
+  const uint32_t lvw = blk0 + wave * OCC_CPW * OCC_CHUNK;  // first voxel of this wave
+  // stamps, flags and slab stamps of all the wave's chunks first: everything in flight before anything is looked at
+  uint32_t t0[OCC_CPW], fl[OCC_CPW], sm[OCC_CPW];
+#pragma unroll
+  for (int k = 0; k < OCC_CPW; ++k) {
+    const uint32_t lv = lvw + k * OCC_CHUNK + lane;
+    t0[k] = 0;
+    fl[k] = 0;
+    sm[k] = 0;
+    if (lv < d.v_count) {
+      t0[k] = __builtin_nontemporal_load(st.vts + lv);
+      fl[k] = __builtin_nontemporal_load(st.vflag + lv);
+      uint32_t rx, ry, rz;
+      voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+      sm[k] = stamp_max(st, rx, ry, rz);
+    }
+  }
+  // constant results (unobserved / empty) leave at once: 8 B and 1 B per lane, contiguous rows
+  uint32_t evalbits = 0;  // bit k: this lane's voxel of chunk k needs its record
+#pragma unroll
+  for (int k = 0; k < OCC_CPW; ++k) {
+    const uint32_t lv = lvw + k * OCC_CHUNK + lane;
+    if (lv < d.v_count) {
+      sdm_voxel_result out;
+      uint8_t nflag = (uint8_t)fl[k];
+      const int cls = occupancy_classify(t0[k], fl[k], sm[k], occ_threshold, 1, out, nflag);
+      if (cls == 1) {
+#ifndef SDM_EXP_NORES
+        store_result(st.res + lv, out);
+#endif
+#ifndef SDM_EXP_NOFLAG
+        st.vflag[lv] = nflag;
+#endif
+      }
+      evalbits |= cls == 2 ? 1u << k : 0u;
+    }
+    sm_stage[wave][k][lane] = sm[k];
+  }
+  // The voxels that hold something.  A chunk with fewer than OCC_DENSE_MIN of them hands them to a list in LDS that
+  // the whole workgroup works off with all lanes busy (a surface crossing the tile leaves a few voxels in many chunks;
+  // chunk by chunk that would be one dependent record fetch + evaluation per chunk with most lanes idle).  Dense chunks
+  // stay with their wave: cooperative fetch, the records of the wave's next dense chunk landing in the other half of
+  // the stage while this one is evaluated.
+  uint32_t densebits = 0;  // wave-uniform: chunk k takes the cooperative path
+  uint32_t n_eval = 0;
+#pragma unroll
+  for (int k = 0; k < OCC_CPW; ++k) {
+    const bool mine = (evalbits >> k) & 1u;
+    const unsigned long long need = __ballot(mine);
+    const uint32_t n = (uint32_t)__popcll(need);
+    n_eval += n;
+    if (n >= OCC_DENSE_MIN) {
+      densebits |= 1u << k;
+    } else if (n) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&n_live, n);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (mine) live_list[base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull))] = (uint16_t)((wave * OCC_CPW + k) * OCC_CHUNK + lane);
+    }
+  }
+  auto fetch = [&](int k, v4u (&buf)[PPL]) {  // lane-linear loads of chunk k's records: 1 KB contiguous per instruction
+    const uint32_t lvc = lvw + k * OCC_CHUNK;
+    const uint32_t nvox = d.v_count - lvc < (uint32_t)OCC_CHUNK ? d.v_count - lvc : (uint32_t)OCC_CHUNK;
+    const uint32_t npieces = nvox * REC / 16;  // nvox is a multiple of 8
+    const v4u *src = reinterpret_cast<const v4u *>(st.rec + (size_t)lvc * REC);
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const uint32_t idx = j * 64 + lane;
+      if (idx < npieces) buf[j] = __builtin_nontemporal_load(src + idx);
+    }
+  };
+  auto to_stage = [&](const v4u (&buf)[PPL]) {
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const uint32_t idx = j * 64 + lane;
+      if (idx < (uint32_t)PIECES) rec_stage[wave][idx] = buf[j];  // pieces beyond v_count hold nothing anybody reads
+    }
+  };
+  auto next_dense = [&](int k) -> int {  // first dense chunk after k
+    const uint32_t rest = k + 1 < 32 ? densebits & ~((2u << k) - 1u) : 0u;
+    return rest ? __builtin_ctz(rest) : OCC_CPW;
+  };
+  // three dense chunks of the wave are under way at any time: one in the stage, two in registers
+  int k = densebits ? __builtin_ctz(densebits) : OCC_CPW;
+  int k1 = k < OCC_CPW ? next_dense(k) : OCC_CPW;
+  int k2 = k1 < OCC_CPW ? next_dense(k1) : OCC_CPW;
+  v4u b0[PPL], b1[PPL];
+  {
+    v4u first[PPL];
+    if (k < OCC_CPW) fetch(k, first);
+    if (k1 < OCC_CPW) fetch(k1, b0);
+    if (k2 < OCC_CPW) fetch(k2, b1);
+    if (k < OCC_CPW) to_stage(first);
+  }
+  __syncthreads();
+  const uint32_t nl = n_live;
+  for (uint32_t q0 = 0; q0 < nl; q0 += TPB) {
+    const uint32_t q = q0 + threadIdx.x;
+    const bool mine = q < nl;
+    const uint32_t lv = blk0 + (mine ? live_list[q] : 0u);
+    uint16_t ts1[S], trk[S];
+    uint8_t st1[S], lab[S];
+    float wv[S];
+    uint32_t smax = 0;
+    if (mine) {
+      const size_t base = (size_t)lv * S;
+      load_vec<rec_align(S)>(st1, st.status + base * REC_STATUS);
+      load_vec<rec_align(S)>(wv, st.w + base * REC_W);
+      load_vec<rec_align(S)>(ts1, st.ts + base * REC_TS);
+      load_vec<rec_align(S)>(trk, st.track + base * REC_TRACK);
+      load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
+      uint32_t rx, ry, rz;
+      voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+      smax = stamp_max(st, rx, ry, rz);
+    }
+    occupancy_evaluate_wave<S>(st, occ_threshold, mine, lv, smax, ts1, st1, wv, trk, lab);
+  }
+  // one step: evaluate chunk k out of the stage, move `up` (chunk k1, landed or landing) into the stage, start the loads
+  // of the chunk after k2 into `up`.  The two register buffers alternate, hence the loop body holds two steps.
+  auto step = [&](v4u (&up)[PPL]) {
+    const bool mine = (evalbits >> k) & 1u;
+    const uint32_t lv = lvw + k * OCC_CHUNK + lane;
+    uint16_t ts1[S], trk[S];
+    uint8_t st1[S], lab[S];
+    float wv[S];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (mine) {
+      const unsigned char *r = reinterpret_cast<const unsigned char *>(rec_stage[wave]) + lane * REC;
+      constexpr int RA = rec_align(S);
+      __builtin_memcpy(wv, __builtin_assume_aligned(r, RA), 4 * S);
+      __builtin_memcpy(ts1, __builtin_assume_aligned(r + 4 * S, RA < 2 * S ? RA : 2 * S), 2 * S);
+      __builtin_memcpy(trk, __builtin_assume_aligned(r + 6 * S, RA < 2 * S ? RA : 2 * S), 2 * S);
+      __builtin_memcpy(lab, __builtin_assume_aligned(r + 8 * S, RA < S ? RA : S), S);
+      __builtin_memcpy(st1, __builtin_assume_aligned(r + 9 * S, RA < S ? RA : S), S);
+    }
+    const uint32_t smk = sm_stage[wave][k][lane];
+    // every lane has its record in registers: the next chunk moves into the stage and the third one's loads start
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int kk = k;
+    k = k1;
+    k1 = k2;
+    k2 = k2 < OCC_CPW ? next_dense(k2) : OCC_CPW;
+    if (k < OCC_CPW) to_stage(up);
+    if (k2 < OCC_CPW) fetch(k2, up);
+    (void)kk;
+    occupancy_evaluate_wave<S>(st, occ_threshold, mine, lv, smk, ts1, st1, wv, trk, lab);
+  };
+#pragma unroll 1
+  while (k < OCC_CPW) {
+    step(b0);
+    if (k >= OCC_CPW) break;
+    step(b1);
+  }
+  if (lane == 0 && n_eval) atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep, n_eval);
 }
 
 // slot 0 of the exported stamp array carries the voxel stamp (sdm_dump_state / sdm_load_state keep the reference's
@@ -737,8 +1008,8 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   const uint32_t smax = stamp_max(st, rx, ry, rz);
   uint8_t stv[S];
   uint16_t tsv[S];
-  load_vec(stv, st.status + base * REC_STATUS);
-  load_vec(tsv, st.ts + base * REC_TS);
+  load_vec<rec_align(S)>(stv, st.status + base * REC_STATUS);
+  load_vec<rec_align(S)>(tsv, st.ts + base * REC_TS);
   bool dirty = false, observed = false, wrote_free = false;
   int valid_n = 0;
   bool live[S];
@@ -806,7 +1077,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
       sc.cnt->overflow = 1;
     }
   }
-  if (dirty) store_vec(st.status + base * REC_STATUS, stv);
+  if (dirty) store_vec<rec_align(S)>(st.status + base * REC_STATUS, stv);
   if (dirty || wrote_free) st.vflag[lv] = VF_DIRTY;
   bool stamped = observed;
   if (!observed && valid_n == 0) stamped = im_ok && im_z <= im_depth;
@@ -1383,7 +1654,7 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
   float weight_sum = 0.f;
   uint32_t updated = 0;
   float wv[S];
-  load_vec(wv, st.w + base * REC_W);
+  load_vec<rec_align(S)>(wv, st.w + base * REC_W);
 #pragma unroll
   for (int i = 1; i < S; ++i)
     if (stv[i] == ST_UPDATED) {
@@ -1441,8 +1712,8 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter fl
   const size_t base = (size_t)(v - d.v_begin) * S;
   uint8_t stv[S];
   uint16_t tsv[S];
-  load_vec(stv, st.status + base * REC_STATUS);
-  load_vec(tsv, st.ts + base * REC_TS);
+  load_vec<rec_align(S)>(stv, st.status + base * REC_STATUS);
+  load_vec<rec_align(S)>(tsv, st.ts + base * REC_TS);
   bool resampled = false, checked = false;
   uint32_t n_success = 0, n_resamp = 0;
   // The candidates of a voxel are consecutive in the sorted list; eight at a time are fetched before the first is
@@ -1785,7 +2056,11 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s, bool fresh) {
 
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, hipStream_t s) {
   dim3 grid(blocks_for(d.v_count, OCC_TILE));
-  SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st, cnt, all_dirty);
+  if (all_dirty) {
+    SDM_DISPATCH_S(k_occupancy_all, grid, s, d, flt.occ_threshold, st, cnt);
+  } else {
+    SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st, cnt);
+  }
 }
 
 

@@ -6,7 +6,7 @@
 //   dense, per voxel    vts    u16     observation stamp (the reference's slot-0 time particle)
 //                       vflag  u8      0 = every slot INVALID
 //                       res    8 B     result of the occupancy sweep
-//   one record per voxel (16*S bytes)  weight, time stamp, track, label, status of its S slots (see REC_* below)
+//   one record per voxel (10*S bytes)  weight, time stamp, track, label, status of its S slots (see REC_* below)
 // plus the three per-axis slab stamp arrays.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -124,18 +124,32 @@ struct Cursors {
 };
 
 // Slot attributes that are only touched where a particle lives - weight, time stamp, track id, label, status - share
-// one record of 16*S bytes per voxel (128 B at S = 8: one cache line):
-//   [w: 4S | ts: 2S | track: 2S | label: S | status: S | pad 6S].
+// one record of 10*S bytes per voxel (80 B at S = 8), records back to back with no padding:
+//   [w: 4S | ts: 2S | track: 2S | label: S | status: S].
+// These are exactly the 10 bytes per slot SURVEY.md 8(d) counts for the occupancy sweep, so a sweep over a dense map
+// moves the algorithmic bytes and nothing else; a single live voxel costs one or two 128-byte lines.
 // State::w / ts / track / label / status point at the first voxel's field; the index of slot i of local voxel lv is
 //   w[lv*S*REC_W + i], ts[lv*S*REC_TS + i], track[lv*S*REC_TRACK + i], label[lv*S*REC_LABEL + i],
-//   status[lv*S*REC_STATUS + i].
+//   status[lv*S*REC_STATUS + i]
+// where REC_* is the record stride per slot in elements of the field's type (2.5 floats, 5 u16, 10 bytes): a
+// RecStride counts half elements, and lv*S is even.  Field alignment inside a record: min(16, 10*S & -10*S) bytes,
+// i.e. 16 at S >= 8, 8 at S = 4, 4 at S = 2.
 // What whole-map sweeps stream stays dense: the per-voxel stamp and "something here" flag, owner, positions.
-constexpr size_t REC_BYTES_PER_SLOT = 16;
-constexpr size_t REC_W = 4, REC_TS = 8, REC_TRACK = 8, REC_LABEL = 16, REC_STATUS = 16;
+constexpr size_t REC_BYTES_PER_SLOT = 10;
+struct RecStride {
+  uint32_t half;  // stride per slot in half elements
+};
+template <typename I>
+__host__ __device__ constexpr size_t operator*(I base, RecStride r) {
+  return (size_t)base * r.half / 2;
+}
+constexpr RecStride REC_W{5}, REC_TS{10}, REC_TRACK{10}, REC_LABEL{20}, REC_STATUS{20};
+// alignment (bytes) every field of a record is guaranteed to have
+__host__ __device__ constexpr int rec_align(int S) { return 10 * S % 16 == 0 ? 16 : (10 * S % 8 == 0 ? 8 : 4); }
 
 struct State {
   float4 *pos4 = nullptr;
-  unsigned char *rec = nullptr;  // v_count records of 16*S bytes
+  unsigned char *rec = nullptr;  // v_count records of 10*S bytes
   float *w = nullptr;
   uint16_t *ts = nullptr;
   // observation stamp of every voxel = time stamp of its slot-0 "time particle" (operations.h:824-837), kept as a
@@ -204,7 +218,7 @@ __device__ __forceinline__ void owner_erase(const State &st, size_t li, uint16_t
 }
 
 // field index of global-slot-order index li = lv << p_n | slot (see the record layout above)
-__host__ __device__ __forceinline__ size_t rec_index(size_t li, int p_n, size_t mult) {
+__host__ __device__ __forceinline__ size_t rec_index(size_t li, int p_n, RecStride mult) {
   return ((li >> p_n) << p_n) * mult + (li & (((size_t)1 << p_n) - 1));
 }
 
