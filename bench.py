@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3")
     ap.add_argument("--particles", type=int, default=2000000, help="live particles per GPU after prefill")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=10, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-case sweep timing after the run")
     args = ap.parse_args()
@@ -117,6 +117,10 @@ def main():
         dt = float(tt.item())
 
     stats = m.stats(count_live=True)
+    launch_mode = {"graph_frames": stats["graph_frames"], "direct_frames": stats["direct_frames"],
+                   "host_enqueue_us_min_direct": round(stats["host_enqueue_us"], 1),
+                   "policy": "SDM_GRAPH=%s (0 launch by launch, 1 hipGraph replay, 2 = default: graph when issuing a frame "
+                             "launch by launch takes this host more than 150 us)" % os.environ.get("SDM_GRAPH", "2")}
     live, n_vis, live_vox_local = stats["live_particles"], stats["n_visible"], stats["live_voxels"]
     if dist is not None:
         lt = torch.tensor([live, n_vis], dtype=torch.int64)
@@ -126,51 +130,73 @@ def main():
     # ---- per-stage GPU times and the roofline of the dominant streaming kernel (occupancy / semantic sweep), taken on
     # a few more frames after the timed region: HIP events on the stream the kernels run on bracket every stage
     # (sdm_set_profiling), so "occupancy" is the in-frame duration of the sweep launch; the voxels it evaluated in full
-    # come from the library's counters.
+    # and the tiles it looked into come from the library's counters.
     n_extra = 6
     m.set_profiling(True)
-    stage_acc = np.zeros(8)
-    sweep_live, sweep_tiles = [], []
-    for t in range(n_frames, n_frames + n_extra):
-        depth, cloud, pos, q = scene.render(t, params)
-        dd, dc = m.device_put(depth), m.device_put(cloud)
-        eng.update(dd, dc, pos, q, scene.moves(t))
-        m.synchronize()
-        stt = m.stats()
-        stage_acc += np.array(stt["stage_ms"])
-        sweep_live.append(stt["sweep_live_voxels"])
-        sweep_tiles.append(stt["sweep_tiles"])
+
+    def profiled(t_lo, t_hi):
+        acc, live_l, tiles_l, slabs = np.zeros(8), [], [], np.zeros(3)
+        for t in range(t_lo, t_hi):
+            depth, cloud, pos, q = scene.render(t, params)
+            dd, dc = m.device_put(depth), m.device_put(cloud)
+            eng.update(dd, dc, pos, q, scene.moves(t))
+            m.synchronize()
+            stt = m.stats()
+            acc += np.array(stt["stage_ms"])
+            live_l.append(stt["sweep_live_voxels"])
+            tiles_l.append(stt["sweep_tiles"])
+            slabs += np.array(stt["restamped_slabs"])
+        n = t_hi - t_lo
+        return acc / n, float(np.mean(live_l)), float(np.mean(tiles_l)), slabs / n
+
+    stage_ms, sweep_live_avg, sweep_tiles_avg, slabs_avg = profiled(n_frames, n_frames + n_extra)
+    # the same with the camera also moving one voxel per frame sideways: an x slab of the ring is recycled every frame (a
+    # turning vehicle) - one voxel of every x row of the map changes its result
+    scene.lateral_extra = (n_frames + n_extra - 1, cfg["voxel_size"])
+    xs_stage, xs_live, xs_tiles, xs_slabs = profiled(n_frames + n_extra, n_frames + 2 * n_extra)
     m.set_profiling(False)
-    stage_ms = stage_acc / n_extra
     sweep_ms = float(stage_ms[7])
-    sweep_live_avg = float(np.mean(sweep_live))
-    sweep_tiles_avg = float(np.mean(sweep_tiles))
     ms_per_step = dt * 1e3 / args.steps
     value = V / (dt / args.steps) / 1e6  # Mvoxels / s, whole map (all shards)
-    # roofline of the occupancy / semantic sweep, the way SURVEY.md 8(d) prescribes it: ALGORITHMIC bytes = the dense-slot
-    # figure, per voxel (S-1) x 10 B of slot fields + 2 B time-slot stamp read + 8 B result written (80 B at S = 8),
-    # x the voxels one launch answers for, / the launch time.  "A sparse layout may legitimately move fewer bytes; the
-    # fraction is still computed from these dense-slot figures" (ibid.) - this layout does, so the
-    # fraction is an *effective* one and exceeds 1.  What the launch really has to move in this layout is reported
-    # beside it under "layout": one byte per 2048-voxel tile; for the tiles something was written or stamped in since
-    # the previous sweep, the 2-byte observation stamp and 1-byte flag of every voxel; the record (10 S used bytes), the
-    # 8-byte result and the flag byte of the voxels that were written to.  (Result entries that flip to "unobserved" /
-    # "empty" are also written, 9 B each, but not counted.)  `traffic` is the PMC measurement of the same launches.
+    # Roofline of the occupancy / semantic sweep.  `frac` = bytes the launch has to move in this layout / launch time /
+    # peak: one byte per 2048-voxel tile; for the tiles something was written or stamped in since the previous sweep,
+    # the 2-byte observation stamp and 1-byte flag of every voxel; the record (10 S bytes), the 8-byte result and the
+    # flag byte of the voxels that were written to.  (Result entries that flip to "unobserved" / "empty" are also
+    # written, 9 B each, but not counted.)  `traffic` is the PMC measurement of the same launches where a committed
+    # profile matches.  SURVEY.md 8(d) counts the dense-slot figure - (S-1) x 10 B + 2 B read + 8 B written per voxel,
+    # 80 B at S = 8 - for every voxel of the map whatever the layout skips: that view is kept under `effective`, it is
+    # a rate of voxels answered for, not of bytes moved.  `dense_case` is the launch on a map where the two views
+    # coincide (every slot of every voxel live), `full_evaluation` the non-incremental launch on the benchmark map.
     TILE = 2048
     vox = V // world
     dense_slot_bytes = vox * ((S - 1) * 10 + 2 + 8)
-    layout_bytes = vox // TILE + sweep_tiles_avg * TILE * (2 + 1) + sweep_live_avg * (10 * S + 8 + 1)
-    achieved = dense_slot_bytes / (sweep_ms * 1e-3)
-    roofline = {"kernel": "k_occupancy<%d>" % S, "bound": "hbm", "achieved": round(achieved / 1e9, 1),
-                "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BPS, 4),
-                "traffic": pmc_traffic(S, vox, sweep_live_avg, sweep_tiles_avg), "bytes_per_launch": int(dense_slot_bytes),
-                "definition": "SURVEY.md 8(d): %d B/voxel dense-slot figure x %d voxels / launch time (effective: the "
-                              "layout moves far fewer bytes, see layout and traffic)" % ((S - 1) * 10 + 10, vox),
+
+    def in_frame_bytes(tiles, evaluated):
+        return vox // TILE + tiles * TILE * (2 + 1) + evaluated * (10 * S + 8 + 1)
+
+    layout_bytes = in_frame_bytes(sweep_tiles_avg, sweep_live_avg)
+    achieved = layout_bytes / (sweep_ms * 1e-3)
+    roofline = {"kernel": "k_occupancy<%d>" % S, "bound": "hbm",
+                "case": "in-frame launch (incremental: tiles / voxels written or stamped since the previous sweep)",
+                "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_BPS, 4),
+                "traffic": pmc_traffic(S, vox, sweep_live_avg, sweep_tiles_avg), "bytes_per_launch": int(layout_bytes),
                 "avg_launch_ms": round(sweep_ms, 5), "voxels": vox, "launches_timed": n_extra,
-                "layout": {"bytes_per_launch": int(layout_bytes), "achieved": round(layout_bytes / (sweep_ms * 1e-3) / 1e9, 1),
-                           "frac": round(layout_bytes / (sweep_ms * 1e-3) / HBM_PEAK_BPS, 4),
-                           "tiles_looked_into": int(sweep_tiles_avg), "tiles": vox // TILE,
-                           "voxels_evaluated_in_full": int(sweep_live_avg), "voxels_with_live_slots": live_vox_local}}
+                "tiles_looked_into": int(sweep_tiles_avg), "tiles": vox // TILE,
+                "voxels_evaluated_in_full": int(sweep_live_avg), "voxels_with_live_slots": live_vox_local,
+                "restamped_slabs_per_frame": [round(float(x), 2) for x in slabs_avg],
+                "effective": {"bytes_per_launch": int(dense_slot_bytes),
+                              "achieved": round(dense_slot_bytes / (sweep_ms * 1e-3) / 1e9, 1),
+                              "x_peak": round(dense_slot_bytes / (sweep_ms * 1e-3) / HBM_PEAK_BPS, 3),
+                              "definition": "SURVEY.md 8(d): %d B/voxel dense-slot figure x %d voxels / launch time - voxels "
+                                            "answered for, not bytes moved" % ((S - 1) * 10 + 10, vox)},
+                "x_shift_frames": {"restamped_slabs_per_frame": [round(float(x), 2) for x in xs_slabs],
+                                   "sweep_ms": round(float(xs_stage[7]), 5), "frame_begin_ms": round(float(xs_stage[1]), 5),
+                                   "gpu_frame_ms": round(float(np.sum(xs_stage[1:])), 4),
+                                   "gpu_frame_ms_other_frames": round(float(np.sum(stage_ms[1:])), 4),
+                                   "tiles_looked_into": int(xs_tiles), "voxels_evaluated_in_full": int(xs_live),
+                                   "frac": round(in_frame_bytes(xs_tiles, xs_live) / (float(xs_stage[7]) * 1e-3) / HBM_PEAK_BPS, 4),
+                                   "launches_timed": n_extra}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_frames > 0:
@@ -183,17 +209,21 @@ def main():
         # that holds a live slot evaluated (what each sweep did before the clean/dirty state, and what the first sweep
         # after sdm_load_state / sdm_set_params does)
         full_ms = m.time_occupancy_sweep(iters=10)
-        full_bytes = V * (2 + 1 + 8) + live_vox_local * (10 * S + 1)
-        roofline["full_evaluation"] = {"bytes_per_launch": full_bytes, "avg_launch_ms": round(full_ms, 5),
+        full_bytes = V * (2 + 1 + 8 + 1) + live_vox_local * 10 * S
+        roofline["full_evaluation"] = {"kernel": "k_occupancy_all<%d>" % S, "bytes_per_launch": full_bytes,
+                                       "avg_launch_ms": round(full_ms, 5),
                                        "achieved": round(full_bytes / full_ms / 1e6, 1),
                                        "frac": round(full_bytes / full_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
                                        "launches_timed": 10}
         m.fill_dense()
         dense_ms = m.time_occupancy_sweep(iters=10)
-        dense_bytes = V * (2 + 1 + 8 + 10 * S)  # here the layout's own count: stamp, flag, result, record
-        roofline["dense_case"] = {"bytes_per_launch": dense_bytes, "avg_launch_ms": round(dense_ms, 5),
+        dense_bytes = V * (2 + 1 + 8 + 1 + 10 * S)  # stamp, flag read; result, flag written; record read
+        roofline["dense_case"] = {"kernel": "k_occupancy_all<%d>" % S, "bytes_per_launch": dense_bytes,
+                                  "avg_launch_ms": round(dense_ms, 5),
                                   "achieved": round(dense_bytes / dense_ms / 1e6, 1),
-                                  "frac": round(dense_bytes / dense_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4), "launches_timed": 10}
+                                  "frac": round(dense_bytes / dense_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
+                                  "frac_on_survey_bytes": round(dense_slot_bytes / dense_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
+                                  "launches_timed": 10}
 
     if rank == 0:
         out = {
@@ -209,7 +239,7 @@ def main():
                        "voxels": V, "live_particles": live, "visible_particles": n_vis,
                        "parallelism": "zslab%d" % world, "inputs": "depth + LabeledPoint image resident in HBM",
                        "render_s": round(t_render, 1),
-                       "host_enqueue_ms_per_step": round(t_enqueue * 1e3 / args.steps, 4)},
+                       "host_enqueue_ms_per_step": round(t_enqueue * 1e3 / args.steps, 4), "launch_mode": launch_mode},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
@@ -223,11 +253,11 @@ def main():
 
 def pmc_traffic(S, voxels, evaluated, tiles):
     """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes over this very command
-    (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r01k_sweep_pmc.json); None if they were
+    (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r02_sweep_pmc.json); None if they were
     taken on a different kernel shape or with a number of fully evaluated voxels or of visited tiles more than 25 % off.  PMC counters
     cannot be read from inside this process."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01k_sweep_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_sweep_pmc.json")) as f:
             p = json.load(f)
         if (p["kernel"] == "k_occupancy<%d>" % S and p["voxels"] == voxels
                 and abs(p["voxels_evaluated_in_full"] - evaluated) <= 0.25 * max(evaluated, 1)
@@ -239,29 +269,41 @@ def pmc_traffic(S, voxels, evaluated, tiles):
 
 
 def cpu_baseline(cfg, params, noise, frames, st, ring, n_frames, V):
-    """The oracle in its literal order (bin_order 0 = the reference's BFS push order), one thread, same
-    prefilled map and same frames: 2 warm-up + n_frames timed frames (about 10-20 s of CPU work)."""
+    """The oracle in its literal order (bin_order 0 = the reference's BFS push order), one thread pinned to one core
+    (taskset), same prefilled map and same frames: 3 warm-up + n_frames timed frames (a few seconds of
+    CPU work)."""
     from oracle import oracle as orc
-    o = orc.OracleMap(dict(cfg, bin_order=0), params, noise)
-    o.load_state(st)
-    o.set_ring_state(ring)
-    warm = 2
-    times = []
-    stages = np.zeros(8)
-    for t in range(min(warm + n_frames, len(frames))):
-        depth, cloud, pos, q, moves = frames[t][:5]
-        t0 = time.perf_counter()
-        o.update(depth, cloud, pos, q, moves)
-        dt = time.perf_counter() - t0
-        if t >= warm:
-            times.append(dt)
-            stages += np.array(o.stats()["stage_ms"])
+    pinned = None
+    try:
+        old_aff = os.sched_getaffinity(0)
+        pinned = max(old_aff)
+        os.sched_setaffinity(0, {pinned})
+    except (AttributeError, OSError):
+        old_aff = None
+    try:
+        o = orc.OracleMap(dict(cfg, bin_order=0), params, noise)
+        o.load_state(st)
+        o.set_ring_state(ring)
+        warm = 3
+        times = []
+        stages = np.zeros(8)
+        for t in range(min(warm + n_frames, len(frames))):
+            depth, cloud, pos, q, moves = frames[t][:5]
+            t0 = time.perf_counter()
+            o.update(depth, cloud, pos, q, moves)
+            dt = time.perf_counter() - t0
+            if t >= warm:
+                times.append(dt)
+                stages += np.array(o.stats()["stage_ms"])
+    finally:
+        if old_aff is not None:
+            os.sched_setaffinity(0, old_aff)
     med = float(np.median(times))
     return {"value": round(V / med / 1e6, 2), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
             "sample": "%d frames of the same workload after %d warm-up frames, median %.1f ms/frame (min %.1f); "
-                      "g++ -O3 -march=native -ffp-contract=off, 1 thread of %d host cores"
-                      % (len(times), warm, med * 1e3, min(times) * 1e3, os.cpu_count()),
-            "ms_per_frame": round(med * 1e3, 2),
+                      "g++ -O3 -march=native -ffp-contract=off, 1 thread pinned to core %s of %d host cores"
+                      % (len(times), warm, med * 1e3, min(times) * 1e3, pinned, os.cpu_count()),
+            "ms_per_frame": round(med * 1e3, 2), "min_ms_per_frame": round(min(times) * 1e3, 2),
             "stage_ms": {k: round(stages[i] / len(times), 2) for i, k in
                          enumerate(["", "ego", "move", "remove", "visibility", "weight", "birth", "occupancy"]) if k}}
 

@@ -109,6 +109,12 @@ typedef struct {
   int8_t occ;
 } sdm_point;
 
+/* Per-frame limits of the object lists (the lists travel to the device as kernel arguments).  A caller with more
+ * moving objects or removals in one frame splits them over calls: sdm_update rejects longer lists with
+ * SDM_ERR_INVALID_ARGUMENT (sdm_last_error says so) and leaves the map untouched. */
+#define SDM_MAX_MOVES 48
+#define SDM_MAX_REMOVALS 128
+
 /* sdm_update flags */
 #define SDM_INPUT_ON_DEVICE 0x1u /* depth / cloud are device pointers already resident in HBM */
 #define SDM_SKIP_OCCUPANCY 0x2u  /* do not run the occupancy sweep (debug)                     */
@@ -153,6 +159,10 @@ typedef struct {
   int64_t sweep_live_voxels; /* voxels the last occupancy sweep evaluated in full: the ones written to since the sweep before */
   int64_t sweep_tiles;      /* 2048-voxel tiles the last occupancy sweep looked into (something in them was written or stamped) */
   double stage_ms[8];       /* GPU time per stage of the last update when profiling is on */
+  int64_t restamped_slabs[3]; /* slabs the last update's ring shift re-stamped, per axis (x, y, z) */
+  int64_t graph_frames;     /* frames replayed from the captured hipGraph so far ...                       */
+  int64_t direct_frames;    /* ... and frames issued launch by launch                                      */
+  double host_enqueue_us;   /* fastest host time to issue a plain frame launch by launch (0 = not measured) */
 } sdm_stats;
 
 /* ---- life cycle: SemanticDSPMap() / ~SemanticDSPMap() / clear() (semantic_dsp_map.h:25-81),

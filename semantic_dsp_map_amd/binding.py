@@ -73,7 +73,8 @@ class Stats(C.Structure):
                 ("n_move_reinserted", C.c_int64), ("n_frustum_voxels", C.c_int64), ("n_occupied", C.c_int64),
                 ("flood_rounds", C.c_int64), ("bfs_start_in_frustum", C.c_int64), ("live_voxels", C.c_int64), ("sweep_live_voxels", C.c_int64),
                 ("sweep_tiles", C.c_int64),
-                ("stage_ms", C.c_double * 8)]
+                ("stage_ms", C.c_double * 8), ("restamped_slabs", C.c_int64 * 3),
+                ("graph_frames", C.c_int64), ("direct_frames", C.c_int64), ("host_enqueue_us", C.c_double)]
 
 
 class SdmError(RuntimeError):
@@ -397,8 +398,9 @@ class SdmMap:
     def stats(self, count_live=False):
         s = Stats()
         _check(self.L, self.L.sdm_get_stats(self.h, C.byref(s), 1 if count_live else 0), "sdm_get_stats")
-        d = {k: getattr(s, k) for k, _ in Stats._fields_ if k != "stage_ms"}
+        d = {k: getattr(s, k) for k, _ in Stats._fields_ if k not in ("stage_ms", "restamped_slabs")}
         d["stage_ms"] = list(s.stage_ms)
+        d["restamped_slabs"] = list(s.restamped_slabs)
         return d
 
     def set_profiling(self, on=True):

@@ -9,6 +9,8 @@
 //
 // Float arithmetic that decides an integer (voxel index, pixel, LUT index, resample survivor)
 // is written in the reference's operation order with contraction off.
+#include <algorithm>
+
 #include "sdm_internal.h"
 #include "sdm_scratch.h"
 
@@ -132,14 +134,31 @@ __device__ __forceinline__ void mark_slab_voxel_dirty(const Dims &d, const State
     out.occ = -1;
     store_result(st.res + lv, out);
   }
-#ifdef SDM_DBG_SLAB_TILE
-  mark_tile(st, lv);
-#endif
+}
+
+// first kernel of a frame: the frame's scalars (pose, ring state, stamp updates, object motions, removals, input pointers)
+// arrive by value and are stored where the frame's other kernels read them (FrameArgs, sdm_scratch.h)
+__global__ __launch_bounds__(TPB) void k_set_frame(FrameArgs *__restrict__ dst, const FrameArgs src) {
+  const uint32_t *s4 = reinterpret_cast<const uint32_t *>(&src);
+  uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+  for (uint32_t i = threadIdx.x; i < sizeof(FrameArgs) / 4; i += blockDim.x) d4[i] = s4[i];
 }
 
 // start of frame: zero the per-frame counters and the per-pixel bin counts (one launch instead of two memsets)
+// It is also where the frame's scalars arrive on the main stream: `src` comes by value and is stored in the block the
+// main-stream kernels read (and, inside a graph, in the side chains' block too).
 __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__restrict__ bin_count, uint32_t n_bins,
-                                                      State st, StampUpdates su, Dims d, uint32_t slab_max) {
+                                                      State st, const FrameArgs src, FrameArgs *__restrict__ dst_main,
+                                                      FrameArgs *__restrict__ dst_side, Dims d, uint32_t slab_max) {
+  const StampUpdates &su = src.su;
+  if (blockIdx.x == 0) {
+    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(&src);
+    uint32_t *m4 = reinterpret_cast<uint32_t *>(dst_main), *e4 = reinterpret_cast<uint32_t *>(dst_side);
+    for (uint32_t k = threadIdx.x; k < sizeof(FrameArgs) / 4; k += blockDim.x) {
+      m4[k] = s4[k];
+      if (e4) e4[k] = s4[k];
+    }
+  }
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   for (uint32_t t = i; t < slab_max * (uint32_t)su.n; t += gridDim.x * blockDim.x) mark_slab_voxel_dirty(d, st, su, slab_max, t);
   if (i < offsetof(Counters, flood_complex) / 4) reinterpret_cast<uint32_t *>(cnt)[i] = 0;  // the flood flags belong to the frustum chain
@@ -306,11 +325,7 @@ template <int S>
 __device__ __forceinline__ void occupancy_evaluate_wave(const State &st, float occ_threshold, bool mine, uint32_t lv, uint32_t smax,
                                                         const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv)[S],
                                                         const uint16_t (&trk)[S], const uint8_t (&lab)[S]) {
-#ifdef SDM_EXP_NOPLAIN
-  const bool special = mine;
-#else
   const bool special = mine && !occupancy_is_plain<S>(smax, ts1, st1, wv);
-#endif
   if (__ballot(special) == 0ull) {  // wave-uniform
     if (mine) occupancy_evaluate<S, true>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab);
   } else {
@@ -449,17 +464,22 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
 // Non-incremental sweep: every voxel's result entry is written.  HBM-bound by construction: per voxel 2 B stamp + 1 B
 // flag read, 8 B result + 1 B flag written, and for voxels that hold something their 10*S-byte record read.
 // Chunk-centric: a wave owns OCC_CPW consecutive chunks of 64 voxels, lane = voxel, so results (8 B per lane) and flags
-// leave as contiguous rows and nothing is staged or listed; no barrier after the first.  Records: when a chunk holds
-// at least OCC_DENSE_MIN voxels to evaluate, the wave copies the chunk's 64 records - one contiguous block of 640*S
-// bytes - into LDS with lane-linear 16-byte global->LDS loads (no VGPR round trip) and every lane reads its own
-// record from there (record stride 80 B at S = 8: conflict-free ds_read_b128); a per-lane fetch of 80-byte records
-// would touch all of the block's lines with every load instruction.  Sparser chunks fetch per lane.
+// leave as contiguous rows with nothing staged.  Records: a chunk that holds at least OCC_DENSE_MIN voxels to evaluate
+// is fetched by its wave as one contiguous block of 640*S bytes - lane-linear 16-byte loads, 1 KB per instruction - and
+// passed through LDS, where every lane picks up its own record (record stride 80 B at S = 8: conflict-free
+// ds_read_b128); a per-lane fetch of 80-byte records would touch all of the block's lines with every load
+// instruction (measured: 0.70 ms for the dense case against 0.33 ms).  The loads of the wave's next two dense chunks
+// are in flight while one is evaluated.  Voxels of sparser chunks go on a workgroup-wide list in LDS and are fetched
+// per lane with all lanes busy.
+// What bounds the dense case (rocprofv3 SQ counters, profiles/r02*_dense_pmc.txt): not the bytes alone - the
+// evaluation costs about 650 instructions per chunk and wave, the SIMDs issue for more than 80 % of the kernel's time.
+// Hence the branch-free evaluation and its PLAIN variant above.
 constexpr int OCC_CHUNK = 64;
 constexpr int OCC_CHUNKS = OCC_TILE / OCC_CHUNK;
 constexpr int OCC_WAVES = TPB / 64;
 constexpr int OCC_CPW = OCC_CHUNKS / OCC_WAVES;  // chunks per wave
 #ifndef SDM_OCC_DENSE_MIN
-#define SDM_OCC_DENSE_MIN 12
+#define SDM_OCC_DENSE_MIN 16
 #endif
 constexpr uint32_t OCC_DENSE_MIN = SDM_OCC_DENSE_MIN;
 
@@ -507,12 +527,8 @@ __global__ __launch_bounds__(TPB) void k_occupancy_all(Dims d, float occ_thresho
       uint8_t nflag = (uint8_t)fl[k];
       const int cls = occupancy_classify(t0[k], fl[k], sm[k], occ_threshold, 1, out, nflag);
       if (cls == 1) {
-#ifndef SDM_EXP_NORES
         store_result(st.res + lv, out);
-#endif
-#ifndef SDM_EXP_NOFLAG
         st.vflag[lv] = nflag;
-#endif
       }
       evalbits |= cls == 2 ? 1u << k : 0u;
     }
@@ -618,17 +634,16 @@ __global__ __launch_bounds__(TPB) void k_occupancy_all(Dims d, float occ_thresho
       __builtin_memcpy(st1, __builtin_assume_aligned(r + 9 * S, RA < S ? RA : S), S);
     }
     const uint32_t smk = sm_stage[wave][k][lane];
-    // every lane has its record in registers: the next chunk moves into the stage and the third one's loads start
+    // the evaluation runs on registers only; the two chunks behind this one are landing meanwhile
+    occupancy_evaluate_wave<S>(st, occ_threshold, mine, lv, smk, ts1, st1, wv, trk, lab);
+    // the next chunk moves into the stage (its loads have had two evaluations' time) and the loads of the third start
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int kk = k;
     k = k1;
     k1 = k2;
     k2 = k2 < OCC_CPW ? next_dense(k2) : OCC_CPW;
     if (k < OCC_CPW) to_stage(up);
     if (k2 < OCC_CPW) fetch(k2, up);
-    (void)kk;
-    occupancy_evaluate_wave<S>(st, occ_threshold, mine, lv, smk, ts1, st1, wv, trk, lab);
   };
 #pragma unroll 1
   while (k < OCC_CPW) {
@@ -670,7 +685,9 @@ __global__ __launch_bounds__(TPB) void k_vts_from_slot0(Dims d, State st) {
 // Both paths are compared with the oracle's literal BFS in the parity tests.
 
 // Frustum vertex mask (isPointInFrustum, operations.h:1240-1258, 1338-1340): one wave per 64 vertices along x.
-__global__ __launch_bounds__(TPB) void k_vertex_mask(Dims d, Frame f, uint64_t *__restrict__ M, int wpl, Counters *cnt) {
+__global__ __launch_bounds__(TPB) void k_vertex_mask(Dims d, const FrameArgs *__restrict__ fa, uint64_t *__restrict__ M, int wpl,
+                                                      Counters *cnt) {
+  const Frame f = fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // first kernel of the frustum chain: its flags start clean
     cnt->flood_complex = 0;
     cnt->flood_rounds = 0;
@@ -678,9 +695,9 @@ __global__ __launch_bounds__(TPB) void k_vertex_mask(Dims d, Frame f, uint64_t *
   }
   const int VY = d.NY + 1;
   const int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
-  uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (gw >= (uint32_t)ny * nz * wpl) return;
   const int lane = threadIdx.x & 63;
+  // the grid does not depend on the frame (the box does): waves stride over the box's words
+  for (uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; gw < (uint32_t)ny * nz * wpl; gw += (gridDim.x * blockDim.x) >> 6) {
   int xw = gw % wpl;
   int l = gw / wpl;
   int y = f.bb0[1] + l % ny, z = f.bb0[2] + l / ny;
@@ -695,20 +712,21 @@ __global__ __launch_bounds__(TPB) void k_vertex_mask(Dims d, Frame f, uint64_t *
   }
   uint64_t mask = __ballot(in);
   if (lane == 0) M[((size_t)z * VY + y) * wpl + xw] = mask;
+  }
 }
 
 constexpr int MAX_WPL = 9;  // 513 vertices along an axis at most (x_n, y_n <= 9)
 
 // per-line summary bitmaps over (y,z); one wave per 64 lines along y, ballot-packed.  wy = words per z row.
-__global__ __launch_bounds__(TPB) void k_line_info(Dims d, Frame f, const uint64_t *__restrict__ M, int wpl, int wy,
-                                                   uint64_t *__restrict__ NE, uint64_t *__restrict__ EY,
+__global__ __launch_bounds__(TPB) void k_line_info(Dims d, const FrameArgs *__restrict__ fa, const uint64_t *__restrict__ M, int wpl,
+                                                   int wy, uint64_t *__restrict__ NE, uint64_t *__restrict__ EY,
                                                    uint64_t *__restrict__ EZ, Counters *cnt) {
+  const Frame f = fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   const int VY = d.NY + 1;
   const int yw0 = f.bb0[1] >> 6, yw1 = f.bb1[1] >> 6;
   const int nyw = yw1 - yw0 + 1, nz = f.bb1[2] - f.bb0[2] + 1;
-  uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (gw >= (uint32_t)nyw * nz) return;
   const int lane = threadIdx.x & 63;
+  for (uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; gw < (uint32_t)nyw * nz; gw += (gridDim.x * blockDim.x) >> 6) {
   const int yw = yw0 + gw % nyw, z = f.bb0[2] + gw / nyw;
   const int y = yw * 64 + lane;
   bool ne = false, ey = false, ez = false, complex_line = false;
@@ -735,6 +753,7 @@ __global__ __launch_bounds__(TPB) void k_line_info(Dims d, Frame f, const uint64
     EY[o] = bey;
     EZ[o] = bez;
     if (bc) cnt->flood_complex = 1;
+  }
   }
 }
 
@@ -763,9 +782,10 @@ __device__ __forceinline__ uint64_t fill64(uint64_t g, uint64_t p) {
 }
 
 // Flood over lines in the (y,z) plane.  One workgroup; r (reached lines, bit y of word [z][yw]) lives in LDS.
-__global__ __launch_bounds__(TPB) void k_flood2d(Dims d, Frame f, const uint64_t *__restrict__ M, int wpl, int wy,
-                                                 const uint64_t *__restrict__ EY, const uint64_t *__restrict__ EZ,
+__global__ __launch_bounds__(TPB) void k_flood2d(Dims d, const FrameArgs *__restrict__ fa, const uint64_t *__restrict__ M, int wpl,
+                                                 int wy, const uint64_t *__restrict__ EY, const uint64_t *__restrict__ EZ,
                                                  uint64_t *__restrict__ R2D, Counters *cnt) {
+  const Frame f = fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   extern __shared__ uint64_t lds[];  // r, ey, ez, pp: [nz][nyw] each
   __shared__ uint32_t changed;
   const int VY = d.NY + 1;
@@ -875,9 +895,10 @@ __global__ __launch_bounds__(TPB) void k_flood2d(Dims d, Frame f, const uint64_t
 
 // Exact 3-D bit flood for arbitrary masks (fallback, one workgroup): line fills along x, carry sweeps along y and z,
 // repeated until a whole round changes nothing.
-__global__ __launch_bounds__(1024) void k_flood_generic(Dims d, Frame f, const uint64_t *__restrict__ M,
-                                                        uint64_t *__restrict__ R, int wpl, int force, Counters *cnt) {
-  if (!force && !cnt->flood_complex) return;
+__global__ __launch_bounds__(1024) void k_flood_generic(Dims d, const FrameArgs *__restrict__ fa, const uint64_t *__restrict__ M,
+                                                        uint64_t *__restrict__ R, int wpl, Counters *cnt) {
+  const Frame f = fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
+  if (!fa->force_generic && !cnt->flood_complex) return;
   __shared__ uint32_t changed;
   const int VY = d.NY + 1;
   const int y0 = f.bb0[1], z0 = f.bb0[2];
@@ -977,8 +998,8 @@ __device__ __forceinline__ bool vbit(const uint64_t *__restrict__ R, size_t line
 // stamps; (3) positions of all live slots; (4) the depth pixel under each; (5) all bin-counter atomics and one
 // work-list reservation per voxel.
 template <int S>
-__device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, const State &st, const Scratch &sc, int ax,
-                                                 int ay, int az) {
+__device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, const State &st, const Scratch &sc,
+                                                 const float *__restrict__ depth_img, int ax, int ay, int az) {
   const uint32_t rx = axis_correct(ax + f.eq[0], d.NX);
   const uint32_t ry = axis_correct(ay + f.eq[1], d.NY);
   const uint32_t rz = axis_correct(az + f.eq[2], d.NZ);
@@ -996,7 +1017,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     float iz = (float)(uint32_t)az * d.voxel_size + d.pmin[2] + f.center[2];
     int row, col;
     im_ok = project_to_image(d, f, ix, iy, iz, row, col, im_z);
-    if (im_ok) im_depth = sc.depth[(size_t)row * d.W + col];
+    if (im_ok) im_depth = depth_img[(size_t)row * d.W + col];
   }
   if (!flag) {
     if (im_ok && im_z <= im_depth) {
@@ -1036,7 +1057,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     int row, col;
     if (project_to_image(d, f, pos[i].x, pos[i].y, pos[i].z, row, col, camz[i])) {
       pixv[i] = row * d.W + col;
-      dptv[i] = sc.depth[pixv[i]];
+      dptv[i] = depth_img[pixv[i]];
     }
   }
   bool vis[S];
@@ -1109,14 +1130,19 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, uint32_t n) {  
 }
 
 template <int S>
-__global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, Scratch sc) {
+__global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc) {
   __shared__ unsigned long long wmask[VIS_WORDS];
   __shared__ uint32_t woff[VIS_WORDS + 1];
+  const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
+  const float *__restrict__ depth_img = sc.fa->depth;
+  const bool force_generic = sc.fa->force_generic != 0;
   const int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];  // voxel box [bb0,bb1)
   if (bx <= 0 || by <= 0 || bz <= 0) return;
   const int wlo = f.bb0[0] >> 6, nwx = ((f.bb1[0] - 1) >> 6) - wlo + 1;
   const uint32_t n_words = (uint32_t)nwx * by * bz;
-  const uint32_t g0 = blockIdx.x * VIS_WORDS;
+  // the grid does not depend on the frame (the box does): workgroups stride over the box's words
+  for (uint32_t g0 = blockIdx.x * VIS_WORDS; g0 < n_words; g0 += gridDim.x * VIS_WORDS) {
+  __syncthreads();  // the previous round's lists have been read
   if (threadIdx.x < VIS_WORDS) {
     const uint32_t g = g0 + threadIdx.x;
     unsigned long long m = 0;
@@ -1126,7 +1152,7 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, S
       const int az = f.bb0[2] + (int)(g / ((uint32_t)nwx * by));
       const uint32_t rz = axis_correct(az + f.eq[2], d.NZ);
       if (rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) {  // else: another shard's slab
-        const bool generic = sc.force_generic || sc.cnt->flood_complex;
+        const bool generic = force_generic || sc.cnt->flood_complex;
         const uint64_t *__restrict__ bits = generic ? sc.reach : sc.vmask;
         const int VY = d.NY + 1;
 #pragma unroll
@@ -1173,7 +1199,8 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, Frame f, State st, S
     const int ax = ((wlo + (int)(g % nwx)) << 6) + nth_set_bit(wmask[w], li - woff[w]);
     const int ay = f.bb0[1] + (int)((g / nwx) % by);
     const int az = f.bb0[2] + (int)(g / ((uint32_t)nwx * by));
-    visibility_voxel<S>(d, f, st, sc, ax, ay, az);
+    visibility_voxel<S>(d, f, st, sc, depth_img, ax, ay, az);
+  }
   }
 }
 
@@ -1294,7 +1321,7 @@ __global__ __launch_bounds__(TPB) void k_ck_light(Dims d, Filter flt, State st, 
                                                   int finish, uint32_t light_max) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.W * d.H) return;
-  const sdm_labeled_point o = sc.cloud[p];
+  const sdm_labeled_point o = sc.fa->cloud[p];
   if (!o.is_valid) {
     if (finish) sc.pixt[p] = 0;  // invalid pixel: skipped by pass 2
     return;
@@ -1361,6 +1388,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
   const uint32_t shard = blockIdx.y;
   const uint32_t n = sc.cnt->shard[shard].heavy;
   const float *__restrict__ pdf = st.pdf;
+  const sdm_labeled_point *__restrict__ cloud_img = sc.fa->cloud;
   for (uint32_t q0 = blockIdx.x * A7_ITEMS; q0 < n; q0 += gridDim.x * A7_ITEMS) {
     const uint32_t q = q0 + it;
     int p = 0;
@@ -1368,7 +1396,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
     sdm_labeled_point o;
     if (q < n) {
       p = (int)sc.ck_heavy[shard * sc.cap_heavy + q];
-      o = sc.cloud[p];
+      o = cloud_img[p];
       const int i = p / d.W, j = p - i * d.W;
       const int ni = i + r - h;
       if (r <= 2 * h && ni >= 0 && ni < d.H) {
@@ -1480,7 +1508,7 @@ __global__ __launch_bounds__(TPB) void k_ck_finish(Dims d, Filter flt, Scratch s
                                                    int n_parts) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.W * d.H) return;
-  const sdm_labeled_point o = sc.cloud[p];
+  const sdm_labeled_point o = sc.fa->cloud[p];
   if (!o.is_valid) {
     sc.pixt[p] = 0;
     return;
@@ -1495,11 +1523,13 @@ __global__ __launch_bounds__(TPB) void k_ck_finish(Dims d, Filter flt, Scratch s
 }
 
 // pass 2 (semantic_dsp_map.h:1041-1119): 16 binned particles x window rows per workgroup.
-__global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Frame f, Filter flt, State st, Scratch sc) {
+__global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Filter flt, State st, Scratch sc) {
+  const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   __shared__ float rowsum[A7_ITEMS][A7_ROWS];
   __shared__ int rowflag[A7_ITEMS][A7_ROWS];
   if (sc.cnt->overflow) return;
   const uint32_t n = sc.cnt->n_vis;
+  const sdm_labeled_point *__restrict__ cloud_img = sc.fa->cloud;
   const int r = threadIdx.x, it = threadIdx.y;
   const int h = d.window_half;
   const float *__restrict__ pdf = st.pdf;
@@ -1514,7 +1544,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Frame f, F
       const int i = p / d.W, j = p % d.W;
       const int ni = i + r - h;
       if (ni >= 0 && ni < d.H) {
-        const float sigma = sc.cloud[p].sigma;  // sigma of the particle's own pixel (semantic_dsp_map.h:1047)
+        const float sigma = cloud_img[p].sigma;  // sigma of the particle's own pixel (semantic_dsp_map.h:1047)
         const float4 pv = sc.vp4[k];
         const uint32_t tf = sc.vtf[k];
         const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
@@ -1600,21 +1630,22 @@ __global__ __launch_bounds__(TPB) void k_birth_flags(Dims d, BirthOrder bo, Scra
   if (q >= d.W * d.H) return;
   int i, j;
   birth_seq_to_pixel(bo, q, i, j);
-  sc.b_valid[q] = sc.cloud[i * d.W + j].is_valid ? 1u : 0u;
+  sc.b_valid[q] = sc.fa->cloud[i * d.W + j].is_valid ? 1u : 0u;
 }
 
 // One thread per birth candidate b = q * nb + n (q = position in the raster order, n = copy).
 // The table cursor of the reference advances by 3 per copy of every valid pixel in raster order
 // (semantic_dsp_map.h:1180-1188, basic_algorithms.h:426-440), so the draw index is a function of the
 // exclusive rank of q among valid pixels.
-__global__ __launch_bounds__(TPB) void k_birth_candidates(Dims d, Frame f, Filter flt, BirthOrder bo, State st, Scratch sc) {
+__global__ __launch_bounds__(TPB) void k_birth_candidates(Dims d, Filter flt, BirthOrder bo, State st, Scratch sc) {
+  const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t total = (uint32_t)(d.W * d.H) * (uint32_t)flt.nb;
   if (b >= total) return;
   int q = (int)(b / (uint32_t)flt.nb), n = (int)(b % (uint32_t)flt.nb);
   int i, j;
   birth_seq_to_pixel(bo, q, i, j);
-  const sdm_labeled_point pt = sc.cloud[i * d.W + j];
+  const sdm_labeled_point pt = sc.fa->cloud[i * d.W + j];
   uint32_t key = d.V;  // sorts behind every real voxel
   float x = pt.x, y = pt.y, z = pt.z;
   if (pt.is_valid) {
@@ -1698,9 +1729,10 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
 // raster order inside each voxel segment; the segment head thread replays it and stops at the fixed point
 // (voxel full and its one resample per frame used up or impossible).
 template <int S>
-__global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Frame f, Filter flt, State st, Scratch sc,
+__global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State st, Scratch sc,
                                                       const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
                                                       uint32_t total) {
+  const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const uint32_t v = skey[t];
@@ -2064,38 +2096,65 @@ void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counter
 }
 
 
-void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s) {
-  uint32_t slab_max = d.NY * d.NZ;  // voxels of the largest slab a ring shift can re-stamp
-  if (d.NX * d.NZ > slab_max) slab_max = d.NX * d.NZ;
-  if (d.NX * d.NY > slab_max) slab_max = d.NX * d.NY;
-  hipLaunchKernelGGL(k_frame_begin, dim3(512), dim3(TPB), 0, s, sc.cnt, sc.bin_count, (uint32_t)(d.W * d.H + 1), st, su, d, slab_max);
+void launch_set_frame(FrameArgs *fa_dev, const FrameArgs &fa, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(TPB), 0, s, fa_dev, fa);
+}
+const void *set_frame_kernel() { return reinterpret_cast<const void *>(k_set_frame); }
+
+// arguments of k_frame_begin in the order of its parameter list; `fa` is the frame block that goes by value
+void FrameBeginLaunch::set(const Dims &d_, const State &st_, const Scratch &sc, const FrameArgs &fa_, bool with_side) {
+  cnt = sc.cnt;
+  bin_count = sc.bin_count;
+  n_bins = (uint32_t)(d_.W * d_.H + 1);
+  st = st_;
+  fa = fa_;
+  dst_main = const_cast<FrameArgs *>(sc.fa);
+  dst_side = with_side ? const_cast<FrameArgs *>(sc.fa_side) : nullptr;
+  d = d_;
+  slab_max = d_.NY * d_.NZ;  // voxels of the largest slab a ring shift can re-stamp
+  if (d_.NX * d_.NZ > slab_max) slab_max = d_.NX * d_.NZ;
+  if (d_.NX * d_.NY > slab_max) slab_max = d_.NX * d_.NY;
+  argv[0] = &cnt;
+  argv[1] = &bin_count;
+  argv[2] = &n_bins;
+  argv[3] = &st;
+  argv[4] = &fa;
+  argv[5] = &dst_main;
+  argv[6] = &dst_side;
+  argv[7] = &d;
+  argv[8] = &slab_max;
+}
+const void *FrameBeginLaunch::kernel() { return reinterpret_cast<const void *>(k_frame_begin); }
+
+void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s) {
+  (void)hipLaunchKernel(FrameBeginLaunch::kernel(), dim3(FrameBeginLaunch::GRID), dim3(FrameBeginLaunch::BLOCK), a.argv, 0, s);
 }
 
 // The frustum reach set depends on the camera pose only, not on the map: it runs on a side stream next to the
-// object moves.
-void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_generic, hipStream_t s) {
+// object moves.  Grids and the flood's LDS size are functions of the map dimensions only (the kernels stride over the
+// frame's box), so that the launch sequence of a frame is the same every frame (hipGraph).
+void launch_frustum(const Dims &d, const Scratch &sc, hipStream_t s) {
   static bool lds_attr_set = false;
   if (!lds_attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_flood2d), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     lds_attr_set = true;
   }
-  const int ny = f.bb1[1] - f.bb0[1] + 1, nz = f.bb1[2] - f.bb0[2] + 1;
-  const int nyw = (f.bb1[1] >> 6) - (f.bb0[1] >> 6) + 1;
-  const size_t n_words = (size_t)ny * nz * sc.wpl;
-  hipLaunchKernelGGL(k_vertex_mask, dim3(blocks_for(n_words * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl, sc.cnt);
-  hipLaunchKernelGGL(k_line_info, dim3(blocks_for((size_t)nyw * nz * 64)), dim3(TPB), 0, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ne,
-                     sc.line_ey, sc.line_ez, sc.cnt);
-  hipLaunchKernelGGL(k_flood2d, dim3(1), dim3(TPB), (size_t)nz * nyw * 8 * 4, s, d, f, sc.vmask, sc.wpl, sc.wy, sc.line_ey, sc.line_ez,
-                     sc.line_reach, sc.cnt);
-  hipLaunchKernelGGL(k_flood_generic, dim3(1), dim3(1024), 0, s, d, f, sc.vmask, sc.reach, sc.wpl, force_generic, sc.cnt);
+  const size_t max_words = (size_t)(d.NY + 1) * (d.NZ + 1) * sc.wpl;  // 64-vertex words of the whole vertex grid
+  const unsigned g_mask = (unsigned)std::min<size_t>(blocks_for(max_words * 64), 4096);
+  const unsigned g_line = (unsigned)std::min<size_t>(blocks_for((size_t)sc.wy * (d.NZ + 1) * 64), 256);
+  hipLaunchKernelGGL(k_vertex_mask, dim3(g_mask), dim3(TPB), 0, s, d, sc.fa_side, sc.vmask, sc.wpl, sc.cnt);
+  hipLaunchKernelGGL(k_line_info, dim3(g_line), dim3(TPB), 0, s, d, sc.fa_side, sc.vmask, sc.wpl, sc.wy, sc.line_ne, sc.line_ey, sc.line_ez,
+                     sc.cnt);
+  hipLaunchKernelGGL(k_flood2d, dim3(1), dim3(TPB), (size_t)(d.NZ + 1) * sc.wy * 8 * 4, s, d, sc.fa_side, sc.vmask, sc.wpl, sc.wy, sc.line_ey,
+                     sc.line_ez, sc.line_reach, sc.cnt);
+  hipLaunchKernelGGL(k_flood_generic, dim3(1), dim3(1024), 0, s, d, sc.fa_side, sc.vmask, sc.reach, sc.wpl, sc.cnt);
 }
 
-void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, hipStream_t s) {
-  int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];
-  if (bx > 0 && by > 0 && bz > 0) {
-    const int nwx = ((f.bb1[0] - 1) >> 6) - (f.bb0[0] >> 6) + 1;
-    dim3 grid(blocks_for((size_t)nwx * by * bz, VIS_WORDS));
-    SDM_DISPATCH_S(k_visibility, grid, s, d, f, st, sc);
+void launch_visibility(const Dims &d, const State &st, const Scratch &sc, hipStream_t s) {
+  {
+    const size_t max_words = (size_t)((d.NX + 63) / 64 + 1) * d.NY * d.NZ;
+    dim3 grid((unsigned)std::min<size_t>(blocks_for(max_words, VIS_WORDS), 2048));
+    SDM_DISPATCH_S(k_visibility, grid, s, d, st, sc);
   }
   // bins: scan the per-pixel counts, scatter, canonical order + gather
   exclusive_scan_u32(sc.bin_count, sc.bin_start, (size_t)d.W * d.H + 1, sc.scan_scratch, s);
@@ -2110,13 +2169,13 @@ void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch 
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s) {
   hipLaunchKernelGGL(k_ck_finish, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, parts, n_parts);
 }
-void launch_weight(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s) {
-  hipLaunchKernelGGL(k_weight, dim3(2048), dim3(A7_ROWS, A7_ITEMS), 0, s, d, f, flt, st, sc);
+void launch_weight(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s) {
+  hipLaunchKernelGGL(k_weight, dim3(2048), dim3(A7_ROWS, A7_ITEMS), 0, s, d, flt, st, sc);
 }
 
 // Birth candidates and their stable sort by target voxel depend on the input cloud only: side stream.
 // Returns which double buffer holds the sorted list.
-int launch_birth_prepare(const Dims &d, const Frame &f, const Filter &flt, const BirthOrder &bo, const State &st,
+int launch_birth_prepare(const Dims &d, const Filter &flt, const BirthOrder &bo, const State &st,
                          const Scratch &sc, hipStream_t s) {
   const size_t hw = (size_t)d.W * d.H;
   const size_t total = hw * flt.nb;
@@ -2124,19 +2183,19 @@ int launch_birth_prepare(const Dims &d, const Frame &f, const Filter &flt, const
     hipLaunchKernelGGL(k_birth_flags, dim3(blocks_for(hw)), dim3(TPB), 0, s, d, bo, sc);
     exclusive_scan_u32(sc.b_valid, sc.b_rank, hw, sc.scan_scratch_b, s);
   }
-  hipLaunchKernelGGL(k_birth_candidates, dim3(blocks_for(total)), dim3(TPB), 0, s, d, f, flt, bo, st, sc);
+  hipLaunchKernelGGL(k_birth_candidates, dim3(blocks_for(total)), dim3(TPB), 0, s, d, flt, bo, st, sc);
   if (flt.use_rng) hipLaunchKernelGGL(k_birth_cursor, dim3(1), dim3(64), 0, s, d, flt, sc);
   int nbits = d.x_n + d.y_n + d.z_n + 1;
   return radix_sort_pairs(sc.bkey_a, sc.bval_a, sc.bkey_b, sc.bval_b, total, nbits, sc.sort_scratch, s);
 }
 
-void launch_birth_replay(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, int which,
+void launch_birth_replay(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, int which,
                          hipStream_t s) {
   const size_t total = (size_t)d.W * d.H * flt.nb;
   const uint32_t *skey = which ? sc.bkey_b : sc.bkey_a;
   const uint32_t *sval = which ? sc.bval_b : sc.bval_a;
   dim3 grid(blocks_for(total));
-  SDM_DISPATCH_S(k_birth_replay, grid, s, d, f, flt, st, sc, skey, sval, (uint32_t)total);
+  SDM_DISPATCH_S(k_birth_replay, grid, s, d, flt, st, sc, skey, sval, (uint32_t)total);
 }
 
 void launch_labeled_cloud(const Dims &d, const CloudArgsHost &h, const float *depth, const uint8_t *static_mask,

@@ -7,6 +7,7 @@
 #include <rocrand/rocrand.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -22,6 +23,9 @@
 namespace {
 
 thread_local std::string g_last_error;
+
+// host time per plain frame above which sdm_update switches to graph replay (graph_mode 2)
+constexpr double GRAPH_ENQUEUE_US = 150.0;
 
 void set_error(const char *what, const char *file, int line, const char *detail) {
   char buf[512];
@@ -92,10 +96,33 @@ struct sdm_map {
   float forgetting_function[5]{};
   bool forgetting_initialized = false;
   float cam_R[9]{}, cam_p[3]{};
-  StampUpdates stamp_updates{};
+  // this frame's scalars (sdm_scratch.h): host copy, the two device blocks and the event that says "the side chains'
+  // block is written"
+  FrameArgs fa{};
+  FrameArgs *d_fa[2]{};        // [0] read by the main-stream kernels, [1] by the chains that run ahead of the frame
+  FrameBeginLaunch fb{};       // arguments of k_frame_begin (the frame block travels with it)
+  hipEvent_t ev_fa = nullptr;
+  const float *cur_depth = nullptr;            // the inputs the last frame read (sdm_get_labeled_cloud)
+  const sdm_labeled_point *cur_cloud = nullptr;
+  // The launch sequence of a plain frame (sdm_update, device-resident inputs, one GPU) does not depend on the frame:
+  // it is captured once into a hipGraph and replayed with one kernel-node parameter update (the frame block) per frame.
+  // Worth it only where the host is the bottleneck: a replay costs the host one call instead of ~50 but the GPU
+  // about 0.1 ms per frame (no overlap between frames, costlier node-to-node dependencies).  graph_mode: 0 never,
+  // 1 always, 2 (default) decide from the measured host time of the first plain frames (SDM_GRAPH=0/1/2).
+  int graph_mode = 2;
+  bool use_graph = false;
+  int n_timed = 0;
+  double enqueue_us_min = 1e30;
+  bool capturing = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  hipGraphNode_t graph_set_node = nullptr;
+  Filter graph_flt{};          // the filter parameters baked into the captured launches
+  hipEvent_t cap_begin = nullptr, cap_frustum = nullptr, cap_birth = nullptr, cap_counts = nullptr;
+  uint64_t n_graph_frames = 0, n_direct_frames = 0;
+  int restamped[3]{};        // slabs re-stamped by the last frame's ring shift, per axis
   bool stamps_dirty = true;  // device copy of the stamp arrays needs a full upload
   bool sweep_all = true;     // the next occupancy sweep evaluates every voxel that holds something, changed or not
-  MoveSet moveset{};
 
   // owned device buffers for inputs
   float *d_depth = nullptr;
@@ -117,8 +144,6 @@ struct sdm_map {
   hipEvent_t ev_copy = nullptr;
   unsigned char *d_src_stage = nullptr;  // BOOST mode: one input image at the sensor's size
   size_t src_stage_bytes = 0;
-  MoveSet *d_moveset = nullptr;
-  uint16_t *d_remove = nullptr;
   unsigned long long *d_u64 = nullptr;
   uint32_t *d_flags = nullptr, *d_offs = nullptr;
   sdm_point *d_points = nullptr;
@@ -225,7 +250,8 @@ void update_ring_index_params(sdm_map *m) {
     const int n = (int)N[a];
     auto stamp = [&](uint32_t idx) {
       (*st[a])[idx] = m->global_time_stamp;
-      StampUpdates &su = m->stamp_updates;
+      m->restamped[a]++;
+      StampUpdates &su = m->fa.su;
       if (su.n < MAX_STAMP_UPDATES) su.entry[su.n++] = (uint16_t)((a << 12) | idx);
       else m->stamps_dirty = true;  // too many for the kernel-argument list: fall back to a full upload
     };
@@ -478,6 +504,11 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   HIP_TRY(hipEventCreateWithFlags(&m->ev_begin, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_frustum, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_birth, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_fa, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&m->cap_begin, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&m->cap_frustum, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&m->cap_birth, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&m->cap_counts, hipEventDisableTiming));
   const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t hw = (size_t)d.W * d.H;
   sdm_status rc;
@@ -577,14 +608,23 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.cur, 1);
   HIP_TRY(hipMemsetAsync(sc.cnt, 0, sizeof(Counters), m->stream));
   HIP_TRY(hipMemsetAsync(sc.cur, 0, sizeof(Cursors), m->stream));
-  A(m->d_moveset, 1);
-  A(m->d_remove, 1024);
+  A(m->d_fa[0], 1);
+  A(m->d_fa[1], 1);
+  HIP_TRY(hipMemsetAsync(m->d_fa[0], 0, sizeof(FrameArgs), m->stream));
+  HIP_TRY(hipMemsetAsync(m->d_fa[1], 0, sizeof(FrameArgs), m->stream));
+  m->sc.fa = m->d_fa[0];
+  m->sc.fa_side = m->d_fa[1];
   A(m->d_u64, 1);
   A(m->d_flags, (size_t)d.v_count + 1);
   A(m->d_offs, (size_t)d.v_count + 1);
 #undef A
-  sc.depth = m->d_depth;
-  sc.cloud = m->d_cloud;
+  m->cur_depth = m->d_depth;
+  m->cur_cloud = m->d_cloud;
+  {
+    const char *e = getenv("SDM_GRAPH");
+    if (e && e[0] >= '0' && e[0] <= '2') m->graph_mode = e[0] - '0';
+    m->use_graph = m->graph_mode == 1;
+  }
   refresh_filter(m);
   build_birth_order(m);
   if ((rc = ensure_birth_buffers(m)) != SDM_OK) return rc;
@@ -627,6 +667,10 @@ sdm_status sdm_destroy(sdm_map *m) {
   if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
   if (m->ev_frustum) (void)hipEventDestroy(m->ev_frustum);
   if (m->ev_birth) (void)hipEventDestroy(m->ev_birth);
+  if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+  if (m->graph) (void)hipGraphDestroy(m->graph);
+  for (hipEvent_t e : {m->ev_fa, m->cap_begin, m->cap_frustum, m->cap_birth, m->cap_counts})
+    if (e) (void)hipEventDestroy(e);
   if (m->s_frustum) (void)hipStreamDestroy(m->s_frustum);
   if (m->s_birth) (void)hipStreamDestroy(m->s_birth);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
@@ -713,159 +757,205 @@ sdm_status sdm_download_pdf_table(sdm_map *m, float *table, int32_t n) {
 //   sdm_frame_predict  import, ordered re-insertion, removals, visibility/binning, this shard's partial ck image
 //                      [exchange 3: all-gather of the partial ck images]  -> sdm_update_finish
 // sdm_update_begin = the three steps back to back (single shard, or a frame without object moves).
-sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
-                           const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
-                           const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after) {
-  if (!m || !depth || !cloud || !cam_pos || !cam_q || n_moves < 0 || n_remove < 0 || (n_moves && !moves) ||
-      (n_remove && !remove_tracks) || n_moves > MAX_MOVE_OBJECTS || n_remove > 1024)
+//
+// Every step is "host arithmetic, then launches".  The host arithmetic of a whole frame sits in frame_host_prepare and
+// ends in one FrameArgs block; the launches read their frame scalars from the device copy of that block, so their
+// arguments, grids and order are the same every frame.  sdm_update uses that to replay the whole frame as a hipGraph.
+namespace {
+
+inline bool stage_done(int32_t stop_after, int stage) { return stop_after != 0 && stop_after <= stage; }
+inline void stage_mark(sdm_map *m, int stage) {
+  if (m->profiling && !m->capturing) {
+    (void)hipEventRecord(m->ev[stage], m->stream);
+    m->stage_ran[stage] = true;
+  }
+}
+
+// P1 on the host: global_time_stamp += 1 (semantic_dsp_map.h:173), ego-centre ring shift (:584-585), extrinsic (:744-747),
+// frustum box; the frame block is complete afterwards except for the input pointers.
+sdm_status frame_host_prepare(sdm_map *m, const float cam_pos[3], const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
+                              const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after) {
+  if (n_moves > MAX_MOVE_OBJECTS || n_remove > MAX_REMOVE_TRACKS) {
+    set_error("sdm_update", __FILE__, __LINE__,
+              "more than SDM_MAX_MOVES (48) moving objects or SDM_MAX_REMOVALS (128) removals in one frame: split the call");
     return SDM_ERR_INVALID_ARGUMENT;
-  HIP_TRY(hipSetDevice(m->device));
-  hipStream_t s = m->stream;
-  const Dims &d = m->d;
-  const size_t hw = (size_t)d.W * d.H;
+  }
   m->stop_after = stop_after;
   m->frame_flags = flags;
-  m->n_moves = 0;
-  m->n_remove = 0;
-  auto done = [&](int stage) { return stop_after != 0 && stop_after <= stage; };
   for (int i = 0; i < 9; ++i) m->stage_ran[i] = false;
-  auto mark = [&](int stage) {
-    if (m->profiling) {
-      (void)hipEventRecord(m->ev[stage], s);
-      m->stage_ran[stage] = true;
-    }
-  };
-
-  m->global_time_stamp += 1;  // semantic_dsp_map.h:173
-  mark(0);
-  // P1: ego-centre ring shift (semantic_dsp_map.h:584-585); the recycled slabs' stamps ride along with the
-  // frame-begin kernel as kernel arguments
-  m->stamp_updates.n = 0;
-  m->stamp_updates.value = m->global_time_stamp;
+  m->global_time_stamp += 1;
+  FrameArgs &fa = m->fa;
+  fa.su.n = 0;
+  fa.su.value = m->global_time_stamp;
+  m->restamped[0] = m->restamped[1] = m->restamped[2] = 0;
   update_ego_center(m, cam_pos);
   sync_frame_scalars(m);
-  sdm_status rc = SDM_OK;
   if (m->stamps_dirty) {
-    m->sweep_all = true;  // stamps replaced wholesale: every stored result may be stale
-    if ((rc = upload_stamps(m)) != SDM_OK) return rc;
-    m->stamp_updates.n = 0;
-  }
-  launch_frame_begin(d, m->st, m->sc, m->stamp_updates, s);
-  if (flags & SDM_INPUT_ON_DEVICE) {
-    m->sc.depth = depth;
-    m->sc.cloud = cloud;
-  } else {
-    HIP_TRY(hipMemcpyAsync(m->d_depth, depth, hw * sizeof(float), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(m->d_cloud, cloud, hw * sizeof(sdm_labeled_point), hipMemcpyHostToDevice, s));
-    m->sc.depth = m->d_depth;
-    m->sc.cloud = m->d_cloud;
+    m->sweep_all = true;  // stamps replaced wholesale (below): every stored result may be stale
+    fa.su.n = 0;
   }
   refresh_filter(m);
   m->forgetting_initialized = true;  // the reference freezes its forgetting table at the first update
   compute_extrinsic(m, cam_pos, cam_q);
   compute_frustum_box(m);
-  mark(1);
-  if (done(1)) return SDM_OK;
+  fa.f = m->f;
+  // P2 / P3 inputs: the objects the object layer decided to move (semantic_dsp_map.h:588-693) and to wipe (:702-736)
+  memset(&fa.ms, 0, sizeof(fa.ms));
+  fa.ms.n = n_moves;
+  for (int k = 0; k < n_moves; ++k) {
+    fa.ms.track[k] = (uint16_t)moves[k].track_id;
+    memcpy(fa.ms.T[k], moves[k].T, 12 * sizeof(float));
+  }
+  fa.n_obj = n_moves;
+  fa.n_move_cnt = (uint32_t)n_moves * 8192u + 1u;  // MV_LIST_CAP rows of the count matrix + its terminator
+  fa.n_remove = n_remove;
+  for (int k = 0; k < n_remove; ++k) fa.remove[k] = (uint16_t)remove_tracks[k];
+  fa.force_generic = m->force_generic_flood;
+  m->n_moves = n_moves;
+  m->n_remove = n_remove;
+  return SDM_OK;
+}
 
-  // The side chains are issued in the order in which they can start: the member count and the frustum chain when the
-  // previous frame's births are done, the birth candidates only after this frame's k_frame_begin.  (Under rocprofv3
-  // whatever is issued right behind the birth chain starts after it; unprofiled frame times do not depend on the
-  // order, nor on GPU_MAX_HW_QUEUES = 4 / 8 / 16, nor on folding the birth chain into one of the other side streams.)
-  // P2 (first part): collect the moving objects' particles (semantic_dsp_map.h:588-693)
-  if (n_moves > 0) {
-    MoveSet &ms = m->moveset;
-    memset(&ms, 0, sizeof(ms));
-    ms.n = n_moves;
-    for (int k = 0; k < n_moves; ++k) {
-      ms.track[k] = (uint16_t)moves[k].track_id;
-      memcpy(ms.T[k], moves[k].T, 12 * sizeof(float));
-    }
-    m->n_moves = n_moves;
-    // The member count only reads the owner sets, which were final when the previous frame's births were done: it runs
-    // on its own stream from that point on (next to the previous frame's sweep when frames are issued back to back)
-    // and the main stream picks its result up below.
+// launches of sdm_frame_start: the frame block goes to the device, the chains that depend on nothing but it start
+sdm_status frame_enqueue_start(sdm_map *m) {
+  hipStream_t s = m->stream;
+  const Dims &d = m->d;
+  const int32_t stop_after = m->stop_after;
+  stage_mark(m, 0);
+  if (m->stamps_dirty) {
+    sdm_status rc = upload_stamps(m);
+    if (rc != SDM_OK) return rc;
+  }
+  m->cur_depth = m->fa.depth;
+  m->cur_cloud = m->fa.cloud;
+  if (m->capturing) {
+    // inside a graph a frame starts when the previous one is through: the first node writes both blocks, the member
+    // count stays on the main stream (a detour over another queue costs more than its kernels)
+    m->fb.set(d, m->st, m->sc, m->fa, true);
+    launch_frame_begin(m->fb, s);
+    HIP_TRY(hipEventRecord(m->cap_begin, s));
+    HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->cap_begin, 0));
+    HIP_TRY(hipStreamWaitEvent(m->s_birth, m->cap_begin, 0));
+  } else {
+    // The frustum reach set and the member count of the moving objects depend on the pose / the owner sets only,
+    // which were final when the previous frame's births were done (ev_state): they get their own copy of the frame
+    // block there and start - next to the previous frame's sweep when frames are issued back to back.
     if (!m->state_event_valid) HIP_TRY(hipEventRecord(m->ev_state, s));
-    HIP_TRY(hipStreamWaitEvent(m->s_moves, m->ev_state, 0));
-    launch_moves_count(d, ms, n_moves, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves);
+    HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->ev_state, 0));
+    launch_set_frame(m->d_fa[1], m->fa, m->s_frustum);
+    HIP_TRY(hipEventRecord(m->ev_fa, m->s_frustum));
+    m->fb.set(d, m->st, m->sc, m->fa, false);
+    launch_frame_begin(m->fb, s);
+  }
+  stage_mark(m, 1);
+  if (stage_done(stop_after, 1)) return SDM_OK;
+
+  // P2 (first part): collect the moving objects' particles (semantic_dsp_map.h:588-693); kernels of a frame without
+  // moving objects return at once
+  if (m->capturing) {
+    launch_moves_count(d, m->st, m->sc, m->d_counts_local, s);
+  } else {
+    HIP_TRY(hipStreamWaitEvent(m->s_moves, m->ev_fa, 0));
+    launch_moves_count(d, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves);
     HIP_TRY(hipEventRecord(m->ev_counts, m->s_moves));
   }
-  // fork: everything that only needs this frame's inputs and pose starts now on the side streams
-  HIP_TRY(hipEventRecord(m->ev_begin, s));
   m->side_pending = false;
-  if (!done(3)) {
-    // the reach set depends on the pose only; its buffers were last read by the previous frame's visibility pass, so
-    // with frames issued back to back it runs next to the previous frame's sweep
-    HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->state_event_valid ? m->ev_state : m->ev_begin, 0));
-    m->sc.force_generic = m->force_generic_flood;
-    launch_frustum(d, m->f, m->sc, m->force_generic_flood, m->s_frustum);
-    HIP_TRY(hipEventRecord(m->ev_frustum, m->s_frustum));
+  if (!stage_done(stop_after, 3)) {
+    launch_frustum(d, m->sc, m->s_frustum);
+    HIP_TRY(hipEventRecord(m->capturing ? m->cap_frustum : m->ev_frustum, m->s_frustum));
     m->side_pending = true;
   }
-  if (!done(5)) {
-    HIP_TRY(hipStreamWaitEvent(m->s_birth, m->ev_begin, 0));
-    m->birth_which = launch_birth_prepare(d, m->f, m->flt, m->bo, m->st, m->sc, m->s_birth);
-    HIP_TRY(hipEventRecord(m->ev_birth, m->s_birth));
+  if (!stage_done(stop_after, 5)) {
+    // the birth candidates read this frame's cloud and the birth cursor: after this frame's k_frame_begin
+    if (!m->capturing) {
+      HIP_TRY(hipEventRecord(m->ev_begin, s));
+      HIP_TRY(hipStreamWaitEvent(m->s_birth, m->ev_begin, 0));
+    }
+    m->birth_which = launch_birth_prepare(d, m->flt, m->bo, m->st, m->sc, m->s_birth);
+    HIP_TRY(hipEventRecord(m->capturing ? m->cap_birth : m->ev_birth, m->s_birth));
   }
-
-  if (n_moves > 0) HIP_TRY(hipStreamWaitEvent(s, m->ev_counts, 0));  // join: the main stream picks the counts up
+  if (!m->capturing) HIP_TRY(hipStreamWaitEvent(s, m->ev_counts, 0));  // join: the main stream picks the counts up
   m->state_event_valid = false;  // set again when this frame's births are done
-  if (n_remove > 0) {
-    std::vector<uint16_t> tr(n_remove);
-    for (int k = 0; k < n_remove; ++k) tr[k] = (uint16_t)remove_tracks[k];
-    HIP_TRY(hipMemcpyAsync(m->d_remove, tr.data(), n_remove * 2, hipMemcpyHostToDevice, s));
-    m->n_remove = n_remove;
+  return SDM_OK;
+}
+
+sdm_status check_frame_args(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3], const float cam_q[4],
+                            const sdm_object_move *moves, int32_t n_moves, const int32_t *remove_tracks, int32_t n_remove) {
+  if (!m || !depth || !cloud || !cam_pos || !cam_q || n_moves < 0 || n_remove < 0 || (n_moves && !moves) || (n_remove && !remove_tracks)) {
+    set_error("sdm_update", __FILE__, __LINE__, "null pointer or negative count");
+    return SDM_ERR_INVALID_ARGUMENT;
   }
   return SDM_OK;
 }
 
+// this frame's inputs -> device pointers in the frame block
+sdm_status stage_inputs(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, uint32_t flags) {
+  const size_t hw = (size_t)m->d.W * m->d.H;
+  if (flags & SDM_INPUT_ON_DEVICE) {
+    m->fa.depth = depth;
+    m->fa.cloud = cloud;
+  } else {
+    HIP_TRY(hipMemcpyAsync(m->d_depth, depth, hw * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->d_cloud, cloud, hw * sizeof(sdm_labeled_point), hipMemcpyHostToDevice, m->stream));
+    m->fa.depth = m->d_depth;
+    m->fa.cloud = m->d_cloud;
+  }
+  return SDM_OK;
+}
+
+}  // namespace
+
+sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
+                           const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
+                           const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after) {
+  sdm_status rc = check_frame_args(m, depth, cloud, cam_pos, cam_q, moves, n_moves, remove_tracks, n_remove);
+  if (rc != SDM_OK) return rc;
+  HIP_TRY(hipSetDevice(m->device));
+  if ((rc = frame_host_prepare(m, cam_pos, cam_q, moves, n_moves, remove_tracks, n_remove, flags, stop_after)) != SDM_OK) return rc;
+  if ((rc = stage_inputs(m, depth, cloud, flags)) != SDM_OK) return rc;
+  m->n_direct_frames++;
+  return frame_enqueue_start(m);
+}
+
 sdm_status sdm_frame_moves(sdm_map *m) {
   if (!m) return SDM_ERR_INVALID_ARGUMENT;
-  if (m->stop_after != 0 && m->stop_after <= SDM_STAGE_EGO) return SDM_OK;
-  HIP_TRY(hipSetDevice(m->device));
+  if (stage_done(m->stop_after, SDM_STAGE_EGO)) return SDM_OK;
+  if (!m->capturing) HIP_TRY(hipSetDevice(m->device));
   const int world = m->cfg.shard_count, rank = m->cfg.shard_rank;
-  if (m->n_moves > 0) {
-    // without gathered counts (single shard, or the caller skipped exchange 1) the local counts are the global ones
-    const int32_t *counts_all = m->counts_all_user;
-    int w = world, r = rank;
-    if (!counts_all) {
-      counts_all = m->counts_local_user ? m->counts_local_user : m->d_counts_local;
-      w = 1;
-      r = 0;
-    }
-    launch_moves_transform(m->d, m->f, m->flt, m->moveset, m->n_moves, m->st, m->sc, counts_all, w, r, m->stream);
+  // without gathered counts (single shard, or the caller skipped exchange 1) the local counts are the global ones
+  const int32_t *counts_all = m->counts_all_user;
+  int w = world, r = rank;
+  if (!counts_all) {
+    counts_all = m->counts_local_user ? m->counts_local_user : m->d_counts_local;
+    w = 1;
+    r = 0;
   }
+  launch_moves_transform(m->d, m->flt, m->st, m->sc, counts_all, w, r, m->stream);
   return SDM_OK;
 }
 
 sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev) {
   if (!m) return SDM_ERR_INVALID_ARGUMENT;
   const int stop_after = m->stop_after;
-  if (stop_after != 0 && stop_after <= SDM_STAGE_EGO) return SDM_OK;
-  HIP_TRY(hipSetDevice(m->device));
+  if (stage_done(stop_after, SDM_STAGE_EGO)) return SDM_OK;
+  if (!m->capturing) HIP_TRY(hipSetDevice(m->device));
   hipStream_t s = m->stream;
   const Dims &d = m->d;
-  auto done = [&](int stage) { return stop_after != 0 && stop_after <= stage; };
-  auto mark = [&](int stage) {
-    if (m->profiling) {
-      (void)hipEventRecord(m->ev[stage], s);
-      m->stage_ran[stage] = true;
-    }
-  };
   // P2 (second part): re-insert the moved copies in the reference's order (operations.h:351-361)
-  launch_moves_finish(d, m->flt, m->n_moves, m->st, m->sc, m->counts_all_user ? m->cfg.shard_count : 1, m->cfg.shard_rank, s);
-  mark(2);
-  if (done(2)) return SDM_OK;
+  launch_moves_finish(d, m->flt, m->st, m->sc, m->counts_all_user ? m->cfg.shard_count : 1, m->cfg.shard_rank, s);
+  stage_mark(m, 2);
+  if (stage_done(stop_after, 2)) return SDM_OK;
 
   // P3: removals (semantic_dsp_map.h:702-736)
-  if (m->n_remove > 0) launch_remove(d, m->st, m->d_remove, m->n_remove, s);
-  mark(3);
-  if (done(3)) return SDM_OK;
+  launch_remove(d, m->st, m->sc, s);
+  stage_mark(m, 3);
+  if (stage_done(stop_after, 3)) return SDM_OK;
 
   // U1: visibility + binning (semantic_dsp_map.h:749); join the frustum stream first
-  HIP_TRY(hipStreamWaitEvent(s, m->ev_frustum, 0));
-  launch_visibility(d, m->f, m->st, m->sc, s);
-  mark(4);
-  if (done(4)) return SDM_OK;
+  HIP_TRY(hipStreamWaitEvent(s, m->capturing ? m->cap_frustum : m->ev_frustum, 0));
+  launch_visibility(d, m->st, m->sc, s);
+  stage_mark(m, 4);
+  if (stage_done(stop_after, 4)) return SDM_OK;
 
   // U2 pass 1: this shard's ck partial sums
   float *ck_dst = m->ck_user ? m->ck_user : m->d_ck_part;
@@ -908,44 +998,148 @@ sdm_status sdm_set_halo_buffers(sdm_map *m, int32_t *counts_local, const int32_t
 // weight update, births/resampling, occupancy sweep.
 sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_parts, uint32_t flags, int32_t stop_after) {
   if (!m || n_parts < 1) return SDM_ERR_INVALID_ARGUMENT;
-  if (stop_after != 0 && stop_after <= SDM_STAGE_VISIBILITY) return SDM_OK;
-  HIP_TRY(hipSetDevice(m->device));
+  if (stage_done(stop_after, SDM_STAGE_VISIBILITY)) return SDM_OK;
+  if (!m->capturing) HIP_TRY(hipSetDevice(m->device));
   hipStream_t s = m->stream;
   const Dims &d = m->d;
-  auto done = [&](int stage) { return stop_after != 0 && stop_after <= stage; };
-  auto mark = [&](int stage) {
-    if (m->profiling) {
-      (void)hipEventRecord(m->ev[stage], s);
-      m->stage_ran[stage] = true;
-    }
-  };
   const float *own = m->ck_user ? m->ck_user : m->d_ck_part;
   if (!m->fused_ck) launch_ck_finish(d, m->flt, m->sc, ck_parts_dev ? ck_parts_dev : own, ck_parts_dev ? n_parts : 1, s);
-  launch_weight(d, m->f, m->flt, m->st, m->sc, s);
-  mark(5);
-  if (done(5)) return SDM_OK;
-  HIP_TRY(hipStreamWaitEvent(s, m->ev_birth, 0));  // join the birth-candidate stream
-  launch_birth_replay(d, m->f, m->flt, m->st, m->sc, m->birth_which, s);
-  HIP_TRY(hipEventRecord(m->ev_state, s));
-  m->state_event_valid = true;
-  mark(6);
-  if (done(6)) return SDM_OK;
+  launch_weight(d, m->flt, m->st, m->sc, s);
+  stage_mark(m, 5);
+  if (stage_done(stop_after, 5)) return SDM_OK;
+  HIP_TRY(hipStreamWaitEvent(s, m->capturing ? m->cap_birth : m->ev_birth, 0));  // join the birth-candidate stream
+  launch_birth_replay(d, m->flt, m->st, m->sc, m->birth_which, s);
+  if (!m->capturing) {
+    HIP_TRY(hipEventRecord(m->ev_state, s));
+    m->state_event_valid = true;
+  }
+  stage_mark(m, 6);
+  if (stage_done(stop_after, 6)) return SDM_OK;
   if (!(flags & SDM_SKIP_OCCUPANCY)) {
     launch_occupancy(d, m->flt, m->st, m->sc.cnt, m->sweep_all ? 1 : 0, s);
     m->sweep_all = false;
   }
-  mark(7);
+  stage_mark(m, 7);
   return SDM_OK;
 }
+
+namespace {
+
+// the frame as a graph: captured from the very launches above (stream capture follows the side streams through their
+// events), instantiated once, replayed with the frame block as the one parameter that changes
+sdm_status graph_capture(sdm_map *m) {
+  if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+  if (m->graph) (void)hipGraphDestroy(m->graph);
+  m->graph_exec = nullptr;
+  m->graph = nullptr;
+  m->graph_set_node = nullptr;
+  // nothing of an earlier frame may still be running on the side streams when they join the capture
+  HIP_TRY(hipStreamSynchronize(m->s_frustum));
+  HIP_TRY(hipStreamSynchronize(m->s_moves));
+  HIP_TRY(hipStreamSynchronize(m->s_birth));
+  m->sc.fa = m->d_fa[0];
+  m->sc.fa_side = m->d_fa[1];
+  m->capturing = true;
+  hipError_t e = hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal);
+  sdm_status rc = SDM_OK;
+  if (e == hipSuccess) {
+    rc = frame_enqueue_start(m);
+    if (rc == SDM_OK) rc = sdm_frame_moves(m);
+    if (rc == SDM_OK) rc = sdm_frame_predict(m, nullptr);
+    if (rc == SDM_OK) rc = sdm_update_finish(m, nullptr, 1, m->frame_flags, 0);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(m->stream, &g);
+    m->graph = g;
+  }
+  m->capturing = false;
+  if (e != hipSuccess || rc != SDM_OK || !m->graph) {
+    set_error("hipStreamCapture", __FILE__, __LINE__, e != hipSuccess ? hipGetErrorString(e) : "frame enqueue failed under capture");
+    (void)hipGetLastError();
+    return rc != SDM_OK ? rc : SDM_ERR_HIP;
+  }
+  size_t n_nodes = 0;
+  HIP_TRY(hipGraphGetNodes(m->graph, nullptr, &n_nodes));
+  std::vector<hipGraphNode_t> nodes(n_nodes);
+  HIP_TRY(hipGraphGetNodes(m->graph, nodes.data(), &n_nodes));
+  for (hipGraphNode_t nd : nodes) {
+    hipGraphNodeType t;
+    if (hipGraphNodeGetType(nd, &t) != hipSuccess || t != hipGraphNodeTypeKernel) continue;
+    hipKernelNodeParams kp;
+    if (hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func == FrameBeginLaunch::kernel()) m->graph_set_node = nd;
+  }
+  if (!m->graph_set_node) {
+    set_error("graph_capture", __FILE__, __LINE__, "frame-block node not found in the captured graph");
+    return SDM_ERR_HIP;
+  }
+  HIP_TRY(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+  m->graph_flt = m->flt;
+  return SDM_OK;
+}
+
+sdm_status graph_launch(sdm_map *m) {
+  m->fb.set(m->d, m->st, m->sc, m->fa, true);
+  hipKernelNodeParams kp;
+  memset(&kp, 0, sizeof(kp));
+  kp.func = const_cast<void *>(FrameBeginLaunch::kernel());
+  kp.gridDim = dim3(FrameBeginLaunch::GRID);
+  kp.blockDim = dim3(FrameBeginLaunch::BLOCK);
+  kp.sharedMemBytes = 0;
+  kp.kernelParams = m->fb.argv;
+  kp.extra = nullptr;
+  HIP_TRY(hipGraphExecKernelNodeSetParams(m->graph_exec, m->graph_set_node, &kp));
+  HIP_TRY(hipGraphLaunch(m->graph_exec, m->stream));
+  m->cur_depth = m->fa.depth;
+  m->cur_cloud = m->fa.cloud;
+  m->state_event_valid = false;  // ev_state was not recorded: the next plain frame forks from its own start
+  m->sweep_all = false;
+  m->n_graph_frames++;
+  return SDM_OK;
+}
+
+}  // namespace
 
 sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
                       const float cam_q[4], const sdm_object_move *moves, int32_t n_moves, const int32_t *remove_tracks,
                       int32_t n_remove, uint32_t flags, int32_t stop_after) {
-  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  sdm_status rc = check_frame_args(m, depth, cloud, cam_pos, cam_q, moves, n_moves, remove_tracks, n_remove);
+  if (rc != SDM_OK) return rc;
+  HIP_TRY(hipSetDevice(m->device));
   m->fused_ck = true;
-  sdm_status rc = sdm_update_begin(m, depth, cloud, cam_pos, cam_q, moves, n_moves, remove_tracks, n_remove, flags,
-                                   stop_after, nullptr);
-  if (rc == SDM_OK) rc = sdm_update_finish(m, nullptr, 1, flags, stop_after);
+  rc = frame_host_prepare(m, cam_pos, cam_q, moves, n_moves, remove_tracks, n_remove, flags, stop_after);
+  if (rc == SDM_OK) rc = stage_inputs(m, depth, cloud, flags);
+  if (rc != SDM_OK) {
+    m->fused_ck = false;
+    return rc;
+  }
+  // A plain frame - whole map on this GPU, every stage, incremental sweep, nobody timing stages or owning the stream -
+  // is replayed from the graph; everything else takes the launches one by one.
+  const bool would_be_plain = stop_after == 0 && (flags & ~(uint32_t)SDM_INPUT_ON_DEVICE) == 0 && !m->profiling &&
+                              m->cfg.shard_count == 1 && !m->comm && !m->ck_user && !m->counts_local_user &&
+                              m->stream == m->own_stream && !m->sweep_all && !m->stamps_dirty;
+  const bool plain = m->use_graph && would_be_plain;
+  if (plain) {
+    if (m->graph_exec && memcmp(&m->graph_flt, &m->flt, sizeof(Filter)) != 0) {  // sdm_set_params / a new noise table since
+      (void)hipGraphExecDestroy(m->graph_exec);
+      m->graph_exec = nullptr;
+    }
+    if (!m->graph_exec) rc = graph_capture(m);
+    if (rc == SDM_OK) rc = graph_launch(m);
+    if (rc != SDM_OK) m->use_graph = false;  // (the frame is lost; later frames take the plain launches)
+  } else {
+    m->n_direct_frames++;
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = frame_enqueue_start(m);
+    if (rc == SDM_OK) rc = sdm_frame_moves(m);
+    if (rc == SDM_OK) rc = sdm_frame_predict(m, nullptr);
+    if (rc == SDM_OK) rc = sdm_update_finish(m, nullptr, 1, flags, stop_after);
+    // graph_mode 2: how long does this host take to issue a plain frame?  Judged on the fastest of eight (the first
+    // ones pay code loading); above GRAPH_ENQUEUE_US the host, not the GPU, sets the frame rate and the graph pays.
+    if (m->graph_mode == 2 && would_be_plain && m->n_timed < 8) {
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      if (us < m->enqueue_us_min) m->enqueue_us_min = us;
+      if (++m->n_timed == 8) m->use_graph = m->enqueue_us_min > GRAPH_ENQUEUE_US;
+    }
+  }
   m->fused_ck = false;
   return rc;
 }
@@ -1084,7 +1278,7 @@ sdm_status sdm_update_raw_ex(sdm_map *m, const float *depth, const uint8_t *stat
 sdm_status sdm_get_labeled_cloud(sdm_map *m, sdm_labeled_point *out) {
   if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
-  HIP_TRY(hipMemcpyAsync(out, m->sc.cloud, (size_t)m->d.W * m->d.H * sizeof(sdm_labeled_point), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipMemcpyAsync(out, m->cur_cloud, (size_t)m->d.W * m->d.H * sizeof(sdm_labeled_point), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return SDM_OK;
 }
@@ -1297,6 +1491,10 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
     out->sweep_tiles += c.shard[k].sweep_tiles;
   }
   out->flood_rounds = c.flood_rounds;
+  for (int a = 0; a < 3; ++a) out->restamped_slabs[a] = m->restamped[a];
+  out->graph_frames = (int64_t)m->n_graph_frames;
+  out->direct_frames = (int64_t)m->n_direct_frames;
+  out->host_enqueue_us = m->enqueue_us_min < 1e29 ? m->enqueue_us_min : 0.0;
   if (m->profiling) {
     int prev = 0;
     for (int sidx = 1; sidx <= 7; ++sidx) {

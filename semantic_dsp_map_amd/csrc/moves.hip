@@ -40,10 +40,12 @@ __device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint16_t *tracks
 // the map's tens of thousands of chunks; everything after this works on the list only.
 __global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *owner_flag, uint32_t n_flags,
                                                       uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Cursors *cur,
-                                                      uint32_t *__restrict__ cnt_tail, uint32_t *__restrict__ alias,
-                                                      uint8_t *owner_flag_w) {
+                                                      uint32_t *__restrict__ cnt, const FrameArgs *__restrict__ fa,
+                                                      uint32_t *__restrict__ alias, uint8_t *owner_flag_w) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t running;
+  if (fa->n_obj <= 0) return;  // no object moves in this frame
+  uint32_t *cnt_tail = cnt + (fa->n_move_cnt - 1);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) {
     running = 0;
@@ -126,12 +128,15 @@ __global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *owner_flag,
 // pass 1: per-chunk, per-object member counts.  cnt[obj * MV_LIST_CAP + list position].  A flagged chunk that turns out
 // to hold no owner any more clears its flag.
 __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__ owner, size_t n_slots,
-                                                    const MoveSet ms, uint32_t *__restrict__ cnt, int n_obj,
+                                                    const FrameArgs *__restrict__ fa, uint32_t *__restrict__ cnt,
                                                     uint8_t *__restrict__ owner_flag, const uint32_t *__restrict__ list,
                                                     const uint32_t *__restrict__ n_list, const uint32_t *__restrict__ alias) {
   __shared__ uint32_t c[MAX_MOVE_OBJECTS];
   __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
   __shared__ uint32_t any_owner;
+  const int n_obj = fa->n_obj;
+  if (n_obj <= 0) return;
+  const MoveSet &ms = fa->ms;
   const uint32_t n = *n_list;
   if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms.track[threadIdx.x] : OWNER_NONE;
   for (uint32_t pos = blockIdx.x; pos < MV_LIST_CAP; pos += gridDim.x) {
@@ -190,8 +195,9 @@ struct HaloRecord {
 };
 static_assert(sizeof(HaloRecord) == HALO_RECORD_BYTES, "halo record layout");
 
-__global__ void k_move_local_counts(const uint32_t *__restrict__ offs, int n_obj, int32_t *counts_local, Scratch sc) {
+__global__ void k_move_local_counts(const uint32_t *__restrict__ offs, int32_t *counts_local, Scratch sc) {
   int k = threadIdx.x;
+  const int n_obj = sc.fa_side->n_obj;  // (runs with the member count, on its stream)
   if (k == 0 && sc.halo_send) *reinterpret_cast<uint32_t *>(sc.halo_send) = 0;  // this frame's export counter
   if (k >= HALO_OBJ) return;
   counts_local[k] = k < n_obj ? (int32_t)(offs[(size_t)(k + 1) * MV_LIST_CAP] - offs[(size_t)k * MV_LIST_CAP]) : 0;
@@ -336,9 +342,12 @@ __device__ __forceinline__ void move_round_with_aliases(const Dims &d, const Fra
 // (ballot ranks inside a wave, wave counts through LDS, chunk offsets from the scanned count matrix), which gives each
 // its global rank e = rank among all members of all moving objects in (object, shard, index) order.  The noise
 // cursor advances by three per particle in that order; the copy joins its target voxel's list or is exported.
-__global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt, const MoveSet ms, State st, Scratch sc,
-                                                    const uint32_t *__restrict__ offs, int n_obj,
+__global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st, Scratch sc, const uint32_t *__restrict__ offs,
                                                     const int32_t *__restrict__ counts_all, int world, int rank) {
+  const int n_obj = sc.fa->n_obj;
+  if (n_obj <= 0) return;
+  const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
+  const MoveSet &ms = sc.fa->ms;
   __shared__ uint32_t obj_base[MAX_MOVE_OBJECTS];  // global rank of the object's next member in this chunk
   __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
   __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
@@ -458,6 +467,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Frame f, Filter flt,
 
 // import the records other shards exported into this slab (blockIdx.y = source shard)
 __global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int world, int rank) {
+  if (sc.fa->n_obj <= 0) return;
   const int src = blockIdx.y;
   if (src == rank || src >= world) return;
   const unsigned char *buf = sc.halo_recv + (size_t)src * (HALO_HEADER_BYTES + (size_t)sc.halo_cap * HALO_RECORD_BYTES);
@@ -495,6 +505,7 @@ __global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int wor
 // operations.h:357).  The list head is left idle again.
 template <int S>
 __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State st, Scratch sc) {
+  if (sc.fa->n_obj <= 0) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // the table cursor of RingBufferOperations::gaussian_random_calculator_ advanced by three per moved particle
     long long c = (long long)sc.cur->move_cursor + 3ll * (long long)sc.cnt->n_moved;
@@ -579,7 +590,10 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
 }
 
 // removeObjectByTrackID (object_layer.h:414-425): every index of the set -> INVALID, set erased.
-__global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const uint16_t *__restrict__ tracks, int n, int p_n) {
+__global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const FrameArgs *__restrict__ fa, int p_n) {
+  const int n = fa->n_remove;
+  if (n <= 0) return;  // nothing to wipe in this frame
+  const uint16_t *__restrict__ tracks = fa->remove;
   if (blockIdx.x == 0) {  // older memberships of the removed objects (State::alias)
     const uint32_t na = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
     for (uint32_t k = threadIdx.x; k < na; k += blockDim.x) {
@@ -595,21 +609,25 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
         }
     }
   }
-  if (st.owner_flag[blockIdx.x] == 0) return;  // one block per OWNER_CHUNK slots
-  size_t i = (size_t)blockIdx.x * OWNER_CHUNK + threadIdx.x;
-  size_t end = (size_t)(blockIdx.x + 1) * OWNER_CHUNK;
-  if (end > n_slots) end = n_slots;
-  for (; i < end; i += blockDim.x) {
-    uint16_t o = st.owner[i];
-    if (o == OWNER_NONE) continue;
-    for (int k = 0; k < n; ++k)
-      if (tracks[k] == o) {
-        st.status[rec_index(i, p_n, REC_STATUS)] = ST_INVALID;
-        st.vflag[i >> p_n] = VF_DIRTY;
-        mark_tile(st, i >> p_n);
-        st.owner[i] = OWNER_NONE;
-        break;
-      }
+  // workgroups stride over the chunks of OWNER_CHUNK slots (the grid does not depend on the frame)
+  const size_t n_chunks = (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK;
+  for (size_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    if (st.owner_flag[chunk] == 0) continue;
+    size_t i = chunk * OWNER_CHUNK + threadIdx.x;
+    size_t end = (chunk + 1) * OWNER_CHUNK;
+    if (end > n_slots) end = n_slots;
+    for (; i < end; i += blockDim.x) {
+      uint16_t o = st.owner[i];
+      if (o == OWNER_NONE) continue;
+      for (int k = 0; k < n; ++k)
+        if (tracks[k] == o) {
+          st.status[rec_index(i, p_n, REC_STATUS)] = ST_INVALID;
+          st.vflag[i >> p_n] = VF_DIRTY;
+          mark_tile(st, i >> p_n);
+          st.owner[i] = OWNER_NONE;
+          break;
+        }
+    }
   }
 }
 
@@ -642,33 +660,29 @@ void launch_owner_flags(const Dims &d, const State &st, hipStream_t s) {
 size_t move_blocks(const Dims &d) { return ((size_t)d.v_count * d.S + MV_CHUNK - 1) / MV_CHUNK; }
 size_t move_count_elems() { return (size_t)MAX_MOVE_OBJECTS * MV_LIST_CAP + 1; }
 
+// The launch sequence below is the same every frame (hipGraph): kernels of a frame without moving objects / removals
+// return at once, the scan covers fa->n_move_cnt elements read on the device.
 // step 1: collect every moving object's members (ascending index) and publish the per-object counts
-void launch_moves_count(const Dims &d, const MoveSet &ms_dev, int n_obj, const State &st, const Scratch &sc, int32_t *counts_local,
-                        hipStream_t s) {
-  if (n_obj <= 0) return;
+void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32_t *counts_local, hipStream_t s) {
   const size_t n_slots = (size_t)d.v_count * d.S;
-  const size_t n_cnt = (size_t)n_obj * MV_LIST_CAP + 1;
   hipLaunchKernelGGL(k_move_chunks, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cur,
-                     sc.mv_cnt + (n_cnt - 1), st.alias, st.owner_flag);
-  hipLaunchKernelGGL(k_move_count, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, ms_dev, sc.mv_cnt, n_obj, st.owner_flag, sc.mv_list,
+                     sc.mv_cnt, sc.fa_side, st.alias, st.owner_flag);
+  hipLaunchKernelGGL(k_move_count, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, sc.fa_side, sc.mv_cnt, st.owner_flag, sc.mv_list,
                      sc.mv_nlist, st.alias);
-  exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, n_cnt, sc.scan_scratch_m, s);
+  exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, move_count_elems(), sc.scan_scratch_m, s, &sc.fa_side->n_move_cnt);
   // the per-object counts are only needed as a separate row when they are exchanged between shards
-  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, n_obj, counts_local, sc);
+  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, counts_local, sc);
 }
 
 // step 2 (after the counts of all shards are known): global ranks, transform, export of slab-crossing copies
-void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms_dev, int n_obj, const State &st,
-                            const Scratch &sc, const int32_t *counts_all, int world, int rank, hipStream_t s) {
-  if (n_obj <= 0) return;
-  hipLaunchKernelGGL(k_move_apply, dim3(1024), dim3(TPB), 0, s, d, f, flt, ms_dev, st, sc, sc.mv_cnt, n_obj,
-                     d.v_count != d.V ? counts_all : nullptr, world, rank);
+void launch_moves_transform(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, const int32_t *counts_all, int world,
+                            int rank, hipStream_t s) {
+  hipLaunchKernelGGL(k_move_apply, dim3(1024), dim3(TPB), 0, s, d, flt, st, sc, sc.mv_cnt, d.v_count != d.V ? counts_all : nullptr, world,
+                     rank);
 }
 
 // step 3 (after the export buffers of all shards are gathered): import, ordered replay per target voxel
-void launch_moves_finish(const Dims &d, const Filter &flt, int n_obj, const State &st, const Scratch &sc, int world, int rank,
-                         hipStream_t s) {
-  if (n_obj <= 0) return;
+void launch_moves_finish(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, int world, int rank, hipStream_t s) {
   if (world > 1 && sc.halo_recv) hipLaunchKernelGGL(k_move_import, dim3(64, world), dim3(TPB), 0, s, d, sc, world, rank);
   dim3 grid(256);
   switch (d.p_n) {
@@ -679,10 +693,10 @@ void launch_moves_finish(const Dims &d, const Filter &flt, int n_obj, const Stat
   }
 }
 
-void launch_remove(const Dims &d, const State &st, const uint16_t *tracks_dev, int n, hipStream_t s) {
-  if (n <= 0) return;
+void launch_remove(const Dims &d, const State &st, const Scratch &sc, hipStream_t s) {
   const size_t n_slots = (size_t)d.v_count * d.S;
-  hipLaunchKernelGGL(k_remove, dim3((unsigned)((n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK)), dim3(TPB), 0, s, st, n_slots, tracks_dev, n, d.p_n);
+  const size_t n_chunks = (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK;
+  hipLaunchKernelGGL(k_remove, dim3((unsigned)(n_chunks < 1024 ? n_chunks : 1024)), dim3(TPB), 0, s, st, n_slots, sc.fa, d.p_n);
 }
 
 }  // namespace sdm

@@ -47,7 +47,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *t
 
 // pass 1: per-tile totals
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const uint32_t *__restrict__ in, uint32_t *__restrict__ sums,
-                                                               size_t n) {
+                                                               size_t n, const uint32_t *__restrict__ n_dev) {
+  if (n_dev) n = *n_dev < n ? (size_t)*n_dev : n;  // tiles beyond the count sum to zero
   size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   uint32_t s = 0;
 #pragma unroll
@@ -63,7 +64,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const uint32_t *_
 // pass 2: every block first reduces the totals of all preceding tiles (a few thousand values at most, read
 // by 256 threads), then scans its own tile.  Two launches per scan instead of three.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                           const uint32_t *__restrict__ sums, size_t n) {
+                                                           const uint32_t *__restrict__ sums, size_t n,
+                                                           const uint32_t *__restrict__ n_dev) {
+  if (n_dev) n = *n_dev < n ? (size_t)*n_dev : n;
+  if ((size_t)blockIdx.x * SCAN_TILE >= n) return;
   uint32_t pre = 0;
   for (uint32_t t = threadIdx.x; t < blockIdx.x; t += SCAN_THREADS) pre += sums[t];
   uint32_t tile_offset;
@@ -186,11 +190,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint32_t *__restr
 
 size_t scan_scratch_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
 
-void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch, hipStream_t s) {
+void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch, hipStream_t s, const uint32_t *n_dev) {
   if (n == 0) return;
   size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, scratch, n);
-  hipLaunchKernelGGL(scan_tiles, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, out, scratch, n);
+  hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, scratch, n, n_dev);
+  hipLaunchKernelGGL(scan_tiles, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, out, scratch, n, n_dev);
 }
 
 size_t sort_scratch_elems(size_t n) {
@@ -211,7 +215,7 @@ int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint3
     uint32_t *kin = which ? keys_b : keys_a, *vin = which ? vals_b : vals_a;
     uint32_t *kout = which ? keys_a : keys_b, *vout = which ? vals_a : vals_b;
     hipLaunchKernelGGL(rs_histogram, dim3((unsigned)tiles), dim3(RS_THREADS), 0, s, kin, hist, n, shift, (uint32_t)tiles, n_dev);
-    exclusive_scan_u32(hist, hist, hist_n, scan_scratch, s);
+    exclusive_scan_u32(hist, hist, hist_n, scan_scratch, s, nullptr);
     hipLaunchKernelGGL(rs_scatter, dim3((unsigned)tiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, hist, n, shift,
                        (uint32_t)tiles, n_dev);
     which ^= 1;

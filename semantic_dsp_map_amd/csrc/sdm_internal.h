@@ -302,9 +302,10 @@ __device__ __forceinline__ float query_pdf(const float *__restrict__ pdf, float 
 }
 
 // ---- primitives (primitives.hip) ------------------------------------------------------
-// exclusive prefix sum of n uint32; in == out allowed. scratch must hold scan_scratch_elems(n) uint32.
+// exclusive prefix sum of n uint32; in == out allowed. scratch must hold scan_scratch_elems(n) uint32.  If n_dev is not
+// null the element count is min(*n_dev, n) read on the device (n is then the capacity the launch is sized for).
 size_t scan_scratch_elems(size_t n);
-void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch, hipStream_t s);
+void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch, hipStream_t s, const uint32_t *n_dev = nullptr);
 // stable LSD radix sort of (key,val) pairs on key bits [0,nbits). Result ends in (keys_a, vals_a) if the returned
 // value is 0, in (keys_b, vals_b) if 1. scratch must hold sort_scratch_elems(n) uint32.  If n_dev is not null the
 // element count is min(*n_dev, n) read on the device (n is then the capacity the launch is sized for).

@@ -22,17 +22,46 @@ struct MoveCopy {
 };
 static_assert(sizeof(MoveCopy) == 32, "MoveCopy layout");
 
+// object moves / removals (moves.hip)
+constexpr int MAX_MOVE_OBJECTS = 48;  // keeps FrameArgs under the 4 KB kernel-argument limit
+constexpr int MAX_REMOVE_TRACKS = 128;
+constexpr int HALO_OBJ = 64;              // ints per shard in the gathered count matrix (>= MAX_MOVE_OBJECTS)
+constexpr int HALO_RECORD_BYTES = 36;
+constexpr int HALO_HEADER_BYTES = 16;
+struct MoveSet {
+  int n;
+  float T[MAX_MOVE_OBJECTS][12];  // rows 0..2 of the 4x4 (row-major)
+  uint16_t track[MAX_MOVE_OBJECTS];
+};
+
+// Everything that changes from frame to frame, in one block of device memory that every kernel of the frame reads its
+// frame scalars from (uniform loads).  The host fills a copy and hands it to the frame's first kernel (k_set_frame) BY
+// VALUE, which stores it: no host-to-device copy, and - what it is for - a frame whose launch sequence is captured in
+// a hipGraph needs exactly one kernel-node parameter update per frame.  Two blocks alternate outside a graph, so that
+// the next frame's pose-only chains (frustum, member count) can start while this frame's sweep still runs.
+struct FrameArgs {
+  Frame f;
+  StampUpdates su;
+  MoveSet ms;
+  int n_obj;           // moving objects of this frame (= ms.n)
+  int n_remove;
+  uint32_t n_move_cnt; // elements of the move-count matrix the scan covers: n_obj * MV_LIST_CAP + 1
+  int force_generic;   // test hook: always run the generic 3-D frustum flood
+  const float *depth;  // this frame's inputs (device)
+  const sdm_labeled_point *cloud;
+  uint16_t remove[MAX_REMOVE_TRACKS];
+};
+static_assert(sizeof(FrameArgs) <= 3400, "FrameArgs travels as a kernel argument (4 KB limit, with the launch's other arguments)");
+
 struct Scratch {
+  const FrameArgs *fa = nullptr;       // this frame's block, as the main-stream kernels see it (written by k_frame_begin)
+  const FrameArgs *fa_side = nullptr;  // the same for the chains that start before it: frustum, member count (k_set_frame)
   // frustum vertex bitsets, one line of wpl 64-bit words per (y,z)
   uint64_t *vmask = nullptr, *reach = nullptr;
   int wpl = 0;
   // per-line bitmaps over (y,z), wy 64-bit words per z row: non-empty, overlaps next line in y / z, reached
   uint64_t *line_ne = nullptr, *line_ey = nullptr, *line_ez = nullptr, *line_reach = nullptr;
   int wy = 0;
-  int force_generic = 0;
-  // inputs of the current frame (device)
-  const float *depth = nullptr;
-  const sdm_labeled_point *cloud = nullptr;
   // per-pixel bins
   uint32_t *bin_count = nullptr, *bin_start = nullptr;
   uint32_t *vis_pix = nullptr, *vis_idx = nullptr, *vis_pib = nullptr;
@@ -91,16 +120,34 @@ void launch_labeled_cloud(const Dims &d, const CloudArgsHost &h, const float *de
 void launch_manual_resize(const Dims &d, const void *src, void *dst, int src_w, int src_h, float scale, int elem_bytes,
                           hipStream_t s);
 
-void launch_frame_begin(const Dims &d, const State &st, const Scratch &sc, const StampUpdates &su, hipStream_t s);
+void launch_set_frame(FrameArgs *fa_dev, const FrameArgs &fa, hipStream_t s);
+const void *set_frame_kernel();  // the kernel behind launch_set_frame (hipGraph kernel-node parameter updates)
+// k_frame_begin's arguments as one object: the same kernel is launched directly and replayed as a hipGraph node whose
+// parameters are replaced every frame
+struct FrameBeginLaunch {
+  static constexpr unsigned GRID = 512, BLOCK = 256;
+  Counters *cnt;
+  uint32_t *bin_count;
+  uint32_t n_bins;
+  State st;
+  FrameArgs fa;
+  FrameArgs *dst_main, *dst_side;
+  Dims d;
+  uint32_t slab_max;
+  void *argv[9];
+  void set(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa, bool with_side);
+  static const void *kernel();
+};
+void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s);
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, hipStream_t s);
-void launch_frustum(const Dims &d, const Frame &f, const Scratch &sc, int force_generic, hipStream_t s);
-void launch_visibility(const Dims &d, const Frame &f, const State &st, const Scratch &sc, hipStream_t s);
+void launch_frustum(const Dims &d, const Scratch &sc, hipStream_t s);
+void launch_visibility(const Dims &d, const State &st, const Scratch &sc, hipStream_t s);
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s);
-void launch_weight(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
-int launch_birth_prepare(const Dims &d, const Frame &f, const Filter &flt, const BirthOrder &bo, const State &st,
+void launch_weight(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
+int launch_birth_prepare(const Dims &d, const Filter &flt, const BirthOrder &bo, const State &st,
                          const Scratch &sc, hipStream_t s);
-void launch_birth_replay(const Dims &d, const Frame &f, const Filter &flt, const State &st, const Scratch &sc, int which,
+void launch_birth_replay(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, int which,
                          hipStream_t s);
 void launch_count_live(const Dims &d, const State &st, unsigned long long *out, hipStream_t s);
 void launch_count_owner(const Dims &d, const State &st, uint16_t track, unsigned long long *out, hipStream_t s);
@@ -118,25 +165,13 @@ void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t
                         uint32_t *scan_scratch, sdm_point *out, uint32_t cap, int want_free, const float sub[3],
                         int mark_fov, hipStream_t s);
 
-// object moves / removals (moves.hip)
-constexpr int MAX_MOVE_OBJECTS = 48;  // keeps the by-value MoveSet kernel argument under the 4 KB kernarg limit
-constexpr int HALO_OBJ = 64;              // ints per shard in the gathered count matrix (>= MAX_MOVE_OBJECTS)
-constexpr int HALO_RECORD_BYTES = 36;
-constexpr int HALO_HEADER_BYTES = 16;
-struct MoveSet {
-  int n;
-  float T[MAX_MOVE_OBJECTS][12];  // rows 0..2 of the 4x4 (row-major)
-  uint16_t track[MAX_MOVE_OBJECTS];
-};
 size_t move_blocks(const Dims &d);
 size_t move_count_elems();
 void launch_owner_flags(const Dims &d, const State &st, hipStream_t s);
-void launch_moves_count(const Dims &d, const MoveSet &ms, int n_obj, const State &st, const Scratch &sc, int32_t *counts_local,
-                        hipStream_t s);
-void launch_moves_transform(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms, int n_obj, const State &st,
-                            const Scratch &sc, const int32_t *counts_all, int world, int rank, hipStream_t s);
-void launch_moves_finish(const Dims &d, const Filter &flt, int n_obj, const State &st, const Scratch &sc, int world, int rank,
-                         hipStream_t s);
-void launch_remove(const Dims &d, const State &st, const uint16_t *tracks_dev, int n, hipStream_t s);
+void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32_t *counts_local, hipStream_t s);
+void launch_moves_transform(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, const int32_t *counts_all, int world,
+                            int rank, hipStream_t s);
+void launch_moves_finish(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, int world, int rank, hipStream_t s);
+void launch_remove(const Dims &d, const State &st, const Scratch &sc, hipStream_t s);
 
 }  // namespace sdm

@@ -118,6 +118,7 @@ class Scene:
         self.wall_top = -min(6.0, 0.45 * (1 << cfg["y_n"]) * cfg["voxel_size"])
         self.speed = speed
         self.yaw_rate = math.radians(yaw_rate_deg)
+        self.lateral_extra = None  # (t0, metres per frame): extra sideways (x) motion from frame t0 on
         self.invalid_fraction = invalid_fraction
         zmax = max(2.0 * half, 6.0)
         r = self.rng
@@ -156,6 +157,8 @@ class Scene:
     def pose(self, t):
         theta = self.yaw_rate * t
         pos = np.array([0.05 * t * self.speed, 0.0, self.speed * t], np.float64)
+        if self.lateral_extra is not None and t > self.lateral_extra[0]:
+            pos[0] += (t - self.lateral_extra[0]) * self.lateral_extra[1]
         return pos, yaw_quat(theta)
 
     def dyn_boxes(self, t):
