@@ -35,6 +35,122 @@ if ROOT not in sys.path:
 HBM_PEAK_BPS = 8.0e12  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+def timed_run(synth, sharded, dist, rank, world, local_rank, cfg, params, particles_per_shard, steps, warmup, scene_kw,
+              prefill_kw=None):
+    """One more map of its own: frames rendered and uploaded, map prefilled, `warmup` + `steps` frames issued back to back,
+    barrier + synchronize on both sides of the timed ones, max over ranks.  Returns the numbers and the engine (open)."""
+    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist)
+    m = eng.map
+    m.generate_noise_table(seed=20250217)
+    scene = synth.Scene(cfg, **scene_kw)
+    frames = []
+    for t in range(warmup + steps):
+        depth, cloud, pos, q = scene.render(t, params)
+        frames.append((depth, cloud, pos, q, scene.moves(t), m.device_put(depth), m.device_put(cloud)))
+    st, ring, _ = synth.prefill_state(cfg, scene, particles_per_shard, shard_rank=rank, shard_count=world, **(prefill_kw or {}))
+    m.load_state(st)
+    m.set_ring_state(ring)
+
+    def fence():
+        m.synchronize()
+        m.device_synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def run(lo, hi):
+        for t in range(lo, hi):
+            eng.update(frames[t][5], frames[t][6], frames[t][2], frames[t][3], frames[t][4])
+
+    run(0, warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(warmup, warmup + steps)
+    t_enq = time.perf_counter() - t0
+    fence()
+    dt = time.perf_counter() - t0
+    stats = m.stats(count_live=True)
+    live, n_vis = stats["live_particles"], stats["n_visible"]
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        lt = torch.tensor([live, n_vis], dtype=torch.int64)
+        dist.all_reduce(lt)
+        live, n_vis = int(lt[0].item()), int(lt[1].item())
+    V = 1 << (cfg["x_n"] + cfg["y_n"] + cfg["z_n"])
+    res = {"value": round(V / (dt / steps) / 1e6, 1), "unit": "Mvoxels/s", "ms_per_step": round(dt * 1e3 / steps, 4), "steps": steps,
+           "warmup": warmup, "n_gpus": world, "voxels": V, "live_particles": live, "visible_particles": n_vis,
+           "host_enqueue_ms_per_step": round(t_enq * 1e3 / steps, 4)}
+    return res, eng, scene, frames, (st, ring)
+
+
+def stress_run(synth, sharded, steps=8, warmup=14, cpu_frames=4):
+    """A busier frame: cluttered street (200 static boxes, 12 moving ones), three noisy births per point (thick
+    surfaces), the camera turning 1.5 deg/frame and drifting sideways so that x slabs of the ring are recycled too, the
+    map topped up to 2.0 M particles.  Timed like the headline run; then per-stage GPU times of four more
+    frames, and the oracle on the very same map state (dumped from the GPU after the warm-up) and frames."""
+    cfg = synth.CONFIGS["C3"]
+    params = synth.PARAMS["vkitti2_nb3"]
+    scene_kw = dict(n_static=200, n_dynamic=12, seed=11, yaw_rate_deg=1.5, lateral_extra=(0, 0.04))
+    res, eng, scene, frames, (st, ring) = timed_run(synth, sharded, None, 0, 1, 0, cfg, params, 2000000, steps, warmup, scene_kw)
+    m = eng.map
+    # the oracle starts where the timed region started: replay is deterministic, so re-run the warm-up on a second map
+    # would do too - cheaper: a fresh map, warm-up, dump
+    eng_b = sharded.NativeShardedMap(cfg, params, 0, 1, 0)
+    mb = eng_b.map
+    noise = m.download_noise_table()
+    mb.upload_noise_table(noise)
+    mb.load_state(st)
+    mb.set_ring_state(ring)
+    del st
+    for t in range(warmup):
+        eng_b.update(frames[t][5], frames[t][6], frames[t][2], frames[t][3], frames[t][4])
+    mb.synchronize()
+    state0, ring0, stamps0 = mb.dump_state(), mb.ring_state(), mb.stamps()
+    # per-stage GPU times of the timed frames, on the copy (same state, same frames)
+    mb.set_profiling(True)
+    acc, live_l, tiles_l, slabs, vis_l = np.zeros(8), [], [], np.zeros(3), []
+    n_prof = min(4, steps)
+    for t in range(warmup, warmup + n_prof):
+        eng_b.update(frames[t][5], frames[t][6], frames[t][2], frames[t][3], frames[t][4])
+        mb.synchronize()
+        stt = mb.stats()
+        acc += np.array(stt["stage_ms"])
+        live_l.append(stt["sweep_live_voxels"])
+        tiles_l.append(stt["sweep_tiles"])
+        vis_l.append(stt["n_visible"])
+        slabs += np.array(stt["restamped_slabs"])
+    mb.close()
+    names = ["", "ego", "move", "remove", "visibility", "weight", "birth", "occupancy"]
+    res["stage_ms"] = {k: round(acc[i] / n_prof, 4) for i, k in enumerate(names) if k}
+    res["sweep"] = {"tiles_looked_into": int(np.mean(tiles_l)), "voxels_evaluated_in_full": int(np.mean(live_l))}
+    res["visible_particles_per_frame"] = int(np.mean(vis_l))
+    res["restamped_slabs_per_frame"] = [round(float(x) / n_prof, 2) for x in slabs]
+    res["workload"] = ("stress: C3 grid, 200 static + 12 moving boxes, 3 noisy births per point, yaw 1.5 deg/frame + sideways drift, "
+                       "%d live particles, %d visible per frame" % (res["live_particles"], res["visible_particles_per_frame"]))
+    if cpu_frames > 0:
+        from oracle import oracle as orc
+        o = orc.OracleMap(dict(cfg, bin_order=0), params, noise)
+        o.load_state(state0)
+        o.set_stamps(*stamps0)
+        o.set_ring_state(ring0)
+        del state0
+        times = []
+        for t in range(warmup, warmup + min(cpu_frames + 1, steps)):
+            t0 = time.perf_counter()
+            o.update(frames[t][0], frames[t][1], frames[t][2], frames[t][3], frames[t][4])
+            if t > warmup:  # the first frame warms the caches
+                times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        res["cpu_baseline"] = {"value": round(res["voxels"] / med / 1e6, 2), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+                               "ms_per_frame": round(med * 1e3, 1),
+                               "sample": "%d frames from the same map state (dumped from the GPU after the warm-up), 1 thread" % len(times)}
+        res["x_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+    m.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -45,10 +161,16 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=10, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-case sweep timing after the run")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling run (C4: 256^3 / 8M particles over the GPUs)")
+    ap.add_argument("--no-stress", action="store_true", help="skip the busy-scene run (N = 1 only)")
+    ap.add_argument("--only-stress", action="store_true", help="run nothing but the busy scene (development)")
     args = ap.parse_args()
 
     from semantic_dsp_map_amd import sharded, synth
 
+    if args.only_stress:
+        print(json.dumps({"stress": stress_run(synth, sharded)}))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -225,6 +347,23 @@ def main():
                                   "frac_on_survey_bytes": round(dense_slot_bytes / dense_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
                                   "launches_timed": 10}
 
+    # ---- strong scaling (BASELINE.json C4): the same 256^3 map with 8 M particles, split into `world` Z slabs.  Its own
+    # map and frames; a separate object in the line (the headline value above stays the weak-scaling one).
+    strong = None
+    if not args.no_strong:
+        m.close()
+        base4 = synth.CONFIGS["C4"]
+        strong, eng4, _, _, _ = timed_run(synth, sharded, dist, rank, world, local_rank, base4, synth.PARAMS[synth.CONFIG_PARAMS["C4"]],
+                                          8000000 // world, min(args.steps, 10), min(args.warmup, 3),
+                                          dict(n_static=48, n_dynamic=6, seed=7))
+        strong["config"] = "C4: 256x256x256 voxels, 8 slots/voxel, 8 M particles prefilled in all, Z-slab shards over %d GPU(s)" % world
+        strong["scaling"] = "strong"
+        eng4.map.close()
+
+    stress = None
+    if world == 1 and not args.no_stress and not args.no_cpu:
+        stress = stress_run(synth, sharded)
+
     if rank == 0:
         out = {
             "metric": "Mvoxels updated/sec (256^3 grid, 2M particles, VKITTI2 camera; whole hot-path frame)",
@@ -243,6 +382,10 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
+        if stress is not None:
+            out["stress"] = stress
         if world == 1:
             out["stage_ms"] = {k: round(stage_ms[i], 4) for i, k in
                                enumerate(["", "ego", "move", "remove", "visibility", "weight", "birth", "occupancy"]) if k}

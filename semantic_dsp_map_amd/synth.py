@@ -68,6 +68,12 @@ PARAMS = {
                     max_obersevation_lost_time=5, forgetting_rate=1.0, max_forget_count=3,
                     match_score_threshold=0.6, id_transition_probability=0.2, if_consider_depth_noise=1,
                     if_use_independent_filter=0, depth_noise_first_order=0.01, depth_noise_zero_order=0.2),
+    # the VKITTI2 preset with the constructor's default of three noisy births per point (semantic_dsp_map.h:29): thick
+    # surfaces, several times the particles per frame - bench.py's busy scene
+    "vkitti2_nb3": dict(detection_probability=0.98, noise_number=0.001, nb_ptc_num_per_point=3, occupancy_threshold=0.5,
+                        max_obersevation_lost_time=5, forgetting_rate=1.0, max_forget_count=3,
+                        match_score_threshold=0.6, id_transition_probability=0.2, if_consider_depth_noise=1,
+                        if_use_independent_filter=0, depth_noise_first_order=0.01, depth_noise_zero_order=0.2),
     # exercises the Gaussian-noise birth path (nb > 1) and the no-noise birth path
     "noisy3": dict(detection_probability=0.95, noise_number=0.1, nb_ptc_num_per_point=3, occupancy_threshold=0.2,
                    max_obersevation_lost_time=5, forgetting_rate=1.0, max_forget_count=5,
@@ -107,7 +113,7 @@ class Scene:
     """Street scene scaled to the map extent of a configuration."""
 
     def __init__(self, cfg, n_static=24, n_dynamic=4, seed=7, speed=0.3, yaw_rate_deg=1.0,
-                 invalid_fraction=0.0, dyn_speed=(0.2, 1.0)):
+                 invalid_fraction=0.0, dyn_speed=(0.2, 1.0), lateral_extra=None):
         self.cfg = dict(cfg)
         self.rng = np.random.default_rng(seed)
         self.seed = seed
@@ -118,7 +124,7 @@ class Scene:
         self.wall_top = -min(6.0, 0.45 * (1 << cfg["y_n"]) * cfg["voxel_size"])
         self.speed = speed
         self.yaw_rate = math.radians(yaw_rate_deg)
-        self.lateral_extra = None  # (t0, metres per frame): extra sideways (x) motion from frame t0 on
+        self.lateral_extra = lateral_extra  # (t0, metres per frame): extra sideways (x) motion from frame t0 on
         self.invalid_fraction = invalid_fraction
         zmax = max(2.0 * half, 6.0)
         r = self.rng
