@@ -156,16 +156,20 @@ int main(int argc, char **argv) {
   }
   CHECK(sdm_get_voxels(m, vox.data()));
   uint64_t h = 1469598103934665603ull;  // FNV-1a over the 8-byte results
+  uint64_t wordsum = 0;  // sum of the results as 64-bit words (what a numpy caller can compute on 10^8 voxels)
   size_t n_occ = 0;
   for (const auto &r : vox) {
     const unsigned char *b = reinterpret_cast<const unsigned char *>(&r);
     for (int i = 0; i < 8; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    uint64_t w;
+    std::memcpy(&w, &r, 8);
+    wordsum += w;
     n_occ += r.occ > 0;
   }
   std::printf("frames %zu  avg %.3f ms/frame (%s host buffers in, %s)  %.1f Mvoxels/s\n", n_updates, total_ms / n_updates,
               pinned ? "page-locked" : "pageable", pipelined ? "frames issued back to back" : "synchronised after every frame",
               (double)V / (total_ms / n_updates) / 1e3);
-  std::printf("occupied %zu  checksum %016llx\n", n_occ, (unsigned long long)h);
+  std::printf("occupied %zu  checksum %016llx  wordsum %016llx\n", n_occ, (unsigned long long)h, (unsigned long long)wordsum);
   sdm_destroy(m);
   return 0;
 }
