@@ -48,3 +48,30 @@ def test_bfs_reaches_the_dense_sweep_set():
         o.update(depth, cloud, pos, q, moves)
         s = o.stats()
         assert s["bfs_start_in_frustum"] == 1 and s["n_frustum_voxels"] > 1000
+
+
+def test_order_gap_at_C2_size_on_a_prefilled_map():
+    """The same question at BASELINE.json's C2 (128^3, 4 slots, 500 k particles prefilled; tools/order_gap.py runs it at
+    C3 too - profiles/r02_order_gap_c3.json): no integer decision flips, weights within 1e-5."""
+    cfg = synth.CONFIGS["C2"]
+    params = synth.PARAMS["zed2"]
+    scene = synth.Scene(cfg, n_static=24, n_dynamic=3, seed=7)
+    noise = synth.noise_table()
+    st, ring, _ = synth.prefill_state(cfg, scene, 500000)
+    maps = []
+    for order in (0, 1):
+        o = orc.OracleMap(dict(cfg, bin_order=order), params, noise)
+        o.load_state(st)
+        o.set_ring_state(ring)
+        maps.append(o)
+    a, b = maps
+    for t in range(3):
+        depth, cloud, pos, q = scene.render(t, params)
+        a.update(depth, cloud, pos, q, scene.moves(t))
+        b.update(depth, cloud, pos, q, scene.moves(t))
+        sa, sb = a.dump_state(), b.dump_state()
+        assert np.array_equal(sa["status"], sb["status"]) and np.array_equal(sa["ts"], sb["ts"])
+        live = sa["status"] != 0
+        assert np.max(np.abs(sa["w"][live] - sb["w"][live])) < 1e-5
+        va, vb = a.voxels(), b.voxels()
+        assert np.array_equal(va["occ"], vb["occ"]) and np.array_equal(va["label"], vb["label"])
