@@ -316,6 +316,31 @@ sdm_status sdm_get_voxels(sdm_map *m, sdm_voxel_result *out);
 #define SDM_OCC_OUT_OF_FOV 0x40
 sdm_status sdm_get_occupied(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t flags);
 sdm_status sdm_get_freespace(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t flags);
+/* ---- the same lists coloured and packed on the device, ready for the ROS message.
+ * getOccupancyResult's colour rules (semantic_dsp_map.h:1274-1351): Background voxels by height through the jet map
+ * (:50-63, :1277-1294), static instances (track id > max_movable_track, or every label when colour_by_label is set:
+ * SETTING == 0) by their label colour (utils/data_base.h:216-232), movable ones (160, perm[track & 255], perm[label])
+ * or, in evaluation format, (label, track >> 8, track & 255); guessed-occupied voxels white; free space green; outside
+ * the evaluation format every colour then takes OpenCV's 8-bit RGB -> HSV -> RGB round trip with V x 0.7 for voxels
+ * outside the camera frustum (:1333-1351; restated from OpenCV 4.x, see oracle/colour.py).
+ * One point = pcl::PointXYZRGB's 32 bytes: x, y, z, 1.0f, then b, g, r, a = 255, then 12 bytes of padding. */
+typedef struct {
+  float x, y, z, one;
+  uint8_t b, g, r, a;
+  uint32_t pad[3];
+} sdm_point_xyzrgb;
+typedef struct {
+  uint8_t label_bgr[256][3]; /* g_label_color_map_default, BGR like cv::Vec3b                       */
+  uint8_t perm[256];         /* color_map_int_256_ (semantic_dsp_map.h:45-48)                         */
+  int32_t background_label;  /* g_label_id_map_default["Background"]                                */
+  int32_t colour_by_label;   /* SETTING == 0 (:1296-1302)                                            */
+  int32_t jet_axis;          /* 0: jet index from -z + 2 (default), 1: from y + 2 (SETTING == 3)       */
+  int32_t evaluation_format; /* if_out_evaluation_format_ (:130-134)                                 */
+} sdm_colour_config;
+sdm_status sdm_set_colours(sdm_map *m, const sdm_colour_config *c);
+/* flags: SDM_POINTS_ZERO_CENTER as above (the frustum test always uses the uncentred position) */
+sdm_status sdm_get_occupied_rgb(sdm_map *m, sdm_point_xyzrgb *out, size_t cap, size_t *n_out, int32_t flags);
+sdm_status sdm_get_freespace_rgb(sdm_map *m, sdm_point_xyzrgb *out, size_t cap, size_t *n_out, int32_t flags);
 /* device pointer to the per-voxel result array (valid until the next update) */
 sdm_status sdm_voxels_device_ptr(sdm_map *m, const sdm_voxel_result **out);
 

@@ -6,16 +6,21 @@
  * subObjectLevelUpdate (semantic_dsp_map.h:576-955) runs on the MI355X behind sdm_update(); what stays on the
  * host is what the reference also does outside that function:
  *   - track-id reallocation (semantic_dsp_map.h:179-186),
- *   - the object layer (objectLevelUpdate, :306-566): NOT re-implemented here.  Plug the reference's own
- *     ObjectSet logic in through SdmObjectLayer (INTEGRATION.md shows the 20-line glue); without one the map runs
- *     like the reference with g_consider_instance == false,
+ *   - the object layer (objectLevelUpdate, :306-566): the library's own restatement (sdm_objects.h, SdmBuiltinObjectLayer)
+ *     is switched on at the first update() of a preset with consider_instance, like the reference's built-in one;
+ *     another implementation (e.g. the reference's ObjectSet) plugs in through SdmObjectLayer / setObjectLayer(),
  *   - packing of the depth image and the MONO8 masks for sdm_update_raw_ex(), which runs generateLabeledPointCloud
  *     (utils/pointcloud_tools.h:88-310) on the device, including the BOOST-mode manualResize and
  *     the ZED2 sky / bounding-box filters (SdmGridPreset::Zed2Boost); the per-object boxes are computed here from the
  *     key points,
- *   - colouring of the emitted cloud (semantic_dsp_map.h:1274-1351): the colour rules and OpenCV's RGB<->HSV round
- *     trip stay host code (one batched cvtColor instead of the reference's two per voxel); the in-view test that
- *     selects the "V x 0.7" dimming comes from the device with each point (SDM_POINTS_MARK_FOV, row N2).
+ *   - nothing of the output side: occupied / free voxels are compacted, coloured (semantic_dsp_map.h:1274-1351,
+ *     including OpenCV's 8-bit RGB <-> HSV round trip and the "V x 0.7" dimming outside the view) and packed as
+ *     pcl::PointXYZRGB on the device (sdm_get_occupied_rgb, row N2); update() copies the array into the cloud.
+ *
+ * Label tables: with SDM_HAVE_REFERENCE_TRACKING_TYPES defined (the node includes the reference's utils/data_base.h
+ * first) the class reads g_label_id_map_default, g_label_color_map_default, g_instance_id_to_label_map_default and
+ * g_max_movable_object_instance_id at the first update(), i.e. after ObjectInfoHandler::readObjectInfo has filled them
+ * from the CSV (src/mapping.cpp:89-93) - an unchanged node needs no extra call.
  *
  * Compile-time grid/camera constants of settings/settings.h become SdmGridPreset; pick one with
  * setGridPreset() before the first update() (default: the reference's SETTING 2, VIRTUAL_KITTI2).
@@ -33,6 +38,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <iostream>
 #include <limits>
 #include <map>
@@ -77,6 +83,8 @@ struct SdmGridPreset {
   /// SETTING 3 (ZED2): sky pixels are dropped and every movable object's points are clipped to the box of its
   /// current key points +- 1 m (pointcloud_tools.h:174-196, 236-242, 254-272)
   bool zed2_filters = false;
+  /// the reference's SETTING for the object layer (settings.h:22): 1 CODA, 2 VIRTUAL_KITTI2, 3 ZED2
+  int object_mode = 2;
   static SdmGridPreset Kitti360() { return {8, 8, 8, 3, 0.15f, 552.554261f, 552.554261f, 682.049453f, 238.769549f, 1408, 376, 0.3f, 30.f, 5, false}; }
   static SdmGridPreset Coda() { return {8, 8, 7, 2, 0.15f, 569.8286f, 565.4818f, 439.2660f, 360.5810f, 960, 540, 0.3f, 10.f, 5, true}; }
   static SdmGridPreset VirtualKitti2() { return {8, 7, 8, 3, 0.2f, 725.0087f, 725.0087f, 620.5f, 187.f, 1242, 375, 0.3f, 30.f, 5, true}; }
@@ -88,6 +96,7 @@ struct SdmGridPreset {
     p.src_height = 720;
     p.rescale = 0.5f;
     p.zed2_filters = true;
+    p.object_mode = 3;
     return p;
   }
 };
@@ -125,6 +134,7 @@ class SdmBuiltinObjectLayer : public SdmObjectLayer {
               const Eigen::Quaterniond &camera_orientation, double time_stamp) override {
     std::vector<sdm_object_observation> obs(ins_seg_result.size());
     std::vector<std::vector<double>> cur(ins_seg_result.size()), prev(ins_seg_result.size());
+    seen_this_frame_.clear();
     for (size_t i = 0; i < ins_seg_result.size(); ++i) {
       const MaskKpts &s = ins_seg_result[i];
       for (const Eigen::Vector3d &p : s.kpts_current) cur[i].insert(cur[i].end(), {p.x(), p.y(), p.z()});
@@ -136,7 +146,10 @@ class SdmBuiltinObjectLayer : public SdmObjectLayer {
       obs[i].n_kpts = (int32_t)s.kpts_current.size();
       obs[i].kpts_current = cur[i].empty() ? nullptr : cur[i].data();
       obs[i].kpts_previous = prev[i].size() == cur[i].size() && !prev[i].empty() ? prev[i].data() : nullptr;
-      if (!obs[i].is_static && s.track_id <= max_movable_) maybe_present_.insert(s.track_id);
+      if (!obs[i].is_static && s.track_id <= max_movable_) {
+        maybe_present_.insert(s.track_id);
+        seen_this_frame_.insert(s.track_id);
+      }
     }
     const double pos[3] = {camera_position.x(), camera_position.y(), camera_position.z()};
     const double q[4] = {camera_orientation.w(), camera_orientation.x(), camera_orientation.y(), camera_orientation.z()};
@@ -159,7 +172,18 @@ class SdmBuiltinObjectLayer : public SdmObjectLayer {
     }
     moves.resize((size_t)n_moves);
     remove_tracks.resize((size_t)n_remove);
-    for (int32_t id : remove_tracks) maybe_present_.erase(id);  // wiped: nothing of it is left in the map
+    // wiped: nothing of it is left in the map - unless it also came with a mask THIS frame: sdm_update applies the
+    // removals before this frame's births, so particles are born under the id again right away and it has to be
+    // offered as "present" next frame like the reference's obj_ptc_hash_map would (semantic_dsp_map.h:713-736)
+    for (int32_t id : remove_tracks)
+      if (!seen_this_frame_.count(id)) maybe_present_.erase(id);
+  }
+  /// the frame these removals belonged to was not applied: offer them again
+  void requeue(const std::vector<int32_t> &remove_tracks) {
+    for (int32_t id : remove_tracks) maybe_present_.insert(id);
+  }
+  void setBayes(double distance_threshold, double probability_threshold, double increment, double decrement) {
+    sdm_objects_set_bayes(h_, distance_threshold, probability_threshold, increment, decrement);
   }
   void clear() override {
     sdm_objects_clear(h_);
@@ -172,7 +196,7 @@ class SdmBuiltinObjectLayer : public SdmObjectLayer {
   std::unordered_map<std::string, int> label_ids_;
   uint32_t global_time_stamp_;
   int max_movable_;
-  std::set<int32_t> maybe_present_;
+  std::set<int32_t> maybe_present_, seen_this_frame_;
 };
 
 class SemanticDSPMap {
@@ -293,6 +317,7 @@ class SemanticDSPMap {
   void setVisualizeOptions(bool visualize_with_zero_center, bool if_out_evaluation_format) {
     visualize_with_zero_center_ = visualize_with_zero_center;
     if_out_evaluation_format_ = if_out_evaluation_format;
+    pushColours();
   }
   /// semantic_dsp_map.h:142-148 (consumed by the object layer)
   void setBeyesianMovementParameters(double distance_threshold, double probability_threshold, double increment, double decrement) {
@@ -300,6 +325,7 @@ class SemanticDSPMap {
     beyesian_[1] = probability_threshold;
     beyesian_[2] = increment;
     beyesian_[3] = decrement;
+    if (builtin_layer_) builtin_layer_->setBayes(distance_threshold, probability_threshold, increment, decrement);
   }
   const double *beyesianMovementParameters() const { return beyesian_; }
   /// semantic_dsp_map.h:153-156
@@ -312,6 +338,7 @@ class SemanticDSPMap {
     params_.depth_noise_first_order = first_order;
     params_.depth_noise_zero_order = zero_order;
     std::cout << "Noise model is " << first_order << " * distance + " << zero_order << std::endl;
+    pushParams();
   }
 
   /// semantic_dsp_map.h:170-251.  Like the reference: no return code, diagnostics on stderr, output clouds are
@@ -321,6 +348,7 @@ class SemanticDSPMap {
               pcl::PointCloud<pcl::PointXYZRGB>::Ptr &freespace_point_cloud, bool if_get_freespace = false,
               double time_stamp_double = 0.0) {
     ensureMap();
+    if (preset_.consider_instance && !object_layer_) useBuiltinObjectLayer(preset_.object_mode);  // like the reference's built-in one
     global_time_stamp_ += 1;
     for (size_t i = 0; i < ins_seg_result.size(); ++i) {  // :179-186
       if (ins_seg_result[i].label != "static" && ins_seg_result[i].track_id > max_movable_track_) {
@@ -335,14 +363,27 @@ class SemanticDSPMap {
       object_layer_->update(ins_seg_result, camera_position, camera_orientation, time_stamp_double);
       object_layer_->collect(global_time_stamp_, params_.max_obersevation_lost_time, moves, removals);
     }
-    if (packRawInputs(depth_value_mat, ins_seg_result) != 0) return;
+    // per-frame limits of the C ABI (SDM_MAX_MOVES / SDM_MAX_REMOVALS): a crowded frame degrades instead of being
+    // dropped - removals beyond the limit wait for the next frame, objects beyond it keep their particles in place
+    removals.insert(removals.begin(), pending_removals_.begin(), pending_removals_.end());
+    pending_removals_.clear();
+    if (removals.size() > (size_t)SDM_MAX_REMOVALS) {
+      pending_removals_.assign(removals.begin() + SDM_MAX_REMOVALS, removals.end());
+      removals.resize(SDM_MAX_REMOVALS);
+    }
+    if (moves.size() > (size_t)SDM_MAX_MOVES) {
+      std::cerr << "sdm: " << moves.size() << " moving objects in one frame, only the first " << SDM_MAX_MOVES << " are moved" << std::endl;
+      moves.resize(SDM_MAX_MOVES);
+    }
+    if (packRawInputs(depth_value_mat, ins_seg_result) != 0) {
+      frameLost(removals);
+      return;
+    }
 
     // pose in double for the back-projection (pointcloud_tools.h:243-247); the library casts it to float for the
     // map update like the reference does (semantic_dsp_map.h:584, 745)
     const double cam_pos_d[3] = {camera_position.x(), camera_position.y(), camera_position.z()};
     const double cam_q_d[4] = {camera_orientation.w(), camera_orientation.x(), camera_orientation.y(), camera_orientation.z()};
-    const Eigen::Vector3f pf = camera_position.cast<float>();
-    const float cam_pos[3] = {pf.x(), pf.y(), pf.z()};
     sdm_raw_options opt;
     opt.src_width = preset_.src_width;
     opt.src_height = preset_.src_height;
@@ -358,10 +399,15 @@ class SemanticDSPMap {
                                  moves.empty() ? nullptr : moves.data(), (int32_t)moves.size(),
                                  removals.empty() ? nullptr : removals.data(), (int32_t)removals.size(),
                                  preset_.consider_instance ? 0u : SDM_NO_INSTANCES, SDM_STAGE_ALL, &opt),
-               "sdm_update_raw_ex"))
+               "sdm_update_raw_ex")) {
+      frameLost(removals);
       return;
-    emit(occupied_point_cloud, false, cam_pos);
-    if (if_get_freespace) emit(freespace_point_cloud, true, cam_pos);
+    }
+    emit(occupied_point_cloud, false);
+    if (if_get_freespace) emit(freespace_point_cloud, true);
+    // the getters above waited for the frame: surface what the device flagged (work-list overflows are recorded in
+    // counters that the next frame resets)
+    check(sdm_synchronize(map_), "sdm_update (device status)");
   }
 
   sdm_map *handle() { return map_; }
@@ -388,7 +434,30 @@ class SemanticDSPMap {
   std::vector<double> boxes_;  // ZED2: per object min x, max x, min y, max y, min z, max z
   uint16_t label_to_inst_[256];  // g_label_to_instance_id_map_default as a table (65535 = Background's instance)
   bool have_static_ = false;
-  std::vector<sdm_point> points_;
+  std::vector<sdm_point_xyzrgb> points_;
+  std::vector<int32_t> pending_removals_;
+  bool tables_from_reference_ = false;
+
+  /// a frame that did not reach the map: its removals are offered again
+  void frameLost(const std::vector<int32_t> &removals) {
+    if (builtin_layer_) builtin_layer_->requeue(removals);
+    else pending_removals_.insert(pending_removals_.end(), removals.begin(), removals.end());
+  }
+  /// colour tables + output format -> device (row N2)
+  void pushColours() {
+    if (!map_) return;
+    sdm_colour_config c;
+    std::memset(&c, 0, sizeof(c));
+    for (const auto &kv : label_color_)
+      if (kv.first >= 0 && kv.first < 256)
+        for (int k = 0; k < 3; ++k) c.label_bgr[kv.first][k] = kv.second[k];
+    for (int i = 0; i < 256; ++i) c.perm[i] = (uint8_t)color_map_int_256_[i];
+    c.background_label = label_id_.count("Background") ? label_id_["Background"] : 0;
+    c.colour_by_label = preset_.consider_instance ? 0 : 1;  // SETTING == 0 (semantic_dsp_map.h:1296-1302)
+    c.jet_axis = preset_.zed2_filters ? 1 : 0;              // SETTING == 3 colours by y (:1281-1286)
+    c.evaluation_format = if_out_evaluation_format_ ? 1 : 0;
+    check(sdm_set_colours(map_, &c), "sdm_set_colours");
+  }
 
   bool check(sdm_status s, const char *what) {
     if (s == SDM_OK) return true;
@@ -400,6 +469,22 @@ class SemanticDSPMap {
   }
   void ensureMap() {
     if (map_) return;
+#ifdef SDM_HAVE_REFERENCE_TRACKING_TYPES
+    // the reference's label globals (utils/data_base.h:108-232), as ObjectInfoHandler::readObjectInfo left them
+    // (utils/object_info_handler.h:76-87, called at src/mapping.cpp:89-93 before the first frame)
+    if (!tables_from_reference_) {
+      label_id_.clear();
+      static_instance_to_label_.clear();
+      label_color_.clear();
+      for (const auto &kv : g_label_id_map_default) label_id_[kv.first] = kv.second;
+      for (const auto &kv : g_instance_id_to_label_map_default)
+        if (label_id_.count(kv.second)) static_instance_to_label_[kv.first] = label_id_[kv.second];
+      for (const auto &kv : g_label_color_map_default) label_color_[kv.first] = kv.second;
+      max_movable_track_ = g_max_movable_object_instance_id;
+      rebuildLabelToInstance();
+      tables_from_reference_ = true;
+    }
+#endif
     sdm_config c{};
     c.x_n = preset_.x_n;
     c.y_n = preset_.y_n;
@@ -423,6 +508,7 @@ class SemanticDSPMap {
     // prediction_stddev_ = 0.05 table of 1,000,000 draws (semantic_dsp_map.h:40,66; basic_algorithms.h:394-402)
     check(sdm_generate_noise_table(map_, 20250217ull, 1000000, 0.05f), "sdm_generate_noise_table");
     pushParams();
+    pushColours();
     depth_.resize((size_t)c.width * c.height);
     static_mask_.resize((size_t)c.width * c.height);
   }
@@ -516,85 +602,23 @@ class SemanticDSPMap {
     return 0;
   }
 
-  /// getOccupancyResult output side (semantic_dsp_map.h:1258-1376): positions come compacted from the GPU,
-  /// colouring follows the reference's rules.
-  void emit(pcl::PointCloud<pcl::PointXYZRGB>::Ptr &out, bool free_space, const float cam_pos[3]) {
+  /// getOccupancyResult output side (semantic_dsp_map.h:1258-1376): compacted, coloured and packed as pcl::PointXYZRGB
+  /// on the device; appended to the cloud as they come (the reference appends too).
+  void emit(pcl::PointCloud<pcl::PointXYZRGB>::Ptr &out, bool free_space) {
+    static_assert(sizeof(pcl::PointXYZRGB) == sizeof(sdm_point_xyzrgb), "sdm_point_xyzrgb is pcl::PointXYZRGB's layout");
     size_t n = 0;
     const size_t cap = (size_t)1 << (preset_.x_n + preset_.y_n + preset_.z_n);
     if (points_.size() < 1024) points_.resize(1024);
-    auto get = free_space ? sdm_get_freespace : sdm_get_occupied;
-    const int32_t flags = (visualize_with_zero_center_ ? SDM_POINTS_ZERO_CENTER : 0) | (free_space ? 0 : SDM_POINTS_MARK_FOV);
-    if (!check(get(map_, points_.data(), points_.size(), &n, flags), "sdm_get_occupied")) return;
+    auto get = free_space ? sdm_get_freespace_rgb : sdm_get_occupied_rgb;
+    const int32_t flags = visualize_with_zero_center_ ? SDM_POINTS_ZERO_CENTER : 0;
+    if (!check(get(map_, points_.data(), points_.size(), &n, flags), "sdm_get_occupied_rgb")) return;
     if (n > points_.size()) {
       points_.resize(std::min(n, cap));
-      if (!check(get(map_, points_.data(), points_.size(), &n, flags), "sdm_get_occupied")) return;
+      if (!check(get(map_, points_.data(), points_.size(), &n, flags), "sdm_get_occupied_rgb")) return;
     }
+    n = std::min(n, points_.size());
     const size_t first_new = out->points.size();
-    const int background = label_id_["Background"];
-    for (size_t k = 0; k < n && k < points_.size(); ++k) {
-      const sdm_point &v = points_[k];
-      pcl::PointXYZRGB pt;
-      pt.x = v.x;
-      pt.y = v.y;
-      pt.z = v.z;
-      if (free_space) {  // :1371-1373
-        pt.r = 0;
-        pt.g = 255;
-        pt.b = 0;
-        out->points.push_back(pt);
-        continue;
-      }
-      const int occ = v.occ & ~SDM_OCC_OUT_OF_FOV;
-      if (occ == 1) {
-        if (v.label == background) {  // :1277-1294
-          const int ci = std::min(std::max(static_cast<int>((-pt.z + 2.f) * 51.2f), 0), 255);
-          pt.r = (uint8_t)color_map_jet_256_[ci](0);
-          pt.g = (uint8_t)color_map_jet_256_[ci](1);
-          pt.b = (uint8_t)color_map_jet_256_[ci](2);
-          if (if_out_evaluation_format_) pt.r = pt.g = pt.b = 0;
-        } else if ((int)v.track > max_movable_track_ || !preset_.consider_instance) {  // :1297-1309
-          const cv::Vec3b c = label_color_.count(v.label) ? label_color_[v.label] : cv::Vec3b(0, 0, 0);
-          pt.r = c[2];
-          pt.g = c[1];
-          pt.b = c[0];
-        } else if (if_out_evaluation_format_) {  // :1311-1316
-          pt.r = v.label;
-          pt.g = (uint8_t)(v.track >> 8);
-          pt.b = (uint8_t)(v.track & 0xFF);
-        } else {  // :1317-1319 (the reference indexes a 256-entry table with the 16-bit track id; clamped here)
-          pt.r = 160;
-          pt.g = (uint8_t)color_map_int_256_[v.track & 0xFF];
-          pt.b = (uint8_t)color_map_int_256_[v.label];
-        }
-      } else {  // guessed occupied, :1325-1331
-        pt.r = pt.g = pt.b = 255;
-      }
-      (void)cam_pos;
-      out->points.push_back(pt);
-    }
-    if (free_space || if_out_evaluation_format_) return;
-    // :1333-1351: every occupied point goes RGB -> HSV -> RGB through OpenCV's 8-bit conversion (not an identity),
-    // with V x 0.7 for voxels outside the camera frustum.  One n x 1 image instead of two 1 x 1 images per voxel.
-    const int n_new = (int)(out->points.size() - first_new);
-    if (n_new == 0) return;
-    cv::Mat rgb(n_new, 1, CV_8UC3), hsv, rgb2;
-    for (int k = 0; k < n_new; ++k) {
-      const pcl::PointXYZRGB &pt = out->points[first_new + k];
-      rgb.at<cv::Vec3b>(k, 0) = cv::Vec3b(pt.r, pt.g, pt.b);
-    }
-    cv::cvtColor(rgb, hsv, cv::COLOR_RGB2HSV);
-    for (int k = 0; k < n_new; ++k)
-      if (points_[k].occ & SDM_OCC_OUT_OF_FOV) {
-        cv::Vec3b &c = hsv.at<cv::Vec3b>(k, 0);
-        c[2] *= 0.7f;  // :1342
-      }
-    cv::cvtColor(hsv, rgb2, cv::COLOR_HSV2RGB);
-    for (int k = 0; k < n_new; ++k) {
-      pcl::PointXYZRGB &pt = out->points[first_new + k];
-      const cv::Vec3b c = rgb2.at<cv::Vec3b>(k, 0);
-      pt.r = c[0];
-      pt.g = c[1];
-      pt.b = c[2];
-    }
+    out->points.resize(first_new + n);
+    if (n) std::memcpy(static_cast<void *>(&out->points[first_new]), points_.data(), n * sizeof(sdm_point_xyzrgb));
   }
 };

@@ -17,6 +17,9 @@ LABELED_POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("sigma", "<
 OBJECT_MOVE = np.dtype([("track_id", "<i4"), ("T", "<f4", (16,))])
 VOXEL_RESULT = np.dtype([("wsum", "<f4"), ("track", "<u2"), ("label", "u1"), ("occ", "i1")])
 POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("track", "<u2"), ("label", "u1"), ("occ", "i1")])
+# sdm_point_xyzrgb = pcl::PointXYZRGB's 32 bytes
+POINT_XYZRGB = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("one", "<f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"), ("a", "u1"),
+                         ("pad", "<u4", (3,))])
 assert LABELED_POINT.itemsize == 20 and OBJECT_MOVE.itemsize == 68 and VOXEL_RESULT.itemsize == 8 and POINT.itemsize == 16
 
 STATE_FIELDS = [("px", np.float32), ("py", np.float32), ("pz", np.float32), ("w", np.float32),
@@ -65,6 +68,11 @@ class RingState(C.Structure):
     _fields_ = [("global_time_stamp", C.c_uint32), ("moved_steps", C.c_int32 * 3), ("eq_steps", C.c_int32 * 3),
                 ("map_center", C.c_float * 3), ("last_pos", C.c_float * 3),
                 ("birth_cursor", C.c_int32), ("move_cursor", C.c_int32)]
+
+
+class ColourConfig(C.Structure):
+    _fields_ = [("label_bgr", (C.c_uint8 * 3) * 256), ("perm", C.c_uint8 * 256), ("background_label", C.c_int32),
+                ("colour_by_label", C.c_int32), ("jet_axis", C.c_int32), ("evaluation_format", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -130,6 +138,9 @@ def load_library():
         "sdm_synchronize": [vp],
         "sdm_get_voxels": [vp, vp],
         "sdm_get_occupied": [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), i32],
+        "sdm_get_occupied_rgb": [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), i32],
+        "sdm_get_freespace_rgb": [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), i32],
+        "sdm_set_colours": [vp, vp],
         "sdm_get_freespace": [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), i32],
         "sdm_voxels_device_ptr": [vp, C.POINTER(vp)],
         "sdm_object_particle_count": [vp, i32, C.POINTER(i64)],
@@ -388,6 +399,26 @@ class SdmMap:
         fn = self.L.sdm_get_freespace if free else self.L.sdm_get_occupied
         _check(self.L, fn(self.h, _ptr(out), cap, C.byref(n), (1 if zero_center else 0) | (2 if mark_fov else 0)),
                "sdm_get_occupied")
+        return out[:min(n.value, cap)], n.value
+
+    def set_colours(self, label_bgr, perm, background_label=0, colour_by_label=False, jet_axis=0, evaluation_format=False):
+        """label_bgr: (256, 3) uint8 BGR per label id; perm: 256 uint8 (color_map_int_256_)."""
+        c = ColourConfig()
+        lb = np.ascontiguousarray(label_bgr, np.uint8).reshape(256, 3)
+        pm = np.ascontiguousarray(perm, np.uint8).reshape(256)
+        C.memmove(c.label_bgr, lb.ctypes.data, 768)
+        C.memmove(c.perm, pm.ctypes.data, 256)
+        c.background_label, c.colour_by_label = int(background_label), 1 if colour_by_label else 0
+        c.jet_axis, c.evaluation_format = int(jet_axis), 1 if evaluation_format else 0
+        _check(self.L, self.L.sdm_set_colours(self.h, C.byref(c)), "sdm_set_colours")
+
+    def occupied_rgb(self, cap=None, zero_center=False, free=False):
+        """getOccupancyResult's cloud coloured and packed on the device: POINT_XYZRGB records."""
+        cap = cap or self.v_count
+        out = np.empty(cap, POINT_XYZRGB)
+        n = C.c_size_t()
+        fn = self.L.sdm_get_freespace_rgb if free else self.L.sdm_get_occupied_rgb
+        _check(self.L, fn(self.h, _ptr(out), cap, C.byref(n), 1 if zero_center else 0), "sdm_get_occupied_rgb")
         return out[:min(n.value, cap)], n.value
 
     def object_particle_count(self, track):

@@ -2052,6 +2052,116 @@ __global__ __launch_bounds__(TPB) void k_emit_points(Dims d, Frame f, State st, 
   out[o] = pt;
 }
 
+// ---- N2: colour rules + OpenCV's 8-bit RGB <-> HSV (published algorithm of OpenCV 4.x imgproc color_hsv: RGB2HSV_b with hsv_shift 12,
+// HSV2RGB_b in float; the test-side restatement performs the same operations in the same order)
+// RGB2HSV_b, hrange 180, hsv_shift 12
+__device__ __forceinline__ void rgb2hsv_8u(const ColourTables &ct, int r, int g, int b, int &h, int &s, int &v) {
+  v = max(max(b, g), r);
+  const int vmin = min(min(b, g), r);
+  const int diff = v - vmin;
+  s = (diff * ct.sdiv[v] + (1 << 11)) >> 12;
+  int hh = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+  hh = (hh * ct.hdiv180[diff] + (1 << 11)) >> 12;  // arithmetic shift
+  hh += hh < 0 ? 180 : 0;
+  h = min(max(hh, 0), 255);
+}
+// HSV2RGB_b -> HSV2RGB_native, float32
+__device__ __forceinline__ void hsv2rgb_8u(int h, int s, int v, int &r, int &g, int &b) {
+  const float sf = (float)s * (1.f / 255.f), vf = (float)v * (1.f / 255.f);
+  float bf, gf, rf;
+  if (s == 0) {
+    bf = gf = rf = vf;
+  } else {
+    float hh = fmodf((float)h * (6.f / 180.f), 6.f);
+    int sector = (int)floorf(hh);
+    hh -= (float)sector;
+    if ((unsigned)sector >= 6u) {
+      sector = 0;
+      hh = 0.f;
+    }
+    const float t0 = vf, t1 = vf * (1.f - sf), t2 = vf * (1.f - sf * hh), t3 = vf * (1.f - sf * (1.f - hh));
+    const float tab[4] = {t0, t1, t2, t3};
+    const int sec[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    bf = tab[sec[sector][0]];
+    gf = tab[sec[sector][1]];
+    rf = tab[sec[sector][2]];
+  }
+  b = min(max(__float2int_rn(bf * 255.f), 0), 255);  // saturate_cast<uchar>: round half to even
+  g = min(max(__float2int_rn(gf * 255.f), 0), 255);
+  r = min(max(__float2int_rn(rf * 255.f), 0), 255);
+}
+
+__global__ __launch_bounds__(TPB) void k_emit_points_rgb(Dims d, Frame f, State st, const ColourTables *__restrict__ ctp,
+                                                         const uint32_t *flags, const uint32_t *offs, sdm_point_xyzrgb *out,
+                                                         uint32_t cap, float sub_x, float sub_y, float sub_z, int want_free) {
+  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lv >= d.v_count || !flags[lv]) return;
+  uint32_t o = offs[lv];
+  if (o >= cap) return;
+  const ColourTables &ct = *ctp;
+  uint32_t v = d.v_begin + lv, rx, ry, rz;
+  voxel_to_ring(d, v, rx, ry, rz);
+  // voxelIdxToGlobalFramePos: ring -> map index -> min corner (operations.h:940-983, 1022-1033)
+  uint32_t mx = axis_correct((int)rx - f.eq[0], d.NX);
+  uint32_t my = axis_correct((int)ry - f.eq[1], d.NY);
+  uint32_t mz = axis_correct((int)rz - f.eq[2], d.NZ);
+  float x = (float)mx * d.voxel_size + d.pmin[0];
+  float y = (float)my * d.voxel_size + d.pmin[1];
+  float z = (float)mz * d.voxel_size + d.pmin[2];
+  x += f.center[0];
+  y += f.center[1];
+  z += f.center[2];
+  const sdm_voxel_result res = st.res[lv];
+  sdm_point_xyzrgb pt;
+  pt.x = x - sub_x;
+  pt.y = y - sub_y;
+  pt.z = z - sub_z;
+  pt.one = 1.f;
+  pt.a = 255;
+  pt.pad[0] = pt.pad[1] = pt.pad[2] = 0;
+  int r, g, b;
+  if (want_free) {  // semantic_dsp_map.h:1371-1373
+    r = 0;
+    g = 255;
+    b = 0;
+  } else {
+    const int label = res.label, track = res.track;
+    if (res.occ != 1) {  // guessed occupied (:1325-1331)
+      r = g = b = 255;
+    } else if (label == ct.cfg.background_label) {  // :1277-1294
+      const float src = ct.cfg.jet_axis == 0 ? -pt.z + 2.f : pt.y + 2.f;
+      const int ci = min(max((int)(src * 51.2f), 0), 255);
+      if (ci < 64) { r = 0; g = 0; b = ci * 4; }
+      else if (ci < 128) { r = 0; g = (ci - 64) * 4; b = 255; }
+      else if (ci < 192) { r = (ci - 128) * 4; g = 255; b = 255 - (ci - 128) * 4; }
+      else { r = 255; g = 255 - (ci - 192) * 4; b = 0; }
+      if (ct.cfg.evaluation_format) r = g = b = 0;
+    } else if (track > d.max_movable || ct.cfg.colour_by_label) {  // :1297-1309
+      b = ct.cfg.label_bgr[label][0];
+      g = ct.cfg.label_bgr[label][1];
+      r = ct.cfg.label_bgr[label][2];
+    } else if (ct.cfg.evaluation_format) {  // :1311-1316
+      r = label;
+      g = track >> 8;
+      b = track & 0xFF;
+    } else {  // :1317-1319 (PINNED: the reference indexes its 256-entry table with the 16-bit track id)
+      r = 160;
+      g = ct.cfg.perm[track & 0xFF];
+      b = ct.cfg.perm[label];
+    }
+    if (!ct.cfg.evaluation_format) {  // :1333-1351
+      int h, s, vv;
+      rgb2hsv_8u(ct, r, g, b, h, s, vv);
+      if (!point_in_frustum(d, f, x, y, z)) vv = (int)((float)vv * 0.7f);  // uchar *= 0.7f
+      hsv2rgb_8u(h, s, vv, r, g, b);
+    }
+  }
+  pt.r = (uint8_t)r;
+  pt.g = (uint8_t)g;
+  pt.b = (uint8_t)b;
+  out[o] = pt;
+}
+
 inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
 
 }  // namespace
@@ -2301,6 +2411,15 @@ void launch_pack_pos4(float4 *pos4, const float *px, const float *py, const floa
 }
 void launch_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_unpack_pos4, dim3(blocks_for(n)), dim3(TPB), 0, s, pos4, px, py, pz, forget, n);
+}
+void launch_emit_points_rgb(const Dims &d, const Frame &f, const State &st, const ColourTables *ct, uint32_t *flags, uint32_t *offs,
+                            uint32_t *scan_scratch, sdm_point_xyzrgb *out, uint32_t cap, int want_free, const float sub[3],
+                            hipStream_t s) {
+  hipLaunchKernelGGL(k_flag_results, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st, flags, want_free);
+  hipMemsetAsync(flags + d.v_count, 0, 4, s);
+  exclusive_scan_u32(flags, offs, (size_t)d.v_count + 1, scan_scratch, s);
+  hipLaunchKernelGGL(k_emit_points_rgb, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, f, st, ct, flags, offs, out, cap, sub[0], sub[1],
+                     sub[2], want_free);
 }
 void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t *flags, uint32_t *offs,
                         uint32_t *scan_scratch, sdm_point *out, uint32_t cap, int want_free, const float sub[3],

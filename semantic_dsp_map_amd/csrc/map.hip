@@ -148,6 +148,10 @@ struct sdm_map {
   uint32_t *d_flags = nullptr, *d_offs = nullptr;
   sdm_point *d_points = nullptr;
   size_t points_cap = 0;
+  sdm_point_xyzrgb *d_points_rgb = nullptr;
+  size_t points_rgb_cap = 0;
+  ColourTables *d_colours = nullptr;
+  bool colours_set = false;
   int nb_alloc = 0;
   size_t sort_cap = 0;
   int noise_n = 0;
@@ -644,6 +648,8 @@ sdm_status sdm_destroy(sdm_map *m) {
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
   for (void *p : m->allocs) (void)hipFree(p);
+  if (m->d_points_rgb) (void)hipFree(m->d_points_rgb);
+  if (m->d_colours) (void)hipFree(m->d_colours);
   void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points, m->raw[0].obj_masks, m->raw[1].obj_masks, m->d_src_stage};
   for (void *p : extra)
     if (p) (void)hipFree(p);
@@ -1450,6 +1456,59 @@ sdm_status sdm_get_occupied(sdm_map *m, sdm_point *out, size_t cap, size_t *n_ou
 sdm_status sdm_get_freespace(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t flags) {
   return get_points(m, out, cap, n_out, flags, 1);
 }
+// ---- N2: coloured, packed lists
+sdm_status sdm_set_colours(sdm_map *m, const sdm_colour_config *c) {
+  if (!m || !c) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  ColourTables t;
+  memset(&t, 0, sizeof(t));
+  t.cfg = *c;
+  // RGB2HSV_b's tables (OpenCV imgproc color_hsv: hsv_shift 12): cvRound = round half to even
+  for (int i = 1; i < 256; ++i) {
+    t.sdiv[i] = (int32_t)nearbyint((double)(255 << 12) / (1.0 * i));
+    t.hdiv180[i] = (int32_t)nearbyint((double)(180 << 12) / (6.0 * i));
+  }
+  if (!m->d_colours) HIP_TRY(dev_alloc(&m->d_colours, 1));
+  HIP_TRY(hipMemcpyAsync(m->d_colours, &t, sizeof(t), hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  m->colours_set = true;
+  return SDM_OK;
+}
+
+static sdm_status get_points_rgb(sdm_map *m, sdm_point_xyzrgb *out, size_t cap, size_t *n_out, int flags, int want_free) {
+  if (!m || !n_out || (cap && !out)) return SDM_ERR_INVALID_ARGUMENT;
+  if (!m->colours_set) {
+    set_error("sdm_get_occupied_rgb", __FILE__, __LINE__, "call sdm_set_colours first");
+    return SDM_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(m->device));
+  if (cap > m->points_rgb_cap) {
+    if (m->d_points_rgb) HIP_TRY(hipFree(m->d_points_rgb));
+    m->d_points_rgb = nullptr;
+    HIP_TRY(dev_alloc(&m->d_points_rgb, cap));
+    m->points_rgb_cap = cap;
+  }
+  float sub[3] = {0.f, 0.f, 0.f};
+  if (flags & SDM_POINTS_ZERO_CENTER)
+    for (int a = 0; a < 3; ++a) sub[a] = m->cam_p[a];
+  uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0xffffffffu);
+  launch_emit_points_rgb(m->d, m->f, m->st, m->d_colours, m->d_flags, m->d_offs, m->sc.scan_scratch, m->d_points_rgb, cap32, want_free,
+                         sub, m->stream);
+  uint32_t total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, m->d_offs + m->d.v_count, 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  *n_out = total;
+  size_t ncopy = std::min<size_t>(total, cap);
+  if (ncopy) HIP_TRY(hipMemcpy(out, m->d_points_rgb, ncopy * sizeof(sdm_point_xyzrgb), hipMemcpyDeviceToHost));
+  return SDM_OK;
+}
+sdm_status sdm_get_occupied_rgb(sdm_map *m, sdm_point_xyzrgb *out, size_t cap, size_t *n_out, int32_t flags) {
+  return get_points_rgb(m, out, cap, n_out, flags, 0);
+}
+sdm_status sdm_get_freespace_rgb(sdm_map *m, sdm_point_xyzrgb *out, size_t cap, size_t *n_out, int32_t flags) {
+  return get_points_rgb(m, out, cap, n_out, flags, 1);
+}
+
 sdm_status sdm_voxels_device_ptr(sdm_map *m, const sdm_voxel_result **out) {
   if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
   *out = m->st.res;

@@ -403,13 +403,20 @@ sdm_status update_impl(sdm_objects *h, const sdm_object_observation *obs, int32_
       double time_interval = 0.15;  // default argument of updateObject
       int moved_observation = -1;
       if (matched_kpts) {  // :383-407
-        if (!ob.kpts_previous) return SDM_ERR_INVALID_ARGUMENT;
-        const std::vector<V3> prev = points_of(ob.kpts_previous, ob.n_kpts);
-        std::vector<int> inl;
-        const double mse = fit_rigid_ransac(prev, cur, T, inl, 100, 0.5, true, call_seed(c.seed, gts, id));
-        // `mse > 0.2f`, `ratio < 0.5f`: float literals widened to double; NaN (no inliers) fails no comparison
-        success = !(mse > (double)0.2f || inl.size() < 5 || (double)inl.size() / (double)ob.n_kpts < (double)0.5f);
-        reference_point = inl.empty() ? prev[0] : prev[inl[0]];  // :492-500
+        if (!ob.kpts_previous) {
+          // a tracker entry without usable previous key points (the adapter passes NULL when the two lists differ in
+          // length; the reference would read past the shorter one): this object's key-point method fails, the frame's
+          // other objects are processed as usual - one malformed entry must not drop the whole update
+          success = false;
+          reference_point = cur[0];
+        } else {
+          const std::vector<V3> prev = points_of(ob.kpts_previous, ob.n_kpts);
+          std::vector<int> inl;
+          const double mse = fit_rigid_ransac(prev, cur, T, inl, 100, 0.5, true, call_seed(c.seed, gts, id));
+          // `mse > 0.2f`, `ratio < 0.5f`: float literals widened to double; NaN (no inliers) fails no comparison
+          success = !(mse > (double)0.2f || inl.size() < 5 || (double)inl.size() / (double)ob.n_kpts < (double)0.5f);
+          reference_point = inl.empty() ? prev[0] : prev[inl[0]];  // :492-500
+        }
       } else {  // :408-483, box keypoints; the reference's matrices have exactly 4 columns
         bool out_of_fov = false;
         for (const V3 &p : cur) out_of_fov = point_out_of_fov(c, cam_pos, cam_q, p, 5);  // PINNED: the last one decides (:420-422)

@@ -161,6 +161,14 @@ void launch_rec_unpack(const Dims &d, const State &st, float *w, uint16_t *ts, u
                        hipStream_t s);
 void launch_fill_dense(const Dims &d, const State &st, uint32_t stamp, hipStream_t s);
 void launch_vts_sync(const Dims &d, const State &st, int to_slot0, hipStream_t s);
+// N2: colour tables on the device (sdm_colour_config + the two division tables of OpenCV's 8-bit RGB2HSV)
+struct ColourTables {
+  sdm_colour_config cfg;
+  int32_t sdiv[256], hdiv180[256];
+};
+void launch_emit_points_rgb(const Dims &d, const Frame &f, const State &st, const ColourTables *ct, uint32_t *flags, uint32_t *offs,
+                            uint32_t *scan_scratch, sdm_point_xyzrgb *out, uint32_t cap, int want_free, const float sub[3],
+                            hipStream_t s);
 void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t *flags, uint32_t *offs,
                         uint32_t *scan_scratch, sdm_point *out, uint32_t cap, int want_free, const float sub[3],
                         int mark_fov, hipStream_t s);

@@ -1,6 +1,7 @@
 // Drives include/semantic_dsp_map.h (the reference's class API) the way src/mapping.cpp does: setters, then
 // update(depth, masks, pose, clouds) per frame.  Built against tests/mock_includes (no Eigen/OpenCV/PCL in the image)
 // and linked with libsdm_hip.so.  Exit code 0 = the occupied cloud of a flat wall came back as expected.
+#include <algorithm>
 #include <cstdio>
 
 #include "semantic_dsp_map.h"
@@ -66,6 +67,24 @@ int main(int argc, char **argv) {
       // the object with the unknown label is never tracked, but particles may be born under its id: wiped every frame
       if (removals.size() != 1 || removals[0] != 3) return 4;
     }
+    // The unknown object's mask disappears.  Frame 8 wiped it BEFORE that frame's births, so particles were born under
+    // its id once more: it has to be reported again (the reference's obj_ptc_hash_map still lists it), and then no more.
+    for (int t = 8; t < 10; ++t) {
+      MaskKpts car;
+      car.track_id = 2;
+      car.label = "Car";
+      const double x = -1.0 + 0.5 * t;
+      car.kpts_current = {Eigen::Vector3d(x, 0, 5), Eigen::Vector3d(x + 0.3, 0, 5), Eigen::Vector3d(x, 0.3, 5), Eigen::Vector3d(x, 0, 5.6)};
+      std::vector<MaskKpts> seg{car};
+      std::vector<sdm_object_move> moves;
+      std::vector<int32_t> removals;
+      layer.setGlobalTimeStamp((uint32_t)t + 1);
+      layer.update(seg, Eigen::Vector3d(0, 0, 0), Eigen::Quaterniond(1, 0, 0, 0), 0.1 * t);
+      layer.collect((uint32_t)t + 1, 5, moves, removals);
+      const bool has3 = std::find(removals.begin(), removals.end(), 3) != removals.end();
+      if (t == 8 && !has3) return 6;  // orphaned particles
+      if (t == 9 && has3) return 7;   // reported for ever
+    }
     std::printf("object layer: car moved in %d of 8 frames\n", moved_frames);
     if (moved_frames < 3) return 5;
     std::printf("adapter constructed\n");
@@ -89,11 +108,19 @@ int main(int argc, char **argv) {
     map.update(depth, seg, pos, q, occ, fr, true, 0.1 * t);
     n_occ = occ->size();
     std::printf("frame %d: %zu occupied, %zu free voxels\n", t, occ->size(), fr->size());
-    for (auto &pt : occ->points)
+    for (auto &pt : occ->points) {
       if (pt.z < 2.7f || pt.z > 3.5f) {
         std::printf("occupied voxel away from the wall: z = %f\n", pt.z);
         return 2;
       }
+      // evaluation format, static instance: the label's colour (Building: BGR 140 140 140), coloured on the device
+      if (pt.r != 140 || pt.g != 140 || pt.b != 140 || pt.a != 255) {
+        std::printf("wall voxel with colour %d %d %d\n", pt.r, pt.g, pt.b);
+        return 8;
+      }
+    }
+    for (auto &pt : fr->points)
+      if (pt.r != 0 || pt.g != 255 || pt.b != 0) return 9;
   }
   return n_occ > 50 ? 0 : 1;
 }
