@@ -38,8 +38,16 @@ def test_committed_bench_line_is_self_consistent():
     assert abs(d["value"] - voxels / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3   # Mvoxels/s from the frame time
     r = d["roofline"]
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-2
-    if "layout" in r:   # what the layout really moves: never more than the dense-slot figure, and the PMC traffic is near it
-        assert r["layout"]["bytes_per_launch"] <= r["bytes_per_launch"]
-        if r["traffic"] is not None:
-            assert 0.5 * r["layout"]["bytes_per_launch"] <= r["traffic"] <= 3 * r["layout"]["bytes_per_launch"]
+    # a roofline fraction is bytes moved / time / peak: never above 1, for none of the reported launches
+    assert 0 < r["frac"] <= 1.0
+    for k in ("full_evaluation", "dense_case"):
+        if k in r:
+            assert 0 < r[k]["frac"] <= 1.0
+            assert abs(r[k]["achieved"] - r[k]["bytes_per_launch"] / (r[k]["avg_launch_ms"] * 1e-3) / 1e9) / r[k]["achieved"] < 1e-2
+    if "dense_case" in r:   # the dense map is where the layout's bytes and SURVEY 8(d)'s 80 B/voxel nearly coincide
+        assert r["dense_case"]["bytes_per_launch"] <= 1.2 * r["effective"]["bytes_per_launch"]
+    if r["traffic"] is not None:   # PMC traffic of the in-frame launches is near what the layout says they have to move
+        assert 0.5 * r["bytes_per_launch"] <= r["traffic"] <= 3 * r["bytes_per_launch"]
     assert d["value"] / d["cpu_baseline"]["value"] >= 50    # BASELINE.json: >= 50x the single-thread CPU frame time at C3
+    if "stress" in d and "x_cpu" in d["stress"]:
+        assert d["stress"]["x_cpu"] >= 50

@@ -1,7 +1,12 @@
 #!/usr/bin/env python
-"""profiles/<tag>_sweep_pmc.json from the two counter passes of tools/pmc_sweep.sh (in-frame sweep launches of bench.py;
-only the last 6 launches count: the 6 frames after the timed region, the ones bench.py takes the sweep's launch time,
-tile and voxel counts from)."""
+"""profiles/<tag>_sweep_pmc.json from the two counter passes of tools/pmc_sweep.sh.
+
+Launch order of the bench command: k_occupancy_all x1 (first frame after sdm_load_state), k_occupancy<S> for the other
+warm-up + timed frames, then 6 profiled frames (the ones bench.py takes the in-frame launch time, tile and voxel counts
+from), 6 x-shift frames, then k_occupancy_all x11 on the benchmark map (non-incremental: 1 warm-up + 10 timed) and x11 on
+the dense map.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated there for
+wide coalesced streaming reads, so for the in-frame launch with its scattered record fetches the corrected figure is an
+upper estimate)."""
 import csv
 import json
 import shutil
@@ -9,32 +14,38 @@ import sys
 
 tag = sys.argv[1]
 g = "gpurun_out/"
-last = 6
-res = {}
-for c in ["FETCH_SIZE", "WRITE_SIZE"]:
-    rows = list(csv.DictReader(open(g + "%s_sweep_%s.csv" % (tag, c))))[-last:]
-    v = [float(r["Counter_Value"]) for r in rows]
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
-    res[c] = (sum(v) / len(v), sum(d) / len(d), len(v))
-    shutil.copy(g + "%s_sweep_%s.csv" % (tag, c), "profiles/%s_sweep_pmc_%s.csv" % (tag, c.lower()))
 b = json.loads(open(g + "%s_sweep_bench.json" % tag).read())
 rf = b["roofline"]
-fetch_kib, us_f, n = res["FETCH_SIZE"]
-write_kib, us_w, _ = res["WRITE_SIZE"]
-out = {"kernel": rf["kernel"], "voxels": rf["voxels"], "voxels_evaluated_in_full": rf["layout"]["voxels_evaluated_in_full"],
-       "tiles": rf["layout"]["tiles"], "tiles_looked_into": rf["layout"]["tiles_looked_into"],
-       "state": "in-frame launches of `python bench.py --no-cpu --no-dense --steps 20 --warmup 5` (C3 benchmark map), the last %d launches of the run" % last,
-       "launches_averaged": n,
-       "FETCH_SIZE_KiB_per_launch": round(fetch_kib, 1), "WRITE_SIZE_KiB_per_launch": round(write_kib, 1),
-       "fetch_correction": "x2 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B; calibrated there for 16 B/lane "
-                           "streaming reads - this kernel streams 16 B/lane stamps and 8 B/lane flags and gathers 128-B records, so "
-                           "the corrected figure is an upper estimate)",
-       "fetch_bytes_per_launch": int(fetch_kib * 1024 * 2), "write_bytes_per_launch": int(write_kib * 1024),
-       "traffic_bytes_per_launch": int(fetch_kib * 1024 * 2 + write_kib * 1024),
-       "layout_bytes_per_launch": rf["layout"]["bytes_per_launch"], "dense_slot_bytes_per_launch": rf["bytes_per_launch"],
-       "avg_kernel_us_under_pmc": round((us_f + us_w) / 2, 1),
-       "commands": ["rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -- python bench.py --no-cpu --no-dense --steps 20 --warmup 5",
-                    "rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -- python bench.py --no-cpu --no-dense --steps 20 --warmup 5"]}
+res = {}
+for c in ["FETCH_SIZE", "WRITE_SIZE"]:
+    rows = list(csv.DictReader(open(g + "%s_sweep_%s.csv" % (tag, c))))
+    inc = [r for r in rows if "k_occupancy_all" not in r["Kernel_Name"]]
+    allr = [r for r in rows if "k_occupancy_all" in r["Kernel_Name"]]
+    sets = {"in_frame": inc[-12:-6], "x_shift_frames": inc[-6:], "full_evaluation": allr[2:12], "dense_case": allr[13:23]}
+    for name, rs in sets.items():
+        v = [float(r["Counter_Value"]) for r in rs]
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rs]
+        res.setdefault(name, {})[c] = (sum(v) / len(v), sum(d) / len(d), len(v))
+    shutil.copy(g + "%s_sweep_%s.csv" % (tag, c), "profiles/%s_sweep_pmc_%s.csv" % (tag, c.lower()))
+out = {"kernel": rf["kernel"], "voxels": rf["voxels"], "voxels_evaluated_in_full": rf["voxels_evaluated_in_full"], "tiles": rf["tiles"],
+       "tiles_looked_into": rf["tiles_looked_into"],
+       "fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section)", "cases": {},
+       "commands": ["SDM_GRAPH=0 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -- python bench.py --no-cpu --no-strong --steps 20 --warmup 5",
+                    "SDM_GRAPH=0 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -- python bench.py --no-cpu --no-strong --steps 20 --warmup 5"]}
+layout = {"in_frame": rf["bytes_per_launch"], "full_evaluation": rf.get("full_evaluation", {}).get("bytes_per_launch"),
+          "dense_case": rf.get("dense_case", {}).get("bytes_per_launch"), "x_shift_frames": None}
+for name, r in res.items():
+    f_kib, us_f, n = r["FETCH_SIZE"]
+    w_kib, us_w, _ = r["WRITE_SIZE"]
+    traffic = int(f_kib * 1024 * 2 + w_kib * 1024)
+    us = (us_f + us_w) / 2
+    out["cases"][name] = {"launches_averaged": n, "FETCH_SIZE_KiB_per_launch": round(f_kib, 1), "WRITE_SIZE_KiB_per_launch": round(w_kib, 1),
+                          "fetch_bytes_per_launch": int(f_kib * 1024 * 2), "write_bytes_per_launch": int(w_kib * 1024),
+                          "traffic_bytes_per_launch": traffic, "avg_kernel_us_under_pmc": round(us, 1),
+                          "traffic_GBps": round(traffic / us / 1e3, 1), "traffic_frac_of_8TBps": round(traffic / us / 1e3 / 8000.0, 4),
+                          "layout_bytes_per_launch": layout[name],
+                          "traffic_over_layout": round(traffic / layout[name], 3) if layout[name] else None}
+out["traffic_bytes_per_launch"] = out["cases"]["in_frame"]["traffic_bytes_per_launch"]
 json.dump(out, open("profiles/%s_sweep_pmc.json" % tag, "w"), indent=1)
-print(json.dumps({k: out[k] for k in ["voxels_evaluated_in_full", "traffic_bytes_per_launch", "layout_bytes_per_launch",
-                                      "avg_kernel_us_under_pmc"]}))
+print(json.dumps({k: (v["traffic_bytes_per_launch"], v["layout_bytes_per_launch"], v["avg_kernel_us_under_pmc"], v["traffic_frac_of_8TBps"])
+                  for k, v in out["cases"].items()}))
