@@ -146,6 +146,7 @@ struct sdm_map {
   size_t src_stage_bytes = 0;
   unsigned long long *d_u64 = nullptr;
   uint32_t *d_flags = nullptr, *d_offs = nullptr;
+  uint32_t *scan_scratch_e = nullptr;
   sdm_point *d_points = nullptr;
   size_t points_cap = 0;
   sdm_point_xyzrgb *d_points_rgb = nullptr;
@@ -236,6 +237,7 @@ sdm_status ensure_birth_buffers(sdm_map *m) {
   HIP_TRY(re(&m->sc.bval_b, need));
   HIP_TRY(re(&m->sc.bpos, hw * nb));
   HIP_TRY(re(&m->sc.sort_scratch, sort_scratch_elems(need)));
+  HIP_TRY(hipMemset(m->sc.sort_scratch, 0, sort_scratch_elems(need) * 4));  // the one-launch scan's words start at zero
   m->nb_alloc = nb;
   m->sort_cap = need;
   return SDM_OK;
@@ -600,10 +602,16 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.mv_copy, sc.cap_move);
   A(sc.track_to_obj, 65536);
   HIP_TRY(hipMemsetAsync(sc.track_to_obj, 0xFF, 65536, m->stream));
-  size_t scan_need = std::max({scan_scratch_elems(hw + 1), scan_scratch_elems(mv_cnt_n), scan_scratch_elems((size_t)d.v_count + 1)});
+  // one scratch buffer per scan call site: the one-launch scan keeps its (self-clearing) words there, which start at zero
+  size_t scan_need = std::max(scan_scratch_elems(hw + 1), scan_scratch_elems(mv_cnt_n));
   A(sc.scan_scratch, scan_need + 16);
   A(sc.scan_scratch_b, scan_scratch_elems(hw + 1) + 16);
   A(sc.scan_scratch_m, scan_scratch_elems(move_count_elems()) + 16);
+  A(m->scan_scratch_e, scan_scratch_elems((size_t)d.v_count + 1) + 16);  // compaction of the result lists (getters)
+  HIP_TRY(hipMemsetAsync(sc.scan_scratch, 0, (scan_need + 16) * 4, m->stream));
+  HIP_TRY(hipMemsetAsync(sc.scan_scratch_b, 0, (scan_scratch_elems(hw + 1) + 16) * 4, m->stream));
+  HIP_TRY(hipMemsetAsync(sc.scan_scratch_m, 0, (scan_scratch_elems(move_count_elems()) + 16) * 4, m->stream));
+  HIP_TRY(hipMemsetAsync(m->scan_scratch_e, 0, (scan_scratch_elems((size_t)d.v_count + 1) + 16) * 4, m->stream));
   A(sc.mv_head, d.v_count);
   HIP_TRY(hipMemset(sc.mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t)));  // MV_NIL; the replay leaves it that way
   A(sc.mv_next, sc.cap_move);
@@ -858,9 +866,11 @@ sdm_status frame_enqueue_start(sdm_map *m) {
 
   // P2 (first part): collect the moving objects' particles (semantic_dsp_map.h:588-693); kernels of a frame without
   // moving objects return at once
+  // (launch by launch the host knows that a frame has no moving objects / removals and skips those launches; inside a
+  // graph they are always there and return at once)
   if (m->capturing) {
     launch_moves_count(d, m->st, m->sc, m->d_counts_local, s);
-  } else {
+  } else if (m->n_moves > 0) {
     HIP_TRY(hipStreamWaitEvent(m->s_moves, m->ev_fa, 0));
     launch_moves_count(d, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves);
     HIP_TRY(hipEventRecord(m->ev_counts, m->s_moves));
@@ -880,7 +890,7 @@ sdm_status frame_enqueue_start(sdm_map *m) {
     m->birth_which = launch_birth_prepare(d, m->flt, m->bo, m->st, m->sc, m->s_birth);
     HIP_TRY(hipEventRecord(m->capturing ? m->cap_birth : m->ev_birth, m->s_birth));
   }
-  if (!m->capturing) HIP_TRY(hipStreamWaitEvent(s, m->ev_counts, 0));  // join: the main stream picks the counts up
+  if (!m->capturing && m->n_moves > 0) HIP_TRY(hipStreamWaitEvent(s, m->ev_counts, 0));  // join: the main stream picks the counts up
   m->state_event_valid = false;  // set again when this frame's births are done
   return SDM_OK;
 }
@@ -936,7 +946,7 @@ sdm_status sdm_frame_moves(sdm_map *m) {
     w = 1;
     r = 0;
   }
-  launch_moves_transform(m->d, m->flt, m->st, m->sc, counts_all, w, r, m->stream);
+  if (m->capturing || m->n_moves > 0) launch_moves_transform(m->d, m->flt, m->st, m->sc, counts_all, w, r, m->stream);
   return SDM_OK;
 }
 
@@ -948,12 +958,13 @@ sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev) {
   hipStream_t s = m->stream;
   const Dims &d = m->d;
   // P2 (second part): re-insert the moved copies in the reference's order (operations.h:351-361)
-  launch_moves_finish(d, m->flt, m->st, m->sc, m->counts_all_user ? m->cfg.shard_count : 1, m->cfg.shard_rank, s);
+  if (m->capturing || m->n_moves > 0)
+    launch_moves_finish(d, m->flt, m->st, m->sc, m->counts_all_user ? m->cfg.shard_count : 1, m->cfg.shard_rank, s);
   stage_mark(m, 2);
   if (stage_done(stop_after, 2)) return SDM_OK;
 
   // P3: removals (semantic_dsp_map.h:702-736)
-  launch_remove(d, m->st, m->sc, s);
+  if (m->capturing || m->n_remove > 0) launch_remove(d, m->st, m->sc, s);
   stage_mark(m, 3);
   if (stage_done(stop_after, 3)) return SDM_OK;
 
@@ -1440,7 +1451,7 @@ static sdm_status get_points(sdm_map *m, sdm_point *out, size_t cap, size_t *n_o
   if (flags & SDM_POINTS_ZERO_CENTER)
     for (int a = 0; a < 3; ++a) sub[a] = m->cam_p[a];
   uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0xffffffffu);
-  launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->sc.scan_scratch, m->d_points, cap32, want_free, sub,
+  launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->scan_scratch_e, m->d_points, cap32, want_free, sub,
                      (flags & SDM_POINTS_MARK_FOV) ? 1 : 0, m->stream);
   uint32_t total = 0;
   HIP_TRY(hipMemcpyAsync(&total, m->d_offs + m->d.v_count, 4, hipMemcpyDeviceToHost, m->stream));
@@ -1492,7 +1503,7 @@ static sdm_status get_points_rgb(sdm_map *m, sdm_point_xyzrgb *out, size_t cap, 
   if (flags & SDM_POINTS_ZERO_CENTER)
     for (int a = 0; a < 3; ++a) sub[a] = m->cam_p[a];
   uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0xffffffffu);
-  launch_emit_points_rgb(m->d, m->f, m->st, m->d_colours, m->d_flags, m->d_offs, m->sc.scan_scratch, m->d_points_rgb, cap32, want_free,
+  launch_emit_points_rgb(m->d, m->f, m->st, m->d_colours, m->d_flags, m->d_offs, m->scan_scratch_e, m->d_points_rgb, cap32, want_free,
                          sub, m->stream);
   uint32_t total = 0;
   HIP_TRY(hipMemcpyAsync(&total, m->d_offs + m->d.v_count, 4, hipMemcpyDeviceToHost, m->stream));
@@ -1573,7 +1584,7 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
     size_t nocc = 0;
     // occupied voxel count from the result array
     const float zero3[3] = {0.f, 0.f, 0.f};
-    launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->sc.scan_scratch, m->d_points, 0, 0, zero3, 0, m->stream);
+    launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->scan_scratch_e, m->d_points, 0, 0, zero3, 0, m->stream);
     uint32_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, m->d_offs + m->d.v_count, 4, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1850,6 +1861,7 @@ sdm_status sdm_test_scan(const uint32_t *in, uint32_t *out, int64_t n) {
   HIP_TRY(dev_alloc(&din, (size_t)n));
   HIP_TRY(dev_alloc(&dout, (size_t)n));
   HIP_TRY(dev_alloc(&scr, scan_scratch_elems((size_t)n) + 16));
+  HIP_TRY(hipMemset(scr, 0, (scan_scratch_elems((size_t)n) + 16) * 4));
   HIP_TRY(hipMemcpy(din, in, (size_t)n * 4, hipMemcpyHostToDevice));
   exclusive_scan_u32(din, dout, (size_t)n, scr, nullptr);
   HIP_TRY(hipDeviceSynchronize());
@@ -1869,6 +1881,7 @@ sdm_status sdm_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in,
   HIP_TRY(dev_alloc(&kb, (size_t)n));
   HIP_TRY(dev_alloc(&vb, (size_t)n));
   HIP_TRY(dev_alloc(&scr, sort_scratch_elems((size_t)n) + 16));
+  HIP_TRY(hipMemset(scr, 0, (sort_scratch_elems((size_t)n) + 16) * 4));
   HIP_TRY(hipMemcpy(ka, keys_in, (size_t)n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(va, vals_in, (size_t)n * 4, hipMemcpyHostToDevice));
   int which = radix_sort_pairs(ka, va, kb, vb, (size_t)n, nbits, scr, nullptr);

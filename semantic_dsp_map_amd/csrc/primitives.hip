@@ -91,6 +91,70 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const uint32_t *__res
   }
 }
 
+// One-launch scan for the sizes a frame needs (a few hundred tiles at most): every tile publishes its total as one
+// 8-byte word {flag, total} (one agent-scope atomic store: flag and value cannot be seen apart), then wave 0 of the tile
+// reads the words of ALL its predecessors, 64 at a time, waiting for each to appear, and adds them up - no chain from tile
+// to tile, so a tile's latency is its own reduction plus one round trip.  Tile ids are handed out by a ticket counter in
+// start order: a tile only ever waits for tiles that started before it.  The last tile to finish clears the words and
+// the counters for the next scan on this scratch buffer.  Integer adds: the result does not depend on the order.
+constexpr int SCAN_ONEPASS_MAX_TILES = 512;
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_onepass(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n,
+                                                             const uint32_t *__restrict__ n_dev,
+                                                             unsigned long long *__restrict__ desc, uint32_t *__restrict__ counters) {
+  __shared__ uint32_t s_tile, s_prefix, s_last;
+  if (n_dev) n = *n_dev < n ? (size_t)*n_dev : n;
+  if (threadIdx.x == 0) s_tile = atomicAdd(&counters[0], 1u);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const size_t base = (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    const size_t k = base + i;
+    v[i] = k < n ? in[k] : 0u;
+    s += v[i];
+  }
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan(s, &total);
+  if (threadIdx.x == 0) __hip_atomic_store(&desc[tile], (1ull << 32) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < 64) {
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < tile; b += 64) {
+      const uint32_t idx = b + threadIdx.x;
+      if (idx < tile) {
+        unsigned long long d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((d >> 32) == 0ull) {
+          __builtin_amdgcn_s_sleep(1);
+          d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        run += (uint32_t)d;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) run += __shfl_down(run, off, 64);
+    if (threadIdx.x == 0) s_prefix = run;
+  }
+  __syncthreads();
+  ex += s_prefix;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    const size_t k = base + i;
+    if (k < n) out[k] = ex;
+    ex += v[i];
+  }
+  // the last tile through clears the scratch for the next scan (every tile has finished reading by then)
+  if (threadIdx.x == 0) s_last = atomicAdd(&counters[1], 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (s_last) {
+    for (uint32_t t = threadIdx.x; t < gridDim.x; t += SCAN_THREADS) __hip_atomic_store(&desc[t], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&counters[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&counters[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- radix sort
 constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 8;
@@ -188,19 +252,37 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint32_t *__restr
 
 }  // namespace
 
-size_t scan_scratch_elems(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
+// the scratch holds either the tile totals of the two-launch scan or, for at most SCAN_ONEPASS_MAX_TILES tiles, the
+// 8-byte words + two counters of the one-launch scan, which must be ZERO before the first use (they clean up after
+// themselves)
+size_t scan_scratch_elems(size_t n) {
+  const size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  return tiles <= (size_t)SCAN_ONEPASS_MAX_TILES ? 2 * tiles + 8 : tiles + 1;
+}
 
 void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch, hipStream_t s, const uint32_t *n_dev) {
   if (n == 0) return;
   size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (tiles <= (size_t)SCAN_ONEPASS_MAX_TILES) {
+    // two counters first, the words behind them (8-byte aligned): the layout does not depend on n, so scans of different
+    // sizes may share a scratch buffer - each leaves the part it used zeroed
+    uint32_t *counters = scratch;
+    unsigned long long *desc = reinterpret_cast<unsigned long long *>(scratch + 2);
+    hipLaunchKernelGGL(scan_onepass, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, out, n, n_dev, desc, counters);
+    return;
+  }
   hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, scratch, n, n_dev);
   hipLaunchKernelGGL(scan_tiles, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, out, scratch, n, n_dev);
 }
 
+// sort scratch: [one-launch scan region, fixed size | digit histogram | tile totals of a two-launch scan, if the
+// histogram is that long].  The scan region sits at a fixed place so that it stays zero whatever n is sorted next.
+constexpr size_t RS_SCAN_REGION = 2 * (size_t)SCAN_ONEPASS_MAX_TILES + 8;
 size_t sort_scratch_elems(size_t n) {
   size_t tiles = (n + RS_TILE - 1) / RS_TILE;
   size_t hist = (size_t)RS_RADIX * tiles;
-  return hist + scan_scratch_elems(hist);
+  size_t scan_tiles = (hist + SCAN_TILE - 1) / SCAN_TILE;
+  return RS_SCAN_REGION + hist + (scan_tiles > (size_t)SCAN_ONEPASS_MAX_TILES ? scan_tiles + 1 : 0);
 }
 
 int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, size_t n, int nbits,
@@ -208,8 +290,9 @@ int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint3
   if (n == 0) return 0;
   size_t tiles = (n + RS_TILE - 1) / RS_TILE;
   size_t hist_n = (size_t)RS_RADIX * tiles;
-  uint32_t *hist = scratch;
-  uint32_t *scan_scratch = scratch + hist_n;
+  uint32_t *hist = scratch + RS_SCAN_REGION;
+  const size_t scan_tiles = (hist_n + SCAN_TILE - 1) / SCAN_TILE;
+  uint32_t *scan_scratch = scan_tiles > (size_t)SCAN_ONEPASS_MAX_TILES ? hist + hist_n : scratch;
   int which = 0;
   for (int shift = 0; shift < nbits; shift += RS_BITS) {
     uint32_t *kin = which ? keys_b : keys_a, *vin = which ? vals_b : vals_a;
