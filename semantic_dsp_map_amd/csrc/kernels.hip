@@ -1389,7 +1389,16 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
   const uint32_t n = sc.cnt->shard[shard].heavy;
   const float *__restrict__ pdf = st.pdf;
   const sdm_labeled_point *__restrict__ cloud_img = sc.fa->cloud;
-  for (uint32_t q0 = blockIdx.x * A7_ITEMS; q0 < n; q0 += gridDim.x * A7_ITEMS) {
+  // batches of 16 listed pixels are handed out by a ticket counter (per shard): window sizes are very uneven, a fixed
+  // assignment leaves the kernel waiting for the workgroup that drew the long batches.  Which workgroup computes a pixel
+  // does not change its value.
+  __shared__ uint32_t s_q0;
+  for (;;) {
+    __syncthreads();
+    if (lane == 0) s_q0 = atomicAdd(&sc.cnt->shard[shard].heavy_ticket, (uint32_t)A7_ITEMS);
+    __syncthreads();
+    const uint32_t q0 = s_q0;
+    if (q0 >= n) break;
     const uint32_t q = q0 + it;
     int p = 0;
     uint32_t s = 0, e = 0;

@@ -94,7 +94,8 @@ struct Counters {
     uint32_t resample;  // voxels resampled
     uint32_t sweep;     // voxels the occupancy sweep evaluated in full (record fetched) in its last launch
     uint32_t sweep_tiles;  // tiles that sweep looked into
-    uint32_t pad[25];
+    uint32_t heavy_ticket; // weight-update pass 1: next batch of this shard's heavy-pixel list to hand out
+    uint32_t pad[24];
   };
   ShardLine shard[64];
   // Written by the frustum chain, which may run ahead of the frame's k_frame_begin (it starts when the previous

@@ -233,3 +233,29 @@ def test_generic_flood_fallback_matches_oracle():
         assert not rep, "\n".join(rep)
         assert o.stats()["n_frustum_voxels"] == g.stats()["n_frustum_voxels"]
     g.close()
+
+
+@pytest.mark.parametrize("cfg_name,params_name,n_frames,kw", [
+    ("T1", "zed2", 8, dict(n_dynamic=2)),
+    ("C2", "zed2", 4, dict(n_static=24, n_dynamic=3)),
+])
+def test_hip_path_against_the_literal_reference_order(cfg_name, params_name, n_frames, kw):
+    """north_star's bar, against the oracle in the reference's LITERAL summation order (bin_order = 0: one running ck sum
+    per pixel in BFS push order, semantic_dsp_map.h:1029, operations.h:1405-1407) instead of the canonical order the
+    other parity tests use: identical voxel indices / labels / status / time stamps, probabilities within 1e-4."""
+    cfg, params, frames = synth.make_frames(cfg_name, n_frames, params_name, **kw)
+    o, g = pu.make_pair(cfg, params, synth.noise_table(), bin_order=0)
+    for t, (depth, cloud, pos, q, moves) in enumerate(frames):
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves, sync=True)
+        so, sg = o.dump_state(), g.dump_state()
+        for k in ("status", "ts", "track", "label", "forget", "owner"):
+            assert np.array_equal(so[k], sg[k]), "frame %d: %s differs from the literal-order oracle" % (t, k)
+        live = so["status"] != 0
+        for k in ("w", "px", "py", "pz"):
+            assert np.max(np.abs(so[k][live] - sg[k][live]), initial=0.0) <= 1e-4, "frame %d: %s" % (t, k)
+        vo, vg = o.voxels(), g.voxels()
+        for k in ("occ", "label", "track"):
+            assert np.array_equal(vo[k], vg[k]), "frame %d: voxels.%s differs from the literal-order oracle" % (t, k)
+        assert np.max(np.abs(vo["wsum"] - vg["wsum"])) <= 1e-4
+    g.close()
