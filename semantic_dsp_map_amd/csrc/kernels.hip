@@ -178,20 +178,24 @@ __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__
 //   k_occupancy      the in-frame sweep: incremental (only tiles / voxels written or stamped since the last sweep),
 //                    latency-bound, kept lean so that the thousands of workgroups that leave after one byte are
 //                    dispatched quickly;
-//   k_occupancy_all  the non-incremental sweep (first sweep of a state: sdm_load_state, sdm_set_params, sdm_clear, a
-//                    wholesale stamp upload): every voxel gets its result, HBM-bound, records fetched cooperatively.
+//   k_occupancy_scan + k_occupancy_dense  the non-incremental sweep (first sweep of a state: sdm_load_state,
+//                    sdm_set_params, sdm_clear, a wholesale stamp upload): every voxel gets its result, HBM-bound,
+//                    records of dense chunks fetched cooperatively.
 
 // A voxel that holds something: weight sum, clamp / cull write-backs and the track vote
 // (calculateWeightAndSemanticsInVoxel, operations.h:390-448).  Written without branches - every decision is a select on
 // values all lanes compute - so that a wave whose lanes hold different slot patterns runs one instruction stream.
 // Skipped terms are added as +0.f: x + 0.f == x bit for bit for every x a sum that starts at +0.f can hold.
+// The voxel's result comes back in `out` (the caller stores it: to the result array, or to an LDS stage first); flag
+// byte and write-backs are stored here.
 // PLAIN = the caller has checked (occupancy_is_plain) that no live slot of the voxel can be clamped, culled or is a
 // guessed birth: those rules and their write-backs drop out.  The sweeps test that per wave - one special voxel sends
 // the whole wave through the general version - because the rules fire rarely and cost a third of the instructions.
 template <int S, bool PLAIN>
 __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_threshold, uint32_t lv, uint32_t smax,
                                                    const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv_in)[S],
-                                                   const uint16_t (&trk16)[S], const uint8_t (&lab8)[S]) {
+                                                   const uint16_t (&trk16)[S], const uint8_t (&lab8)[S],
+                                                   sdm_voxel_result &out) {
   float wv[S];
   uint32_t trk[S], lab[S], stv[S];
   bool vote[S];
@@ -256,13 +260,11 @@ __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_th
 #pragma unroll
   for (int j = 1; j < S; ++j) best_l = tv[j] == best_t ? lab[j] : best_l;
   best_t = have ? best_t : 0u;
-  sdm_voxel_result out;
   if (!any_live) {  // deleted since it was flagged, or only stale slots: the empty result
     out.wsum = 0.f;
     out.track = 0;
     out.label = 0;
     out.occ = 0.f > occ_threshold ? 1 : 0;
-    store_result(st.res + lv, out);
     st.vflag[lv] = (uint8_t)((any ? VF_CLEAN : VF_EMPTY) | VR_EMPTY);  // the entry holds the empty result
     return;
   }
@@ -270,7 +272,6 @@ __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_th
   out.track = (uint16_t)best_t;  // 0 / 0 without a winner (PINNED)
   out.label = (uint8_t)best_l;
   out.occ = weight_sum > occ_threshold ? 1 : (guessed >= SDM_OCC_INIT_WEIGHT ? 2 : 0);
-  store_result(st.res + lv, out);
   if constexpr (PLAIN) {
     st.vflag[lv] = VF_CLEAN;
     return;
@@ -324,12 +325,13 @@ __device__ __forceinline__ bool occupancy_is_plain(uint32_t smax, const uint16_t
 template <int S>
 __device__ __forceinline__ void occupancy_evaluate_wave(const State &st, float occ_threshold, bool mine, uint32_t lv, uint32_t smax,
                                                         const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv)[S],
-                                                        const uint16_t (&trk)[S], const uint8_t (&lab)[S]) {
+                                                        const uint16_t (&trk)[S], const uint8_t (&lab)[S],
+                                                        sdm_voxel_result &out) {
   const bool special = mine && !occupancy_is_plain<S>(smax, ts1, st1, wv);
   if (__ballot(special) == 0ull) {  // wave-uniform
-    if (mine) occupancy_evaluate<S, true>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab);
+    if (mine) occupancy_evaluate<S, true>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab, out);
   } else {
-    if (mine) occupancy_evaluate<S, false>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab);
+    if (mine) occupancy_evaluate<S, false>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab, out);
   }
 }
 
@@ -373,8 +375,12 @@ constexpr int OCC_VPT = 8;  // consecutive voxels of one thread: one 16-byte loa
 constexpr int OCC_TILE = TPB * OCC_VPT;  // voxels of one workgroup
 static_assert(OCC_TILE == (1 << TILE_SHIFT), "one workgroup per tile of State::tile_dirty");
 
+// (told to fit 7 waves per SIMD the compiler allocates 72 registers without spills at S <= 8 - 76 left alone, 6 waves)
+#ifndef SDM_OCC_INFRAME_WAVES
+#define SDM_OCC_INFRAME_WAVES 7
+#endif
 template <int S>
-__global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, State st, Counters *cnt) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? SDM_OCC_INFRAME_WAVES : 4, S <= 8 ? SDM_OCC_INFRAME_WAVES : 4))) void k_occupancy(Dims d, float occ_threshold, State st, Counters *cnt) {
   __shared__ uint16_t live_list[OCC_TILE];
   __shared__ uint32_t n_live;
   const uint32_t blk0 = blockIdx.x * OCC_TILE;
@@ -457,21 +463,29 @@ __global__ __launch_bounds__(TPB) void k_occupancy(Dims d, float occ_threshold, 
     voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
     // (latency-bound here, not issue-bound: the general version only - the plain one would cost registers, i.e.
     // resident workgroups, i.e. dispatch time of the many workgroups that leave at once)
-    occupancy_evaluate<S, false>(st, occ_threshold, lv, stamp_max(st, rx, ry, rz), ts1, st1, wv, trk, lab);
+    sdm_voxel_result out;
+    occupancy_evaluate<S, false>(st, occ_threshold, lv, stamp_max(st, rx, ry, rz), ts1, st1, wv, trk, lab, out);
+    store_result(st.res + lv, out);
   }
 }
 
-// Non-incremental sweep: every voxel's result entry is written.  HBM-bound by construction: per voxel 2 B stamp + 1 B
-// flag read, 8 B result + 1 B flag written, and for voxels that hold something their 10*S-byte record read.
-// Chunk-centric: a wave owns OCC_CPW consecutive chunks of 64 voxels, lane = voxel, so results (8 B per lane) and flags
-// leave as contiguous rows with nothing staged.  Records: a chunk that holds at least OCC_DENSE_MIN voxels to evaluate
-// is fetched by its wave as one contiguous block of 640*S bytes - lane-linear 16-byte loads, 1 KB per instruction - and
-// passed through LDS, where every lane picks up its own record (record stride 80 B at S = 8: conflict-free
-// ds_read_b128); a per-lane fetch of 80-byte records would touch all of the block's lines with every load
-// instruction (measured: 0.70 ms for the dense case against 0.33 ms).  The loads of the wave's next two dense chunks
-// are in flight while one is evaluated.  Voxels of sparser chunks go on a workgroup-wide list in LDS and are fetched
-// per lane with all lanes busy.
-// What bounds the dense case (rocprofv3 SQ counters, profiles/r02*_dense_pmc.txt): not the bytes alone - the
+// Non-incremental sweep: every voxel's result entry is written (first sweep of a state).  Two launches:
+//
+// k_occupancy_scan   streams stamps and flags of every voxel like the in-frame kernel (8 consecutive voxels per thread,
+//   wide loads) and finds the constant results.  Voxels that hold something: chunks of 64 voxels with fewer than
+//   OCC_DENSE_MIN of them put them on the workgroup's list and they are evaluated here, one record per lane; denser
+//   chunks are left to the second kernel as a 64-bit mask per chunk.  All results of the tile - constant or evaluated -
+//   are collected in LDS and leave as lane-linear 16-byte stores, 1 KB contiguous per instruction, every line written
+//   whole and once (stored from registers they are 8-byte pieces 64 bytes apart with holes where the evaluated voxels
+//   are: measured 75 us against 46 us for the same bytes on the benchmark state).  On a sparse map this launch is all
+//   there is.
+// k_occupancy_dense  a wave owns 8 consecutive chunks, lane = voxel, and leaves at once when none of them has a mask.
+//   A chunk's 64 records are one contiguous block of 640*S bytes: fetched with lane-linear 16-byte loads (1 KB per
+//   instruction), passed through LDS, where every lane picks up its own record (record stride 80 B at S = 8:
+//   conflict-free ds_read_b128); a per-lane fetch of 80-byte records would touch all of the block's lines with every
+//   load instruction (measured: 0.70 ms for the dense case against 0.33 ms).  The loads of the wave's next two chunks
+//   are in flight while one is evaluated.
+// What bounds the dense case (rocprofv3 SQ counters, profiles/r02_dense_pmc.txt): not the bytes alone - the
 // evaluation costs about 650 instructions per chunk and wave, the SIMDs issue for more than 80 % of the kernel's time.
 // Hence the branch-free evaluation and its PLAIN variant above.
 constexpr int OCC_CHUNK = 64;
@@ -483,78 +497,186 @@ constexpr int OCC_CPW = OCC_CHUNKS / OCC_WAVES;  // chunks per wave
 #endif
 constexpr uint32_t OCC_DENSE_MIN = SDM_OCC_DENSE_MIN;
 
+struct OccScanInputs {  // what one thread reads of a tile: 8 voxel stamps, 8 flag bytes, the ring stamps of its row
+  uint16_t t0v[OCC_VPT];
+  uint8_t flag[OCC_VPT];
+  uint32_t sx[OCC_VPT], yz;
+};
+
+__device__ __forceinline__ void occ_scan_fetch(const Dims &d, const State &st, uint32_t tile, uint32_t n_tiles, uint32_t tid,
+                                               OccScanInputs &in) {
+  const uint32_t lv0 = tile * OCC_TILE + tid * OCC_VPT;
+  if (tile >= n_tiles || lv0 >= d.v_count) return;
+  load_vec(in.t0v, st.vts + lv0);
+  load_vec(in.flag, st.vflag + lv0);
+  if (d.x_n >= 3) {  // a group lies in one x row of the ring: one y and one z stamp, eight consecutive x stamps
+    uint32_t rx, ry, rz;
+    voxel_to_ring(d, d.v_begin + lv0, rx, ry, rz);
+    const uint32_t b = st.stamps_y[ry], c = st.stamps_z[rz];
+    in.yz = b > c ? b : c;
+    load_vec(in.sx, st.stamps_x + rx);
+  }
+}
+
+// (registers: told to fit 8 waves per SIMD the compiler finds an allocation with 64 registers and no spills at S <= 8;
+// left alone it takes 91, i.e. 5 resident workgroups per CU instead of 8 - this launch lives on resident workgroups)
 template <int S>
-__global__ __launch_bounds__(TPB) void k_occupancy_all(Dims d, float occ_threshold, State st, Counters *cnt) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 : 4, S <= 8 ? 8 : 4))) void k_occupancy_scan(Dims d, float occ_threshold, State st, Counters *cnt,
+                                                        unsigned long long *__restrict__ need, uint32_t n_tiles) {
+  // the tile's results, 64 bytes (8 voxels) per thread; the 16-byte pieces of a row are swizzled so that neither the
+  // row-wise writes nor the lane-linear reads run into bank conflicts
+  __shared__ v4u res_stage[TPB * 4];
+  __shared__ uint16_t live_list[OCC_CHUNKS * (OCC_DENSE_MIN - 1)];  // a sparse chunk lists fewer than OCC_DENSE_MIN
+  __shared__ unsigned long long chunk_mask[OCC_CHUNKS];
+  __shared__ uint32_t n_live;
+  auto stage_slot = [&](uint32_t v) -> v2u * {  // where voxel v of the tile sits in the stage
+    const uint32_t t = v >> 3, q = (v >> 1) & 3u;
+    return reinterpret_cast<v2u *>(&res_stage[t * 4 + (q ^ ((t >> 1) & 3u))]) + (v & 1u);
+  };
+  // (One tile per workgroup.  A persistent version - 1024 workgroups walking the tiles, the next tile's inputs pulled
+  // into L2 or registers meanwhile - was measured: what the loop keeps alive costs 30 registers, one resident workgroup
+  // per CU less, 90 us against 75 us on the benchmark state.)
+  const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) n_live = 0;
+  OccScanInputs in;
+  occ_scan_fetch(d, st, tile, n_tiles, tid, in);
+  __syncthreads();
+  {
+    const uint32_t blk0 = tile * OCC_TILE;
+    if (tid == 0) {
+      st.tile_dirty[tile] = 0;  // the evaluation may set it again
+      atomicAdd(&cnt->shard[tile & (VIS_SHARDS - 1)].sweep_tiles, 1u);
+    }
+    const uint32_t lv0 = blk0 + tid * OCC_VPT;  // v_count is a multiple of 8: whole groups only
+    const bool in_range = lv0 < d.v_count;
+    v2u outw[OCC_VPT];
+    uint32_t want = 0, listed = 0;
+    if (in_range) {
+      uint8_t nflag[OCC_VPT];
+      const bool rows = d.x_n >= 3;
+      bool flags_changed = false;
+#pragma unroll
+      for (int u = 0; u < OCC_VPT; ++u) {
+        uint32_t smax;
+        if (rows) {
+          smax = in.sx[u] > in.yz ? in.sx[u] : in.yz;
+        } else {
+          uint32_t rx, ry, rz;
+          voxel_to_ring(d, d.v_begin + lv0 + u, rx, ry, rz);
+          smax = stamp_max(st, rx, ry, rz);
+        }
+        nflag[u] = in.flag[u];
+        outw[u] = v2u{0u, 0u};
+        sdm_voxel_result out;
+        // (non-incremental: 1 or 2, never 0)
+        const int cls = occupancy_classify(in.t0v[u], in.flag[u], smax, occ_threshold, 1, out, nflag[u]);
+        if (cls == 1) {
+          __builtin_memcpy(&outw[u], &out, 8);
+          want |= 1u << u;
+          flags_changed = true;
+        } else {
+          listed |= 1u << u;
+        }
+      }
+      if (flags_changed) store_vec(st.vflag + lv0, nflag);  // the evaluation rewrites the bytes of the listed voxels later
+    }
+    // which way do this thread's listed voxels go?  Its chunk = the aligned group of eight lanes it sits in.
+    bool whole;  // every result of this thread's group is known in this launch: it leaves through the stage
+    {
+      uint32_t in_chunk = (uint32_t)__popc(listed);
+      in_chunk += __shfl_xor(in_chunk, 1, 64);
+      in_chunk += __shfl_xor(in_chunk, 2, 64);
+      in_chunk += __shfl_xor(in_chunk, 4, 64);
+      const bool dense = in_chunk >= OCC_DENSE_MIN;
+      whole = in_range && (!dense || listed == 0);
+      reinterpret_cast<uint8_t *>(chunk_mask)[tid] = dense ? (uint8_t)listed : (uint8_t)0;
+      if (!dense && listed) {
+        uint32_t k = atomicAdd(&n_live, (uint32_t)__popc(listed));
+#pragma unroll
+        for (int u = 0; u < OCC_VPT; ++u)
+          if (listed & (1u << u)) live_list[k++] = (uint16_t)(tid * OCC_VPT + u);
+      }
+      uint32_t nw = (uint32_t)__popc(listed);
+      for (int off = 32; off > 0; off >>= 1) nw += __shfl_down(nw, off, 64);
+      if (lane == 0 && nw) atomicAdd(&cnt->shard[(tile + wave) & (VIS_SHARDS - 1)].sweep, nw);
+    }
+    if (whole) {  // constant results into the stage (the slots of listed voxels are filled in by the evaluation)
+      const uint32_t sw = (tid >> 1) & 3u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        res_stage[tid * 4 + (q ^ sw)] = v4u{outw[2 * q].x, outw[2 * q].y, outw[2 * q + 1].x, outw[2 * q + 1].y};
+    } else if (in_range) {  // a group with voxels the second launch evaluates: its constant results one by one
+#pragma unroll
+      for (int u = 0; u < OCC_VPT; ++u)
+        if (want & (1u << u)) __builtin_nontemporal_store(outw[u], reinterpret_cast<v2u *>(st.res + lv0 + u));
+    }
+    __syncthreads();
+    if (tid < OCC_CHUNKS && blk0 + tid * OCC_CHUNK < d.v_count)
+      need[(size_t)tile * OCC_CHUNKS + tid] = chunk_mask[tid];
+    const uint32_t nl = n_live;
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < nl; k0 += TPB) {  // workgroup-uniform
+      const uint32_t k = k0 + tid;
+      if (k < nl) {
+        const uint32_t tv = live_list[k], lv = blk0 + tv;
+        uint16_t ts1[S], trk[S];
+        uint8_t st1[S], lab[S];
+        float wv[S];
+        const size_t base = (size_t)lv * S;
+        load_vec<rec_align(S)>(st1, st.status + base * REC_STATUS);
+        load_vec<rec_align(S)>(wv, st.w + base * REC_W);
+        load_vec<rec_align(S)>(ts1, st.ts + base * REC_TS);
+        load_vec<rec_align(S)>(trk, st.track + base * REC_TRACK);
+        load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
+        uint32_t rx, ry, rz;
+        voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+        sdm_voxel_result out;
+        // (the general version only: the plain one next to it costs registers and was measured to gain nothing here)
+        occupancy_evaluate<S, false>(st, occ_threshold, lv, stamp_max(st, rx, ry, rz), ts1, st1, wv, trk, lab, out);
+        v2u o;
+        __builtin_memcpy(&o, &out, 8);
+        *stage_slot(tv) = o;
+      }
+    }
+    __syncthreads();
+    // the stage leaves as lane-linear 16-byte stores: 1 KB contiguous per instruction
+    {
+      const unsigned long long whole_mask = __ballot(whole);
+      v4u *dst = reinterpret_cast<v4u *>(st.res + blk0 + wave * 64 * OCC_VPT);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t row = k * 16 + (lane >> 2), piece = lane & 3u;  // row = the lane of this wave whose group it is
+        if ((whole_mask >> row) & 1ull) {
+          const uint32_t t = wave * 64 + row;
+          __builtin_nontemporal_store(res_stage[t * 4 + (piece ^ ((t >> 1) & 3u))], dst + row * 4 + piece);
+        }
+      }
+    }
+  }
+}
+
+template <int S>
+__global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_threshold, State st,
+                                                         const unsigned long long *__restrict__ need) {
   constexpr int REC = 10 * S;                    // bytes of one record
   constexpr int PIECES = OCC_CHUNK * REC / 16;   // 16-byte pieces of one chunk of records
   constexpr int PPL = (PIECES + 63) / 64;
   __shared__ v4u rec_stage[OCC_WAVES][PIECES];  // one chunk of records per wave, for the lane <-> record transposition
-  __shared__ uint32_t sm_stage[OCC_WAVES][OCC_CPW][64];  // slab stamps of the wave's voxels (indexed by a run-time chunk below)
-  __shared__ uint16_t live_list[OCC_TILE];
-  __shared__ uint32_t n_live;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t blk0 = blockIdx.x * OCC_TILE;
-  if (threadIdx.x == 0) {
-    st.tile_dirty[blockIdx.x] = 0;  // the evaluation may set it again
-    n_live = 0;
-    atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep_tiles, 1u);
-  }
-  __syncthreads();
-  const uint32_t lvw = blk0 + wave * OCC_CPW * OCC_CHUNK;  // first voxel of this wave
-  // stamps, flags and slab stamps of all the wave's chunks first: everything in flight before anything is looked at
-  uint32_t t0[OCC_CPW], fl[OCC_CPW], sm[OCC_CPW];
+  const uint32_t lvw = blockIdx.x * OCC_TILE + wave * OCC_CPW * OCC_CHUNK;  // first voxel of this wave
+  // the masks of the wave's chunks: lane k holds chunk k's
+  unsigned long long mk = 0;
+  if (lane < (uint32_t)OCC_CPW && lvw + lane * OCC_CHUNK < d.v_count)
+    mk = need[(size_t)blockIdx.x * OCC_CHUNKS + wave * OCC_CPW + lane];
+  const uint32_t densebits = (uint32_t)(__ballot(mk != 0ull) & ((1ull << OCC_CPW) - 1ull));
+  if (!densebits) return;  // nothing of this wave's was left to this kernel
+  uint32_t evalbits = 0;   // bit k: this lane's voxel of chunk k is to be evaluated
 #pragma unroll
   for (int k = 0; k < OCC_CPW; ++k) {
-    const uint32_t lv = lvw + k * OCC_CHUNK + lane;
-    t0[k] = 0;
-    fl[k] = 0;
-    sm[k] = 0;
-    if (lv < d.v_count) {
-      t0[k] = __builtin_nontemporal_load(st.vts + lv);
-      fl[k] = __builtin_nontemporal_load(st.vflag + lv);
-      uint32_t rx, ry, rz;
-      voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
-      sm[k] = stamp_max(st, rx, ry, rz);
-    }
-  }
-  // constant results (unobserved / empty) leave at once: 8 B and 1 B per lane, contiguous rows
-  uint32_t evalbits = 0;  // bit k: this lane's voxel of chunk k needs its record
-#pragma unroll
-  for (int k = 0; k < OCC_CPW; ++k) {
-    const uint32_t lv = lvw + k * OCC_CHUNK + lane;
-    if (lv < d.v_count) {
-      sdm_voxel_result out;
-      uint8_t nflag = (uint8_t)fl[k];
-      const int cls = occupancy_classify(t0[k], fl[k], sm[k], occ_threshold, 1, out, nflag);
-      if (cls == 1) {
-        store_result(st.res + lv, out);
-        st.vflag[lv] = nflag;
-      }
-      evalbits |= cls == 2 ? 1u << k : 0u;
-    }
-    sm_stage[wave][k][lane] = sm[k];
-  }
-  // The voxels that hold something.  A chunk with fewer than OCC_DENSE_MIN of them hands them to a list in LDS that
-  // the whole workgroup works off with all lanes busy (a surface crossing the tile leaves a few voxels in many chunks;
-  // chunk by chunk that would be one dependent record fetch + evaluation per chunk with most lanes idle).  Dense chunks
-  // stay with their wave: cooperative fetch, the records of the wave's next dense chunk landing in the other half of
-  // the stage while this one is evaluated.
-  uint32_t densebits = 0;  // wave-uniform: chunk k takes the cooperative path
-  uint32_t n_eval = 0;
-#pragma unroll
-  for (int k = 0; k < OCC_CPW; ++k) {
-    const bool mine = (evalbits >> k) & 1u;
-    const unsigned long long need = __ballot(mine);
-    const uint32_t n = (uint32_t)__popcll(need);
-    n_eval += n;
-    if (n >= OCC_DENSE_MIN) {
-      densebits |= 1u << k;
-    } else if (n) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&n_live, n);
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (mine) live_list[base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull))] = (uint16_t)((wave * OCC_CPW + k) * OCC_CHUNK + lane);
-    }
+    const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mk >> 32), k) << 32) |
+                                 (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, k);
+    evalbits |= (uint32_t)((m >> lane) & 1ull) << k;
   }
   auto fetch = [&](int k, v4u (&buf)[PPL]) {  // lane-linear loads of chunk k's records: 1 KB contiguous per instruction
     const uint32_t lvc = lvw + k * OCC_CHUNK;
@@ -575,43 +697,20 @@ __global__ __launch_bounds__(TPB) void k_occupancy_all(Dims d, float occ_thresho
     }
   };
   auto next_dense = [&](int k) -> int {  // first dense chunk after k
-    const uint32_t rest = k + 1 < 32 ? densebits & ~((2u << k) - 1u) : 0u;
+    const uint32_t rest = densebits & ~((2u << k) - 1u);
     return rest ? __builtin_ctz(rest) : OCC_CPW;
   };
-  // three dense chunks of the wave are under way at any time: one in the stage, two in registers
-  int k = densebits ? __builtin_ctz(densebits) : OCC_CPW;
-  int k1 = k < OCC_CPW ? next_dense(k) : OCC_CPW;
+  // three chunks of the wave are under way at any time: one in the stage, two in registers
+  int k = __builtin_ctz(densebits);
+  int k1 = next_dense(k);
   int k2 = k1 < OCC_CPW ? next_dense(k1) : OCC_CPW;
   v4u b0[PPL], b1[PPL];
   {
     v4u first[PPL];
-    if (k < OCC_CPW) fetch(k, first);
+    fetch(k, first);
     if (k1 < OCC_CPW) fetch(k1, b0);
     if (k2 < OCC_CPW) fetch(k2, b1);
-    if (k < OCC_CPW) to_stage(first);
-  }
-  __syncthreads();
-  const uint32_t nl = n_live;
-  for (uint32_t q0 = 0; q0 < nl; q0 += TPB) {
-    const uint32_t q = q0 + threadIdx.x;
-    const bool mine = q < nl;
-    const uint32_t lv = blk0 + (mine ? live_list[q] : 0u);
-    uint16_t ts1[S], trk[S];
-    uint8_t st1[S], lab[S];
-    float wv[S];
-    uint32_t smax = 0;
-    if (mine) {
-      const size_t base = (size_t)lv * S;
-      load_vec<rec_align(S)>(st1, st.status + base * REC_STATUS);
-      load_vec<rec_align(S)>(wv, st.w + base * REC_W);
-      load_vec<rec_align(S)>(ts1, st.ts + base * REC_TS);
-      load_vec<rec_align(S)>(trk, st.track + base * REC_TRACK);
-      load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
-      uint32_t rx, ry, rz;
-      voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
-      smax = stamp_max(st, rx, ry, rz);
-    }
-    occupancy_evaluate_wave<S>(st, occ_threshold, mine, lv, smax, ts1, st1, wv, trk, lab);
+    to_stage(first);
   }
   // one step: evaluate chunk k out of the stage, move `up` (chunk k1, landed or landing) into the stage, start the loads
   // of the chunk after k2 into `up`.  The two register buffers alternate, hence the loop body holds two steps.
@@ -621,6 +720,7 @@ __global__ __launch_bounds__(TPB) void k_occupancy_all(Dims d, float occ_thresho
     uint16_t ts1[S], trk[S];
     uint8_t st1[S], lab[S];
     float wv[S];
+    uint32_t smk = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -632,10 +732,14 @@ __global__ __launch_bounds__(TPB) void k_occupancy_all(Dims d, float occ_thresho
       __builtin_memcpy(trk, __builtin_assume_aligned(r + 6 * S, RA < 2 * S ? RA : 2 * S), 2 * S);
       __builtin_memcpy(lab, __builtin_assume_aligned(r + 8 * S, RA < S ? RA : S), S);
       __builtin_memcpy(st1, __builtin_assume_aligned(r + 9 * S, RA < S ? RA : S), S);
+      uint32_t rx, ry, rz;
+      voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+      smk = stamp_max(st, rx, ry, rz);
     }
-    const uint32_t smk = sm_stage[wave][k][lane];
     // the evaluation runs on registers only; the two chunks behind this one are landing meanwhile
-    occupancy_evaluate_wave<S>(st, occ_threshold, mine, lv, smk, ts1, st1, wv, trk, lab);
+    sdm_voxel_result out;
+    occupancy_evaluate_wave<S>(st, occ_threshold, mine, lv, smk, ts1, st1, wv, trk, lab, out);
+    if (mine) store_result(st.res + lv, out);
     // the next chunk moves into the stage (its loads have had two evaluations' time) and the loads of the third start
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -651,7 +755,6 @@ __global__ __launch_bounds__(TPB) void k_occupancy_all(Dims d, float occ_thresho
     if (k >= OCC_CPW) break;
     step(b1);
   }
-  if (lane == 0 && n_eval) atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep, n_eval);
 }
 
 // slot 0 of the exported stamp array carries the voxel stamp (sdm_dump_state / sdm_load_state keep the reference's
@@ -2208,7 +2311,8 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s, bool fresh) {
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, hipStream_t s) {
   dim3 grid(blocks_for(d.v_count, OCC_TILE));
   if (all_dirty) {
-    SDM_DISPATCH_S(k_occupancy_all, grid, s, d, flt.occ_threshold, st, cnt);
+    SDM_DISPATCH_S(k_occupancy_scan, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, grid.x);
+    SDM_DISPATCH_S(k_occupancy_dense, grid, s, d, flt.occ_threshold, st, st.occ_need);
   } else {
     SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st, cnt);
   }

@@ -530,6 +530,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(m->st.vts, d.v_count);
   A(m->st.vflag, d.v_count);
   A(m->st.tile_dirty, (d.v_count >> TILE_SHIFT) + 1);
+  A(m->st.occ_need, ((size_t)d.v_count + 63) / 64 + 32);
   A(m->st.owner, n_slots);
   A(m->st.owner_flag, (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK);
   A(m->st.alias, 2 + 2 * ALIAS_CAP);

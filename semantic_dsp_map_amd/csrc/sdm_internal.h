@@ -164,6 +164,8 @@ struct State {
   // let the sweep finish an unobserved, empty or unchanged voxel from 3 bytes read and nothing written.
   uint8_t *vflag = nullptr;
   uint8_t *tile_dirty = nullptr;  // per tile of 2^TILE_SHIFT voxels: something in it needs the sweep
+  // per chunk of 64 voxels: the voxels the non-incremental sweep's first launch left to its second (dense chunks)
+  unsigned long long *occ_need = nullptr;
   uint16_t *track = nullptr;
   uint8_t *label = nullptr;
   uint8_t *status = nullptr;

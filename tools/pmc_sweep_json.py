@@ -1,10 +1,11 @@
 #!/usr/bin/env python
 """profiles/<tag>_sweep_pmc.json from the two counter passes of tools/pmc_sweep.sh.
 
-Launch order of the bench command: k_occupancy_all x1 (first frame after sdm_load_state), k_occupancy<S> for the other
-warm-up + timed frames, then 6 profiled frames (the ones bench.py takes the in-frame launch time, tile and voxel counts
-from), 6 x-shift frames, then k_occupancy_all x11 on the benchmark map (non-incremental: 1 warm-up + 10 timed) and x11 on
-the dense map.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated there for
+Launch order of the bench command: one non-incremental sweep (k_occupancy_scan + k_occupancy_dense, first frame after
+sdm_load_state), k_occupancy<S> for the other warm-up + timed frames, then 6 profiled frames (the ones bench.py takes the
+in-frame launch time, tile and voxel counts from), 6 x-shift frames, then 11 non-incremental sweeps on the benchmark map
+(1 warm-up + 10 timed) and 11 on the dense map.  A non-incremental sweep is two launches: their counters and durations
+are added.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated there for
 wide coalesced streaming reads, so for the in-frame launch with its scattered record fetches the corrected figure is an
 upper estimate)."""
 import csv
@@ -19,19 +20,24 @@ rf = b["roofline"]
 res = {}
 for c in ["FETCH_SIZE", "WRITE_SIZE"]:
     rows = list(csv.DictReader(open(g + "%s_sweep_%s.csv" % (tag, c))))
-    inc = [r for r in rows if "k_occupancy_all" not in r["Kernel_Name"]]
-    allr = [r for r in rows if "k_occupancy_all" in r["Kernel_Name"]]
+    def one(r):
+        return [(float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)]
+    inc = [one(r) for r in rows if "k_occupancy<" in r["Kernel_Name"]]
+    scan = [r for r in rows if "k_occupancy_scan" in r["Kernel_Name"]]
+    dense = [r for r in rows if "k_occupancy_dense" in r["Kernel_Name"]]
+    assert len(scan) == len(dense) == 23 and len(inc) + len(scan) + len(dense) == len(rows), (len(scan), len(dense), len(inc), len(rows))
+    allr = [one(a) + one(b) for a, b in zip(scan, dense)]
     sets = {"in_frame": inc[-12:-6], "x_shift_frames": inc[-6:], "full_evaluation": allr[2:12], "dense_case": allr[13:23]}
     for name, rs in sets.items():
-        v = [float(r["Counter_Value"]) for r in rs]
-        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rs]
+        v = [sum(x[0] for x in r) for r in rs]
+        d = [sum(x[1] for x in r) for r in rs]
         res.setdefault(name, {})[c] = (sum(v) / len(v), sum(d) / len(d), len(v))
     shutil.copy(g + "%s_sweep_%s.csv" % (tag, c), "profiles/%s_sweep_pmc_%s.csv" % (tag, c.lower()))
-out = {"kernel": rf["kernel"], "voxels": rf["voxels"], "voxels_evaluated_in_full": rf["voxels_evaluated_in_full"], "tiles": rf["tiles"],
+out = {"kernel": rf["kernel"], "non_incremental_kernels": "k_occupancy_scan + k_occupancy_dense (two launches, added)", "voxels": rf["voxels"], "voxels_evaluated_in_full": rf["voxels_evaluated_in_full"], "tiles": rf["tiles"],
        "tiles_looked_into": rf["tiles_looked_into"],
        "fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section)", "cases": {},
-       "commands": ["SDM_GRAPH=0 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -- python bench.py --no-cpu --no-strong --steps 20 --warmup 5",
-                    "SDM_GRAPH=0 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -- python bench.py --no-cpu --no-strong --steps 20 --warmup 5"]}
+       "commands": ["SDM_GRAPH=0 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -- python bench.py --no-cpu --no-strong --no-stress --steps 20 --warmup 5",
+                    "SDM_GRAPH=0 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -- python bench.py --no-cpu --no-strong --no-stress --steps 20 --warmup 5"]}
 layout = {"in_frame": rf["bytes_per_launch"], "full_evaluation": rf.get("full_evaluation", {}).get("bytes_per_launch"),
           "dense_case": rf.get("dense_case", {}).get("bytes_per_launch"), "x_shift_frames": None}
 for name, r in res.items():
