@@ -242,7 +242,7 @@ def main():
     launch_mode = {"graph_frames": stats["graph_frames"], "direct_frames": stats["direct_frames"],
                    "host_enqueue_us_min_direct": round(stats["host_enqueue_us"], 1),
                    "policy": "SDM_GRAPH=%s (0 launch by launch, 1 hipGraph replay, 2 = default: graph when issuing a frame "
-                             "launch by launch takes this host more than 150 us)" % os.environ.get("SDM_GRAPH", "2")}
+                             "launch by launch takes this host more than 300 us)" % os.environ.get("SDM_GRAPH", "2")}
     live, n_vis, live_vox_local = stats["live_particles"], stats["n_visible"], stats["live_voxels"]
     if dist is not None:
         lt = torch.tensor([live, n_vis], dtype=torch.int64)

@@ -24,8 +24,11 @@ namespace {
 
 thread_local std::string g_last_error;
 
-// host time per plain frame above which sdm_update switches to graph replay (graph_mode 2)
-constexpr double GRAPH_ENQUEUE_US = 150.0;
+// Host time per plain frame above which sdm_update switches to graph replay (graph_mode 2).  The graph is one chain
+// (see graph_capture): replaying it costs this host 10 us, but its kernels run one after the other, 0.40 ms per
+// benchmark frame on the GPU against 0.32 ms for the launch-by-launch frame with its three side streams.  So the graph
+// pays only where the host needs more than about that long to issue a frame.
+constexpr double GRAPH_ENQUEUE_US = 300.0;
 
 void set_error(const char *what, const char *file, int line, const char *detail) {
   char buf[512];
@@ -113,6 +116,8 @@ struct sdm_map {
   bool use_graph = false;
   int n_timed = 0;
   double enqueue_us_min = 1e30;
+  double t_prepare_us = 0, t_setparams_us = 0, t_launch_us = 0, t_direct_us = 0;  // SDM_HOST_TIMING: host time per step of sdm_update
+  bool host_timing = false;
   bool capturing = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -637,6 +642,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
     const char *e = getenv("SDM_GRAPH");
     if (e && e[0] >= '0' && e[0] <= '2') m->graph_mode = e[0] - '0';
     m->use_graph = m->graph_mode == 1;
+    m->host_timing = getenv("SDM_HOST_TIMING") != nullptr;  // debugging aid: per-step host time of sdm_update on stderr at destroy
   }
   refresh_filter(m);
   build_birth_order(m);
@@ -654,6 +660,12 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
 
 sdm_status sdm_destroy(sdm_map *m) {
   if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  if (m->host_timing) {
+    const double ng = m->n_graph_frames ? (double)m->n_graph_frames : 1.0, nd = m->n_direct_frames ? (double)m->n_direct_frames : 1.0;
+    fprintf(stderr, "sdm host timing: prepare+inputs %.1f us/frame; graph frames %llu: set-params %.1f us, hipGraphLaunch %.1f us; direct frames %llu: %.1f us\n",
+            m->t_prepare_us / (ng + nd - ((m->n_graph_frames && m->n_direct_frames) ? 0.0 : 1.0)), (unsigned long long)m->n_graph_frames,
+            m->t_setparams_us / ng, m->t_launch_us / ng, (unsigned long long)m->n_direct_frames, m->t_direct_us / nd);
+  }
   (void)hipSetDevice(m->device);
   (void)hipStreamSynchronize(m->stream);
   for (void *p : m->allocs) (void)hipFree(p);
@@ -1043,8 +1055,11 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
 
 namespace {
 
-// the frame as a graph: captured from the very launches above (stream capture follows the side streams through their
-// events), instantiated once, replayed with the frame block as the one parameter that changes
+// The frame as a graph: captured from the very launches above, instantiated once, replayed with the frame block as the
+// one parameter that changes.  Captured as ONE chain - the side streams' launches are issued on the main stream for the
+// capture: hipGraphLaunch of a chain of kernel nodes costs 7 us on the host, the same frame with its three forks and joins
+// 79 us (measured, ROCm 7.2: every fork / join is a separate submission with its own synchronisation) - next to 105 us
+// for issuing the launches one by one, that graph would buy nothing.
 sdm_status graph_capture(sdm_map *m) {
   if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
   if (m->graph) (void)hipGraphDestroy(m->graph);
@@ -1058,6 +1073,8 @@ sdm_status graph_capture(sdm_map *m) {
   m->sc.fa = m->d_fa[0];
   m->sc.fa_side = m->d_fa[1];
   m->capturing = true;
+  hipStream_t side[3] = {m->s_frustum, m->s_birth, m->s_moves};
+  m->s_frustum = m->s_birth = m->s_moves = m->stream;  // one chain
   hipError_t e = hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal);
   sdm_status rc = SDM_OK;
   if (e == hipSuccess) {
@@ -1069,6 +1086,9 @@ sdm_status graph_capture(sdm_map *m) {
     e = hipStreamEndCapture(m->stream, &g);
     m->graph = g;
   }
+  m->s_frustum = side[0];
+  m->s_birth = side[1];
+  m->s_moves = side[2];
   m->capturing = false;
   if (e != hipSuccess || rc != SDM_OK || !m->graph) {
     set_error("hipStreamCapture", __FILE__, __LINE__, e != hipSuccess ? hipGetErrorString(e) : "frame enqueue failed under capture");
@@ -1104,8 +1124,14 @@ sdm_status graph_launch(sdm_map *m) {
   kp.sharedMemBytes = 0;
   kp.kernelParams = m->fb.argv;
   kp.extra = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipGraphExecKernelNodeSetParams(m->graph_exec, m->graph_set_node, &kp));
+  const auto t1 = std::chrono::steady_clock::now();
   HIP_TRY(hipGraphLaunch(m->graph_exec, m->stream));
+  if (m->host_timing) {
+    m->t_setparams_us += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    m->t_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+  }
   m->cur_depth = m->fa.depth;
   m->cur_cloud = m->fa.cloud;
   m->state_event_valid = false;  // ev_state was not recorded: the next plain frame forks from its own start
@@ -1123,8 +1149,10 @@ sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *c
   if (rc != SDM_OK) return rc;
   HIP_TRY(hipSetDevice(m->device));
   m->fused_ck = true;
+  const auto tp0 = std::chrono::steady_clock::now();
   rc = frame_host_prepare(m, cam_pos, cam_q, moves, n_moves, remove_tracks, n_remove, flags, stop_after);
   if (rc == SDM_OK) rc = stage_inputs(m, depth, cloud, flags);
+  if (m->host_timing) m->t_prepare_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count();
   if (rc != SDM_OK) {
     m->fused_ck = false;
     return rc;
@@ -1150,6 +1178,7 @@ sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *c
     if (rc == SDM_OK) rc = sdm_frame_moves(m);
     if (rc == SDM_OK) rc = sdm_frame_predict(m, nullptr);
     if (rc == SDM_OK) rc = sdm_update_finish(m, nullptr, 1, flags, stop_after);
+    if (m->host_timing) m->t_direct_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     // graph_mode 2: how long does this host take to issue a plain frame?  Judged on the fastest of eight (the first
     // ones pay code loading); above GRAPH_ENQUEUE_US the host, not the GPU, sets the frame rate and the graph pays.
     if (m->graph_mode == 2 && would_be_plain && m->n_timed < 8) {
