@@ -240,9 +240,10 @@ def main():
 
     stats = m.stats(count_live=True)
     launch_mode = {"graph_frames": stats["graph_frames"], "direct_frames": stats["direct_frames"],
-                   "host_enqueue_us_min_direct": round(stats["host_enqueue_us"], 1),
-                   "policy": "SDM_GRAPH=%s (0 launch by launch, 1 hipGraph replay, 2 = default: graph when issuing a frame "
-                             "launch by launch takes this host more than 300 us)" % os.environ.get("SDM_GRAPH", "2")}
+                   "host_us_per_launched_frame": round(stats["host_enqueue_us"], 1),
+                   "policy": "SDM_GRAPH=%s (0 launch by launch, 1 hipGraph replay with the frustum and birth chains as branches, "
+                             "3 replay as one chain, 2 = default: the branched graph, or the chain if this host needs more than "
+                             "170 us to issue 50 empty kernel launches - measured when the map is created)" % os.environ.get("SDM_GRAPH", "2")}
     live, n_vis, live_vox_local = stats["live_particles"], stats["n_visible"], stats["live_voxels"]
     if dist is not None:
         lt = torch.tensor([live, n_vis], dtype=torch.int64)
@@ -354,7 +355,7 @@ def main():
         m.close()
         base4 = synth.CONFIGS["C4"]
         strong, eng4, _, _, _ = timed_run(synth, sharded, dist, rank, world, local_rank, base4, synth.PARAMS[synth.CONFIG_PARAMS["C4"]],
-                                          8000000 // world, min(args.steps, 10), min(args.warmup, 3),
+                                          8000000 // world, min(args.steps, 10), 6,  # warm-up: the state's first frame, three timed launch-by-launch frames, the graph capture
                                           dict(n_static=48, n_dynamic=6, seed=7))
         strong["config"] = "C4: 256x256x256 voxels, 8 slots/voxel, 8 M particles prefilled in all, Z-slab shards over %d GPU(s)" % world
         strong["scaling"] = "strong"

@@ -162,7 +162,7 @@ typedef struct {
   int64_t restamped_slabs[3]; /* slabs the last update's ring shift re-stamped, per axis (x, y, z) */
   int64_t graph_frames;     /* frames replayed from the captured hipGraph so far ...                       */
   int64_t direct_frames;    /* ... and frames issued launch by launch                                      */
-  double host_enqueue_us;   /* fastest host time to issue a plain frame launch by launch (0 = not measured) */
+  double host_enqueue_us;   /* host time to issue 50 empty kernel launches (a frame's worth), measured at sdm_create */
 } sdm_stats;
 
 /* ---- life cycle: SemanticDSPMap() / ~SemanticDSPMap() / clear() (semantic_dsp_map.h:25-81),

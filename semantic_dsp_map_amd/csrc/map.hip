@@ -24,11 +24,16 @@ namespace {
 
 thread_local std::string g_last_error;
 
-// Host time per plain frame above which sdm_update switches to graph replay (graph_mode 2).  The graph is one chain
-// (see graph_capture): replaying it costs this host 10 us, but its kernels run one after the other, 0.40 ms per
-// benchmark frame on the GPU against 0.32 ms for the launch-by-launch frame with its three side streams.  So the graph
-// pays only where the host needs more than about that long to issue a frame.
-constexpr double GRAPH_ENQUEUE_US = 300.0;
+// A plain frame is replayed from a hipGraph.  Two shapes of it (graph_capture): with the frustum and the birth chains
+// as branches - hipGraphLaunch costs this host 78 us, the GPU needs 0.305 ms per benchmark frame (0.31 ms launch by
+// launch with 105 us of host time) - and as ONE chain - 5 us on the host, 0.40 ms on the GPU.  The chain pays where the
+// host needs longer than that to launch the branched graph, i.e. is about 4.5 times slower than this one.  The host's
+// speed is measured when the map is created: the time to issue 50 launches - a frame's worth - of an empty kernel
+// (this host: 39 us; the frame's real launches, with their arguments and events, take it 105 us).
+constexpr double GRAPH_CHAIN_US = 170.0;
+constexpr int LAUNCHES_PER_FRAME = 50;
+
+__global__ void k_noop() {}
 
 void set_error(const char *what, const char *file, int line, const char *detail) {
   char buf[512];
@@ -109,13 +114,11 @@ struct sdm_map {
   const sdm_labeled_point *cur_cloud = nullptr;
   // The launch sequence of a plain frame (sdm_update, device-resident inputs, one GPU) does not depend on the frame:
   // it is captured once into a hipGraph and replayed with one kernel-node parameter update (the frame block) per frame.
-  // Worth it only where the host is the bottleneck: a replay costs the host one call instead of ~50 but the GPU
-  // about 0.1 ms per frame (no overlap between frames, costlier node-to-node dependencies).  graph_mode: 0 never,
-  // 1 always, 2 (default) decide from the measured host time of the first plain frames (SDM_GRAPH=0/1/2).
+  // graph_mode (SDM_GRAPH): 0 never, 1 always the branched graph, 3 always the chain, 2 (default): the branched graph, or
+  // the chain on a host that is slow at issuing launches (measured at creation, GRAPH_CHAIN_US).
   int graph_mode = 2;
-  bool use_graph = false;
-  int n_timed = 0;
-  double enqueue_us_min = 1e30;
+  bool use_graph = false, graph_chain = false;
+  double enqueue_us = 0.0;  // measured at creation: host time to issue a frame's worth of launches
   double t_prepare_us = 0, t_setparams_us = 0, t_launch_us = 0, t_direct_us = 0;  // SDM_HOST_TIMING: host time per step of sdm_update
   bool host_timing = false;
   bool capturing = false;
@@ -640,8 +643,9 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->cur_cloud = m->d_cloud;
   {
     const char *e = getenv("SDM_GRAPH");
-    if (e && e[0] >= '0' && e[0] <= '2') m->graph_mode = e[0] - '0';
-    m->use_graph = m->graph_mode == 1;
+    if (e && e[0] >= '0' && e[0] <= '3') m->graph_mode = e[0] - '0';
+    m->use_graph = m->graph_mode != 0;
+    m->graph_chain = m->graph_mode == 3;
     m->host_timing = getenv("SDM_HOST_TIMING") != nullptr;  // debugging aid: per-step host time of sdm_update on stderr at destroy
   }
   refresh_filter(m);
@@ -654,6 +658,21 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   launch_clear(d, m->st, m->stream, true);
   if ((rc = upload_stamps(m)) != SDM_OK) return rc;
   HIP_TRY(hipStreamSynchronize(m->stream));
+  {
+    // how fast does this host issue launches?  (fastest of three bursts of 16 empty kernels; decides the graph's shape)
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(1), 0, m->stream);
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < 16; ++i) hipLaunchKernelGGL(k_noop, dim3(1), dim3(1), 0, m->stream);
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      if (us < best) best = us;
+      HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    m->enqueue_us = best / 16.0 * LAUNCHES_PER_FRAME;
+    if (m->graph_mode == 2) m->graph_chain = m->enqueue_us > GRAPH_CHAIN_US;
+  }
   *out = m;
   return SDM_OK;
 }
@@ -1056,10 +1075,10 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
 namespace {
 
 // The frame as a graph: captured from the very launches above, instantiated once, replayed with the frame block as the
-// one parameter that changes.  Captured as ONE chain - the side streams' launches are issued on the main stream for the
-// capture: hipGraphLaunch of a chain of kernel nodes costs 7 us on the host, the same frame with its three forks and joins
-// 79 us (measured, ROCm 7.2: every fork / join is a separate submission with its own synchronisation) - next to 105 us
-// for issuing the launches one by one, that graph would buy nothing.
+// one parameter that changes.  Two shapes.  Branched: the frustum chain and the birth-candidate chain keep their side
+// streams and become branches.  Chain: their launches are issued on the main stream for the capture.  hipGraphLaunch of
+// a chain of 40 kernel nodes costs the host 5 us, of the branched graph 78 us (ROCm 7.2: a graph with forks and joins is
+// submitted piecewise, with synchronisation between the pieces) - against 105 us for issuing the launches one by one.
 sdm_status graph_capture(sdm_map *m) {
   if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
   if (m->graph) (void)hipGraphDestroy(m->graph);
@@ -1074,7 +1093,8 @@ sdm_status graph_capture(sdm_map *m) {
   m->sc.fa_side = m->d_fa[1];
   m->capturing = true;
   hipStream_t side[3] = {m->s_frustum, m->s_birth, m->s_moves};
-  m->s_frustum = m->s_birth = m->s_moves = m->stream;  // one chain
+  // (under capture the member count of the moving objects is issued on the main stream, frame_enqueue_start)
+  if (m->graph_chain) m->s_frustum = m->s_birth = m->stream;
   hipError_t e = hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal);
   sdm_status rc = SDM_OK;
   if (e == hipSuccess) {
@@ -1168,7 +1188,11 @@ sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *c
       (void)hipGraphExecDestroy(m->graph_exec);
       m->graph_exec = nullptr;
     }
-    if (!m->graph_exec) rc = graph_capture(m);
+    if (!m->graph_exec) {
+      const auto tc = std::chrono::steady_clock::now();
+      rc = graph_capture(m);
+      if (m->host_timing) fprintf(stderr, "sdm host timing: graph capture + instantiate %.0f us (%s)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc).count(), m->graph_chain ? "chain" : "branched");
+    }
     if (rc == SDM_OK) rc = graph_launch(m);
     if (rc != SDM_OK) m->use_graph = false;  // (the frame is lost; later frames take the plain launches)
   } else {
@@ -1179,13 +1203,6 @@ sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *c
     if (rc == SDM_OK) rc = sdm_frame_predict(m, nullptr);
     if (rc == SDM_OK) rc = sdm_update_finish(m, nullptr, 1, flags, stop_after);
     if (m->host_timing) m->t_direct_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    // graph_mode 2: how long does this host take to issue a plain frame?  Judged on the fastest of eight (the first
-    // ones pay code loading); above GRAPH_ENQUEUE_US the host, not the GPU, sets the frame rate and the graph pays.
-    if (m->graph_mode == 2 && would_be_plain && m->n_timed < 8) {
-      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-      if (us < m->enqueue_us_min) m->enqueue_us_min = us;
-      if (++m->n_timed == 8) m->use_graph = m->enqueue_us_min > GRAPH_ENQUEUE_US;
-    }
   }
   m->fused_ck = false;
   return rc;
@@ -1594,7 +1611,7 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
   for (int a = 0; a < 3; ++a) out->restamped_slabs[a] = m->restamped[a];
   out->graph_frames = (int64_t)m->n_graph_frames;
   out->direct_frames = (int64_t)m->n_direct_frames;
-  out->host_enqueue_us = m->enqueue_us_min < 1e29 ? m->enqueue_us_min : 0.0;
+  out->host_enqueue_us = m->enqueue_us;
   if (m->profiling) {
     int prev = 0;
     for (int sidx = 1; sidx <= 7; ++sidx) {

@@ -1,9 +1,10 @@
-"""The frame replayed as a hipGraph (SDM_GRAPH=1) against the CPU oracle, bit for bit.
+"""The frame replayed as a hipGraph against the CPU oracle, bit for bit.
 
-The default policy (SDM_GRAPH=2) only switches to the graph on a host that is slow at issuing launches, so the suite
-would not see the replay path on a fast box: these tests force it.  The graph is one chain of kernel nodes captured from
-the very launches of the launch-by-launch frame; what changes from frame to frame travels in the one kernel-node
-parameter that is updated before every replay."""
+The default policy (SDM_GRAPH=2) replays plain frames from the branched graph, or from the chain on a host that is slow
+at issuing launches, so a given box only ever sees one of the three ways a frame can be issued: these tests force each
+of them (SDM_GRAPH=0: launch by launch; 1: frustum and birth chains as branches; 3: one chain of kernel nodes).  The
+graph is captured from the very launches of the launch-by-launch frame; what changes from frame to frame travels in the
+one kernel-node parameter that is updated before every replay."""
 import os
 
 import numpy as np
@@ -15,11 +16,11 @@ from tests import parity_utils as pu
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def graph_mode():
+@pytest.fixture(params=["0", "1", "3"], ids=["launches", "branched", "chain"])
+def graph_mode(request):
     old = os.environ.get("SDM_GRAPH")
-    os.environ["SDM_GRAPH"] = "1"  # read when a map is created
-    yield
+    os.environ["SDM_GRAPH"] = request.param  # read when a map is created
+    yield request.param
     if old is None:
         os.environ.pop("SDM_GRAPH", None)
     else:
@@ -44,7 +45,7 @@ def test_graph_replay_matches_oracle(graph_mode, cfg_name, params_name, n_frames
         assert not rep, "\n".join(rep)
     st = g.stats()
     # the first frame after creation is the non-incremental one and takes the launches; the others are replays
-    assert st["graph_frames"] >= n_frames - 1, st
+    assert st["graph_frames"] == (0 if graph_mode == "0" else n_frames - 1), st
     g.close()
 
 
@@ -64,7 +65,7 @@ def test_graph_is_recaptured_when_parameters_change(graph_mode):
         rep = pu.compare_maps(o, g, S, check_bins=True, tag="frame %d: " % t)
         assert not rep, "\n".join(rep)
     st = g.stats()
-    assert st["graph_frames"] >= 5 and st["direct_frames"] >= 2, st
+    assert (st["graph_frames"] == 0 and st["direct_frames"] == 8) if graph_mode == "0" else (st["graph_frames"] == 6 and st["direct_frames"] == 2), st
     g.close()
 
 
@@ -81,5 +82,5 @@ def test_graph_replay_without_synchronisation(graph_mode):
     g.synchronize()
     rep = pu.compare_maps(o, g, S, tag="after 10 frames: ")
     assert not rep, "\n".join(rep)
-    assert g.stats()["graph_frames"] >= 9
+    assert g.stats()["graph_frames"] == (0 if graph_mode == "0" else 9)
     g.close()
