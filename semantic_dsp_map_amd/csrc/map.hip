@@ -24,13 +24,24 @@ namespace {
 
 thread_local std::string g_last_error;
 
-// A plain frame is replayed from a hipGraph.  Two shapes of it (graph_capture): with the frustum and the birth chains
-// as branches - hipGraphLaunch costs this host 78 us, the GPU needs 0.305 ms per benchmark frame (0.31 ms launch by
-// launch with 105 us of host time) - and as ONE chain - 5 us on the host, 0.40 ms on the GPU.  The chain pays where the
-// host needs longer than that to launch the branched graph, i.e. is about 4.5 times slower than this one.  The host's
-// speed is measured when the map is created: the time to issue 50 launches - a frame's worth - of an empty kernel
-// (this host: 39 us; the frame's real launches, with their arguments and events, take it 105 us).
-constexpr double GRAPH_CHAIN_US = 170.0;
+// How a plain frame is issued.  Measured on MI355X / ROCm 7.2 (host time inside sdm_update per frame; GPU time per
+// benchmark frame, frames back to back, several runs):
+//   launches  launch by launch, three side streams, events between them     105-160 us   0.312-0.325 ms, steady
+//   pieces    five chain graphs - frustum chain, birth-candidate chain, three sections of the main stream - launched on
+//             the streams of the launch-by-launch frame with the same events between them (hipGraphLaunch of a CHAIN
+//             of kernel nodes costs the host 5 us whatever its length; the events the rest)
+//                                                                            59-64 us     0.326-0.371 ms
+//   branched  one graph with the two side chains as branches: a graph with forks and joins is submitted piecewise by
+//             the runtime, with synchronisation between the pieces             78-100 us    0.305-0.345 ms
+//   chain     ONE chain of all 40 kernels, nothing overlaps                   5-7 us       0.397-0.406 ms, steady
+// The graphs' GPU times scatter from run to run on the same box; launch by launch is the steadiest and on average the
+// fastest on the GPU, and costs the host the most.  So the default goes by the host: launches while the host issues a
+// frame in well under a frame's GPU time, pieces on a host 2-4.5 x slower than this one, the chain beyond that (where
+// even the pieces' dozen calls would take longer than the chain needs on the GPU).  The host's speed is measured when
+// the map is created: the time to issue 50 launches - a frame's worth - of an empty kernel (this host: 34-40 us; the
+// frame's real launches, with their arguments and events, take it 105-160 us).
+enum { GRAPH_PIECES = 0, GRAPH_BRANCHED = 1, GRAPH_CHAIN = 2 };
+constexpr double GRAPH_PIECES_US = 75.0, GRAPH_CHAIN_US = 170.0;
 constexpr int LAUNCHES_PER_FRAME = 50;
 
 __global__ void k_noop() {}
@@ -114,10 +125,12 @@ struct sdm_map {
   const sdm_labeled_point *cur_cloud = nullptr;
   // The launch sequence of a plain frame (sdm_update, device-resident inputs, one GPU) does not depend on the frame:
   // it is captured once into a hipGraph and replayed with one kernel-node parameter update (the frame block) per frame.
-  // graph_mode (SDM_GRAPH): 0 never, 1 always the branched graph, 3 always the chain, 2 (default): the branched graph, or
-  // the chain on a host that is slow at issuing launches (measured at creation, GRAPH_CHAIN_US).
+  // graph_mode (SDM_GRAPH): 0 never, 1 the branched graph, 3 the chain, 4 the pieces, 2 (default): by the host's speed
+  // at issuing launches, measured at creation - launch by launch, the pieces (GRAPH_PIECES_US) or the chain (GRAPH_CHAIN_US).
   int graph_mode = 2;
-  bool use_graph = false, graph_chain = false;
+  bool use_graph = false;
+  int graph_shape = 0;             // GRAPH_PIECES / GRAPH_BRANCHED / GRAPH_CHAIN
+  hipGraphExec_t piece[5] = {};    // GRAPH_PIECES: frustum chain, birth chain, main stream part 1 / 2 / 3
   double enqueue_us = 0.0;  // measured at creation: host time to issue a frame's worth of launches
   double t_prepare_us = 0, t_setparams_us = 0, t_launch_us = 0, t_direct_us = 0;  // SDM_HOST_TIMING: host time per step of sdm_update
   bool host_timing = false;
@@ -643,9 +656,9 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->cur_cloud = m->d_cloud;
   {
     const char *e = getenv("SDM_GRAPH");
-    if (e && e[0] >= '0' && e[0] <= '3') m->graph_mode = e[0] - '0';
+    if (e && e[0] >= '0' && e[0] <= '4') m->graph_mode = e[0] - '0';
     m->use_graph = m->graph_mode != 0;
-    m->graph_chain = m->graph_mode == 3;
+    m->graph_shape = m->graph_mode == 1 ? GRAPH_BRANCHED : (m->graph_mode == 3 ? GRAPH_CHAIN : GRAPH_PIECES);
     m->host_timing = getenv("SDM_HOST_TIMING") != nullptr;  // debugging aid: per-step host time of sdm_update on stderr at destroy
   }
   refresh_filter(m);
@@ -671,7 +684,10 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
       HIP_TRY(hipStreamSynchronize(m->stream));
     }
     m->enqueue_us = best / 16.0 * LAUNCHES_PER_FRAME;
-    if (m->graph_mode == 2) m->graph_chain = m->enqueue_us > GRAPH_CHAIN_US;
+    if (m->graph_mode == 2) {
+      m->use_graph = m->enqueue_us > GRAPH_PIECES_US;
+      m->graph_shape = m->enqueue_us > GRAPH_CHAIN_US ? GRAPH_CHAIN : GRAPH_PIECES;
+    }
   }
   *out = m;
   return SDM_OK;
@@ -714,6 +730,8 @@ sdm_status sdm_destroy(sdm_map *m) {
   if (m->ev_frustum) (void)hipEventDestroy(m->ev_frustum);
   if (m->ev_birth) (void)hipEventDestroy(m->ev_birth);
   if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+  for (hipGraphExec_t &g : m->piece)
+    if (g) (void)hipGraphExecDestroy(g);
   if (m->graph) (void)hipGraphDestroy(m->graph);
   for (hipEvent_t e : {m->ev_fa, m->cap_begin, m->cap_frustum, m->cap_birth, m->cap_counts})
     if (e) (void)hipEventDestroy(e);
@@ -1094,7 +1112,7 @@ sdm_status graph_capture(sdm_map *m) {
   m->capturing = true;
   hipStream_t side[3] = {m->s_frustum, m->s_birth, m->s_moves};
   // (under capture the member count of the moving objects is issued on the main stream, frame_enqueue_start)
-  if (m->graph_chain) m->s_frustum = m->s_birth = m->stream;
+  if (m->graph_shape == GRAPH_CHAIN) m->s_frustum = m->s_birth = m->stream;
   hipError_t e = hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal);
   sdm_status rc = SDM_OK;
   if (e == hipSuccess) {
@@ -1160,6 +1178,93 @@ sdm_status graph_launch(sdm_map *m) {
   return SDM_OK;
 }
 
+// GRAPH_PIECES: the frame's kernels as five chain graphs.  Which kernels, in which order, on which stream and behind
+// which event is exactly what frame_enqueue_start / sdm_frame_moves / sdm_frame_predict / sdm_update_finish issue for a
+// plain frame (the member count of the moving objects on the main stream, as under capture); only k_frame_begin, whose
+// argument is the frame block, is launched directly.
+sdm_status pieces_capture(sdm_map *m) {
+  for (hipGraphExec_t &g : m->piece) {
+    if (g) (void)hipGraphExecDestroy(g);
+    g = nullptr;
+  }
+  HIP_TRY(hipStreamSynchronize(m->s_frustum));
+  HIP_TRY(hipStreamSynchronize(m->s_moves));
+  HIP_TRY(hipStreamSynchronize(m->s_birth));
+  m->sc.fa = m->d_fa[0];
+  m->sc.fa_side = m->d_fa[1];
+  const Dims &d = m->d;
+  auto capture = [&](hipStream_t st, int which, auto &&body) -> sdm_status {
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    body(st);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (e != hipSuccess || !g) {
+      set_error("hipStreamEndCapture", __FILE__, __LINE__, e != hipSuccess ? hipGetErrorString(e) : "no graph");
+      (void)hipGetLastError();
+      return SDM_ERR_HIP;
+    }
+    e = hipGraphInstantiate(&m->piece[which], g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) {
+      set_error("hipGraphInstantiate", __FILE__, __LINE__, hipGetErrorString(e));
+      return SDM_ERR_HIP;
+    }
+    return SDM_OK;
+  };
+  m->capturing = true;  // (launchers that skip work the host knows to be empty issue everything while this is set)
+  sdm_status rc = capture(m->s_frustum, 0, [&](hipStream_t st) { launch_frustum(d, m->sc, st); });
+  if (rc == SDM_OK)
+    rc = capture(m->s_birth, 1, [&](hipStream_t st) { m->birth_which = launch_birth_prepare(d, m->flt, m->bo, m->st, m->sc, st); });
+  if (rc == SDM_OK)
+    rc = capture(m->stream, 2, [&](hipStream_t st) {
+      launch_moves_count(d, m->st, m->sc, m->d_counts_local, st);
+      launch_moves_transform(d, m->flt, m->st, m->sc, m->d_counts_local, 1, 0, st);
+      launch_moves_finish(d, m->flt, m->st, m->sc, 1, m->cfg.shard_rank, st);
+      launch_remove(d, m->st, m->sc, st);
+    });
+  if (rc == SDM_OK)
+    rc = capture(m->stream, 3, [&](hipStream_t st) {
+      launch_visibility(d, m->st, m->sc, st);
+      launch_ck(d, m->flt, m->st, m->sc, m->d_ck_part, 1, st);
+      launch_weight(d, m->flt, m->st, m->sc, st);
+    });
+  if (rc == SDM_OK)
+    rc = capture(m->stream, 4, [&](hipStream_t st) {
+      launch_birth_replay(d, m->flt, m->st, m->sc, m->birth_which, st);
+      launch_occupancy(d, m->flt, m->st, m->sc.cnt, 0, st);
+    });
+  m->capturing = false;
+  m->graph_flt = m->flt;
+  return rc;
+}
+
+sdm_status pieces_launch(sdm_map *m) {
+  hipStream_t s = m->stream;
+  const auto t0 = std::chrono::steady_clock::now();
+  m->fb.set(m->d, m->st, m->sc, m->fa, true);  // k_frame_begin writes both copies of the frame block
+  launch_frame_begin(m->fb, s);
+  HIP_TRY(hipEventRecord(m->ev_begin, s));
+  HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->ev_begin, 0));
+  HIP_TRY(hipGraphLaunch(m->piece[0], m->s_frustum));
+  HIP_TRY(hipEventRecord(m->ev_frustum, m->s_frustum));
+  HIP_TRY(hipStreamWaitEvent(m->s_birth, m->ev_begin, 0));
+  HIP_TRY(hipGraphLaunch(m->piece[1], m->s_birth));
+  HIP_TRY(hipEventRecord(m->ev_birth, m->s_birth));
+  HIP_TRY(hipGraphLaunch(m->piece[2], s));
+  HIP_TRY(hipStreamWaitEvent(s, m->ev_frustum, 0));
+  HIP_TRY(hipGraphLaunch(m->piece[3], s));
+  HIP_TRY(hipStreamWaitEvent(s, m->ev_birth, 0));
+  HIP_TRY(hipGraphLaunch(m->piece[4], s));
+  if (m->host_timing) m->t_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  m->side_pending = true;
+  m->cur_depth = m->fa.depth;
+  m->cur_cloud = m->fa.cloud;
+  m->state_event_valid = false;
+  m->sweep_all = false;
+  m->n_graph_frames++;
+  return SDM_OK;
+}
+
 }  // namespace
 
 sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
@@ -1184,16 +1289,18 @@ sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *c
                               m->stream == m->own_stream && !m->sweep_all && !m->stamps_dirty;
   const bool plain = m->use_graph && would_be_plain;
   if (plain) {
-    if (m->graph_exec && memcmp(&m->graph_flt, &m->flt, sizeof(Filter)) != 0) {  // sdm_set_params / a new noise table since
-      (void)hipGraphExecDestroy(m->graph_exec);
-      m->graph_exec = nullptr;
-    }
-    if (!m->graph_exec) {
+    const bool pieces = m->graph_shape == GRAPH_PIECES;
+    bool have = pieces ? m->piece[4] != nullptr : m->graph_exec != nullptr;
+    if (have && memcmp(&m->graph_flt, &m->flt, sizeof(Filter)) != 0) have = false;  // sdm_set_params / a new noise table since
+    if (!have) {
       const auto tc = std::chrono::steady_clock::now();
-      rc = graph_capture(m);
-      if (m->host_timing) fprintf(stderr, "sdm host timing: graph capture + instantiate %.0f us (%s)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc).count(), m->graph_chain ? "chain" : "branched");
+      rc = pieces ? pieces_capture(m) : graph_capture(m);
+      if (m->host_timing)
+        fprintf(stderr, "sdm host timing: graph capture + instantiate %.0f us (%s)\n",
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc).count(),
+                pieces ? "pieces" : (m->graph_shape == GRAPH_CHAIN ? "chain" : "branched"));
     }
-    if (rc == SDM_OK) rc = graph_launch(m);
+    if (rc == SDM_OK) rc = pieces ? pieces_launch(m) : graph_launch(m);
     if (rc != SDM_OK) m->use_graph = false;  // (the frame is lost; later frames take the plain launches)
   } else {
     m->n_direct_frames++;

@@ -16,7 +16,7 @@ from tests import parity_utils as pu
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["0", "1", "3"], ids=["launches", "branched", "chain"])
+@pytest.fixture(params=["0", "1", "3", "4"], ids=["launches", "branched", "chain", "pieces"])
 def graph_mode(request):
     old = os.environ.get("SDM_GRAPH")
     os.environ["SDM_GRAPH"] = request.param  # read when a map is created
