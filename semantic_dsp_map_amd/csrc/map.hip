@@ -30,7 +30,7 @@ thread_local std::string g_last_error;
 //   pieces    five chain graphs - frustum chain, birth-candidate chain, three sections of the main stream - launched on
 //             the streams of the launch-by-launch frame with the same events between them (hipGraphLaunch of a CHAIN
 //             of kernel nodes costs the host 5 us whatever its length; the events the rest)
-//                                                                            59-64 us     0.326-0.371 ms
+//                                                                            45-95 us     0.335-0.364 ms
 //   branched  one graph with the two side chains as branches: a graph with forks and joins is submitted piecewise by
 //             the runtime, with synchronisation between the pieces             78-100 us    0.305-0.345 ms
 //   chain     ONE chain of all 40 kernels, nothing overlaps                   5-7 us       0.397-0.406 ms, steady
@@ -1181,7 +1181,9 @@ sdm_status graph_launch(sdm_map *m) {
 // GRAPH_PIECES: the frame's kernels as five chain graphs.  Which kernels, in which order, on which stream and behind
 // which event is exactly what frame_enqueue_start / sdm_frame_moves / sdm_frame_predict / sdm_update_finish issue for a
 // plain frame (the member count of the moving objects on the main stream, as under capture); only k_frame_begin, whose
-// argument is the frame block, is launched directly.
+// argument is the frame block, is launched directly.  (A version that mirrors the launch-by-launch frame completely -
+// member count as a sixth graph on its own stream, frustum and count chains started behind the previous frame's births -
+// was measured: 0.34-0.35 instead of 0.36 ms on the GPU, but 115 instead of 60 us on the host.)
 sdm_status pieces_capture(sdm_map *m) {
   for (hipGraphExec_t &g : m->piece) {
     if (g) (void)hipGraphExecDestroy(g);
@@ -1211,7 +1213,8 @@ sdm_status pieces_capture(sdm_map *m) {
     }
     return SDM_OK;
   };
-  m->capturing = true;  // (launchers that skip work the host knows to be empty issue everything while this is set)
+  // (every launch is issued, also those a launch-by-launch frame skips when the host knows there is nothing to move or
+  // remove: the kernels check on the device and return)
   sdm_status rc = capture(m->s_frustum, 0, [&](hipStream_t st) { launch_frustum(d, m->sc, st); });
   if (rc == SDM_OK)
     rc = capture(m->s_birth, 1, [&](hipStream_t st) { m->birth_which = launch_birth_prepare(d, m->flt, m->bo, m->st, m->sc, st); });
@@ -1233,7 +1236,6 @@ sdm_status pieces_capture(sdm_map *m) {
       launch_birth_replay(d, m->flt, m->st, m->sc, m->birth_which, st);
       launch_occupancy(d, m->flt, m->st, m->sc.cnt, 0, st);
     });
-  m->capturing = false;
   m->graph_flt = m->flt;
   return rc;
 }
