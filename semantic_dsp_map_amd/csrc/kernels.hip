@@ -368,7 +368,7 @@ __device__ __forceinline__ int occupancy_classify(uint32_t t0, uint32_t flag, ui
 // result entry is written only when it does not already hold that constant (bits 2-3 of the flag byte).  The others are
 // listed in LDS and handled in phase 2 with all lanes busy: the voxel's record (status, slot stamps, weights, tracks,
 // labels), vote, write-backs.  (Draining the list in a separate kernel was measured in round 1: the scattered fetches
-// then take longer than the whole fused sweep.  Giving this kernel the cooperative record fetch of k_occupancy_all for
+// then take longer than the whole fused sweep.  Giving this kernel the cooperative record fetch of k_occupancy_dense for
 // dense tiles was measured in round 2: the registers and LDS it needs cut the resident workgroups from 8 to 5 per CU
 // and the launch - 8192 workgroups of which most leave at once - went from 22 to 33 us.)
 constexpr int OCC_VPT = 8;  // consecutive voxels of one thread: one 16-byte load of stamps, one 8-byte load of flags
