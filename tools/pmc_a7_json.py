@@ -3,8 +3,9 @@
 (averages per launch), instruction mix per wave, VALU and LDS issue utilisation.
 
 Utilisation = quad-cycles the SIMDs spent issuing that instruction class (SQ_ACTIVE_INST_*: one count = 4 shader cycles of
-one SIMD, MI355X_MICROARCH.md) / (kernel duration in shader cycles / 4 x 1024 SIMDs); the duration comes from
-GRBM_GUI_ACTIVE of the same dispatch."""
+one SIMD, MI355X_MICROARCH.md) / (kernel duration x 2.4 GHz / 4 x 1024 SIMDs); the duration is the dispatch's in the
+kernel trace of the same run.  (GRBM_GUI_ACTIVE, which an earlier version of this script divided by, is summed over the
+8 XCDs - 8 x the kernel's cycles - and made every utilisation 8 x too small.)"""
 import csv
 import glob
 import json
@@ -14,6 +15,7 @@ from collections import defaultdict
 tag = sys.argv[1]
 KERNELS = ("k_ck_light", "k_ck_heavy", "k_weight", "k_visibility", "k_birth_replay", "k_occupancy<")
 SIMDS = 256 * 4
+CLOCK_MHZ = 2400.0
 
 
 def short(n):
@@ -41,8 +43,8 @@ for wl in ("c3", "stress"):
     res = {}
     for k in sorted(acc):
         c = {n: sum(v) / len(v) for n, v in acc[k].items()}
-        gui = c.get("GRBM_GUI_ACTIVE", 0.0)
-        quads = gui / 4.0 * SIMDS if gui else 0.0
+        dur_us = sum(dur[k]) / max(len(dur[k]), 1)
+        quads = dur_us * CLOCK_MHZ / 4.0 * SIMDS
         waves = max(c.get("SQ_WAVES", 1.0), 1.0)
         res[k] = {"launches": max(len(v) for v in acc[k].values()), "avg_us_under_pmc": round(sum(dur[k]) / max(len(dur[k]), 1), 2),
                   "counters": {n: round(v, 1) for n, v in sorted(c.items())},
@@ -50,6 +52,7 @@ for wl in ("c3", "stress"):
                                "lds": round(c.get("SQ_INSTS_LDS", 0) / waves, 1), "vmem": round(c.get("SQ_INSTS_VMEM", 0) / waves, 1)},
                   "valu_issue_utilisation": round(c.get("SQ_ACTIVE_INST_VALU", 0) / quads, 4) if quads else None,
                   "lds_issue_utilisation": round(c.get("SQ_ACTIVE_INST_LDS", 0) / quads, 4) if quads else None,
+                  "any_issue_utilisation": round(c.get("SQ_ACTIVE_INST_ANY", 0) / quads, 4) if quads else None,
                   "lds_bank_conflict_fraction": round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], 4)
                   if c.get("SQ_LDS_IDX_ACTIVE") else None,
                   "wave_time_split": {n: round(c.get(s, 0) / c["SQ_WAVE_CYCLES"], 3) for n, s in
