@@ -1397,10 +1397,11 @@ constexpr int A7_ITEMS = 16;  // pixels / particles per workgroup
 constexpr uint32_t CK_LIGHT_MAX = 4;
 
 __device__ __forceinline__ float ck_term(const Filter &flt, const float *__restrict__ pdf, const float4 pv, const uint32_t tf,
-                                         const sdm_labeled_point &o, bool &skip) {
+                                         const sdm_labeled_point &o, float rsig, bool &skip) {
   const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
   skip = flt.independent && ptrack != o.track_id;
-  float gk = query_pdf(pdf, pv.x, o.x, o.sigma) * query_pdf(pdf, pv.y, o.y, o.sigma) * query_pdf(pdf, pv.z, o.z, o.sigma);
+  float gk = query_pdf_r(pdf, pv.x, o.x, o.sigma, rsig) * query_pdf_r(pdf, pv.y, o.y, o.sigma, rsig) *
+             query_pdf_r(pdf, pv.z, o.z, o.sigma, rsig);
   if (!flt.independent) {
     gk *= flt.forget[(tf >> 16) & 7];
     if (ptrack != o.track_id) gk *= flt.id_transition;
@@ -1455,13 +1456,14 @@ __global__ __launch_bounds__(TPB) void k_ck_light(Dims d, Filter flt, State st, 
   float ck = 0.f;
   if (total) {
     const float *__restrict__ pdf = st.pdf;
+    const float rsig = div_recip(o.sigma);
 #pragma unroll
     for (int r = 0; r < A7_ROWS; ++r) {
       if (ss[r] == ee[r]) continue;  // an empty row adds +0
       float acc = 0.f;
       for (uint32_t k = ss[r]; k < ee[r]; ++k) {
         bool skip;
-        const float t = ck_term(flt, pdf, sc.vp4[k], sc.vtf[k], o, skip);
+        const float t = ck_term(flt, pdf, sc.vp4[k], sc.vtf[k], o, rsig, skip);
         if (!skip) acc += t;
       }
       ck += acc;
@@ -1482,7 +1484,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
   __shared__ float rowsum[A7_ITEMS][A7_ROWS];
   __shared__ uint32_t rowoff[A7_ITEMS * A7_ROWS + 1];  // exclusive prefix of the row lengths, flattened (pixel, row)
   __shared__ uint32_t rowbeg[A7_ITEMS * A7_ROWS];      // first bin entry of the row
-  __shared__ float opx[A7_ITEMS][4];                   // x, y, z, sigma of the pixel's point
+  __shared__ float opx[A7_ITEMS][5];                   // x, y, z, sigma of the pixel's point, div_recip(sigma)
   __shared__ uint32_t otrk[A7_ITEMS];
   __shared__ float term[CK_TERM_CAP];
   const int r = threadIdx.x, it = threadIdx.y;
@@ -1522,6 +1524,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
         opx[it][1] = o.y;
         opx[it][2] = o.z;
         opx[it][3] = o.sigma;
+        opx[it][4] = div_recip(o.sigma);
         otrk[it] = o.track_id;
       }
     }
@@ -1592,7 +1595,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
           oo.sigma = opx[px[u]][3];
           oo.track_id = (uint16_t)otrk[px[u]];
           bool skip;
-          const float t = ck_term(flt, pdf, pv[u], tf[u], oo, skip);
+          const float t = ck_term(flt, pdf, pv[u], tf[u], oo, opx[px[u]][4], skip);
           term[g0 + (uint32_t)u * 256u - base] = skip ? -0.f : t;  // x + (-0) == x: a skipped term leaves the sum untouched
         }
       }
@@ -1657,6 +1660,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Filter flt
       const int ni = i + r - h;
       if (ni >= 0 && ni < d.H) {
         const float sigma = cloud_img[p].sigma;  // sigma of the particle's own pixel (semantic_dsp_map.h:1047)
+        const float rsig = div_recip(sigma);
         const float4 pv = sc.vp4[k];
         const uint32_t tf = sc.vtf[k];
         const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
@@ -1679,8 +1683,8 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Filter flt
             if (!(ot[u] >> 16)) continue;  // outside the window / image, or an invalid pixel
             const uint16_t otrack = (uint16_t)(ot[u] & 0xffffu);
             if (flt.independent && otrack != ptrack) continue;
-            float gk = query_pdf(pdf, pv.x, o[u].x, sigma) * query_pdf(pdf, pv.y, o[u].y, sigma) *
-                       query_pdf(pdf, pv.z, o[u].z, sigma);
+            float gk = query_pdf_r(pdf, pv.x, o[u].x, sigma, rsig) * query_pdf_r(pdf, pv.y, o[u].y, sigma, rsig) *
+                       query_pdf_r(pdf, pv.z, o[u].z, sigma, rsig);
             if (!flt.independent) {
               if (ptrack != otrack) {
                 gk *= flt.id_transition;

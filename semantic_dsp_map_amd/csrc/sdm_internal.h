@@ -304,6 +304,36 @@ __device__ __forceinline__ float query_pdf(const float *__restrict__ pdf, float 
   return pdf[(int)(c * 1000 + 10000)];
 }
 
+// The weight update divides three coordinates by the same sigma for every particle-pixel pair, and its kernels are
+// bound by instruction issue (profiles/r02_a7_sq.json).  The compiler's IEEE division is v_div_scale x 2, v_rcp, two
+// Newton steps on the reciprocal, the quotient with two residual corrections, v_div_fmas, v_div_fixup - 11
+// instructions, of which the scaling and the fix-up only matter at extreme exponents and the reciprocal depends on the
+// denominator alone.  div_recip + div_by are the same arithmetic without them: the reciprocal once per sigma, five
+// instructions per quotient.  tools/probes/div_probe.hip compares the bits with a / b for EVERY float b in
+// [2^-10, 2^10] and numerators 0, 1e-7, around 9.9 b and with exponents -40 .. 20 (1.3e9 pairs, no mismatch apart from
+// -0 / b = -0 coming out as +0, which selects the same table entry).  Outside that range of sigma div_recip returns 0
+// and the plain division is used.  A numerator beyond the probed exponents cannot select a different entry either:
+// smaller ones land on the table's centre with any rounding, larger ones (or an overflow to NaN) outside its range.
+__device__ __forceinline__ float div_recip(float b) {
+  if (!(b >= 0.0009765625f && b <= 1024.f)) return 0.f;
+  const float r0 = __builtin_amdgcn_rcpf(b);
+  const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+  return __builtin_fmaf(e0, r0, r0);
+}
+__device__ __forceinline__ float div_by(float a, float b, float r) {
+  const float q0 = a * r;
+  const float e1 = __builtin_fmaf(-b, q0, a);
+  const float q1 = __builtin_fmaf(e1, r, q0);
+  const float e2 = __builtin_fmaf(-b, q1, a);
+  return __builtin_fmaf(e2, r, q1);
+}
+// query_pdf with the reciprocal of sigma from div_recip (0 = divide)
+__device__ __forceinline__ float query_pdf_r(const float *__restrict__ pdf, float x, float mu, float sigma, float rsig) {
+  const float c = rsig != 0.f ? div_by(x - mu, sigma, rsig) : (x - mu) / sigma;
+  if (!(fabsf(c) <= 9.9f)) return 1e-9f;
+  return pdf[(uint32_t)(int)(c * 1000 + 10000)];  // 100 .. 19900: an unsigned offset spares the 64-bit address arithmetic
+}
+
 // ---- primitives (primitives.hip) ------------------------------------------------------
 // exclusive prefix sum of n uint32; in == out allowed. scratch must hold scan_scratch_elems(n) uint32.  If n_dev is not
 // null the element count is min(*n_dev, n) read on the device (n is then the capacity the launch is sized for).
