@@ -11,6 +11,8 @@
 // is written in the reference's operation order with contraction off.
 #include <algorithm>
 
+#include <type_traits>
+
 #include "sdm_internal.h"
 #include "sdm_scratch.h"
 
@@ -1396,12 +1398,13 @@ constexpr int A7_ITEMS = 16;  // pixels / particles per workgroup
 // order (canonical order) - the value does not depend on which kernel produced it.
 constexpr uint32_t CK_LIGHT_MAX = 4;
 
+template <bool FAST>
 __device__ __forceinline__ float ck_term(const Filter &flt, const float *__restrict__ pdf, const float4 pv, const uint32_t tf,
                                          const sdm_labeled_point &o, float rsig, bool &skip) {
   const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
   skip = flt.independent && ptrack != o.track_id;
-  float gk = query_pdf_r(pdf, pv.x, o.x, o.sigma, rsig) * query_pdf_r(pdf, pv.y, o.y, o.sigma, rsig) *
-             query_pdf_r(pdf, pv.z, o.z, o.sigma, rsig);
+  float gk = query_pdf_r<FAST>(pdf, pv.x, o.x, o.sigma, rsig) * query_pdf_r<FAST>(pdf, pv.y, o.y, o.sigma, rsig) *
+             query_pdf_r<FAST>(pdf, pv.z, o.z, o.sigma, rsig);
   if (!flt.independent) {
     gk *= flt.forget[(tf >> 16) & 7];
     if (ptrack != o.track_id) gk *= flt.id_transition;
@@ -1454,20 +1457,25 @@ __global__ __launch_bounds__(TPB) void k_ck_light(Dims d, Filter flt, State st, 
     return;
   }
   float ck = 0.f;
-  if (total) {
-    const float *__restrict__ pdf = st.pdf;
-    const float rsig = div_recip(o.sigma);
+  const float *__restrict__ pdf = st.pdf;
+  const float rsig = total ? div_recip(o.sigma) : 1.f;
+  auto rows = [&](auto fast) {
 #pragma unroll
     for (int r = 0; r < A7_ROWS; ++r) {
       if (ss[r] == ee[r]) continue;  // an empty row adds +0
       float acc = 0.f;
       for (uint32_t k = ss[r]; k < ee[r]; ++k) {
         bool skip;
-        const float t = ck_term(flt, pdf, sc.vp4[k], sc.vtf[k], o, rsig, skip);
+        const float t = ck_term<decltype(fast)::value>(flt, pdf, sc.vp4[k], sc.vtf[k], o, rsig, skip);
         if (!skip) acc += t;
       }
       ck += acc;
     }
+  };
+  if (__ballot(rsig == 0.f) == 0ull) {  // wave-uniform: every sigma of the wave inside the range div_by is verified for
+    if (total) rows(std::true_type{});
+  } else {
+    if (total) rows(std::false_type{});
   }
   ck_store(flt, sc, ck_out, finish, p, o, ck);
 }
@@ -1497,10 +1505,13 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
   // batches of 16 listed pixels are handed out by a ticket counter (per shard): window sizes are very uneven, a fixed
   // assignment leaves the kernel waiting for the workgroup that drew the long batches.  Which workgroup computes a pixel
   // does not change its value.
-  __shared__ uint32_t s_q0;
+  __shared__ uint32_t s_q0, s_slow;
   for (;;) {
     __syncthreads();
-    if (lane == 0) s_q0 = atomicAdd(&sc.cnt->shard[shard].heavy_ticket, (uint32_t)A7_ITEMS);
+    if (lane == 0) {
+      s_q0 = atomicAdd(&sc.cnt->shard[shard].heavy_ticket, (uint32_t)A7_ITEMS);
+      s_slow = 0;  // set by a pixel whose sigma is outside the range div_by is verified for
+    }
     __syncthreads();
     const uint32_t q0 = s_q0;
     if (q0 >= n) break;
@@ -1525,6 +1536,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
         opx[it][2] = o.z;
         opx[it][3] = o.sigma;
         opx[it][4] = div_recip(o.sigma);
+        if (opx[it][4] == 0.f) s_slow = 1;
         otrk[it] = o.track_id;
       }
     }
@@ -1560,6 +1572,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
       const uint32_t cnt = total - base < CK_TERM_CAP ? total - base : CK_TERM_CAP;
       // lane l computes terms base + l, base + l + 256, ...; four at a time, so that the loads of four
       // independent terms are in flight together (a lane's terms are otherwise a chain of dependent loads)
+      auto terms = [&](auto fast) {
       for (uint32_t g0 = base + (uint32_t)lane; g0 < base + cnt; g0 += 4u * 256u) {
         float4 pv[4];
         uint32_t tf[4];
@@ -1595,10 +1608,12 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
           oo.sigma = opx[px[u]][3];
           oo.track_id = (uint16_t)otrk[px[u]];
           bool skip;
-          const float t = ck_term(flt, pdf, pv[u], tf[u], oo, opx[px[u]][4], skip);
+          const float t = ck_term<decltype(fast)::value>(flt, pdf, pv[u], tf[u], oo, opx[px[u]][4], skip);
           term[g0 + (uint32_t)u * 256u - base] = skip ? -0.f : t;  // x + (-0) == x: a skipped term leaves the sum untouched
         }
       }
+      };
+      if (!s_slow) terms(std::true_type{}); else terms(std::false_type{});  // workgroup-uniform
       __syncthreads();
       {
         const uint32_t a = my_a > base ? my_a : base;
@@ -1655,12 +1670,15 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Filter flt
     int right = 0;
     uint32_t p = 0;
     if (k < n) p = sc.vpix[k];
-    if (k < n && r <= 2 * h) {
+    // sigma of the particle's own pixel (semantic_dsp_map.h:1047); which division the wave's pairs take (div_by is
+    // verified for a range of sigma, div_recip returns 0 outside it) is decided for the wave as a whole
+    const float sigma = k < n ? cloud_img[p].sigma : 1.f;
+    const float rsig = div_recip(sigma);
+    const bool wave_fast = __ballot(rsig == 0.f) == 0ull;
+    auto row = [&](auto fast) {
       const int i = p / d.W, j = p % d.W;
       const int ni = i + r - h;
       if (ni >= 0 && ni < d.H) {
-        const float sigma = cloud_img[p].sigma;  // sigma of the particle's own pixel (semantic_dsp_map.h:1047)
-        const float rsig = div_recip(sigma);
         const float4 pv = sc.vp4[k];
         const uint32_t tf = sc.vtf[k];
         const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
@@ -1683,8 +1701,9 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Filter flt
             if (!(ot[u] >> 16)) continue;  // outside the window / image, or an invalid pixel
             const uint16_t otrack = (uint16_t)(ot[u] & 0xffffu);
             if (flt.independent && otrack != ptrack) continue;
-            float gk = query_pdf_r(pdf, pv.x, o[u].x, sigma, rsig) * query_pdf_r(pdf, pv.y, o[u].y, sigma, rsig) *
-                       query_pdf_r(pdf, pv.z, o[u].z, sigma, rsig);
+            constexpr bool F = decltype(fast)::value;
+            float gk = query_pdf_r<F>(pdf, pv.x, o[u].x, sigma, rsig) * query_pdf_r<F>(pdf, pv.y, o[u].y, sigma, rsig) *
+                       query_pdf_r<F>(pdf, pv.z, o[u].z, sigma, rsig);
             if (!flt.independent) {
               if (ptrack != otrack) {
                 gk *= flt.id_transition;
@@ -1697,6 +1716,11 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Filter flt
           }
         }
       }
+    };
+    if (wave_fast) {
+      if (k < n && r <= 2 * h) row(std::true_type{});
+    } else {
+      if (k < n && r <= 2 * h) row(std::false_type{});
     }
     rowsum[it][r] = acc;
     rowflag[it][r] = right;

@@ -327,9 +327,11 @@ __device__ __forceinline__ float div_by(float a, float b, float r) {
   const float e2 = __builtin_fmaf(-b, q1, a);
   return __builtin_fmaf(e2, r, q1);
 }
-// query_pdf with the reciprocal of sigma from div_recip (0 = divide)
+// query_pdf with the reciprocal of sigma from div_recip.  FAST = the caller has checked, for the whole wave, that no
+// lane's reciprocal is 0 (a test per quotient costs the scalar unit what the shorter division saves the vector unit).
+template <bool FAST>
 __device__ __forceinline__ float query_pdf_r(const float *__restrict__ pdf, float x, float mu, float sigma, float rsig) {
-  const float c = rsig != 0.f ? div_by(x - mu, sigma, rsig) : (x - mu) / sigma;
+  const float c = FAST ? div_by(x - mu, sigma, rsig) : (x - mu) / sigma;
   if (!(fabsf(c) <= 9.9f)) return 1e-9f;
   return pdf[(uint32_t)(int)(c * 1000 + 10000)];  // 100 .. 19900: an unsigned offset spares the 64-bit address arithmetic
 }
