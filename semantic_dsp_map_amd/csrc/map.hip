@@ -90,7 +90,6 @@ struct sdm_map {
   bool state_event_valid = false;
   hipEvent_t ev_begin = nullptr, ev_frustum = nullptr, ev_birth = nullptr;
   int birth_which = 0;
-  bool side_pending = false;
   float *ck_user = nullptr;
   bool fused_ck = false;  // single-GPU sdm_update: pass 1 writes ck+kappa directly
   int32_t stop_after = 0;
@@ -139,7 +138,7 @@ struct sdm_map {
   hipGraphExec_t graph_exec = nullptr;
   hipGraphNode_t graph_set_node = nullptr;
   Filter graph_flt{};          // the filter parameters baked into the captured launches
-  hipEvent_t cap_begin = nullptr, cap_frustum = nullptr, cap_birth = nullptr, cap_counts = nullptr;
+  hipEvent_t cap_begin = nullptr, cap_frustum = nullptr, cap_birth = nullptr;
   uint64_t n_graph_frames = 0, n_direct_frames = 0;
   int restamped[3]{};        // slabs re-stamped by the last frame's ring shift, per axis
   bool stamps_dirty = true;  // device copy of the stamp arrays needs a full upload
@@ -535,7 +534,6 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   HIP_TRY(hipEventCreateWithFlags(&m->cap_begin, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->cap_frustum, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->cap_birth, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&m->cap_counts, hipEventDisableTiming));
   const size_t n_slots = (size_t)d.v_count * d.S;
   const size_t hw = (size_t)d.W * d.H;
   sdm_status rc;
@@ -733,7 +731,7 @@ sdm_status sdm_destroy(sdm_map *m) {
   for (hipGraphExec_t &g : m->piece)
     if (g) (void)hipGraphExecDestroy(g);
   if (m->graph) (void)hipGraphDestroy(m->graph);
-  for (hipEvent_t e : {m->ev_fa, m->cap_begin, m->cap_frustum, m->cap_birth, m->cap_counts})
+  for (hipEvent_t e : {m->ev_fa, m->cap_begin, m->cap_frustum, m->cap_birth})
     if (e) (void)hipEventDestroy(e);
   if (m->s_frustum) (void)hipStreamDestroy(m->s_frustum);
   if (m->s_birth) (void)hipStreamDestroy(m->s_birth);
@@ -925,11 +923,9 @@ sdm_status frame_enqueue_start(sdm_map *m) {
     launch_moves_count(d, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves);
     HIP_TRY(hipEventRecord(m->ev_counts, m->s_moves));
   }
-  m->side_pending = false;
   if (!stage_done(stop_after, 3)) {
     launch_frustum(d, m->sc, m->s_frustum);
     HIP_TRY(hipEventRecord(m->capturing ? m->cap_frustum : m->ev_frustum, m->s_frustum));
-    m->side_pending = true;
   }
   if (!stage_done(stop_after, 5)) {
     // the birth candidates read this frame's cloud and the birth cursor: after this frame's k_frame_begin
@@ -1258,7 +1254,6 @@ sdm_status pieces_launch(sdm_map *m) {
   HIP_TRY(hipStreamWaitEvent(s, m->ev_birth, 0));
   HIP_TRY(hipGraphLaunch(m->piece[4], s));
   if (m->host_timing) m->t_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-  m->side_pending = true;
   m->cur_depth = m->fa.depth;
   m->cur_cloud = m->fa.cloud;
   m->state_event_valid = false;
