@@ -1495,6 +1495,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
   __shared__ float opx[A7_ITEMS][5];                   // x, y, z, sigma of the pixel's point, div_recip(sigma)
   __shared__ uint32_t otrk[A7_ITEMS];
   __shared__ float term[CK_TERM_CAP];
+  __shared__ uint8_t rowof[CK_TERM_CAP];              // which (pixel, row) a term of the pass belongs to
   const int r = threadIdx.x, it = threadIdx.y;
   const int lane = it * A7_ROWS + r;
   const int h = d.window_half;
@@ -1570,6 +1571,14 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
     float acc = 0.f;
     for (uint32_t base = 0; base < total; base += CK_TERM_CAP) {
       const uint32_t cnt = total - base < CK_TERM_CAP ? total - base : CK_TERM_CAP;
+      // every row marks its slice of the pass (a search for the row of each term cost 8 LDS reads and 40 instructions per
+      // term)
+      {
+        const uint32_t a = my_a > base ? my_a : base;
+        const uint32_t b = my_b < base + cnt ? my_b : base + cnt;
+        for (uint32_t t = a; t < b; ++t) rowof[t - base] = (uint8_t)lane;
+      }
+      __syncthreads();
       // lane l computes terms base + l, base + l + 256, ...; four at a time, so that the loads of four
       // independent terms are in flight together (a lane's terms are otherwise a chain of dependent loads)
       auto terms = [&](auto fast) {
@@ -1584,14 +1593,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
           on[u] = g < base + cnt;
           px[u] = 0;
           if (on[u]) {
-            // row that holds term g: largest index with rowoff[idx] <= g (rows of length 0 share an offset with
-            // their successor and are never selected)
-            int lo = 0, hi = A7_ITEMS * A7_ROWS;
-#pragma unroll
-            for (int step = 0; step < 8; ++step) {
-              const int mid = (lo + hi) >> 1;
-              if (rowoff[mid] <= g) lo = mid; else hi = mid;
-            }
+            const int lo = rowof[g - base];
             const uint32_t k = rowbeg[lo] + (g - rowoff[lo]);
             px[u] = lo / A7_ROWS;
             pv[u] = sc.vp4[k];
