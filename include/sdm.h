@@ -191,7 +191,11 @@ sdm_status sdm_download_pdf_table(sdm_map *m, float *table, int32_t n);
  *   moves          objects the object layer decided to move this frame (:593-693), caller's order
  *   remove_tracks  lost / floating objects to wipe (:702-736)
  *   stop_after     SDM_STAGE_ALL, or a stage id to stop after (parity debugging)
- * Asynchronous: returns after enqueueing; results are fetched with the getters below. */
+ * Asynchronous: returns after enqueueing; results are fetched with the getters below.
+ * How the frame's ~50 kernels are issued follows the host's speed at issuing launches, measured in sdm_create
+ * (sdm_stats.host_enqueue_us): launch by launch on a fast host, replayed from hipGraphs on a slow one.  The environment
+ * variable SDM_GRAPH forces one way (0 launch by launch, 4 five chain graphs, 3 one chain graph, 1 one branched graph;
+ * read when the map is created); the results are bit-identical. */
 sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *cloud,
                       const float cam_pos[3], const float cam_q[4],
                       const sdm_object_move *moves, int32_t n_moves,
