@@ -8,7 +8,8 @@ SMC-PHD weight update, births + resampling, occupancy/semantic sweep), inputs re
   N = 1 : BASELINE config C3 — 256^3 voxels, 8 slots/voxel, ~2M live particles, 1242x375 VKITTI2 camera,
           dynamic objects (4x4 transforms), cfg/options_virtual_kitti2.yaml parameters.
   N > 1 : weak scaling, 2^24 voxels and ~2M particles per GPU (…C5 = 512^3 / 16M particles at N = 8),
-          Z-slab shards, one process per GPU, all-gather of the partial ck images over RCCL.
+          Z-slab shards, one process per GPU, exchanges over RCCL inside the library (member counts, slab-crossing
+          copies, chunk-owner reduction of the partial ck images); per-collective GPU times in `collectives_us`.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with two extra objects:
   roofline     — occupancy/semantic sweep kernel: algorithmic bytes (80 B/voxel at 8 slots)
@@ -256,6 +257,10 @@ def main():
     # and the tiles it looked into come from the library's counters.
     n_extra = 6
     m.set_profiling(True)
+    if world > 1:
+        m.comm_timing(True)
+
+    comm_us = {}
 
     def profiled(t_lo, t_hi):
         acc, live_l, tiles_l, slabs = np.zeros(8), [], [], np.zeros(3)
@@ -264,6 +269,9 @@ def main():
             dd, dc = m.device_put(depth), m.device_put(cloud)
             eng.update(dd, dc, pos, q, scene.moves(t))
             m.synchronize()
+            if world > 1:
+                for k, v in m.comm_times().items():
+                    comm_us.setdefault(k, []).append(v)
             stt = m.stats()
             acc += np.array(stt["stage_ms"])
             live_l.append(stt["sweep_live_voxels"])
@@ -278,6 +286,27 @@ def main():
     scene.lateral_extra = (n_frames + n_extra - 1, cfg["voxel_size"])
     xs_stage, xs_live, xs_tiles, xs_slabs = profiled(n_frames + n_extra, n_frames + 2 * n_extra)
     m.set_profiling(False)
+    collectives = None
+    if world > 1:
+        # GPU time of each collective of a sharded frame (HIP events around it on the stream it is issued on; includes
+        # waiting for the slowest shard to arrive), averaged over the profiled frames, max over the ranks; and what a shard
+        # receives per frame
+        m.comm_timing(False)
+        import torch
+        names = sorted(comm_us)
+        ct = torch.tensor([float(np.mean(comm_us[k])) for k in names], dtype=torch.float64)
+        dist.all_reduce(ct, op=dist.ReduceOp.MAX)
+        chunk = m.ck_chunk_elems()
+        seg = sharded.halo_segment_bytes(sharded.HALO_DEFAULT_CAP)
+        collectives = {"us": {k: round(float(v), 1) for k, v in zip(names, ct.tolist())},
+                       "frames_timed": 2 * n_extra,
+                       "bytes_received_per_shard_per_frame": {"counts_allgather": (world - 1) * sharded.HALO_OBJ * 4,
+                                                              "halo_alltoall": (world - 1) * seg,
+                                                              "ck_alltoall": (world - 1) * chunk * 4,
+                                                              "ck_allgather": (world - 1) * chunk * 4},
+                       "note": "counts_allgather rides the member-count stream beside the previous frame's sweep; the other "
+                               "three are on the frame's critical path"}
+        collectives["us_on_critical_path"] = round(sum(v for k, v in collectives["us"].items() if k != "counts_allgather"), 1)
     sweep_ms = float(stage_ms[7])
     ms_per_step = dt * 1e3 / args.steps
     value = V / (dt / args.steps) / 1e6  # Mvoxels / s, whole map (all shards)
@@ -383,6 +412,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if collectives is not None:
+            out["collectives_us"] = collectives
         if strong is not None:
             out["strong_scaling"] = strong
         if stress is not None:

@@ -247,10 +247,11 @@ sdm_status sdm_get_labeled_cloud(sdm_map *m, sdm_labeled_point *out);
 
 /* The same frame split at its one cross-shard dependency: sdm_update_begin runs the
  * prediction, visibility/binning and this shard's partial ck image (pass 1 of updateParticles,
- * semantic_dsp_map.h:973-1037) and hands back its device pointer; the caller gathers the partial images of
- * all Z-slab shards (RCCL all-gather) and passes them, in slab order, to sdm_update_finish, which forms
- * ck+kappa, updates the weights and runs births, resampling and the occupancy sweep.
- * sdm_update == begin + finish with the shard's own image. */
+ * semantic_dsp_map.h:973-1037) and hands back its device pointer; the partial images of all Z-slab shards are summed
+ * IN SLAB ORDER (see sdm_ck_reduce for the exchange that does it with 2 (G-1)/G images of traffic) and the result goes
+ * to sdm_update_finish, which forms ck+kappa, updates the weights and runs births, resampling and the occupancy sweep.
+ * sdm_update_finish accepts either n_parts whole partial images in slab order (it adds them itself) or, with
+ * n_parts = 1, the image already summed.  sdm_update == begin + finish with the shard's own image. */
 sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_point *cloud,
                             const float cam_pos[3], const float cam_q[4],
                             const sdm_object_move *moves, int32_t n_moves,
@@ -261,12 +262,20 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
 /* sdm_update_begin itself in three steps, for sharded maps whose moving objects cross slab borders
  * (moveParticlesInSetsByTransformations, mc_ring/operations.h:321-362, needs the other shards twice):
  *   sdm_frame_start   -> all-gather of the per-object member counts (SDM_HALO_OBJ int32 per shard)
- *   sdm_frame_moves   -> all-gather of the export buffers (copies whose target voxel lies in another slab)
- *   sdm_frame_predict -> all-gather of the partial ck images -> sdm_update_finish
- * The exchange buffers are device memory owned by the caller and registered once with sdm_set_halo_buffers. */
+ *   sdm_frame_moves   -> all-to-all of the export segments: a copy whose target voxel lies in another slab goes to
+ *                        the shard that owns that slab, and to nobody else
+ *   sdm_frame_predict -> chunk-owner exchange of the partial ck images (below) -> sdm_update_finish
+ * The exchange buffers are device memory owned by the caller and registered once with sdm_set_halo_buffers:
+ *   counts_local  SDM_HALO_OBJ int32                      counts_all  shard_count x SDM_HALO_OBJ int32 (gathered)
+ *   send, recv    shard_count segments of SDM_HALO_HEADER_BYTES + cap_records x SDM_HALO_RECORD_BYTES each; segment d of
+ *                 send is addressed to shard d, segment s of recv is what shard s addressed to this one.
+ * cap_records is the capacity PER DESTINATION; more slab-crossing copies towards one shard in one frame than that is a
+ * capacity error (SDM_ERR_CAPACITY at the next sdm_synchronize; the copies beyond it are dropped like copies whose
+ * target voxel is full, mc_ring/operations.h:357). */
 #define SDM_HALO_OBJ 64
 #define SDM_HALO_RECORD_BYTES 36
 #define SDM_HALO_HEADER_BYTES 16
+#define SDM_HALO_DEFAULT_CAP 1024
 sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_point *cloud,
                            const float cam_pos[3], const float cam_q[4],
                            const sdm_object_move *moves, int32_t n_moves,
@@ -280,19 +289,37 @@ sdm_status sdm_set_halo_buffers(sdm_map *m, int32_t *counts_local, const int32_t
  * sdm_update_begin, the all-gather and sdm_update_finish); NULL restores the map's own stream. */
 sdm_status sdm_stream(sdm_map *m, void **stream_out);
 sdm_status sdm_set_stream(sdm_map *m, void *hip_stream);
-/* caller-provided device buffer (H*W floats) that sdm_update_begin writes this shard's partial ck image to
- * (e.g. a slice of the all-gather send buffer); NULL restores the internal buffer. */
+/* caller-provided device buffer that sdm_update_begin writes this shard's partial ck image to (H*W floats; for the
+ * chunk-owner exchange shard_count x sdm_ck_chunk_elems floats, the image padded to whole chunks); NULL restores the
+ * internal buffer. */
 sdm_status sdm_set_ck_buffer(sdm_map *m, float *dev_buffer);
+/* Chunk-owner exchange of the partial ck images: the image is cut into shard_count chunks of `chunk` pixels
+ * (sdm_ck_chunk_elems: ceil(H*W / shard_count) rounded up to 64), shard r owns chunk r.
+ *   1. all-to-all: chunk d of every shard's partial image goes to shard d  -> stage (shard_count x chunk floats, part s
+ *      from shard s)
+ *   2. sdm_ck_reduce: the owner adds the parts in slab order (the float sums a single map split into the same slabs
+ *      forms, oracle `ck_slabs`) into chunk `shard_rank` of full (shard_count x chunk floats)
+ *   3. all-gather of the summed chunks (in place on full)               -> sdm_update_finish(m, full, 1, ...)
+ * 2 (G-1)/G images received per shard instead of the G-1 whole images of a plain all-gather. */
+sdm_status sdm_ck_chunk_elems(sdm_map *m, int64_t *chunk_out);
+sdm_status sdm_ck_reduce(sdm_map *m, const float *stage_dev, float *full_dev);
 
 /* ---- native multi-GPU path: RCCL over xGMI, one process per GPU.  Rank 0 draws an id, the caller hands it to
  * every rank (any out-of-band channel), every rank calls sdm_comm_init on its shard map (collective), then
- * sdm_update_sharded runs whole frames: the three all-gathers above are issued on the map's stream. */
+ * sdm_update_sharded runs whole frames: the exchanges above are issued on the map's streams, nothing waits on the host. */
 sdm_status sdm_comm_unique_id(uint8_t out[128]);
+/* halo_cap_records: capacity per destination shard of the export segments, 0 = SDM_HALO_DEFAULT_CAP */
 sdm_status sdm_comm_init(sdm_map *m, const uint8_t id[128], int32_t halo_cap_records);
 sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_point *cloud,
                               const float cam_pos[3], const float cam_q[4],
                               const sdm_object_move *moves, int32_t n_moves,
                               const int32_t *remove_tracks, int32_t n_remove, uint32_t flags);
+/* HIP events around the four collectives of sdm_update_sharded frames; sdm_get_comm_times waits for the last frame and
+ * returns their GPU times in microseconds: [0] member counts (all-gather), [1] slab-crossing copies (all-to-all),
+ * [2] partial ck chunks to their owners (all-to-all), [3] summed ck chunks (all-gather); 0 for one the frame did not
+ * issue.  The time of a collective includes waiting for the slowest shard to arrive at it. */
+sdm_status sdm_comm_timing(sdm_map *m, int32_t on);
+sdm_status sdm_get_comm_times(sdm_map *m, double out_us[4]);
 
 /* ---- plain device buffers (for frames kept resident in HBM, see SDM_INPUT_ON_DEVICE) */
 /* page-locked host memory for input buffers (uploads then run at PCIe speed, beside the previous frame's kernels) */

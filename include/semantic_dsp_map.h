@@ -22,8 +22,11 @@
  * g_max_movable_object_instance_id at the first update(), i.e. after ObjectInfoHandler::readObjectInfo has filled them
  * from the CSV (src/mapping.cpp:89-93) - an unchanged node needs no extra call.
  *
- * Compile-time grid/camera constants of settings/settings.h become SdmGridPreset; pick one with
- * setGridPreset() before the first update() (default: the reference's SETTING 2, VIRTUAL_KITTI2).
+ * Compile-time grid/camera constants of settings/settings.h become SdmGridPreset.  Like the reference, the class picks
+ * its preset from the macros SETTING (0 KITTI_360, 1 CODA, 2 VIRTUAL_KITTI2, 3 ZED2; settings.h:22) and BOOST_MODE
+ * (:25-29) when the translation unit defines them - the node still includes the reference's settings/settings.h, or is
+ * built with -DSETTING=n [-DBOOST_MODE=b] - and from what the reference ships (SETTING 3, hence BOOST_MODE 1) when it
+ * does not: an unchanged node gets the grid it was built for.  setGridPreset() before the first update() overrides it.
  *
  * Needs Eigen3, OpenCV and PCL headers like the reference does.  They are not available in the build image of this
  * repository, where this file is only compile-checked against minimal stand-in headers (tests/mock_includes).
@@ -51,6 +54,18 @@
 
 #include "sdm.h"
 #include "sdm_objects.h"
+
+// settings/settings.h:22-29: `#define SETTING 3` as shipped, BOOST_MODE 1 for SETTING 3 and 0 otherwise
+#ifdef SETTING
+#define SDM_SETTING (SETTING)
+#else
+#define SDM_SETTING 3
+#endif
+#ifdef BOOST_MODE
+#define SDM_BOOST_MODE (BOOST_MODE)
+#else
+#define SDM_BOOST_MODE ((SDM_SETTING) == 3 ? 1 : 0)
+#endif
 
 #ifndef SDM_HAVE_REFERENCE_TRACKING_TYPES
 /// utils/data_base.h:25-31
@@ -98,6 +113,42 @@ struct SdmGridPreset {
     p.zed2_filters = true;
     p.object_mode = 3;
     return p;
+  }
+  /// SETTING 3 without BOOST_MODE: the ZED2 grid at the sensor's 1280 x 720 (settings.h:100-119, 128-134), window 5
+  static SdmGridPreset Zed2() {
+    SdmGridPreset p{7, 5, 7, 2, 0.15f, 527.8191528320312f, 527.8191528320312f, 633.9357299804688f, 366.3338623046875f, 1280, 720, 0.3f, 15.f, 5, true};
+    p.zed2_filters = true;
+    p.object_mode = 3;
+    return p;
+  }
+  /// BOOST_MODE 1 on top of a full-size preset (settings.h:135-143: image and intrinsics scaled by g_image_rescale = 0.5;
+  /// semantic_dsp_map.h:964-970: neighbour half-size 3 instead of 5; pointcloud_tools.h:101, 129, 175: inputs resized)
+  static SdmGridPreset Boosted(SdmGridPreset p) {
+    const float r = 0.5f;
+    p.src_width = p.width;
+    p.src_height = p.height;
+    p.rescale = r;
+    p.fx = r * p.fx;
+    p.fy = r * p.fy;
+    p.cx = r * p.cx;
+    p.cy = r * p.cy;
+    p.width = (int)(r * (float)p.width);
+    p.height = (int)(r * (float)p.height);
+    p.window_half = 3;
+    return p;
+  }
+  /// the preset the reference compiles in for `#define SETTING setting` / `#define BOOST_MODE boost` (settings.h:22-143);
+  /// throws std::invalid_argument where the reference has `#error`
+  static SdmGridPreset FromSetting(int setting, int boost) {
+    SdmGridPreset p;
+    switch (setting) {
+      case 0: p = Kitti360(); p.object_mode = 2; break;
+      case 1: p = Coda(); p.object_mode = 1; break;
+      case 2: p = VirtualKitti2(); p.object_mode = 2; break;
+      case 3: p = Zed2(); break;
+      default: throw std::invalid_argument("SETTING must be 0 (KITTI_360), 1 (CODA), 2 (VIRTUAL_KITTI2) or 3 (ZED2)");
+    }
+    return boost ? Boosted(p) : p;
   }
 };
 
@@ -203,7 +254,7 @@ class SemanticDSPMap {
  public:
   /// semantic_dsp_map.h:25-67
   SemanticDSPMap()
-      : map_(nullptr), object_layer_(nullptr), preset_(SdmGridPreset::VirtualKitti2()), device_(0),
+      : map_(nullptr), object_layer_(nullptr), preset_(SdmGridPreset::FromSetting(SDM_SETTING, SDM_BOOST_MODE)), device_(0),
         global_time_stamp_(0), visualize_with_zero_center_(false), if_out_evaluation_format_(false) {
     params_.detection_probability = 0.95f;
     params_.noise_number = 0.1f;
@@ -243,6 +294,7 @@ class SemanticDSPMap {
 
   // ---- additions (the reference fixes these at compile time / inside the class) ----
   void setGridPreset(const SdmGridPreset &p) { preset_ = p; }
+  const SdmGridPreset &gridPreset() const { return preset_; }
   void setDevice(int hip_device) { device_ = hip_device; }
   void setObjectLayer(SdmObjectLayer *layer) { object_layer_ = layer; }
   /// Use the library's object layer (sdm_objects.h).  mode = the reference's SETTING (settings.h:22); call after
@@ -277,8 +329,19 @@ class SemanticDSPMap {
       static_instance_to_label_[kv.second] = label_id_[kv.first];
       min_static = std::min(min_static, kv.second);
     }
-    max_movable_track_ = min_static - 1;  // object_info_handler.h:84
+    const int max_movable = min_static - 1;  // object_info_handler.h:84
+    if (map_ && max_movable != max_movable_track_)
+      std::cerr << "setLabelTables: g_max_movable_object_instance_id changed after the map was created (" << max_movable_track_
+                << " -> " << max_movable << "): the device keeps the value of the first update()" << std::endl;
+    max_movable_track_ = max_movable;
     rebuildLabelToInstance();
+    pushColours();  // the emitted colours are baked on the device: tables set after the first update() take effect too
+  }
+  /// g_label_color_map_default (utils/data_base.h:216-232): BGR colour of a label id
+  void setLabelColours(const std::map<int, cv::Vec3b> &label_colours) {
+    label_color_.clear();
+    for (const auto &kv : label_colours) label_color_[kv.first] = kv.second;
+    pushColours();
   }
 
   // ---- the reference's public interface ----

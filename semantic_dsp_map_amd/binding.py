@@ -29,6 +29,7 @@ STATE_FIELDS = [("px", np.float32), ("py", np.float32), ("pz", np.float32), ("w"
 STAGES = {"all": 0, "ego": 1, "move": 2, "remove": 3, "visibility": 4, "weight": 5, "birth": 6, "occupancy": 7}
 INPUT_ON_DEVICE = 0x1
 SKIP_OCCUPANCY = 0x2
+NO_INSTANCES = 0x4     # sdm_update_raw: ignore the object masks (g_consider_instance == false)
 
 STATUS_NAMES = {0: "SDM_OK", 1: "SDM_ERR_INVALID_ARGUMENT", 2: "SDM_ERR_NO_DEVICE", 3: "SDM_ERR_HIP",
                 4: "SDM_ERR_CAPACITY", 5: "SDM_ERR_NOT_CONVERGED", 6: "SDM_ERR_COMM"}
@@ -127,6 +128,10 @@ def load_library():
         "sdm_comm_unique_id": [vp],
         "sdm_comm_init": [vp, vp, i32],
         "sdm_update_sharded": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32],
+        "sdm_ck_chunk_elems": [vp, C.POINTER(i64)],
+        "sdm_ck_reduce": [vp, vp, vp],
+        "sdm_comm_timing": [vp, i32],
+        "sdm_get_comm_times": [vp, vp],
         "sdm_device_alloc": [vp, C.c_size_t, C.POINTER(vp)],
         "sdm_device_free": [vp, vp],
         "sdm_device_upload": [vp, vp, vp, C.c_size_t],
@@ -342,6 +347,24 @@ class SdmMap:
         keep, args = self._frame_args(depth, cloud, cam_pos, cam_q, moves, remove_tracks, on_device)
         fl = flags | (INPUT_ON_DEVICE if on_device else 0)
         _check(self.L, self.L.sdm_update_sharded(self.h, *args, fl), "sdm_update_sharded")
+
+    def ck_chunk_elems(self):
+        """pixels per shard of the chunk-owner ck exchange (sdm_ck_chunk_elems)"""
+        n = C.c_int64()
+        _check(self.L, self.L.sdm_ck_chunk_elems(self.h, C.byref(n)), "sdm_ck_chunk_elems")
+        return int(n.value)
+
+    def ck_reduce(self, stage_dev, full_dev):
+        _check(self.L, self.L.sdm_ck_reduce(self.h, _ptr(int(stage_dev)), _ptr(int(full_dev))), "sdm_ck_reduce")
+
+    def comm_timing(self, on=True):
+        _check(self.L, self.L.sdm_comm_timing(self.h, 1 if on else 0), "sdm_comm_timing")
+
+    def comm_times(self):
+        """GPU microseconds of the last sharded frame's collectives: counts, halo, ck all-to-all, ck all-gather."""
+        out = np.zeros(4, np.float64)
+        _check(self.L, self.L.sdm_get_comm_times(self.h, _ptr(out)), "sdm_get_comm_times")
+        return dict(zip(("counts_allgather", "halo_alltoall", "ck_alltoall", "ck_allgather"), [float(x) for x in out]))
 
     def device_alloc(self, nbytes):
         p = C.c_void_p()

@@ -1654,6 +1654,19 @@ __global__ __launch_bounds__(TPB) void k_ck_finish(Dims d, Filter flt, Scratch s
   sc.pixt[p] = (uint32_t)o.track_id | (1u << 16);
 }
 
+// Chunk-owner exchange of the partial ck images (multi-GPU path): the image is cut into `world` chunks of `chunk` pixels,
+// shard r owns chunk r.  stage holds, for this shard's chunk, the `world` partial sums of all shards (part s = what shard
+// s computed for these pixels, received by an all-to-all); they are added in slab order - the same float sums as
+// k_ck_finish forms from whole images - into this shard's chunk of the full image, which is then all-gathered.
+__global__ __launch_bounds__(TPB) void k_ck_reduce_chunk(const float *__restrict__ stage, float *__restrict__ full, uint32_t chunk,
+                                                         int world, int rank) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= chunk) return;
+  float ck = 0.f;
+  for (int g = 0; g < world; ++g) ck += stage[(size_t)g * chunk + i];
+  full[(size_t)rank * chunk + i] = ck;
+}
+
 // pass 2 (semantic_dsp_map.h:1041-1119): 16 binned particles x window rows per workgroup.
 __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Filter flt, State st, Scratch sc) {
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
@@ -2421,6 +2434,9 @@ void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch 
 }
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s) {
   hipLaunchKernelGGL(k_ck_finish, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, parts, n_parts);
+}
+void launch_ck_reduce_chunk(const float *stage, float *full, uint32_t chunk, int world, int rank, hipStream_t s) {
+  hipLaunchKernelGGL(k_ck_reduce_chunk, dim3((chunk + TPB - 1) / TPB), dim3(TPB), 0, s, stage, full, chunk, world, rank);
 }
 void launch_weight(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s) {
   hipLaunchKernelGGL(k_weight, dim3(2048), dim3(A7_ROWS, A7_ITEMS), 0, s, d, flt, st, sc);

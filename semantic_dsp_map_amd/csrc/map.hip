@@ -100,8 +100,13 @@ struct sdm_map {
   ncclComm_t comm = nullptr;
   int32_t *d_counts_all = nullptr;
   unsigned char *d_halo_send = nullptr, *d_halo_recv = nullptr;
-  float *d_ck_all = nullptr;
+  float *d_ck_stage = nullptr, *d_ck_full = nullptr;  // chunk-owner exchange of the partial ck images (sdm_update_sharded)
   uint32_t halo_cap_own = 0;
+  uint32_t ck_chunk = 0;  // pixels per shard of the chunk-owner exchange: ceil(H*W / shard_count), a multiple of 64
+  // HIP events around every collective of the last sharded frame (sdm_comm_timing): [2k], [2k+1] bracket collective k
+  hipEvent_t ev_comm[8]{};
+  bool comm_timing = false, comm_timed[4]{};
+  bool sharded_frame = false;  // inside sdm_update_sharded
   int32_t *counts_local_user = nullptr;
   const int32_t *counts_all_user = nullptr;
   int device = 0;
@@ -601,7 +606,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   // pixels reach the heavy list from blocks of TPB consecutive pixels, shard = block & 63
   sc.cap_heavy = (uint32_t)(((hw + 255) / 256 + VIS_SHARDS - 1) / VIS_SHARDS * 256);
   A(sc.ck_heavy, (size_t)sc.cap_heavy * VIS_SHARDS);
-  A(m->d_ck_part, hw);
+  m->ck_chunk = (uint32_t)(((hw + shard_count - 1) / shard_count + 63) / 64 * 64);
+  A(m->d_ck_part, (size_t)m->ck_chunk * shard_count);  // H*W floats, padded to shard_count whole chunks
   for (auto &r : m->raw) {
     A(r.depth, hw);
     A(r.static_mask, hw);
@@ -659,6 +665,15 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
     m->graph_shape = m->graph_mode == 1 ? GRAPH_BRANCHED : (m->graph_mode == 3 ? GRAPH_CHAIN : GRAPH_PIECES);
     m->host_timing = getenv("SDM_HOST_TIMING") != nullptr;  // debugging aid: per-step host time of sdm_update on stderr at destroy
   }
+  {
+    // the line flood keeps its bitmaps in LDS, sized by the map ((NZ+1) x wy x 32 bytes: 148 KB at 512^3 - fits gfx950's
+    // 160 KB): where the device offers less than that, every frame takes the generic flood (exact as well)
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeSharedMemPerBlockOptin, cfg->device) != hipSuccess || lds_max <= 0)
+      (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device);
+    (void)hipGetLastError();
+    if ((size_t)(d.NZ + 1) * sc.wy * 32 > (size_t)std::min(lds_max, 152 * 1024)) m->force_generic_flood = 1;
+  }
   refresh_filter(m);
   build_birth_order(m);
   if ((rc = ensure_birth_buffers(m)) != SDM_OK) return rc;
@@ -708,9 +723,11 @@ sdm_status sdm_destroy(sdm_map *m) {
   for (void *p : extra)
     if (p) (void)hipFree(p);
   if (m->comm) (void)ncclCommDestroy(m->comm);
-  void *comm_bufs[] = {m->d_counts_all, m->d_halo_send, m->d_halo_recv, m->d_ck_all};
+  void *comm_bufs[] = {m->d_counts_all, m->d_halo_send, m->d_halo_recv, m->d_ck_stage, m->d_ck_full};
   for (void *p : comm_bufs)
     if (p) (void)hipFree(p);
+  for (hipEvent_t e : m->ev_comm)
+    if (e) (void)hipEventDestroy(e);
   if (m->ev_valid)
     for (int i = 0; i < 9; ++i) (void)hipEventDestroy(m->ev[i]);
   if (m->s_frustum) (void)hipStreamSynchronize(m->s_frustum);
@@ -921,11 +938,31 @@ sdm_status frame_enqueue_start(sdm_map *m) {
   } else if (m->n_moves > 0) {
     HIP_TRY(hipStreamWaitEvent(m->s_moves, m->ev_fa, 0));
     launch_moves_count(d, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves);
+    if (m->comm && m->sharded_frame) {
+      // exchange 1 of a sharded frame rides the member-count stream: it runs beside the previous frame's sweep.  (Every
+      // use of the communicator is ordered by events: this one behind the previous frame's births, the next one - the
+      // export all-to-all on the main stream - behind ev_counts.)
+      if (m->comm_timing) HIP_TRY(hipEventRecord(m->ev_comm[0], m->s_moves));
+      ncclResult_t r_ = ncclAllGather(m->d_counts_local, m->d_counts_all, HALO_OBJ, ncclInt32, m->comm, m->s_moves);
+      if (r_ != ncclSuccess) {
+        set_error("ncclAllGather(counts)", __FILE__, __LINE__, ncclGetErrorString(r_));
+        return SDM_ERR_COMM;
+      }
+      if (m->comm_timing) {
+        HIP_TRY(hipEventRecord(m->ev_comm[1], m->s_moves));
+        m->comm_timed[0] = true;
+      }
+    }
     HIP_TRY(hipEventRecord(m->ev_counts, m->s_moves));
   }
   if (!stage_done(stop_after, 3)) {
     launch_frustum(d, m->sc, m->s_frustum);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->capturing ? m->cap_frustum : m->ev_frustum, m->s_frustum));
+  } else if (!m->capturing) {
+    // (parity debugging, stop_after <= 3) nothing else joins the side block's k_set_frame back: the next frame's first
+    // kernel, which may write that block from the main stream, has to come after it
+    HIP_TRY(hipStreamWaitEvent(s, m->ev_fa, 0));
   }
   if (!stage_done(stop_after, 5)) {
     // the birth candidates read this frame's cloud and the birth cursor: after this frame's k_frame_begin
@@ -1044,8 +1081,10 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
 
 // buffers of the two move exchanges (all device pointers, caller-owned):
 //   counts_local  HALO_OBJ int32 written by sdm_frame_start      counts_all  shard_count x HALO_OBJ, gathered
-//   send          16-byte header + cap_records x 36 B, written by sdm_frame_moves
-//   recv_all      shard_count such buffers in shard order, gathered, read by sdm_frame_predict
+//   send          shard_count segments of (16-byte header + cap_records x 36 B), written by sdm_frame_moves: segment d
+//                 holds the copies whose target voxel lies in shard d's slab
+//   recv_all      shard_count such segments, segment s = what shard s addressed to this one (all-to-all), read by
+//                 sdm_frame_predict
 sdm_status sdm_set_halo_buffers(sdm_map *m, int32_t *counts_local, const int32_t *counts_all, void *send, const void *recv_all,
                                 int32_t cap_records) {
   if (!m || cap_records < 0) return SDM_ERR_INVALID_ARGUMENT;
@@ -1054,6 +1093,7 @@ sdm_status sdm_set_halo_buffers(sdm_map *m, int32_t *counts_local, const int32_t
   m->sc.halo_send = (unsigned char *)send;
   m->sc.halo_recv = (const unsigned char *)recv_all;
   m->sc.halo_cap = (uint32_t)cap_records;
+  m->sc.halo_world = (uint32_t)m->cfg.shard_count;
   return SDM_OK;
 }
 
@@ -1297,8 +1337,30 @@ sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *c
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc).count(),
                 pieces ? "pieces" : (m->graph_shape == GRAPH_CHAIN ? "chain" : "branched"));
     }
-    if (rc == SDM_OK) rc = pieces ? pieces_launch(m) : graph_launch(m);
-    if (rc != SDM_OK) m->use_graph = false;  // (the frame is lost; later frames take the plain launches)
+    bool direct = false;
+    if (rc != SDM_OK) {
+      // the capture failed: nothing of this frame has been enqueued yet, so it takes the plain launches (as every later
+      // frame does)
+      m->use_graph = false;
+      direct = true;
+      rc = SDM_OK;
+    } else {
+      rc = pieces ? pieces_launch(m) : graph_launch(m);
+      if (rc != SDM_OK) {
+        // a launch failed in mid-frame: the host's ring state has moved on, the device may not have got this frame's slab
+        // stamps - the next frame uploads them wholesale and sweeps every voxel
+        m->use_graph = false;
+        m->stamps_dirty = true;
+        m->sweep_all = true;
+      }
+    }
+    if (direct) {
+      m->n_direct_frames++;
+      rc = frame_enqueue_start(m);
+      if (rc == SDM_OK) rc = sdm_frame_moves(m);
+      if (rc == SDM_OK) rc = sdm_frame_predict(m, nullptr);
+      if (rc == SDM_OK) rc = sdm_update_finish(m, nullptr, 1, flags, stop_after);
+    }
   } else {
     m->n_direct_frames++;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1508,41 +1570,134 @@ sdm_status sdm_comm_init(sdm_map *m, const uint8_t id_bytes[128], int32_t halo_c
   ncclUniqueId id;
   memcpy(id.internal, id_bytes, 128);
   NCCL_TRY(ncclCommInitRank(&m->comm, world, id, rank));
-  const size_t hw = (size_t)m->d.W * m->d.H;
-  m->halo_cap_own = halo_cap_records > 0 ? (uint32_t)halo_cap_records : 16384u;
-  const size_t hb = HALO_HEADER_BYTES + (size_t)m->halo_cap_own * HALO_RECORD_BYTES;
+  m->halo_cap_own = halo_cap_records > 0 ? (uint32_t)halo_cap_records : (uint32_t)SDM_HALO_DEFAULT_CAP;
+  const size_t hb = halo_segment_bytes(m->halo_cap_own) * (size_t)world;
+  const size_t ck_elems = (size_t)m->ck_chunk * world;
   HIP_TRY(dev_alloc(&m->d_counts_all, (size_t)world * HALO_OBJ));
   HIP_TRY(dev_alloc(&m->d_halo_send, hb));
-  HIP_TRY(dev_alloc(&m->d_halo_recv, (size_t)world * hb));
-  HIP_TRY(dev_alloc(&m->d_ck_all, (size_t)world * hw));
+  HIP_TRY(dev_alloc(&m->d_halo_recv, hb));
+  HIP_TRY(dev_alloc(&m->d_ck_stage, ck_elems));
+  HIP_TRY(dev_alloc(&m->d_ck_full, ck_elems));
   HIP_TRY(hipMemsetAsync(m->d_halo_send, 0, hb, m->stream));
-  HIP_TRY(hipMemsetAsync(m->d_halo_recv, 0, (size_t)world * hb, m->stream));
+  HIP_TRY(hipMemsetAsync(m->d_halo_recv, 0, hb, m->stream));
+  HIP_TRY(hipMemsetAsync(m->d_ck_stage, 0, ck_elems * 4, m->stream));
+  HIP_TRY(hipMemsetAsync(m->d_ck_full, 0, ck_elems * 4, m->stream));
+  HIP_TRY(hipMemsetAsync(m->d_ck_part, 0, ck_elems * 4, m->stream));
+  for (hipEvent_t &e : m->ev_comm) HIP_TRY(hipEventCreate(&e));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return sdm_set_halo_buffers(m, m->d_counts_local, m->d_counts_all, m->d_halo_send, m->d_halo_recv, (int32_t)m->halo_cap_own);
 }
 
-// One frame of a sharded map with all exchanges done here: start -> all-gather(counts) -> moves ->
-// all-gather(exports) -> predict -> all-gather(ck images) -> finish, everything on the map's stream.
+sdm_status sdm_ck_chunk_elems(sdm_map *m, int64_t *chunk_out) {
+  if (!m || !chunk_out) return SDM_ERR_INVALID_ARGUMENT;
+  *chunk_out = m->ck_chunk;
+  return SDM_OK;
+}
+
+// Step between the two ck exchanges: stage = shard_count parts of chunk floats (part s = shard s's partial sums for the
+// pixels this shard owns), summed in slab order into this shard's chunk of full (shard_count x chunk floats).
+sdm_status sdm_ck_reduce(sdm_map *m, const float *stage_dev, float *full_dev) {
+  if (!m || !stage_dev || !full_dev) return SDM_ERR_INVALID_ARGUMENT;
+  if (stage_done(m->stop_after, SDM_STAGE_VISIBILITY)) return SDM_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  launch_ck_reduce_chunk(stage_dev, full_dev, m->ck_chunk, m->cfg.shard_count, m->cfg.shard_rank, m->stream);
+  return SDM_OK;
+}
+
+sdm_status sdm_comm_timing(sdm_map *m, int32_t on) {
+  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  m->comm_timing = on != 0;
+  for (bool &b : m->comm_timed) b = false;
+  return SDM_OK;
+}
+
+// GPU time of the four collectives of the last sdm_update_sharded frame, microseconds (0 for one the frame did not
+// issue): [0] member counts (all-gather, beside the previous frame's sweep), [1] slab-crossing copies (all-to-all),
+// [2] partial ck chunks to their owners (all-to-all), [3] summed chunks (all-gather).  Waits for the frame.
+sdm_status sdm_get_comm_times(sdm_map *m, double out_us[4]) {
+  if (!m || !out_us || !m->comm) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->s_moves));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  for (int k = 0; k < 4; ++k) {
+    out_us[k] = 0.0;
+    if (!m->comm_timed[k]) continue;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, m->ev_comm[2 * k], m->ev_comm[2 * k + 1]));
+    out_us[k] = (double)ms * 1e3;
+  }
+  return SDM_OK;
+}
+
+namespace {
+// ncclSend / ncclRecv of one equally sized piece per peer (all-to-all); this rank's own piece is a device copy
+sdm_status all_to_all(sdm_map *m, const void *send, void *recv, size_t piece_bytes, hipStream_t s) {
+  const int world = m->cfg.shard_count, rank = m->cfg.shard_rank;
+  HIP_TRY(hipMemcpyAsync((char *)recv + (size_t)rank * piece_bytes, (const char *)send + (size_t)rank * piece_bytes, piece_bytes,
+                         hipMemcpyDeviceToDevice, s));
+  if (world == 1) return SDM_OK;
+  NCCL_TRY(ncclGroupStart());
+  for (int peer = 0; peer < world; ++peer) {
+    if (peer == rank) continue;
+    NCCL_TRY(ncclSend((const char *)send + (size_t)peer * piece_bytes, piece_bytes, ncclUint8, peer, m->comm, s));
+    NCCL_TRY(ncclRecv((char *)recv + (size_t)peer * piece_bytes, piece_bytes, ncclUint8, peer, m->comm, s));
+  }
+  NCCL_TRY(ncclGroupEnd());
+  return SDM_OK;
+}
+struct CommTimer {
+  sdm_map *m;
+  int k;
+  hipStream_t s;
+  CommTimer(sdm_map *m_, int k_, hipStream_t s_) : m(m_), k(k_), s(s_) {
+    if (m->comm_timing) (void)hipEventRecord(m->ev_comm[2 * k], s);
+  }
+  ~CommTimer() {
+    if (m->comm_timing) {
+      (void)hipEventRecord(m->ev_comm[2 * k + 1], s);
+      m->comm_timed[k] = true;
+    }
+  }
+};
+}  // namespace
+
+// One frame of a sharded map with all exchanges done here, everything stream-ordered (no host synchronisation):
+//   start   -> all-gather of the member counts (64 ints per shard; on the member-count stream, i.e. beside the previous
+//              frame's sweep - frame_enqueue_start issues it)
+//   moves   -> all-to-all of the export segments (slab-crossing copies go to the shard that owns their target voxel)
+//   predict -> all-to-all of the partial ck image's chunks to their owners, slab-ordered sum there, all-gather of the
+//              summed chunks
+//   finish
+// Received per shard and frame: (G-1) x [256 B + 16 B + cap x 36 B + 2 x 4 x H*W/G B].
 sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
                               const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
                               const int32_t *remove_tracks, int32_t n_remove, uint32_t flags) {
   if (!m || !m->comm) return SDM_ERR_INVALID_ARGUMENT;
-  const int world = m->cfg.shard_count;
-  const size_t hw = (size_t)m->d.W * m->d.H;
+  const int world = m->cfg.shard_count, rank = m->cfg.shard_rank;
+  for (bool &b : m->comm_timed) b = false;
+  m->sharded_frame = true;
   sdm_status rc = sdm_frame_start(m, depth, cloud, cam_pos, cam_q, moves, n_moves, remove_tracks, n_remove, flags, 0);
+  m->sharded_frame = false;
   if (rc != SDM_OK) return rc;
-  if (n_moves > 0) NCCL_TRY(ncclAllGather(m->d_counts_local, m->d_counts_all, HALO_OBJ, ncclInt32, m->comm, m->stream));
   rc = sdm_frame_moves(m);
   if (rc != SDM_OK) return rc;
   if (n_moves > 0) {
-    const size_t hb = HALO_HEADER_BYTES + (size_t)m->halo_cap_own * HALO_RECORD_BYTES;
-    NCCL_TRY(ncclAllGather(m->d_halo_send, m->d_halo_recv, hb, ncclUint8, m->comm, m->stream));
+    CommTimer t(m, 1, m->stream);
+    if ((rc = all_to_all(m, m->d_halo_send, m->d_halo_recv, halo_segment_bytes(m->halo_cap_own), m->stream)) != SDM_OK) return rc;
   }
   const float *part = nullptr;
   rc = sdm_frame_predict(m, &part);
   if (rc != SDM_OK) return rc;
-  NCCL_TRY(ncclAllGather(part, m->d_ck_all, hw, ncclFloat32, m->comm, m->stream));
-  return sdm_update_finish(m, m->d_ck_all, world, flags, 0);
+  {
+    CommTimer t(m, 2, m->stream);
+    if ((rc = all_to_all(m, part, m->d_ck_stage, (size_t)m->ck_chunk * 4, m->stream)) != SDM_OK) return rc;
+  }
+  launch_ck_reduce_chunk(m->d_ck_stage, m->d_ck_full, m->ck_chunk, world, rank, m->stream);
+  {
+    CommTimer t(m, 3, m->stream);
+    NCCL_TRY(ncclAllGather(m->d_ck_full + (size_t)rank * m->ck_chunk, m->d_ck_full, m->ck_chunk, ncclFloat32, m->comm, m->stream));
+  }
+  return sdm_update_finish(m, m->d_ck_full, 1, flags, 0);
 }
 
 // ---- plain device buffers for callers that keep their frames resident in HBM (SDM_INPUT_ON_DEVICE) ----

@@ -183,7 +183,10 @@ __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__
 // and the global rank of the j-th local member of object k on shard r is
 //     e = sum_{k'<k} sum_r' C[r'][k']  +  sum_{r'<r} C[r'][k]  +  j.
 // Moved copies are stored at index e and replayed per target voxel in ascending e: the reference's order, without
-// knowing where a copy came from.  A copy whose target voxel belongs to another slab is exported as a 36-byte record.
+// knowing where a copy came from.  A copy whose target voxel belongs to another slab is exported as a 36-byte record
+// into the segment of the export buffer that is addressed to that slab's shard (one segment per shard: 16-byte header
+// with the record count, then halo_cap records); the segments travel as an all-to-all, so a shard receives what was
+// meant for it and nothing else.
 struct HaloRecord {
   float x, y, z;
   uint32_t forget_bits;
@@ -198,7 +201,9 @@ static_assert(sizeof(HaloRecord) == HALO_RECORD_BYTES, "halo record layout");
 __global__ void k_move_local_counts(const uint32_t *__restrict__ offs, int32_t *counts_local, Scratch sc) {
   int k = threadIdx.x;
   const int n_obj = sc.fa_side->n_obj;  // (runs with the member count, on its stream)
-  if (k == 0 && sc.halo_send) *reinterpret_cast<uint32_t *>(sc.halo_send) = 0;  // this frame's export counter
+  // this frame's export counters, one per destination shard
+  const uint32_t world = sc.halo_world;
+  if (sc.halo_send && (uint32_t)k < world) *reinterpret_cast<uint32_t *>(sc.halo_send + (size_t)k * halo_segment_bytes(sc.halo_cap)) = 0;
   if (k >= HALO_OBJ) return;
   counts_local[k] = k < n_obj ? (int32_t)(offs[(size_t)(k + 1) * MV_LIST_CAP] - offs[(size_t)k * MV_LIST_CAP]) : 0;
 }
@@ -258,8 +263,9 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
     c.pad = 0;
     sc.mv_copy[e] = c;
     move_link(d, sc, v, e);
-  } else if (sc.halo_send) {  // crosses into another slab: export
-    uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(sc.halo_send), 1u);
+  } else if (sc.halo_send) {  // crosses into another slab: export to the shard that owns it
+    unsigned char *seg = sc.halo_send + (size_t)(rz / d.rz_count) * halo_segment_bytes(sc.halo_cap);
+    uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(seg), 1u);
     if (k < sc.halo_cap) {
       HaloRecord r;
       r.x = nx;
@@ -271,7 +277,7 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
       r.e = e;
       r.ts_track = (uint32_t)pts | ((uint32_t)ptrack << 16);
       r.owner_label_status = (uint32_t)powner | ((uint32_t)plabel << 16) | ((uint32_t)pstatus << 24);
-      reinterpret_cast<HaloRecord *>(sc.halo_send + HALO_HEADER_BYTES)[k] = r;
+      reinterpret_cast<HaloRecord *>(seg + HALO_HEADER_BYTES)[k] = r;
     } else {
       sc.cnt->overflow = 1;
     }
@@ -465,12 +471,13 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
   }
 }
 
-// import the records other shards exported into this slab (blockIdx.y = source shard)
+// import the records other shards exported into this slab (blockIdx.y = source shard; segment s of the receive buffer is
+// what shard s addressed to this one)
 __global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int world, int rank) {
   if (sc.fa->n_obj <= 0) return;
   const int src = blockIdx.y;
   if (src == rank || src >= world) return;
-  const unsigned char *buf = sc.halo_recv + (size_t)src * (HALO_HEADER_BYTES + (size_t)sc.halo_cap * HALO_RECORD_BYTES);
+  const unsigned char *buf = sc.halo_recv + (size_t)src * halo_segment_bytes(sc.halo_cap);
   uint32_t n = *reinterpret_cast<const uint32_t *>(buf);
   if (n > sc.halo_cap) n = sc.halo_cap;
   const HaloRecord *rec = reinterpret_cast<const HaloRecord *>(buf + HALO_HEADER_BYTES);

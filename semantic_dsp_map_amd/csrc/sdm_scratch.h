@@ -28,6 +28,8 @@ constexpr int MAX_REMOVE_TRACKS = 128;
 constexpr int HALO_OBJ = 64;              // ints per shard in the gathered count matrix (>= MAX_MOVE_OBJECTS)
 constexpr int HALO_RECORD_BYTES = 36;
 constexpr int HALO_HEADER_BYTES = 16;
+// one segment of an export / import buffer: header (record count) + cap records
+__host__ __device__ constexpr size_t halo_segment_bytes(uint32_t cap) { return HALO_HEADER_BYTES + (size_t)cap * HALO_RECORD_BYTES; }
 struct MoveSet {
   int n;
   float T[MAX_MOVE_OBJECTS][12];  // rows 0..2 of the 4x4 (row-major)
@@ -85,10 +87,12 @@ struct Scratch {
   uint32_t *mv_list = nullptr, *mv_nlist = nullptr;  // ascending list of chunks that may hold owned slots
   MoveCopy *mv_copy = nullptr;     // the moved copies, indexed by global rank (32 B each: two 16-byte accesses)
   uint32_t cap_move = 0;
-  // slab-crossing copies: [u32 count, pad to 16 B][records]; recv = one such buffer per shard, shard order
+  // slab-crossing copies: one segment [u32 count, pad to 16 B][halo_cap records] per shard.  Segment d of halo_send holds
+  // the copies addressed to shard d, segment s of halo_recv what shard s addressed to this one (all-to-all)
   unsigned char *halo_send = nullptr;
   const unsigned char *halo_recv = nullptr;
   uint32_t halo_cap = 0;
+  uint32_t halo_world = 1;
   uint8_t *track_to_obj = nullptr; // 65536 entries: moving-object rank of a track id, 0xFF = not moving
   // generic
   uint32_t *scan_scratch = nullptr, *sort_scratch = nullptr;
@@ -144,6 +148,7 @@ void launch_frustum(const Dims &d, const Scratch &sc, hipStream_t s);
 void launch_visibility(const Dims &d, const State &st, const Scratch &sc, hipStream_t s);
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s);
+void launch_ck_reduce_chunk(const float *stage, float *full, uint32_t chunk, int world, int rank, hipStream_t s);
 void launch_weight(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
 int launch_birth_prepare(const Dims &d, const Filter &flt, const BirthOrder &bo, const State &st,
                          const Scratch &sc, hipStream_t s);

@@ -2,22 +2,27 @@
 
 The ring buffer is split by ring-z slab; a ring shift moves no data, so slab ownership never changes.  A frame
 needs the other shards three times:
-  1. per-object member counts        (SDM_HALO_OBJ int32 per shard)  -> global particle ranks for the noise cursor
-  2. slab-crossing copies of moved particles (36-byte records)       -> imported by the slab that owns the target voxel
-  3. partial ck images of pass 1 of the weight update (4*H*W bytes)  -> summed in slab order on every shard
-Each is an all-gather.  On GPUs the library issues them itself with RCCL over xGMI on the map's stream
-(sdm_comm_init / sdm_update_sharded); this module only does the rendezvous: rank 0 draws the RCCL id and it is
-broadcast over torch.distributed's gloo backend (CPU only — torch's bundled HIP runtime is never initialised, the
-process has exactly one HIP runtime, the system one libsdm_hip links against).
+  1. per-object member counts (SDM_HALO_OBJ int32 per shard), all-gather   -> global particle ranks for the noise cursor
+  2. slab-crossing copies of moved particles (36-byte records), all-to-all: every copy goes to the shard that owns its
+     target voxel and to nobody else (one export segment per destination)
+  3. partial ck images of pass 1 of the weight update, chunk-owner exchange: shard r owns 1/G of the pixels, receives
+     every shard's partial sums for them (all-to-all), adds them in slab order, and the summed chunks are all-gathered:
+     2 (G-1)/G images received per shard instead of G-1
+On GPUs the library issues them itself with RCCL over xGMI on the map's streams (sdm_comm_init / sdm_update_sharded);
+this module only does the rendezvous: rank 0 draws the RCCL id and it is broadcast over torch.distributed's gloo backend
+(CPU only - torch's bundled HIP runtime is never initialised, the process has exactly one HIP runtime, the system one
+libsdm_hip links against).
 
 ShardedDriver is the same frame protocol over a generic engine and a torch.distributed-like module; it is what the
-2-process gloo test drives with a CPU stand-in engine (tests/test_sharded_gloo.py).
+multi-process tests drive: with a CPU stand-in engine (tests/test_sharded_gloo.py) and with real libsdm_hip shards that
+share one GPU (GlooShardEngine, tests/test_sharded_multiprocess_gpu.py).
 """
 import numpy as np
 
 HALO_OBJ = 64            # SDM_HALO_OBJ
 HALO_RECORD_BYTES = 36   # SDM_HALO_RECORD_BYTES
 HALO_HEADER_BYTES = 16   # SDM_HALO_HEADER_BYTES
+HALO_DEFAULT_CAP = 1024  # SDM_HALO_DEFAULT_CAP: records per destination shard
 
 
 def weak_scaled_config(base_cfg, world):
@@ -45,7 +50,7 @@ def broadcast_unique_id(dist, rank):
 class NativeShardedMap:
     """A libsdm_hip shard whose exchanges run inside the library on RCCL."""
 
-    def __init__(self, cfg, params, rank, world, device, dist=None, noise_table=None, halo_cap=16384, max_visible=0):
+    def __init__(self, cfg, params, rank, world, device, dist=None, noise_table=None, halo_cap=0, max_visible=0):
         from . import binding
         self.rank, self.world = rank, world
         self.map = binding.SdmMap(cfg, params, noise_table, device=device, shard_rank=rank, shard_count=world,
@@ -76,54 +81,74 @@ class NativeShardedMap:
         self.map.synchronize()
 
 
+def halo_segment_bytes(cap):
+    return HALO_HEADER_BYTES + cap * HALO_RECORD_BYTES
+
+
 class GlooShardEngine:
-    """A real libsdm_hip shard driven through the split entry points (sdm_frame_start / _moves / _predict /
-    sdm_update_finish) with the three exchanges carried by a CPU backend: the exchange buffers live on the device
-    (sdm_set_halo_buffers, sdm_set_ck_buffer), `pull` copies this shard's part to a host tensor before an all-gather
-    and `push` copies the gathered tensor back.  This is how two processes that share ONE GPU run the sharded engine
+    """A real libsdm_hip shard driven through the split entry points (sdm_frame_start / _moves / _predict / sdm_ck_reduce
+    / sdm_update_finish) with the exchanges carried by a CPU backend: the exchange buffers live on the device
+    (sdm_set_halo_buffers, sdm_set_ck_buffer), `pull` copies this shard's part to a host tensor before a collective
+    and `push` copies the received tensor back.  This is how several processes that share ONE GPU run the sharded engine
     (RCCL refuses two ranks on one device); on one GPU per process NativeShardedMap does the same with RCCL and no
     host copies."""
 
-    def __init__(self, cfg, params, rank, world, device=0, noise_table=None, halo_cap=16384, max_visible=0):
+    def __init__(self, cfg, params, rank, world, device=0, noise_table=None, halo_cap=1024, max_visible=0):
         import torch
         from . import binding
         self.rank, self.world = rank, world
         self.map = m = binding.SdmMap(cfg, params, noise_table, device=device, shard_rank=rank, shard_count=world,
                                       max_visible=max_visible)
         self.hw = cfg["width"] * cfg["height"]
-        self.hb = HALO_HEADER_BYTES + halo_cap * HALO_RECORD_BYTES
+        self.chunk = m.ck_chunk_elems()
+        self.seg = halo_segment_bytes(halo_cap)
+        hb, ck = world * self.seg, world * self.chunk
         self.d = {"counts_local": m.device_put(np.zeros(HALO_OBJ, np.int32)),
                   "counts_all": m.device_put(np.zeros(world * HALO_OBJ, np.int32)),
-                  "halo_send": m.device_put(np.zeros(self.hb, np.uint8)),
-                  "halo_recv": m.device_put(np.zeros(world * self.hb, np.uint8)),
-                  "part": m.device_alloc(self.hw * 4),
-                  "gathered": m.device_alloc(world * self.hw * 4)}
-        m.set_ck_buffer(self.d["part"])
+                  "halo_send": m.device_put(np.zeros(hb, np.uint8)),
+                  "halo_recv": m.device_put(np.zeros(hb, np.uint8)),
+                  "ck_part": m.device_put(np.zeros(ck, np.float32)),
+                  "ck_stage": m.device_put(np.zeros(ck, np.float32)),
+                  "ck_full": m.device_put(np.zeros(ck, np.float32))}
+        m.set_ck_buffer(self.d["ck_part"])
         m.set_halo_buffers(self.d["counts_local"], self.d["counts_all"], self.d["halo_send"], self.d["halo_recv"], halo_cap)
         self.counts_local = torch.zeros(HALO_OBJ, dtype=torch.int32)
         self.counts_all = torch.zeros(world * HALO_OBJ, dtype=torch.int32)
-        self.halo_send = torch.zeros(self.hb, dtype=torch.uint8)
-        self.halo_recv = torch.zeros(world * self.hb, dtype=torch.uint8)
-        self.part = torch.zeros(self.hw, dtype=torch.float32)
-        self.gathered = torch.zeros(world * self.hw, dtype=torch.float32)
-        self.bytes_exchanged = {"counts": 0, "halo": 0, "halo_records": 0, "ck": 0}
+        self.halo_send = torch.zeros(hb, dtype=torch.uint8)
+        self.halo_recv = torch.zeros(hb, dtype=torch.uint8)
+        self.ck_part = torch.zeros(ck, dtype=torch.float32)
+        self.ck_stage = torch.zeros(ck, dtype=torch.float32)
+        self.ck_chunk = torch.zeros(self.chunk, dtype=torch.float32)
+        self.ck_full = torch.zeros(ck, dtype=torch.float32)
+        # bytes RECEIVED from other shards per exchange, summed over the frames; halo_records = records this shard exported
+        self.bytes_exchanged = {"counts": 0, "halo": 0, "halo_records": 0, "ck_alltoall": 0, "ck_allgather": 0, "frames": 0}
 
-    # exchange hooks of ShardedDriver: name -> (device source, host tensor) / (host tensor, device destination)
+    # exchange hooks of ShardedDriver: device source -> host tensor before a collective, host tensor -> device after it
     def pull(self, name):
         src, dst = {"counts": ("counts_local", self.counts_local), "halo": ("halo_send", self.halo_send),
-                    "ck": ("part", self.part)}[name]
+                    "ck_part": ("ck_part", self.ck_part), "ck_chunk": ("ck_full", self.ck_chunk)}[name]
         host = dst.numpy()
-        host.view(np.uint8)[:] = self.map.device_download(self.d[src], host.nbytes)
-        self.bytes_exchanged[name] += host.nbytes * (self.world - 1)          # what an all-gather receives per rank
-        if name == "halo":
-            self.bytes_exchanged["halo_records"] += int(host[:4].copy().view(np.uint32)[0])
+        off = self.rank * self.chunk * 4 if name == "ck_chunk" else 0
+        host.view(np.uint8)[:] = self.map.device_download(self.d[src] + off, host.nbytes)
+        w1 = self.world - 1
+        if name == "counts":
+            self.bytes_exchanged["counts"] += host.nbytes * w1
+        elif name == "halo":
+            self.bytes_exchanged["halo"] += self.seg * w1
+            heads = host.view(np.uint8).reshape(self.world, self.seg)[:, :4].copy().view(np.uint32)
+            self.bytes_exchanged["halo_records"] += int(heads.sum())
+        elif name == "ck_part":
+            self.bytes_exchanged["ck_alltoall"] += self.chunk * 4 * w1
+        else:
+            self.bytes_exchanged["ck_allgather"] += self.chunk * 4 * w1
 
     def push(self, name):
         src, dst = {"counts": (self.counts_all, "counts_all"), "halo": (self.halo_recv, "halo_recv"),
-                    "ck": (self.gathered, "gathered")}[name]
+                    "ck_stage": (self.ck_stage, "ck_stage"), "ck_full": (self.ck_full, "ck_full")}[name]
         self.map.device_upload(self.d[dst], src.numpy())
 
     def start(self, depth, cloud, pos, q, moves=None, remove_tracks=None, **kw):
+        self.bytes_exchanged["frames"] += 1
         self.map.frame_start(depth, cloud, pos, q, moves, remove_tracks, **kw)
 
     def moves(self):
@@ -131,21 +156,25 @@ class GlooShardEngine:
 
     def predict(self):
         self.map.frame_predict()
-        return self.part
 
-    def finish(self, gathered, n_parts):
-        self.map.update_finish(self.d["gathered"], n_parts)
+    def ck_reduce(self):
+        self.map.ck_reduce(self.d["ck_stage"], self.d["ck_full"])
+
+    def finish(self):
+        self.map.update_finish(self.d["ck_full"], 1)
 
     def close(self):
         self.map.close()
 
 
 class ShardedDriver:
-    """The frame protocol over a generic engine: start -> [counts] -> moves -> [exports] -> predict -> [ck images]
-    -> finish, where [x] is dist.all_gather_into_tensor over the shards (the first two only when objects move).
-    Engine attributes: counts_local/counts_all, halo_send/halo_recv, part/gathered (torch tensors on the engine's
-    device); methods start, moves, predict, finish; optional pull(name) / push(name) around every exchange for engines
-    whose buffers have to be staged (GlooShardEngine)."""
+    """The frame protocol over a generic engine:
+        start -> [counts: all-gather] -> moves -> [export segments: all-to-all] -> predict
+              -> [partial ck chunks: all-to-all] -> ck_reduce -> [summed chunks: all-gather] -> finish
+    where [x] is a collective over the shards (the first two only when objects move).  Engine attributes (torch tensors
+    on the engine's device): counts_local / counts_all, halo_send / halo_recv (world segments each), ck_part / ck_stage /
+    ck_full (world chunks each) and ck_chunk (this shard's summed chunk); methods start, moves, predict, ck_reduce, finish;
+    optional pull(name) / push(name) around every collective for engines whose buffers have to be staged (GlooShardEngine)."""
 
     def __init__(self, engine, rank, world, dist=None):
         self.engine, self.rank, self.world, self.dist = engine, rank, world, dist
@@ -153,25 +182,32 @@ class ShardedDriver:
             raise ValueError("world > 1 needs a torch.distributed module")
 
     def update(self, depth, cloud, pos, q, moves=None, remove_tracks=None, **kw):
-        e = self.engine
+        e, d = self.engine, self.dist
         has_moves = moves is not None and len(moves) > 0   # replicated input: the same on every rank
         pull, push = getattr(e, "pull", lambda name: None), getattr(e, "push", lambda name: None)
+        multi = self.world > 1
         e.start(depth, cloud, pos, q, moves, remove_tracks, **kw)
-        if has_moves and self.world > 1:
+        if has_moves and multi:
             pull("counts")
-            self.dist.all_gather_into_tensor(e.counts_all, e.counts_local)
+            d.all_gather_into_tensor(e.counts_all, e.counts_local)
             push("counts")
         e.moves()
-        if has_moves and self.world > 1:
+        if has_moves and multi:
             pull("halo")
-            self.dist.all_gather_into_tensor(e.halo_recv, e.halo_send)
+            d.all_to_all_single(e.halo_recv, e.halo_send)         # segment s of recv = segment `rank` of shard s's send
             push("halo")
-        part = e.predict()
-        pull("ck")
-        if self.world > 1:
-            # rank r's image lands at [r*HW, (r+1)*HW): slab order
-            self.dist.all_gather_into_tensor(e.gathered, part)
+        e.predict()
+        pull("ck_part")
+        if multi:
+            d.all_to_all_single(e.ck_stage, e.ck_part)            # part s of stage = shard s's sums for my pixels
         else:
-            e.gathered[:part.numel()] = part
-        push("ck")
-        e.finish(e.gathered, self.world)
+            e.ck_stage.copy_(e.ck_part)
+        push("ck_stage")
+        e.ck_reduce()
+        pull("ck_chunk")
+        if multi:
+            d.all_gather_into_tensor(e.ck_full, e.ck_chunk)
+        else:
+            e.ck_full[:e.ck_chunk.numel()] = e.ck_chunk
+        push("ck_full")
+        e.finish()

@@ -39,7 +39,18 @@ _ZED2_BOOST = dict(fx=0.5 * 527.8191528320312, fy=0.5 * 527.8191528320312, cx=0.
 _VKITTI2 = dict(fx=725.0087, fy=725.0087, cx=620.5, cy=187.0, width=1242, height=375,
                 depth_min=0.3, depth_max=30.0, voxel_size=0.2, window_half=5)          # settings.h:79-98
 
+_CODA = dict(fx=569.8286, fy=565.4818, cx=439.2660, cy=360.5810, width=960, height=540,
+             depth_min=0.3, depth_max=10.0, voxel_size=0.15, window_half=5)                # settings.h:54-77
+_ZED2_FULL = dict(fx=527.8191528320312, fy=527.8191528320312, cx=633.9357299804688, cy=366.3338623046875, width=1280,
+                  height=720, depth_min=0.3, depth_max=15.0, voxel_size=0.15, window_half=5)  # settings.h:100-119, BOOST_MODE 0
+
 CONFIGS = {
+    # the grids the reference ships (settings/settings.h:32-143, one per SETTING value; BASELINE.json's cubes are below)
+    "REF_KITTI360": dict(x_n=8, y_n=8, z_n=8, p_n=3, max_movable_track=MAX_MOVABLE_TRACK, **_KITTI360),     # SETTING 0
+    "REF_CODA": dict(x_n=8, y_n=8, z_n=7, p_n=2, max_movable_track=MAX_MOVABLE_TRACK, **_CODA),             # SETTING 1
+    "REF_VKITTI2": dict(x_n=8, y_n=7, z_n=8, p_n=3, max_movable_track=MAX_MOVABLE_TRACK, **_VKITTI2),       # SETTING 2
+    "REF_ZED2_BOOST": dict(x_n=7, y_n=5, z_n=7, p_n=2, max_movable_track=MAX_MOVABLE_TRACK, **_ZED2_BOOST), # SETTING 3 (shipped)
+    "REF_ZED2_SENSOR": dict(x_n=7, y_n=5, z_n=7, p_n=2, max_movable_track=MAX_MOVABLE_TRACK, **_ZED2_FULL), # its 1280x720 inputs
     "C1": dict(x_n=6, y_n=6, z_n=6, p_n=3, max_movable_track=MAX_MOVABLE_TRACK, **_KITTI360),
     "C2": dict(x_n=7, y_n=7, z_n=7, p_n=2, max_movable_track=MAX_MOVABLE_TRACK, **_ZED2_BOOST),
     "C3": dict(x_n=8, y_n=8, z_n=8, p_n=3, max_movable_track=MAX_MOVABLE_TRACK, **_VKITTI2),
@@ -64,6 +75,11 @@ PARAMS = {
                  max_obersevation_lost_time=20, forgetting_rate=1.0, max_forget_count=5,
                  match_score_threshold=0.6, id_transition_probability=0.5, if_consider_depth_noise=1,
                  if_use_independent_filter=0, depth_noise_first_order=0.02, depth_noise_zero_order=0.3),
+    # cfg/options.yaml (the CODA run)
+    "coda": dict(detection_probability=0.6, noise_number=0.6, nb_ptc_num_per_point=1, occupancy_threshold=0.1,
+                 max_obersevation_lost_time=10, forgetting_rate=0.5, max_forget_count=3,
+                 match_score_threshold=0.6, id_transition_probability=0.2, if_consider_depth_noise=1,
+                 if_use_independent_filter=1, depth_noise_first_order=0.01, depth_noise_zero_order=0.2),
     "vkitti2": dict(detection_probability=0.98, noise_number=0.001, nb_ptc_num_per_point=1, occupancy_threshold=0.5,
                     max_obersevation_lost_time=5, forgetting_rate=1.0, max_forget_count=3,
                     match_score_threshold=0.6, id_transition_probability=0.2, if_consider_depth_noise=1,
@@ -85,7 +101,8 @@ PARAMS = {
                          if_consider_depth_noise=0, if_use_independent_filter=0, depth_noise_first_order=0.0,
                          depth_noise_zero_order=0.1),
 }
-CONFIG_PARAMS = {"C1": "kitti360", "C2": "zed2", "C3": "vkitti2", "C4": "vkitti2", "C5": "vkitti2",
+CONFIG_PARAMS = {"REF_KITTI360": "kitti360", "REF_CODA": "coda", "REF_VKITTI2": "vkitti2", "REF_ZED2_BOOST": "zed2",
+                 "REF_ZED2_SENSOR": "zed2", "C1": "kitti360", "C2": "zed2", "C3": "vkitti2", "C4": "vkitti2", "C5": "vkitti2",
                  "T0": "vkitti2", "T1": "zed2"}
 
 
@@ -186,8 +203,10 @@ class Scene:
         return out
 
     # -------------------------------------------------------------- render
-    def render(self, t, params):
-        """Returns depth (H,W) f32, cloud (H*W,) LABELED_POINT, cam_pos (3,) f32, cam_q (4,) f32."""
+    def render(self, t, params, fast=True):
+        """Returns depth (H,W) f32, cloud (H*W,) LABELED_POINT, cam_pos (3,) f32, cam_q (4,) f32.
+        fast: a box is only tested against the rays of the image rectangle its eight corners project into (+ 2 pixels);
+        the per-ray arithmetic is the same, so is the result (tests/test_synth.py holds the two paths equal)."""
         c = self.cfg
         W, H = c["width"], c["height"]
         pos, q = self.pose(t)
@@ -208,6 +227,19 @@ class Scene:
             best_label[m] = label
             best_track[m] = track
 
+        def rect_of(box):
+            """pixel rectangle (i0, i1, j0, j1) that contains every ray hitting the box, or None = the whole image"""
+            cs = np.array([[box[x], box[y], box[z]] for x in (0, 3) for y in (1, 4) for z in (2, 5)], np.float64) - pos
+            pc = cs @ R                                   # camera frame: R^T (corner - pos)
+            if np.min(pc[:, 2]) <= 0.05:
+                return None
+            u = c["fx"] * pc[:, 0] / pc[:, 2] + c["cx"]
+            v = c["fy"] * pc[:, 1] / pc[:, 2] + c["cy"]
+            j0, j1 = int(np.floor(u.min())) - 2, int(np.ceil(u.max())) + 3
+            i0, i1 = int(np.floor(v.min())) - 2, int(np.ceil(v.max())) + 3
+            j0, j1, i0, i1 = max(j0, 0), min(j1, W), max(i0, 0), min(i1, H)
+            return (i0, i1, j0, j1)
+
         with np.errstate(divide="ignore", invalid="ignore"):
             tg = (self.ground_y - pos[1]) / dw[:, 1]
             take(tg, dw[:, 1] > 1e-9, LABEL_ROAD, TRACK_ROAD)
@@ -219,13 +251,34 @@ class Scene:
             boxes = [(self.static_boxes, self.static_labels, self.static_tracks),
                      (self.dyn_boxes(t), np.full(len(self.dyn_tracks), LABEL_CAR, np.uint8), self.dyn_tracks)]
             inv = 1.0 / dw
+            inv2 = inv.reshape(H, W, 3)
+            bt2, bl2, bk2 = best_t.reshape(H, W), best_label.reshape(H, W), best_track.reshape(H, W)
             for bx, labs, trks in boxes:
                 for k in range(len(bx)):
-                    t0 = (bx[k, 0:3] - pos) * inv
-                    t1 = (bx[k, 3:6] - pos) * inv
-                    tn = np.nanmax(np.minimum(t0, t1), axis=1)
-                    tf = np.nanmin(np.maximum(t0, t1), axis=1)
-                    take(tn, (tn <= tf) & (tf > 0), labs[k], trks[k])
+                    r = rect_of(bx[k]) if fast else None
+                    if r is None:
+                        t0 = (bx[k, 0:3] - pos) * inv
+                        t1 = (bx[k, 3:6] - pos) * inv
+                        tn = np.nanmax(np.minimum(t0, t1), axis=1)
+                        tf = np.nanmin(np.maximum(t0, t1), axis=1)
+                        best_t = bt2.reshape(-1)
+                        take(tn, (tn <= tf) & (tf > 0), labs[k], trks[k])
+                        bt2 = best_t.reshape(H, W)
+                        continue
+                    i0, i1, j0, j1 = r
+                    if i0 >= i1 or j0 >= j1:
+                        continue                          # out of the picture
+                    iv = inv2[i0:i1, j0:j1]
+                    t0 = (bx[k, 0:3] - pos) * iv
+                    t1 = (bx[k, 3:6] - pos) * iv
+                    tn = np.nanmax(np.minimum(t0, t1), axis=2)
+                    tf = np.nanmin(np.maximum(t0, t1), axis=2)
+                    cur = bt2[i0:i1, j0:j1]
+                    m = (tn <= tf) & (tf > 0) & (tn > 1e-6) & (tn < cur)
+                    bt2[i0:i1, j0:j1] = np.where(m, tn, cur)
+                    bl2[i0:i1, j0:j1][m] = labs[k]
+                    bk2[i0:i1, j0:j1][m] = trks[k]
+            best_t = bt2.reshape(-1)
 
         depth = best_t.astype(np.float32)  # camera-frame z == ray parameter (dc.z == 1)
         if self.invalid_fraction > 0:

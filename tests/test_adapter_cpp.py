@@ -25,6 +25,24 @@ def test_adapter_header_compiles_and_links():
     assert out.returncode == 0 and "adapter constructed" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("defs,setting,boost", [
+    ([], 3, 1),                                   # nothing defined: what the reference ships (settings.h:22-29)
+    (["-DSETTING=0"], 0, 0), (["-DSETTING=1"], 1, 0), (["-DSETTING=2"], 2, 0), (["-DSETTING=3"], 3, 1),
+    (["-DSETTING=3", "-DBOOST_MODE=0"], 3, 0), (["-DSETTING=2", "-DBOOST_MODE=1"], 2, 1),
+])
+def test_adapter_honours_the_setting_macros(defs, setting, boost, tmp_path):
+    """`#define SETTING n` / BOOST_MODE select the adapter's preset like they select the reference's constants."""
+    csrc = os.path.dirname(binding.LIB_PATH)
+    exe = str(tmp_path / "adapter_setting")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall"] + defs +
+                          ["-I", os.path.join(ROOT, "tests", "mock_includes"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "adapter_setting.cpp"), "-o", exe, "-L", csrc, "-lsdm_hip",
+                           "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "preset ok" in out.stdout, out.stdout + out.stderr
+    assert "setting %d boost %d:" % (setting, boost) in out.stdout, out.stdout
+
+
 @pytest.mark.gpu
 def test_adapter_runs_a_wall_scene():
     build_exe()

@@ -259,3 +259,50 @@ def test_hip_path_against_the_literal_reference_order(cfg_name, params_name, n_f
             assert np.array_equal(vo[k], vg[k]), "frame %d: voxels.%s differs from the literal-order oracle" % (t, k)
         assert np.max(np.abs(vo["wsum"] - vg["wsum"])) <= 1e-4
     g.close()
+
+
+@pytest.mark.parametrize("name,params_name,n_particles,n_warm,n_frames,scene_kw", [
+    # the benchmark state of bench.py: C3 prefilled to 2 M particles, 6 moving objects
+    ("C3_benchmark_state", "vkitti2", 2000000, 0, 10, dict(n_static=48, n_dynamic=6, seed=7)),
+    # bench.py's busy scene: 200 static + 12 moving boxes, three noisy births per point, yaw + sideways drift; the GPU
+    # runs the warm-up alone (the state the timed frames of `stress` start from, ~51 k visible particles), then both
+    ("C3_stress_scene", "vkitti2_nb3", 2000000, 14, 3, dict(n_static=200, n_dynamic=12, seed=11, yaw_rate_deg=1.5, lateral_extra=(0, 0.04))),
+])
+def test_literal_reference_order_on_the_benchmark_workloads(name, params_name, n_particles, n_warm, n_frames, scene_kw):
+    """The same bar on the workloads the numbers of bench.py are quoted on (the bit-exact tests hold them in canonical
+    order only): free-running against the literal-order oracle, identical integers in the particle state and the
+    voxel results, probabilities within 1e-4, frame after frame."""
+    cfg = synth.CONFIGS["C3"]
+    params = synth.PARAMS[params_name]
+    scene = synth.Scene(cfg, **scene_kw)
+    o, g = pu.make_pair(cfg, params, synth.noise_table(), bin_order=0)
+    st, ring, n_pre = synth.prefill_state(cfg, scene, n_particles)
+    assert n_pre >= 0.85 * n_particles
+    g.load_state(st)
+    g.set_ring_state(ring)
+    del st
+    for t in range(n_warm):
+        depth, cloud, pos, q = scene.render(t, params)
+        g.update(depth, cloud, pos, q, scene.moves(t))
+    g.synchronize()
+    pu.restore(o, pu.snapshot(g))
+    n_vis = []
+    for t in range(n_warm, n_warm + n_frames):
+        depth, cloud, pos, q = scene.render(t, params)
+        moves = scene.moves(t)
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves, sync=True)
+        so, sg = o.dump_state(), g.dump_state()
+        for k in ("status", "ts", "track", "label", "forget", "owner"):
+            assert np.array_equal(so[k], sg[k]), "%s frame %d: %s differs from the literal-order oracle" % (name, t, k)
+        live = so["status"] != 0
+        for k in ("w", "px", "py", "pz"):
+            assert np.max(np.abs(so[k][live] - sg[k][live]), initial=0.0) <= 1e-4, "%s frame %d: %s" % (name, t, k)
+        vo, vg = o.voxels(), g.voxels()
+        for k in ("occ", "label", "track"):
+            assert np.array_equal(vo[k], vg[k]), "%s frame %d: voxels.%s differs from the literal-order oracle" % (name, t, k)
+        assert np.max(np.abs(vo["wsum"] - vg["wsum"])) <= 1e-4
+        assert o.stats()["n_visible"] == g.stats()["n_visible"]
+        n_vis.append(g.stats()["n_visible"])
+    assert min(n_vis) > (40000 if n_warm else 15000), n_vis
+    g.close()

@@ -1,10 +1,11 @@
-"""The multi-shard frame protocol (semantic_dsp_map_amd/sharded.py) on CPU: 2 processes, gloo backend.
+"""The multi-shard frame protocol (semantic_dsp_map_amd/sharded.py) on CPU: 2 and 4 processes, gloo backend.
 
-What can be checked without a GPU: the order and content of the three exchanges of ShardedDriver (counts ->
-exports -> ck images, the first two only when objects move), that every rank ends up with every shard's buffers in
-shard order, the RCCL-id rendezvous (broadcast from rank 0), and the weak-scaling grid rule.  The engine is a CPU
-stand-in that fills its buffers with rank-dependent patterns; the kernels behind the real engine are tested on the
-GPU in tests/test_sharded_gpu.py."""
+What can be checked without a GPU: the order and content of the exchanges of ShardedDriver (member counts: all-gather ->
+export segments: all-to-all -> partial ck chunks: all-to-all -> summed chunks: all-gather; the first two only when
+objects move), that every piece lands where the protocol says (segment / part s of a receive buffer comes from shard s and
+was addressed to this shard), the RCCL-id rendezvous (broadcast from rank 0), and the weak-scaling grid rule.  The engine
+is a CPU stand-in that fills its buffers with patterns that encode (source, destination); the kernels behind the real
+engine are tested on the GPU in tests/test_sharded_gpu.py and tests/test_sharded_multiprocess_gpu.py."""
 import os
 import socket
 
@@ -22,15 +23,17 @@ def free_port():
 
 
 class FakeEngine:
-    def __init__(self, torch, rank, world, hw=24, cap=8):
-        self.t, self.rank, self.world, self.hw = torch, rank, world, hw
-        nb = sharded.HALO_HEADER_BYTES + cap * sharded.HALO_RECORD_BYTES
+    def __init__(self, torch, rank, world, chunk=8, cap=2):
+        self.t, self.rank, self.world, self.chunk = torch, rank, world, chunk
+        self.seg = sharded.halo_segment_bytes(cap)
         self.counts_local = torch.zeros(sharded.HALO_OBJ, dtype=torch.int32)
         self.counts_all = torch.full((world * sharded.HALO_OBJ,), -1, dtype=torch.int32)
-        self.halo_send = torch.zeros(nb, dtype=torch.uint8)
-        self.halo_recv = torch.zeros(world * nb, dtype=torch.uint8)
-        self.part = torch.zeros(hw, dtype=torch.float32)
-        self.gathered = torch.zeros(world * hw, dtype=torch.float32)
+        self.halo_send = torch.zeros(world * self.seg, dtype=torch.uint8)
+        self.halo_recv = torch.zeros(world * self.seg, dtype=torch.uint8)
+        self.ck_part = torch.zeros(world * chunk, dtype=torch.float32)
+        self.ck_stage = torch.zeros(world * chunk, dtype=torch.float32)
+        self.ck_chunk = torch.zeros(chunk, dtype=torch.float32)
+        self.ck_full = torch.zeros(world * chunk, dtype=torch.float32)
         self.log = []
 
     def start(self, depth, cloud, pos, q, moves=None, remove_tracks=None, **kw):
@@ -41,16 +44,25 @@ class FakeEngine:
 
     def moves(self):
         self.log.append("moves")
-        self.halo_send[:] = self.rank + 1
+        for d in range(self.world):   # segment d: "from rank to d"
+            self.halo_send[d * self.seg:(d + 1) * self.seg] = 16 * self.rank + d
 
     def predict(self):
         self.log.append("predict")
-        self.part[:] = float(self.rank) + self.t.arange(self.hw, dtype=self.t.float32) / 100
-        return self.part
+        # partial sum of shard `rank` for pixel p: (rank + 1) * 1000 + p
+        self.ck_part[:] = 1000.0 * (self.rank + 1) + self.t.arange(self.world * self.chunk, dtype=self.t.float32)
 
-    def finish(self, gathered, n_parts):
-        self.log.append("finish%d" % n_parts)
-        self.final = gathered.clone()
+    def ck_reduce(self):
+        self.log.append("reduce")
+        st = self.ck_stage.reshape(self.world, self.chunk)
+        acc = self.t.zeros(self.chunk)
+        for s in range(self.world):   # slab order
+            acc = acc + st[s]
+        self.ck_chunk[:] = acc
+
+    def finish(self):
+        self.log.append("finish")
+        self.final = self.ck_full.clone()
 
 
 def worker(rank, world, port, results):
@@ -64,18 +76,23 @@ def worker(rank, world, port, results):
         drv = sharded.ShardedDriver(eng, rank, world, dist)
         # frame 1: no moving object -> only the ck exchange
         drv.update(None, None, None, None, moves=[])
-        assert eng.log == ["start", "moves", "predict", "finish%d" % world]
+        assert eng.log == ["start", "moves", "predict", "reduce", "finish"]
         assert int(eng.counts_all[0]) == -1 and int(eng.halo_recv.sum()) == 0      # untouched
-        for r in range(world):
-            want = float(r) + torch.arange(eng.hw, dtype=torch.float32) / 100
-            assert torch.equal(eng.final[r * eng.hw:(r + 1) * eng.hw], want)        # shard order
-        # frame 2: two moving objects -> all three exchanges
+        # part s of the stage buffer = shard s's sums for MY chunk of the pixels
+        st = eng.ck_stage.reshape(world, eng.chunk)
+        mine = torch.arange(rank * eng.chunk, (rank + 1) * eng.chunk, dtype=torch.float32)
+        for s in range(world):
+            assert torch.equal(st[s], 1000.0 * (s + 1) + mine)
+        # every shard ends up with the whole summed image: sum_s (1000 (s + 1) + p)
+        p = torch.arange(world * eng.chunk, dtype=torch.float32)
+        assert torch.equal(eng.final, 1000.0 * world * (world + 1) / 2 + world * p)
+        # frame 2: two moving objects -> all four exchanges
         drv.update(None, None, None, None, moves=[1, 2])
         for r in range(world):
             row = eng.counts_all[r * sharded.HALO_OBJ:(r + 1) * sharded.HALO_OBJ]
             assert int(row[0]) == 10 * (r + 1) and int(row[1]) == 10 * (r + 1) + 1 and int(row[2]) == 0
-            nb = eng.halo_send.numel()
-            assert torch.all(eng.halo_recv[r * nb:(r + 1) * nb] == r + 1)
+            # segment r of the receive buffer: from shard r, addressed to me
+            assert torch.all(eng.halo_recv[r * eng.seg:(r + 1) * eng.seg] == 16 * r + rank)
         # rendezvous of the RCCL id: everybody gets rank 0's bytes
         from semantic_dsp_map_amd import binding
         binding.comm_unique_id = lambda: bytes([(7 * i + 3) % 256 for i in range(128)]) if rank == 0 else b"\0" * 128
@@ -83,19 +100,20 @@ def worker(rank, world, port, results):
         assert got == bytes([(7 * i + 3) % 256 for i in range(128)])
         results[rank] = "ok"
     except Exception as e:  # noqa: BLE001
-        results[rank] = "FAILED: %r" % (e,)
+        import traceback
+        results[rank] = "FAILED: %r %s" % (e, traceback.format_exc())
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_driver_two_processes_gloo():
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_driver_processes_gloo(world):
     import torch.multiprocessing as mp
-    world = 2
     port = free_port()
     mgr = mp.get_context("spawn").Manager()
     results = mgr.dict()
     mp.spawn(worker, args=(world, port, results), nprocs=world, join=True)
-    assert dict(results) == {0: "ok", 1: "ok"}, dict(results)
+    assert dict(results) == {r: "ok" for r in range(world)}, dict(results)
 
 
 def test_weak_scaled_config_matches_baseline_configs():

@@ -1,7 +1,8 @@
 """Z-slab sharding exercised on ONE GPU: G shard maps live side by side on device 0, the test plays
-the role of the three all-gathers (concatenating the per-shard buffers in shard order) and the union of the shard
-states must equal the oracle run with the same slab-ordered ck summation (ck_slabs = G).  The RCCL calls themselves
-are exercised with a 1-rank communicator (test_native_rccl_single_rank)."""
+the role of the collectives (member counts: all-gather; export segments: all-to-all; partial ck chunks: all-to-all, then
+the summed chunks: all-gather) and the union of the shard states must equal the oracle run with the same slab-ordered ck
+summation (ck_slabs = G).  The RCCL calls themselves are exercised with a 1-rank communicator
+(test_native_rccl_single_rank); the same protocol with one PROCESS per shard in tests/test_sharded_multiprocess_gpu.py."""
 import numpy as np
 import pytest
 
@@ -13,26 +14,38 @@ pytestmark = pytest.mark.gpu
 
 
 class Shard:
-    def __init__(self, cfg, params, noise, r, G, halo_cap=4096):
-        self.m = binding.SdmMap(cfg, params, noise, shard_rank=r, shard_count=G)
+    def __init__(self, cfg, params, noise, r, G, halo_cap=1024):
+        self.m = m = binding.SdmMap(cfg, params, noise, shard_rank=r, shard_count=G)
         self.hw = cfg["width"] * cfg["height"]
-        self.hb = sharded.HALO_HEADER_BYTES + halo_cap * sharded.HALO_RECORD_BYTES
-        m = self.m
-        self.part = m.device_alloc(self.hw * 4)
-        self.gathered = m.device_alloc(G * self.hw * 4)
+        self.chunk = m.ck_chunk_elems()
+        assert self.chunk * G >= self.hw and self.chunk % 64 == 0
+        self.seg = sharded.halo_segment_bytes(halo_cap)
+        self.ck_part = m.device_put(np.zeros(G * self.chunk, np.float32))
+        self.ck_stage = m.device_put(np.zeros(G * self.chunk, np.float32))
+        self.ck_full = m.device_put(np.zeros(G * self.chunk, np.float32))
         self.counts_local = m.device_alloc(sharded.HALO_OBJ * 4)
         self.counts_all = m.device_alloc(G * sharded.HALO_OBJ * 4)
-        self.send = m.device_put(np.zeros(self.hb, np.uint8))
-        self.recv = m.device_put(np.zeros(G * self.hb, np.uint8))
-        m.set_ck_buffer(self.part)
+        self.send = m.device_put(np.zeros(G * self.seg, np.uint8))
+        self.recv = m.device_put(np.zeros(G * self.seg, np.uint8))
+        m.set_ck_buffer(self.ck_part)
         m.set_halo_buffers(self.counts_local, self.counts_all, self.send, self.recv, halo_cap)
 
 
-def gather(shards, src_attr, dst_attr, nbytes):
-    allb = np.concatenate([s.m.device_download(getattr(s, src_attr), nbytes) for s in shards])
+def gather(shards, src_attr, dst_attr, nbytes, src_offset=lambda r: 0):
+    """all-gather: every shard's `nbytes` at src, concatenated in shard order, land at every shard's dst"""
+    allb = np.concatenate([s.m.device_download(getattr(s, src_attr) + src_offset(r), nbytes) for r, s in enumerate(shards)])
     for s in shards:
         s.m.device_upload(getattr(s, dst_attr), allb)
     return allb
+
+
+def all_to_all(shards, src_attr, dst_attr, piece):
+    """all-to-all: piece d of shard s's src becomes piece s of shard d's dst"""
+    G = len(shards)
+    src = [s.m.device_download(getattr(s, src_attr), G * piece).reshape(G, piece) for s in shards]
+    for d, s in enumerate(shards):
+        s.m.device_upload(getattr(s, dst_attr), np.concatenate([src[r][d] for r in range(G)]))
+    return src
 
 
 def run_frame(shards, frame):
@@ -47,13 +60,16 @@ def run_frame(shards, frame):
         s.m.frame_moves()
     exported = 0
     if has_moves:
-        allb = gather(shards, "send", "recv", shards[0].hb)
-        exported = int(allb.reshape(G, -1)[:, :4].copy().view(np.uint32).sum())
+        src = all_to_all(shards, "send", "recv", shards[0].seg)
+        exported = int(sum(int(x[:, :4].copy().view(np.uint32).sum()) for x in src))
     for s in shards:
         s.m.frame_predict()
-    gather(shards, "part", "gathered", shards[0].hw * 4)
+    all_to_all(shards, "ck_part", "ck_stage", shards[0].chunk * 4)
     for s in shards:
-        s.m.update_finish(s.gathered, G)
+        s.m.ck_reduce(s.ck_stage, s.ck_full)
+    gather(shards, "ck_full", "ck_full", shards[0].chunk * 4, src_offset=lambda r: r * shards[0].chunk * 4)
+    for s in shards:
+        s.m.update_finish(s.ck_full, 1)
     for s in shards:
         s.m.synchronize()
     return exported
@@ -110,10 +126,15 @@ def test_native_rccl_single_rank():
     a = binding.SdmMap(cfg, params, noise)
     b = binding.SdmMap(cfg, params, noise)
     b.comm_init(binding.comm_unique_id(), 1024)
+    b.comm_timing(True)
     for depth, cloud, pos, q, moves in frames:
         a.update(depth, cloud, pos, q, moves, sync=True)
         b.update_sharded(depth, cloud, pos, q, moves)
         b.synchronize()
+        ct = b.comm_times()
+        assert set(ct) == {"counts_allgather", "halo_alltoall", "ck_alltoall", "ck_allgather"}
+        assert ct["ck_alltoall"] > 0 and ct["ck_allgather"] > 0 and all(0 <= v < 1e5 for v in ct.values())
+        assert (ct["counts_allgather"] > 0) == (len(moves) > 0) == (ct["halo_alltoall"] > 0)
     sa, sb = a.dump_state(), b.dump_state()
     for k in pu.STATE_KEYS:
         assert pu.diff_report(k, sa[k], sb[k]) is None
