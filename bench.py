@@ -152,6 +152,94 @@ def stress_run(synth, sharded, steps=8, warmup=14, cpu_frames=4):
     return res
 
 
+def grown_run(synth, sharded, n_grow=180, steps=20, cpu_frames=3):
+    """A map whose population the filter grew itself: start EMPTY, run n_grow frames of a cluttered street with ego
+    motion (forward 0.3 m / frame, yaw 1 deg / frame, sideways drift: slabs recycled on two axes), three noisy births per
+    point, then time `steps` frames issued back to back like the headline run; per-stage GPU times of four more frames on
+    a copy of the state, and the oracle (literal order, one thread) on that very state and frames."""
+    cfg = synth.CONFIGS["C3"]
+    params = synth.PARAMS["vkitti2_nb3"]
+    scene = synth.Scene(cfg, n_static=100, n_dynamic=8, seed=13, yaw_rate_deg=1.0, lateral_extra=(0, 0.03))
+    eng = sharded.NativeShardedMap(cfg, params, 0, 1, 0)
+    m = eng.map
+    m.generate_noise_table(seed=20250217)
+    noise = m.download_noise_table()
+    t0 = time.time()
+    pending = []
+    for t in range(n_grow):
+        depth, cloud, pos, q = scene.render(t, params)
+        dd, dc = m.device_put(depth), m.device_put(cloud)
+        eng.update(dd, dc, pos, q, scene.moves(t))
+        pending += [dd, dc]
+        if len(pending) >= 16:
+            m.synchronize()
+            for ptr in pending:
+                m.device_free(ptr)
+            pending = []
+    m.synchronize()
+    for ptr in pending:
+        m.device_free(ptr)
+    state0, ring0, stamps0 = m.dump_state(), m.ring_state(), m.stamps()
+    n_prof = 4
+    frames = []
+    for t in range(n_grow, n_grow + steps + n_prof):
+        depth, cloud, pos, q = scene.render(t, params)
+        frames.append((depth, cloud, pos, q, scene.moves(t), m.device_put(depth), m.device_put(cloud)))
+    t_grow = time.time() - t0
+
+    def fence():
+        m.synchronize()
+        m.device_synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for f in frames[:steps]:
+        eng.update(f[5], f[6], f[2], f[3], f[4])
+    fence()
+    dt = time.perf_counter() - t0
+    stats = m.stats(count_live=True)
+    m.set_profiling(True)
+    acc, vis_l, live_l, tiles_l = np.zeros(8), [], [], []
+    for f in frames[steps:]:
+        eng.update(f[5], f[6], f[2], f[3], f[4])
+        m.synchronize()
+        stt = m.stats()
+        acc += np.array(stt["stage_ms"])
+        vis_l.append(stt["n_visible"])
+        live_l.append(stt["sweep_live_voxels"])
+        tiles_l.append(stt["sweep_tiles"])
+    m.set_profiling(False)
+    V = 1 << (cfg["x_n"] + cfg["y_n"] + cfg["z_n"])
+    names = ["", "ego", "move", "remove", "visibility", "weight", "birth", "occupancy"]
+    res = {"value": round(V / (dt / steps) / 1e6, 1), "unit": "Mvoxels/s", "ms_per_step": round(dt * 1e3 / steps, 4), "steps": steps,
+           "frames_grown_from_empty": n_grow, "live_particles": stats["live_particles"], "live_voxels": stats["live_voxels"],
+           "visible_particles_per_frame": int(np.mean(vis_l)),
+           "stage_ms": {k: round(acc[i] / n_prof, 4) for i, k in enumerate(names) if k},
+           "sweep": {"tiles_looked_into": int(np.mean(tiles_l)), "voxels_evaluated_in_full": int(np.mean(live_l))},
+           "grow_and_render_s": round(t_grow, 1),
+           "workload": "grown: C3 grid, empty map, %d frames of 100 static + 8 moving boxes, 3 noisy births per point, forward 0.3 m + yaw "
+                       "1 deg + 0.03 m sideways per frame; then %d timed frames" % (n_grow, steps)}
+    if cpu_frames > 0:
+        from oracle import oracle as orc
+        o = orc.OracleMap(dict(cfg, bin_order=0), params, noise)
+        o.load_state(state0)
+        o.set_stamps(*stamps0)
+        o.set_ring_state(ring0)
+        del state0
+        times = []
+        for k, f in enumerate(frames[:cpu_frames + 1]):
+            t0 = time.perf_counter()
+            o.update(f[0], f[1], f[2], f[3], f[4])
+            if k > 0:  # the first frame warms the caches
+                times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        res["cpu_baseline"] = {"value": round(V / med / 1e6, 2), "unit": "Mvoxels/s", "cores": 1, "kind": "port", "ms_per_frame": round(med * 1e3, 1),
+                               "sample": "%d frames from the same map state (dumped from the GPU after the %d growth frames), 1 thread" % (len(times), n_grow)}
+        res["x_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+    m.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,12 +253,17 @@ def main():
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling run (C4: 256^3 / 8M particles over the GPUs)")
     ap.add_argument("--no-stress", action="store_true", help="skip the busy-scene run (N = 1 only)")
     ap.add_argument("--only-stress", action="store_true", help="run nothing but the busy scene (development)")
+    ap.add_argument("--no-grown", action="store_true", help="skip the run on a map grown from empty (N = 1 only)")
+    ap.add_argument("--only-grown", action="store_true", help="run nothing but the grown-map leg (development)")
     args = ap.parse_args()
 
     from semantic_dsp_map_amd import sharded, synth
 
     if args.only_stress:
         print(json.dumps({"stress": stress_run(synth, sharded)}))
+        return
+    if args.only_grown:
+        print(json.dumps({"grown": grown_run(synth, sharded)}))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -240,6 +333,9 @@ def main():
         dt = float(tt.item())
 
     stats = m.stats(count_live=True)
+    issue_mode = ("sharded: launch by launch, collectives on the streams" if world > 1 else
+                  "hipGraph replay" if stats["graph_frames"] >= args.steps else
+                  "launch by launch" if stats["graph_frames"] == 0 else "mixed")
     launch_mode = {"graph_frames": stats["graph_frames"], "direct_frames": stats["direct_frames"],
                    "host_us_per_launched_frame": round(stats["host_enqueue_us"], 1),
                    "policy": "SDM_GRAPH=%s (0 launch by launch, 1 one branched hipGraph, 3 one chain graph, 4 five chain graphs on the "
@@ -328,11 +424,15 @@ def main():
 
     layout_bytes = in_frame_bytes(sweep_tiles_avg, sweep_live_avg)
     achieved = layout_bytes / (sweep_ms * 1e-3)
+    traffic, traffic_source = pmc_traffic(S, vox, sweep_live_avg, sweep_tiles_avg)
     roofline = {"kernel": "k_occupancy<%d>" % S, "bound": "hbm",
                 "case": "in-frame launch (incremental: tiles / voxels written or stamped since the previous sweep)",
                 "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_BPS, 4),
-                "traffic": pmc_traffic(S, vox, sweep_live_avg, sweep_tiles_avg), "bytes_per_launch": int(layout_bytes),
+                "traffic": traffic,
+                "traffic_source": None if traffic is None else "%s: rocprofv3 PMC passes of this command committed with the tree "
+                                                               "(FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run" % traffic_source,
+                "bytes_per_launch": int(layout_bytes),
                 "avg_launch_ms": round(sweep_ms, 5), "voxels": vox, "launches_timed": n_extra,
                 "tiles_looked_into": int(sweep_tiles_avg), "tiles": vox // TILE,
                 "voxels_evaluated_in_full": int(sweep_live_avg), "voxels_with_live_slots": live_vox_local,
@@ -375,7 +475,17 @@ def main():
                                   "achieved": round(dense_bytes / dense_ms / 1e6, 1),
                                   "frac": round(dense_bytes / dense_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
                                   "frac_on_survey_bytes": round(dense_slot_bytes / dense_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
+                                  "track_ids": "every slot draws one of eight: 4-5 different track ids per voxel, the worst case for the vote",
                                   "launches_timed": 10}
+        # the same with the track ids of a real map: a voxel holds particles of ONE surface, i.e. one track id (one voxel
+        # in 16 two: object borders) - the vote then takes its single-track path
+        m.fill_dense_ex(1)
+        surf_ms = m.time_occupancy_sweep(iters=10)
+        roofline["dense_case_surface"] = {"kernel": roofline["dense_case"]["kernel"], "bytes_per_launch": dense_bytes,
+                                          "avg_launch_ms": round(surf_ms, 5), "achieved": round(dense_bytes / surf_ms / 1e6, 1),
+                                          "frac": round(dense_bytes / surf_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
+                                          "frac_on_survey_bytes": round(dense_slot_bytes / surf_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
+                                          "track_ids": "every voxel draws one track id, one voxel in 16 two", "launches_timed": 10}
 
     # ---- strong scaling (BASELINE.json C4): the same 256^3 map with 8 M particles, split into `world` Z slabs.  Its own
     # map and frames; a separate object in the line (the headline value above stays the weak-scaling one).
@@ -394,12 +504,16 @@ def main():
     if world == 1 and not args.no_stress and not args.no_cpu:
         stress = stress_run(synth, sharded)
 
+    grown = None
+    if world == 1 and not args.no_grown and not args.no_cpu:
+        grown = grown_run(synth, sharded)
+
     if rank == 0:
         out = {
             "metric": "Mvoxels updated/sec (256^3 grid, 2M particles, VKITTI2 camera; whole hot-path frame)",
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "issue_mode": issue_mode,
             "config": {"workload": "%s: %dx%dx%d voxels, %d slots/voxel, %dx%d image, window %d, %s params, "
                                    "6 dynamic objects, %d live particles, %d visible/frame"
                                    % (args.config if world == 1 else "%s weak-scaled x%d" % (args.config, world),
@@ -418,6 +532,8 @@ def main():
             out["strong_scaling"] = strong
         if stress is not None:
             out["stress"] = stress
+        if grown is not None:
+            out["grown"] = grown
         if world == 1:
             out["stage_ms"] = {k: round(stage_ms[i], 4) for i, k in
                                enumerate(["", "ego", "move", "remove", "visibility", "weight", "birth", "occupancy"]) if k}
@@ -426,21 +542,26 @@ def main():
         dist.destroy_process_group()
 
 
+PMC_FILES = ("r03_sweep_pmc.json", "r02_sweep_pmc.json")  # newest first
+
+
 def pmc_traffic(S, voxels, evaluated, tiles):
-    """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes over this very command
-    (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, separate runs: profiles/r02_sweep_pmc.json); None if they were
-    taken on a different kernel shape or with a number of fully evaluated voxels or of visited tiles more than 25 % off.  PMC counters
-    cannot be read from inside this process."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_sweep_pmc.json")) as f:
-            p = json.load(f)
-        if (p["kernel"] == "k_occupancy<%d>" % S and p["voxels"] == voxels
-                and abs(p["voxels_evaluated_in_full"] - evaluated) <= 0.25 * max(evaluated, 1)
-                and abs(p["tiles_looked_into"] - tiles) <= 0.25 * max(tiles, 1)):
-            return int(p["traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+    """(HBM bytes per launch of the sweep kernel, the committed file they come from).  PMC counters cannot be read from
+    inside this process: the figure is taken from the rocprofv3 PMC passes over this very command that are committed
+    under profiles/ (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, separate runs; tools/pmc_sweep.sh) - it is NOT a
+    measurement of this run, `traffic_source` says so in the line.  (None, None) if no committed pass matches: different
+    kernel shape, or a number of fully evaluated voxels or of visited tiles more than 25 % off."""
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                p = json.load(f)
+            if (p["kernel"] == "k_occupancy<%d>" % S and p["voxels"] == voxels
+                    and abs(p["voxels_evaluated_in_full"] - evaluated) <= 0.25 * max(evaluated, 1)
+                    and abs(p["tiles_looked_into"] - tiles) <= 0.25 * max(tiles, 1)):
+                return int(p["traffic_bytes_per_launch"]), "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
 
 
 def cpu_baseline(cfg, params, noise, frames, st, ring, n_frames, V):

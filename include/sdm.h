@@ -406,6 +406,10 @@ sdm_status sdm_get_extrinsic(sdm_map *m, float *out16);
 sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms);
 /* bench hook: overwrite the map with the dense case of SURVEY.md 8(d) (every slot live, every voxel observed) */
 sdm_status sdm_debug_fill_dense(sdm_map *m);
+/* mode 0 (= sdm_debug_fill_dense): every slot draws one of eight track ids - four to five different ones per voxel, the
+ * worst case for the track vote; mode 1: every voxel draws one (a voxel of a real map holds particles of one surface),
+ * one voxel in 16 two */
+sdm_status sdm_debug_fill_dense_ex(sdm_map *m, int32_t mode);
 
 /* ---- device-side unit tests of the hand-written primitives (tests/test_primitives_gpu.py) */
 sdm_status sdm_test_scan(const uint32_t *in, uint32_t *out, int64_t n);

@@ -164,6 +164,7 @@ def load_library():
         "sdm_get_extrinsic": [vp, vp],
         "sdm_time_occupancy_sweep": [vp, i32, C.POINTER(C.c_float)],
         "sdm_debug_fill_dense": [vp],
+        "sdm_debug_fill_dense_ex": [vp, i32],
         "sdm_test_scan": [vp, vp, i64],
         "sdm_test_sort_pairs": [vp, vp, vp, vp, i64, i32],
     }
@@ -525,6 +526,9 @@ class SdmMap:
         out = np.empty(16, np.float32)
         _check(self.L, self.L.sdm_get_extrinsic(self.h, _ptr(out)), "sdm_get_extrinsic")
         return out.reshape(4, 4)
+
+    def fill_dense_ex(self, mode):
+        _check(self.L, self.L.sdm_debug_fill_dense_ex(self.h, mode), "sdm_debug_fill_dense_ex")
 
     def fill_dense(self):
         _check(self.L, self.L.sdm_debug_fill_dense(self.h), "sdm_debug_fill_dense")

@@ -24,6 +24,20 @@ namespace {
 
 constexpr int TPB = 256;
 
+#ifdef SDM_AB_TIMERS
+// development aid (tools/ab_build.sh -DSDM_AB_TIMERS=1): where does a kernel's time go?  100 MHz wall-clock ticks at a few
+// checkpoints per wave, reduced with atomics into g_dbg (read with hipMemcpyFromSymbol by tools/probes/timers.py via
+// sdm_debug_timers)
+}  // namespace
+__device__ unsigned long long g_dbg[4096 * 4];  // per workgroup: 4 checkpoints, plain stores by one lane
+namespace {
+#define DBG_T() wall_clock64()
+#define DBG_PUT(i, v) do { if (blockIdx.x < 4096) g_dbg[blockIdx.x * 4 + (i)] = (unsigned long long)(v); } while (0)
+#else
+#define DBG_T() 0ull
+#define DBG_PUT(i, v)
+#endif
+
 // Whole-voxel fetch: all S slots of one field with the widest aligned vector loads (16 B pieces).  The copy goes
 // through a plain vector type so that the compiler cannot narrow it to the bytes it happens to use (slot 0 of
 // most arrays is dead, which otherwise splits a 32-byte row into dword/dwordx3 pieces).
@@ -193,7 +207,12 @@ __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__
 // PLAIN = the caller has checked (occupancy_is_plain) that no live slot of the voxel can be clamped, culled or is a
 // guessed birth: those rules and their write-backs drop out.  The sweeps test that per wave - one special voxel sends
 // the whole wave through the general version - because the rules fire rarely and cost a third of the instructions.
-template <int S, bool PLAIN>
+// SINGLE (with PLAIN) = the caller has checked (occupancy_is_plain) that all live slots of the voxel carry ONE track id -
+// nearly every voxel of a real map: a voxel holds particles of one surface.  The vote then needs no pair comparisons:
+// every voting slot's total is the sum of all voting weights in slot order (the very additions the pair loop performs for
+// it, the +0.f terms of the other slots included), the first voting slot wins, nobody beats it (equal total, equal
+// track), and the label is the last voting slot's.
+template <int S, bool PLAIN, bool SINGLE = false>
 __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_threshold, uint32_t lv, uint32_t smax,
                                                    const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv_in)[S],
                                                    const uint16_t (&trk16)[S], const uint8_t (&lab8)[S],
@@ -240,27 +259,44 @@ __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_th
     tv[i] = vote[i] ? trk[i] : 0xffffffffu - (uint32_t)i;  // distinct per slot: matches no other slot's id
     wvote[i] = vote[i] ? wv[i] : 0.f;
   }
-  float best_w = 0.f;
   uint32_t best_t = 0xffffff00u;  // matches no slot, voting or not
+  uint32_t best_l = 0;
   bool have = false;
-#pragma unroll
-  for (int i = 1; i < S; ++i) {
+  if constexpr (SINGLE) {
+    static_assert(PLAIN, "the single-track vote is only instantiated for plain voxels");
     float tot = 0.f;
+    uint32_t t1 = 0, l1 = 0;
+    bool any_vote = false;
 #pragma unroll
     for (int j = 1; j < S; ++j) {
-      // (a slot always matches itself.  Sharing the 21 symmetric comparisons was tried: the compiler keeps them in
-      // SGPR pairs, runs out, and spills to VGPR lanes - more instructions than the 21 comparisons saved)
-      if (j == i) tot += wvote[j];
-      else tot += tv[j] == trk[i] ? wv[j] : 0.f;
+      tot += wvote[j];
+      t1 = vote[j] ? trk[j] : t1;
+      l1 = vote[j] ? lab[j] : l1;
+      any_vote = any_vote || vote[j];
     }
-    const bool better = vote[i] && tot > 0.f && (!have || tot > best_w || (tot == best_w && trk[i] < best_t));
-    best_w = better ? tot : best_w;
-    best_t = better ? trk[i] : best_t;
-    have = have || better;
-  }
-  uint32_t best_l = 0;
+    have = any_vote && tot > 0.f;
+    best_t = t1;
+    best_l = have ? l1 : 0u;
+  } else {
+    float best_w = 0.f;
 #pragma unroll
-  for (int j = 1; j < S; ++j) best_l = tv[j] == best_t ? lab[j] : best_l;
+    for (int i = 1; i < S; ++i) {
+      float tot = 0.f;
+#pragma unroll
+      for (int j = 1; j < S; ++j) {
+        // (a slot always matches itself.  Sharing the 21 symmetric comparisons was tried: the compiler keeps them in
+        // SGPR pairs, runs out, and spills to VGPR lanes - more instructions than the 21 comparisons saved)
+        if (j == i) tot += wvote[j];
+        else tot += tv[j] == trk[i] ? wv[j] : 0.f;
+      }
+      const bool better = vote[i] && tot > 0.f && (!have || tot > best_w || (tot == best_w && trk[i] < best_t));
+      best_w = better ? tot : best_w;
+      best_t = better ? trk[i] : best_t;
+      have = have || better;
+    }
+#pragma unroll
+    for (int j = 1; j < S; ++j) best_l = tv[j] == best_t ? lab[j] : best_l;
+  }
   best_t = have ? best_t : 0u;
   if (!any_live) {  // deleted since it was flagged, or only stale slots: the empty result
     out.wsum = 0.f;
@@ -307,11 +343,13 @@ __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_th
 // (clamp) or below the initial weight (cull candidates), and no slot at all is a guessed birth.  Stale and empty
 // slots are ignored for the weights (their weight may be anything), which costs the vacancy test the evaluation
 // repeats - still far cheaper than the rules it saves.
+// `single` comes back true iff all live slots carry one track id (the voting slots are among the live ones).
 template <int S>
 __device__ __forceinline__ bool occupancy_is_plain(uint32_t smax, const uint16_t (&ts1)[S], const uint8_t (&st1)[S],
-                                                   const float (&wv)[S]) {
+                                                   const float (&wv)[S], const uint16_t (&trk)[S], bool &single) {
   float lo = SDM_OCC_INIT_WEIGHT, hi = 1.f;
   bool guess = false;
+  uint32_t tmin = 0xffffffffu, tmax = 0u;
 #pragma unroll
   for (int i = 1; i < S; ++i) {
     const bool live = st1[i] != ST_INVALID && (uint32_t)ts1[i] >= smax;
@@ -319,7 +357,11 @@ __device__ __forceinline__ bool occupancy_is_plain(uint32_t smax, const uint16_t
     lo = fminf(lo, w);
     hi = fmaxf(hi, w);
     guess = guess || st1[i] == ST_GUESSED_BORN;
+    const uint32_t t = trk[i];
+    tmin = min(tmin, live ? t : 0xffffffffu);
+    tmax = max(tmax, live ? t : 0u);
   }
+  single = tmin >= tmax;  // one track id (or no live slot at all: 0xffffffff >= 0)
   return !guess && lo >= SDM_OCC_INIT_WEIGHT && hi <= 1.f;  // (a NaN weight fails neither test: it takes no rule either)
 }
 
@@ -329,9 +371,14 @@ __device__ __forceinline__ void occupancy_evaluate_wave(const State &st, float o
                                                         const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv)[S],
                                                         const uint16_t (&trk)[S], const uint8_t (&lab)[S],
                                                         sdm_voxel_result &out) {
-  const bool special = mine && !occupancy_is_plain<S>(smax, ts1, st1, wv);
+  bool single = true;
+  const bool special = mine && !occupancy_is_plain<S>(smax, ts1, st1, wv, trk, single);
   if (__ballot(special) == 0ull) {  // wave-uniform
-    if (mine) occupancy_evaluate<S, true>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab, out);
+    if (__ballot(mine && !single) == 0ull) {
+      if (mine) occupancy_evaluate<S, true, true>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab, out);
+    } else {
+      if (mine) occupancy_evaluate<S, true, false>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab, out);
+    }
   } else {
     if (mine) occupancy_evaluate<S, false>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab, out);
   }
@@ -665,6 +712,7 @@ __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_thres
   constexpr int PIECES = OCC_CHUNK * REC / 16;   // 16-byte pieces of one chunk of records
   constexpr int PPL = (PIECES + 63) / 64;
   __shared__ v4u rec_stage[OCC_WAVES][PIECES];  // one chunk of records per wave, for the lane <-> record transposition
+  __shared__ uint32_t smax_stage[OCC_WAVES][OCC_CHUNK];  // ... and the slab stamps of its voxels
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t lvw = blockIdx.x * OCC_TILE + wave * OCC_CPW * OCC_CHUNK;  // first voxel of this wave
   // the masks of the wave's chunks: lane k holds chunk k's
@@ -680,8 +728,15 @@ __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_thres
                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, k);
     evalbits |= (uint32_t)((m >> lane) & 1ull) << k;
   }
-  auto fetch = [&](int k, v4u (&buf)[PPL]) {  // lane-linear loads of chunk k's records: 1 KB contiguous per instruction
+  // (the slab stamp of this lane's voxel of the chunk travels with the chunk's records: loaded where the evaluation needs
+  // it, it was a dependent L2 round trip in every step)
+  auto fetch = [&](int k, v4u (&buf)[PPL], uint32_t &smax) {  // lane-linear loads of chunk k's records: 1 KB contiguous per instruction
     const uint32_t lvc = lvw + k * OCC_CHUNK;
+    if (lvc + lane < d.v_count) {
+      uint32_t rx, ry, rz;
+      voxel_to_ring(d, d.v_begin + lvc + lane, rx, ry, rz);
+      smax = stamp_max(st, rx, ry, rz);
+    }
     const uint32_t nvox = d.v_count - lvc < (uint32_t)OCC_CHUNK ? d.v_count - lvc : (uint32_t)OCC_CHUNK;
     const uint32_t npieces = nvox * REC / 16;  // nvox is a multiple of 8
     const v4u *src = reinterpret_cast<const v4u *>(st.rec + (size_t)lvc * REC);
@@ -691,7 +746,8 @@ __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_thres
       if (idx < npieces) buf[j] = __builtin_nontemporal_load(src + idx);
     }
   };
-  auto to_stage = [&](const v4u (&buf)[PPL]) {
+  auto to_stage = [&](const v4u (&buf)[PPL], uint32_t smax) {
+    smax_stage[wave][lane] = smax;
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const uint32_t idx = j * 64 + lane;
@@ -707,16 +763,18 @@ __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_thres
   int k1 = next_dense(k);
   int k2 = k1 < OCC_CPW ? next_dense(k1) : OCC_CPW;
   v4u b0[PPL], b1[PPL];
+  uint32_t s0 = 0, s1 = 0;  // slab stamps of the chunks in b0, b1
   {
     v4u first[PPL];
-    fetch(k, first);
-    if (k1 < OCC_CPW) fetch(k1, b0);
-    if (k2 < OCC_CPW) fetch(k2, b1);
-    to_stage(first);
+    uint32_t sf = 0;
+    fetch(k, first, sf);
+    if (k1 < OCC_CPW) fetch(k1, b0, s0);
+    if (k2 < OCC_CPW) fetch(k2, b1, s1);
+    to_stage(first, sf);
   }
   // one step: evaluate chunk k out of the stage, move `up` (chunk k1, landed or landing) into the stage, start the loads
   // of the chunk after k2 into `up`.  The two register buffers alternate, hence the loop body holds two steps.
-  auto step = [&](v4u (&up)[PPL]) {
+  auto step = [&](v4u (&up)[PPL], uint32_t &s_up) {
     const bool mine = (evalbits >> k) & 1u;
     const uint32_t lv = lvw + k * OCC_CHUNK + lane;
     uint16_t ts1[S], trk[S];
@@ -734,9 +792,15 @@ __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_thres
       __builtin_memcpy(trk, __builtin_assume_aligned(r + 6 * S, RA < 2 * S ? RA : 2 * S), 2 * S);
       __builtin_memcpy(lab, __builtin_assume_aligned(r + 8 * S, RA < S ? RA : S), S);
       __builtin_memcpy(st1, __builtin_assume_aligned(r + 9 * S, RA < S ? RA : S), S);
-      uint32_t rx, ry, rz;
-      voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
-      smk = stamp_max(st, rx, ry, rz);
+#ifdef SDM_AB_DENSE_STAMP_IN_STEP
+      {
+        uint32_t rx, ry, rz;
+        voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+        smk = stamp_max(st, rx, ry, rz);
+      }
+#else
+      smk = smax_stage[wave][lane];
+#endif
     }
     // the evaluation runs on registers only; the two chunks behind this one are landing meanwhile
     sdm_voxel_result out;
@@ -748,14 +812,14 @@ __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_thres
     k = k1;
     k1 = k2;
     k2 = k2 < OCC_CPW ? next_dense(k2) : OCC_CPW;
-    if (k < OCC_CPW) to_stage(up);
-    if (k2 < OCC_CPW) fetch(k2, up);
+    if (k < OCC_CPW) to_stage(up, s_up);
+    if (k2 < OCC_CPW) fetch(k2, up, s_up);
   };
 #pragma unroll 1
   while (k < OCC_CPW) {
-    step(b0);
+    step(b0, s0);
     if (k >= OCC_CPW) break;
-    step(b1);
+    step(b1, s1);
   }
 }
 
@@ -1211,14 +1275,19 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   if (dirty || wrote_free || stamped) mark_tile(st, lv);
 }
 
-// Two phases per workgroup.  Only about a third of the voxels of the frustum's index box were reached, and testing
+// Three phases per workgroup round.  Only about a third of the voxels of the frustum's index box were reached, and testing
 // them one by one costs a dozen bit-test loads each.  So the candidates are taken 64 at a time: a "word" is the 64
 // voxels along x whose lower corner vertices share one 64-bit word of the vertex bitmaps.  A voxel is handled iff one
 // of its 8 corner vertices was reached by the flood: per vertex line (4 per voxel row) that is word | word >> 1 (the
 // upper-x corner; bit 0 of the next word shifts in).  Simple masks: vertex reached = in-frustum bit & its x-line
-// reached; complex masks: the generic flood wrote the reached bits to sc.reach.  VIS_WORDS words per workgroup; their
-// set bits are then dealt out to the lanes, so the loads that go to HBM are issued by full waves.
-constexpr int VIS_WORDS = 16;
+// reached; complex masks: the generic flood wrote the reached bits to sc.reach.  VIS_WORDS words per workgroup round;
+// their set bits are then dealt out to the lanes.
+// Nine candidates in ten are empty voxels, which need two dependent loads (flag byte, depth under the corner); the
+// kernel is a chain of such dependent loads, so every thread runs its (up to VIS_J) candidates side by side: all flag
+// bytes are requested, then all depths, then the stamps go out.  Voxels that hold something are listed in LDS and
+// handled afterwards by full waves (round 2 ran one candidate per thread at a time, empty or not: 39 us, waiting).
+constexpr int VIS_WORDS = 32;
+constexpr int VIS_J = VIS_WORDS * 64 / TPB;  // candidates per thread and round, at most
 
 __device__ __forceinline__ int nth_set_bit(unsigned long long m, uint32_t n) {  // position of the n-th (0-based) set bit
   int pos = 0;
@@ -1238,6 +1307,8 @@ template <int S>
 __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc) {
   __shared__ unsigned long long wmask[VIS_WORDS];
   __shared__ uint32_t woff[VIS_WORDS + 1];
+  __shared__ uint16_t full_list[VIS_WORDS * 64];  // candidates that hold something: word << 6 | bit
+  __shared__ uint32_t n_full;
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   const float *__restrict__ depth_img = sc.fa->depth;
   const bool force_generic = sc.fa->force_generic != 0;
@@ -1248,6 +1319,7 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
   // the grid does not depend on the frame (the box does): workgroups stride over the box's words
   for (uint32_t g0 = blockIdx.x * VIS_WORDS; g0 < n_words; g0 += gridDim.x * VIS_WORDS) {
   __syncthreads();  // the previous round's lists have been read
+  if (threadIdx.x == 0) n_full = 0;
   if (threadIdx.x < VIS_WORDS) {
     const uint32_t g = g0 + threadIdx.x;
     unsigned long long m = 0;
@@ -1281,27 +1353,85 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
       }
     }
     wmask[threadIdx.x] = m;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
+    // exclusive prefix of the words' popcounts by the wave that holds them
+    const uint32_t c = (uint32_t)__popcll(m);
+    uint32_t inc = c;
 #pragma unroll
-    for (int w = 0; w < VIS_WORDS; ++w) {
-      woff[w] = run;
-      run += (uint32_t)__popcll(wmask[w]);
+    for (int off = 1; off < VIS_WORDS; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if ((int)threadIdx.x >= off) inc += t;
     }
-    woff[VIS_WORDS] = run;
+    woff[threadIdx.x] = inc - c;
+    if (threadIdx.x == VIS_WORDS - 1) woff[VIS_WORDS] = inc;
   }
   __syncthreads();
   const uint32_t nl = woff[VIS_WORDS];
   // voxels handled (statistics): one add per workgroup - an atomic per voxel on these 64 addresses cost 26 us
   if (threadIdx.x == 0 && nl) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].fv, nl);
-  for (uint32_t li = threadIdx.x; li < nl; li += TPB) {
-    int w = 0;
+  if (nl == 0) continue;  // workgroup-uniform
+  // ---- phase 1: every candidate's flag byte; empty voxels finished, the others listed
+  uint32_t code[VIS_J], lvv[VIS_J], flg[VIS_J];
 #pragma unroll
-    for (int k = 1; k < VIS_WORDS; ++k) w += woff[k] <= li ? 1 : 0;
-    const uint32_t g = g0 + w;
-    const int ax = ((wlo + (int)(g % nwx)) << 6) + nth_set_bit(wmask[w], li - woff[w]);
+  for (int j = 0; j < VIS_J; ++j) {
+    const uint32_t li = threadIdx.x + (uint32_t)j * TPB;
+    code[j] = 0xffffffffu;
+    lvv[j] = 0;
+    flg[j] = 0;
+    if (li < nl) {
+      int w = 0;
+#pragma unroll
+      for (int k = 1; k < VIS_WORDS; ++k) w += woff[k] <= li ? 1 : 0;
+      const int bit = nth_set_bit(wmask[w], li - woff[w]);
+      code[j] = (uint32_t)(w << 6 | bit);
+      const uint32_t g = g0 + (uint32_t)w;
+      const int ax = ((wlo + (int)(g % nwx)) << 6) + bit;
+      const int ay = f.bb0[1] + (int)((g / nwx) % by);
+      const int az = f.bb0[2] + (int)(g / ((uint32_t)nwx * by));
+      const uint32_t rx = axis_correct(ax + f.eq[0], d.NX), ry = axis_correct(ay + f.eq[1], d.NY), rz = axis_correct(az + f.eq[2], d.NZ);
+      lvv[j] = ring_to_voxel(d, rx, ry, rz) - d.v_begin;
+      flg[j] = st.vflag[lvv[j]] & VF_STATE;  // VF_EMPTY: every slot INVALID, the record is not touched
+    }
+  }
+  float imz[VIS_J], imd[VIS_J];
+#pragma unroll
+  for (int j = 0; j < VIS_J; ++j) {
+    imz[j] = 1.f;
+    imd[j] = 0.f;  // "not seen"
+    if (code[j] == 0xffffffffu) continue;
+    if (flg[j]) {
+      full_list[atomicAdd(&n_full, 1u)] = (uint16_t)code[j];
+      continue;
+    }
+    // imaginary particle at the voxel's min corner, mapXYZIdxToGlobalPose (operations.h:986-991, 1418-1431)
+    const uint32_t g = g0 + (code[j] >> 6);
+    const int ax = ((wlo + (int)(g % nwx)) << 6) + (int)(code[j] & 63u);
+    const int ay = f.bb0[1] + (int)((g / nwx) % by);
+    const int az = f.bb0[2] + (int)(g / ((uint32_t)nwx * by));
+    const float ix = (float)(uint32_t)ax * d.voxel_size + d.pmin[0] + f.center[0];
+    const float iy = (float)(uint32_t)ay * d.voxel_size + d.pmin[1] + f.center[1];
+    const float iz = (float)(uint32_t)az * d.voxel_size + d.pmin[2] + f.center[2];
+    int row, col;
+    float z;
+    if (project_to_image(d, f, ix, iy, iz, row, col, z)) {
+      imz[j] = z;
+      imd[j] = depth_img[(size_t)row * d.W + col];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VIS_J; ++j) {
+    if (code[j] == 0xffffffffu || flg[j]) continue;
+    if (imz[j] <= imd[j]) {  // (imd = 0 where the corner does not project into the image: z >= depth_min > 0)
+      st.vts[lvv[j]] = (uint16_t)f.gts;
+      mark_tile(st, lvv[j]);
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: the voxels that hold something, full waves
+  const uint32_t nf = n_full;
+  for (uint32_t k = threadIdx.x; k < nf; k += TPB) {
+    const uint32_t c = full_list[k];
+    const uint32_t g = g0 + (c >> 6);
+    const int ax = ((wlo + (int)(g % nwx)) << 6) + (int)(c & 63u);
     const int ay = f.bb0[1] + (int)((g / nwx) % by);
     const int az = f.bb0[2] + (int)(g / ((uint32_t)nwx * by));
     visibility_voxel<S>(d, f, st, sc, depth_img, ax, ay, az);
@@ -1338,46 +1468,100 @@ __device__ __forceinline__ void sift_down(uint32_t *a, uint32_t start, uint32_t 
   }
 }
 
+// pass 1 of the weight update (A7 below) splits the pixels by the number of particles their window holds
+constexpr int A7_ROWS = 16;   // >= 2*window_half+1
+constexpr int A7_ITEMS = 16;  // pixels / particles per workgroup
+constexpr uint32_t CK_LIGHT_MAX = 4;
+enum : uint8_t { CK_DONE = 0, CK_LIGHT = 1, CK_HEAVY = 2 };
+
+__device__ __forceinline__ void ck_store(const Filter &flt, const Scratch &sc, float *__restrict__ ck_out, int finish, int p,
+                                         const sdm_labeled_point &o, float ck) {
+  if (finish) {
+    const float ckk = ck * flt.p_detect + flt.noise_number;
+    sc.ck_kappa[p] = ckk;
+    sc.pix4[p] = make_float4(o.x, o.y, o.z, ckk);
+    sc.pixt[p] = (uint32_t)o.track_id | (1u << 16);
+  } else {
+    ck_out[p] = ck;
+  }
+}
+
 // Canonical bin order = ascending particle index (the reference's push order is its BFS order),
 // then gather the fields the weight update reads into arrays laid out in bin order (pixel-major), so that
 // a window row is one contiguous segment.
-__global__ __launch_bounds__(TPB) void k_bin_sort_gather(Dims d, State st, Scratch sc) {
-  if (sc.cnt->overflow) return;
+// The same thread also classifies its pixel for pass 1 of the weight update (the bin ranges are final here): how many
+// particles does its window hold?  None (half of all windows): ck = 0, stored right away.  Up to CK_LIGHT_MAX: left to
+// the one-thread-per-pixel part of k_ck.  More: onto the sharded list of the row-parallel part.  Both parts then run in
+// ONE launch side by side (round 2 ran k_ck_light, which also did this classification, and k_ck_heavy back to back).
+__global__ __launch_bounds__(TPB) void k_bin_sort_gather(Dims d, Filter flt, State st, Scratch sc, float *__restrict__ ck_out, int finish) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (uint32_t)(d.W * d.H)) return;
-  uint32_t n = sc.bin_count[p];
-  if (n == 0) return;
-  uint32_t s = sc.bin_start[p];
-  uint32_t *a = sc.bin_idx + s;
-  if (n > 1) {
-    if (n <= 32) {
-      for (uint32_t i = 1; i < n; ++i) {
-        uint32_t x = a[i];
-        uint32_t j = i;
-        while (j > 0 && a[j - 1] > x) {
-          a[j] = a[j - 1];
-          --j;
-        }
-        a[j] = x;
-      }
-    } else {  // heap sort, in place
-      for (int start = (int)(n - 2) / 2; start >= 0; --start) sift_down(a, (uint32_t)start, n - 1);
-      for (uint32_t end = n - 1; end > 0; --end) {
-        uint32_t t = a[end];
-        a[end] = a[0];
-        a[0] = t;
-        sift_down(a, 0, end - 1);
-      }
+  const bool overflow = sc.cnt->overflow != 0;
+  // ---- classification, first half: its loads go out now, their results are used at the end of the kernel (the sort and
+  // gather below are a chain of dependent loads of their own; the two chains overlap)
+  const sdm_labeled_point o = sc.fa->cloud[p];
+  uint32_t total = 0;
+  if (o.is_valid && !overflow) {
+    const int h = d.window_half;
+    const int i = (int)p / d.W, j = (int)p - i * d.W;
+    const int j0 = j - h < 0 ? 0 : j - h;
+    const int j1 = j + h >= d.W ? d.W - 1 : j + h;
+#pragma unroll
+    for (int r = 0; r < A7_ROWS; ++r) {
+      const int ni = i + r - h;
+      if (r <= 2 * h && ni >= 0 && ni < d.H) total += sc.bin_start[ni * d.W + j1 + 1] - sc.bin_start[ni * d.W + j0];
     }
   }
-  const size_t slot_base = (size_t)d.v_begin << d.p_n;
-  for (uint32_t i = 0; i < n; ++i) {
-    size_t li = (size_t)a[i] - slot_base;
-    float4 q = st.pos4[li];
-    sc.vp4[s + i] = make_float4(q.x, q.y, q.z, st.w[rec_index(li, d.p_n, REC_W)]);
-    sc.vtf[s + i] = (uint32_t)st.track[rec_index(li, d.p_n, REC_TRACK)] | ((__float_as_uint(q.w) & 0xffu) << 16);
-    sc.vpix[s + i] = p;
+  // ---- this pixel's bin: canonical order, gather
+  const uint32_t n = overflow ? 0u : sc.bin_count[p];
+  if (n) {
+    const uint32_t s = sc.bin_start[p];
+    uint32_t *a = sc.bin_idx + s;
+    if (n > 1) {
+      if (n <= 32) {
+        for (uint32_t i = 1; i < n; ++i) {
+          uint32_t x = a[i];
+          uint32_t j = i;
+          while (j > 0 && a[j - 1] > x) {
+            a[j] = a[j - 1];
+            --j;
+          }
+          a[j] = x;
+        }
+      } else {  // heap sort, in place
+        for (int start = (int)(n - 2) / 2; start >= 0; --start) sift_down(a, (uint32_t)start, n - 1);
+        for (uint32_t end = n - 1; end > 0; --end) {
+          uint32_t t = a[end];
+          a[end] = a[0];
+          a[0] = t;
+          sift_down(a, 0, end - 1);
+        }
+      }
+    }
+    const size_t slot_base = (size_t)d.v_begin << d.p_n;
+    for (uint32_t i = 0; i < n; ++i) {
+      size_t li = (size_t)a[i] - slot_base;
+      float4 q = st.pos4[li];
+      sc.vp4[s + i] = make_float4(q.x, q.y, q.z, st.w[rec_index(li, d.p_n, REC_W)]);
+      sc.vtf[s + i] = (uint32_t)st.track[rec_index(li, d.p_n, REC_TRACK)] | ((__float_as_uint(q.w) & 0xffu) << 16);
+      sc.vpix[s + i] = p;
+    }
   }
+  // ---- classification, second half
+  uint8_t cls = CK_DONE;
+  if (!o.is_valid) {
+    if (finish) sc.pixt[p] = 0;  // invalid pixel: skipped by pass 2
+  } else if (total == 0) {
+    ck_store(flt, sc, ck_out, finish, (int)p, o, 0.f);
+  } else if (total <= CK_LIGHT_MAX) {
+    cls = CK_LIGHT;
+  } else {
+    cls = CK_HEAVY;
+    const uint32_t shard = blockIdx.x & (VIS_SHARDS - 1);
+    const uint32_t k = atomicAdd(&sc.cnt->shard[shard].heavy, 1u);
+    sc.ck_heavy[shard * sc.cap_heavy + k] = p;  // cap_heavy covers every pixel a shard's blocks can hold
+  }
+  sc.ck_class[p] = cls;
 }
 
 // ------------------------------------------------------------------------------------ A7
@@ -1387,16 +1571,14 @@ __global__ __launch_bounds__(TPB) void k_bin_sort_gather(Dims d, State st, Scrat
 // pixels (pass 1) or 16 particles (pass 2) times up to 16 window rows; every thread accumulates its row in the
 // reference's order, then the row sums are added in row order.  (Canonical summation order, DESIGN.md: the value is
 // identical on the oracle's canonical mode and differs from the reference's single running sum only in rounding.)
-constexpr int A7_ROWS = 16;   // >= 2*window_half+1
-constexpr int A7_ITEMS = 16;  // pixels / particles per workgroup
-
 // pass 1 (semantic_dsp_map.h:973-1037): ck of every valid pixel.  finish != 0 also applies ck*P_d + kappa (:1035).
 // Visible particles are far fewer than pixels (C3: ~27 K against 466 K) and clustered: half the windows are empty,
-// the median window holds one particle, the 99th percentile 124.  So the pixels are split: k_ck_light (one thread per
-// pixel) finishes every pixel whose window holds at most CK_LIGHT_MAX particles and lists the others; k_ck_heavy
-// spreads each listed pixel over its window rows.  Both add a row's terms in bin order and the row sums in row
-// order (canonical order) - the value does not depend on which kernel produced it.
-constexpr uint32_t CK_LIGHT_MAX = 4;
+// the median window holds one particle, the 99th percentile 124.  So the pixels are split (by k_bin_sort_gather, which
+// also finishes the empty windows): the light part of k_ck (one thread per pixel) computes every pixel whose window holds
+// at most CK_LIGHT_MAX particles, the heavy part spreads each listed pixel over its window rows.  Both add a row's terms
+// in bin order and the row sums in row order (canonical order) - the value does not depend on which part
+// produced it.  One launch: the first CK_HEAVY_BLOCKS workgroups take batches of the heavy list (ticketed), the others
+// one block of 256 pixels each.
 
 template <bool FAST>
 __device__ __forceinline__ float ck_term(const Filter &flt, const float *__restrict__ pdf, const float4 pv, const uint32_t tf,
@@ -1412,31 +1594,15 @@ __device__ __forceinline__ float ck_term(const Filter &flt, const float *__restr
   return pv.w * gk;
 }
 
-__device__ __forceinline__ void ck_store(const Filter &flt, const Scratch &sc, float *__restrict__ ck_out, int finish, int p,
-                                         const sdm_labeled_point &o, float ck) {
-  if (finish) {
-    const float ckk = ck * flt.p_detect + flt.noise_number;
-    sc.ck_kappa[p] = ckk;
-    sc.pix4[p] = make_float4(o.x, o.y, o.z, ckk);
-    sc.pixt[p] = (uint32_t)o.track_id | (1u << 16);
-  } else {
-    ck_out[p] = ck;
-  }
-}
-
-__global__ __launch_bounds__(TPB) void k_ck_light(Dims d, Filter flt, State st, Scratch sc, float *__restrict__ ck_out,
-                                                  int finish, uint32_t light_max) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.W * d.H) return;
-  const sdm_labeled_point o = sc.fa->cloud[p];
-  if (!o.is_valid) {
-    if (finish) sc.pixt[p] = 0;  // invalid pixel: skipped by pass 2
-    return;
-  }
-  const int h = d.window_half;
-  const int i = p / d.W, j = p - i * d.W;
-  uint32_t ss[A7_ROWS], ee[A7_ROWS], total = 0;
-  if (!sc.cnt->overflow) {
+__device__ __forceinline__ void ck_light_pixel(const Dims &d, const Filter &flt, const State &st, const Scratch &sc,
+                                               float *__restrict__ ck_out, int finish, int p) {
+  const bool mine = p < d.W * d.H && sc.ck_class[p] == CK_LIGHT;
+  sdm_labeled_point o;
+  uint32_t ss[A7_ROWS], ee[A7_ROWS];
+  if (mine) {
+    o = sc.fa->cloud[p];
+    const int h = d.window_half;
+    const int i = p / d.W, j = p - i * d.W;
     const int j0 = j - h < 0 ? 0 : j - h;
     const int j1 = j + h >= d.W ? d.W - 1 : j + h;
 #pragma unroll
@@ -1447,18 +1613,11 @@ __global__ __launch_bounds__(TPB) void k_ck_light(Dims d, Filter flt, State st, 
         ss[r] = sc.bin_start[ni * d.W + j0];
         ee[r] = sc.bin_start[ni * d.W + j1 + 1];
       }
-      total += ee[r] - ss[r];
     }
-  }
-  if (total > light_max) {
-    const uint32_t shard = blockIdx.x & (VIS_SHARDS - 1);
-    const uint32_t k = atomicAdd(&sc.cnt->shard[shard].heavy, 1u);
-    sc.ck_heavy[shard * sc.cap_heavy + k] = (uint32_t)p;  // cap_heavy covers every pixel a shard's blocks can hold
-    return;
   }
   float ck = 0.f;
   const float *__restrict__ pdf = st.pdf;
-  const float rsig = total ? div_recip(o.sigma) : 1.f;
+  const float rsig = mine ? div_recip(o.sigma) : 1.f;
   auto rows = [&](auto fast) {
 #pragma unroll
     for (int r = 0; r < A7_ROWS; ++r) {
@@ -1473,22 +1632,29 @@ __global__ __launch_bounds__(TPB) void k_ck_light(Dims d, Filter flt, State st, 
     }
   };
   if (__ballot(rsig == 0.f) == 0ull) {  // wave-uniform: every sigma of the wave inside the range div_by is verified for
-    if (total) rows(std::true_type{});
+    if (mine) rows(std::true_type{});
   } else {
-    if (total) rows(std::false_type{});
+    if (mine) rows(std::false_type{});
   }
-  ck_store(flt, sc, ck_out, finish, p, o, ck);
+  if (mine) ck_store(flt, sc, ck_out, finish, p, o, ck);
 }
 
-// 16 listed pixels per workgroup round, blockIdx.y = shard of the list.  Window sizes are very uneven (9 .. ~300
+// heavy part: 16 listed pixels per workgroup round, shard of the list = blockIdx.x & 63.  Window sizes are very uneven (9 .. ~300
 // particles), so the particle-pixel terms of the 16 pixels are flattened (pixel, row, bin order) and dealt out evenly
 // to the 256 lanes - each computes a contiguous chunk of terms into LDS - and then lane (pixel, row) adds its row's
 // terms in bin order; the row sums are added in row order.  More terms than the LDS buffer holds: several passes,
 // the running row sums stay in registers.
 constexpr uint32_t CK_TERM_CAP = 4096;
 
-__global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter flt, State st, Scratch sc,
-                                                                float *__restrict__ ck_out, int finish) {
+constexpr uint32_t CK_HEAVY_BLOCKS = 64 * VIS_SHARDS;
+
+__global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, State st, Scratch sc,
+                                                          float *__restrict__ ck_out, int finish) {
+  if (blockIdx.x >= CK_HEAVY_BLOCKS) {  // light part: one thread per pixel
+    ck_light_pixel(d, flt, st, sc, ck_out, finish,
+                   (int)((blockIdx.x - CK_HEAVY_BLOCKS) * (A7_ROWS * A7_ITEMS) + threadIdx.y * A7_ROWS + threadIdx.x));
+    return;
+  }
   __shared__ float rowsum[A7_ITEMS][A7_ROWS];
   __shared__ uint32_t rowoff[A7_ITEMS * A7_ROWS + 1];  // exclusive prefix of the row lengths, flattened (pixel, row)
   __shared__ uint32_t rowbeg[A7_ITEMS * A7_ROWS];      // first bin entry of the row
@@ -1499,7 +1665,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck_heavy(Dims d, Filter f
   const int r = threadIdx.x, it = threadIdx.y;
   const int lane = it * A7_ROWS + r;
   const int h = d.window_half;
-  const uint32_t shard = blockIdx.y;
+  const uint32_t shard = blockIdx.x & (VIS_SHARDS - 1);
   const uint32_t n = sc.cnt->shard[shard].heavy;
   const float *__restrict__ pdf = st.pdf;
   const sdm_labeled_point *__restrict__ cloud_img = sc.fa->cloud;
@@ -1834,9 +2000,57 @@ __global__ void k_birth_cursor(Dims d, Filter flt, Scratch sc) {
   }
 }
 
-// resampleParticlesInVoxel (semantic_dsp_map.h:1448-1519) on the register copy of one voxel.
+// resampleParticlesInVoxel (semantic_dsp_map.h:1448-1519) on the register copy of one voxel (status row, owner row).
+// wv / trk: the voxel's weight and track rows as they were when the replay started - the slots the resampling looks at
+// (UPDATED ones) are not written by births, so the rows are still theirs.  (Loaded here, behind the stores of the
+// insertions before it, they cost a store drain and a round trip in the middle of the replay.)
 template <int S>
-__device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t base, uint8_t (&stv)[S]) {
+__device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t base, uint8_t (&stv)[S], uint16_t (&own)[S],
+                                               uint32_t n_alias, bool touched, const float (&wv)[S], const uint16_t (&trk)[S]) {
+  float weight_sum = 0.f;
+  uint32_t updated = 0;
+#pragma unroll
+  for (int i = 1; i < S; ++i)
+    if (stv[i] == ST_UPDATED) {
+      weight_sum += wv[i];
+      ++updated;
+    }
+  const uint32_t trigger = S >> 1;
+  if (updated <= trigger) return false;
+  if (weight_sum < 0.01f) {
+#pragma unroll
+    for (int i = 1; i < S; ++i)
+      if (stv[i] == ST_UPDATED) {
+        stv[i] = ST_INVALID;
+        st.status[base * REC_STATUS + i] = ST_INVALID;
+        owner_erase_local(st, base + i, trk[i], own[i], n_alias, touched);  // removeParticleFromObj
+      }
+    return true;
+  }
+  float wpp = weight_sum / (float)trigger;
+  if (wpp > 1.f) wpp = 1.f;
+  float run = 0.f, thr = wpp;
+#pragma unroll
+  for (int i = 1; i < S; ++i)
+    if (stv[i] == ST_UPDATED) {
+      run += wv[i];
+      if (run < thr) {
+        stv[i] = ST_INVALID;
+        st.status[base * REC_STATUS + i] = ST_INVALID;
+        owner_erase_local(st, base + i, trk[i], own[i], n_alias, touched);
+      } else {
+        st.w[base * REC_W + i] = wpp;
+        thr += wpp;
+        while (run > thr) thr += wpp;
+      }
+    }
+  return true;
+}
+
+// The same with every row read where it is needed (owner_erase / owner_insert of sdm_internal.h): used by the sequential
+// replay below only.
+template <int S>
+__device__ __forceinline__ bool resample_voxel_seq(const Dims &d, State &st, size_t base, uint8_t (&stv)[S]) {
   float weight_sum = 0.f;
   uint32_t updated = 0;
   float wv[S];
@@ -1879,23 +2093,15 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
   return true;
 }
 
-// Ordered per-voxel replay of the births (addNewbornParticleAndResample / ...WithNoiseAndResample,
-// semantic_dsp_map.h:1148-1230; addParticleByGlobalPos, operations.h:782-803).  The sorted list keeps
-// raster order inside each voxel segment; the segment head thread replays it and stops at the fixed point
-// (voxel full and its one resample per frame used up or impossible).
+// The literal candidate-by-candidate walk of one voxel's segment (the reference's loop): k_birth_replay<S, true>.  The
+// frames of a map replay in closed form (k_birth_replay<S, false>, below) - except where the closed form's premise fails:
+// once global_time_stamp has passed 65535 the 16-bit time stamp of a fresh particle can be older than the voxel's 32-bit
+// slab stamp; the reference's comparison (operations.h:810-816) then finds the fresh particle vacant again, every
+// candidate lands in the same slot and the voxel never fills.  The host picks the kernel by the time stamp.
 template <int S>
-__global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State st, Scratch sc,
-                                                      const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
-                                                      uint32_t total) {
-  const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const uint32_t v = skey[t];
-  if (v >= d.V) return;
-  if (t > 0 && skey[t - 1] == v) return;  // not a segment head
-  uint32_t rx, ry, rz;
-  voxel_to_ring(d, v, rx, ry, rz);
-  const uint32_t smax = stamp_max(st, rx, ry, rz);
+__device__ __forceinline__ void birth_replay_sequential(const Dims &d, const Frame &f, const Filter &flt, State &st, const Scratch &sc,
+                                                     const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval, uint32_t total,
+                                                     uint32_t t, uint32_t v, uint32_t smax, uint32_t &n_success_out, uint32_t &n_resamp_out) {
   const size_t base = (size_t)(v - d.v_begin) * S;
   uint8_t stv[S];
   uint16_t tsv[S];
@@ -1962,7 +2168,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
         // voxel full
         if (!flt.consider_depth_noise) break;     // no retry in the no-noise flavour
         if (attempt == 1 || resampled || checked) break;
-        if (resample_voxel<S>(d, st, base, stv)) {
+        if (resample_voxel_seq<S>(d, st, base, stv)) {
           resampled = true;
           changed = true;
           n_resamp++;
@@ -1973,7 +2179,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
       }
       if (!flt.consider_depth_noise && !resampled && !checked) {
         // semantic_dsp_map.h:1165-1170: after every add, resample until it has triggered once
-        if (resample_voxel<S>(d, st, base, stv)) {
+        if (resample_voxel_seq<S>(d, st, base, stv)) {
           resampled = true;
           changed = true;
           n_resamp++;
@@ -1986,6 +2192,164 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
       if (!changed && (resampled || checked)) done = true;
     }
   }
+  n_success_out = n_success;
+  n_resamp_out = n_resamp;
+}
+
+// Ordered per-voxel replay of the births (addNewbornParticleAndResample / ...WithNoiseAndResample,
+// semantic_dsp_map.h:1148-1230; addParticleByGlobalPos, operations.h:782-803).  The sorted list keeps
+// raster order inside each voxel segment; the segment head thread replays it and stops at the fixed point
+// (voxel full and its one resample per frame used up or impossible).
+template <int S, bool LITERAL>
+__global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State st, Scratch sc,
+                                                      const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+                                                      uint32_t total) {
+  const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (threadIdx.x == 0) DBG_PUT(0, DBG_T());
+  // The kernel is a chain of dependent loads in the few lanes that are segment heads (one candidate in fifty): left where
+  // they are, nearly every wave of the launch carries one or two of them through the whole chain.  So the heads of a
+  // workgroup's 256 candidates are compacted first (LDS) and replayed by its first lanes: a quarter of the waves do all
+  // the work, the others leave.
+  __shared__ uint32_t heads[TPB];
+  __shared__ uint32_t n_heads;
+  if (threadIdx.x == 0) n_heads = 0;
+  __syncthreads();
+  if (t < total) {
+    const uint32_t key = skey[t];
+    const uint32_t prev = t > 0 ? skey[t - 1] : 0xffffffffu;
+    if (key < d.V && prev != key) heads[atomicAdd(&n_heads, 1u)] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x >= n_heads) return;
+  if (threadIdx.x == 0) DBG_PUT(1, DBG_T());
+  t = heads[threadIdx.x];
+  // How many candidates does the segment hold?  At most 2 (S-1) of them can ever be inserted (the voxel's vacant slots, and
+  // after its one resampling the slots that freed), so the count is needed up to LMAX only.
+  constexpr int LMAX = 2 * (S - 1) + 1;
+  uint32_t kb[LMAX];
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) kb[j] = t + j < total ? skey[t + j] : 0xffffffffu;
+  const uint32_t v = kb[0];
+  uint32_t rx, ry, rz;
+  voxel_to_ring(d, v, rx, ry, rz);
+  const uint32_t smax = stamp_max(st, rx, ry, rz);
+  if constexpr (LITERAL) {
+    uint32_t ns = 0, nr = 0;
+    birth_replay_sequential<S>(d, f, flt, st, sc, skey, sval, total, t, v, smax, ns, nr);
+    if (ns || nr) {
+      st.vflag[v - d.v_begin] = VF_DIRTY;
+      mark_tile(st, v - d.v_begin);
+    }
+    if (ns) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].birth, ns);
+    if (nr) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].resample, nr);
+    return;
+  } else {
+  const size_t base = (size_t)(v - d.v_begin) * S;
+  uint8_t stv[S];
+  uint16_t tsv[S];
+  load_vec<rec_align(S)>(stv, st.status + base * REC_STATUS);
+  load_vec<rec_align(S)>(tsv, st.ts + base * REC_TS);
+  // the voxel's owner entries and the length of the table of older memberships (addParticleToObj / removeParticleFromObj),
+  // and the rows the one resampling of the voxel reads: everything the replay needs of the voxel, in one round
+  uint16_t own[S];
+  load_vec<(2 * S < 16 ? 2 * S : 16)>(own, st.owner + base);
+  const uint32_t n_alias = st.alias[0];
+  bool alias_touched = false;
+  float wv0[S];
+  uint16_t trk0[S];
+  load_vec<rec_align(S)>(wv0, st.w + base * REC_W);
+  load_vec<rec_align(S)>(trk0, st.track + base * REC_TRACK);
+  uint32_t L = 0;  // candidates of the segment, capped at LMAX
+  {
+    bool run = true;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+      run = run && kb[j] == v;
+      L += run ? 1u : 0u;
+    }
+  }
+  // ---- The replay in closed form.  The reference walks the segment candidate by candidate (addNewbornParticleAndResample
+  // / ...WithNoiseAndResample, semantic_dsp_map.h:1148-1230); what that walk does to a voxel follows from three numbers:
+  //   * an insertion takes the LOWEST vacant slot (operations.h:790-796), so the first candidates fill the voxel's vacant
+  //     slots in ascending order;
+  //   * the voxel is resampled at most once per frame (:1166-1169, 1212), and births never add UPDATED particles, so
+  //     whether the resampling triggers does not depend on how many candidates came before it.  Noise flavour (:1205-1228):
+  //     it is tried when a candidate finds the voxel full, and that candidate retries once; plain flavour (:1160-1170): it
+  //     is tried after the first candidate, inserted or not;
+  //   * afterwards the remaining candidates fill what is vacant then, ascending, and the first one that finds the voxel
+  //     full with the resampling used up (or impossible) ends the walk: nothing later can change the voxel.
+  // Phase A = insertions before the resampling, phase B = after it.  One pass over the slots per phase instead of a loop
+  // over candidates whose every iteration was a few hundred dependent instructions for the slowest lane of the wave.
+  const bool noise_flavour = flt.consider_depth_noise != 0;
+  uint32_t vac0 = 0;
+#pragma unroll
+  for (int i = 1; i < S; ++i)
+    if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) vac0 |= 1u << i;
+  const uint32_t V0 = (uint32_t)__popc(vac0);
+  const uint32_t nA = noise_flavour ? (L < V0 ? L : V0) : ((L >= 1 && V0 >= 1) ? 1u : 0u);
+  int cand[S];  // candidate (position in the segment) that goes into slot i, -1: none
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    const uint32_t rank = (uint32_t)__popc(vac0 & ((1u << i) - 1u));
+    const bool take = ((vac0 >> i) & 1u) && rank < nA;
+    cand[i] = take ? (int)rank : -1;
+    if (take) {
+      stv[i] = ST_REGULAR_BORN;
+      tsv[i] = (uint16_t)f.gts;
+    }
+  }
+  const bool try_resample = noise_flavour ? L > V0 : L >= 1;
+  uint32_t n_resamp = 0;
+  if (try_resample && resample_voxel<S>(d, st, base, stv, own, n_alias, alias_touched, wv0, trk0)) n_resamp = 1;
+  uint32_t nB = 0;
+  if (try_resample) {
+    const uint32_t consumed = noise_flavour ? V0 : 1u;  // (noise flavour: the candidate that found the voxel full retries)
+    uint32_t vac1 = 0;
+#pragma unroll
+    for (int i = 1; i < S; ++i)
+      if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) vac1 |= 1u << i;
+    const uint32_t V1 = (uint32_t)__popc(vac1), left = L - consumed;
+    nB = left < V1 ? left : V1;
+#pragma unroll
+    for (int i = 1; i < S; ++i) {
+      const uint32_t rank = (uint32_t)__popc(vac1 & ((1u << i) - 1u));
+      if (((vac1 >> i) & 1u) && rank < nB) cand[i] = (int)(consumed + rank);
+    }
+  }
+  const uint32_t n_success = nA + nB;
+  // the candidates that made it: index, then position / track / label - two rounds for all of them
+  uint32_t cidx[S];
+  float4 bps[S];
+#pragma unroll
+  for (int i = 1; i < S; ++i)
+    if (cand[i] >= 0) cidx[i] = sval[t + (uint32_t)cand[i]];
+#pragma unroll
+  for (int i = 1; i < S; ++i)
+    if (cand[i] >= 0) bps[i] = sc.bpos[cidx[i]];
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    if (cand[i] < 0) continue;
+    const float4 bp = bps[i];
+    const uint32_t tl = __float_as_uint(bp.w);
+    const uint16_t track = (uint16_t)(tl & 0xffffu);
+    const uint8_t label = (uint8_t)((tl >> 16) & 0xffu);
+    // addNewParticleWithSemantics (operations.h:171-184)
+    st.pos4[base + i] = make_float4(bp.x, bp.y, bp.z, __uint_as_float(0u));
+    st.w[base * REC_W + i] = SDM_OCC_INIT_WEIGHT;
+    st.ts[base * REC_TS + i] = (uint16_t)f.gts;
+    st.track[base * REC_TRACK + i] = track;
+    st.label[base * REC_LABEL + i] = label;
+    st.status[base * REC_STATUS + i] = ST_REGULAR_BORN;
+    if ((int)track <= d.max_movable) {  // addParticleToObj
+      if (!owner_insert_local(st, base + i, track, own[i], n_alias, alias_touched)) sc.cnt->overflow = 1;
+      st.owner_flag[(base + i) / OWNER_CHUNK] = 1;
+    }
+  }
+  if (threadIdx.x == 0) {
+    DBG_PUT(2, DBG_T());
+    DBG_PUT(3, n_success);
+  }
   // same-address atomics retire one at a time: counters every wave bumps are sharded by block
   if (n_success || n_resamp) {
     st.vflag[v - d.v_begin] = VF_DIRTY;
@@ -1993,6 +2357,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   }
   if (n_success) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].birth, n_success);
   if (n_resamp) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].resample, n_resamp);
+  }
 }
 
 // ------------------------------------------------------------------------------------ N1
@@ -2416,7 +2781,7 @@ void launch_frustum(const Dims &d, const Scratch &sc, hipStream_t s) {
   hipLaunchKernelGGL(k_flood_generic, dim3(1), dim3(1024), 0, s, d, sc.fa_side, sc.vmask, sc.reach, sc.wpl, sc.cnt);
 }
 
-void launch_visibility(const Dims &d, const State &st, const Scratch &sc, hipStream_t s) {
+void launch_visibility(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s) {
   {
     const size_t max_words = (size_t)((d.NX + 63) / 64 + 1) * d.NY * d.NZ;
     dim3 grid((unsigned)std::min<size_t>(blocks_for(max_words, VIS_WORDS), 2048));
@@ -2425,12 +2790,12 @@ void launch_visibility(const Dims &d, const State &st, const Scratch &sc, hipStr
   // bins: scan the per-pixel counts, scatter, canonical order + gather
   exclusive_scan_u32(sc.bin_count, sc.bin_start, (size_t)d.W * d.H + 1, sc.scan_scratch, s);
   hipLaunchKernelGGL(k_bin_fill, dim3(16, VIS_SHARDS), dim3(TPB), 0, s, sc, (uint32_t)(d.W * d.H));
-  hipLaunchKernelGGL(k_bin_sort_gather, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, st, sc);
+  hipLaunchKernelGGL(k_bin_sort_gather, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, st, sc, ck_out, finish);
 }
 
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s) {
-  hipLaunchKernelGGL(k_ck_light, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, st, sc, ck_out, finish, CK_LIGHT_MAX);
-  hipLaunchKernelGGL(k_ck_heavy, dim3(64, VIS_SHARDS), dim3(A7_ROWS, A7_ITEMS), 0, s, d, flt, st, sc, ck_out, finish);
+  hipLaunchKernelGGL(k_ck, dim3(CK_HEAVY_BLOCKS + blocks_for((size_t)d.W * d.H, A7_ROWS * A7_ITEMS)), dim3(A7_ROWS, A7_ITEMS), 0, s, d, flt, st, sc,
+                     ck_out, finish);
 }
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s) {
   hipLaunchKernelGGL(k_ck_finish, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, parts, n_parts);
@@ -2458,13 +2823,23 @@ int launch_birth_prepare(const Dims &d, const Filter &flt, const BirthOrder &bo,
   return radix_sort_pairs(sc.bkey_a, sc.bval_a, sc.bkey_b, sc.bval_b, total, nbits, sc.sort_scratch, s);
 }
 
-void launch_birth_replay(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, int which,
+// literal: walk every segment candidate by candidate (frames whose 16-bit time stamp has wrapped, see above)
+void launch_birth_replay(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, int which, bool literal,
                          hipStream_t s) {
   const size_t total = (size_t)d.W * d.H * flt.nb;
   const uint32_t *skey = which ? sc.bkey_b : sc.bkey_a;
   const uint32_t *sval = which ? sc.bval_b : sc.bval_a;
   dim3 grid(blocks_for(total));
-  SDM_DISPATCH_S(k_birth_replay, grid, s, d, flt, st, sc, skey, sval, (uint32_t)total);
+#define SDM_BIRTH(SS)                                                                                                  \
+  if (literal) hipLaunchKernelGGL((k_birth_replay<SS, true>), grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval, (uint32_t)total); \
+  else hipLaunchKernelGGL((k_birth_replay<SS, false>), grid, dim3(TPB), 0, s, d, flt, st, sc, skey, sval, (uint32_t)total);
+  switch (d.p_n) {
+    case 1: SDM_BIRTH(2) break;
+    case 2: SDM_BIRTH(4) break;
+    case 3: SDM_BIRTH(8) break;
+    default: SDM_BIRTH(16) break;
+  }
+#undef SDM_BIRTH
 }
 
 void launch_labeled_cloud(const Dims &d, const CloudArgsHost &h, const float *depth, const uint8_t *static_mask,
@@ -2524,8 +2899,11 @@ void launch_rec_unpack(const Dims &d, const State &st, float *w, uint16_t *ts, u
 }
 
 // bench hook: every slot of every voxel holds a live particle with pseudo-random weight / track / label, every voxel is
-// observed - the dense case of SURVEY.md 8(d) for the occupancy sweep.
-__global__ __launch_bounds__(TPB) void k_fill_dense(Dims d, State st, uint32_t stamp) {
+// observed - the dense case of SURVEY.md 8(d) for the occupancy sweep.  mode 0: every SLOT draws one of eight track ids
+// (four to five different ones per voxel: the worst case for the vote); mode 1 ("surface"): every VOXEL draws one, as in
+// a real map, where a voxel holds particles of one surface - except one voxel in 16, whose slots are split between two
+// (object borders).
+__global__ __launch_bounds__(TPB) void k_fill_dense(Dims d, State st, uint32_t stamp, int mode) {
   size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = (size_t)d.v_count * d.S;
   if (li >= n) return;
@@ -2538,17 +2916,35 @@ __global__ __launch_bounds__(TPB) void k_fill_dense(Dims d, State st, uint32_t s
   st.status[rec_index(li, d.p_n, REC_STATUS)] = i == 0 ? (uint8_t)ST_TIMEPTC : (uint8_t)((h & 7u) == 0 ? ST_REGULAR_BORN : ST_UPDATED);
   st.w[rec_index(li, d.p_n, REC_W)] = 0.06f + (float)(h >> 20) * (0.3f / 4096.f);
   st.ts[rec_index(li, d.p_n, REC_TS)] = (uint16_t)stamp;
-  st.track[rec_index(li, d.p_n, REC_TRACK)] = (uint16_t)(65524u + ((h >> 8) & 7u));
-  st.label[rec_index(li, d.p_n, REC_LABEL)] = (uint8_t)(5u + ((h >> 8) & 7u));
+  uint32_t pick = (h >> 8) & 7u;
+  if (mode == 1) {
+    uint32_t hv = (uint32_t)lv * 2654435761u;
+    hv ^= hv >> 15;
+    hv *= 2246822519u;
+    hv ^= hv >> 13;
+    pick = (hv >> 8) & 7u;
+    if (((hv >> 4) & 15u) == 0 && (i & 1u)) pick = (pick + 1u) & 7u;  // a border voxel: two tracks
+  }
+  st.track[rec_index(li, d.p_n, REC_TRACK)] = (uint16_t)(65524u + pick);
+  st.label[rec_index(li, d.p_n, REC_LABEL)] = (uint8_t)(5u + pick);
   st.owner[li] = OWNER_NONE;
   if (i == 0) {
     st.vts[lv] = (uint16_t)stamp;
     st.vflag[lv] = VF_DIRTY;
   }
 }
-void launch_fill_dense(const Dims &d, const State &st, uint32_t stamp, hipStream_t s) {
+#ifdef SDM_AB_TIMERS
+void debug_timers(unsigned long long *out32, int reset) {
+  (void)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
+  if (reset) {
+    static unsigned long long z[4096 * 4];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z));
+  }
+}
+#endif
+void launch_fill_dense(const Dims &d, const State &st, uint32_t stamp, int mode, hipStream_t s) {
   const size_t n = (size_t)d.v_count * d.S;
-  hipLaunchKernelGGL(k_fill_dense, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, stamp);
+  hipLaunchKernelGGL(k_fill_dense, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, stamp, mode);
 }
 
 void launch_vts_sync(const Dims &d, const State &st, int to_slot0, hipStream_t s) {

@@ -122,7 +122,7 @@ struct sdm_map {
   // this frame's scalars (sdm_scratch.h): host copy, the two device blocks and the event that says "the side chains'
   // block is written"
   FrameArgs fa{};
-  FrameArgs *d_fa[2]{};        // [0] read by the main-stream kernels, [1] by the chains that run ahead of the frame
+  FrameArgs *d_fa[3]{};        // [0] read by the main-stream kernels, [1] by the frustum chain that runs ahead of the frame, [2] by the member-count chain
   FrameBeginLaunch fb{};       // arguments of k_frame_begin (the frame block travels with it)
   hipEvent_t ev_fa = nullptr;
   const float *cur_depth = nullptr;            // the inputs the last frame read (sdm_get_labeled_cloud)
@@ -606,6 +606,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   // pixels reach the heavy list from blocks of TPB consecutive pixels, shard = block & 63
   sc.cap_heavy = (uint32_t)(((hw + 255) / 256 + VIS_SHARDS - 1) / VIS_SHARDS * 256);
   A(sc.ck_heavy, (size_t)sc.cap_heavy * VIS_SHARDS);
+  A(sc.ck_class, hw);
   m->ck_chunk = (uint32_t)(((hw + shard_count - 1) / shard_count + 63) / 64 * 64);
   A(m->d_ck_part, (size_t)m->ck_chunk * shard_count);  // H*W floats, padded to shard_count whole chunks
   for (auto &r : m->raw) {
@@ -648,10 +649,11 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   HIP_TRY(hipMemsetAsync(sc.cur, 0, sizeof(Cursors), m->stream));
   A(m->d_fa[0], 1);
   A(m->d_fa[1], 1);
-  HIP_TRY(hipMemsetAsync(m->d_fa[0], 0, sizeof(FrameArgs), m->stream));
-  HIP_TRY(hipMemsetAsync(m->d_fa[1], 0, sizeof(FrameArgs), m->stream));
+  A(m->d_fa[2], 1);
+  for (FrameArgs *p : m->d_fa) HIP_TRY(hipMemsetAsync(p, 0, sizeof(FrameArgs), m->stream));
   m->sc.fa = m->d_fa[0];
   m->sc.fa_side = m->d_fa[1];
+  m->sc.fa_moves = m->d_fa[2];
   A(m->d_u64, 1);
   A(m->d_flags, (size_t)d.v_count + 1);
   A(m->d_offs, (size_t)d.v_count + 1);
@@ -936,8 +938,10 @@ sdm_status frame_enqueue_start(sdm_map *m) {
   if (m->capturing) {
     launch_moves_count(d, m->st, m->sc, m->d_counts_local, s);
   } else if (m->n_moves > 0) {
-    HIP_TRY(hipStreamWaitEvent(m->s_moves, m->ev_fa, 0));
-    launch_moves_count(d, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves);
+    // (its own copy of the frame block travels with its first kernel: nothing of another stream in front of the chain but
+    // the previous frame's births)
+    HIP_TRY(hipStreamWaitEvent(m->s_moves, m->ev_state, 0));
+    launch_moves_count(d, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves, &m->fa);
     if (m->comm && m->sharded_frame) {
       // exchange 1 of a sharded frame rides the member-count stream: it runs beside the previous frame's sweep.  (Every
       // use of the communicator is ordered by events: this one behind the previous frame's births, the next one - the
@@ -1053,12 +1057,12 @@ sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev) {
 
   // U1: visibility + binning (semantic_dsp_map.h:749); join the frustum stream first
   HIP_TRY(hipStreamWaitEvent(s, m->capturing ? m->cap_frustum : m->ev_frustum, 0));
-  launch_visibility(d, m->st, m->sc, s);
+  float *ck_dst = m->ck_user ? m->ck_user : m->d_ck_part;
+  launch_visibility(d, m->flt, m->st, m->sc, ck_dst, m->fused_ck ? 1 : 0, s);
   stage_mark(m, 4);
   if (stage_done(stop_after, 4)) return SDM_OK;
 
   // U2 pass 1: this shard's ck partial sums
-  float *ck_dst = m->ck_user ? m->ck_user : m->d_ck_part;
   launch_ck(d, m->flt, m->st, m->sc, ck_dst, m->fused_ck ? 1 : 0, s);
   if (ck_part_dev) *ck_part_dev = ck_dst;
   return SDM_OK;
@@ -1111,7 +1115,7 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
   stage_mark(m, 5);
   if (stage_done(stop_after, 5)) return SDM_OK;
   HIP_TRY(hipStreamWaitEvent(s, m->capturing ? m->cap_birth : m->ev_birth, 0));  // join the birth-candidate stream
-  launch_birth_replay(d, m->flt, m->st, m->sc, m->birth_which, s);
+  launch_birth_replay(d, m->flt, m->st, m->sc, m->birth_which, m->global_time_stamp > 65535u, s);
   if (!m->capturing) {
     HIP_TRY(hipEventRecord(m->ev_state, s));
     m->state_event_valid = true;
@@ -1263,13 +1267,13 @@ sdm_status pieces_capture(sdm_map *m) {
     });
   if (rc == SDM_OK)
     rc = capture(m->stream, 3, [&](hipStream_t st) {
-      launch_visibility(d, m->st, m->sc, st);
+      launch_visibility(d, m->flt, m->st, m->sc, m->d_ck_part, 1, st);
       launch_ck(d, m->flt, m->st, m->sc, m->d_ck_part, 1, st);
       launch_weight(d, m->flt, m->st, m->sc, st);
     });
   if (rc == SDM_OK)
     rc = capture(m->stream, 4, [&](hipStream_t st) {
-      launch_birth_replay(d, m->flt, m->st, m->sc, m->birth_which, st);
+      launch_birth_replay(d, m->flt, m->st, m->sc, m->birth_which, false, st);
       launch_occupancy(d, m->flt, m->st, m->sc.cnt, 0, st);
     });
   m->graph_flt = m->flt;
@@ -1323,7 +1327,8 @@ sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *c
   // is replayed from the graph; everything else takes the launches one by one.
   const bool would_be_plain = stop_after == 0 && (flags & ~(uint32_t)SDM_INPUT_ON_DEVICE) == 0 && !m->profiling &&
                               m->cfg.shard_count == 1 && !m->comm && !m->ck_user && !m->counts_local_user &&
-                              m->stream == m->own_stream && !m->sweep_all && !m->stamps_dirty;
+                              m->stream == m->own_stream && !m->sweep_all && !m->stamps_dirty &&
+                              m->global_time_stamp <= 65535u;  // (beyond: the literal birth replay, not in the captured graphs)
   const bool plain = m->use_graph && would_be_plain;
   if (plain) {
     const bool pieces = m->graph_shape == GRAPH_PIECES;
@@ -2140,13 +2145,26 @@ sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms) {
 }
 
 // Bench hook: overwrite the map with the dense case (every slot live, every voxel observed).
-sdm_status sdm_debug_fill_dense(sdm_map *m) {
-  if (!m) return SDM_ERR_INVALID_ARGUMENT;
+sdm_status sdm_debug_fill_dense_ex(sdm_map *m, int32_t mode) {
+  if (!m || mode < 0 || mode > 1) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
-  launch_fill_dense(m->d, m->st, m->global_time_stamp ? m->global_time_stamp : 1u, m->stream);
+  launch_fill_dense(m->d, m->st, m->global_time_stamp ? m->global_time_stamp : 1u, mode, m->stream);
   HIP_TRY(hipStreamSynchronize(m->stream));
   return SDM_OK;
 }
+sdm_status sdm_debug_fill_dense(sdm_map *m) { return sdm_debug_fill_dense_ex(m, 0); }
+
+#ifdef SDM_AB_TIMERS
+extern "C++" {
+namespace sdm { void debug_timers(unsigned long long *out32, int reset); }
+}
+sdm_status sdm_debug_timers(sdm_map *m, unsigned long long *out32, int reset) {
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipDeviceSynchronize());
+  sdm::debug_timers(out32, reset);
+  return SDM_OK;
+}
+#endif
 
 // Page-locked host memory for the buffers handed to sdm_update / sdm_update_raw: uploads from it run at PCIe speed
 // and beside the kernels of the previous frame.

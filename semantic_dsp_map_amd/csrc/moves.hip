@@ -38,14 +38,13 @@ __device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint16_t *tracks
 // pass 0: ascending list of the chunks whose owner_flag is set (one workgroup; each thread takes 32 consecutive
 // flag bytes, one block-wide scan of the per-thread counts per 32 K flags).  Dynamic objects touch a few hundred of
 // the map's tens of thousands of chunks; everything after this works on the list only.
-__global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *owner_flag, uint32_t n_flags,
-                                                      uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Cursors *cur,
-                                                      uint32_t *__restrict__ cnt, const FrameArgs *__restrict__ fa,
-                                                      uint32_t *__restrict__ alias, uint8_t *owner_flag_w) {
+__device__ __forceinline__ void move_chunks_body(const uint8_t *owner_flag, uint32_t n_flags, uint32_t *__restrict__ list,
+                                                 uint32_t *__restrict__ n_list, Cursors *cur, uint32_t *__restrict__ cnt, int n_obj,
+                                                 uint32_t n_move_cnt, uint32_t *__restrict__ alias, uint8_t *owner_flag_w) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t running;
-  if (fa->n_obj <= 0) return;  // no object moves in this frame
-  uint32_t *cnt_tail = cnt + (fa->n_move_cnt - 1);
+  if (n_obj <= 0) return;  // no object moves in this frame
+  uint32_t *cnt_tail = cnt + (n_move_cnt - 1);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) {
     running = 0;
@@ -124,6 +123,24 @@ __global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *owner_flag,
     *cnt_tail = 0;  // terminator of the count matrix (becomes the grand total after the scan)
   }
 }
+__global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *owner_flag, uint32_t n_flags,
+                                                      uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Cursors *cur,
+                                                      uint32_t *__restrict__ cnt, const FrameArgs *__restrict__ fa,
+                                                      uint32_t *__restrict__ alias, uint8_t *owner_flag_w) {
+  move_chunks_body(owner_flag, n_flags, list, n_list, cur, cnt, fa->n_obj, fa->n_move_cnt, alias, owner_flag_w);
+}
+// The same as the first kernel of a chain of its own (the member count of a launch-by-launch frame starts behind the
+// PREVIOUS frame's births, on its own stream): the frame block arrives by value and is stored for the chain's other
+// kernels - no k_set_frame launch and no event from another stream in front of the chain.
+__global__ __launch_bounds__(1024) void k_move_chunks_v(const uint8_t *owner_flag, uint32_t n_flags,
+                                                        uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Cursors *cur,
+                                                        uint32_t *__restrict__ cnt, const FrameArgs src, FrameArgs *__restrict__ dst,
+                                                        uint32_t *__restrict__ alias, uint8_t *owner_flag_w) {
+  const uint32_t *s4 = reinterpret_cast<const uint32_t *>(&src);
+  uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+  for (uint32_t i = threadIdx.x; i < sizeof(FrameArgs) / 4; i += blockDim.x) d4[i] = s4[i];
+  move_chunks_body(owner_flag, n_flags, list, n_list, cur, cnt, src.n_obj, src.n_move_cnt, alias, owner_flag_w);
+}
 
 // pass 1: per-chunk, per-object member counts.  cnt[obj * MV_LIST_CAP + list position].  A flagged chunk that turns out
 // to hold no owner any more clears its flag.
@@ -198,9 +215,9 @@ struct HaloRecord {
 };
 static_assert(sizeof(HaloRecord) == HALO_RECORD_BYTES, "halo record layout");
 
-__global__ void k_move_local_counts(const uint32_t *__restrict__ offs, int32_t *counts_local, Scratch sc) {
+__global__ void k_move_local_counts(const uint32_t *__restrict__ offs, int32_t *counts_local, Scratch sc, const FrameArgs *__restrict__ fa) {
   int k = threadIdx.x;
-  const int n_obj = sc.fa_side->n_obj;  // (runs with the member count, on its stream)
+  const int n_obj = fa->n_obj;  // (runs with the member count, on its stream)
   // this frame's export counters, one per destination shard
   const uint32_t world = sc.halo_world;
   if (sc.halo_send && (uint32_t)k < world) *reinterpret_cast<uint32_t *>(sc.halo_send + (size_t)k * halo_segment_bytes(sc.halo_cap)) = 0;
@@ -212,33 +229,73 @@ constexpr uint32_t MV_NIL = 0xffffffffu;
 
 // A moved copy of global rank e joins the list of its target voxel (push-front; the replay restores rank order).
 // The copy that finds the list idle also enters the voxel in this frame's work list.
-__device__ __forceinline__ void move_link(const Dims &d, const Scratch &sc, uint32_t v, uint32_t e) {
+// (The work list's cursor is ONE word: an atomic per touched voxel on it retires at ~12 ns each, a few thousand per frame -
+// that was most of k_move_apply's time.  A workgroup therefore collects its new voxels in LDS - vox_list / vox_n - and
+// reserves their places with one atomic, flush_move_voxels; callers without such a list pass nullptr.)
+__device__ __forceinline__ void move_link(const Dims &d, const Scratch &sc, uint32_t v, uint32_t e, uint32_t *vox_list = nullptr,
+                                          uint32_t *vox_n = nullptr) {
   const uint32_t lv = v - d.v_begin;
   const uint32_t prev = atomicExch(&sc.mv_head[lv], e);
   sc.mv_next[e] = prev;
-  if (prev == MV_NIL) sc.mv_vlist[atomicAdd(&sc.cnt->n_move_voxels, 1u)] = lv;
+  if (prev == MV_NIL) {
+    if (vox_list) vox_list[atomicAdd(vox_n, 1u)] = lv;
+    else sc.mv_vlist[atomicAdd(&sc.cnt->n_move_voxels, 1u)] = lv;
+  }
+}
+// all threads of the workgroup; vox_base is an LDS word
+__device__ __forceinline__ void flush_move_voxels(const Scratch &sc, const uint32_t *vox_list, uint32_t *vox_n, uint32_t *vox_base) {
+  __syncthreads();
+  const uint32_t n = *vox_n;
+  if (threadIdx.x == 0 && n) *vox_base = atomicAdd(&sc.cnt->n_move_voxels, n);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) sc.mv_vlist[*vox_base + i] = vox_list[i];
+  __syncthreads();
+  if (threadIdx.x == 0) *vox_n = 0;
 }
 
 // one member of moving object `obj`, global rank e, local slot li
 // alias: the membership is an older one kept in State::alias (the slot's owner entry belongs to somebody else and
 // stays); copy_invalid: an object earlier in this frame's order already moved this very slot, the reference then
 // copies a particle whose status it has just set to INVALID (operations.h:339-349 run object by object).
-__device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms, const State &st,
-                                         const Scratch &sc, int obj, uint32_t e, size_t li, bool alias = false,
-                                         bool copy_invalid = false) {
-  const float4 p = st.pos4[li];
+// (in two halves, so that a thread with several members can request all their loads before the first store goes out:
+// one member is a chain of three dependent round trips, and stores between two members keep the compiler from overlapping
+// them)
+struct MoveLoaded {
+  float4 p;
+  float n[3];
+  float w;
+  uint16_t ts, track;
+  uint8_t label, status;
+};
+__device__ __forceinline__ MoveLoaded move_load(const Dims &d, const Filter &flt, const State &st, long long cursor, uint32_t e,
+                                                size_t li, bool copy_invalid) {
+  MoveLoaded m;
+  m.p = st.pos4[li];
+  const long long draw = cursor + 3ll * e;
+  m.n[0] = st.noise[(draw + 1) % flt.noise_n];
+  m.n[1] = st.noise[(draw + 2) % flt.noise_n];
+  m.n[2] = st.noise[(draw + 3) % flt.noise_n];
+  m.w = st.w[rec_index(li, d.p_n, REC_W)];
+  m.ts = st.ts[rec_index(li, d.p_n, REC_TS)];
+  m.track = st.track[rec_index(li, d.p_n, REC_TRACK)];
+  m.label = st.label[rec_index(li, d.p_n, REC_LABEL)];
+  m.status = copy_invalid ? (uint8_t)ST_INVALID : st.status[rec_index(li, d.p_n, REC_STATUS)];
+  return m;
+}
+__device__ __forceinline__ void move_store(const Dims &d, const Frame &f, const MoveSet &ms, const State &st, const Scratch &sc,
+                                           const MoveLoaded &m, int obj, uint32_t e, size_t li, bool alias, uint32_t *vox_list,
+                                           uint32_t *vox_n) {
+  const float4 p = m.p;
   const float *T = ms.T[obj];
   float nx = row4(T + 0, p.x, p.y, p.z);
   float ny = row4(T + 4, p.x, p.y, p.z);
   float nz = row4(T + 8, p.x, p.y, p.z);
-  long long draw = (long long)sc.cur->move_cursor + 3ll * e;
-  nx = nx + st.noise[(draw + 1) % flt.noise_n];
-  ny = ny + st.noise[(draw + 2) % flt.noise_n];
-  nz = nz + st.noise[(draw + 3) % flt.noise_n];
-  const float pw = st.w[rec_index(li, d.p_n, REC_W)];
-  const uint16_t pts = st.ts[rec_index(li, d.p_n, REC_TS)], ptrack = st.track[rec_index(li, d.p_n, REC_TRACK)];
-  const uint8_t plabel = st.label[rec_index(li, d.p_n, REC_LABEL)];
-  const uint8_t pstatus = copy_invalid ? (uint8_t)ST_INVALID : st.status[rec_index(li, d.p_n, REC_STATUS)];
+  nx = nx + m.n[0];
+  ny = ny + m.n[1];
+  nz = nz + m.n[2];
+  const float pw = m.w;
+  const uint16_t pts = m.ts, ptrack = m.track;
+  const uint8_t plabel = m.label, pstatus = m.status;
   const uint16_t powner = ms.track[obj];
   st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_INVALID;  // deleteParticleByIndex
   st.vflag[li >> d.p_n] = VF_DIRTY;
@@ -262,7 +319,7 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
     c.status = pstatus;
     c.pad = 0;
     sc.mv_copy[e] = c;
-    move_link(d, sc, v, e);
+    move_link(d, sc, v, e, vox_list, vox_n);
   } else if (sc.halo_send) {  // crosses into another slab: export to the shard that owns it
     unsigned char *seg = sc.halo_send + (size_t)(rz / d.rz_count) * halo_segment_bytes(sc.halo_cap);
     uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(seg), 1u);
@@ -282,6 +339,12 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
       sc.cnt->overflow = 1;
     }
   }
+}
+__device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms, const State &st,
+                                         const Scratch &sc, int obj, uint32_t e, size_t li, bool alias = false,
+                                         bool copy_invalid = false, uint32_t *vox_list = nullptr, uint32_t *vox_n = nullptr) {
+  const MoveLoaded m = move_load(d, flt, st, (long long)sc.cur->move_cursor, e, li, copy_invalid);
+  move_store(d, f, ms, st, sc, m, obj, e, li, alias, vox_list, vox_n);
 }
 
 // One round (TPB consecutive slots) of k_move_apply in a chunk that holds older set memberships (State::alias): a slot can
@@ -361,7 +424,11 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
   __shared__ uint32_t block_total;
   __shared__ uint32_t ca_idx[CA_CAP], ca_ent[CA_CAP], ca_n;
   __shared__ uint8_t ca_obj[CA_CAP];
+  __shared__ uint32_t vox_list[MV_CHUNK], vox_n, vox_base;  // voxels that got their first copy from this chunk
+  __shared__ uint32_t my_e[MV_ITEMS][TPB];                  // global rank of the member in slot r * TPB + thread of the chunk, MV_NIL: none
+  __shared__ uint8_t my_o[MV_ITEMS][TPB];                   // ... and its object
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) vox_n = 0;
   const uint32_t n = *sc.mv_nlist;
   const size_t n_slots = (size_t)d.v_count * d.S;
   if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms.track[threadIdx.x] : OWNER_NONE;
@@ -448,13 +515,16 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
         const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
         if (valid && rank_in_wave == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
         __syncthreads();
+        // the member's global rank and object; the move itself comes after the ranking rounds (below)
+        uint32_t e = MV_NIL;
         if (valid) {
-          uint32_t e = obj_base[o] + rank_in_wave;
+          e = obj_base[o] + rank_in_wave;
 #pragma unroll
           for (int w = 0; w < MV_WAVES; ++w)
             if (w < wid) e += wave_cnt[w][o];
-          move_one(d, f, flt, ms, st, sc, (int)o, e, li);
         }
+        my_e[r][threadIdx.x] = e;
+        my_o[r][threadIdx.x] = o;
       } else {
         move_round_with_aliases(d, f, flt, ms, st, sc, li, n_slots, n_obj, tracks, obj_base, wave_cnt, ca_idx, ca_ent, ca_obj, n_ca,
                                 lt_mask, wid);
@@ -467,6 +537,29 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
         obj_base[threadIdx.x] += add;
       }
       __syncthreads();
+    }
+    // The moves themselves, outside the rounds: a move is a chain of dependent loads (position, noise, record) in a few
+    // lanes, and inside a round every barrier waited for the slowest of them - sixteen times per chunk.  Four members at a
+    // time: all their loads, then their stores.  (Ranks and objects wait in LDS: sixteen copies of the move code, which
+    // register arrays would need, are 47 K instructions.)
+    if (n_ca == 0) {
+      const long long cursor = (long long)sc.cur->move_cursor;  // (advanced by k_move_replay, after this kernel)
+#pragma unroll 1
+      for (int r0 = 0; r0 < MV_ITEMS; r0 += 4) {
+        MoveLoaded ml[4];
+        uint32_t e4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          e4[u] = my_e[r0 + u][threadIdx.x];
+          if (e4[u] != MV_NIL) ml[u] = move_load(d, flt, st, cursor, e4[u], base + (size_t)(r0 + u) * TPB + threadIdx.x, false);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (e4[u] != MV_NIL)
+            move_store(d, f, ms, st, sc, ml[u], (int)my_o[r0 + u][threadIdx.x], e4[u], base + (size_t)(r0 + u) * TPB + threadIdx.x, false,
+                       vox_list, &vox_n);
+      }
+      flush_move_voxels(sc, vox_list, &vox_n, &vox_base);  // (n_ca is workgroup-uniform)
     }
   }
 }
@@ -520,6 +613,9 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
   }
   const uint32_t n_vox = sc.cnt->n_move_voxels;
   const uint32_t stride = gridDim.x * blockDim.x;
+  __shared__ uint32_t n_ok_block;  // (statistic: one global atomic per workgroup, not per voxel)
+  if (threadIdx.x == 0) n_ok_block = 0;
+  __syncthreads();
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_vox; t += stride) {
     const uint32_t lv = sc.mv_vlist[t];
     const uint32_t head = sc.mv_head[lv];
@@ -536,6 +632,11 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
     uint16_t tsv[S];
     __builtin_memcpy(stv, st.status + base * REC_STATUS, S);
     __builtin_memcpy(tsv, st.ts + base * REC_TS, 2 * S);
+    // the voxel's owner entries and the length of the table of older memberships, with the rows above (owner_insert_local)
+    uint16_t own[S];
+    __builtin_memcpy(own, st.owner + base, 2 * S);
+    const uint32_t n_alias = st.alias[0];
+    bool alias_touched = false;
     uint32_t n_ok = 0;
     bool more = true, full = false;
     long long last = -1;  // largest rank replayed so far
@@ -555,6 +656,10 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
           }
       }
       more = best[S - 2] != MV_NIL;  // a full batch: there may be further ranks
+      MoveCopy cc[S - 1];  // the batch's copies, requested together
+#pragma unroll
+      for (int u = 0; u < S - 1; ++u)
+        if (best[u] != MV_NIL) cc[u] = sc.mv_copy[best[u]];
 #pragma unroll
       for (int u = 0; u < S - 1; ++u) {
         const uint32_t e = best[u];
@@ -568,7 +673,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
           full = true;
           break;
         }
-        const MoveCopy c = sc.mv_copy[e];
+        const MoveCopy c = cc[u];
         const uint8_t cs = c.status;
         const uint16_t cts = c.ts;
         st.pos4[base + slot] = make_float4(c.x, c.y, c.z, __uint_as_float(c.forget_bits));
@@ -577,7 +682,9 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
         st.track[base * REC_TRACK + slot] = c.track;
         st.label[base * REC_LABEL + slot] = c.label;
         st.status[base * REC_STATUS + slot] = cs;
-        if (!owner_insert(st, base + slot, c.owner)) sc.cnt->overflow = 1;  // new index joins the object's set
+#pragma unroll
+        for (int i = 1; i < S; ++i)  // the new index joins the object's set
+          if (i == slot && !owner_insert_local(st, base + i, c.owner, own[i], n_alias, alias_touched)) sc.cnt->overflow = 1;
         st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
 #pragma unroll
         for (int i = 1; i < S; ++i)
@@ -591,9 +698,11 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
     if (n_ok) {
       st.vflag[lv] = VF_DIRTY;
       mark_tile(st, lv);
-      atomicAdd(&sc.cnt->n_move_reinserted, n_ok);
+      atomicAdd(&n_ok_block, n_ok);
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0 && n_ok_block) atomicAdd(&sc.cnt->n_move_reinserted, n_ok_block);
 }
 
 // removeObjectByTrackID (object_layer.h:414-425): every index of the set -> INVALID, set erased.
@@ -670,15 +779,22 @@ size_t move_count_elems() { return (size_t)MAX_MOVE_OBJECTS * MV_LIST_CAP + 1; }
 // The launch sequence below is the same every frame (hipGraph): kernels of a frame without moving objects / removals
 // return at once, the scan covers fa->n_move_cnt elements read on the device.
 // step 1: collect every moving object's members (ascending index) and publish the per-object counts
-void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32_t *counts_local, hipStream_t s) {
+// by_value != nullptr: the chain runs ahead of the frame's k_frame_begin on a stream of its own; its first kernel takes
+// the frame block by value and stores it in fa_moves for the others
+void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32_t *counts_local, hipStream_t s, const FrameArgs *by_value) {
   const size_t n_slots = (size_t)d.v_count * d.S;
-  hipLaunchKernelGGL(k_move_chunks, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cur,
-                     sc.mv_cnt, sc.fa_side, st.alias, st.owner_flag);
-  hipLaunchKernelGGL(k_move_count, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, sc.fa_side, sc.mv_cnt, st.owner_flag, sc.mv_list,
-                     sc.mv_nlist, st.alias);
-  exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, move_count_elems(), sc.scan_scratch_m, s, &sc.fa_side->n_move_cnt);
+  const FrameArgs *fa = by_value ? sc.fa_moves : sc.fa_side;
+  if (by_value)
+    hipLaunchKernelGGL(k_move_chunks_v, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cur,
+                       sc.mv_cnt, *by_value, const_cast<FrameArgs *>(sc.fa_moves), st.alias, st.owner_flag);
+  else
+    hipLaunchKernelGGL(k_move_chunks, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cur,
+                       sc.mv_cnt, fa, st.alias, st.owner_flag);
+  hipLaunchKernelGGL(k_move_count, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, fa, sc.mv_cnt, st.owner_flag, sc.mv_list, sc.mv_nlist,
+                     st.alias);
+  exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, move_count_elems(), sc.scan_scratch_m, s, &fa->n_move_cnt);
   // the per-object counts are only needed as a separate row when they are exchanged between shards
-  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, counts_local, sc);
+  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, counts_local, sc, fa);
 }
 
 // step 2 (after the counts of all shards are known): global ranks, transform, export of slab-crossing copies

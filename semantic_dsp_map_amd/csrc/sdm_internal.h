@@ -220,6 +220,42 @@ __device__ __forceinline__ void owner_erase(const State &st, size_t li, uint16_t
     if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
 }
 
+// The same two for a kernel in which ONE thread owns all slots of a voxel (the ordered replays): `own` is the thread's
+// register copy of the slot's owner entry (loaded with the voxel's other rows), n_alias the table length read once at
+// kernel start, touched = this thread has added an entry since.  Entries other threads add meanwhile concern other
+// voxels' slots and cannot match li, so the length read at the start serves until this thread adds one itself.  What the
+// generic versions load between the stores of one insertion and the next - the owner entry, the table length: two
+// dependent round trips per insertion - is already there.
+__device__ __forceinline__ bool owner_insert_local(const State &st, size_t li, uint16_t track, uint16_t &own, uint32_t n_alias,
+                                                   bool &touched) {
+  const uint16_t prev = own;
+  st.owner[li] = track;
+  own = track;
+  uint32_t n = touched ? st.alias[0] : n_alias;
+  if (n > ALIAS_CAP) n = ALIAS_CAP;
+  for (uint32_t k = 0; k < n; ++k)  // a set holds an index once
+    if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+  if (prev == OWNER_NONE || prev == track) return true;
+  const uint32_t k = atomicAdd(&st.alias[0], 1u);  // prev's set keeps the index
+  touched = true;
+  if (k >= ALIAS_CAP) return false;
+  st.alias[2 + 2 * k] = (uint32_t)li;
+  st.alias[3 + 2 * k] = prev;
+  return true;
+}
+__device__ __forceinline__ void owner_erase_local(const State &st, size_t li, uint16_t track, uint16_t &own, uint32_t n_alias,
+                                                  bool touched) {
+  if (own == track) {
+    st.owner[li] = OWNER_NONE;
+    own = OWNER_NONE;
+    return;
+  }
+  uint32_t n = touched ? st.alias[0] : n_alias;
+  if (n > ALIAS_CAP) n = ALIAS_CAP;
+  for (uint32_t k = 0; k < n; ++k)
+    if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+}
+
 // field index of global-slot-order index li = lv << p_n | slot (see the record layout above)
 __host__ __device__ __forceinline__ size_t rec_index(size_t li, int p_n, RecStride mult) {
   return ((li >> p_n) << p_n) * mult + (li & (((size_t)1 << p_n) - 1));

@@ -58,6 +58,7 @@ static_assert(sizeof(FrameArgs) <= 3400, "FrameArgs travels as a kernel argument
 struct Scratch {
   const FrameArgs *fa = nullptr;       // this frame's block, as the main-stream kernels see it (written by k_frame_begin)
   const FrameArgs *fa_side = nullptr;  // the same for the chains that start before it: frustum, member count (k_set_frame)
+  const FrameArgs *fa_moves = nullptr; // the member-count chain's own copy when it runs on its own stream (k_move_chunks_v)
   // frustum vertex bitsets, one line of wpl 64-bit words per (y,z)
   uint64_t *vmask = nullptr, *reach = nullptr;
   int wpl = 0;
@@ -76,6 +77,7 @@ struct Scratch {
   float4 *pix4 = nullptr;
   uint32_t *pixt = nullptr;
   float *ck_kappa = nullptr;
+  uint8_t *ck_class = nullptr;   // per pixel: CK_DONE / CK_LIGHT / CK_HEAVY (k_bin_sort_gather -> k_ck)
   uint32_t *ck_heavy = nullptr;  // sharded list of pixels with long windows (cap_heavy entries per shard)
   uint32_t cap_heavy = 0;
   // births
@@ -145,14 +147,15 @@ struct FrameBeginLaunch {
 void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s);
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, hipStream_t s);
 void launch_frustum(const Dims &d, const Scratch &sc, hipStream_t s);
-void launch_visibility(const Dims &d, const State &st, const Scratch &sc, hipStream_t s);
+// visibility + binning; its last kernel also classifies the pixels for launch_ck (same ck_out / finish)
+void launch_visibility(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s);
 void launch_ck_reduce_chunk(const float *stage, float *full, uint32_t chunk, int world, int rank, hipStream_t s);
 void launch_weight(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
 int launch_birth_prepare(const Dims &d, const Filter &flt, const BirthOrder &bo, const State &st,
                          const Scratch &sc, hipStream_t s);
-void launch_birth_replay(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, int which,
+void launch_birth_replay(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, int which, bool literal,
                          hipStream_t s);
 void launch_count_live(const Dims &d, const State &st, unsigned long long *out, hipStream_t s);
 void launch_count_owner(const Dims &d, const State &st, uint16_t track, unsigned long long *out, hipStream_t s);
@@ -164,7 +167,7 @@ void launch_rec_pack(const Dims &d, const State &st, const float *w, const uint1
                      const uint8_t *label, const uint8_t *status, hipStream_t s);
 void launch_rec_unpack(const Dims &d, const State &st, float *w, uint16_t *ts, uint16_t *track, uint8_t *label, uint8_t *status,
                        hipStream_t s);
-void launch_fill_dense(const Dims &d, const State &st, uint32_t stamp, hipStream_t s);
+void launch_fill_dense(const Dims &d, const State &st, uint32_t stamp, int mode, hipStream_t s);
 void launch_vts_sync(const Dims &d, const State &st, int to_slot0, hipStream_t s);
 // N2: colour tables on the device (sdm_colour_config + the two division tables of OpenCV's 8-bit RGB2HSV)
 struct ColourTables {
@@ -181,7 +184,8 @@ void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t
 size_t move_blocks(const Dims &d);
 size_t move_count_elems();
 void launch_owner_flags(const Dims &d, const State &st, hipStream_t s);
-void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32_t *counts_local, hipStream_t s);
+void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32_t *counts_local, hipStream_t s,
+                        const FrameArgs *by_value = nullptr);
 void launch_moves_transform(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, const int32_t *counts_all, int world,
                             int rank, hipStream_t s);
 void launch_moves_finish(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, int world, int rank, hipStream_t s);

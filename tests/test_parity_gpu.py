@@ -264,8 +264,8 @@ def test_hip_path_against_the_literal_reference_order(cfg_name, params_name, n_f
 @pytest.mark.parametrize("name,params_name,n_particles,n_warm,n_frames,scene_kw", [
     # the benchmark state of bench.py: C3 prefilled to 2 M particles, 6 moving objects
     ("C3_benchmark_state", "vkitti2", 2000000, 0, 10, dict(n_static=48, n_dynamic=6, seed=7)),
-    # bench.py's busy scene: 200 static + 12 moving boxes, three noisy births per point, yaw + sideways drift; the GPU
-    # runs the warm-up alone (the state the timed frames of `stress` start from, ~51 k visible particles), then both
+    # bench.py's busy scene: 200 static + 12 moving boxes, three noisy births per point, yaw + sideways drift: the 14
+    # warm-up frames and 3 of the frames `stress` times (~51 k visible particles per frame)
     ("C3_stress_scene", "vkitti2_nb3", 2000000, 14, 3, dict(n_static=200, n_dynamic=12, seed=11, yaw_rate_deg=1.5, lateral_extra=(0, 0.04))),
 ])
 def test_literal_reference_order_on_the_benchmark_workloads(name, params_name, n_particles, n_warm, n_frames, scene_kw):
@@ -278,16 +278,12 @@ def test_literal_reference_order_on_the_benchmark_workloads(name, params_name, n
     o, g = pu.make_pair(cfg, params, synth.noise_table(), bin_order=0)
     st, ring, n_pre = synth.prefill_state(cfg, scene, n_particles)
     assert n_pre >= 0.85 * n_particles
-    g.load_state(st)
-    g.set_ring_state(ring)
+    for m in (o, g):
+        m.load_state(st)
+        m.set_ring_state(ring)
     del st
-    for t in range(n_warm):
-        depth, cloud, pos, q = scene.render(t, params)
-        g.update(depth, cloud, pos, q, scene.moves(t))
-    g.synchronize()
-    pu.restore(o, pu.snapshot(g))
     n_vis = []
-    for t in range(n_warm, n_warm + n_frames):
+    for t in range(n_warm + n_frames):
         depth, cloud, pos, q = scene.render(t, params)
         moves = scene.moves(t)
         o.update(depth, cloud, pos, q, moves)
@@ -304,5 +300,5 @@ def test_literal_reference_order_on_the_benchmark_workloads(name, params_name, n
         assert np.max(np.abs(vo["wsum"] - vg["wsum"])) <= 1e-4
         assert o.stats()["n_visible"] == g.stats()["n_visible"]
         n_vis.append(g.stats()["n_visible"])
-    assert min(n_vis) > (40000 if n_warm else 15000), n_vis
+    assert (min(n_vis[n_warm:]) > 40000) if n_warm else (max(n_vis) > 15000), n_vis  # (the benchmark state's first frame sees births only)
     g.close()

@@ -7,7 +7,11 @@ semantic_dsp_map.h:1029, mc_ring/operations.h:1405-1407), bin_order 1 = the cano
 see the same frames; after every frame: slots whose status / time stamp differ, voxels whose occupancy code / label
 differ, max |dw| over slots live in both, max relative d(ck+kappa) over valid pixels.  Writes a JSON summary.
 
-usage: python tools/order_gap.py C2|C3 [n_frames] [out.json]"""
+"stress" = bench.py's busy scene (C3 grid, 200 static + 12 moving boxes, three noisy births per point, ~51 k visible
+particles per frame): one map in canonical order runs the 14 warm-up frames from the prefilled state, both orders continue
+from its state.
+
+usage: python tools/order_gap.py C2|C3|stress [n_frames] [out.json]"""
 import json
 import os
 import sys
@@ -22,22 +26,39 @@ from semantic_dsp_map_amd import synth  # noqa: E402
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "C2"
     n_frames = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-    cfg = synth.CONFIGS[name]
-    params = synth.PARAMS[synth.CONFIG_PARAMS[name]]
-    n_particles = {"C2": 500000, "C3": 2000000}.get(name, 100000)
-    scene = synth.Scene(cfg, n_static=48 if name == "C3" else 24, n_dynamic=6 if name == "C3" else 3, seed=7)
+    stress = name == "stress"
+    cfg = synth.CONFIGS["C3" if stress else name]
+    params = synth.PARAMS["vkitti2_nb3" if stress else synth.CONFIG_PARAMS[name]]
+    n_particles = {"C2": 500000, "C3": 2000000, "stress": 2000000}.get(name, 100000)
+    if stress:
+        scene = synth.Scene(cfg, n_static=200, n_dynamic=12, seed=11, yaw_rate_deg=1.5, lateral_extra=(0, 0.04))
+    else:
+        scene = synth.Scene(cfg, n_static=48 if name == "C3" else 24, n_dynamic=6 if name == "C3" else 3, seed=7)
     noise = synth.noise_table()
     st, ring, n_pre = synth.prefill_state(cfg, scene, n_particles)
+    n_warm = 14 if stress else 0
+    stamps = None
+    if n_warm:
+        w = orc.OracleMap(dict(cfg, bin_order=1), params, noise)
+        w.load_state(st)
+        w.set_ring_state(ring)
+        for t in range(n_warm):
+            depth, cloud, pos, q = scene.render(t, params)
+            w.update(depth, cloud, pos, q, scene.moves(t))
+        st, ring, stamps = w.dump_state(), w.ring_state(), w.stamps()
+        del w
     maps = []
     for order in (0, 1):
         o = orc.OracleMap(dict(cfg, bin_order=order), params, noise)
         o.load_state(st)
+        if stamps is not None:
+            o.set_stamps(*stamps)
         o.set_ring_state(ring)
         maps.append(o)
     del st
     a, b = maps
     rows = []
-    for t in range(n_frames):
+    for t in range(n_warm, n_warm + n_frames):
         depth, cloud, pos, q = scene.render(t, params)
         mv = scene.moves(t)
         a.update(depth, cloud, pos, q, mv)

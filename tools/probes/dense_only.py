@@ -1,4 +1,5 @@
-"""The dense case of the occupancy sweep alone (for rocprofv3 counter passes): C3 map, every slot live, N launches."""
+"""The dense case of the occupancy sweep alone (for rocprofv3 counter passes and quick A/B runs): C3 map, every slot
+live, N launches; mode 0 = eight track ids drawn per slot, 1 = one per voxel (sdm_debug_fill_dense_ex)."""
 import os
 import sys
 
@@ -6,6 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from semantic_dsp_map_amd import binding, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+modes = [int(x) for x in sys.argv[2:]] or [0]
 m = binding.SdmMap(synth.CONFIGS["C3"], synth.PARAMS["vkitti2"], None, device=0)
-m.fill_dense()
-print("dense_ms", m.time_occupancy_sweep(iters=n))
+V = 1 << 24
+for mode in modes:
+    m.fill_dense_ex(mode)
+    m.time_occupancy_sweep(iters=2)
+    m.fill_dense_ex(mode)
+    ms = m.time_occupancy_sweep(iters=n)
+    print("dense mode %d: %.4f ms  %.3f of 8 TB/s on layout bytes (92 B/voxel)" % (mode, ms, V * 92 / ms / 1e6 / 8000.0))
