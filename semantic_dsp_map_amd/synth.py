@@ -342,6 +342,26 @@ def make_frames(cfg_name, n_frames, params_name=None, seed=7, **scene_kw):
     return cfg, params, frames
 
 
+def _render_job(job):
+    cfg, params, scene_kw, t = job
+    return Scene(cfg, **scene_kw).render(t, params)
+
+
+def render_frames(cfg, params, scene_kw, frames, workers=None):
+    """[Scene(cfg, **scene_kw).render(t, params) for t in frames], rendered by a pool of worker processes (spawned: they
+    import numpy and this module only, never the HIP library the parent may hold).  Frames are independent and a cluttered
+    scene costs about a second each; with one worker the list is rendered in this process."""
+    import multiprocessing as mp
+    import os
+    frames = list(frames)
+    workers = min(workers or min(32, os.cpu_count() or 1), len(frames))
+    jobs = [(cfg, params, scene_kw, t) for t in frames]
+    if workers <= 1:
+        return [_render_job(j) for j in jobs]
+    with mp.get_context("spawn").Pool(workers) as pool:
+        return pool.map(_render_job, jobs, chunksize=1)
+
+
 STATE_FIELDS = [("px", np.float32), ("py", np.float32), ("pz", np.float32), ("w", np.float32),
                 ("ts", np.uint16), ("track", np.uint16), ("label", np.uint8), ("status", np.uint8),
                 ("forget", np.uint8), ("owner", np.uint16)]

@@ -4,7 +4,8 @@
 Launch order of the bench command: one non-incremental sweep (k_occupancy_scan + k_occupancy_dense, first frame after
 sdm_load_state), k_occupancy<S> for the other warm-up + timed frames, then 6 profiled frames (the ones bench.py takes the
 in-frame launch time, tile and voxel counts from), 6 x-shift frames, then 11 non-incremental sweeps on the benchmark map
-(1 warm-up + 10 timed) and 11 on the dense map.  A non-incremental sweep is two launches: their counters and durations
+(1 warm-up + 10 timed), 11 on the dense map (eight track ids per slot) and 11 on the dense map with one track id per
+voxel (`dense_case_surface`).  A non-incremental sweep is two launches: their counters and durations
 are added.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated there for
 wide coalesced streaming reads, so for the in-frame launch with its scattered record fetches the corrected figure is an
 upper estimate)."""
@@ -25,9 +26,10 @@ for c in ["FETCH_SIZE", "WRITE_SIZE"]:
     inc = [one(r) for r in rows if "k_occupancy<" in r["Kernel_Name"]]
     scan = [r for r in rows if "k_occupancy_scan" in r["Kernel_Name"]]
     dense = [r for r in rows if "k_occupancy_dense" in r["Kernel_Name"]]
-    assert len(scan) == len(dense) == 23 and len(inc) + len(scan) + len(dense) == len(rows), (len(scan), len(dense), len(inc), len(rows))
+    assert len(scan) == len(dense) == 34 and len(inc) + len(scan) + len(dense) == len(rows), (len(scan), len(dense), len(inc), len(rows))
     allr = [one(a) + one(b) for a, b in zip(scan, dense)]
-    sets = {"in_frame": inc[-12:-6], "x_shift_frames": inc[-6:], "full_evaluation": allr[2:12], "dense_case": allr[13:23]}
+    sets = {"in_frame": inc[-12:-6], "x_shift_frames": inc[-6:], "full_evaluation": allr[2:12], "dense_case": allr[13:23],
+            "dense_case_surface": allr[24:34]}
     for name, rs in sets.items():
         v = [sum(x[0] for x in r) for r in rs]
         d = [sum(x[1] for x in r) for r in rs]
@@ -39,7 +41,8 @@ out = {"kernel": rf["kernel"], "non_incremental_kernels": "k_occupancy_scan + k_
        "commands": ["SDM_GRAPH=0 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -- python bench.py --no-cpu --no-strong --no-stress --steps 20 --warmup 5",
                     "SDM_GRAPH=0 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -- python bench.py --no-cpu --no-strong --no-stress --steps 20 --warmup 5"]}
 layout = {"in_frame": rf["bytes_per_launch"], "full_evaluation": rf.get("full_evaluation", {}).get("bytes_per_launch"),
-          "dense_case": rf.get("dense_case", {}).get("bytes_per_launch"), "x_shift_frames": None}
+          "dense_case": rf.get("dense_case", {}).get("bytes_per_launch"),
+          "dense_case_surface": rf.get("dense_case_surface", {}).get("bytes_per_launch"), "x_shift_frames": None}
 for name, r in res.items():
     f_kib, us_f, n = r["FETCH_SIZE"]
     w_kib, us_w, _ = r["WRITE_SIZE"]
