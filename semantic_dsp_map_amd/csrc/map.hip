@@ -2156,12 +2156,16 @@ sdm_status sdm_debug_fill_dense(sdm_map *m) { return sdm_debug_fill_dense_ex(m, 
 
 #ifdef SDM_AB_TIMERS
 extern "C++" {
-namespace sdm { void debug_timers(unsigned long long *out32, int reset); }
+namespace sdm {
+void debug_timers(unsigned long long *out32, int reset);
+void debug_timers_moves(unsigned long long *out, int reset);
+}
 }
 sdm_status sdm_debug_timers(sdm_map *m, unsigned long long *out32, int reset) {
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipDeviceSynchronize());
   sdm::debug_timers(out32, reset);
+  sdm::debug_timers_moves(out32 + 4096 * 4, reset);
   return SDM_OK;
 }
 #endif

@@ -17,6 +17,22 @@
 
 namespace sdm {
 
+#ifdef SDM_AB_TIMERS
+__device__ unsigned long long g_dbg_m[2][4096 * 4];  // [kernel][workgroup][checkpoint], see kernels.hip
+void debug_timers_moves(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_m), sizeof(g_dbg_m));
+  if (reset) {
+    static unsigned long long z[2][4096 * 4];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_m), z, sizeof(z));
+  }
+}
+#define DBGM(k, i, v) do { if (blockIdx.x < 4096 && threadIdx.x == 0) g_dbg_m[k][blockIdx.x * 4 + (i)] = (unsigned long long)(v); } while (0)
+#define DBGM_T() wall_clock64()
+#else
+#define DBGM(k, i, v)
+#define DBGM_T() 0ull
+#endif
+
 namespace {
 
 constexpr int TPB = 256;
@@ -415,6 +431,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
                                                     const int32_t *__restrict__ counts_all, int world, int rank) {
   const int n_obj = sc.fa->n_obj;
   if (n_obj <= 0) return;
+  DBGM(0, 0, DBGM_T());
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   const MoveSet &ms = sc.fa->ms;
   __shared__ uint32_t obj_base[MAX_MOVE_OBJECTS];  // global rank of the object's next member in this chunk
@@ -427,6 +444,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
   __shared__ uint32_t vox_list[MV_CHUNK], vox_n, vox_base;  // voxels that got their first copy from this chunk
   __shared__ uint32_t my_e[MV_ITEMS][TPB];                  // global rank of the member in slot r * TPB + thread of the chunk, MV_NIL: none
   __shared__ uint8_t my_o[MV_ITEMS][TPB];                   // ... and its object
+  __shared__ uint32_t rank_cnt[MV_ITEMS][MV_WAVES][MAX_MOVE_OBJECTS];  // members per (round, wave, object), then their running offsets
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) vox_n = 0;
   const uint32_t n = *sc.mv_nlist;
@@ -493,17 +511,24 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
       n_ca = ca_n < CA_CAP ? ca_n : CA_CAP;
       if (threadIdx.x == 0 && ca_n > CA_CAP) sc.cnt->overflow = 1;
     }
-    for (int r = 0; r < MV_ITEMS; ++r) {
-      if (threadIdx.x < MAX_MOVE_OBJECTS) {
-#pragma unroll
-        for (int w = 0; w < MV_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
-      }
+    if (n_ca == 0) {
+      // The usual case: every slot belongs to at most one moving object.  Ranks in three steps with two barriers (round 2
+      // ranked round by round: 48 barriers per chunk, each owner load behind the barrier before it):
+      //   1. every wave ranks its 64 slots of each of the 16 rounds by ballot and notes how many members of which object it
+      //      saw - rank_cnt[round][wave][object]; nothing waits for anybody, the 16 owner loads of a thread overlap;
+      //   2. one thread per object turns its 64 counts into running offsets, in (round, wave) order = ascending slot index;
+      //   3. a member's global rank = the object's first rank in this chunk + the offset of its (round, wave) + its rank in the wave.
+      for (uint32_t k = threadIdx.x; k < (uint32_t)(MV_ITEMS * MV_WAVES * MAX_MOVE_OBJECTS); k += TPB) (&rank_cnt[0][0][0])[k] = 0;
       __syncthreads();
-      const size_t li = base + (size_t)r * TPB + threadIdx.x;
-      if (n_ca == 0) {
-        // the usual case: every slot belongs to at most one moving object
-        uint8_t o = 0xFF;
-        if (li < n_slots) o = obj_of(st.owner[li], tracks, n_obj);
+      uint16_t ow[MV_ITEMS];  // the thread's sixteen owner entries, requested together
+#pragma unroll
+      for (int r = 0; r < MV_ITEMS; ++r) {
+        const size_t li = base + (size_t)r * TPB + threadIdx.x;
+        ow[r] = li < n_slots ? st.owner[li] : OWNER_NONE;
+      }
+#pragma unroll
+      for (int r = 0; r < MV_ITEMS; ++r) {
+        const uint8_t o = obj_of(ow[r], tracks, n_obj);
         const bool valid = o != 0xFF;
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -513,30 +538,42 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
           peers &= bit ? m : ~m;
         }
         const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
-        if (valid && rank_in_wave == 0) wave_cnt[wid][o] = (uint32_t)__popcll(peers);
-        __syncthreads();
-        // the member's global rank and object; the move itself comes after the ranking rounds (below)
-        uint32_t e = MV_NIL;
-        if (valid) {
-          e = obj_base[o] + rank_in_wave;
-#pragma unroll
-          for (int w = 0; w < MV_WAVES; ++w)
-            if (w < wid) e += wave_cnt[w][o];
-        }
-        my_e[r][threadIdx.x] = e;
+        if (valid && rank_in_wave == 0) rank_cnt[r][wid][o] = (uint32_t)__popcll(peers);
+        my_e[r][threadIdx.x] = valid ? rank_in_wave : MV_NIL;
         my_o[r][threadIdx.x] = o;
-      } else {
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < n_obj) {
+        uint32_t run = obj_base[threadIdx.x];
+        for (int r = 0; r < MV_ITEMS; ++r)
+#pragma unroll
+          for (int w = 0; w < MV_WAVES; ++w) {
+            const uint32_t c = rank_cnt[r][w][threadIdx.x];
+            rank_cnt[r][w][threadIdx.x] = run;
+            run += c;
+          }
+      }
+      __syncthreads();
+      DBGM(0, 1, DBGM_T());
+    } else {
+      for (int r = 0; r < MV_ITEMS; ++r) {
+        if (threadIdx.x < MAX_MOVE_OBJECTS) {
+#pragma unroll
+          for (int w = 0; w < MV_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+        }
+        __syncthreads();
+        const size_t li = base + (size_t)r * TPB + threadIdx.x;
         move_round_with_aliases(d, f, flt, ms, st, sc, li, n_slots, n_obj, tracks, obj_base, wave_cnt, ca_idx, ca_ent, ca_obj, n_ca,
                                 lt_mask, wid);
-      }
-      __syncthreads();
-      if (threadIdx.x < MAX_MOVE_OBJECTS) {
-        uint32_t add = 0;
+        __syncthreads();
+        if (threadIdx.x < MAX_MOVE_OBJECTS) {
+          uint32_t add = 0;
 #pragma unroll
-        for (int w = 0; w < MV_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
-        obj_base[threadIdx.x] += add;
+          for (int w = 0; w < MV_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
+          obj_base[threadIdx.x] += add;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
     // The moves themselves, outside the rounds: a move is a chain of dependent loads (position, noise, record) in a few
     // lanes, and inside a round every barrier waited for the slowest of them - sixteen times per chunk.  Four members at a
@@ -550,7 +587,8 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
         uint32_t e4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          e4[u] = my_e[r0 + u][threadIdx.x];
+          e4[u] = my_e[r0 + u][threadIdx.x];  // rank in its wave so far
+          if (e4[u] != MV_NIL) e4[u] += rank_cnt[r0 + u][wid][my_o[r0 + u][threadIdx.x]];
           if (e4[u] != MV_NIL) ml[u] = move_load(d, flt, st, cursor, e4[u], base + (size_t)(r0 + u) * TPB + threadIdx.x, false);
         }
 #pragma unroll
@@ -559,7 +597,9 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
             move_store(d, f, ms, st, sc, ml[u], (int)my_o[r0 + u][threadIdx.x], e4[u], base + (size_t)(r0 + u) * TPB + threadIdx.x, false,
                        vox_list, &vox_n);
       }
+      DBGM(0, 2, DBGM_T());
       flush_move_voxels(sc, vox_list, &vox_n, &vox_base);  // (n_ca is workgroup-uniform)
+      DBGM(0, 3, DBGM_T());
     }
   }
 }
@@ -617,6 +657,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
   if (threadIdx.x == 0) n_ok_block = 0;
   __syncthreads();
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_vox; t += stride) {
+    DBGM(1, 0, DBGM_T());
     const uint32_t lv = sc.mv_vlist[t];
     const uint32_t head = sc.mv_head[lv];
     sc.mv_head[lv] = MV_NIL;
@@ -644,8 +685,10 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
       uint32_t best[S - 1];  // the S-1 smallest ranks above `last`, ascending
 #pragma unroll
       for (int i = 0; i < S - 1; ++i) best[i] = MV_NIL;
+      uint32_t n_above = 0;  // ranks above `last` on the list
       for (uint32_t cur = head; cur != MV_NIL; cur = sc.mv_next[cur]) {
         if ((long long)cur <= last) continue;
+        ++n_above;
         uint32_t x = cur;
 #pragma unroll
         for (int i = 0; i < S - 1; ++i)
@@ -655,7 +698,8 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
             x = y;
           }
       }
-      more = best[S - 2] != MV_NIL;  // a full batch: there may be further ranks
+      DBGM(1, 1, DBGM_T() + (stv[1] == 0xEE ? 1 : 0) + (own[1] == 0xEEEE ? 1 : 0));
+      more = n_above > (uint32_t)(S - 1);  // ranks beyond this batch (a walk of the list is a chain of dependent loads: no second one to find nothing)
       MoveCopy cc[S - 1];  // the batch's copies, requested together
 #pragma unroll
       for (int u = 0; u < S - 1; ++u)
@@ -682,9 +726,15 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
         st.track[base * REC_TRACK + slot] = c.track;
         st.label[base * REC_LABEL + slot] = c.label;
         st.status[base * REC_STATUS + slot] = cs;
+        {  // the new index joins the object's set.  (ONE copy of the insertion with the slot as a run-time value: inside
+           // `if (i == slot)` of an unrolled loop a wave whose lanes fill different slots runs the body once per slot)
+          uint16_t o = OWNER_NONE;
 #pragma unroll
-        for (int i = 1; i < S; ++i)  // the new index joins the object's set
-          if (i == slot && !owner_insert_local(st, base + i, c.owner, own[i], n_alias, alias_touched)) sc.cnt->overflow = 1;
+          for (int i = 1; i < S; ++i) o = i == slot ? own[i] : o;
+          if (!owner_insert_local(st, base + slot, c.owner, o, n_alias, alias_touched)) sc.cnt->overflow = 1;
+#pragma unroll
+          for (int i = 1; i < S; ++i) own[i] = i == slot ? o : own[i];
+        }
         st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
 #pragma unroll
         for (int i = 1; i < S; ++i)
@@ -695,6 +745,8 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
         ++n_ok;
       }
     }
+    DBGM(1, 2, DBGM_T());
+    DBGM(1, 3, n_ok);
     if (n_ok) {
       st.vflag[lv] = VF_DIRTY;
       mark_tile(st, lv);

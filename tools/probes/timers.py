@@ -18,17 +18,33 @@ m.load_state(st)
 m.set_ring_state(ring)
 L = m.L
 L.sdm_debug_timers.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-out = np.zeros((4096, 4), np.uint64)
+out = np.zeros((3, 4096, 4), np.uint64)   # k_birth_replay, k_move_apply, k_move_replay: [workgroup][checkpoint]
+us = lambda x: x / 100.0
 for t in range(12):
     depth, cloud, pos, q = scene.render(t, params)
     L.sdm_debug_timers(m.h, out.ctypes.data, 1)
     m.update(depth, cloud, pos, q, scene.moves(t), sync=True)
     L.sdm_debug_timers(m.h, out.ctypes.data, 0)
     o = out.astype(np.int64)
-    ran = o[:, 0] > 0
-    t0 = o[ran, 0].min()
-    rep = ran & (o[:, 2] > 0)
-    print("frame %2d: %d workgroups, starts spread over %.1f us | %d with heads: compaction %.1f us (max), replay avg %.1f / max %.1f us, "
-          "last one ends at %.1f us | inserts of lane 0: max %d"
-          % (t, ran.sum(), (o[ran, 0].max() - t0) / 100.0, rep.sum(), ((o[rep, 1] - o[rep, 0]).max()) / 100.0,
-             ((o[rep, 2] - o[rep, 1]).mean()) / 100.0, ((o[rep, 2] - o[rep, 1]).max()) / 100.0, (o[rep, 2].max() - t0) / 100.0, o[rep, 3].max()))
+    b = o[0]
+    ran = b[:, 0] > 0
+    rep = ran & (b[:, 2] > 0)
+    if rep.any():
+        t0 = b[ran, 0].min()
+        print("frame %2d birth_replay: %d workgroups, %d with heads: compaction %.1f us (max), replay avg %.1f / max %.1f us, ends at %.1f us"
+              % (t, ran.sum(), rep.sum(), us((b[rep, 1] - b[rep, 0]).max()), us((b[rep, 2] - b[rep, 1]).mean()), us((b[rep, 2] - b[rep, 1]).max()),
+                 us(b[rep, 2].max() - t0)))
+    a = o[1]
+    act = (a[:, 0] > 0) & (a[:, 3] > 0)
+    if act.any():
+        t0 = a[a[:, 0] > 0, 0].min()
+        print("         move_apply: %d workgroups with members: ranking avg %.1f / max %.1f us, moves avg %.1f / max %.1f us, flush max %.1f us, ends at %.1f us"
+              % (act.sum(), us((a[act, 1] - a[act, 0]).mean()), us((a[act, 1] - a[act, 0]).max()), us((a[act, 2] - a[act, 1]).mean()),
+                 us((a[act, 2] - a[act, 1]).max()), us((a[act, 3] - a[act, 2]).max()), us(a[act, 3].max() - t0)))
+    r = o[2]
+    act = (r[:, 0] > 0) & (r[:, 2] > 0)
+    if act.any():
+        t0 = r[act, 0].min()
+        print("         move_replay (thread 0 of each workgroup, its last voxel): %d workgroups: rows + list walk avg %.1f / max %.1f us, inserts avg %.1f / max %.1f us (max %d copies), ends at %.1f us"
+              % (act.sum(), us((r[act, 1] - r[act, 0]).mean()), us((r[act, 1] - r[act, 0]).max()), us((r[act, 2] - r[act, 1]).mean()),
+                 us((r[act, 2] - r[act, 1]).max()), r[act, 3].max(), us(r[act, 2].max() - t0)))
