@@ -29,13 +29,16 @@ constexpr int TPB = 256;
 // checkpoints per wave, reduced with atomics into g_dbg (read with hipMemcpyFromSymbol by tools/probes/timers.py via
 // sdm_debug_timers)
 }  // namespace
-__device__ unsigned long long g_dbg[4096 * 4];  // per workgroup: 4 checkpoints, plain stores by one lane
+__device__ unsigned long long g_dbg[6][8192 * 4];  // [kernel][workgroup][checkpoint], plain stores by one lane
 namespace {
 #define DBG_T() wall_clock64()
-#define DBG_PUT(i, v) do { if (blockIdx.x < 4096) g_dbg[blockIdx.x * 4 + (i)] = (unsigned long long)(v); } while (0)
+#define DBG_PUTK(k, i, v) do { if (blockIdx.x < 8192) g_dbg[k][blockIdx.x * 4 + (i)] = (unsigned long long)(v); } while (0)
+#define DBG_PUT(i, v) DBG_PUTK(0, i, v)
+#define DBG_LANE0(k, i) do { if (threadIdx.x == 0 && threadIdx.y == 0) DBG_PUTK(k, i, DBG_T()); } while (0)
 #else
 #define DBG_T() 0ull
 #define DBG_PUT(i, v)
+#define DBG_LANE0(k, i)
 #endif
 
 // Whole-voxel fetch: all S slots of one field with the widest aligned vector loads (16 B pieces).  The copy goes
@@ -434,7 +437,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? SD
   __shared__ uint32_t n_live;
   const uint32_t blk0 = blockIdx.x * OCC_TILE;
   // a tile nobody wrote to and no stamp changed in since the last sweep: every result entry of it stands
-  if (st.tile_dirty[blockIdx.x] == 0) return;
+  DBG_LANE0(5, 0);
+  if (st.tile_dirty[blockIdx.x] == 0) {
+    DBG_LANE0(5, 1);
+    return;
+  }
   if (threadIdx.x == 0) n_live = 0;
   __syncthreads();  // every wave has read the byte
   if (threadIdx.x == 0) {
@@ -516,6 +523,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? SD
     occupancy_evaluate<S, false>(st, occ_threshold, lv, stamp_max(st, rx, ry, rz), ts1, st1, wv, trk, lab, out);
     store_result(st.res + lv, out);
   }
+  DBG_LANE0(5, 3);
 }
 
 // Non-incremental sweep: every voxel's result entry is written (first sweep of a state).  Two launches:
@@ -1309,6 +1317,7 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
   __shared__ uint32_t woff[VIS_WORDS + 1];
   __shared__ uint16_t full_list[VIS_WORDS * 64];  // candidates that hold something: word << 6 | bit
   __shared__ uint32_t n_full;
+  DBG_LANE0(1, 0);
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   const float *__restrict__ depth_img = sc.fa->depth;
   const bool force_generic = sc.fa->force_generic != 0;
@@ -1366,6 +1375,7 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
   }
   __syncthreads();
   const uint32_t nl = woff[VIS_WORDS];
+  DBG_LANE0(1, 1);
   // voxels handled (statistics): one add per workgroup - an atomic per voxel on these 64 addresses cost 26 us
   if (threadIdx.x == 0 && nl) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].fv, nl);
   if (nl == 0) continue;  // workgroup-uniform
@@ -1426,6 +1436,7 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
     }
   }
   __syncthreads();
+  DBG_LANE0(1, 2);
   // ---- phase 2: the voxels that hold something, full waves
   const uint32_t nf = n_full;
   for (uint32_t k = threadIdx.x; k < nf; k += TPB) {
@@ -1436,6 +1447,7 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
     const int az = f.bb0[2] + (int)(g / ((uint32_t)nwx * by));
     visibility_voxel<S>(d, f, st, sc, depth_img, ax, ay, az);
   }
+  DBG_LANE0(1, 3);
   }
 }
 
@@ -1496,6 +1508,7 @@ __device__ __forceinline__ void ck_store(const Filter &flt, const Scratch &sc, f
 __global__ __launch_bounds__(TPB) void k_bin_sort_gather(Dims d, Filter flt, State st, Scratch sc, float *__restrict__ ck_out, int finish) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (uint32_t)(d.W * d.H)) return;
+  DBG_LANE0(2, 0);
   const bool overflow = sc.cnt->overflow != 0;
   // ---- classification, first half: its loads go out now, their results are used at the end of the kernel (the sort and
   // gather below are a chain of dependent loads of their own; the two chains overlap)
@@ -1562,6 +1575,7 @@ __global__ __launch_bounds__(TPB) void k_bin_sort_gather(Dims d, Filter flt, Sta
     sc.ck_heavy[shard * sc.cap_heavy + k] = p;  // cap_heavy covers every pixel a shard's blocks can hold
   }
   sc.ck_class[p] = cls;
+  DBG_LANE0(2, 1);
 }
 
 // ------------------------------------------------------------------------------------ A7
@@ -1650,9 +1664,11 @@ constexpr uint32_t CK_HEAVY_BLOCKS = 64 * VIS_SHARDS;
 
 __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, State st, Scratch sc,
                                                           float *__restrict__ ck_out, int finish) {
+  DBG_LANE0(3, 0);
   if (blockIdx.x >= CK_HEAVY_BLOCKS) {  // light part: one thread per pixel
     ck_light_pixel(d, flt, st, sc, ck_out, finish,
                    (int)((blockIdx.x - CK_HEAVY_BLOCKS) * (A7_ROWS * A7_ITEMS) + threadIdx.y * A7_ROWS + threadIdx.x));
+    DBG_LANE0(3, 1);
     return;
   }
   __shared__ float rowsum[A7_ITEMS][A7_ROWS];
@@ -1682,6 +1698,9 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, St
     __syncthreads();
     const uint32_t q0 = s_q0;
     if (q0 >= n) break;
+#ifdef SDM_AB_TIMERS
+    if (lane == 0) g_dbg[3][blockIdx.x * 4 + 2] += 1;  // batches of this workgroup
+#endif
     const uint32_t q = q0 + it;
     int p = 0;
     uint32_t s = 0, e = 0;
@@ -1799,6 +1818,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, St
     }
     __syncthreads();
   }
+  DBG_LANE0(3, 1);
 }
 
 // ck_kappa from the per-slab partial images, summed in slab order (multi-GPU path)
@@ -1835,6 +1855,7 @@ __global__ __launch_bounds__(TPB) void k_ck_reduce_chunk(const float *__restrict
 
 // pass 2 (semantic_dsp_map.h:1041-1119): 16 binned particles x window rows per workgroup.
 __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Filter flt, State st, Scratch sc) {
+  DBG_LANE0(4, 0);
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   __shared__ float rowsum[A7_ITEMS][A7_ROWS];
   __shared__ int rowflag[A7_ITEMS][A7_ROWS];
@@ -1931,6 +1952,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Filter flt
     }
     __syncthreads();
   }
+  DBG_LANE0(4, 1);
 }
 
 // ------------------------------------------------------------------------------------ A8 / A9
@@ -2937,7 +2959,7 @@ __global__ __launch_bounds__(TPB) void k_fill_dense(Dims d, State st, uint32_t s
 void debug_timers(unsigned long long *out32, int reset) {
   (void)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
   if (reset) {
-    static unsigned long long z[4096 * 4];
+    static unsigned long long z[6][8192 * 4];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z));
   }
 }

@@ -2165,7 +2165,7 @@ sdm_status sdm_debug_timers(sdm_map *m, unsigned long long *out32, int reset) {
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipDeviceSynchronize());
   sdm::debug_timers(out32, reset);
-  sdm::debug_timers_moves(out32 + 4096 * 4, reset);
+  sdm::debug_timers_moves(out32 + 6 * 8192 * 4, reset);
   return SDM_OK;
 }
 #endif

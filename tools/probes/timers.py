@@ -18,33 +18,47 @@ m.load_state(st)
 m.set_ring_state(ring)
 L = m.L
 L.sdm_debug_timers.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-out = np.zeros((3, 4096, 4), np.uint64)   # k_birth_replay, k_move_apply, k_move_replay: [workgroup][checkpoint]
+buf = np.zeros(6 * 8192 * 4 + 2 * 4096 * 4, np.uint64)
 us = lambda x: x / 100.0
-for t in range(12):
+
+
+def span(name, a, extra=""):
+    """a: [workgroup][4] of one kernel, checkpoint 0 = start, 1 = end"""
+    ran = (a[:, 0] > 0) & (a[:, 1] > 0)
+    if not ran.any():
+        return
+    t0 = a[a[:, 0] > 0, 0].min()
+    dur = a[ran, 1] - a[ran, 0]
+    print("   %-24s %5d workgroups: starts spread %.1f us | duration avg %.1f / p90 %.1f / max %.1f us | last end %.1f us %s"
+          % (name, ran.sum(), us(a[ran, 0].max() - t0), us(dur.mean()), us(np.percentile(dur, 90)), us(dur.max()), us(a[ran, 1].max() - t0), extra))
+
+
+for t in range(10):
     depth, cloud, pos, q = scene.render(t, params)
-    L.sdm_debug_timers(m.h, out.ctypes.data, 1)
+    L.sdm_debug_timers(m.h, buf.ctypes.data, 1)
     m.update(depth, cloud, pos, q, scene.moves(t), sync=True)
-    L.sdm_debug_timers(m.h, out.ctypes.data, 0)
-    o = out.astype(np.int64)
-    b = o[0]
-    ran = b[:, 0] > 0
-    rep = ran & (b[:, 2] > 0)
-    if rep.any():
-        t0 = b[ran, 0].min()
-        print("frame %2d birth_replay: %d workgroups, %d with heads: compaction %.1f us (max), replay avg %.1f / max %.1f us, ends at %.1f us"
-              % (t, ran.sum(), rep.sum(), us((b[rep, 1] - b[rep, 0]).max()), us((b[rep, 2] - b[rep, 1]).mean()), us((b[rep, 2] - b[rep, 1]).max()),
-                 us(b[rep, 2].max() - t0)))
-    a = o[1]
-    act = (a[:, 0] > 0) & (a[:, 3] > 0)
-    if act.any():
-        t0 = a[a[:, 0] > 0, 0].min()
-        print("         move_apply: %d workgroups with members: ranking avg %.1f / max %.1f us, moves avg %.1f / max %.1f us, flush max %.1f us, ends at %.1f us"
-              % (act.sum(), us((a[act, 1] - a[act, 0]).mean()), us((a[act, 1] - a[act, 0]).max()), us((a[act, 2] - a[act, 1]).mean()),
-                 us((a[act, 2] - a[act, 1]).max()), us((a[act, 3] - a[act, 2]).max()), us(a[act, 3].max() - t0)))
-    r = o[2]
-    act = (r[:, 0] > 0) & (r[:, 2] > 0)
-    if act.any():
-        t0 = r[act, 0].min()
-        print("         move_replay (thread 0 of each workgroup, its last voxel): %d workgroups: rows + list walk avg %.1f / max %.1f us, inserts avg %.1f / max %.1f us (max %d copies), ends at %.1f us"
-              % (act.sum(), us((r[act, 1] - r[act, 0]).mean()), us((r[act, 1] - r[act, 0]).max()), us((r[act, 2] - r[act, 1]).mean()),
-                 us((r[act, 2] - r[act, 1]).max()), r[act, 3].max(), us(r[act, 2].max() - t0)))
+    L.sdm_debug_timers(m.h, buf.ctypes.data, 0)
+    if t < 7:
+        continue
+    k = buf[:6 * 8192 * 4].astype(np.int64).reshape(6, 8192, 4)
+    mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(2, 4096, 4)
+    print("frame %d (thread 0 of every workgroup; 100 MHz wall clock)" % t)
+    a = mv[0].copy(); a[:, 1] = a[:, 3]
+    span("move_apply", a)
+    r = mv[1].copy(); r[:, 1] = r[:, 2]
+    span("move_replay", r)
+    v = k[1]; w = v.copy(); w[:, 1] = w[:, 3]
+    act = (v[:, 0] > 0) & (v[:, 3] > 0)
+    span("visibility", w, "| masks %.1f, empty voxels %.1f, full voxels %.1f us (avg)" % (us((v[act, 1] - v[act, 0]).mean()), us((v[act, 2] - v[act, 1]).mean()), us((v[act, 3] - v[act, 2]).mean())) if act.any() else "")
+    span("bin_sort_gather", k[2])
+    c = k[3]
+    span("ck heavy part", c[:4096], "| batches per workgroup max %d" % c[:4096, 2].max())
+    span("ck light part", c[4096:])
+    span("weight", k[4])
+    b = k[0].copy(); b[:, 1] = b[:, 2]
+    span("birth_replay (heads)", b)
+    o = k[5]
+    early = o.copy(); early[o[:, 3] > 0] = 0
+    span("occupancy (clean tiles)", early)
+    full = o.copy(); full[:, 1] = full[:, 3]
+    span("occupancy (dirty tiles)", full)
