@@ -10,7 +10,51 @@
 
 static bool close_to(float a, double b) { return std::fabs((double)a - b) <= 1e-4 * std::fabs(b); }
 
-int main() {
+// `run`: the default-constructed class - the grid the macros select, nothing else set but the reference's YAML parameters -
+// takes four frames of a wall 3 m ahead through update() the way src/mapping.cpp does (depth + "static" mask at the
+// sensor's size, i.e. before the BOOST reduction) and must emit the wall, and only the wall.
+static int run_wall() {
+  SemanticDSPMap map;
+  const SdmGridPreset p = map.gridPreset();
+  map.setMapParameters(0.8f, 0.2f, 1, 0.15f, 20, 1.0f, 5, 0.6f, 0.5f);  // cfg/options_zed2.yaml
+  map.setMapOptions(true, false);
+  map.setVisualizeOptions(false, true);
+  map.setDepthNoiseModelParameters(0.02f, 0.3f);
+  const int W = p.src_width > 0 ? p.src_width : p.width, H = p.src_height > 0 ? p.src_height : p.height;
+  cv::Mat depth(H, W, 4);
+  for (int i = 0; i < H; ++i)
+    for (int j = 0; j < W; ++j) depth.at<float>(i, j) = 3.0f;
+  MaskKpts st;
+  st.track_id = 65535;
+  st.label = "static";
+  st.mask = cv::Mat(H, W, 1);
+  for (int i = 0; i < H; ++i)
+    for (int j = 0; j < W; ++j) st.mask.at<uchar>(i, j) = 5;  // pixel value + 1 = label 6 (Building)
+  Eigen::Vector3d pos(0, 0, 0);
+  Eigen::Quaterniond q(1, 0, 0, 0);
+  size_t n_occ = 0;
+  for (int t = 0; t < 4; ++t) {
+    std::vector<MaskKpts> seg{st};  // (update() may resize the masks in place in BOOST mode, like the reference)
+    cv::Mat d = depth;
+    pcl::PointCloud<pcl::PointXYZRGB>::Ptr occ(new pcl::PointCloud<pcl::PointXYZRGB>), fr(new pcl::PointCloud<pcl::PointXYZRGB>);
+    map.update(d, seg, pos, q, occ, fr, false, 0.1 * t);
+    n_occ = occ->size();
+    for (auto &pt : occ->points)
+      if (pt.z < 3.0f - 3.f * p.voxel_size || pt.z > 3.0f + 3.f * p.voxel_size) {
+        std::printf("occupied voxel away from the wall: z = %f\n", pt.z);
+        return 2;
+      }
+  }
+  // the wall fills the view: about (2 * 3 m * tan) / voxel_size voxels across, clipped by the map
+  const double half_w = 3.0 * (0.5 * p.width / p.fx), half_h = 3.0 * (0.5 * p.height / p.fy);
+  const double map_half_x = 0.5 * (1 << p.x_n) * p.voxel_size, map_half_y = 0.5 * (1 << p.y_n) * p.voxel_size;
+  const double expect = (2.0 * std::fmin(half_w, map_half_x) / p.voxel_size) * (2.0 * std::fmin(half_h, map_half_y) / p.voxel_size);
+  std::printf("setting %d boost %d: %zu occupied voxels after 4 frames (wall face: about %.0f)\n", (int)SDM_SETTING, (int)SDM_BOOST_MODE, n_occ, expect);
+  return n_occ > 0.5 * expect && n_occ < 4.0 * expect ? 0 : 1;
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1) return run_wall();
   SemanticDSPMap map;
   const SdmGridPreset &p = map.gridPreset();
   std::printf("setting %d boost %d: grid %d %d %d slots_n %d voxel %.3f image %dx%d (source %dx%d) fx %.4f cx %.4f depth_max %.1f window %d instance %d zed2 %d mode %d\n",

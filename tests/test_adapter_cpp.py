@@ -43,6 +43,25 @@ def test_adapter_honours_the_setting_macros(defs, setting, boost, tmp_path):
     assert "setting %d boost %d:" % (setting, boost) in out.stdout, out.stdout
 
 
+def build_setting_exe(defs, exe):
+    csrc = os.path.dirname(binding.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall"] + defs +
+                          ["-I", os.path.join(ROOT, "tests", "mock_includes"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "adapter_setting.cpp"), "-o", exe, "-L", csrc, "-lsdm_hip",
+                           "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("defs", [[], ["-DSETTING=0"], ["-DSETTING=1"], ["-DSETTING=2"], ["-DSETTING=3", "-DBOOST_MODE=0"]])
+def test_adapter_runs_the_shipped_grids(defs, tmp_path):
+    """The default-constructed class at every grid the reference ships (nothing defined = SETTING 3 + BOOST_MODE, its ZED2
+    configuration with 1280 x 720 inputs reduced on the device) takes a wall scene through update()."""
+    exe = str(tmp_path / "adapter_setting")
+    build_setting_exe(defs, exe)
+    out = subprocess.run([exe, "run"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "occupied voxels after 4 frames" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.gpu
 def test_adapter_runs_a_wall_scene():
     build_exe()
