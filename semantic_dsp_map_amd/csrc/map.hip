@@ -696,17 +696,19 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   if ((rc = upload_stamps(m)) != SDM_OK) return rc;
   HIP_TRY(hipStreamSynchronize(m->stream));
   {
-    // how fast does this host issue launches?  (fastest of three bursts of 16 empty kernels; decides the graph's shape)
+    // how fast does this host issue launches?  (median of five bursts of 16 empty kernels: one burst is noisy, and the
+    // answer decides how every frame of this map is issued)
     hipLaunchKernelGGL(k_noop, dim3(1), dim3(1), 0, m->stream);
     HIP_TRY(hipStreamSynchronize(m->stream));
-    double best = 1e30;
-    for (int rep = 0; rep < 3; ++rep) {
+    double burst[5];
+    for (int rep = 0; rep < 5; ++rep) {
       const auto t0 = std::chrono::steady_clock::now();
       for (int i = 0; i < 16; ++i) hipLaunchKernelGGL(k_noop, dim3(1), dim3(1), 0, m->stream);
-      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-      if (us < best) best = us;
+      burst[rep] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
       HIP_TRY(hipStreamSynchronize(m->stream));
     }
+    std::sort(burst, burst + 5);
+    const double best = burst[2];
     m->enqueue_us = best / 16.0 * LAUNCHES_PER_FRAME;
     if (m->graph_mode == 2) {
       m->use_graph = m->enqueue_us > GRAPH_PIECES_US;
