@@ -40,7 +40,7 @@ def timed_run(synth, sharded, dist, rank, world, local_rank, cfg, params, partic
               prefill_kw=None):
     """One more map of its own: frames rendered and uploaded, map prefilled, `warmup` + `steps` frames issued back to back,
     barrier + synchronize on both sides of the timed ones, max over ranks.  Returns the numbers and the engine (open)."""
-    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist)
+    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist, force_comm=dist is not None)
     m = eng.map
     m.generate_noise_table(seed=20250217)
     scene = synth.Scene(cfg, **scene_kw)
@@ -276,14 +276,18 @@ def main():
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, args.gpus))
+    # SDM_BENCH_SHARDED=1: take the N > 1 code path - gloo process group, RCCL communicator, sdm_update_sharded, collective
+    # timers - with whatever world size there is (1 on the boxes with one GPU): a rehearsal of the multi-GPU bench line
+    multi = world > 1 or os.environ.get("SDM_BENCH_SHARDED") == "1"
     dist = None
-    if world > 1:
+    if multi:
         # torch.distributed is plumbing only: gloo (CPU) for the rendezvous, barriers and the max over ranks.
         # The data-path collectives are RCCL calls inside libsdm_hip on the system HIP runtime.
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        with sharded.stdout_to_stderr():  # gloo prints its connection summary on stdout
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     base = synth.CONFIGS[args.config]
     cfg = sharded.weak_scaled_config(base, world)
@@ -292,7 +296,7 @@ def main():
     S = 1 << cfg["p_n"]
     n_frames = args.warmup + args.steps
 
-    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist)
+    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist, force_comm=multi)
     m = eng.map
     # noise table: rocRAND on the device, read back so that the CPU baseline uses the same floats
     m.generate_noise_table(seed=20250217)
@@ -338,7 +342,7 @@ def main():
         dt = float(tt.item())
 
     stats = m.stats(count_live=True)
-    issue_mode = ("sharded: launch by launch, collectives on the streams" if world > 1 else
+    issue_mode = ("sharded: launch by launch, collectives on the streams" if multi else
                   "hipGraph replay" if stats["graph_frames"] >= args.steps else
                   "launch by launch" if stats["graph_frames"] == 0 else "mixed")
     launch_mode = {"graph_frames": stats["graph_frames"], "direct_frames": stats["direct_frames"],
@@ -358,7 +362,7 @@ def main():
     # and the tiles it looked into come from the library's counters.
     n_extra = 6
     m.set_profiling(True)
-    if world > 1:
+    if multi:
         m.comm_timing(True)
 
     comm_us = {}
@@ -370,7 +374,7 @@ def main():
             dd, dc = m.device_put(depth), m.device_put(cloud)
             eng.update(dd, dc, pos, q, scene.moves(t))
             m.synchronize()
-            if world > 1:
+            if multi:
                 for k, v in m.comm_times().items():
                     comm_us.setdefault(k, []).append(v)
             stt = m.stats()
@@ -388,7 +392,7 @@ def main():
     xs_stage, xs_live, xs_tiles, xs_slabs = profiled(n_frames + n_extra, n_frames + 2 * n_extra)
     m.set_profiling(False)
     collectives = None
-    if world > 1:
+    if multi:
         # GPU time of each collective of a sharded frame (HIP events around it on the stream it is issued on; includes
         # waiting for the slowest shard to arrive), averaged over the profiled frames, max over the ranks; and what a shard
         # receives per frame
@@ -456,10 +460,10 @@ def main():
                                    "launches_timed": n_extra}}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_frames > 0:
+    if rank == 0 and not multi and not args.no_cpu and args.cpu_frames > 0:
         cpu = cpu_baseline(cfg, params, noise, frames, st, ring, args.cpu_frames, V)
 
-    if world == 1 and not args.no_dense:
+    if not multi and not args.no_dense:
         # the same kernel on SURVEY.md 8(d)'s dense case (every slot of every voxel live, all of them to be evaluated):
         # run last, it overwrites the map
         # first the non-incremental launch on the benchmark state: every tile, every voxel's result written, every voxel
@@ -506,11 +510,11 @@ def main():
         eng4.map.close()
 
     stress = None
-    if world == 1 and not args.no_stress and not args.no_cpu:
+    if not multi and not args.no_stress and not args.no_cpu:
         stress = stress_run(synth, sharded)
 
     grown = None
-    if world == 1 and not args.no_grown and not args.no_cpu:
+    if not multi and not args.no_grown and not args.no_cpu:
         grown = grown_run(synth, sharded)
 
     if rank == 0:
@@ -539,7 +543,7 @@ def main():
             out["stress"] = stress
         if grown is not None:
             out["grown"] = grown
-        if world == 1:
+        if not multi:
             out["stage_ms"] = {k: round(stage_ms[i], 4) for i, k in
                                enumerate(["", "ego", "move", "remove", "visibility", "weight", "birth", "occupancy"]) if k}
         print(json.dumps(out))

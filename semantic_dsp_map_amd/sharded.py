@@ -36,6 +36,31 @@ def weak_scaled_config(base_cfg, world):
     return cfg
 
 
+class stdout_to_stderr:
+    """`with stdout_to_stderr():` - file descriptor 1 points at stderr inside the block, C-level buffers flushed on the
+    way out.  RCCL (version banner at communicator creation) and gloo (connection summary at init_process_group) print
+    on the process's stdout from C++; bench.py's stdout carries ONE JSON line and nothing else."""
+
+    def __enter__(self):
+        import os
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import os
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def broadcast_unique_id(dist, rank):
     """rank 0 draws the RCCL id (sdm_comm_unique_id), everybody receives it (gloo broadcast of 128 bytes)."""
     import torch
@@ -50,29 +75,21 @@ def broadcast_unique_id(dist, rank):
 class NativeShardedMap:
     """A libsdm_hip shard whose exchanges run inside the library on RCCL."""
 
-    def __init__(self, cfg, params, rank, world, device, dist=None, noise_table=None, halo_cap=0, max_visible=0):
+    def __init__(self, cfg, params, rank, world, device, dist=None, noise_table=None, halo_cap=0, max_visible=0, force_comm=False):
         from . import binding
         self.rank, self.world = rank, world
+        self.sharded = world > 1 or force_comm   # force_comm: the RCCL path with a communicator of one rank (rehearsal)
         self.map = binding.SdmMap(cfg, params, noise_table, device=device, shard_rank=rank, shard_count=world,
                                   max_visible=max_visible)
-        if world > 1:
+        if self.sharded:
             if dist is None:
                 raise ValueError("world > 1 needs a torch.distributed module for the rendezvous")
             uid = broadcast_unique_id(dist, rank)
-            # RCCL prints a version banner on stdout at communicator creation; keep stdout clean for the caller's JSON
-            import os
-            import sys
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
+            with stdout_to_stderr():  # RCCL prints a version banner on stdout at communicator creation
                 self.map.comm_init(uid, halo_cap)
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
 
     def update(self, depth, cloud, pos, q, moves=None, remove_tracks=None, on_device=True):
-        if self.world == 1:
+        if not self.sharded:
             self.map.update(depth, cloud, pos, q, moves, remove_tracks, on_device=on_device)
         else:
             self.map.update_sharded(depth, cloud, pos, q, moves, remove_tracks, on_device=on_device)

@@ -51,3 +51,29 @@ def test_committed_bench_line_is_self_consistent():
     assert d["value"] / d["cpu_baseline"]["value"] >= 50    # BASELINE.json: >= 50x the single-thread CPU frame time at C3
     if "stress" in d and "x_cpu" in d["stress"]:
         assert d["stress"]["x_cpu"] >= 50
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_sharded_bench_line_rehearsal():
+    """The N > 1 path of bench.py - gloo process group, RCCL communicator inside the library, sdm_update_sharded, the
+    collective timers, the strong-scaling leg - with the one rank a one-GPU box allows (SDM_BENCH_SHARDED=1): the line the
+    driver's multi-GPU run will print has to come out whole."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SDM_BENCH_SHARDED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "3"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [x for x in r.stdout.strip().splitlines() if x.strip()]
+    assert len(lines) == 1, "stdout must carry the one JSON line and nothing else (RCCL's banner goes to stderr): %r" % lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "collectives_us", "strong_scaling"):
+        assert k in d, k
+    c = d["collectives_us"]
+    assert set(c["us"]) == {"counts_allgather", "halo_alltoall", "ck_alltoall", "ck_allgather"}
+    assert c["us"]["ck_alltoall"] > 0 and c["us"]["ck_allgather"] > 0 and c["us_on_critical_path"] > 0
+    assert d["issue_mode"].startswith("sharded") and d["cpu_baseline"] is None and d["n_gpus"] == 1
