@@ -62,3 +62,19 @@ for t in range(10):
     span("occupancy (clean tiles)", early)
     full = o.copy(); full[:, 1] = full[:, 3]
     span("occupancy (dirty tiles)", full)
+
+    def first_last(a, end_col=1):
+        ran = a[:, 0] > 0
+        ends = a[:, end_col][a[:, end_col] > 0]
+        return (a[ran, 0].min(), max(ends.max(), a[ran, 0].max())) if ran.any() and ends.size else None
+
+    order = [("move_apply", mv[0], 3), ("move_replay", mv[1], 2), ("visibility", k[1], 3), ("bin_sort_gather", k[2], 1), ("ck", k[3], 1),
+             ("weight", k[4], 1), ("birth_replay", k[0], 2), ("occupancy", k[5], 3)]
+    tl = [(n, first_last(a, c)) for n, a, c in order]
+    tl = [(n, x) for n, x in tl if x]
+    t0 = tl[0][1][0]
+    print("   main stream, first workgroup start -> last recorded end, us from move_apply's start (scan and bin_fill sit between visibility and bin_sort_gather):")
+    prev_end = None
+    for n, (a0, a1) in tl:
+        print("      %-16s %7.1f -> %7.1f%s" % (n, us(a0 - t0), us(a1 - t0), "" if prev_end is None else "   gap to the kernel before: %.1f us" % us(a0 - prev_end)))
+        prev_end = a1
