@@ -1853,90 +1853,129 @@ __global__ __launch_bounds__(TPB) void k_ck_reduce_chunk(const float *__restrict
   full[(size_t)rank * chunk + i] = ck;
 }
 
-// pass 2 (semantic_dsp_map.h:1041-1119): 16 binned particles x window rows per workgroup.
-__global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Filter flt, State st, Scratch sc) {
+// pass 2 (semantic_dsp_map.h:1041-1119): one wave per U binned particles, one lane per pixel of a particle's window
+// (ROUNDS rounds of 64 lanes: 49 pixels at window_half 3, 121 at 5, at most 225).  A dependent fetch costs 1-2 us here
+// whatever its size (in-kernel clocks, profiles/r03_in_kernel_timers.txt), and eight waves per SIMD hold fewer particles
+// than a frame shows: so a wave issues the fetches of all its U particles level by level - own entries (wave-uniform,
+// scalar loads), then sigma beside every window pixel, then the table - and is through after three levels.
+// The terms go through LDS and are added in the order of the reference's loops: along each window row from 0.f, then
+// the rows; a skipped pixel adds +0.f, which leaves a sum that started at +0.f (and so never is -0.f) as it is.
+constexpr int WT_WAVES = 4;
+constexpr int WT_GRID = 2048;  // x 4 waves = the 8192 waves the chip holds at once
+template <int U, int ROUNDS>
+__global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, State st, Scratch sc) {
+  static_assert(U * A7_ROWS <= 64, "lanes (u, row) of the row sums");
   DBG_LANE0(4, 0);
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
-  __shared__ float rowsum[A7_ITEMS][A7_ROWS];
-  __shared__ int rowflag[A7_ITEMS][A7_ROWS];
+  __shared__ float term[WT_WAVES][U][ROUNDS * 64];
+  __shared__ float rowsum[WT_WAVES][U][A7_ROWS];
   if (sc.cnt->overflow) return;
   const uint32_t n = sc.cnt->n_vis;
   const sdm_labeled_point *__restrict__ cloud_img = sc.fa->cloud;
-  const int r = threadIdx.x, it = threadIdx.y;
-  const int h = d.window_half;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = d.window_half, side = 2 * h + 1, pairs = side * side;
   const float *__restrict__ pdf = st.pdf;
   const size_t slot_base = (size_t)d.v_begin << d.p_n;
-  for (uint32_t k0 = blockIdx.x * A7_ITEMS; k0 < n; k0 += gridDim.x * A7_ITEMS) {
-    const uint32_t k = k0 + it;
-    float acc = 0.f;
-    int right = 0;
-    uint32_t p = 0;
-    if (k < n) p = sc.vpix[k];
-    // sigma of the particle's own pixel (semantic_dsp_map.h:1047); which division the wave's pairs take (div_by is
-    // verified for a range of sigma, div_recip returns 0 outside it) is decided for the wave as a whole
-    const float sigma = k < n ? cloud_img[p].sigma : 1.f;
-    const float rsig = div_recip(sigma);
-    const bool wave_fast = __ballot(rsig == 0.f) == 0ull;
-    auto row = [&](auto fast) {
-      const int i = p / d.W, j = p % d.W;
-      const int ni = i + r - h;
-      if (ni >= 0 && ni < d.H) {
-        const float4 pv = sc.vp4[k];
-        const uint32_t tf = sc.vtf[k];
-        const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
-        const float ff = flt.forget[(tf >> 16) & 7];
-        // the loads of a window row are issued eight pixels at a time; the adds stay in column order
-        for (int n0 = -h; n0 <= h; n0 += 8) {
-          uint32_t ot[8];
-          float4 o[8];
+  // the lane's window pixel in each round
+  int wr[ROUNDS], wc[ROUNDS];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int nj = j + n0 + u;
-            ot[u] = 0;
-            if (n0 + u <= h && nj >= 0 && nj < d.W) ot[u] = sc.pixt[ni * d.W + nj];
-          }
+  for (int rd = 0; rd < ROUNDS; ++rd) {
+    const int q = rd * 64 + lane;
+    wr[rd] = q / side;
+    wc[rd] = q - wr[rd] * side;
+  }
+  const uint32_t stride = gridDim.x * WT_WAVES * U;
+  for (uint32_t k0 = (blockIdx.x * WT_WAVES + wv) * U; k0 < n; k0 += stride) {
+    uint32_t p[U], tf[U], bi[U];
+    float4 pv[U];
+    float sigma[U], rsig[U];
 #pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (ot[u] >> 16) o[u] = sc.pix4[ni * d.W + j + n0 + u];  // x, y, z, ck+kappa
+    for (int u = 0; u < U; ++u) {
+      p[u] = tf[u] = bi[u] = 0;
+      pv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + u < n) p[u] = sc.vpix[k0 + u], pv[u] = sc.vp4[k0 + u], tf[u] = sc.vtf[k0 + u], bi[u] = sc.bin_idx[k0 + u];
+    }
+    uint32_t ot[U][ROUNDS];
+    float4 o[U][ROUNDS];
+    bool all_fast = true;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            if (!(ot[u] >> 16)) continue;  // outside the window / image, or an invalid pixel
-            const uint16_t otrack = (uint16_t)(ot[u] & 0xffffu);
-            if (flt.independent && otrack != ptrack) continue;
-            constexpr bool F = decltype(fast)::value;
-            float gk = query_pdf_r<F>(pdf, pv.x, o[u].x, sigma, rsig) * query_pdf_r<F>(pdf, pv.y, o[u].y, sigma, rsig) *
-                       query_pdf_r<F>(pdf, pv.z, o[u].z, sigma, rsig);
+    for (int u = 0; u < U; ++u) {
+      // sigma of the particle's own pixel (semantic_dsp_map.h:1047); div_by is verified against the division for a
+      // range of sigma, div_recip returns 0 outside it
+      sigma[u] = k0 + u < n ? cloud_img[p[u]].sigma : 1.f;
+      const int i = p[u] / d.W, j = p[u] % d.W;
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int ni = i + wr[rd] - h, nj = j + wc[rd] - h;
+        ot[u][rd] = 0;
+        o[u][rd] = make_float4(0.f, 0.f, 0.f, 1.f);
+        if (k0 + u < n && rd * 64 + lane < pairs && ni >= 0 && ni < d.H && nj >= 0 && nj < d.W) {
+          ot[u][rd] = sc.pixt[ni * d.W + nj];
+          o[u][rd] = sc.pix4[ni * d.W + nj];  // x, y, z, ck+kappa (beside the validity word, not behind it)
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      rsig[u] = div_recip(sigma[u]);
+      all_fast = all_fast && rsig[u] != 0.f;
+    }
+    int right[U];
+    auto terms = [&](auto fast) {
+      constexpr bool F = decltype(fast)::value;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint16_t ptrack = (uint16_t)(tf[u] & 0xffffu);
+        const float ff = flt.forget[(tf[u] >> 16) & 7];
+        right[u] = 0;
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+          float t = 0.f;
+          const uint16_t otrack = (uint16_t)(ot[u][rd] & 0xffffu);
+          if ((ot[u][rd] >> 16) && !(flt.independent && otrack != ptrack)) {  // a valid pixel
+            float gk = query_pdf_r<F>(pdf, pv[u].x, o[u][rd].x, sigma[u], rsig[u]) *
+                       query_pdf_r<F>(pdf, pv[u].y, o[u][rd].y, sigma[u], rsig[u]) *
+                       query_pdf_r<F>(pdf, pv[u].z, o[u][rd].z, sigma[u], rsig[u]);
             if (!flt.independent) {
               if (ptrack != otrack) {
                 gk *= flt.id_transition;
               } else {
-                if (gk > SDM_MIN_RIGHT_PDF) right = 1;
+                if (gk > SDM_MIN_RIGHT_PDF) right[u] = 1;
               }
               gk *= ff;
             }
-            acc += gk / o[u].w;
+            t = gk / o[u][rd].w;
           }
+          term[wv][u][rd * 64 + lane] = t;
         }
       }
     };
-    if (wave_fast) {
-      if (k < n && r <= 2 * h) row(std::true_type{});
-    } else {
-      if (k < n && r <= 2 * h) row(std::false_type{});
+    if (all_fast) terms(std::true_type{}); else terms(std::false_type{});
+    unsigned long long rb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) rb[u] = __ballot(right[u]);
+    __builtin_amdgcn_wave_barrier();
+    // lane (u, r): row r of particle u
+    const int lu = lane / A7_ROWS, lr = lane % A7_ROWS;
+    if (lu < U && lr < side) {
+      float acc = 0.f;
+      for (int c = 0; c < side; ++c) acc += term[wv][lu][lr * side + c];
+      rowsum[wv][lu][lr] = acc;
     }
-    rowsum[it][r] = acc;
-    rowflag[it][r] = right;
-    __syncthreads();
-    if (r == 0 && k < n) {
+    __builtin_amdgcn_wave_barrier();
+    if (lu < U && lr == 0 && k0 + lu < n) {
       float a = 0.f;
-      int right_id = 0;
-      for (int m = 0; m <= 2 * h; ++m) {
-        a += rowsum[it][m];
-        right_id |= rowflag[it][m];
-      }
-      const size_t li = (size_t)sc.bin_idx[k] - slot_base;
-      const uint32_t fc = (sc.vtf[k] >> 16) & 0xffu;
-      st.w[rec_index(li, d.p_n, REC_W)] = sc.vp4[k].w * (a * flt.p_detect + 1.f - flt.p_detect);
+      for (int m = 0; m < side; ++m) a += rowsum[wv][lu][m];
+      uint32_t my_bi = bi[0], my_tf = tf[0];
+      float my_w = pv[0].w;
+      bool right_id = rb[0] != 0ull;
+#pragma unroll
+      for (int u = 1; u < U; ++u)
+        if (lu == u) my_bi = bi[u], my_tf = tf[u], my_w = pv[u].w, right_id = rb[u] != 0ull;
+      const size_t li = (size_t)my_bi - slot_base;
+      const uint32_t fc = (my_tf >> 16) & 0xffu;
+      st.w[rec_index(li, d.p_n, REC_W)] = my_w * (a * flt.p_detect + 1.f - flt.p_detect);
       st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_UPDATED;
       st.vflag[li >> d.p_n] = VF_DIRTY;
       mark_tile(st, li >> d.p_n);
@@ -1950,7 +1989,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_weight(Dims d, Filter flt
         }
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
   DBG_LANE0(4, 1);
 }
@@ -2826,7 +2865,14 @@ void launch_ck_reduce_chunk(const float *stage, float *full, uint32_t chunk, int
   hipLaunchKernelGGL(k_ck_reduce_chunk, dim3((chunk + TPB - 1) / TPB), dim3(TPB), 0, s, stage, full, chunk, world, rank);
 }
 void launch_weight(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s) {
-  hipLaunchKernelGGL(k_weight, dim3(2048), dim3(A7_ROWS, A7_ITEMS), 0, s, d, flt, st, sc);
+  // four particles per wave while a window fits two rounds of 64 lanes (window_half <= 5), two beyond
+  const int side = 2 * d.window_half + 1;
+  if (side * side <= 64)
+    hipLaunchKernelGGL((k_weight<4, 1>), dim3(WT_GRID), dim3(64 * WT_WAVES), 0, s, d, flt, st, sc);
+  else if (side * side <= 128)
+    hipLaunchKernelGGL((k_weight<4, 2>), dim3(WT_GRID), dim3(64 * WT_WAVES), 0, s, d, flt, st, sc);
+  else
+    hipLaunchKernelGGL((k_weight<2, 4>), dim3(WT_GRID), dim3(64 * WT_WAVES), 0, s, d, flt, st, sc);
 }
 
 // Birth candidates and their stable sort by target voxel depend on the input cloud only: side stream.

@@ -42,6 +42,21 @@ def test_other_slot_counts(p_n, params_name):
     assert st["live_particles"] > 0
 
 
+@pytest.mark.parametrize("window_half", [1, 2, 4, 6, 7])
+def test_other_window_sizes(window_half):
+    """The weight update is instantiated per window size class (<= 64, <= 128, <= 256 window pixels per particle: one,
+    two or four rounds of 64 lanes); the presets only use window_half 3 and 5."""
+    cfg = dict(synth.CONFIGS["T0"], window_half=window_half)
+    params = synth.PARAMS["noisy3"]
+    sc = synth.Scene(cfg, n_dynamic=2, seed=13)
+    frames = []
+    for t in range(6):
+        depth, cloud, pos, q = sc.render(t, params)
+        frames.append((depth, cloud, pos, q, sc.moves(t)))
+    st = run_clip(cfg, params, frames)
+    assert st["live_particles"] > 0
+
+
 def test_independent_filter_with_moving_objects():
     cfg = synth.CONFIGS["T0"]
     params = synth.PARAMS["kitti360"]
