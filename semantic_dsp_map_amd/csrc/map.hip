@@ -31,7 +31,22 @@ thread_local std::string g_last_error;
 // 0.319-0.332 ms without, 0.300-0.302 ms with.  The HIP runtime reads the variable when it initialises (first HIP call of
 // the process), so it is set when this library is loaded - unless the user has set it, or HIP is already up (then
 // nothing changes).
-__attribute__((constructor)) void sdm_runtime_defaults() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+//
+// Hardware queues: a map issues a frame on five streams (main chain, frustum chain, birth candidates, member counts,
+// uploads), and frames issued back to back take either 0.270 or 0.295 ms on C3 - the same in every frame of one set of
+// streams, different from one set to the next (and from process to process); the per-stage times with a synchronisation
+// after each stage are the same in both modes, so what differs is how well the next frame's side chains run beside this
+// frame's sweep.  The runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues.  Measured on one box, 7
+// processes each: 4 queues 0.292-0.332 ms; default 1 fast run in 7; 8 queues 4 in 7; 16 queues 6-7 in 7; 32 queues 7 in 7
+// (0.270-0.272 ms).  On a second box 32 queues changed nothing (3 runs in 3 at 0.295 ms); a high-priority main stream and
+// one or two side streams instead of three did not change the odds on either.  So: no harm, sometimes the fast mode
+// every time.  Set like the variable above.
+// (Priority 101: before the constructors that register this library's kernels with the runtime - they are what brings
+// the runtime up when nothing else in the process has, and run at the default priority.)
+__attribute__((constructor(101))) void sdm_runtime_defaults() {
+  setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+  setenv("GPU_MAX_HW_QUEUES", "32", 0);
+}
 
 // How a plain frame is issued.  Measured on MI355X / ROCm 7.2 (host time inside sdm_update per frame; GPU time per
 // benchmark frame, frames back to back, several runs):
