@@ -216,7 +216,7 @@ __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__
 // it, the +0.f terms of the other slots included), the first voting slot wins, nobody beats it (equal total, equal
 // track), and the label is the last voting slot's.
 template <int S, bool PLAIN, bool SINGLE = false>
-__device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_threshold, uint32_t lv, uint32_t smax,
+__device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_threshold, uint32_t remark, uint32_t lv, uint32_t smax,
                                                    const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv_in)[S],
                                                    const uint16_t (&trk16)[S], const uint8_t (&lab8)[S],
                                                    sdm_voxel_result &out) {
@@ -339,7 +339,7 @@ __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_th
     flag = left ? VF_DIRTY : VF_EMPTY;  // a culled slot still counted in this sum
   }
   st.vflag[lv] = flag;
-  if (flag != VF_CLEAN) mark_tile(st, lv);  // the next sweep evaluates it again resp. writes the empty result
+  if (flag != VF_CLEAN) mark_tile(st, lv, remark);  // the next sweep evaluates it again resp. writes the empty result
 }
 
 // Conservative test for the PLAIN version above: true only if no slot that could be live carries a weight above 1
@@ -370,7 +370,7 @@ __device__ __forceinline__ bool occupancy_is_plain(uint32_t smax, const uint16_t
 
 // one voxel per lane; `mine` = this lane has a voxel to evaluate (its arrays are loaded)
 template <int S>
-__device__ __forceinline__ void occupancy_evaluate_wave(const State &st, float occ_threshold, bool mine, uint32_t lv, uint32_t smax,
+__device__ __forceinline__ void occupancy_evaluate_wave(const State &st, float occ_threshold, uint32_t remark, bool mine, uint32_t lv, uint32_t smax,
                                                         const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv)[S],
                                                         const uint16_t (&trk)[S], const uint8_t (&lab)[S],
                                                         sdm_voxel_result &out) {
@@ -378,12 +378,12 @@ __device__ __forceinline__ void occupancy_evaluate_wave(const State &st, float o
   const bool special = mine && !occupancy_is_plain<S>(smax, ts1, st1, wv, trk, single);
   if (__ballot(special) == 0ull) {  // wave-uniform
     if (__ballot(mine && !single) == 0ull) {
-      if (mine) occupancy_evaluate<S, true, true>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab, out);
+      if (mine) occupancy_evaluate<S, true, true>(st, occ_threshold, remark, lv, smax, ts1, st1, wv, trk, lab, out);
     } else {
-      if (mine) occupancy_evaluate<S, true, false>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab, out);
+      if (mine) occupancy_evaluate<S, true, false>(st, occ_threshold, remark, lv, smax, ts1, st1, wv, trk, lab, out);
     }
   } else {
-    if (mine) occupancy_evaluate<S, false>(st, occ_threshold, lv, smax, ts1, st1, wv, trk, lab, out);
+    if (mine) occupancy_evaluate<S, false>(st, occ_threshold, remark, lv, smax, ts1, st1, wv, trk, lab, out);
   }
 }
 
@@ -427,27 +427,81 @@ constexpr int OCC_VPT = 8;  // consecutive voxels of one thread: one 16-byte loa
 constexpr int OCC_TILE = TPB * OCC_VPT;  // voxels of one workgroup
 static_assert(OCC_TILE == (1 << TILE_SHIFT), "one workgroup per tile of State::tile_dirty");
 
-// (told to fit 7 waves per SIMD the compiler allocates 72 registers without spills at S <= 8 - 76 left alone, 6 waves)
-#ifndef SDM_OCC_INFRAME_WAVES
-#define SDM_OCC_INFRAME_WAVES 7
+// Which tiles?  The launch has OCC_GRID workgroups whatever the map's size, and every one of them reads the whole array of
+// tile marks (8 KB for 256^3 voxels, from L2), counts the tiles that carry this sweep's epoch and takes the b-th, the
+// (b + OCC_GRID)-th, ... of them: a few hundred tiles of a frame are then one tile per workgroup, all of them resident at
+// once, and the workgroups without a tile leave after that scan.  (Round 2/3 launched one workgroup per tile - 8192 of
+// which 7600 left after one byte - and spent 13 of the launch's 22 us on dispatching them; several tiles per workgroup
+// at fixed positions were measured too: tiles in need come in clusters, 35-61 us.)  The marks are never cleared
+// (mark_tile), so the scan sees the same array in every workgroup.  Maps with more than 64 * TPB tiles: one workgroup
+// per tile as before (seg = 0).
+#ifndef SDM_OCC_GRID
+#define SDM_OCC_GRID 1024
 #endif
+constexpr uint32_t OCC_GRID = SDM_OCC_GRID;
+constexpr uint32_t OCC_SEG_MAX = 64;  // tile marks per thread of the scan (one 64-bit mask)
+
 template <int S>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? SDM_OCC_INFRAME_WAVES : 4, S <= 8 ? SDM_OCC_INFRAME_WAVES : 4))) void k_occupancy(Dims d, float occ_threshold, State st, Counters *cnt) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_occupancy(Dims d, float occ_threshold, State st, Counters *cnt,
+                                                                                             const FrameArgs *__restrict__ fa, uint32_t n_tiles, uint32_t seg) {
   __shared__ uint16_t live_list[OCC_TILE];
   __shared__ uint32_t n_live;
-  const uint32_t blk0 = blockIdx.x * OCC_TILE;
-  // a tile nobody wrote to and no stamp changed in since the last sweep: every result entry of it stands
+  __shared__ uint32_t wave_total[TPB / 64];
+  __shared__ uint32_t sel_tile;
   DBG_LANE0(5, 0);
-  if (st.tile_dirty[blockIdx.x] == 0) {
+  const uint32_t epoch = fa->f.epoch, remark = next_epoch(epoch);
+  // ---- the tiles this sweep has to look into: this thread's stretch of the marks as a bit mask, ranks by a block scan
+  unsigned long long mask = 0;
+  uint32_t my_rank = 0, n_dirty = 0;
+  if (seg) {
+    const uint32_t t0 = threadIdx.x * seg;
+    for (uint32_t j = 0; j < seg; j += 16) {
+      if (t0 + j >= n_tiles) break;
+      const v4u w = *reinterpret_cast<const v4u *>(st.tile_dirty + t0 + j);  // (the array is padded to whole stretches)
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (((ww[q >> 2] >> (8 * (q & 3))) & 0xffu) == epoch && t0 + j + q < n_tiles) mask |= 1ull << (j + q);
+    }
+    const uint32_t mine = (uint32_t)__popcll(mask);
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if ((threadIdx.x & 63u) >= (uint32_t)off) inc += t;
+    }
+    if ((threadIdx.x & 63u) == 63u) wave_total[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    my_rank = inc - mine;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) {
+      if ((uint32_t)w < (threadIdx.x >> 6)) my_rank += wave_total[w];
+      n_dirty += wave_total[w];
+    }
+  } else {
+    n_dirty = st.tile_dirty[blockIdx.x] == epoch ? gridDim.x : 0;  // (rank = tile: the loop below runs once, for this tile)
+  }
+  if (blockIdx.x >= n_dirty) {
     DBG_LANE0(5, 1);
     return;
   }
-  if (threadIdx.x == 0) n_live = 0;
-  __syncthreads();  // every wave has read the byte
-  if (threadIdx.x == 0) {
-    st.tile_dirty[blockIdx.x] = 0;  // phase 2 may set it again
-    atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep_tiles, 1u);
+ for (uint32_t r = blockIdx.x; r < n_dirty; r += gridDim.x) {
+  uint32_t tile = blockIdx.x;
+  if (seg) {
+    if (r >= my_rank && r < my_rank + (uint32_t)__popcll(mask)) {
+      unsigned long long m = mask;
+      for (uint32_t k = my_rank; k < r; ++k) m &= m - 1ull;  // drop the set bits below the wanted one
+      sel_tile = threadIdx.x * seg + (uint32_t)__builtin_ctzll(m);
+    }
+    if (threadIdx.x == 0) n_live = 0;
+    __syncthreads();
+    tile = sel_tile;
+  } else {
+    if (threadIdx.x == 0) n_live = 0;
+    __syncthreads();
   }
+  const uint32_t blk0 = tile * OCC_TILE;
+  if (threadIdx.x == 0) atomicAdd(&cnt->shard[tile & (VIS_SHARDS - 1)].sweep_tiles, 1u);
   const uint32_t lv0 = blk0 + threadIdx.x * OCC_VPT;  // v_count is a multiple of 8: whole groups only
   if (lv0 < d.v_count) {
     uint16_t t0v[OCC_VPT];
@@ -503,7 +557,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? SD
   }
   __syncthreads();
   const uint32_t nl = n_live;
-  if (threadIdx.x == 0 && nl) atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep, nl);
+  if (threadIdx.x == 0 && nl) atomicAdd(&cnt->shard[tile & (VIS_SHARDS - 1)].sweep, nl);
   for (uint32_t k = threadIdx.x; k < nl; k += TPB) {
     const uint32_t lv = blk0 + live_list[k];
     const size_t base = (size_t)lv * S;
@@ -520,9 +574,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? SD
     // (latency-bound here, not issue-bound: the general version only - the plain one would cost registers, i.e.
     // resident workgroups, i.e. dispatch time of the many workgroups that leave at once)
     sdm_voxel_result out;
-    occupancy_evaluate<S, false>(st, occ_threshold, lv, stamp_max(st, rx, ry, rz), ts1, st1, wv, trk, lab, out);
+    occupancy_evaluate<S, false>(st, occ_threshold, remark, lv, stamp_max(st, rx, ry, rz), ts1, st1, wv, trk, lab, out);
     store_result(st.res + lv, out);
   }
+  __syncthreads();  // the list and the selection are reused by the next tile of this workgroup
+ }
   DBG_LANE0(5, 3);
 }
 
@@ -579,7 +635,7 @@ __device__ __forceinline__ void occ_scan_fetch(const Dims &d, const State &st, u
 // left alone it takes 91, i.e. 5 resident workgroups per CU instead of 8 - this launch lives on resident workgroups)
 template <int S>
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 : 4, S <= 8 ? 8 : 4))) void k_occupancy_scan(Dims d, float occ_threshold, State st, Counters *cnt,
-                                                        unsigned long long *__restrict__ need, uint32_t n_tiles) {
+                                                        unsigned long long *__restrict__ need, uint32_t n_tiles, uint32_t remark) {
   // the tile's results, 64 bytes (8 voxels) per thread; the 16-byte pieces of a row are swizzled so that neither the
   // row-wise writes nor the lane-linear reads run into bank conflicts
   __shared__ v4u res_stage[TPB * 4];
@@ -601,10 +657,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 
   __syncthreads();
   {
     const uint32_t blk0 = tile * OCC_TILE;
-    if (tid == 0) {
-      st.tile_dirty[tile] = 0;  // the evaluation may set it again
-      atomicAdd(&cnt->shard[tile & (VIS_SHARDS - 1)].sweep_tiles, 1u);
-    }
+    if (tid == 0) atomicAdd(&cnt->shard[tile & (VIS_SHARDS - 1)].sweep_tiles, 1u);
     const uint32_t lv0 = blk0 + tid * OCC_VPT;  // v_count is a multiple of 8: whole groups only
     const bool in_range = lv0 < d.v_count;
     v2u outw[OCC_VPT];
@@ -690,7 +743,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 
         voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
         sdm_voxel_result out;
         // (the general version only: the plain one next to it costs registers and was measured to gain nothing here)
-        occupancy_evaluate<S, false>(st, occ_threshold, lv, stamp_max(st, rx, ry, rz), ts1, st1, wv, trk, lab, out);
+        occupancy_evaluate<S, false>(st, occ_threshold, remark, lv, stamp_max(st, rx, ry, rz), ts1, st1, wv, trk, lab, out);
         v2u o;
         __builtin_memcpy(&o, &out, 8);
         *stage_slot(tv) = o;
@@ -715,7 +768,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 
 
 template <int S>
 __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_threshold, State st,
-                                                         const unsigned long long *__restrict__ need) {
+                                                         const unsigned long long *__restrict__ need, uint32_t remark) {
   constexpr int REC = 10 * S;                    // bytes of one record
   constexpr int PIECES = OCC_CHUNK * REC / 16;   // 16-byte pieces of one chunk of records
   constexpr int PPL = (PIECES + 63) / 64;
@@ -812,7 +865,7 @@ __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_thres
     }
     // the evaluation runs on registers only; the two chunks behind this one are landing meanwhile
     sdm_voxel_result out;
-    occupancy_evaluate_wave<S>(st, occ_threshold, mine, lv, smk, ts1, st1, wv, trk, lab, out);
+    occupancy_evaluate_wave<S>(st, occ_threshold, remark, mine, lv, smk, ts1, st1, wv, trk, lab, out);
     if (mine) store_result(st.res + lv, out);
     // the next chunk moves into the stage (its loads have had two evaluations' time) and the loads of the third start
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1199,7 +1252,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   if (!flag) {
     if (im_ok && im_z <= im_depth) {
       st.vts[lv] = (uint16_t)f.gts;
-      mark_tile(st, lv);
+      mark_tile(st, lv, f.epoch);
     }
     return;
   }
@@ -1280,7 +1333,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   bool stamped = observed;
   if (!observed && valid_n == 0) stamped = im_ok && im_z <= im_depth;
   if (stamped) st.vts[lv] = (uint16_t)f.gts;
-  if (dirty || wrote_free || stamped) mark_tile(st, lv);
+  if (dirty || wrote_free || stamped) mark_tile(st, lv, f.epoch);
 }
 
 // Three phases per workgroup round.  Only about a third of the voxels of the frustum's index box were reached, and testing
@@ -1432,7 +1485,7 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
     if (code[j] == 0xffffffffu || flg[j]) continue;
     if (imz[j] <= imd[j]) {  // (imd = 0 where the corner does not project into the image: z >= depth_min > 0)
       st.vts[lvv[j]] = (uint16_t)f.gts;
-      mark_tile(st, lvv[j]);
+      mark_tile(st, lvv[j], f.epoch);
     }
   }
   __syncthreads();
@@ -1978,7 +2031,7 @@ __global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, St
       st.w[rec_index(li, d.p_n, REC_W)] = my_w * (a * flt.p_detect + 1.f - flt.p_detect);
       st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_UPDATED;
       st.vflag[li >> d.p_n] = VF_DIRTY;
-      mark_tile(st, li >> d.p_n);
+      mark_tile(st, li >> d.p_n, f.epoch);
       st.ts[rec_index(li, d.p_n, REC_TS)] = (uint16_t)f.gts;
       if (!flt.independent) {
         uint32_t nf = right_id ? 0u : (fc < 5u ? fc + 1u : fc);
@@ -2300,7 +2353,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
     birth_replay_sequential<S>(d, f, flt, st, sc, skey, sval, total, t, v, smax, ns, nr);
     if (ns || nr) {
       st.vflag[v - d.v_begin] = VF_DIRTY;
-      mark_tile(st, v - d.v_begin);
+      mark_tile(st, v - d.v_begin, f.epoch);
     }
     if (ns) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].birth, ns);
     if (nr) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].resample, nr);
@@ -2414,7 +2467,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   // same-address atomics retire one at a time: counters every wave bumps are sharded by block
   if (n_success || n_resamp) {
     st.vflag[v - d.v_begin] = VF_DIRTY;
-    mark_tile(st, v - d.v_begin);
+    mark_tile(st, v - d.v_begin, f.epoch);
   }
   if (n_success) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].birth, n_success);
   if (n_resamp) atomicAdd(&sc.cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].resample, n_resamp);
@@ -2777,13 +2830,24 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s, bool fresh) {
     default: hipLaunchKernelGGL(kernel<16>, grid, dim3(TPB), 0, s, __VA_ARGS__); break;            \
   }
 
-void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, hipStream_t s) {
+// remark = the epoch a sweep marks the tiles with that it has to see again (non-incremental sweeps: given by the host,
+// they also run outside frames; the in-frame sweep derives it from the frame block, which also works inside a graph)
+size_t tile_mark_bytes(const Dims &d) {
+  const size_t n_tiles = blocks_for(d.v_count, OCC_TILE);
+  return std::max<size_t>(n_tiles, (size_t)TPB * OCC_SEG_MAX) + 16;
+}
+void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, const FrameArgs *fa, uint32_t remark,
+                      hipStream_t s) {
   dim3 grid(blocks_for(d.v_count, OCC_TILE));
   if (all_dirty) {
-    SDM_DISPATCH_S(k_occupancy_scan, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, grid.x);
-    SDM_DISPATCH_S(k_occupancy_dense, grid, s, d, flt.occ_threshold, st, st.occ_need);
+    SDM_DISPATCH_S(k_occupancy_scan, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, grid.x, remark);
+    SDM_DISPATCH_S(k_occupancy_dense, grid, s, d, flt.occ_threshold, st, st.occ_need, remark);
   } else {
-    SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st, cnt);
+    const uint32_t n_tiles = grid.x;
+    // marks per thread of the tile scan, in whole 16-byte loads; 0: too many tiles for one workgroup to scan
+    const uint32_t seg = n_tiles <= TPB * OCC_SEG_MAX ? ((n_tiles + TPB - 1) / TPB + 15u) / 16u * 16u : 0u;
+    if (seg) grid = dim3(std::min<uint32_t>(OCC_GRID, n_tiles));
+    SDM_DISPATCH_S(k_occupancy, grid, s, d, flt.occ_threshold, st, cnt, fa, n_tiles, seg);
   }
 }
 

@@ -172,6 +172,7 @@ struct sdm_map {
   int restamped[3]{};        // slabs re-stamped by the last frame's ring shift, per axis
   bool stamps_dirty = true;  // device copy of the stamp arrays needs a full upload
   bool sweep_all = true;     // the next occupancy sweep evaluates every voxel that holds something, changed or not
+  uint32_t sweep_epoch = 1;  // the number the next sweep looks for in State::tile_dirty (mark_tile): advanced by every sweep issued
 
   // owned device buffers for inputs
   float *d_depth = nullptr;
@@ -430,6 +431,7 @@ void sync_frame_scalars(sdm_map *m) {
     m->f.center[a] = m->map_center[a];
   }
   m->f.gts = m->global_time_stamp;
+  m->f.epoch = m->sweep_epoch;
 }
 
 sdm_status upload_stamps(sdm_map *m) {
@@ -577,7 +579,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->st.status = m->st.rec + 9 * (size_t)d.S;
   A(m->st.vts, d.v_count);
   A(m->st.vflag, d.v_count);
-  A(m->st.tile_dirty, (d.v_count >> TILE_SHIFT) + 1);
+  A(m->st.tile_dirty, tile_mark_bytes(d));
   A(m->st.occ_need, ((size_t)d.v_count + 63) / 64 + 32);
   A(m->st.owner, n_slots);
   A(m->st.owner_flag, (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK);
@@ -1149,8 +1151,10 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
   stage_mark(m, 6);
   if (stage_done(stop_after, 6)) return SDM_OK;
   if (!(flags & SDM_SKIP_OCCUPANCY)) {
-    launch_occupancy(d, m->flt, m->st, m->sc.cnt, m->sweep_all ? 1 : 0, s);
+    // (under capture nothing runs: the frame the graph is then launched for advances the epoch)
+    launch_occupancy(d, m->flt, m->st, m->sc.cnt, m->sweep_all ? 1 : 0, m->sc.fa, next_epoch(m->f.epoch), s);
     m->sweep_all = false;
+    if (!m->capturing) m->sweep_epoch = next_epoch(m->f.epoch);
   }
   stage_mark(m, 7);
   return SDM_OK;
@@ -1240,6 +1244,7 @@ sdm_status graph_launch(sdm_map *m) {
   m->cur_cloud = m->fa.cloud;
   m->state_event_valid = false;  // ev_state was not recorded: the next plain frame forks from its own start
   m->sweep_all = false;
+  m->sweep_epoch = next_epoch(m->f.epoch);
   m->n_graph_frames++;
   return SDM_OK;
 }
@@ -1300,7 +1305,7 @@ sdm_status pieces_capture(sdm_map *m) {
   if (rc == SDM_OK)
     rc = capture(m->stream, 4, [&](hipStream_t st) {
       launch_birth_replay(d, m->flt, m->st, m->sc, m->birth_which, false, st);
-      launch_occupancy(d, m->flt, m->st, m->sc.cnt, 0, st);
+      launch_occupancy(d, m->flt, m->st, m->sc.cnt, 0, m->sc.fa, 0, st);
     });
   m->graph_flt = m->flt;
   return rc;
@@ -1328,6 +1333,7 @@ sdm_status pieces_launch(sdm_map *m) {
   m->cur_cloud = m->fa.cloud;
   m->state_event_valid = false;
   m->sweep_all = false;
+  m->sweep_epoch = next_epoch(m->f.epoch);
   m->n_graph_frames++;
   return SDM_OK;
 }
@@ -2157,9 +2163,10 @@ sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms) {
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a));
   HIP_TRY(hipEventCreate(&b));
-  launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->stream);  // warm-up; all_dirty: the full evaluation every time
+  // (what these sweeps have to see again, the next frame's sweep has to see: marked with its epoch)
+  launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->sc.fa, m->sweep_epoch, m->stream);  // warm-up; all_dirty: the full evaluation every time
   HIP_TRY(hipEventRecord(a, m->stream));
-  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->stream);
+  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->sc.fa, m->sweep_epoch, m->stream);
   HIP_TRY(hipEventRecord(b, m->stream));
   HIP_TRY(hipEventSynchronize(b));
   float ms = 0.f;

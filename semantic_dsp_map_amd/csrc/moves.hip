@@ -315,7 +315,7 @@ __device__ __forceinline__ void move_store(const Dims &d, const Frame &f, const 
   const uint16_t powner = ms.track[obj];
   st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_INVALID;  // deleteParticleByIndex
   st.vflag[li >> d.p_n] = VF_DIRTY;
-  mark_tile(st, li >> d.p_n);
+  mark_tile(st, li >> d.p_n, f.epoch);
   if (!alias) st.owner[li] = OWNER_NONE;  // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
   uint32_t rx, ry, rz;
   uint32_t v = global_pos_to_voxel(d, f, nx, ny, nz, rx, ry, rz);
@@ -652,6 +652,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
     sc.cur->move_cursor = (int32_t)(c % flt.noise_n);
   }
   const uint32_t n_vox = sc.cnt->n_move_voxels;
+  const uint32_t epoch = sc.fa->f.epoch;
   const uint32_t stride = gridDim.x * blockDim.x;
   __shared__ uint32_t n_ok_block;  // (statistic: one global atomic per workgroup, not per voxel)
   if (threadIdx.x == 0) n_ok_block = 0;
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
     DBGM(1, 3, n_ok);
     if (n_ok) {
       st.vflag[lv] = VF_DIRTY;
-      mark_tile(st, lv);
+      mark_tile(st, lv, epoch);
       atomicAdd(&n_ok_block, n_ok);
     }
   }
@@ -761,6 +762,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
 __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const FrameArgs *__restrict__ fa, int p_n) {
   const int n = fa->n_remove;
   if (n <= 0) return;  // nothing to wipe in this frame
+  const uint32_t epoch = fa->f.epoch;
   const uint16_t *__restrict__ tracks = fa->remove;
   if (blockIdx.x == 0) {  // older memberships of the removed objects (State::alias)
     const uint32_t na = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
@@ -771,7 +773,7 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
         if (tracks[q] == trk) {
           st.status[rec_index(st.alias[2 + 2 * k], p_n, REC_STATUS)] = ST_INVALID;
           st.vflag[st.alias[2 + 2 * k] >> p_n] = VF_DIRTY;
-          mark_tile(st, st.alias[2 + 2 * k] >> p_n);
+          mark_tile(st, st.alias[2 + 2 * k] >> p_n, epoch);
           st.alias[3 + 2 * k] = OWNER_NONE;
           break;
         }
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
         if (tracks[k] == o) {
           st.status[rec_index(i, p_n, REC_STATUS)] = ST_INVALID;
           st.vflag[i >> p_n] = VF_DIRTY;
-          mark_tile(st, i >> p_n);
+          mark_tile(st, i >> p_n, epoch);
           st.owner[i] = OWNER_NONE;
           break;
         }

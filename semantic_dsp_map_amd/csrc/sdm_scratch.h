@@ -145,7 +145,9 @@ struct FrameBeginLaunch {
   static const void *kernel();
 };
 void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s);
-void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, hipStream_t s);
+void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, const FrameArgs *fa, uint32_t remark,
+                      hipStream_t s);
+size_t tile_mark_bytes(const Dims &d);  // State::tile_dirty, padded for the sweep's tile scan
 void launch_frustum(const Dims &d, const Scratch &sc, hipStream_t s);
 // visibility + binning; its last kernel also classifies the pixels for launch_ck (same ck_out / finish)
 void launch_visibility(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
