@@ -413,8 +413,8 @@ __device__ __forceinline__ int occupancy_classify(uint32_t t0, uint32_t flag, ui
   return 2;
 }
 
-// In-frame sweep.  One workgroup per tile of 2^TILE_SHIFT voxels; a tile whose State::tile_dirty byte is 0 (nothing in
-// it was written or stamped since the last sweep) is left after one load.  Otherwise two phases.  Phase 1 streams the
+// In-frame sweep.  A workgroup takes one tile of 2^TILE_SHIFT voxels that carries this sweep's mark (something in it was
+// written or stamped since the last sweep; how the tiles are dealt out: below).  Two phases per tile.  Phase 1 streams the
 // voxel stamps and flag bytes (OCC_VPT consecutive voxels per thread, everything requested before the first value is
 // looked at) and finishes every voxel that is unobserved, empty or unchanged - the vast majority - from 3 bytes; a
 // result entry is written only when it does not already hold that constant (bits 2-3 of the flag byte).  The others are
@@ -425,15 +425,15 @@ __device__ __forceinline__ int occupancy_classify(uint32_t t0, uint32_t flag, ui
 // and the launch - 8192 workgroups of which most leave at once - went from 22 to 33 us.)
 constexpr int OCC_VPT = 8;  // consecutive voxels of one thread: one 16-byte load of stamps, one 8-byte load of flags
 constexpr int OCC_TILE = TPB * OCC_VPT;  // voxels of one workgroup
-static_assert(OCC_TILE == (1 << TILE_SHIFT), "one workgroup per tile of State::tile_dirty");
+static_assert(OCC_TILE == (1 << TILE_SHIFT), "a workgroup takes one tile of State::tile_dirty at a time");
 
 // Which tiles?  The launch has OCC_GRID workgroups whatever the map's size, and every one of them reads the whole array of
 // tile marks (8 KB for 256^3 voxels, from L2), counts the tiles that carry this sweep's epoch and takes the b-th, the
 // (b + OCC_GRID)-th, ... of them: a few hundred tiles of a frame are then one tile per workgroup, all of them resident at
 // once, and the workgroups without a tile leave after that scan.  (Round 2/3 launched one workgroup per tile - 8192 of
 // which 7600 left after one byte - and spent 13 of the launch's 22 us on dispatching them; several tiles per workgroup
-// at fixed positions were measured too: tiles in need come in clusters, 35-61 us.)  The marks are never cleared
-// (mark_tile), so the scan sees the same array in every workgroup.  Maps with more than 64 * TPB tiles: one workgroup
+// at fixed positions were measured too: tiles in need come in clusters, 35-61 us.)  Nobody writes the array of this
+// sweep's epoch while the sweep runs (mark_tile), so the scan sees the same marks in every workgroup.  Maps with more than 64 * TPB tiles: one workgroup
 // per tile as before (seg = 0).
 #ifndef SDM_OCC_GRID
 #define SDM_OCC_GRID 1024
@@ -441,8 +441,9 @@ static_assert(OCC_TILE == (1 << TILE_SHIFT), "one workgroup per tile of State::t
 constexpr uint32_t OCC_GRID = SDM_OCC_GRID;
 constexpr uint32_t OCC_SEG_MAX = 64;  // tile marks per thread of the scan (one 64-bit mask)
 
+// (OCC_GRID workgroups = 4 waves per SIMD: 128 registers are free; S = 16 takes more and runs at 2)
 template <int S>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_occupancy(Dims d, float occ_threshold, State st, Counters *cnt,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 4 : 2, S <= 8 ? 4 : 2))) void k_occupancy(Dims d, float occ_threshold, State st, Counters *cnt,
                                                                                              const FrameArgs *__restrict__ fa, uint32_t n_tiles, uint32_t seg) {
   __shared__ uint16_t live_list[OCC_TILE];
   __shared__ uint32_t n_live;
@@ -453,11 +454,12 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // ---- the tiles this sweep has to look into: this thread's stretch of the marks as a bit mask, ranks by a block scan
   unsigned long long mask = 0;
   uint32_t my_rank = 0, n_dirty = 0;
+  const uint8_t *__restrict__ marks = tile_marks(st, epoch);  // (what this sweep marks goes into the other array)
   if (seg) {
     const uint32_t t0 = threadIdx.x * seg;
     for (uint32_t j = 0; j < seg; j += 16) {
       if (t0 + j >= n_tiles) break;
-      const v4u w = *reinterpret_cast<const v4u *>(st.tile_dirty + t0 + j);  // (the array is padded to whole stretches)
+      const v4u w = *reinterpret_cast<const v4u *>(marks + t0 + j);  // (the array is padded to whole stretches)
       const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
       for (int q = 0; q < 16; ++q)
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       n_dirty += wave_total[w];
     }
   } else {
-    n_dirty = st.tile_dirty[blockIdx.x] == epoch ? gridDim.x : 0;  // (rank = tile: the loop below runs once, for this tile)
+    n_dirty = marks[blockIdx.x] == epoch ? gridDim.x : 0;  // (rank = tile: the loop below runs once, for this tile)
   }
   if (blockIdx.x >= n_dirty) {
     DBG_LANE0(5, 1);
@@ -2834,7 +2836,7 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s, bool fresh) {
 // they also run outside frames; the in-frame sweep derives it from the frame block, which also works inside a graph)
 size_t tile_mark_bytes(const Dims &d) {
   const size_t n_tiles = blocks_for(d.v_count, OCC_TILE);
-  return std::max<size_t>(n_tiles, (size_t)TPB * OCC_SEG_MAX) + 16;
+  return (std::max<size_t>(n_tiles, (size_t)TPB * OCC_SEG_MAX) + 16 + 15) / 16 * 16;  // one of the two arrays
 }
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, const FrameArgs *fa, uint32_t remark,
                       hipStream_t s) {

@@ -32,20 +32,17 @@ thread_local std::string g_last_error;
 // the process), so it is set when this library is loaded - unless the user has set it, or HIP is already up (then
 // nothing changes).
 //
-// Hardware queues: a map issues a frame on five streams (main chain, frustum chain, birth candidates, member counts,
-// uploads), and frames issued back to back take either 0.270 or 0.295 ms on C3 - the same in every frame of one set of
-// streams, different from one set to the next (and from process to process); the per-stage times with a synchronisation
-// after each stage are the same in both modes, so what differs is how well the next frame's side chains run beside this
-// frame's sweep.  The runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues.  Measured on one box, 7
-// processes each: 4 queues 0.292-0.332 ms; default 1 fast run in 7; 8 queues 4 in 7; 16 queues 6-7 in 7; 32 queues 7 in 7
-// (0.270-0.272 ms).  On a second box 32 queues changed nothing (3 runs in 3 at 0.295 ms); a high-priority main stream and
-// one or two side streams instead of three did not change the odds on either.  So: no harm, sometimes the fast mode
-// every time.  Set like the variable above.
+// (Not set here: GPU_MAX_HW_QUEUES.  Frames issued back to back take either 0.270 or 0.295 ms on C3 - the same in every
+// frame of one set of streams, different from one set to the next; the per-stage times with a synchronisation after each
+// stage are the same in both modes, so what differs is how well the next frame's side chains run beside this frame's
+// sweep.  On one box 32 hardware queues instead of the default gave the fast mode in 7 processes of 7 (4 queues: 0 of 7,
+// default: 1 of 7); on a second box they changed nothing, stream creation took twice as long and a pytest process that
+// had created and destroyed ~120 maps aborted inside the runtime.  A high-priority main stream and one or two side
+// streams instead of three did not change the odds either.  tools/probes/modes.py shows the modes.)
 // (Priority 101: before the constructors that register this library's kernels with the runtime - they are what brings
 // the runtime up when nothing else in the process has, and run at the default priority.)
 __attribute__((constructor(101))) void sdm_runtime_defaults() {
   setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
-  setenv("GPU_MAX_HW_QUEUES", "32", 0);
 }
 
 // How a plain frame is issued.  Measured on MI355X / ROCm 7.2 (host time inside sdm_update per frame; GPU time per
@@ -579,7 +576,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->st.status = m->st.rec + 9 * (size_t)d.S;
   A(m->st.vts, d.v_count);
   A(m->st.vflag, d.v_count);
-  A(m->st.tile_dirty, tile_mark_bytes(d));
+  m->st.tile_stride = (uint32_t)tile_mark_bytes(d);
+  A(m->st.tile_dirty, 2 * (size_t)m->st.tile_stride);
   A(m->st.occ_need, ((size_t)d.v_count + 63) / 64 + 32);
   A(m->st.owner, n_slots);
   A(m->st.owner_flag, (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK);

@@ -164,7 +164,8 @@ struct State {
   // entry holds right now - VR_UNOBSERVED, VR_EMPTY (the two constant results) or 0 = something else.  Together they
   // let the sweep finish an unobserved, empty or unchanged voxel from 3 bytes read and nothing written.
   uint8_t *vflag = nullptr;
-  uint8_t *tile_dirty = nullptr;  // per tile of 2^TILE_SHIFT voxels: the sweep epoch that has to look into it (mark_tile)
+  uint8_t *tile_dirty = nullptr;  // per tile of 2^TILE_SHIFT voxels: the sweep epoch that has to look into it (mark_tile); two arrays
+  uint32_t tile_stride = 0;       // bytes of one of the two
   // per chunk of 64 voxels: the voxels the non-incremental sweep's first launch left to its second (dense chunks)
   unsigned long long *occ_need = nullptr;
   uint16_t *track = nullptr;
@@ -192,11 +193,14 @@ constexpr int TILE_SHIFT = 11;
 enum : uint8_t { VF_EMPTY = 0, VF_CLEAN = 1, VF_DIRTY = 2, VF_STATE = 3, VR_UNOBSERVED = 1 << 2, VR_EMPTY = 2 << 2, VR_MASK = 3 << 2 };
 // State::tile_dirty holds, per tile, the sweep epoch in which something in the tile was last written or stamped: the
 // frame's kernels mark with the epoch of the frame's sweep (Frame::epoch), the sweep looks for exactly that number and
-// marks what it has to see again with the next one.  Nothing is ever cleared, so the workgroups of the sweep can all read
-// the whole array while others already work (k_occupancy).  Epochs run 1..255 and start over (0 = never marked): a mark
-// left from 255 sweeps ago sends the sweep through one tile in which it then finds nothing to do.
-__device__ __host__ __forceinline__ uint32_t next_epoch(uint32_t e) { return e % 255u + 1u; }
-__device__ __forceinline__ void mark_tile(const State &st, size_t lv, uint32_t epoch) { st.tile_dirty[lv >> TILE_SHIFT] = (uint8_t)epoch; }
+// marks what it has to see again with the next one.  There are two arrays, odd and even epochs: while a sweep reads the
+// marks of its epoch - every workgroup of k_occupancy reads all of them - what it has to see again goes into the other
+// array, and so do the next frame's marks; nothing is ever cleared.  Epochs run 1..254 and start over (0 = never marked;
+// an even count, so that consecutive epochs always differ in parity): a mark left from 254 sweeps ago sends the sweep
+// through one tile in which it then finds nothing to do.
+__device__ __host__ __forceinline__ uint32_t next_epoch(uint32_t e) { return e % 254u + 1u; }
+__device__ __forceinline__ uint8_t *tile_marks(const State &st, uint32_t epoch) { return st.tile_dirty + (epoch & 1u) * st.tile_stride; }
+__device__ __forceinline__ void mark_tile(const State &st, size_t lv, uint32_t epoch) { tile_marks(st, epoch)[lv >> TILE_SHIFT] = (uint8_t)epoch; }
 constexpr uint32_t ALIAS_CAP = 8192;
 
 // ObjectParticleHashMap::addParticleToObj (object_layer.h:31-33): slot li joins track's set.  li is the shard-local slot
