@@ -59,9 +59,9 @@ for t in range(10):
     span("birth_replay (heads)", b)
     o = k[5]
     early = o.copy(); early[o[:, 3] > 0] = 0
-    span("occupancy (clean tiles)", early)
+    span("occupancy (no tile)", early)
     full = o.copy(); full[:, 1] = full[:, 3]
-    span("occupancy (dirty tiles)", full)
+    span("occupancy (one tile)", full)
 
     def first_last(a, end_col=1):
         ran = a[:, 0] > 0
