@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 tag = sys.argv[1]
-KERNELS = ("k_ck_light", "k_ck_heavy", "k_weight", "k_visibility", "k_birth_replay", "k_occupancy<")
+KERNELS = ("k_ck", "k_weight", "k_visibility", "k_birth_replay", "k_occupancy<")
 SIMDS = 256 * 4
 CLOCK_MHZ = 2400.0
 
