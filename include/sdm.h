@@ -195,7 +195,15 @@ sdm_status sdm_download_pdf_table(sdm_map *m, float *table, int32_t n);
  * How the frame's ~50 kernels are issued follows the host's speed at issuing launches, measured in sdm_create
  * (sdm_stats.host_enqueue_us): launch by launch on a fast host, replayed from hipGraphs on a slow one.  The environment
  * variable SDM_GRAPH forces one way (0 launch by launch, 4 five chain graphs, 3 one chain graph, 1 one branched graph;
- * read when the map is created); the results are bit-identical. */
+ * read when the map is created), and so does sdm_set_issue_mode at any time between frames; the results are
+ * bit-identical. */
+#define SDM_ISSUE_LAUNCHES 0   /* launch by launch */
+#define SDM_ISSUE_BRANCHED 1   /* one hipGraph, frustum and birth chains as branches */
+#define SDM_ISSUE_AUTO 2       /* by the host's measured speed (the default) */
+#define SDM_ISSUE_CHAIN 3      /* one hipGraph, a chain of kernel nodes */
+#define SDM_ISSUE_PIECES 4     /* five chain hipGraphs on the frame's streams */
+/* mode: one of SDM_ISSUE_*.  Graphs captured for another mode are dropped; the next plain frame captures anew. */
+sdm_status sdm_set_issue_mode(sdm_map *m, int32_t mode);
 sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *cloud,
                       const float cam_pos[3], const float cam_q[4],
                       const sdm_object_move *moves, int32_t n_moves,

@@ -163,6 +163,7 @@ def load_library():
         "sdm_get_bins": [vp, vp, i64, C.POINTER(i64)],
         "sdm_get_extrinsic": [vp, vp],
         "sdm_time_occupancy_sweep": [vp, i32, C.POINTER(C.c_float)],
+        "sdm_set_issue_mode": [vp, i32],
         "sdm_debug_fill_dense": [vp],
         "sdm_debug_fill_dense_ex": [vp, i32],
         "sdm_test_scan": [vp, vp, i64],
@@ -407,6 +408,10 @@ class SdmMap:
 
     def set_ck_buffer(self, dev_ptr):
         _check(self.L, self.L.sdm_set_ck_buffer(self.h, _ptr(int(dev_ptr)) if dev_ptr else None), "sdm_set_ck_buffer")
+
+    def set_issue_mode(self, mode):
+        """0 launch by launch, 1 branched graph, 2 by the host's speed, 3 chain graph, 4 five chain graphs (sdm.h SDM_ISSUE_*)"""
+        _check(self.L, self.L.sdm_set_issue_mode(self.h, int(mode)), "sdm_set_issue_mode")
 
     def synchronize(self):
         _check(self.L, self.L.sdm_synchronize(self.h), "sdm_synchronize")

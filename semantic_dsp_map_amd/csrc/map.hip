@@ -1338,6 +1338,33 @@ sdm_status pieces_launch(sdm_map *m) {
 
 }  // namespace
 
+sdm_status sdm_set_issue_mode(sdm_map *m, int32_t mode) {
+  if (!m || mode < 0 || mode > 4) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  const bool use = mode == 2 ? m->enqueue_us > GRAPH_PIECES_US : mode != 0;
+  const int shape = mode == 1 ? GRAPH_BRANCHED
+                    : mode == 3 ? GRAPH_CHAIN
+                    : mode == 2 ? (m->enqueue_us > GRAPH_CHAIN_US ? GRAPH_CHAIN : GRAPH_PIECES)
+                                : GRAPH_PIECES;
+  if (shape != m->graph_shape) {
+    // the branched graph and the chain share one executable: whatever was captured for the old shape goes
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) (void)hipGraphDestroy(m->graph);
+    m->graph_exec = nullptr;
+    m->graph = nullptr;
+    m->graph_set_node = nullptr;
+    for (hipGraphExec_t &g : m->piece) {
+      if (g) (void)hipGraphExecDestroy(g);
+      g = nullptr;
+    }
+  }
+  m->graph_mode = mode;
+  m->use_graph = use;
+  m->graph_shape = shape;
+  return SDM_OK;
+}
+
 sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
                       const float cam_q[4], const sdm_object_move *moves, int32_t n_moves, const int32_t *remove_tracks,
                       int32_t n_remove, uint32_t flags, int32_t stop_after) {

@@ -84,3 +84,24 @@ def test_graph_replay_without_synchronisation(graph_mode):
     assert not rep, "\n".join(rep)
     assert g.stats()["graph_frames"] == (0 if graph_mode == "0" else 9)
     g.close()
+
+
+def test_issue_mode_switched_between_frames():
+    """sdm_set_issue_mode: the ways to issue a frame taken in turn inside one clip, three frames each (the graphs of the
+    mode before are dropped, the next plain frame captures anew) - the map stays bit-exact against the oracle."""
+    cfg, params, frames = synth.make_frames("T0", 16, "vkitti2", n_dynamic=3)
+    o, g = pu.make_pair(cfg, params, synth.noise_table())
+    S = 1 << cfg["p_n"]
+    modes = [0, 4, 3, 1, 0]
+    for t, (depth, cloud, pos, q, moves) in enumerate(frames):
+        if t % 3 == 1:
+            g.set_issue_mode(modes[(t // 3) % len(modes)])
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves, sync=True)
+        rep = pu.compare_maps(o, g, S, tag="frame %d: " % t)
+        assert not rep, "\n".join(rep)
+    st = g.stats()
+    assert st["graph_frames"] >= 6 and st["direct_frames"] >= 4, st
+    with pytest.raises(Exception):
+        g.set_issue_mode(7)
+    g.close()
