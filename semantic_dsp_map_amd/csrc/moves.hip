@@ -58,12 +58,21 @@ __device__ __forceinline__ void move_chunks_body(const uint8_t *owner_flag, uint
                                                  uint32_t *__restrict__ n_list, Cursors *cur, uint32_t *__restrict__ cnt, int n_obj,
                                                  uint32_t n_move_cnt, uint32_t *__restrict__ alias, uint8_t *owner_flag_w) {
   __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t running;
+  __shared__ uint32_t running, alias_live;
   if (n_obj <= 0) return;  // no object moves in this frame
-  uint32_t *cnt_tail = cnt + (n_move_cnt - 1);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  constexpr uint32_t PER = 32;
+  // the first 32 K flags are requested before anything else is looked at (the table of older memberships below is a
+  // dependent fetch of its own, and nearly always empty); if it does set flags, they are read again
+  const bool early = threadIdx.x * PER + PER <= n_flags && ((size_t)(owner_flag + threadIdx.x * PER) & 15) == 0;
+  uint4 ea = make_uint4(0, 0, 0, 0), eb = make_uint4(0, 0, 0, 0);
+  if (early) {
+    ea = *reinterpret_cast<const uint4 *>(owner_flag + threadIdx.x * PER);
+    eb = *reinterpret_cast<const uint4 *>(owner_flag + threadIdx.x * PER + 16);
+  }
   if (threadIdx.x == 0) {
     running = 0;
+    alias_live = 0;
     cur->move_list_overflow = 0;
     // extra set memberships (State::alias): drop the deleted entries, and make sure the chunks of the live ones are
     // on the list even if no slot of theirs has a primary owner any more
@@ -79,6 +88,7 @@ __device__ __forceinline__ void move_chunks_body(const uint8_t *owner_flag, uint
       alias[3 + 2 * keep] = trk;
       ++keep;
       owner_flag_w[idx / OWNER_CHUNK] = 1;
+      alias_live = 1;
     }
     for (uint32_t k = keep; k < na; ++k) {
       alias[2 + 2 * k] = INVALID_INDEX;
@@ -88,13 +98,24 @@ __device__ __forceinline__ void move_chunks_body(const uint8_t *owner_flag, uint
     __threadfence();
   }
   __syncthreads();
-  constexpr uint32_t PER = 32;
+  const bool reuse_early = alias_live == 0;
   for (uint32_t tile = 0; tile < n_flags; tile += 1024 * PER) {
     const uint32_t first = tile + threadIdx.x * PER;
     uint32_t mask = 0;  // bit j: flag first + j is set
     if (first + PER <= n_flags && ((size_t)(owner_flag + first) & 15) == 0) {
-      const uint4 a = *reinterpret_cast<const uint4 *>(owner_flag + first);
-      const uint4 b4 = *reinterpret_cast<const uint4 *>(owner_flag + first + 16);
+      uint4 a = ea, b4 = eb;
+      if (tile != 0) {
+        a = *reinterpret_cast<const uint4 *>(owner_flag + first);
+        b4 = *reinterpret_cast<const uint4 *>(owner_flag + first + 16);
+      } else if (!reuse_early) {  // thread 0 has just set flags: past this CU's L1, which holds the lines as they were
+        uint32_t *wa = reinterpret_cast<uint32_t *>(&a), *wb = reinterpret_cast<uint32_t *>(&b4);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(owner_flag + first);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          wa[q] = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          wb[q] = __hip_atomic_load(src + 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
       const uint32_t w[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
       for (int q = 0; q < 8; ++q)
@@ -135,8 +156,13 @@ __device__ __forceinline__ void move_chunks_body(const uint8_t *owner_flag, uint
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    *n_list = running < MV_LIST_CAP ? running : MV_LIST_CAP;
-    *cnt_tail = 0;  // terminator of the count matrix (becomes the grand total after the scan)
+    // The count matrix has one row per object and one column per listed chunk - its row length is the list's length,
+    // not the list's capacity: the scan that turns it into offsets covers n_obj x n + 1 elements (2 K at the benchmark's
+    // 6 objects x 347 chunks, where rows of MV_LIST_CAP were 49 K, most of them zeros somebody had to write first).
+    const uint32_t nl = running < MV_LIST_CAP ? running : MV_LIST_CAP;
+    n_list[0] = nl;
+    n_list[2] = (uint32_t)n_obj * nl + 1u;   // what the scan covers (read on the device)
+    cnt[(size_t)n_obj * nl] = 0;             // terminator of the count matrix (becomes the grand total after the scan)
   }
 }
 __global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *owner_flag, uint32_t n_flags,
@@ -158,7 +184,7 @@ __global__ __launch_bounds__(1024) void k_move_chunks_v(const uint8_t *owner_fla
   move_chunks_body(owner_flag, n_flags, list, n_list, cur, cnt, src.n_obj, src.n_move_cnt, alias, owner_flag_w);
 }
 
-// pass 1: per-chunk, per-object member counts.  cnt[obj * MV_LIST_CAP + list position].  A flagged chunk that turns out
+// pass 1: per-chunk, per-object member counts.  cnt[obj * n + list position], n = chunks on the list.  A flagged chunk that turns out
 // to hold no owner any more clears its flag.
 __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__ owner, size_t n_slots,
                                                     const FrameArgs *__restrict__ fa, uint32_t *__restrict__ cnt,
@@ -172,26 +198,25 @@ __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__
   const MoveSet &ms = fa->ms;
   const uint32_t n = *n_list;
   if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms.track[threadIdx.x] : OWNER_NONE;
-  for (uint32_t pos = blockIdx.x; pos < MV_LIST_CAP; pos += gridDim.x) {
-    if (pos >= n) {  // unused tail of the count matrix
-      if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * MV_LIST_CAP + pos] = 0;
-      continue;
-    }
+  for (uint32_t pos = blockIdx.x; pos < n; pos += gridDim.x) {
     __syncthreads();
     if (threadIdx.x < MAX_MOVE_OBJECTS) c[threadIdx.x] = 0;
     if (threadIdx.x == 0) any_owner = 0;
     __syncthreads();
     const uint32_t chunk = list[pos];
     size_t base = (size_t)chunk * MV_CHUNK;
-#pragma unroll 4
+    // (all 16 owner loads of the thread in flight, then the counting: four at a time were four dependent round trips)
+    uint16_t ow[MV_ITEMS];
+#pragma unroll
     for (int r = 0; r < MV_ITEMS; ++r) {
-      size_t i = base + (size_t)r * TPB + threadIdx.x;
-      if (i < n_slots) {
-        uint16_t ow = owner[i];
-        if (ow != OWNER_NONE) any_owner = 1;
-        uint8_t o = obj_of(ow, tracks, n_obj);
-        if (o != 0xFF) atomicAdd(&c[o], 1u);
-      }
+      const size_t i = base + (size_t)r * TPB + threadIdx.x;
+      ow[r] = i < n_slots ? owner[i] : OWNER_NONE;
+    }
+#pragma unroll
+    for (int r = 0; r < MV_ITEMS; ++r) {
+      if (ow[r] != OWNER_NONE) any_owner = 1;
+      const uint8_t o = obj_of(ow[r], tracks, n_obj);
+      if (o != 0xFF) atomicAdd(&c[o], 1u);
     }
     {  // older memberships the reference's sets still hold (State::alias; nearly always none)
       const uint32_t na = alias[0] < ALIAS_CAP ? alias[0] : ALIAS_CAP;
@@ -204,7 +229,7 @@ __global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__
       }
     }
     __syncthreads();
-    if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * MV_LIST_CAP + pos] = c[threadIdx.x];
+    if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * n + pos] = c[threadIdx.x];
     if (threadIdx.x == 0 && any_owner == 0) owner_flag[chunk] = 0;
   }
 }
@@ -238,7 +263,8 @@ __global__ void k_move_local_counts(const uint32_t *__restrict__ offs, int32_t *
   const uint32_t world = sc.halo_world;
   if (sc.halo_send && (uint32_t)k < world) *reinterpret_cast<uint32_t *>(sc.halo_send + (size_t)k * halo_segment_bytes(sc.halo_cap)) = 0;
   if (k >= HALO_OBJ) return;
-  counts_local[k] = k < n_obj ? (int32_t)(offs[(size_t)(k + 1) * MV_LIST_CAP] - offs[(size_t)k * MV_LIST_CAP]) : 0;
+  const uint32_t nl = *sc.mv_nlist;  // row length of the count matrix
+  counts_local[k] = k < n_obj ? (int32_t)(offs[(size_t)(k + 1) * nl] - offs[(size_t)k * nl]) : 0;
 }
 
 constexpr uint32_t MV_NIL = 0xffffffffu;
@@ -459,7 +485,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
       for (int k = 0; k < (int)threadIdx.x; ++k)
         for (int r = 0; r < world; ++r) run += (uint32_t)counts_all[r * HALO_OBJ + k];
       for (int r = 0; r < rank; ++r) run += (uint32_t)counts_all[r * HALO_OBJ + threadIdx.x];
-      shift = run - offs[(size_t)threadIdx.x * MV_LIST_CAP];
+      shift = run - offs[(size_t)threadIdx.x * n];
     }
     e_shift[threadIdx.x] = shift;
   }
@@ -469,7 +495,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
       for (int k = 0; k < n_obj; ++k)
         for (int r = 0; r < world; ++r) total += (uint32_t)counts_all[r * HALO_OBJ + k];
     } else {
-      total = offs[(size_t)n_obj * MV_LIST_CAP];
+      total = offs[(size_t)n_obj * n];
     }
     sc.cnt->n_moved = total;
     if (total > sc.cap_move || sc.cur->move_list_overflow) sc.cnt->overflow = 1;
@@ -481,8 +507,8 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
     if (threadIdx.x == 0) block_total = 0;
     __syncthreads();
     if ((int)threadIdx.x < n_obj) {
-      uint32_t o0 = offs[(size_t)threadIdx.x * MV_LIST_CAP + pos];
-      uint32_t o1 = offs[(size_t)threadIdx.x * MV_LIST_CAP + pos + 1];  // next position (or next object's first)
+      uint32_t o0 = offs[(size_t)threadIdx.x * n + pos];
+      uint32_t o1 = offs[(size_t)threadIdx.x * n + pos + 1];  // next position (or next object's first)
       obj_base[threadIdx.x] = o0 + e_shift[threadIdx.x];
       if (o1 != o0) atomicAdd(&block_total, o1 - o0);
     }
@@ -831,7 +857,7 @@ size_t move_blocks(const Dims &d) { return ((size_t)d.v_count * d.S + MV_CHUNK -
 size_t move_count_elems() { return (size_t)MAX_MOVE_OBJECTS * MV_LIST_CAP + 1; }
 
 // The launch sequence below is the same every frame (hipGraph): kernels of a frame without moving objects / removals
-// return at once, the scan covers fa->n_move_cnt elements read on the device.
+// return at once, the scan covers n_obj x (chunks on the list) + 1 elements, a number read on the device.
 // step 1: collect every moving object's members (ascending index) and publish the per-object counts
 // by_value != nullptr: the chain runs ahead of the frame's k_frame_begin on a stream of its own; its first kernel takes
 // the frame block by value and stores it in fa_moves for the others
@@ -846,7 +872,7 @@ void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32
                        sc.mv_cnt, fa, st.alias, st.owner_flag);
   hipLaunchKernelGGL(k_move_count, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, fa, sc.mv_cnt, st.owner_flag, sc.mv_list, sc.mv_nlist,
                      st.alias);
-  exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, move_count_elems(), sc.scan_scratch_m, s, &fa->n_move_cnt);
+  exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, move_count_elems(), sc.scan_scratch_m, s, sc.mv_nlist + 2);
   // the per-object counts are only needed as a separate row when they are exchanged between shards
   if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, counts_local, sc, fa);
 }
