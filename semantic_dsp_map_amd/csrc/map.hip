@@ -66,6 +66,15 @@ constexpr double GRAPH_PIECES_US = 75.0, GRAPH_CHAIN_US = 170.0;
 constexpr int LAUNCHES_PER_FRAME = 50;
 
 __global__ void k_noop() {}
+// Do two streams of a map run side by side?  k_spin holds its stream for `ticks` of the 100 MHz wall clock and leaves the
+// clock at its start and end; k_stamp, launched right behind it on another stream, leaves the clock when it runs.
+__global__ void k_spin(unsigned long long ticks, unsigned long long *out) {
+  const unsigned long long t0 = wall_clock64();
+  out[0] = t0;
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  out[1] = wall_clock64();
+}
+__global__ void k_stamp(unsigned long long *out) { *out = wall_clock64(); }
 
 void set_error(const char *what, const char *file, int line, const char *detail) {
   char buf[512];
@@ -1337,6 +1346,27 @@ sdm_status pieces_launch(sdm_map *m) {
 }
 
 }  // namespace
+
+// Development aid (tools/probes/modes.py): a 60 us spin on the main stream, a stamp right behind it on side stream
+// `which` (0 frustum, 1 birth candidates, 2 member count).  out_us[0] = stamp - spin start, out_us[1] = spin length.
+extern "C" sdm_status sdm_debug_overlap(sdm_map *m, int32_t which, double out_us[2]) {
+  if (!m || which < 0 || which > 2 || !out_us) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  unsigned long long *d = nullptr, h[3] = {0, 0, 0};
+  HIP_TRY(hipMalloc(&d, sizeof(h)));
+  hipStream_t side = which == 0 ? m->s_frustum : (which == 1 ? m->s_birth : m->s_moves);
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  HIP_TRY(hipStreamSynchronize(side));
+  hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, m->stream, 6000ull, d);
+  hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, side, d + 2);
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  HIP_TRY(hipStreamSynchronize(side));
+  HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  out_us[0] = ((double)h[2] - (double)h[0]) / 100.0;
+  out_us[1] = ((double)h[1] - (double)h[0]) / 100.0;
+  return SDM_OK;
+}
 
 sdm_status sdm_set_issue_mode(sdm_map *m, int32_t mode) {
   if (!m || mode < 0 || mode > 4) return SDM_ERR_INVALID_ARGUMENT;

@@ -27,5 +27,14 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
         eng.update(*frames[t])
     m.synchronize()
     m.device_synchronize()
-    print("map %d: %.4f ms/frame" % (rep, (time.perf_counter() - t0) / 20 * 1e3), flush=True)
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    import ctypes as C
+    ov = []
+    if hasattr(m.L, "sdm_debug_overlap"):
+        m.L.sdm_debug_overlap.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        for which in range(3):
+            out = (C.c_double * 2)()
+            m.L.sdm_debug_overlap(m.h, which, out)
+            ov.append("%s %.0f/%.0f" % (("frustum", "birth", "moves")[which], out[0], out[1]))
+    print("map %d: %.4f ms/frame   stamp on the side stream after .. us of a .. us spin on the main stream: %s" % (rep, ms, ", ".join(ov)), flush=True)
     m.close()
