@@ -245,6 +245,38 @@ def grown_run(synth, sharded, n_grow=180, steps=20, cpu_frames=3):
     return res
 
 
+def pin_to_device_node(device):
+    """The process moves onto the NUMA node its GPU hangs off BEFORE the HIP runtime comes up in it: a frame is a chain of
+    ~50 dependent launches whose packets and completion signals live in host memory the runtime allocates where the
+    process runs; from the far socket every gap between two dependent kernels is 2-4 us longer (C3: 0.265 against 0.292 ms
+    per frame; DESIGN.md 7 "Two modes").  Which node that is only HIP knows (device ordinal -> PCI address), so a child
+    process asks the library (sdm_bind_host_thread) and this one sets its affinity from the answer.  The library does the
+    same for the thread that calls sdm_create, but by then the runtime has made its first allocations.
+    SDM_NUMA_BIND=0: leave the affinity alone.  Returns a description for the bench line."""
+    if os.environ.get("SDM_NUMA_BIND") == "0":
+        return "not pinned (SDM_NUMA_BIND=0)"
+    import subprocess
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from semantic_dsp_map_amd import binding; L = binding.load_library(); "
+            "L.sdm_bind_host_thread.restype = ctypes.c_int32; L.sdm_bind_host_thread.argtypes = [ctypes.c_int32]; "
+            "print('NODE', L.sdm_bind_host_thread(%d))" % (os.path.dirname(os.path.abspath(__file__)), device))
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout
+        node = int([l for l in out.splitlines() if l.startswith("NODE")][-1].split()[1])
+        if node < 0:
+            return "not pinned (one node, or nothing to choose)"
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return "not pinned (no allowed CPU on node %d)" % node
+        os.sched_setaffinity(0, cpus)
+        return "pinned to NUMA node %d (the GPU's), %d CPUs, before HIP initialised" % (node, len(cpus))
+    except Exception as e:  # noqa: BLE001 - the pin is an optimisation
+        return "not pinned (%s)" % type(e).__name__
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,6 +294,7 @@ def main():
     ap.add_argument("--only-grown", action="store_true", help="run nothing but the grown-map leg (development)")
     args = ap.parse_args()
 
+    host_numa = pin_to_device_node(int(os.environ.get("LOCAL_RANK", "0")))
     from semantic_dsp_map_amd import sharded, synth
 
     if args.only_stress:
@@ -531,7 +564,8 @@ def main():
                        "voxels": V, "live_particles": live, "visible_particles": n_vis,
                        "parallelism": "zslab%d" % world, "inputs": "depth + LabeledPoint image resident in HBM",
                        "render_s": round(t_render, 1),
-                       "host_enqueue_ms_per_step": round(t_enqueue * 1e3 / args.steps, 4), "launch_mode": launch_mode},
+                       "host_enqueue_ms_per_step": round(t_enqueue * 1e3 / args.steps, 4), "launch_mode": launch_mode,
+                       "host_numa": host_numa},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

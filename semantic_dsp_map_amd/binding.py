@@ -164,6 +164,7 @@ def load_library():
         "sdm_get_extrinsic": [vp, vp],
         "sdm_time_occupancy_sweep": [vp, i32, C.POINTER(C.c_float)],
         "sdm_set_issue_mode": [vp, i32],
+        "sdm_bind_host_thread": [i32],
         "sdm_debug_fill_dense": [vp],
         "sdm_debug_fill_dense_ex": [vp, i32],
         "sdm_test_scan": [vp, vp, i64],

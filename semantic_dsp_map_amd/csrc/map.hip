@@ -5,6 +5,7 @@
 // else is enqueued on one HIP stream with no host synchronisation inside a frame.
 #include <rccl/rccl.h>
 #include <rocrand/rocrand.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <chrono>
@@ -481,6 +482,64 @@ extern "C" {
 const char *sdm_last_error(void) { return g_last_error.c_str(); }
 const char *sdm_version(void) { return "libsdm_hip 0.1 (gfx950)"; }
 
+// The host thread that issues a map's frames belongs on the NUMA node the GPU hangs off.  A frame is a chain of ~50
+// dependent launches; the command processor fetches every packet and signals every completion through host memory that
+// the runtime allocates where the calling thread runs.  Measured on a two-socket MI355X box (bench.py, 8 processes each):
+// pinned to the GPU's node 0.264-0.267 ms per C3 frame (7 of 8; one 0.293), pinned to the other node 0.290-0.297 ms
+// (8 of 8), not pinned one or the other - every gap between two dependent kernels is 2-4 us longer from the far socket
+// (tools/probes/crossframe.py).  This was the "two modes" of rounds 2 and 3.
+// sdm_bind_host_thread moves the CALLING thread (and the threads it starts later) onto the device's node, within the
+// CPUs the process is allowed to use; sdm_create calls it unless SDM_NUMA_BIND=0.  Returns the node, -1 if there is
+// nothing to do (one node, no sysfs entry, no allowed CPU on that node).
+static int bind_host_thread_to(int device) {
+  char bus[32] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  for (char *c = bus; *c; ++c) *c = (char)tolower(*c);
+  char path[128];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  if (node < 0) return -1;
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  f = fopen(path, "r");
+  if (!f) return -1;
+  char list[1024] = {0};
+  const bool got = fgets(list, sizeof(list), f) != nullptr;
+  fclose(f);
+  if (!got) return -1;
+  cpu_set_t allowed, want;
+  CPU_ZERO(&allowed);
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return -1;
+  int n_want = 0, n_allowed = CPU_COUNT(&allowed);
+  for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {  // "0-63,128-191"
+    int a = 0, b = 0;
+    const int k = sscanf(tok, "%d-%d", &a, &b);
+    if (k < 1) continue;
+    if (k == 1) b = a;
+    for (int c = a; c <= b && c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &allowed)) {
+        CPU_SET(c, &want);
+        ++n_want;
+      }
+  }
+  if (n_want == 0 || n_want == n_allowed) return n_want ? node : -1;  // nothing allowed there / already there
+  if (sched_setaffinity(0, sizeof(want), &want) != 0) return -1;
+  return node;
+}
+
+int32_t sdm_bind_host_thread(int32_t device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -1;
+  return bind_host_thread_to(device);
+}
+
 sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   if (!cfg || !out) return SDM_ERR_INVALID_ARGUMENT;
   *out = nullptr;
@@ -502,6 +561,10 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
     return SDM_ERR_NO_DEVICE;
   }
   HIP_TRY(hipSetDevice(cfg->device));
+  {
+    const char *e = getenv("SDM_NUMA_BIND");
+    if (!(e && e[0] == '0')) (void)bind_host_thread_to(cfg->device);  // before the streams (their queues) exist
+  }
   sdm_map *m = new sdm_map();
   m->cfg = *cfg;
   m->cfg.shard_count = shard_count;

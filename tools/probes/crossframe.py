@@ -27,6 +27,15 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     for t in range(6):
         eng.update(*frames[t])
     m.synchronize()
+    m.device_synchronize()
+    import time
+    tt = time.perf_counter()
+    for rep2 in range(4):
+        for t in range(1, 6):
+            eng.update(*frames[t])
+    m.synchronize()
+    m.device_synchronize()
+    ms = (time.perf_counter() - tt) / 20 * 1e3
     L.sdm_debug_timers(m.h, buf.ctypes.data, 1)
     import time
     t0 = time.perf_counter()
@@ -44,6 +53,14 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     birth_end = k[0][:, 2].max()
     ap = mv[0]
     ap_start = ap[ap[:, 0] > 0, 0].min()
-    print("map %d: sweep(8) %.1f us long; births(8) end -> sweep(8) start %.1f us; sweep(8) end -> move_apply(9) start %.1f us"
-          % (rep, (occ_end - occ_start) / 100.0, (occ_start - birth_end) / 100.0, (ap_start - occ_end) / 100.0), flush=True)
+    def first(a, c=0):
+        return a[a[:, c] > 0, c].min()
+    rp_end = mv[1][:, 2].max()
+    vis_start, vis_end = first(k[1]), k[1][:, 3].max()
+    bsg_start = first(k[2])
+    wt_end = k[4][:, 1].max()
+    br_start = first(k[0])
+    print("map %d: %.4f ms/frame | sweep(8) %.1f us; births end -> sweep start %.1f; sweep end -> move_apply(9) start %.1f | frame 8: move_replay end -> visibility start %.1f, visibility end -> bin_sort_gather start %.1f, weight end -> birth_replay start %.1f us"
+          % (rep, ms, (occ_end - occ_start) / 100.0, (occ_start - birth_end) / 100.0, (ap_start - occ_end) / 100.0,
+             (vis_start - rp_end) / 100.0, (bsg_start - vis_end) / 100.0, (br_start - wt_end) / 100.0), flush=True)
     m.close()
