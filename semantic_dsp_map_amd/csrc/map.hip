@@ -33,13 +33,9 @@ thread_local std::string g_last_error;
 // the process), so it is set when this library is loaded - unless the user has set it, or HIP is already up (then
 // nothing changes).
 //
-// (Not set here: GPU_MAX_HW_QUEUES.  Frames issued back to back take either 0.270 or 0.295 ms on C3 - the same in every
-// frame of one set of streams, different from one set to the next; the per-stage times with a synchronisation after each
-// stage are the same in both modes, so what differs is how well the next frame's side chains run beside this frame's
-// sweep.  On one box 32 hardware queues instead of the default gave the fast mode in 7 processes of 7 (4 queues: 0 of 7,
-// default: 1 of 7); on a second box they changed nothing, stream creation took twice as long and a pytest process that
-// had created and destroyed ~120 maps aborted inside the runtime.  A high-priority main stream and one or two side
-// streams instead of three did not change the odds either.  tools/probes/modes.py shows the modes.)
+// (Not set here: GPU_MAX_HW_QUEUES.  32 hardware queues seemed to cure the two "modes" of the frame time on one box and
+// did nothing on another; stream creation took twice as long and a pytest process that had created and destroyed ~120
+// maps aborted inside the runtime.  The modes were the host's NUMA node: bind_host_thread_to below.)
 // (Priority 101: before the constructors that register this library's kernels with the runtime - they are what brings
 // the runtime up when nothing else in the process has, and run at the default priority.)
 __attribute__((constructor(101))) void sdm_runtime_defaults() {
