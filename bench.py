@@ -245,16 +245,36 @@ def grown_run(synth, sharded, n_grow=180, steps=20, cpu_frames=3):
     return res
 
 
+import ctypes
+
+C_INT32 = ctypes.c_int32
+
+
 def pin_to_device_node(device):
     """The process moves onto the NUMA node its GPU hangs off BEFORE the HIP runtime comes up in it: a frame is a chain of
     ~50 dependent launches whose packets and completion signals live in host memory the runtime allocates where the
-    process runs; from the far socket every gap between two dependent kernels is 2-4 us longer (C3: 0.265 against 0.292 ms
-    per frame; DESIGN.md 7 "Two modes").  Which node that is only HIP knows (device ordinal -> PCI address), so a child
-    process asks the library (sdm_bind_host_thread) and this one sets its affinity from the answer.  The library does the
-    same for the thread that calls sdm_create, but by then the runtime has made its first allocations.
+    process runs; from the far socket every gap between two dependent kernels is 2-4 us longer (C3: 0.266 against 0.292 ms
+    per frame; DESIGN.md 7).  The library finds the node without the runtime (KFD topology in sysfs) when it is loaded;
+    where sysfs cannot tell, a child process asks HIP and this one sets its affinity from the answer.
     SDM_NUMA_BIND=0: leave the affinity alone.  Returns a description for the bench line."""
     if os.environ.get("SDM_NUMA_BIND") == "0":
         return "not pinned (SDM_NUMA_BIND=0)"
+    # 1. without the runtime: the library finds the device's node in sysfs (KFD topology) and moves this thread when it is
+    #    loaded - no HIP call has happened in this process yet
+    try:
+        from semantic_dsp_map_amd import binding
+        L = binding.load_library()
+        L.sdm_host_numa_node_early.restype = C_INT32
+        L.sdm_host_numa_node_early.argtypes = [C_INT32]
+        if L.sdm_host_numa_node_early(device) >= 0:
+            node = binding.HOST_NUMA_NODE
+            if node is not None and node >= 0:
+                return ("pinned to NUMA node %d (the GPU's, from the KFD topology), %d CPUs, before HIP initialised"
+                        % (node, len(os.sched_getaffinity(0))))
+            return "not pinned (one node, or already there)"
+    except Exception:  # noqa: BLE001 - fall through to the second way
+        pass
+    # 2. sysfs cannot tell: a child process asks HIP, this one sets its affinity from the answer (still before HIP here)
     import subprocess
     code = ("import ctypes, sys; sys.path.insert(0, %r); from semantic_dsp_map_amd import binding; L = binding.load_library(); "
             "L.sdm_bind_host_thread.restype = ctypes.c_int32; L.sdm_bind_host_thread.argtypes = [ctypes.c_int32]; "
@@ -272,7 +292,7 @@ def pin_to_device_node(device):
         if not cpus:
             return "not pinned (no allowed CPU on node %d)" % node
         os.sched_setaffinity(0, cpus)
-        return "pinned to NUMA node %d (the GPU's), %d CPUs, before HIP initialised" % (node, len(cpus))
+        return "pinned to NUMA node %d (the GPU's, asked of HIP in a child process), %d CPUs" % (node, len(cpus))
     except Exception as e:  # noqa: BLE001 - the pin is an optimisation
         return "not pinned (%s)" % type(e).__name__
 

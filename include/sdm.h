@@ -170,10 +170,15 @@ typedef struct {
  * socket the GPU does not hang off, every gap between two dependent kernels is 2-4 us longer (C3 frame: 0.292 against
  * 0.265 ms).  sdm_bind_host_thread moves the CALLING thread (and the threads it starts afterwards) onto the NUMA node
  * of `device`, within the CPUs the process may use, and returns that node (-1: nothing to do - one node, no sysfs entry,
- * no allowed CPU there).  Best called first thing in the process, before any other HIP call (it brings the runtime up
- * itself only to ask for the device's PCI address; `numactl --cpunodebind` on the command line is better still).
+ * no allowed CPU there).  Best called first thing in the process, before any other HIP call: it finds the node in sysfs
+ * (KFD topology) without touching the runtime, so that the runtime's first allocations land on the right node too; only
+ * when sysfs cannot tell does it ask HIP for the device's PCI address.
  * sdm_create calls it for its device unless SDM_NUMA_BIND=0 is set in the environment. */
 int32_t sdm_bind_host_thread(int32_t device);
+/* The NUMA node of HIP device `device` found WITHOUT the HIP runtime (KFD topology in sysfs + the *_VISIBLE_DEVICES index
+ * lists), which is what sdm_bind_host_thread tries first: -2 if that cannot tell (it then asks HIP, i.e. brings the runtime
+ * up before the thread is moved). */
+int32_t sdm_host_numa_node_early(int32_t device);
 
 /* ---- life cycle: SemanticDSPMap() / ~SemanticDSPMap() / clear() (semantic_dsp_map.h:25-81),
  * RingBufferOperations::initialize / clear (mc_ring/operations.h:684-767) */

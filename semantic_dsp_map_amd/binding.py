@@ -93,6 +93,9 @@ class SdmError(RuntimeError):
 _lib = None
 
 
+HOST_NUMA_NODE = None  # what sdm_bind_host_thread answered when the library was loaded (-1: nothing done)
+
+
 def load_library():
     """Load libsdm_hip.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -165,6 +168,7 @@ def load_library():
         "sdm_time_occupancy_sweep": [vp, i32, C.POINTER(C.c_float)],
         "sdm_set_issue_mode": [vp, i32],
         "sdm_bind_host_thread": [i32],
+        "sdm_host_numa_node_early": [i32],
         "sdm_debug_fill_dense": [vp],
         "sdm_debug_fill_dense_ex": [vp, i32],
         "sdm_test_scan": [vp, vp, i64],
@@ -176,6 +180,10 @@ def load_library():
         fn.restype = C.c_int
     L.sdm_last_error.restype = C.c_char_p
     L.sdm_version.restype = C.c_char_p
+    # The process belongs on the NUMA node of its GPU before the HIP runtime makes its first allocations (sdm.h,
+    # sdm_bind_host_thread; SDM_NUMA_BIND=0 switches it off): nothing of HIP has been called yet at this point.
+    global HOST_NUMA_NODE
+    HOST_NUMA_NODE = L.sdm_bind_host_thread(int(os.environ.get("LOCAL_RANK", "0")))
     _lib = L
     return L
 

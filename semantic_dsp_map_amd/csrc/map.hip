@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>
 #include <rocrand/rocrand.h>
 #include <sched.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -487,23 +488,12 @@ const char *sdm_version(void) { return "libsdm_hip 0.1 (gfx950)"; }
 // sdm_bind_host_thread moves the CALLING thread (and the threads it starts later) onto the device's node, within the
 // CPUs the process is allowed to use; sdm_create calls it unless SDM_NUMA_BIND=0.  Returns the node, -1 if there is
 // nothing to do (one node, no sysfs entry, no allowed CPU on that node).
-static int bind_host_thread_to(int device) {
-  char bus[32] = {0};
-  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
-    (void)hipGetLastError();
-    return -1;
-  }
-  for (char *c = bus; *c; ++c) *c = (char)tolower(*c);
-  char path[128];
-  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
-  FILE *f = fopen(path, "r");
-  if (!f) return -1;
-  int node = -1;
-  if (fscanf(f, "%d", &node) != 1) node = -1;
-  fclose(f);
+// the calling thread onto NUMA node `node`, within the CPUs the process may use; returns the node, -1: nothing to do
+static int bind_to_node(int node) {
   if (node < 0) return -1;
+  char path[128];
   snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
-  f = fopen(path, "r");
+  FILE *f = fopen(path, "r");
   if (!f) return -1;
   char list[1024] = {0};
   const bool got = fgets(list, sizeof(list), f) != nullptr;
@@ -529,8 +519,87 @@ static int bind_host_thread_to(int device) {
   if (sched_setaffinity(0, sizeof(want), &want) != 0) return -1;
   return node;
 }
+static int numa_node_of_pci(const char *bus_lower) {
+  char path[128];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus_lower);
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
+// with the runtime up: HIP knows the device's PCI address
+static int bind_host_thread_to(int device) {
+  char bus[32] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  for (char *c = bus; *c; ++c) *c = (char)tolower(*c);
+  return bind_to_node(numa_node_of_pci(bus));
+}
+// WITHOUT the runtime (so that its first allocations already land on the right node): HIP device `device` is the
+// device-th GPU of the KFD topology (/sys/class/kfd/kfd/topology/nodes/<i>/properties: simd_count > 0, readable only
+// for the GPUs this process may open) after ROCR_VISIBLE_DEVICES and HIP_VISIBLE_DEVICES, lists of indices.  Returns
+// the NUMA node, -2 if this cannot tell (other forms of the variables, no topology).
+static int numa_node_without_runtime(int device) {
+  struct Gpu { int domain, location; };
+  std::vector<Gpu> gpus;
+  for (int i = 0; i < 256; ++i) {
+    char path[128];
+    snprintf(path, sizeof(path), "/sys/class/kfd/kfd/topology/nodes/%d/properties", i);
+    FILE *f = fopen(path, "r");
+    if (!f) {
+      snprintf(path, sizeof(path), "/sys/class/kfd/kfd/topology/nodes/%d", i);
+      if (access(path, F_OK) != 0) break;  // past the last node
+      continue;                            // a node this process may not read
+    }
+    char key[64];
+    unsigned long long val = 0;
+    long long simd = 0, domain = 0, location = -1;
+    while (fscanf(f, "%63s %llu", key, &val) == 2) {
+      if (!strcmp(key, "simd_count")) simd = (long long)val;
+      else if (!strcmp(key, "domain")) domain = (long long)val;
+      else if (!strcmp(key, "location_id")) location = (long long)val;
+    }
+    fclose(f);
+    if (simd > 0 && location >= 0) gpus.push_back({(int)domain, (int)location});
+  }
+  if (gpus.empty()) return -2;
+  for (const char *var : {"ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"}) {
+    const char *e = getenv(var);
+    if (!e || !*e) continue;
+    if (!strcmp(var, "CUDA_VISIBLE_DEVICES") && getenv("HIP_VISIBLE_DEVICES")) continue;  // HIP's own variable wins
+    std::vector<Gpu> keep;
+    const char *c = e;
+    while (*c) {
+      if (*c < '0' || *c > '9') return -2;  // a UUID or anything else: cannot tell
+      char *end = nullptr;
+      const long k = strtol(c, &end, 10);
+      if (k < 0 || k >= (long)gpus.size()) break;  // the runtime stops at the first index out of range
+      keep.push_back(gpus[(size_t)k]);
+      c = end;
+      if (*c == ',') ++c;
+      else if (*c) return -2;
+    }
+    gpus.swap(keep);
+  }
+  if (device < 0 || device >= (int)gpus.size()) return -2;
+  char bus[32];
+  const int loc = gpus[(size_t)device].location;
+  snprintf(bus, sizeof(bus), "%04x:%02x:%02x.%x", gpus[(size_t)device].domain, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7);
+  const int node = numa_node_of_pci(bus);
+  return node < 0 ? -2 : node;
+}
+
+int32_t sdm_host_numa_node_early(int32_t device) { return numa_node_without_runtime(device); }
 
 int32_t sdm_bind_host_thread(int32_t device) {
+  const char *e = getenv("SDM_NUMA_BIND");
+  if (e && e[0] == '0') return -1;
+  const int early = numa_node_without_runtime(device);  // no HIP call: the runtime may still be down after this
+  if (early >= -1) return bind_to_node(early);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -1;
   return bind_host_thread_to(device);
