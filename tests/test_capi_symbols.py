@@ -80,3 +80,27 @@ def test_product_package_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(text), "%s references the oracle" % f
+
+
+def test_host_placement_calls_are_safe_without_a_gpu():
+    """sdm_bind_host_thread / sdm_host_numa_node_early (sdm.h "host placement"): no GPU and no KFD topology here - they must
+    say so and leave the caller's CPU affinity alone; SDM_NUMA_BIND=0 switches the binding off altogether."""
+    import ctypes
+    import os
+    import subprocess
+    import sys
+    code = ("import ctypes, os; L = ctypes.CDLL(%r); "
+            "L.sdm_host_numa_node_early.restype = ctypes.c_int32; L.sdm_bind_host_thread.restype = ctypes.c_int32; "
+            "a = os.sched_getaffinity(0); e = L.sdm_host_numa_node_early(0); b = L.sdm_bind_host_thread(0); "
+            "print(e, b, a == os.sched_getaffinity(0))")
+    from semantic_dsp_map_amd import binding
+    for env_extra in ({}, {"SDM_NUMA_BIND": "0"}):
+        out = subprocess.run([sys.executable, "-c", code % binding.LIB_PATH], capture_output=True, text=True, timeout=120,
+                             env=dict(os.environ, **env_extra)).stdout.split()
+        has_kfd = os.path.isdir("/sys/class/kfd/kfd/topology/nodes")
+        if not has_kfd:
+            assert out[0] == "-2", out          # cannot tell without the runtime
+            assert out[1] == "-1", out          # ... and the runtime finds no device: nothing done
+            assert out[2] == "True", out        # affinity untouched
+        if env_extra:
+            assert out[1] == "-1" and out[2] == "True", out
