@@ -60,7 +60,7 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     bsg_start = first(k[2])
     wt_end = k[4][:, 1].max()
     br_start = first(k[0])
-    print("map %d: %.4f ms/frame | sweep(8) %.1f us; births end -> sweep start %.1f; sweep end -> move_apply(9) start %.1f | frame 8: move_replay end -> visibility start %.1f, visibility end -> bin_sort_gather start %.1f, weight end -> birth_replay start %.1f us"
+    print("map %d: %.4f ms/frame | sweep(8) %.1f us; births end -> sweep start %.1f; sweep end -> move_apply(9) start %.1f | frame 8: visibility end -> bin_sort_gather start %.1f, weight end -> birth_replay start %.1f us"
           % (rep, ms, (occ_end - occ_start) / 100.0, (occ_start - birth_end) / 100.0, (ap_start - occ_end) / 100.0,
-             (vis_start - rp_end) / 100.0, (bsg_start - vis_end) / 100.0, (br_start - wt_end) / 100.0), flush=True)
+             (bsg_start - vis_end) / 100.0, (br_start - wt_end) / 100.0), flush=True)
     m.close()
