@@ -163,6 +163,8 @@ typedef struct {
   int64_t graph_frames;     /* frames replayed from the captured hipGraph so far ...                       */
   int64_t direct_frames;    /* ... and frames issued launch by launch                                      */
   double host_enqueue_us;   /* host time to issue 50 empty kernel launches (a frame's worth), measured at sdm_create */
+  int64_t halo_dropped;     /* sharded maps: slab-crossing copies of the last update beyond the export capacity towards their
+                               destination shard (dropped; SDM_ERR_CAPACITY at the next sdm_synchronize) */
 } sdm_stats;
 
 /* ---- host placement.  A frame is a chain of ~50 dependent launches; the command processor fetches every packet and
@@ -298,7 +300,7 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
 #define SDM_HALO_OBJ 64
 #define SDM_HALO_RECORD_BYTES 36
 #define SDM_HALO_HEADER_BYTES 16
-#define SDM_HALO_DEFAULT_CAP 1024
+#define SDM_HALO_DEFAULT_CAP 4096
 sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_point *cloud,
                            const float cam_pos[3], const float cam_q[4],
                            const sdm_object_move *moves, int32_t n_moves,
@@ -400,6 +402,12 @@ sdm_status sdm_voxels_device_ptr(sdm_map *m, const sdm_voxel_result **out);
 
 /* ---- owner sets of the object layer: ObjectParticleHashMap (object_layer.h:20-52) */
 sdm_status sdm_object_particle_count(sdm_map *m, int32_t track_id, int64_t *count);
+/* The keys of ObjectParticleHashMap::indices_map whose sets are not empty: every track id that owns at least one slot of
+ * this map (this shard), ascending, at most `cap` of them; *n_out = how many there are.  What the reference's floating-object
+ * check iterates over (semantic_dsp_map.h:712-736: an owner set without a tracked object is wiped): an object layer on the
+ * C ABI lists these, drops the ids it tracks, and passes the rest to sdm_update as remove_tracks.  Synchronises the map's
+ * stream. */
+sdm_status sdm_tracks_with_particles(sdm_map *m, int32_t *out, int32_t cap, int32_t *n_out);
 
 /* ---- introspection / checkpoint (tests, fixtures; SURVEY.md §5 checkpoint row) */
 sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live);

@@ -164,12 +164,18 @@ struct SdmObjectLayer {
   virtual void clear() = 0;
   /// global_time_stamp after the increment at the head of update() (semantic_dsp_map.h:173), told before update()
   virtual void setGlobalTimeStamp(uint32_t) {}
+  /// the track ids that own particles in the map right now (sdm_tracks_with_particles: the non-empty keys of the
+  /// reference's obj_ptc_hash_map.indices_map, which its floating-object check walks, semantic_dsp_map.h:712-736), told
+  /// before collect()
+  virtual void setTracksWithParticles(const int32_t *, int32_t) {}
 };
 
 /// The library's own object layer (sdm_objects.h): objectLevelUpdate and the object loop of the
 /// prediction step restated on plain doubles with a seeded RANSAC sampler.  "Floating" objects (tracks that own
-/// particles but are not tracked, semantic_dsp_map.h:713-733): every movable track id that came with a mask may have
-/// particles born under it, so those ids are handed to sdm_objects_collect as "present" until they have been wiped.
+/// particles but are not tracked, semantic_dsp_map.h:713-733): the map says which track ids own particles
+/// (setTracksWithParticles; SemanticDSPMap::update asks sdm_tracks_with_particles every frame) and those go to
+/// sdm_objects_collect as "present".  Driven without a map (nobody tells), it falls back on its own bookkeeping: every
+/// movable track id that came with a mask may have particles born under it and counts as present until wiped.
 class SdmBuiltinObjectLayer : public SdmObjectLayer {
  public:
   SdmBuiltinObjectLayer(const sdm_objects_config &cfg, const std::unordered_map<std::string, int> &label_ids)
@@ -211,7 +217,8 @@ class SdmBuiltinObjectLayer : public SdmObjectLayer {
                std::vector<int32_t> &remove_tracks) override {
     int32_t n_tracked = 0;
     sdm_objects_count(h_, &n_tracked);
-    const std::vector<int32_t> present(maybe_present_.begin(), maybe_present_.end());
+    const std::vector<int32_t> present = have_owner_tracks_ ? owner_tracks_ : std::vector<int32_t>(maybe_present_.begin(), maybe_present_.end());
+    have_owner_tracks_ = false;  // (told anew before every collect)
     const int32_t cap = n_tracked + (int32_t)present.size();
     moves.resize((size_t)cap);
     remove_tracks.resize((size_t)cap);
@@ -228,6 +235,10 @@ class SdmBuiltinObjectLayer : public SdmObjectLayer {
     // offered as "present" next frame like the reference's obj_ptc_hash_map would (semantic_dsp_map.h:713-736)
     for (int32_t id : remove_tracks)
       if (!seen_this_frame_.count(id)) maybe_present_.erase(id);
+  }
+  void setTracksWithParticles(const int32_t *ids, int32_t n) override {
+    owner_tracks_.assign(ids, ids + (n > 0 ? n : 0));
+    have_owner_tracks_ = true;
   }
   /// the frame these removals belonged to was not applied: offer them again
   void requeue(const std::vector<int32_t> &remove_tracks) {
@@ -248,6 +259,8 @@ class SdmBuiltinObjectLayer : public SdmObjectLayer {
   uint32_t global_time_stamp_;
   int max_movable_;
   std::set<int32_t> maybe_present_, seen_this_frame_;
+  std::vector<int32_t> owner_tracks_;
+  bool have_owner_tracks_ = false;
 };
 
 class SemanticDSPMap {
@@ -296,6 +309,11 @@ class SemanticDSPMap {
   void setGridPreset(const SdmGridPreset &p) { preset_ = p; }
   const SdmGridPreset &gridPreset() const { return preset_; }
   void setDevice(int hip_device) { device_ = hip_device; }
+  /// The Gaussian table the prediction step and the noisy births draw from (basic_algorithms.h:394-402: 1,000,000 draws
+  /// with standard deviation prediction_stddev_ = 0.05, seeded from std::random_device in the reference).  By default the
+  /// map fills its own with rocRAND (fixed seed); a caller that needs a particular table - a reproducible run, a parity
+  /// test - hands it over before the first update().
+  void setNoiseTable(const float *table, size_t n) { noise_table_.assign(table, table + n); }
   void setObjectLayer(SdmObjectLayer *layer) { object_layer_ = layer; }
   /// Use the library's object layer (sdm_objects.h).  mode = the reference's SETTING (settings.h:22); call after
   /// setGridPreset / setLabelTables / setBeyesianMovementParameters.
@@ -424,6 +442,17 @@ class SemanticDSPMap {
     if (preset_.consider_instance && object_layer_) {  // :189-191
       object_layer_->setGlobalTimeStamp(global_time_stamp_);
       object_layer_->update(ins_seg_result, camera_position, camera_orientation, time_stamp_double);
+      {  // the keys of the owner sets as the previous frame left them (semantic_dsp_map.h:712-736 walks them here)
+        int32_t n_own = 0;
+        if (owner_tracks_.size() < 64) owner_tracks_.resize(64);
+        if (check(sdm_tracks_with_particles(map_, owner_tracks_.data(), (int32_t)owner_tracks_.size(), &n_own), "sdm_tracks_with_particles")) {
+          if ((size_t)n_own > owner_tracks_.size()) {
+            owner_tracks_.resize((size_t)n_own);
+            check(sdm_tracks_with_particles(map_, owner_tracks_.data(), (int32_t)owner_tracks_.size(), &n_own), "sdm_tracks_with_particles");
+          }
+          object_layer_->setTracksWithParticles(owner_tracks_.data(), n_own);
+        }
+      }
       object_layer_->collect(global_time_stamp_, params_.max_obersevation_lost_time, moves, removals);
     }
     // per-frame limits of the C ABI (SDM_MAX_MOVES / SDM_MAX_REMOVALS): a crowded frame degrades instead of being
@@ -499,6 +528,8 @@ class SemanticDSPMap {
   bool have_static_ = false;
   std::vector<sdm_point_xyzrgb> points_;
   std::vector<int32_t> pending_removals_;
+  std::vector<int32_t> owner_tracks_;
+  std::vector<float> noise_table_;
   bool tables_from_reference_ = false;
 
   /// a frame that did not reach the map: its removals are offered again
@@ -569,7 +600,8 @@ class SemanticDSPMap {
     c.shard_count = 1;
     if (sdm_create(&c, &map_) != SDM_OK) throw std::runtime_error(std::string("sdm_create: ") + sdm_last_error());
     // prediction_stddev_ = 0.05 table of 1,000,000 draws (semantic_dsp_map.h:40,66; basic_algorithms.h:394-402)
-    check(sdm_generate_noise_table(map_, 20250217ull, 1000000, 0.05f), "sdm_generate_noise_table");
+    if (noise_table_.empty()) check(sdm_generate_noise_table(map_, 20250217ull, 1000000, 0.05f), "sdm_generate_noise_table");
+    else check(sdm_upload_noise_table(map_, noise_table_.data(), (int32_t)noise_table_.size()), "sdm_upload_noise_table");
     pushParams();
     pushColours();
     depth_.resize((size_t)c.width * c.height);

@@ -83,7 +83,8 @@ class Stats(C.Structure):
                 ("flood_rounds", C.c_int64), ("bfs_start_in_frustum", C.c_int64), ("live_voxels", C.c_int64), ("sweep_live_voxels", C.c_int64),
                 ("sweep_tiles", C.c_int64),
                 ("stage_ms", C.c_double * 8), ("restamped_slabs", C.c_int64 * 3),
-                ("graph_frames", C.c_int64), ("direct_frames", C.c_int64), ("host_enqueue_us", C.c_double)]
+                ("graph_frames", C.c_int64), ("direct_frames", C.c_int64), ("host_enqueue_us", C.c_double),
+                ("halo_dropped", C.c_int64)]
 
 
 class SdmError(RuntimeError):
@@ -152,6 +153,7 @@ def load_library():
         "sdm_get_freespace": [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), i32],
         "sdm_voxels_device_ptr": [vp, C.POINTER(vp)],
         "sdm_object_particle_count": [vp, i32, C.POINTER(i64)],
+        "sdm_tracks_with_particles": [vp, vp, i32, C.POINTER(i32)],
         "sdm_get_stats": [vp, C.POINTER(Stats), i32],
         "sdm_set_profiling": [vp, i32],
         "sdm_debug_force_generic_flood": [vp, i32],
@@ -463,6 +465,13 @@ class SdmMap:
         n = C.c_int64()
         _check(self.L, self.L.sdm_object_particle_count(self.h, track, C.byref(n)), "sdm_object_particle_count")
         return n.value
+
+    def tracks_with_particles(self):
+        """Track ids that own at least one slot, ascending (the non-empty keys of the reference's indices_map)."""
+        out = np.zeros(65536, np.int32)
+        n = C.c_int32(0)
+        _check(self.L, self.L.sdm_tracks_with_particles(self.h, _ptr(out), out.size, C.byref(n)), "sdm_tracks_with_particles")
+        return out[:n.value].copy()
 
     def stats(self, count_live=False):
         s = Stats()

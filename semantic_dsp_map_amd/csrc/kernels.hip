@@ -77,12 +77,6 @@ __device__ __forceinline__ void store_vec(T *dst, const T (&src)[N]) {
   __builtin_memcpy(__builtin_assume_aligned(dst, AL), src, B);
 }
 
-__device__ __forceinline__ void store_result(sdm_voxel_result *dst, const sdm_voxel_result &r) {
-  v2u v;
-  __builtin_memcpy(&v, &r, 8);
-  __builtin_nontemporal_store(v, reinterpret_cast<v2u *>(dst));  // written once, read by the next stage only
-}
-
 __device__ __forceinline__ uint32_t stamp_max(const State &st, uint32_t rx, uint32_t ry, uint32_t rz) {
   uint32_t a = st.stamps_x[rx], b = st.stamps_y[ry], c = st.stamps_z[rz];
   uint32_t m = a > b ? a : b;
@@ -110,83 +104,12 @@ __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, size_t n)
   st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_INVALID;  // slot 0 becomes the time particle again in k_clear_status
 }
 
-// a ring shift re-stamped these slabs: what the voxels there hold has just become stale (operations.h:1131-1181), so
-// their results turn into "unobserved" although nobody wrote to them.  That is all the sweep would do for such a voxel
-// (isVoxelValid fails: its observation stamp is older than the new slab stamp), so it is done right here, voxel by
-// voxel, and the tile needs no mark: an x shift touches one voxel of every x row, i.e. every tile of the map, and
-// would otherwise send the next sweep through all of them.  Should the visibility pass observe the voxel again in
-// this very frame, it marks the tile itself.  t = update k * slab_max + j-th voxel of its slab.
-__device__ __forceinline__ void mark_slab_voxel_dirty(const Dims &d, const State &st, const StampUpdates &su, uint32_t slab_max,
-                                                      uint32_t t) {
-  const uint32_t k = t / slab_max, j = t - k * slab_max;
-  if ((int)k >= su.n) return;
-  const uint32_t e = su.entry[k], axis = e >> 12, idx = e & 0xfffu;
-  uint32_t rx, ry, rz;
-  if (axis == 0) {
-    if (j >= d.NY * d.NZ) return;
-    rx = idx;
-    ry = j % d.NY;
-    rz = j / d.NY;
-  } else if (axis == 1) {
-    if (j >= d.NX * d.NZ) return;
-    ry = idx;
-    rx = j % d.NX;
-    rz = j / d.NX;
-  } else {
-    if (j >= d.NX * d.NY) return;
-    rz = idx;
-    rx = j % d.NX;
-    ry = j / d.NX;
-  }
-  if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) return;  // another shard's slab
-  const uint32_t lv = ring_to_voxel(d, rx, ry, rz) - d.v_begin;
-  const uint8_t fl = st.vflag[lv];
-  const uint8_t state = fl & VF_STATE;
-  // a CLEAN voxel's stored result is gone with this: it is evaluated again when the voxel is seen again
-  const uint8_t nf = (uint8_t)((state == VF_CLEAN ? VF_DIRTY : state) | VR_UNOBSERVED);
-  if (nf != fl) st.vflag[lv] = nf;
-  if ((fl & VR_MASK) != VR_UNOBSERVED) {
-    sdm_voxel_result out;
-    out.wsum = -1.f;
-    out.track = 0;
-    out.label = 0;
-    out.occ = -1;
-    store_result(st.res + lv, out);
-  }
-}
-
 // first kernel of a frame: the frame's scalars (pose, ring state, stamp updates, object motions, removals, input pointers)
 // arrive by value and are stored where the frame's other kernels read them (FrameArgs, sdm_scratch.h)
 __global__ __launch_bounds__(TPB) void k_set_frame(FrameArgs *__restrict__ dst, const FrameArgs src) {
   const uint32_t *s4 = reinterpret_cast<const uint32_t *>(&src);
   uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
   for (uint32_t i = threadIdx.x; i < sizeof(FrameArgs) / 4; i += blockDim.x) d4[i] = s4[i];
-}
-
-// start of frame: zero the per-frame counters and the per-pixel bin counts (one launch instead of two memsets)
-// It is also where the frame's scalars arrive on the main stream: `src` comes by value and is stored in the block the
-// main-stream kernels read (and, inside a graph, in the side chains' block too).
-__global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__restrict__ bin_count, uint32_t n_bins,
-                                                      State st, const FrameArgs src, FrameArgs *__restrict__ dst_main,
-                                                      FrameArgs *__restrict__ dst_side, Dims d, uint32_t slab_max) {
-  const StampUpdates &su = src.su;
-  if (blockIdx.x == 0) {
-    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(&src);
-    uint32_t *m4 = reinterpret_cast<uint32_t *>(dst_main), *e4 = reinterpret_cast<uint32_t *>(dst_side);
-    for (uint32_t k = threadIdx.x; k < sizeof(FrameArgs) / 4; k += blockDim.x) {
-      m4[k] = s4[k];
-      if (e4) e4[k] = s4[k];
-    }
-  }
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  for (uint32_t t = i; t < slab_max * (uint32_t)su.n; t += gridDim.x * blockDim.x) mark_slab_voxel_dirty(d, st, su, slab_max, t);
-  if (i < offsetof(Counters, flood_complex) / 4) reinterpret_cast<uint32_t *>(cnt)[i] = 0;  // the flood flags belong to the frustum chain
-  if (i < (uint32_t)su.n) {  // this frame's recycled slabs (no host-to-device copy of the stamp arrays)
-    const uint32_t e = su.entry[i], axis = e >> 12, idx = e & 0xfffu;
-    uint32_t *arr = axis == 0 ? st.stamps_x : (axis == 1 ? st.stamps_y : st.stamps_z);
-    arr[idx] = su.value;
-  }
-  for (; i < n_bins; i += gridDim.x * blockDim.x) bin_count[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------ A10
@@ -1352,20 +1275,6 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
 constexpr int VIS_WORDS = 32;
 constexpr int VIS_J = VIS_WORDS * 64 / TPB;  // candidates per thread and round, at most
 
-__device__ __forceinline__ int nth_set_bit(unsigned long long m, uint32_t n) {  // position of the n-th (0-based) set bit
-  int pos = 0;
-#pragma unroll
-  for (int w = 32; w >= 1; w >>= 1) {
-    const uint32_t c = (uint32_t)__popcll(m & ((1ull << w) - 1ull));
-    if (n >= c) {
-      n -= c;
-      m >>= w;
-      pos += w;
-    }
-  }
-  return pos;
-}
-
 template <int S>
 __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc) {
   __shared__ unsigned long long wmask[VIS_WORDS];
@@ -1508,8 +1417,10 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
 
 // counting sort of the visible particles by pixel: scatter into the scanned bin ranges.
 // blockIdx.y = shard of the work list; the total (last entry of the scanned counts) becomes n_vis.
-__global__ __launch_bounds__(TPB) void k_bin_fill(Scratch sc, uint32_t hw) {
+__global__ __launch_bounds__(TPB) void k_bin_fill(State st, Scratch sc, uint32_t hw) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sc.cnt->n_vis = sc.bin_start[hw];
+  // (the one place of a frame where nobody reads or writes the table of older set memberships: its deleted entries go)
+  if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && threadIdx.x < 64) alias_compact_wave(st);
   if (sc.cnt->overflow) return;
   const uint32_t cap_sub = sc.cap_vis / VIS_SHARDS;
   const uint32_t shard = blockIdx.y;
@@ -1915,6 +1826,14 @@ __global__ __launch_bounds__(TPB) void k_ck_reduce_chunk(const float *__restrict
 // scalar loads), then sigma beside every window pixel, then the table - and is through after three levels.
 // The terms go through LDS and are added in the order of the reference's loops: along each window row from 0.f, then
 // the rows; a skipped pixel adds +0.f, which leaves a sum that started at +0.f (and so never is -0.f) as it is.
+// lanes of ONE wave hand values to each other through LDS: the scheduling barrier keeps the compiler from moving the
+// accesses across it, the wavefront-scope release / acquire pair orders them in the memory model (the barrier alone
+// rests on the hardware's in-order LDS path)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 constexpr int WT_WAVES = 4;
 constexpr int WT_GRID = 2048;  // x 4 waves = the 8192 waves the chip holds at once
 template <int U, int ROUNDS>
@@ -2010,7 +1929,7 @@ __global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, St
     unsigned long long rb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) rb[u] = __ballot(right[u]);
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     // lane (u, r): row r of particle u
     const int lu = lane / A7_ROWS, lr = lane % A7_ROWS;
     if (lu < U && lr < side) {
@@ -2018,7 +1937,7 @@ __global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, St
       for (int c = 0; c < side; ++c) acc += term[wv][lu][lr * side + c];
       rowsum[wv][lu][lr] = acc;
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     if (lu < U && lr == 0 && k0 + lu < n) {
       float a = 0.f;
       for (int m = 0; m < side; ++m) a += rowsum[wv][lu][m];
@@ -2044,7 +1963,7 @@ __global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, St
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
   }
   DBG_LANE0(4, 1);
 }
@@ -2269,7 +2188,7 @@ __device__ __forceinline__ void birth_replay_sequential(const Dims &d, const Fra
           st.status[base * REC_STATUS + slot] = ST_REGULAR_BORN;
           if ((int)track <= d.max_movable) {  // addParticleToObj
             if (!owner_insert(st, base + slot, track)) sc.cnt->overflow = 1;
-            st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
+            flag_owner_chunk(st, base + slot);
           }
 #pragma unroll
           for (int i = 1; i < S; ++i)
@@ -2459,7 +2378,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
     st.status[base * REC_STATUS + i] = ST_REGULAR_BORN;
     if ((int)track <= d.max_movable) {  // addParticleToObj
       if (!owner_insert_local(st, base + i, track, own[i], n_alias, alias_touched)) sc.cnt->overflow = 1;
-      st.owner_flag[(base + i) / OWNER_CHUNK] = 1;
+      flag_owner_chunk(st, base + i);
     }
   }
   if (threadIdx.x == 0) {
@@ -2819,7 +2738,8 @@ void launch_clear(const Dims &d, const State &st, hipStream_t s, bool fresh) {
 
   hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
   hipMemsetAsync(st.alias, 0, 8, s);  // no older memberships
-  hipMemsetAsync(st.owner_flag, 0, (n + OWNER_CHUNK - 1) / OWNER_CHUNK, s);
+  hipMemsetAsync(st.owner_flag, 0, owner_flag_bytes(n), s);
+  hipMemsetAsync(st.owner_flag2, 0, owner_flag2_bytes(n), s);
   hipMemsetAsync(st.res, 0, (size_t)d.v_count * sizeof(sdm_voxel_result), s);
   hipLaunchKernelGGL(k_clear_status, dim3(4096), dim3(TPB), 0, s, st.status, (uint32_t)d.v_count, (uint32_t)(d.S * REC_STATUS));
 }
@@ -2859,35 +2779,6 @@ void launch_set_frame(FrameArgs *fa_dev, const FrameArgs &fa, hipStream_t s) {
 }
 const void *set_frame_kernel() { return reinterpret_cast<const void *>(k_set_frame); }
 
-// arguments of k_frame_begin in the order of its parameter list; `fa` is the frame block that goes by value
-void FrameBeginLaunch::set(const Dims &d_, const State &st_, const Scratch &sc, const FrameArgs &fa_, bool with_side) {
-  cnt = sc.cnt;
-  bin_count = sc.bin_count;
-  n_bins = (uint32_t)(d_.W * d_.H + 1);
-  st = st_;
-  fa = fa_;
-  dst_main = const_cast<FrameArgs *>(sc.fa);
-  dst_side = with_side ? const_cast<FrameArgs *>(sc.fa_side) : nullptr;
-  d = d_;
-  slab_max = d_.NY * d_.NZ;  // voxels of the largest slab a ring shift can re-stamp
-  if (d_.NX * d_.NZ > slab_max) slab_max = d_.NX * d_.NZ;
-  if (d_.NX * d_.NY > slab_max) slab_max = d_.NX * d_.NY;
-  argv[0] = &cnt;
-  argv[1] = &bin_count;
-  argv[2] = &n_bins;
-  argv[3] = &st;
-  argv[4] = &fa;
-  argv[5] = &dst_main;
-  argv[6] = &dst_side;
-  argv[7] = &d;
-  argv[8] = &slab_max;
-}
-const void *FrameBeginLaunch::kernel() { return reinterpret_cast<const void *>(k_frame_begin); }
-
-void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s) {
-  (void)hipLaunchKernel(FrameBeginLaunch::kernel(), dim3(FrameBeginLaunch::GRID), dim3(FrameBeginLaunch::BLOCK), a.argv, 0, s);
-}
-
 // The frustum reach set depends on the camera pose only, not on the map: it runs on a side stream next to the
 // object moves.  Grids and the flood's LDS size are functions of the map dimensions only (the kernels stride over the
 // frame's box), so that the launch sequence of a frame is the same every frame (hipGraph).
@@ -2916,7 +2807,7 @@ void launch_visibility(const Dims &d, const Filter &flt, const State &st, const 
   }
   // bins: scan the per-pixel counts, scatter, canonical order + gather
   exclusive_scan_u32(sc.bin_count, sc.bin_start, (size_t)d.W * d.H + 1, sc.scan_scratch, s);
-  hipLaunchKernelGGL(k_bin_fill, dim3(16, VIS_SHARDS), dim3(TPB), 0, s, sc, (uint32_t)(d.W * d.H));
+  hipLaunchKernelGGL(k_bin_fill, dim3(16, VIS_SHARDS), dim3(TPB), 0, s, st, sc, (uint32_t)(d.W * d.H));
   hipLaunchKernelGGL(k_bin_sort_gather, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, st, sc, ck_out, finish);
 }
 

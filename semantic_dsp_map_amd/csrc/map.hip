@@ -115,6 +115,9 @@ struct sdm_map {
   // ev_state: the particles of the last frame are final (after its births, before its sweep); the next frame's
   // member count of the moving objects starts there, next to the sweep
   hipEvent_t ev_state = nullptr, ev_counts = nullptr;
+  hipEvent_t ev_vis = nullptr;      // the frame's visibility pass (and binning) has been issued up to here
+  bool vis_event_valid = false;
+  bool mv_pending = false;          // a member count has run whose k_move_apply has not (it resets the totals)
   bool state_event_valid = false;
   hipEvent_t ev_begin = nullptr, ev_frustum = nullptr, ev_birth = nullptr;
   int birth_which = 0;
@@ -123,6 +126,8 @@ struct sdm_map {
   int32_t stop_after = 0;
   uint32_t frame_flags = 0;
   int n_moves = 0, n_remove = 0;
+  uint32_t mv_seq = 0;            // frames with moving objects so far (FrameArgs::mv_seq)
+  uint32_t *d_track_bits = nullptr;  // sdm_tracks_with_particles: one bit per track id
   int32_t *d_counts_local = nullptr;
   // native RCCL path (sdm_comm_init): communicator + exchange buffers owned by the map
   ncclComm_t comm = nullptr;
@@ -499,12 +504,29 @@ static int bind_to_node(int node) {
   const bool got = fgets(list, sizeof(list), f) != nullptr;
   fclose(f);
   if (!got) return -1;
+  // The CPUs the process was allowed BEFORE the first bind: a later bind for a GPU on the other socket (a second map on
+  // another device, SdmMap(device=k) after the load-time bind for device 0) chooses among those, not among what an
+  // earlier bind narrowed the thread down to - which would leave it nothing to choose from.
+  static std::mutex mu;
+  static cpu_set_t original;
+  static bool have_original = false;
   cpu_set_t allowed, want;
-  CPU_ZERO(&allowed);
   CPU_ZERO(&want);
-  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return -1;
-  int n_want = 0, n_allowed = CPU_COUNT(&allowed);
-  for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {  // "0-63,128-191"
+  {
+    std::lock_guard<std::mutex> g(mu);
+    if (!have_original) {
+      CPU_ZERO(&original);
+      if (sched_getaffinity(0, sizeof(original), &original) != 0) return -1;
+      have_original = true;
+    }
+    allowed = original;
+  }
+  cpu_set_t current;
+  CPU_ZERO(&current);
+  if (sched_getaffinity(0, sizeof(current), &current) != 0) return -1;
+  int n_want = 0;
+  char *save = nullptr;
+  for (char *tok = strtok_r(list, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {  // "0-63,128-191"
     int a = 0, b = 0;
     const int k = sscanf(tok, "%d-%d", &a, &b);
     if (k < 1) continue;
@@ -515,9 +537,10 @@ static int bind_to_node(int node) {
         ++n_want;
       }
   }
-  if (n_want == 0 || n_want == n_allowed) return n_want ? node : -1;  // nothing allowed there / already there
-  if (sched_setaffinity(0, sizeof(want), &want) != 0) return -1;
-  return node;
+  if (n_want == 0) return -1;  // nothing allowed on that node
+  const bool one_node = n_want == CPU_COUNT(&allowed);  // every CPU the process may use is on that node: nothing to choose
+  if (!CPU_EQUAL(&want, &current) && sched_setaffinity(0, sizeof(want), &want) != 0) return -1;
+  return one_node ? -1 : node;
 }
 static int numa_node_of_pci(const char *bus_lower) {
   char path[128];
@@ -696,6 +719,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   HIP_TRY(hipEventCreateWithFlags(&m->ev_frustum, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_birth, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_fa, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_vis, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->cap_begin, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->cap_frustum, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->cap_birth, hipEventDisableTiming));
@@ -717,7 +741,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(m->st.tile_dirty, 2 * (size_t)m->st.tile_stride);
   A(m->st.occ_need, ((size_t)d.v_count + 63) / 64 + 32);
   A(m->st.owner, n_slots);
-  A(m->st.owner_flag, (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK);
+  A(m->st.owner_flag, owner_flag_bytes(n_slots));
+  A(m->st.owner_flag2, owner_flag2_bytes(n_slots));
   A(m->st.alias, 2 + 2 * ALIAS_CAP);
   HIP_TRY(hipMemset(m->st.alias, 0, 8));
   A(m->st.res, d.v_count);
@@ -787,23 +812,26 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.mv_cnt, mv_cnt_n);
   A(sc.mv_list, 8192);
   A(sc.mv_nlist, 4);
+  HIP_TRY(hipMemsetAsync(sc.mv_nlist, 0, 4 * sizeof(uint32_t), m->stream));
+  A(sc.mv_nmem, 8192);
+  A(sc.mv_mem, move_member_elems());
+  A(sc.mv_tot, move_total_elems());
+  HIP_TRY(hipMemsetAsync(sc.mv_tot, 0, move_total_elems() * sizeof(uint32_t), m->stream));
+  A(m->d_track_bits, 2048);
   A(sc.mv_copy, sc.cap_move);
   A(sc.track_to_obj, 65536);
   HIP_TRY(hipMemsetAsync(sc.track_to_obj, 0xFF, 65536, m->stream));
   // one scratch buffer per scan call site: the one-launch scan keeps its (self-clearing) words there, which start at zero
-  size_t scan_need = std::max(scan_scratch_elems(hw + 1), scan_scratch_elems(mv_cnt_n));
+  size_t scan_need = scan_scratch_elems(hw + 1);
   A(sc.scan_scratch, scan_need + 16);
   A(sc.scan_scratch_b, scan_scratch_elems(hw + 1) + 16);
-  A(sc.scan_scratch_m, scan_scratch_elems(move_count_elems()) + 16);
   A(m->scan_scratch_e, scan_scratch_elems((size_t)d.v_count + 1) + 16);  // compaction of the result lists (getters)
   HIP_TRY(hipMemsetAsync(sc.scan_scratch, 0, (scan_need + 16) * 4, m->stream));
   HIP_TRY(hipMemsetAsync(sc.scan_scratch_b, 0, (scan_scratch_elems(hw + 1) + 16) * 4, m->stream));
-  HIP_TRY(hipMemsetAsync(sc.scan_scratch_m, 0, (scan_scratch_elems(move_count_elems()) + 16) * 4, m->stream));
   HIP_TRY(hipMemsetAsync(m->scan_scratch_e, 0, (scan_scratch_elems((size_t)d.v_count + 1) + 16) * 4, m->stream));
   A(sc.mv_head, d.v_count);
   HIP_TRY(hipMemset(sc.mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t)));  // MV_NIL; the replay leaves it that way
   A(sc.mv_next, sc.cap_move);
-  A(sc.mv_vlist, sc.cap_move);
   A(sc.cnt, 1);
   A(sc.cur, 1);
   HIP_TRY(hipMemsetAsync(sc.cnt, 0, sizeof(Counters), m->stream));
@@ -913,7 +941,7 @@ sdm_status sdm_destroy(sdm_map *m) {
   for (hipGraphExec_t &g : m->piece)
     if (g) (void)hipGraphExecDestroy(g);
   if (m->graph) (void)hipGraphDestroy(m->graph);
-  for (hipEvent_t e : {m->ev_fa, m->cap_begin, m->cap_frustum, m->cap_birth})
+  for (hipEvent_t e : {m->ev_fa, m->ev_vis, m->cap_begin, m->cap_frustum, m->cap_birth})
     if (e) (void)hipEventDestroy(e);
   if (m->s_frustum) (void)hipStreamDestroy(m->s_frustum);
   if (m->s_birth) (void)hipStreamDestroy(m->s_birth);
@@ -928,6 +956,7 @@ sdm_status sdm_clear(sdm_map *m) {
   if (!m) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
   m->state_event_valid = false;
+  m->vis_event_valid = false;
   m->sweep_all = true;
   host_initialize(m);
   HIP_TRY(hipMemsetAsync(m->sc.mv_head, 0xff, (size_t)m->d.v_count * sizeof(uint32_t), m->stream));
@@ -1051,7 +1080,10 @@ sdm_status frame_host_prepare(sdm_map *m, const float cam_pos[3], const float ca
     memcpy(fa.ms.T[k], moves[k].T, 12 * sizeof(float));
   }
   fa.n_obj = n_moves;
-  fa.n_move_cnt = (uint32_t)n_moves * 8192u + 1u;  // MV_LIST_CAP rows of the count matrix + its terminator
+  // (the parity of the per-object totals the member count adds up and k_move_apply reads and resets: it advances with
+  // every frame in which the two run)
+  if (n_moves > 0 && !stage_done(stop_after, 1)) m->mv_seq++;
+  fa.mv_seq = m->mv_seq;
   fa.n_remove = n_remove;
   for (int k = 0; k < n_remove; ++k) fa.remove[k] = (uint16_t)remove_tracks[k];
   fa.force_generic = m->force_generic_flood;
@@ -1065,6 +1097,7 @@ sdm_status frame_enqueue_start(sdm_map *m) {
   hipStream_t s = m->stream;
   const Dims &d = m->d;
   const int32_t stop_after = m->stop_after;
+  const bool whole = d.v_count == d.V;  // not a Z-slab shard
   stage_mark(m, 0);
   if (m->stamps_dirty) {
     sdm_status rc = upload_stamps(m);
@@ -1075,7 +1108,7 @@ sdm_status frame_enqueue_start(sdm_map *m) {
   if (m->capturing) {
     // inside a graph a frame starts when the previous one is through: the first node writes both blocks, the member
     // count stays on the main stream (a detour over another queue costs more than its kernels)
-    m->fb.set(d, m->st, m->sc, m->fa, true);
+    m->fb.set(d, m->st, m->sc, m->fa, true, whole);
     launch_frame_begin(m->fb, s);
     HIP_TRY(hipEventRecord(m->cap_begin, s));
     HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->cap_begin, 0));
@@ -1085,11 +1118,16 @@ sdm_status frame_enqueue_start(sdm_map *m) {
     // which were final when the previous frame's births were done (ev_state): they get their own copy of the frame
     // block there and start - next to the previous frame's sweep when frames are issued back to back.
     if (!m->state_event_valid) HIP_TRY(hipEventRecord(m->ev_state, s));
-    HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->ev_state, 0));
+    // (the frustum chain reads the pose only; its bitmaps and flood flags are last read by the previous frame's
+    // k_visibility: it starts behind THAT, a hundred microseconds before the births are done, and is off the path that
+    // leads from one frame's sweep to the next frame's visibility pass)
+    HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->vis_event_valid ? m->ev_vis : m->ev_state, 0));
     launch_set_frame(m->d_fa[1], m->fa, m->s_frustum);
     HIP_TRY(hipEventRecord(m->ev_fa, m->s_frustum));
-    m->fb.set(d, m->st, m->sc, m->fa, false);
+    if (whole && m->mv_pending) HIP_TRY(hipMemsetAsync(m->sc.mv_tot, 0, move_total_elems() * sizeof(uint32_t), s));
+    m->fb.set(d, m->st, m->sc, m->fa, false, whole);
     launch_frame_begin(m->fb, s);
+    if (whole && m->n_moves > 0) m->mv_pending = true;
   }
   stage_mark(m, 1);
   if (stage_done(stop_after, 1)) return SDM_OK;
@@ -1098,13 +1136,19 @@ sdm_status frame_enqueue_start(sdm_map *m) {
   // moving objects return at once
   // (launch by launch the host knows that a frame has no moving objects / removals and skips those launches; inside a
   // graph they are always there and return at once)
+  // (a whole map counts in k_frame_begin; a shard in a chain of its own, whose counts the all-gather below picks up)
+  const bool side_chain = !m->capturing && m->n_moves > 0 && (!whole || (m->comm && m->sharded_frame));
   if (m->capturing) {
-    launch_moves_count(d, m->st, m->sc, m->d_counts_local, s);
-  } else if (m->n_moves > 0) {
+    if (!whole) launch_moves_count(d, m->st, m->sc, m->d_counts_local, s);
+  } else if (side_chain) {
     // (its own copy of the frame block travels with its first kernel: nothing of another stream in front of the chain but
     // the previous frame's births)
     HIP_TRY(hipStreamWaitEvent(m->s_moves, m->ev_state, 0));
-    launch_moves_count(d, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves, &m->fa);
+    if (!whole) {
+      if (m->mv_pending) HIP_TRY(hipMemsetAsync(m->sc.mv_tot, 0, move_total_elems() * sizeof(uint32_t), m->s_moves));
+      launch_moves_count(d, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves, &m->fa);
+      m->mv_pending = true;
+    }
     if (m->comm && m->sharded_frame) {
       // exchange 1 of a sharded frame rides the member-count stream: it runs beside the previous frame's sweep.  (Every
       // use of the communicator is ordered by events: this one behind the previous frame's births, the next one - the
@@ -1140,8 +1184,9 @@ sdm_status frame_enqueue_start(sdm_map *m) {
     m->birth_which = launch_birth_prepare(d, m->flt, m->bo, m->st, m->sc, m->s_birth);
     HIP_TRY(hipEventRecord(m->capturing ? m->cap_birth : m->ev_birth, m->s_birth));
   }
-  if (!m->capturing && m->n_moves > 0) HIP_TRY(hipStreamWaitEvent(s, m->ev_counts, 0));  // join: the main stream picks the counts up
+  if (side_chain) HIP_TRY(hipStreamWaitEvent(s, m->ev_counts, 0));  // join: the main stream picks the counts up
   m->state_event_valid = false;  // set again when this frame's births are done
+  m->vis_event_valid = false;    // ... and when its visibility pass has been issued
   return SDM_OK;
 }
 
@@ -1196,7 +1241,10 @@ sdm_status sdm_frame_moves(sdm_map *m) {
     w = 1;
     r = 0;
   }
-  if (m->capturing || m->n_moves > 0) launch_moves_transform(m->d, m->flt, m->st, m->sc, counts_all, w, r, m->stream);
+  if (m->capturing || m->n_moves > 0) {
+    launch_moves_transform(m->d, m->flt, m->st, m->sc, counts_all, w, r, m->stream);
+    m->mv_pending = false;  // k_move_apply has reset the totals the next member count adds to
+  }
   return SDM_OK;
 }
 
@@ -1222,6 +1270,10 @@ sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev) {
   HIP_TRY(hipStreamWaitEvent(s, m->capturing ? m->cap_frustum : m->ev_frustum, 0));
   float *ck_dst = m->ck_user ? m->ck_user : m->d_ck_part;
   launch_visibility(d, m->flt, m->st, m->sc, ck_dst, m->fused_ck ? 1 : 0, s);
+  if (!m->capturing) {
+    HIP_TRY(hipEventRecord(m->ev_vis, s));  // the next frame's frustum chain may overwrite what this pass read
+    m->vis_event_valid = true;
+  }
   stage_mark(m, 4);
   if (stage_done(stop_after, 4)) return SDM_OK;
 
@@ -1358,7 +1410,7 @@ sdm_status graph_capture(sdm_map *m) {
 }
 
 sdm_status graph_launch(sdm_map *m) {
-  m->fb.set(m->d, m->st, m->sc, m->fa, true);
+  m->fb.set(m->d, m->st, m->sc, m->fa, true, m->d.v_count == m->d.V);
   hipKernelNodeParams kp;
   memset(&kp, 0, sizeof(kp));
   kp.func = const_cast<void *>(FrameBeginLaunch::kernel());
@@ -1378,6 +1430,7 @@ sdm_status graph_launch(sdm_map *m) {
   m->cur_depth = m->fa.depth;
   m->cur_cloud = m->fa.cloud;
   m->state_event_valid = false;  // ev_state was not recorded: the next plain frame forks from its own start
+  m->vis_event_valid = false;
   m->sweep_all = false;
   m->sweep_epoch = next_epoch(m->f.epoch);
   m->n_graph_frames++;
@@ -1426,7 +1479,7 @@ sdm_status pieces_capture(sdm_map *m) {
     rc = capture(m->s_birth, 1, [&](hipStream_t st) { m->birth_which = launch_birth_prepare(d, m->flt, m->bo, m->st, m->sc, st); });
   if (rc == SDM_OK)
     rc = capture(m->stream, 2, [&](hipStream_t st) {
-      launch_moves_count(d, m->st, m->sc, m->d_counts_local, st);
+      if (d.v_count != d.V) launch_moves_count(d, m->st, m->sc, m->d_counts_local, st);  // (a whole map counts in k_frame_begin)
       launch_moves_transform(d, m->flt, m->st, m->sc, m->d_counts_local, 1, 0, st);
       launch_moves_finish(d, m->flt, m->st, m->sc, 1, m->cfg.shard_rank, st);
       launch_remove(d, m->st, m->sc, st);
@@ -1449,7 +1502,7 @@ sdm_status pieces_capture(sdm_map *m) {
 sdm_status pieces_launch(sdm_map *m) {
   hipStream_t s = m->stream;
   const auto t0 = std::chrono::steady_clock::now();
-  m->fb.set(m->d, m->st, m->sc, m->fa, true);  // k_frame_begin writes both copies of the frame block
+  m->fb.set(m->d, m->st, m->sc, m->fa, true, m->d.v_count == m->d.V);  // k_frame_begin writes both copies of the frame block
   launch_frame_begin(m->fb, s);
   HIP_TRY(hipEventRecord(m->ev_begin, s));
   HIP_TRY(hipStreamWaitEvent(m->s_frustum, m->ev_begin, 0));
@@ -1467,6 +1520,7 @@ sdm_status pieces_launch(sdm_map *m) {
   m->cur_depth = m->fa.depth;
   m->cur_cloud = m->fa.cloud;
   m->state_event_valid = false;
+  m->vis_event_valid = false;
   m->sweep_all = false;
   m->sweep_epoch = next_epoch(m->f.epoch);
   m->n_graph_frames++;
@@ -2063,6 +2117,23 @@ sdm_status sdm_object_particle_count(sdm_map *m, int32_t track_id, int64_t *coun
   return SDM_OK;
 }
 
+sdm_status sdm_tracks_with_particles(sdm_map *m, int32_t *out, int32_t cap, int32_t *n_out) {
+  if (!m || !n_out || cap < 0 || (cap > 0 && !out)) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  launch_tracks_with_particles(m->d, m->st, m->d_track_bits, m->stream);
+  std::vector<uint32_t> bits(2048);
+  HIP_TRY(hipMemcpyAsync(bits.data(), m->d_track_bits, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  int32_t n = 0;
+  for (uint32_t t = 0; t < 65535u; ++t)  // (65535 = "no owner")
+    if ((bits[t >> 5] >> (t & 31u)) & 1u) {
+      if (n < cap) out[n] = (int32_t)t;
+      ++n;
+    }
+  *n_out = n;
+  return SDM_OK;
+}
+
 // ---- introspection ------------------------------------------------------------------------------
 sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
   if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
@@ -2091,6 +2162,7 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
   out->graph_frames = (int64_t)m->n_graph_frames;
   out->direct_frames = (int64_t)m->n_direct_frames;
   out->host_enqueue_us = m->enqueue_us;
+  out->halo_dropped = c.n_halo_dropped;
   if (m->profiling) {
     int prev = 0;
     for (int sidx = 1; sidx <= 7; ++sidx) {

@@ -18,11 +18,11 @@
 namespace sdm {
 
 #ifdef SDM_AB_TIMERS
-__device__ unsigned long long g_dbg_m[2][4096 * 4];  // [kernel][workgroup][checkpoint], see kernels.hip
+__device__ unsigned long long g_dbg_m[3][4096 * 4];  // [kernel][workgroup][checkpoint], see kernels.hip
 void debug_timers_moves(unsigned long long *out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_m), sizeof(g_dbg_m));
   if (reset) {
-    static unsigned long long z[2][4096 * 4];
+    static unsigned long long z[3][4096 * 4];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_m), z, sizeof(z));
   }
 }
@@ -51,187 +51,280 @@ __device__ __forceinline__ uint8_t obj_of(uint16_t owner, const uint16_t *tracks
   return o;
 }
 
-// pass 0: ascending list of the chunks whose owner_flag is set (one workgroup; each thread takes 32 consecutive
-// flag bytes, one block-wide scan of the per-thread counts per 32 K flags).  Dynamic objects touch a few hundred of
-// the map's tens of thousands of chunks; everything after this works on the list only.
-__device__ __forceinline__ void move_chunks_body(const uint8_t *owner_flag, uint32_t n_flags, uint32_t *__restrict__ list,
-                                                 uint32_t *__restrict__ n_list, Cursors *cur, uint32_t *__restrict__ cnt, int n_obj,
-                                                 uint32_t n_move_cnt, uint32_t *__restrict__ alias, uint8_t *owner_flag_w) {
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t running, alias_live;
-  if (n_obj <= 0) return;  // no object moves in this frame
+// exclusive prefix of v over the workgroup's TPB threads (thread order); total = the sum.  Two barriers.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_tot, uint32_t &total) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  constexpr uint32_t PER = 32;
-  // the first 32 K flags are requested before anything else is looked at (the table of older memberships below is a
-  // dependent fetch of its own, and nearly always empty); if it does set flags, they are read again
-  const bool early = threadIdx.x * PER + PER <= n_flags && ((size_t)(owner_flag + threadIdx.x * PER) & 15) == 0;
-  uint4 ea = make_uint4(0, 0, 0, 0), eb = make_uint4(0, 0, 0, 0);
-  if (early) {
-    ea = *reinterpret_cast<const uint4 *>(owner_flag + threadIdx.x * PER);
-    eb = *reinterpret_cast<const uint4 *>(owner_flag + threadIdx.x * PER + 16);
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t nb = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += nb;
   }
-  if (threadIdx.x == 0) {
-    running = 0;
-    alias_live = 0;
-    cur->move_list_overflow = 0;
-    // extra set memberships (State::alias): drop the deleted entries, and make sure the chunks of the live ones are
-    // on the list even if no slot of theirs has a primary owner any more
-    uint32_t na = alias[0], keep = 0;
-    if (na > ALIAS_CAP) {
-      na = ALIAS_CAP;
-      cur->move_list_overflow = 1;
-    }
-    for (uint32_t k = 0; k < na; ++k) {
-      const uint32_t idx = alias[2 + 2 * k], trk = alias[3 + 2 * k];
-      if (trk == OWNER_NONE) continue;
-      alias[2 + 2 * keep] = idx;
-      alias[3 + 2 * keep] = trk;
-      ++keep;
-      owner_flag_w[idx / OWNER_CHUNK] = 1;
-      alias_live = 1;
-    }
-    for (uint32_t k = keep; k < na; ++k) {
-      alias[2 + 2 * k] = INVALID_INDEX;
-      alias[3 + 2 * k] = OWNER_NONE;
-    }
-    alias[0] = keep;
-    __threadfence();
-  }
+  __syncthreads();  // wave_tot of an earlier call has been read
+  if (lane == 63) wave_tot[wid] = inc;
   __syncthreads();
-  const bool reuse_early = alias_live == 0;
-  for (uint32_t tile = 0; tile < n_flags; tile += 1024 * PER) {
-    const uint32_t first = tile + threadIdx.x * PER;
-    uint32_t mask = 0;  // bit j: flag first + j is set
-    if (first + PER <= n_flags && ((size_t)(owner_flag + first) & 15) == 0) {
-      uint4 a = ea, b4 = eb;
-      if (tile != 0) {
-        a = *reinterpret_cast<const uint4 *>(owner_flag + first);
-        b4 = *reinterpret_cast<const uint4 *>(owner_flag + first + 16);
-      } else if (!reuse_early) {  // thread 0 has just set flags: past this CU's L1, which holds the lines as they were
-        uint32_t *wa = reinterpret_cast<uint32_t *>(&a), *wb = reinterpret_cast<uint32_t *>(&b4);
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(owner_flag + first);
+  uint32_t base = 0, t = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          wa[q] = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          wb[q] = __hip_atomic_load(src + 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      const uint32_t w[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if ((w[q] >> (8 * j)) & 0xffu) mask |= 1u << (4 * q + j);
-    } else {
-      for (uint32_t j = 0; j < PER; ++j)
-        if (first + j < n_flags && owner_flag[first + j]) mask |= 1u << j;
-    }
-    const uint32_t c = (uint32_t)__popc(mask);
-    // block exclusive scan of c
-    uint32_t inc = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      uint32_t nb = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += nb;
-    }
-    if (lane == 63) wave_tot[wid] = inc;
-    __syncthreads();
-    uint32_t base = running;
-    for (int w2 = 0; w2 < wid; ++w2) base += wave_tot[w2];
-    uint32_t pos = base + inc - c;
-    uint32_t mm = mask;
-    while (mm) {
-      const int j = __ffs((int)mm) - 1;
-      mm &= mm - 1;
-      if (pos < MV_LIST_CAP) list[pos] = first + (uint32_t)j;
-      else cur->move_list_overflow = 1;
-      ++pos;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t t = 0;
-      for (int w2 = 0; w2 < 16; ++w2) t += wave_tot[w2];
-      running += t;
-    }
-    __syncthreads();
+  for (int w = 0; w < MV_WAVES; ++w) {
+    if (w < wid) base += wave_tot[w];
+    t += wave_tot[w];
   }
-  if (threadIdx.x == 0) {
-    // The count matrix has one row per object and one column per listed chunk - its row length is the list's length,
-    // not the list's capacity: the scan that turns it into offsets covers n_obj x n + 1 elements (2 K at the benchmark's
-    // 6 objects x 347 chunks, where rows of MV_LIST_CAP were 49 K, most of them zeros somebody had to write first).
-    const uint32_t nl = running < MV_LIST_CAP ? running : MV_LIST_CAP;
-    n_list[0] = nl;
-    n_list[2] = (uint32_t)n_obj * nl + 1u;   // what the scan covers (read on the device)
-    cnt[(size_t)n_obj * nl] = 0;             // terminator of the count matrix (becomes the grand total after the scan)
-  }
-}
-__global__ __launch_bounds__(1024) void k_move_chunks(const uint8_t *owner_flag, uint32_t n_flags,
-                                                      uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Cursors *cur,
-                                                      uint32_t *__restrict__ cnt, const FrameArgs *__restrict__ fa,
-                                                      uint32_t *__restrict__ alias, uint8_t *owner_flag_w) {
-  move_chunks_body(owner_flag, n_flags, list, n_list, cur, cnt, fa->n_obj, fa->n_move_cnt, alias, owner_flag_w);
-}
-// The same as the first kernel of a chain of its own (the member count of a launch-by-launch frame starts behind the
-// PREVIOUS frame's births, on its own stream): the frame block arrives by value and is stored for the chain's other
-// kernels - no k_set_frame launch and no event from another stream in front of the chain.
-__global__ __launch_bounds__(1024) void k_move_chunks_v(const uint8_t *owner_flag, uint32_t n_flags,
-                                                        uint32_t *__restrict__ list, uint32_t *__restrict__ n_list, Cursors *cur,
-                                                        uint32_t *__restrict__ cnt, const FrameArgs src, FrameArgs *__restrict__ dst,
-                                                        uint32_t *__restrict__ alias, uint8_t *owner_flag_w) {
-  const uint32_t *s4 = reinterpret_cast<const uint32_t *>(&src);
-  uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
-  for (uint32_t i = threadIdx.x; i < sizeof(FrameArgs) / 4; i += blockDim.x) d4[i] = s4[i];
-  move_chunks_body(owner_flag, n_flags, list, n_list, cur, cnt, src.n_obj, src.n_move_cnt, alias, owner_flag_w);
+  total = t;
+  return base + inc - v;
 }
 
-// pass 1: per-chunk, per-object member counts.  cnt[obj * n + list position], n = chunks on the list.  A flagged chunk that turns out
-// to hold no owner any more clears its flag.
-__global__ __launch_bounds__(TPB) void k_move_count(const uint16_t *__restrict__ owner, size_t n_slots,
-                                                    const FrameArgs *__restrict__ fa, uint32_t *__restrict__ cnt,
-                                                    uint8_t *__restrict__ owner_flag, const uint32_t *__restrict__ list,
-                                                    const uint32_t *__restrict__ n_list, const uint32_t *__restrict__ alias) {
-  __shared__ uint32_t c[MAX_MOVE_OBJECTS];
+// The member count of the moving objects, ONE launch (round 3: list of flagged chunks, per-chunk counts, device-wide scan -
+// three dependent launches on their own stream, 22 us of kernels plus their gaps, and the next frame's k_move_apply
+// waited for them 20 us longer than for the main stream).
+//   1. Every workgroup finds the flagged chunks itself: the coarse flag level whole (one byte per 64 chunks, 512 bytes
+//      for a 256^3 x 8 map), then the 64 flag bytes of every marked group, two block scans - and takes the chunks of
+//      rank blockIdx.x, blockIdx.x + gridDim.x, ... ("positions") among them.  Nobody waits for anybody: no list kernel.
+//   2. It ranks the chunk's members (ballot ranks per object, as k_move_apply used to) and writes them out as a list
+//      in ascending slot order - mv_mem - together with the per-object counts of the chunk.  k_move_apply then has a
+//      thread per MEMBER and neither loads owner entries nor ranks.
+//   3. No scan: a member's global rank is (members of the objects before its own: mv_tot, added up here with one atomic
+//      per chunk and object, every object on a cache line of its own) + (members of its object in the chunks before its
+//      own: the workgroup that applies the chunk sums that row of mv_cnt up to its position - a few hundred words) +
+//      its rank in the chunk.
+// Chunks that hold older set memberships (State::alias; nearly never) are only counted; k_move_apply ranks them on its
+// alias path.  A flagged chunk without any owner clears its flag, a marked group without flagged chunk its mark.
+constexpr uint32_t MV_COMPLEX = 0xffffffffu;
+constexpr uint32_t MV_CLEAR_FLAG = 0x80000000u;  // in mv_list: the chunk holds no owner, k_move_apply clears its flag
+constexpr uint32_t MV_GROUP_CAP = 4096;   // marked groups a workgroup lists (x 64 chunks >> MV_LIST_CAP)
+constexpr int MV_GRID = (int)FrameBeginLaunch::GRID;  // (all resident beside the previous frame's sweep: one workgroup per CU)
+constexpr int MV_PER_WG = (int)(MV_LIST_CAP / MV_GRID);
+constexpr uint32_t MV_TOT_STRIDE = 32;    // uint32 per object in mv_tot: one 128-byte line each
+
+__device__ __forceinline__ void move_members_body(const State &st, const MembersArgs &sc, uint32_t n_flags, size_t n_slots, int n_obj,
+                                                  const uint16_t *__restrict__ ms_track, uint32_t mv_seq) {
   __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
-  __shared__ uint32_t any_owner;
-  const int n_obj = fa->n_obj;
-  if (n_obj <= 0) return;
-  const MoveSet &ms = fa->ms;
-  const uint32_t n = *n_list;
-  if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms.track[threadIdx.x] : OWNER_NONE;
-  for (uint32_t pos = blockIdx.x; pos < n; pos += gridDim.x) {
-    __syncthreads();
-    if (threadIdx.x < MAX_MOVE_OBJECTS) c[threadIdx.x] = 0;
-    if (threadIdx.x == 0) any_owner = 0;
-    __syncthreads();
-    const uint32_t chunk = list[pos];
-    size_t base = (size_t)chunk * MV_CHUNK;
-    // (all 16 owner loads of the thread in flight, then the counting: four at a time were four dependent round trips)
-    uint16_t ow[MV_ITEMS];
+  __shared__ uint32_t wave_tot[MV_WAVES];
+  __shared__ uint16_t glist[MV_GROUP_CAP];
+  __shared__ uint32_t my_chunk[MV_PER_WG];
+  __shared__ uint32_t rank_cnt[MV_ITEMS][MV_WAVES][MAX_MOVE_OBJECTS];  // members per (round, wave, object), then running offsets
+  __shared__ uint32_t all_cnt[MV_ITEMS][MV_WAVES];                     // members per (round, wave), then running offsets
+  __shared__ uint32_t c_obj[MAX_MOVE_OBJECTS];                          // members per object: primary + older memberships
+  __shared__ uint32_t any_owner, n_alias_here;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  DBGM(2, 0, DBGM_T());
+  if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms_track[threadIdx.x] : OWNER_NONE;
+  // ---- 1a. the coarse level: marked groups, ascending, into glist
+  const uint32_t n_groups = (n_flags + OWNER_GROUP - 1) / OWNER_GROUP;
+  uint32_t n_marked = 0;
+  bool overflow = false;
+  for (uint32_t tile = 0; tile < n_groups; tile += TPB * 16) {  // (the level is padded to whole tiles, zero-filled)
+    const uint32_t first = tile + threadIdx.x * 16;
+    const uint4 q = *reinterpret_cast<const uint4 *>(st.owner_flag2 + first);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    uint32_t mask = 0;
 #pragma unroll
-    for (int r = 0; r < MV_ITEMS; ++r) {
-      const size_t i = base + (size_t)r * TPB + threadIdx.x;
-      ow[r] = i < n_slots ? owner[i] : OWNER_NONE;
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((w[a] >> (8 * j)) & 0xffu) mask |= 1u << (4 * a + j);
+    uint32_t total;
+    uint32_t at = n_marked + block_excl_scan((uint32_t)__popc(mask), wave_tot, total);
+    while (mask) {
+      const int j = __ffs((int)mask) - 1;
+      mask &= mask - 1;
+      if (at < MV_GROUP_CAP) glist[at] = (uint16_t)(first + (uint32_t)j);
+      ++at;
     }
+    n_marked += total;
+  }
+  if (n_marked > MV_GROUP_CAP) {
+    n_marked = MV_GROUP_CAP;
+    overflow = true;
+  }
+  __syncthreads();
+  // ---- 1b. the flag bytes of the marked groups: this workgroup's positions
+  uint32_t n_list = 0;
+  for (uint32_t g0 = 0; g0 < n_marked; g0 += TPB) {
+    const uint32_t gi = g0 + threadIdx.x;
+    unsigned long long m = 0;
+    uint32_t grp = 0;
+    if (gi < n_marked) {
+      grp = glist[gi];
+      const uint4 *src = reinterpret_cast<const uint4 *>(st.owner_flag + (size_t)grp * OWNER_GROUP);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const uint4 q = src[a];
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((w[b4] >> (8 * j)) & 0xffu) m |= 1ull << (16 * a + 4 * b4 + j);
+      }
+      if (m == 0ull && blockIdx.x == 0) st.owner_flag2[grp] = 0;  // a mark nobody needs any more
+    }
+    const uint32_t c = (uint32_t)__popcll(m);
+    uint32_t total;
+    const uint32_t at = n_list + block_excl_scan(c, wave_tot, total);
+    {  // the one position of this workgroup that can fall among the group's (at most 64 < gridDim.x) chunks
+      const uint32_t j = at > blockIdx.x ? (at - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+      const uint32_t pos = blockIdx.x + j * gridDim.x;
+      if (pos < at + c && j < (uint32_t)MV_PER_WG) my_chunk[j] = grp * OWNER_GROUP + (uint32_t)nth_set_bit(m, pos - at);
+    }
+    n_list += total;
+  }
+  if (n_list > MV_LIST_CAP) {
+    n_list = MV_LIST_CAP;
+    overflow = true;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sc.mv_nlist[0] = n_list;
+    sc.cur->move_list_overflow = (overflow || st.alias[0] > ALIAS_CAP) ? 1u : 0u;
+  }
+  __syncthreads();
+  DBGM(2, 1, DBGM_T());
+  // ---- 2. this workgroup's chunks
+  const uint32_t na_total = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t *tot = sc.mv_tot + (size_t)(mv_seq & 1u) * MAX_MOVE_OBJECTS * MV_TOT_STRIDE;
+  for (int j = 0; j < MV_PER_WG; ++j) {
+    const uint32_t pos = blockIdx.x + (uint32_t)j * gridDim.x;
+    if (pos >= n_list) break;
+    const uint32_t chunk = my_chunk[j];
+    const size_t base = (size_t)chunk * MV_CHUNK;
+    uint16_t ow[MV_ITEMS];  // the thread's sixteen owner entries, requested together
 #pragma unroll
     for (int r = 0; r < MV_ITEMS; ++r) {
-      if (ow[r] != OWNER_NONE) any_owner = 1;
+      const size_t li = base + (size_t)r * TPB + threadIdx.x;
+      ow[r] = li < n_slots ? st.owner[li] : OWNER_NONE;
+    }
+    __syncthreads();  // the LDS tables of the chunk before have been read
+    for (uint32_t k = threadIdx.x; k < (uint32_t)(MV_ITEMS * MV_WAVES * MAX_MOVE_OBJECTS); k += TPB) (&rank_cnt[0][0][0])[k] = 0;
+    if (threadIdx.x < MV_ITEMS * MV_WAVES) (&all_cnt[0][0])[threadIdx.x] = 0;
+    if (threadIdx.x < MAX_MOVE_OBJECTS) c_obj[threadIdx.x] = 0;
+    if (threadIdx.x == 0) any_owner = 0, n_alias_here = 0;
+    __syncthreads();
+    uint32_t ent[MV_ITEMS];  // object << 12 | rank among the object's members in this wave and round << 18; MV_COMPLEX: no member
+    uint32_t pre[MV_ITEMS];  // rank among the members of any object in this wave and round
+    bool some = false;
+#pragma unroll
+    for (int r = 0; r < MV_ITEMS; ++r) {
+      some = some || ow[r] != OWNER_NONE;
       const uint8_t o = obj_of(ow[r], tracks, n_obj);
-      if (o != 0xFF) atomicAdd(&c[o], 1u);
+      const bool valid = o != 0xFF;
+      const uint64_t members = __ballot(valid);
+      uint64_t peers = members;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const bool bit = (o >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+      }
+      const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
+      if (valid && rank_in_wave == 0) rank_cnt[r][wid][o] = (uint32_t)__popcll(peers);
+      if (lane == 0) all_cnt[r][wid] = (uint32_t)__popcll(members);
+      ent[r] = valid ? ((uint32_t)o << 12 | rank_in_wave << 18) : MV_COMPLEX;
+      pre[r] = (uint32_t)__popcll(members & lt_mask);
     }
-    {  // older memberships the reference's sets still hold (State::alias; nearly always none)
-      const uint32_t na = alias[0] < ALIAS_CAP ? alias[0] : ALIAS_CAP;
-      for (uint32_t k = threadIdx.x; k < na; k += blockDim.x) {
-        const uint32_t idx = alias[2 + 2 * k], trk = alias[3 + 2 * k];
+    if (some) any_owner = 1;
+    if (na_total) {  // older memberships the reference's sets still hold (block-uniform; the table is nearly always empty)
+      for (uint32_t k = threadIdx.x; k < na_total; k += TPB) {
+        const uint32_t idx = st.alias[2 + 2 * k], trk = st.alias[3 + 2 * k];
         if (trk == OWNER_NONE || idx / MV_CHUNK != chunk) continue;
         any_owner = 1;
         const uint8_t o = obj_of((uint16_t)trk, tracks, n_obj);
-        if (o != 0xFF) atomicAdd(&c[o], 1u);
+        if (o != 0xFF) {
+          atomicAdd(&c_obj[o], 1u);
+          n_alias_here = 1;
+        }
       }
     }
     __syncthreads();
-    if ((int)threadIdx.x < n_obj) cnt[(size_t)threadIdx.x * n + pos] = c[threadIdx.x];
-    if (threadIdx.x == 0 && any_owner == 0) owner_flag[chunk] = 0;
+    if ((int)threadIdx.x < n_obj) {  // running offsets in (round, wave) order = ascending slot index
+      uint32_t run = 0;
+      for (int r = 0; r < MV_ITEMS; ++r)
+#pragma unroll
+        for (int w = 0; w < MV_WAVES; ++w) {
+          const uint32_t c = rank_cnt[r][w][threadIdx.x];
+          rank_cnt[r][w][threadIdx.x] = run;
+          run += c;
+        }
+      const uint32_t c = run + c_obj[threadIdx.x];
+      sc.mv_cnt[(size_t)threadIdx.x * MV_LIST_CAP + pos] = c;
+      if (c) atomicAdd(&tot[threadIdx.x * MV_TOT_STRIDE], c);
+    } else if (threadIdx.x == 64) {
+      uint32_t run = 0;
+      for (int r = 0; r < MV_ITEMS; ++r)
+#pragma unroll
+        for (int w = 0; w < MV_WAVES; ++w) {
+          const uint32_t c = all_cnt[r][w];
+          all_cnt[r][w] = run;
+          run += c;
+        }
+      sc.mv_nmem[pos] = n_alias_here ? MV_COMPLEX : run;
+      // A flagged chunk that holds no owner any more loses its flag - in k_move_apply, not here: other workgroups of this
+      // launch may still be reading the flags, and they all have to see the same list.
+      sc.mv_list[pos] = chunk | (any_owner == 0 ? MV_CLEAR_FLAG : 0u);
+    }
+    __syncthreads();
+    if (!n_alias_here) {
+      uint32_t *mem = sc.mv_mem + (size_t)pos * MV_CHUNK;
+#pragma unroll
+      for (int r = 0; r < MV_ITEMS; ++r) {
+        if (ent[r] == MV_COMPLEX) continue;
+        const uint32_t o = (ent[r] >> 12) & 63u;
+        const uint32_t rank = (ent[r] >> 18) + rank_cnt[r][wid][o];
+        mem[all_cnt[r][wid] + pre[r]] = ((uint32_t)r * TPB + threadIdx.x) | o << 12 | rank << 18;
+      }
+    }
+    DBGM(2, 2, DBGM_T());
   }
+  DBGM(2, 3, DBGM_T());
+}
+__global__ __launch_bounds__(TPB) void k_move_members(State st, MembersArgs ma, const FrameArgs *__restrict__ fa) {
+  const int n_obj = fa->n_obj;
+  if (n_obj <= 0) return;  // no object moves in this frame
+  move_members_body(st, ma, ma.n_flags, ma.n_slots, n_obj, fa->ms.track, fa->mv_seq);
+}
+// The same as the first kernel of a chain of its own (sharded maps: the member count starts behind the PREVIOUS frame's
+// births on its own stream, and the all-gather of the counts rides that stream): the frame block arrives by value - every
+// workgroup reads what it needs from the kernel arguments - and is stored for the chain's other kernel.
+__global__ __launch_bounds__(TPB) void k_move_members_v(State st, MembersArgs ma, const FrameArgs src, FrameArgs *__restrict__ dst) {
+  if (blockIdx.x == 0) {
+    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(&src);
+    uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+    for (uint32_t i = threadIdx.x; i < sizeof(FrameArgs) / 4; i += blockDim.x) d4[i] = s4[i];
+  }
+  if (src.n_obj <= 0) return;
+  move_members_body(st, ma, ma.n_flags, ma.n_slots, src.n_obj, src.ms.track, src.mv_seq);
+}
+
+// First kernel of a frame on the main stream: the frame's scalars (pose, ring state, stamp updates, object motions,
+// removals, input pointers) arrive by value and are stored where the frame's other kernels read them (FrameArgs,
+// sdm_scratch.h) - and, inside a graph, in the side chains' block too; the per-frame counters and the per-pixel bin
+// counts are zeroed, the recycled slabs get their stamps and their voxels' results (mark_slab_voxel_dirty).
+// with_members: the SAME launch is the member count of the frame's moving objects (move_members_body reads the object
+// list from the kernel arguments).  A whole map needs nothing from anybody between the previous frame's sweep and this
+// frame's k_move_apply but this one launch; round 3 ran the count as a chain of three launches on a stream of its own
+// and k_move_apply started 25-32 us after the sweep had ended (two event hand-overs, the chain's gaps).
+__global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__restrict__ bin_count, uint32_t n_bins,
+                                                      State st, const FrameArgs src, FrameArgs *__restrict__ dst_main,
+                                                      FrameArgs *__restrict__ dst_side, Dims d, uint32_t slab_max, MembersArgs ma,
+                                                      int with_members) {
+  const StampUpdates &su = src.su;
+  if (blockIdx.x == gridDim.x - 1) {
+    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(&src);
+    uint32_t *m4 = reinterpret_cast<uint32_t *>(dst_main), *e4 = reinterpret_cast<uint32_t *>(dst_side);
+    for (uint32_t k = threadIdx.x; k < sizeof(FrameArgs) / 4; k += blockDim.x) {
+      m4[k] = s4[k];
+      if (e4) e4[k] = s4[k];
+    }
+  }
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t t = i; t < slab_max * (uint32_t)su.n; t += gridDim.x * blockDim.x) mark_slab_voxel_dirty(d, st, su, slab_max, t);
+  if (i < offsetof(Counters, flood_complex) / 4) reinterpret_cast<uint32_t *>(cnt)[i] = 0;  // the flood flags belong to the frustum chain
+  if (i < (uint32_t)su.n) {  // this frame's recycled slabs (no host-to-device copy of the stamp arrays)
+    const uint32_t e = su.entry[i], axis = e >> 12, idx = e & 0xfffu;
+    uint32_t *arr = axis == 0 ? st.stamps_x : (axis == 1 ? st.stamps_y : st.stamps_z);
+    arr[idx] = su.value;
+  }
+  for (; i < n_bins; i += gridDim.x * blockDim.x) bin_count[i] = 0;
+  if (with_members && src.n_obj > 0) move_members_body(st, ma, ma.n_flags, ma.n_slots, src.n_obj, src.ms.track, src.mv_seq);
 }
 
 // ---- global ranks across Z-slab shards ------------------------------------------------------------------
@@ -256,43 +349,29 @@ struct HaloRecord {
 };
 static_assert(sizeof(HaloRecord) == HALO_RECORD_BYTES, "halo record layout");
 
-__global__ void k_move_local_counts(const uint32_t *__restrict__ offs, int32_t *counts_local, Scratch sc, const FrameArgs *__restrict__ fa) {
-  int k = threadIdx.x;
+__global__ void k_move_local_counts(int32_t *counts_local, Scratch sc, const FrameArgs *__restrict__ fa) {
+  const int k = threadIdx.x;
   const int n_obj = fa->n_obj;  // (runs with the member count, on its stream)
   // this frame's export counters, one per destination shard
   const uint32_t world = sc.halo_world;
-  if (sc.halo_send && (uint32_t)k < world) *reinterpret_cast<uint32_t *>(sc.halo_send + (size_t)k * halo_segment_bytes(sc.halo_cap)) = 0;
+  if (sc.halo_send)
+    for (uint32_t dst = (uint32_t)k; dst < world; dst += blockDim.x)
+      *reinterpret_cast<uint32_t *>(sc.halo_send + (size_t)dst * halo_segment_bytes(sc.halo_cap)) = 0;
   if (k >= HALO_OBJ) return;
-  const uint32_t nl = *sc.mv_nlist;  // row length of the count matrix
-  counts_local[k] = k < n_obj ? (int32_t)(offs[(size_t)(k + 1) * nl] - offs[(size_t)k * nl]) : 0;
+  const uint32_t *tot = sc.mv_tot + (size_t)(fa->mv_seq & 1u) * MAX_MOVE_OBJECTS * MV_TOT_STRIDE;
+  counts_local[k] = k < n_obj ? (int32_t)tot[k * MV_TOT_STRIDE] : 0;
 }
 
 constexpr uint32_t MV_NIL = 0xffffffffu;
 
-// A moved copy of global rank e joins the list of its target voxel (push-front; the replay restores rank order).
-// The copy that finds the list idle also enters the voxel in this frame's work list.
-// (The work list's cursor is ONE word: an atomic per touched voxel on it retires at ~12 ns each, a few thousand per frame -
-// that was most of k_move_apply's time.  A workgroup therefore collects its new voxels in LDS - vox_list / vox_n - and
-// reserves their places with one atomic, flush_move_voxels; callers without such a list pass nullptr.)
-__device__ __forceinline__ void move_link(const Dims &d, const Scratch &sc, uint32_t v, uint32_t e, uint32_t *vox_list = nullptr,
-                                          uint32_t *vox_n = nullptr) {
+// A moved copy of global rank e joins the list of its target voxel (push-front; the replay restores rank order).  The copy
+// itself says where it went (MoveCopy::voxel), so the replay needs no list of touched voxels: the thread of the copy a
+// list's head points at replays the list.  (Round 3 kept such a list: an atomic per touched voxel on one word, then one
+// per workgroup through LDS plus a flush - two more dependent steps at the end of k_move_apply.)
+__device__ __forceinline__ void move_link(const Dims &d, const Scratch &sc, uint32_t v, uint32_t e) {
   const uint32_t lv = v - d.v_begin;
   const uint32_t prev = atomicExch(&sc.mv_head[lv], e);
   sc.mv_next[e] = prev;
-  if (prev == MV_NIL) {
-    if (vox_list) vox_list[atomicAdd(vox_n, 1u)] = lv;
-    else sc.mv_vlist[atomicAdd(&sc.cnt->n_move_voxels, 1u)] = lv;
-  }
-}
-// all threads of the workgroup; vox_base is an LDS word
-__device__ __forceinline__ void flush_move_voxels(const Scratch &sc, const uint32_t *vox_list, uint32_t *vox_n, uint32_t *vox_base) {
-  __syncthreads();
-  const uint32_t n = *vox_n;
-  if (threadIdx.x == 0 && n) *vox_base = atomicAdd(&sc.cnt->n_move_voxels, n);
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) sc.mv_vlist[*vox_base + i] = vox_list[i];
-  __syncthreads();
-  if (threadIdx.x == 0) *vox_n = 0;
 }
 
 // one member of moving object `obj`, global rank e, local slot li
@@ -309,24 +388,30 @@ struct MoveLoaded {
   uint16_t ts, track;
   uint8_t label, status;
 };
-__device__ __forceinline__ MoveLoaded move_load(const Dims &d, const Filter &flt, const State &st, long long cursor, uint32_t e,
-                                                size_t li, bool copy_invalid) {
-  MoveLoaded m;
+// (in two steps: the particle's own fields need its slot only, the noise draw its global rank)
+__device__ __forceinline__ void move_load_particle(const Dims &d, const State &st, size_t li, bool copy_invalid, MoveLoaded &m) {
   m.p = st.pos4[li];
-  const long long draw = cursor + 3ll * e;
-  m.n[0] = st.noise[(draw + 1) % flt.noise_n];
-  m.n[1] = st.noise[(draw + 2) % flt.noise_n];
-  m.n[2] = st.noise[(draw + 3) % flt.noise_n];
   m.w = st.w[rec_index(li, d.p_n, REC_W)];
   m.ts = st.ts[rec_index(li, d.p_n, REC_TS)];
   m.track = st.track[rec_index(li, d.p_n, REC_TRACK)];
   m.label = st.label[rec_index(li, d.p_n, REC_LABEL)];
   m.status = copy_invalid ? (uint8_t)ST_INVALID : st.status[rec_index(li, d.p_n, REC_STATUS)];
+}
+__device__ __forceinline__ void move_load_noise(const Filter &flt, const State &st, long long cursor, uint32_t e, MoveLoaded &m) {
+  const long long draw = cursor + 3ll * e;
+  m.n[0] = st.noise[(draw + 1) % flt.noise_n];
+  m.n[1] = st.noise[(draw + 2) % flt.noise_n];
+  m.n[2] = st.noise[(draw + 3) % flt.noise_n];
+}
+__device__ __forceinline__ MoveLoaded move_load(const Dims &d, const Filter &flt, const State &st, long long cursor, uint32_t e,
+                                                size_t li, bool copy_invalid) {
+  MoveLoaded m;
+  move_load_particle(d, st, li, copy_invalid, m);
+  move_load_noise(flt, st, cursor, e, m);
   return m;
 }
 __device__ __forceinline__ void move_store(const Dims &d, const Frame &f, const MoveSet &ms, const State &st, const Scratch &sc,
-                                           const MoveLoaded &m, int obj, uint32_t e, size_t li, bool alias, uint32_t *vox_list,
-                                           uint32_t *vox_n) {
+                                           const MoveLoaded &m, int obj, uint32_t e, size_t li, bool alias) {
   const float4 p = m.p;
   const float *T = ms.T[obj];
   float nx = row4(T + 0, p.x, p.y, p.z);
@@ -359,9 +444,9 @@ __device__ __forceinline__ void move_store(const Dims &d, const Frame &f, const 
     c.owner = powner;
     c.label = plabel;
     c.status = pstatus;
-    c.pad = 0;
+    c.voxel = v - d.v_begin;
     sc.mv_copy[e] = c;
-    move_link(d, sc, v, e, vox_list, vox_n);
+    move_link(d, sc, v, e);
   } else if (sc.halo_send) {  // crosses into another slab: export to the shard that owns it
     unsigned char *seg = sc.halo_send + (size_t)(rz / d.rz_count) * halo_segment_bytes(sc.halo_cap);
     uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(seg), 1u);
@@ -379,14 +464,15 @@ __device__ __forceinline__ void move_store(const Dims &d, const Frame &f, const 
       reinterpret_cast<HaloRecord *>(seg + HALO_HEADER_BYTES)[k] = r;
     } else {
       sc.cnt->overflow = 1;
+      atomicAdd(&sc.cnt->n_halo_dropped, 1u);
     }
   }
 }
 __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms, const State &st,
                                          const Scratch &sc, int obj, uint32_t e, size_t li, bool alias = false,
-                                         bool copy_invalid = false, uint32_t *vox_list = nullptr, uint32_t *vox_n = nullptr) {
+                                         bool copy_invalid = false) {
   const MoveLoaded m = move_load(d, flt, st, (long long)sc.cur->move_cursor, e, li, copy_invalid);
-  move_store(d, f, ms, st, sc, m, obj, e, li, alias, vox_list, vox_n);
+  move_store(d, f, ms, st, sc, m, obj, e, li, alias);
 }
 
 // One round (TPB consecutive slots) of k_move_apply in a chunk that holds older set memberships (State::alias): a slot can
@@ -449,185 +535,168 @@ __device__ __forceinline__ void move_round_with_aliases(const Dims &d, const Fra
 }
 
 // phase 1 of moveParticlesInSetsByTransformations (operations.h:331-349): copy, transform + table noise, delete the
-// original.  One workgroup per flagged chunk: the members of every moving object are ranked in ascending index order
-// (ballot ranks inside a wave, wave counts through LDS, chunk offsets from the scanned count matrix), which gives each
-// its global rank e = rank among all members of all moving objects in (object, shard, index) order.  The noise
-// cursor advances by three per particle in that order; the copy joins its target voxel's list or is exported.
-__global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st, Scratch sc, const uint32_t *__restrict__ offs,
-                                                    const int32_t *__restrict__ counts_all, int world, int rank) {
+// original.  One workgroup per listed chunk, one thread per member (k_move_members listed and ranked them).  A member's
+// global rank e = rank among all members of all moving objects in (object, shard, index) order:
+//   members of the objects before its own (mv_tot, or the gathered counts of all shards)
+// + members of its own object on the shards before this one
+// + members of its object in the listed chunks before this one (the workgroup adds up that row of mv_cnt)
+// + its rank in the chunk.
+// The noise cursor advances by three per particle in that order; the copy joins its target voxel's list or is exported.
+// Chunks with older set memberships (MV_COMPLEX) are ranked here, round by round, on the alias path.
+__global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st, Scratch sc, const int32_t *__restrict__ counts_all,
+                                                    int world, int rank) {
+  // Everything whose address depends on nothing but the workgroup's first position goes out before the first value is
+  // looked at (a dependent fetch costs 1-2 us in these short kernels, whatever its size): the chunk's member count, its
+  // first members, its per-object counts, both parities of the per-object totals.  Beyond the list they are garbage
+  // nobody looks at (the arrays hold MV_LIST_CAP positions, the grid is smaller).
+  uint32_t pos = blockIdx.x;
+  uint32_t nm = sc.mv_nmem[pos], listed = sc.mv_list[pos];
+  uint32_t first_entry = sc.mv_mem[(size_t)pos * MV_CHUNK + threadIdx.x];
+  uint32_t my_c = threadIdx.x < MAX_MOVE_OBJECTS ? sc.mv_cnt[(size_t)threadIdx.x * MV_LIST_CAP + pos] : 0u;
+  uint32_t tot2[2] = {0u, 0u};
+  if (threadIdx.x < MAX_MOVE_OBJECTS) {
+    tot2[0] = sc.mv_tot[(size_t)threadIdx.x * MV_TOT_STRIDE];
+    tot2[1] = sc.mv_tot[((size_t)MAX_MOVE_OBJECTS + threadIdx.x) * MV_TOT_STRIDE];
+  }
+  const long long cursor = (long long)sc.cur->move_cursor;  // (advanced by k_move_replay, after this kernel)
+  const uint32_t n = *sc.mv_nlist;
+  const uint32_t na_raw = st.alias[0];
   const int n_obj = sc.fa->n_obj;
   if (n_obj <= 0) return;
   DBGM(0, 0, DBGM_T());
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   const MoveSet &ms = sc.fa->ms;
+  const uint32_t par = sc.fa->mv_seq & 1u;
   __shared__ uint32_t obj_base[MAX_MOVE_OBJECTS];  // global rank of the object's next member in this chunk
+  __shared__ uint32_t obj_first[MAX_MOVE_OBJECTS]; // global rank of the object's first member on this shard
+  __shared__ uint32_t c_here[MAX_MOVE_OBJECTS];    // the object's members in this chunk
+  __shared__ uint32_t tot_l[MAX_MOVE_OBJECTS];     // the object's members on this shard
   __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
   __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
-  __shared__ uint32_t e_shift[MAX_MOVE_OBJECTS];   // global rank of the object's first local member - its local offset
-  __shared__ uint32_t block_total;
   __shared__ uint32_t ca_idx[CA_CAP], ca_ent[CA_CAP], ca_n;
   __shared__ uint8_t ca_obj[CA_CAP];
-  __shared__ uint32_t vox_list[MV_CHUNK], vox_n, vox_base;  // voxels that got their first copy from this chunk
-  __shared__ uint32_t my_e[MV_ITEMS][TPB];                  // global rank of the member in slot r * TPB + thread of the chunk, MV_NIL: none
-  __shared__ uint8_t my_o[MV_ITEMS][TPB];                   // ... and its object
-  __shared__ uint32_t rank_cnt[MV_ITEMS][MV_WAVES][MAX_MOVE_OBJECTS];  // members per (round, wave, object), then their running offsets
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (threadIdx.x == 0) vox_n = 0;
-  const uint32_t n = *sc.mv_nlist;
   const size_t n_slots = (size_t)d.v_count * d.S;
-  if (threadIdx.x < MAX_MOVE_OBJECTS) tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms.track[threadIdx.x] : OWNER_NONE;
+  if (threadIdx.x < MAX_MOVE_OBJECTS) {
+    tracks[threadIdx.x] = (int)threadIdx.x < n_obj ? ms.track[threadIdx.x] : OWNER_NONE;
+    tot_l[threadIdx.x] = (int)threadIdx.x < n_obj ? tot2[par] : 0u;
+  }
+  __syncthreads();
   if ((int)threadIdx.x < n_obj) {
-    // e = sum_{k'<k} sum_r' C[r'][k'] + sum_{r'<rank} C[r'][k] + j.  Single shard: the scanned count matrix already
-    // is that prefix (shift 0).
-    uint32_t shift = 0;
+    uint32_t run = 0;
     if (counts_all) {
-      uint32_t run = 0;
       for (int k = 0; k < (int)threadIdx.x; ++k)
         for (int r = 0; r < world; ++r) run += (uint32_t)counts_all[r * HALO_OBJ + k];
       for (int r = 0; r < rank; ++r) run += (uint32_t)counts_all[r * HALO_OBJ + threadIdx.x];
-      shift = run - offs[(size_t)threadIdx.x * n];
-    }
-    e_shift[threadIdx.x] = shift;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    uint32_t total = 0;
-    if (counts_all) {
-      for (int k = 0; k < n_obj; ++k)
-        for (int r = 0; r < world; ++r) total += (uint32_t)counts_all[r * HALO_OBJ + k];
     } else {
-      total = offs[(size_t)n_obj * n];
+      for (int k = 0; k < (int)threadIdx.x; ++k) run += tot_l[k];
     }
-    sc.cnt->n_moved = total;
-    if (total > sc.cap_move || sc.cur->move_list_overflow) sc.cnt->overflow = 1;
+    obj_first[threadIdx.x] = run;
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      uint32_t total = 0;
+      if (counts_all) {
+        for (int k = 0; k < n_obj; ++k)
+          for (int r = 0; r < world; ++r) total += (uint32_t)counts_all[r * HALO_OBJ + k];
+      } else {
+        for (int k = 0; k < n_obj; ++k) total += tot_l[k];
+      }
+      sc.cnt->n_moved = total;
+      if (total > sc.cap_move || sc.cur->move_list_overflow) sc.cnt->overflow = 1;
+    }
+    // the totals of the next frame with moving objects start at zero (its member count runs after this kernel)
+    if (threadIdx.x < MAX_MOVE_OBJECTS) sc.mv_tot[((size_t)(par ^ 1u) * MAX_MOVE_OBJECTS + threadIdx.x) * MV_TOT_STRIDE] = 0;
   }
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const uint32_t na_total = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
-  for (uint32_t pos = blockIdx.x; pos < n; pos += gridDim.x) {
-    __syncthreads();
-    if (threadIdx.x == 0) block_total = 0;
-    __syncthreads();
-    if ((int)threadIdx.x < n_obj) {
-      uint32_t o0 = offs[(size_t)threadIdx.x * n + pos];
-      uint32_t o1 = offs[(size_t)threadIdx.x * n + pos + 1];  // next position (or next object's first)
-      obj_base[threadIdx.x] = o0 + e_shift[threadIdx.x];
-      if (o1 != o0) atomicAdd(&block_total, o1 - o0);
-    }
-    __syncthreads();
-    if (block_total == 0) continue;  // no member of any moving object in this chunk
-    const uint32_t chunk = sc.mv_list[pos];
+  const uint32_t na_total = na_raw < ALIAS_CAP ? na_raw : ALIAS_CAP;
+  while (pos < n) {
+    const uint32_t chunk = listed & ~MV_CLEAR_FLAG;
     const size_t base = (size_t)chunk * MV_CHUNK;
-    // older memberships of moving objects inside this chunk (State::alias): slot, object rank, entry
-    uint32_t n_ca = 0;
-    if (na_total) {  // (block-uniform; the table is empty in nearly every frame)
-      if (threadIdx.x == 0) ca_n = 0;
-      __syncthreads();
-      for (uint32_t k = threadIdx.x; k < na_total; k += blockDim.x) {
-        const uint32_t idx = st.alias[2 + 2 * k], trk = st.alias[3 + 2 * k];
-        if (trk == OWNER_NONE || idx / MV_CHUNK != chunk) continue;
-        const uint8_t o = obj_of((uint16_t)trk, tracks, n_obj);
-        if (o == 0xFF) continue;
-        const uint32_t c = atomicAdd(&ca_n, 1u);
-        if (c < CA_CAP) {
-          ca_idx[c] = idx;
-          ca_obj[c] = o;
-          ca_ent[c] = k;
-        }
-      }
-      __syncthreads();
-      n_ca = ca_n < CA_CAP ? ca_n : CA_CAP;
-      if (threadIdx.x == 0 && ca_n > CA_CAP) sc.cnt->overflow = 1;
-    }
-    if (n_ca == 0) {
-      // The usual case: every slot belongs to at most one moving object.  Ranks in three steps with two barriers (round 2
-      // ranked round by round: 48 barriers per chunk, each owner load behind the barrier before it):
-      //   1. every wave ranks its 64 slots of each of the 16 rounds by ballot and notes how many members of which object it
-      //      saw - rank_cnt[round][wave][object]; nothing waits for anybody, the 16 owner loads of a thread overlap;
-      //   2. one thread per object turns its 64 counts into running offsets, in (round, wave) order = ascending slot index;
-      //   3. a member's global rank = the object's first rank in this chunk + the offset of its (round, wave) + its rank in the wave.
-      for (uint32_t k = threadIdx.x; k < (uint32_t)(MV_ITEMS * MV_WAVES * MAX_MOVE_OBJECTS); k += TPB) (&rank_cnt[0][0][0])[k] = 0;
-      __syncthreads();
-      uint16_t ow[MV_ITEMS];  // the thread's sixteen owner entries, requested together
+    __syncthreads();  // the LDS tables of the chunk before have been read (and obj_first is there)
+    if ((int)threadIdx.x < n_obj) c_here[threadIdx.x] = my_c;
+    if (threadIdx.x == 0 && (listed & MV_CLEAR_FLAG)) st.owner_flag[chunk] = 0;  // no owner in the chunk any more
+    // the thread's member of the chunk (nearly always the only one: a chunk holds a dozen members on average): its own
+    // fields are requested before the ranks are known
+    MoveLoaded ml;
+    const bool simple = nm != MV_COMPLEX;
+    const bool mine = simple && threadIdx.x < nm;
+    if (mine) move_load_particle(d, st, base + (first_entry & 4095u), false, ml);
+    __syncthreads();
+    if (nm != 0) {  // (workgroup-uniform)
+      // the object's members in the chunks before this one: every wave takes the objects of its number
+      for (int k = wid; k < n_obj; k += MV_WAVES) {
+        if (c_here[k] == 0) continue;  // (wave-uniform)
+        uint32_t sum = 0;
+        const uint32_t *row = sc.mv_cnt + (size_t)k * MV_LIST_CAP;
+        for (uint32_t p = (uint32_t)lane; p < pos; p += 64) sum += row[p];
 #pragma unroll
-      for (int r = 0; r < MV_ITEMS; ++r) {
-        const size_t li = base + (size_t)r * TPB + threadIdx.x;
-        ow[r] = li < n_slots ? st.owner[li] : OWNER_NONE;
-      }
-#pragma unroll
-      for (int r = 0; r < MV_ITEMS; ++r) {
-        const uint8_t o = obj_of(ow[r], tracks, n_obj);
-        const bool valid = o != 0xFF;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          bool bit = (o >> b) & 1u;
-          uint64_t m = __ballot(bit);
-          peers &= bit ? m : ~m;
-        }
-        const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
-        if (valid && rank_in_wave == 0) rank_cnt[r][wid][o] = (uint32_t)__popcll(peers);
-        my_e[r][threadIdx.x] = valid ? rank_in_wave : MV_NIL;
-        my_o[r][threadIdx.x] = o;
-      }
-      __syncthreads();
-      if ((int)threadIdx.x < n_obj) {
-        uint32_t run = obj_base[threadIdx.x];
-        for (int r = 0; r < MV_ITEMS; ++r)
-#pragma unroll
-          for (int w = 0; w < MV_WAVES; ++w) {
-            const uint32_t c = rank_cnt[r][w][threadIdx.x];
-            rank_cnt[r][w][threadIdx.x] = run;
-            run += c;
-          }
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (lane == 0) obj_base[k] = obj_first[k] + sum;
       }
       __syncthreads();
       DBGM(0, 1, DBGM_T());
-    } else {
-      for (int r = 0; r < MV_ITEMS; ++r) {
-        if (threadIdx.x < MAX_MOVE_OBJECTS) {
-#pragma unroll
-          for (int w = 0; w < MV_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+      if (simple) {
+        if (mine) {
+          const uint32_t o = (first_entry >> 12) & 63u;
+          const uint32_t e = obj_base[o] + (first_entry >> 18);
+          move_load_noise(flt, st, cursor, e, ml);
+          move_store(d, f, ms, st, sc, ml, (int)o, e, base + (first_entry & 4095u), false);
+        }
+        for (uint32_t i = TPB + threadIdx.x; i < nm; i += TPB) {  // (a chunk with more than 256 members)
+          const uint32_t en = sc.mv_mem[(size_t)pos * MV_CHUNK + i];
+          const uint32_t o = (en >> 12) & 63u;
+          move_one(d, f, flt, ms, st, sc, (int)o, obj_base[o] + (en >> 18), base + (en & 4095u));
+        }
+        DBGM(0, 2, DBGM_T());
+      } else {
+        // older memberships of moving objects inside this chunk (State::alias): slot, object rank, entry
+        if (threadIdx.x == 0) ca_n = 0;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < na_total; k += blockDim.x) {
+          const uint32_t idx = st.alias[2 + 2 * k], trk = st.alias[3 + 2 * k];
+          if (trk == OWNER_NONE || idx / MV_CHUNK != chunk) continue;
+          const uint8_t o = obj_of((uint16_t)trk, tracks, n_obj);
+          if (o == 0xFF) continue;
+          const uint32_t c = atomicAdd(&ca_n, 1u);
+          if (c < CA_CAP) {
+            ca_idx[c] = idx;
+            ca_obj[c] = o;
+            ca_ent[c] = k;
+          }
         }
         __syncthreads();
-        const size_t li = base + (size_t)r * TPB + threadIdx.x;
-        move_round_with_aliases(d, f, flt, ms, st, sc, li, n_slots, n_obj, tracks, obj_base, wave_cnt, ca_idx, ca_ent, ca_obj, n_ca,
-                                lt_mask, wid);
-        __syncthreads();
-        if (threadIdx.x < MAX_MOVE_OBJECTS) {
-          uint32_t add = 0;
+        const uint32_t n_ca = ca_n < CA_CAP ? ca_n : CA_CAP;
+        if (threadIdx.x == 0 && ca_n > CA_CAP) sc.cnt->overflow = 1;
+        for (int r = 0; r < MV_ITEMS; ++r) {
+          if (threadIdx.x < MAX_MOVE_OBJECTS) {
 #pragma unroll
-          for (int w = 0; w < MV_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
-          obj_base[threadIdx.x] += add;
+            for (int w = 0; w < MV_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+          }
+          __syncthreads();
+          const size_t li = base + (size_t)r * TPB + threadIdx.x;
+          move_round_with_aliases(d, f, flt, ms, st, sc, li, n_slots, n_obj, tracks, obj_base, wave_cnt, ca_idx, ca_ent, ca_obj, n_ca,
+                                  lt_mask, wid);
+          __syncthreads();
+          if (threadIdx.x < MAX_MOVE_OBJECTS) {
+            uint32_t add = 0;
+#pragma unroll
+            for (int w = 0; w < MV_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
+            obj_base[threadIdx.x] += add;
+          }
+          __syncthreads();
         }
-        __syncthreads();
       }
     }
-    // The moves themselves, outside the rounds: a move is a chain of dependent loads (position, noise, record) in a few
-    // lanes, and inside a round every barrier waited for the slowest of them - sixteen times per chunk.  Four members at a
-    // time: all their loads, then their stores.  (Ranks and objects wait in LDS: sixteen copies of the move code, which
-    // register arrays would need, are 47 K instructions.)
-    if (n_ca == 0) {
-      const long long cursor = (long long)sc.cur->move_cursor;  // (advanced by k_move_replay, after this kernel)
-#pragma unroll 1
-      for (int r0 = 0; r0 < MV_ITEMS; r0 += 4) {
-        MoveLoaded ml[4];
-        uint32_t e4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          e4[u] = my_e[r0 + u][threadIdx.x];  // rank in its wave so far
-          if (e4[u] != MV_NIL) e4[u] += rank_cnt[r0 + u][wid][my_o[r0 + u][threadIdx.x]];
-          if (e4[u] != MV_NIL) ml[u] = move_load(d, flt, st, cursor, e4[u], base + (size_t)(r0 + u) * TPB + threadIdx.x, false);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (e4[u] != MV_NIL)
-            move_store(d, f, ms, st, sc, ml[u], (int)my_o[r0 + u][threadIdx.x], e4[u], base + (size_t)(r0 + u) * TPB + threadIdx.x, false,
-                       vox_list, &vox_n);
-      }
-      DBGM(0, 2, DBGM_T());
-      flush_move_voxels(sc, vox_list, &vox_n, &vox_base);  // (n_ca is workgroup-uniform)
-      DBGM(0, 3, DBGM_T());
+    pos += gridDim.x;
+    if (pos < n) {
+      nm = sc.mv_nmem[pos];
+      listed = sc.mv_list[pos];
+      first_entry = sc.mv_mem[(size_t)pos * MV_CHUNK + threadIdx.x];
+      my_c = threadIdx.x < MAX_MOVE_OBJECTS ? sc.mv_cnt[(size_t)threadIdx.x * MV_LIST_CAP + pos] : 0u;
     }
   }
+  DBGM(0, 3, DBGM_T());
 }
 
 // import the records other shards exported into this slab (blockIdx.y = source shard; segment s of the receive buffer is
@@ -658,43 +727,58 @@ __global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int wor
     c.owner = (uint16_t)(r.owner_label_status & 0xffffu);
     c.label = (uint8_t)((r.owner_label_status >> 16) & 0xffu);
     c.status = (uint8_t)(r.owner_label_status >> 24);
-    c.pad = 0;
+    c.voxel = r.voxel - d.v_begin;
     sc.mv_copy[e] = c;
     move_link(d, sc, r.voxel, e);
   }
 }
 
 // phase 2 (operations.h:351-361): re-insert the copies, first vacant slot, in (object, index) order = ascending global
-// rank.  One thread per target voxel: it walks the voxel's list, picks the next S-1 ranks in ascending order, replays
-// them, and repeats while the voxel still has a vacant slot (a copy whose own stamp is older than the slab's leaves
-// its slot vacant, so a list can be longer than the voxel; once the voxel is full every later copy is dropped,
-// operations.h:357).  The list head is left idle again.
+// rank.  One thread per COPY: it looks up its target voxel's list head, and the one copy the head points at walks the
+// list, picks the next S-1 ranks in ascending order, replays them, and repeats while the voxel still has a vacant slot (a
+// copy whose own stamp is older than the slab's leaves its slot vacant, so a list can be longer than the voxel; once the
+// voxel is full every later copy is dropped, operations.h:357).  The list head is left idle again.  (Copies that left
+// the map, went to another shard or belong to other shards' members were not written this frame: whatever their entry
+// holds, no list head of this frame points at it.)
+constexpr int RP_TPB = 64;
+constexpr int RP_GRID = 1024;
 template <int S>
-__global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State st, Scratch sc) {
+__global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, State st, Scratch sc) {
+  // (the thread's copy and its successor on the list: their addresses depend on the thread's number only, so they are
+  // requested before anything else is looked at - stale or garbage beyond this frame's copies, where nobody looks)
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  MoveCopy c0;
+  c0.voxel = MV_NIL;
+  uint32_t nx0 = MV_NIL;
+  if (t < sc.cap_move) {
+    c0 = sc.mv_copy[t];
+    nx0 = sc.mv_next[t];
+  }
+  const uint32_t n_alias = st.alias[0];
   if (sc.fa->n_obj <= 0) return;
+  const uint32_t n_moved = sc.cnt->n_moved;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // the table cursor of RingBufferOperations::gaussian_random_calculator_ advanced by three per moved particle
-    long long c = (long long)sc.cur->move_cursor + 3ll * (long long)sc.cnt->n_moved;
+    long long c = (long long)sc.cur->move_cursor + 3ll * (long long)n_moved;
     sc.cur->move_cursor = (int32_t)(c % flt.noise_n);
   }
-  const uint32_t n_vox = sc.cnt->n_move_voxels;
+  const uint32_t n_copies = n_moved < sc.cap_move ? n_moved : sc.cap_move;
   const uint32_t epoch = sc.fa->f.epoch;
   const uint32_t stride = gridDim.x * blockDim.x;
+  const bool overflow = sc.cnt->overflow != 0;
   __shared__ uint32_t n_ok_block;  // (statistic: one global atomic per workgroup, not per voxel)
   if (threadIdx.x == 0) n_ok_block = 0;
   __syncthreads();
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_vox; t += stride) {
+  for (; t < n_copies; t += stride, c0 = t < n_copies ? sc.mv_copy[t] : c0, nx0 = t < n_copies ? sc.mv_next[t] : nx0) {
     DBGM(1, 0, DBGM_T());
-    const uint32_t lv = sc.mv_vlist[t];
+    const uint32_t lv = c0.voxel;
+    if (lv >= d.v_count) continue;
+    // the list head, and - requested with it, whoever turns out to be the head - the voxel's rows
     const uint32_t head = sc.mv_head[lv];
-    sc.mv_head[lv] = MV_NIL;
-    if (sc.cnt->overflow) continue;
     const uint32_t v = d.v_begin + lv;
     uint32_t rx, ry, rz;
     voxel_to_ring(d, v, rx, ry, rz);
     uint32_t a = st.stamps_x[rx], b = st.stamps_y[ry], c = st.stamps_z[rz];
-    uint32_t smax = a > b ? a : b;
-    smax = smax > c ? smax : c;
     const size_t base = (size_t)lv * S;
     uint8_t stv[S];
     uint16_t tsv[S];
@@ -703,7 +787,11 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
     // the voxel's owner entries and the length of the table of older memberships, with the rows above (owner_insert_local)
     uint16_t own[S];
     __builtin_memcpy(own, st.owner + base, 2 * S);
-    const uint32_t n_alias = st.alias[0];
+    if (head != t) continue;  // another copy replays this voxel's list (or the entry is a stale one)
+    sc.mv_head[lv] = MV_NIL;
+    if (overflow) continue;
+    uint32_t smax = a > b ? a : b;
+    smax = smax > c ? smax : c;
     bool alias_touched = false;
     uint32_t n_ok = 0;
     bool more = true, full = false;
@@ -713,7 +801,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
 #pragma unroll
       for (int i = 0; i < S - 1; ++i) best[i] = MV_NIL;
       uint32_t n_above = 0;  // ranks above `last` on the list
-      for (uint32_t cur = head; cur != MV_NIL; cur = sc.mv_next[cur]) {
+      for (uint32_t cur = head; cur != MV_NIL; cur = cur == t ? nx0 : sc.mv_next[cur]) {
         if ((long long)cur <= last) continue;
         ++n_above;
         uint32_t x = cur;
@@ -730,7 +818,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
       MoveCopy cc[S - 1];  // the batch's copies, requested together
 #pragma unroll
       for (int u = 0; u < S - 1; ++u)
-        if (best[u] != MV_NIL) cc[u] = sc.mv_copy[best[u]];
+        if (best[u] != MV_NIL && best[u] != t) cc[u] = sc.mv_copy[best[u]];
 #pragma unroll
       for (int u = 0; u < S - 1; ++u) {
         const uint32_t e = best[u];
@@ -744,7 +832,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
           full = true;
           break;
         }
-        const MoveCopy c = cc[u];
+        const MoveCopy c = e == t ? c0 : cc[u];
         const uint8_t cs = c.status;
         const uint16_t cts = c.ts;
         st.pos4[base + slot] = make_float4(c.x, c.y, c.z, __uint_as_float(c.forget_bits));
@@ -762,7 +850,7 @@ __global__ __launch_bounds__(TPB) void k_move_replay(Dims d, Filter flt, State s
 #pragma unroll
           for (int i = 1; i < S; ++i) own[i] = i == slot ? o : own[i];
         }
-        st.owner_flag[(base + slot) / OWNER_CHUNK] = 1;
+        flag_owner_chunk(st, base + slot);
 #pragma unroll
         for (int i = 1; i < S; ++i)
           if (i == slot) {
@@ -827,9 +915,9 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
   }
 }
 
-// after sdm_load_state: recompute the chunk flags from the owner array
+// after sdm_load_state: recompute the chunk flags (both levels; the coarse one was zeroed by the launcher) from the owner array
 __global__ __launch_bounds__(TPB) void k_owner_flags(const uint16_t *__restrict__ owner, size_t n_slots,
-                                                     uint8_t *__restrict__ owner_flag) {
+                                                     uint8_t *__restrict__ owner_flag, uint8_t *__restrict__ owner_flag2) {
   __shared__ uint32_t any_owner;
   if (threadIdx.x == 0) any_owner = 0;
   __syncthreads();
@@ -840,7 +928,39 @@ __global__ __launch_bounds__(TPB) void k_owner_flags(const uint16_t *__restrict_
   for (; i < end; i += blockDim.x) a = a || owner[i] != OWNER_NONE;
   if (a) any_owner = 1;
   __syncthreads();
-  if (threadIdx.x == 0) owner_flag[blockIdx.x] = any_owner ? 1 : 0;
+  if (threadIdx.x == 0) {
+    owner_flag[blockIdx.x] = any_owner ? 1 : 0;
+    if (any_owner) owner_flag2[blockIdx.x / OWNER_GROUP] = 1;
+  }
+}
+
+// sdm_tracks_with_particles: one bit per track id that owns at least one slot (primary owner or an older membership the
+// reference's sets still hold) - the keys of ObjectParticleHashMap::indices_map with a non-empty set
+// (object_layer.h:20-52, semantic_dsp_map.h:712-736).  bitmap: 2048 uint32, zeroed by the launcher.
+__global__ __launch_bounds__(TPB) void k_tracks_with_particles(State st, size_t n_slots, uint32_t *__restrict__ bitmap) {
+  __shared__ uint32_t seen[2048];
+  for (uint32_t k = threadIdx.x; k < 2048; k += TPB) seen[k] = 0;
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    const uint32_t na = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
+    for (uint32_t k = threadIdx.x; k < na; k += TPB) {
+      const uint32_t trk = st.alias[3 + 2 * k];
+      if (trk != OWNER_NONE) atomicOr(&seen[trk >> 5], 1u << (trk & 31u));
+    }
+  }
+  const size_t n_chunks = (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK;
+  for (size_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    if (st.owner_flag[chunk] == 0) continue;
+    size_t end = (chunk + 1) * OWNER_CHUNK;
+    if (end > n_slots) end = n_slots;
+    for (size_t i = chunk * OWNER_CHUNK + threadIdx.x; i < end; i += TPB) {
+      const uint16_t o = st.owner[i];
+      if (o != OWNER_NONE && !((seen[o >> 5] >> (o & 31u)) & 1u)) atomicOr(&seen[o >> 5], 1u << (o & 31u));
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < 2048; k += TPB)
+    if (seen[k]) atomicOr(&bitmap[k], seen[k]);
 }
 
 inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
@@ -849,50 +969,99 @@ inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb
 
 void launch_owner_flags(const Dims &d, const State &st, hipStream_t s) {
   const size_t n_slots = (size_t)d.v_count * d.S;
+  hipMemsetAsync(st.owner_flag2, 0, owner_flag2_bytes(n_slots), s);
   hipLaunchKernelGGL(k_owner_flags, dim3((unsigned)((n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK)), dim3(TPB), 0, s, st.owner, n_slots,
-                     st.owner_flag);
+                     st.owner_flag, st.owner_flag2);
+}
+
+void launch_tracks_with_particles(const Dims &d, const State &st, uint32_t *bitmap, hipStream_t s) {
+  const size_t n_slots = (size_t)d.v_count * d.S;
+  hipMemsetAsync(bitmap, 0, 2048 * sizeof(uint32_t), s);
+  hipLaunchKernelGGL(k_tracks_with_particles, dim3(1024), dim3(TPB), 0, s, st, n_slots, bitmap);
 }
 
 size_t move_blocks(const Dims &d) { return ((size_t)d.v_count * d.S + MV_CHUNK - 1) / MV_CHUNK; }
 size_t move_count_elems() { return (size_t)MAX_MOVE_OBJECTS * MV_LIST_CAP + 1; }
+size_t move_member_elems() { return (size_t)MV_LIST_CAP * MV_CHUNK; }
+size_t move_total_elems() { return (size_t)2 * MAX_MOVE_OBJECTS * MV_TOT_STRIDE; }
 
 // The launch sequence below is the same every frame (hipGraph): kernels of a frame without moving objects / removals
-// return at once, the scan covers n_obj x (chunks on the list) + 1 elements, a number read on the device.
-// step 1: collect every moving object's members (ascending index) and publish the per-object counts
-// by_value != nullptr: the chain runs ahead of the frame's k_frame_begin on a stream of its own; its first kernel takes
-// the frame block by value and stores it in fa_moves for the others
+// return at once.
+// step 1: list and rank every moving object's members (ascending index) and publish the per-object counts
+// by_value != nullptr: the launch runs ahead of the frame's k_frame_begin on a stream of its own; it takes the frame block
+// by value and stores it in fa_moves for the chain's other kernel
+static MembersArgs members_args(const Dims &d, const Scratch &sc) {
+  MembersArgs ma;
+  ma.mv_cnt = sc.mv_cnt;
+  ma.mv_list = sc.mv_list;
+  ma.mv_nlist = sc.mv_nlist;
+  ma.mv_nmem = sc.mv_nmem;
+  ma.mv_mem = sc.mv_mem;
+  ma.mv_tot = sc.mv_tot;
+  ma.cur = sc.cur;
+  ma.n_flags = (uint32_t)move_blocks(d);
+  ma.n_slots = (size_t)d.v_count * d.S;
+  return ma;
+}
 void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32_t *counts_local, hipStream_t s, const FrameArgs *by_value) {
-  const size_t n_slots = (size_t)d.v_count * d.S;
   const FrameArgs *fa = by_value ? sc.fa_moves : sc.fa_side;
+  const MembersArgs ma = members_args(d, sc);
   if (by_value)
-    hipLaunchKernelGGL(k_move_chunks_v, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cur,
-                       sc.mv_cnt, *by_value, const_cast<FrameArgs *>(sc.fa_moves), st.alias, st.owner_flag);
+    hipLaunchKernelGGL(k_move_members_v, dim3(MV_GRID), dim3(TPB), 0, s, st, ma, *by_value, const_cast<FrameArgs *>(sc.fa_moves));
   else
-    hipLaunchKernelGGL(k_move_chunks, dim3(1), dim3(1024), 0, s, st.owner_flag, (uint32_t)move_blocks(d), sc.mv_list, sc.mv_nlist, sc.cur,
-                       sc.mv_cnt, fa, st.alias, st.owner_flag);
-  hipLaunchKernelGGL(k_move_count, dim3(1024), dim3(TPB), 0, s, st.owner, n_slots, fa, sc.mv_cnt, st.owner_flag, sc.mv_list, sc.mv_nlist,
-                     st.alias);
-  exclusive_scan_u32(sc.mv_cnt, sc.mv_cnt, move_count_elems(), sc.scan_scratch_m, s, sc.mv_nlist + 2);
+    hipLaunchKernelGGL(k_move_members, dim3(MV_GRID), dim3(TPB), 0, s, st, ma, fa);
   // the per-object counts are only needed as a separate row when they are exchanged between shards
-  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, sc.mv_cnt, counts_local, sc, fa);
+  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, counts_local, sc, fa);
+}
+
+// arguments of k_frame_begin in the order of its parameter list; `fa` is the frame block that goes by value
+void FrameBeginLaunch::set(const Dims &d_, const State &st_, const Scratch &sc, const FrameArgs &fa_, bool with_side, bool with_members_) {
+  cnt = sc.cnt;
+  bin_count = sc.bin_count;
+  n_bins = (uint32_t)(d_.W * d_.H + 1);
+  st = st_;
+  fa = fa_;
+  dst_main = const_cast<FrameArgs *>(sc.fa);
+  dst_side = with_side ? const_cast<FrameArgs *>(sc.fa_side) : nullptr;
+  d = d_;
+  slab_max = d_.NY * d_.NZ;  // voxels of the largest slab a ring shift can re-stamp
+  if (d_.NX * d_.NZ > slab_max) slab_max = d_.NX * d_.NZ;
+  if (d_.NX * d_.NY > slab_max) slab_max = d_.NX * d_.NY;
+  ma = members_args(d_, sc);
+  with_members = with_members_ ? 1 : 0;
+  argv[0] = &cnt;
+  argv[1] = &bin_count;
+  argv[2] = &n_bins;
+  argv[3] = &st;
+  argv[4] = &fa;
+  argv[5] = &dst_main;
+  argv[6] = &dst_side;
+  argv[7] = &d;
+  argv[8] = &slab_max;
+  argv[9] = &ma;
+  argv[10] = &with_members;
+}
+const void *FrameBeginLaunch::kernel() { return reinterpret_cast<const void *>(k_frame_begin); }
+
+void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s) {
+  (void)hipLaunchKernel(FrameBeginLaunch::kernel(), dim3(FrameBeginLaunch::GRID), dim3(FrameBeginLaunch::BLOCK), a.argv, 0, s);
 }
 
 // step 2 (after the counts of all shards are known): global ranks, transform, export of slab-crossing copies
 void launch_moves_transform(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, const int32_t *counts_all, int world,
                             int rank, hipStream_t s) {
-  hipLaunchKernelGGL(k_move_apply, dim3(1024), dim3(TPB), 0, s, d, flt, st, sc, sc.mv_cnt, d.v_count != d.V ? counts_all : nullptr, world,
-                     rank);
+  hipLaunchKernelGGL(k_move_apply, dim3(1024), dim3(TPB), 0, s, d, flt, st, sc, d.v_count != d.V ? counts_all : nullptr, world, rank);
 }
 
 // step 3 (after the export buffers of all shards are gathered): import, ordered replay per target voxel
 void launch_moves_finish(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, int world, int rank, hipStream_t s) {
   if (world > 1 && sc.halo_recv) hipLaunchKernelGGL(k_move_import, dim3(64, world), dim3(TPB), 0, s, d, sc, world, rank);
-  dim3 grid(256);
+  dim3 grid(RP_GRID);
   switch (d.p_n) {
-    case 1: hipLaunchKernelGGL(k_move_replay<2>, grid, dim3(TPB), 0, s, d, flt, st, sc); break;
-    case 2: hipLaunchKernelGGL(k_move_replay<4>, grid, dim3(TPB), 0, s, d, flt, st, sc); break;
-    case 3: hipLaunchKernelGGL(k_move_replay<8>, grid, dim3(TPB), 0, s, d, flt, st, sc); break;
-    default: hipLaunchKernelGGL(k_move_replay<16>, grid, dim3(TPB), 0, s, d, flt, st, sc); break;
+    case 1: hipLaunchKernelGGL(k_move_replay<2>, grid, dim3(RP_TPB), 0, s, d, flt, st, sc); break;
+    case 2: hipLaunchKernelGGL(k_move_replay<4>, grid, dim3(RP_TPB), 0, s, d, flt, st, sc); break;
+    case 3: hipLaunchKernelGGL(k_move_replay<8>, grid, dim3(RP_TPB), 0, s, d, flt, st, sc); break;
+    default: hipLaunchKernelGGL(k_move_replay<16>, grid, dim3(RP_TPB), 0, s, d, flt, st, sc); break;
   }
 }
 

@@ -82,7 +82,7 @@ struct Counters {
   uint32_t n_free;
   uint32_t overflow;
   uint32_t n_valid_px;
-  uint32_t n_move_voxels;  // voxels that receive at least one moved copy this frame
+  uint32_t n_halo_dropped;  // slab-crossing copies beyond the export capacity of their destination (dropped, SDM_ERR_CAPACITY)
   uint32_t pad[7];
   // Atomics on one cache line retire one at a time (~12 ns each on MI355X) - same address or not.  Counters that
   // every wave bumps are therefore sharded by block index, one 128-byte line per shard; the per-shard
@@ -109,6 +109,13 @@ struct Counters {
 static_assert(sizeof(Counters::ShardLine) == 128, "one cache line per shard");
 constexpr uint32_t VIS_SHARDS = 64;
 constexpr uint32_t OWNER_CHUNK = 4096;  // slots per owner_flag byte (= slots per block of the move sweep)
+constexpr uint32_t OWNER_GROUP = 64;    // chunks per owner_flag2 byte
+// sizes of the two flag levels for n_slots slots, padded so that the member count reads them in whole 16-byte pieces
+// without range checks: the fine level to whole groups, the coarse level to whole tiles of 4096 groups
+__host__ __device__ constexpr size_t owner_flag_bytes(size_t n_slots) {
+  return ((n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK + OWNER_GROUP - 1) / OWNER_GROUP * OWNER_GROUP;
+}
+__host__ __device__ constexpr size_t owner_flag2_bytes(size_t n_slots) { return (owner_flag_bytes(n_slots) / OWNER_GROUP + 4095) / 4096 * 4096; }
 // Slab stamps written by this frame's ring shift (mc_ring/operations.h:1131-1181), applied on the device by the
 // frame-begin kernel; all stamps of one frame carry the same value (the frame's global_time_stamp).
 constexpr int MAX_STAMP_UPDATES = 96;
@@ -175,6 +182,11 @@ struct State {
   // one byte per OWNER_CHUNK consecutive slots: 1 if any slot of the chunk may have an owner.  Lets the object-move
   // and removal sweeps skip the (vast) part of the map no dynamic object ever touched.
   uint8_t *owner_flag = nullptr;
+  // one byte per OWNER_GROUP consecutive chunks: 1 if any of their owner_flag bytes may be set.  The member count of the
+  // move stage finds the flagged chunks of a map of any size from a few hundred bytes (every workgroup reads this level
+  // whole, then the 64 flag bytes of the groups that are marked).  Both levels are plain byte stores by whoever gives a
+  // slot an owner (flag_owner_chunk); cleared by the member count when it finds a chunk / a group without owners.
+  uint8_t *owner_flag2 = nullptr;
   // Extra memberships: the reference's owner sets (object_layer.h:20-52) are real sets, and a slot can sit in two of
   // them - a stale index of object A whose slot is taken by a particle of object B stays in A's set until A moves or
   // is removed.  owner[] holds the latest owner; every older membership that the reference still has is an entry
@@ -202,6 +214,26 @@ __device__ __host__ __forceinline__ uint32_t next_epoch(uint32_t e) { return e %
 __device__ __forceinline__ uint8_t *tile_marks(const State &st, uint32_t epoch) { return st.tile_dirty + (epoch & 1u) * st.tile_stride; }
 __device__ __forceinline__ void mark_tile(const State &st, size_t lv, uint32_t epoch) { tile_marks(st, epoch)[lv >> TILE_SHIFT] = (uint8_t)epoch; }
 constexpr uint32_t ALIAS_CAP = 8192;
+// the slot with shard-local index li has (or may have) an owner: both levels of the chunk flags
+__device__ __forceinline__ void flag_owner_chunk(const State &st, size_t li) {
+  const size_t c = li / OWNER_CHUNK;
+  st.owner_flag[c] = 1;
+  st.owner_flag2[c / OWNER_GROUP] = 1;
+}
+// position of the n-th (0-based) set bit of m
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, uint32_t n) {
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const uint32_t c = (uint32_t)__popcll(m & ((1ull << w) - 1ull));
+    if (n >= c) {
+      n -= c;
+      m >>= w;
+      pos += w;
+    }
+  }
+  return pos;
+}
 
 // ObjectParticleHashMap::addParticleToObj (object_layer.h:31-33): slot li joins track's set.  li is the shard-local slot
 // index.  Returns false when the alias table is full.
@@ -265,6 +297,39 @@ __device__ __forceinline__ void owner_erase_local(const State &st, size_t li, ui
   if (n > ALIAS_CAP) n = ALIAS_CAP;
   for (uint32_t k = 0; k < n; ++k)
     if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+}
+
+// Garbage collection of the table of older memberships: deleted entries (track OWNER_NONE) go, the live ones keep their
+// order.  Called by ONE wave of a kernel that runs while nobody else touches the table (k_bin_fill: after the frame's
+// moves and removals, before its births).  Batches of 64 entries: a batch is read whole before its survivors are
+// written, and they land at or below the batch's own positions.
+__device__ __forceinline__ void alias_compact_wave(const State &st) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t na = st.alias[0];
+  if (na == 0) return;
+  if (na > ALIAS_CAP) na = ALIAS_CAP;
+  uint32_t keep = 0;
+  for (uint32_t b0 = 0; b0 < na; b0 += 64) {
+    const uint32_t k = b0 + lane;
+    uint32_t idx = INVALID_INDEX, trk = OWNER_NONE;
+    if (k < na) {
+      idx = st.alias[2 + 2 * k];
+      trk = st.alias[3 + 2 * k];
+    }
+    const bool live = trk != OWNER_NONE;
+    const unsigned long long m = __ballot(live);
+    if (live) {
+      const uint32_t at = keep + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      st.alias[2 + 2 * at] = idx;
+      st.alias[3 + 2 * at] = trk;
+    }
+    keep += (uint32_t)__popcll(m);
+  }
+  for (uint32_t k = keep + lane; k < na; k += 64) {
+    st.alias[2 + 2 * k] = INVALID_INDEX;
+    st.alias[3 + 2 * k] = OWNER_NONE;
+  }
+  if (lane == 0) st.alias[0] = keep;
 }
 
 // field index of global-slot-order index li = lv << p_n | slot (see the record layout above)
@@ -382,6 +447,60 @@ __device__ __forceinline__ float query_pdf_r(const float *__restrict__ pdf, floa
   if (!(fabsf(c) <= 9.9f)) return 1e-9f;
   return pdf[(uint32_t)(int)(c * 1000 + 10000)];  // 100 .. 19900: an unsigned offset spares the 64-bit address arithmetic
 }
+
+typedef uint32_t sdm_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_result(sdm_voxel_result *dst, const sdm_voxel_result &r) {
+  sdm_v2u v;
+  __builtin_memcpy(&v, &r, 8);
+  __builtin_nontemporal_store(v, reinterpret_cast<sdm_v2u *>(dst));  // written once, read by the next stage only
+}
+
+
+// a ring shift re-stamped these slabs: what the voxels there hold has just become stale (operations.h:1131-1181), so
+// their results turn into "unobserved" although nobody wrote to them.  That is all the sweep would do for such a voxel
+// (isVoxelValid fails: its observation stamp is older than the new slab stamp), so it is done right here, voxel by
+// voxel, and the tile needs no mark: an x shift touches one voxel of every x row, i.e. every tile of the map, and
+// would otherwise send the next sweep through all of them.  Should the visibility pass observe the voxel again in
+// this very frame, it marks the tile itself.  t = update k * slab_max + j-th voxel of its slab.
+__device__ __forceinline__ void mark_slab_voxel_dirty(const Dims &d, const State &st, const StampUpdates &su, uint32_t slab_max,
+                                                      uint32_t t) {
+  const uint32_t k = t / slab_max, j = t - k * slab_max;
+  if ((int)k >= su.n) return;
+  const uint32_t e = su.entry[k], axis = e >> 12, idx = e & 0xfffu;
+  uint32_t rx, ry, rz;
+  if (axis == 0) {
+    if (j >= d.NY * d.NZ) return;
+    rx = idx;
+    ry = j % d.NY;
+    rz = j / d.NY;
+  } else if (axis == 1) {
+    if (j >= d.NX * d.NZ) return;
+    ry = idx;
+    rx = j % d.NX;
+    rz = j / d.NX;
+  } else {
+    if (j >= d.NX * d.NY) return;
+    rz = idx;
+    rx = j % d.NX;
+    ry = j / d.NX;
+  }
+  if (rz < d.rz_begin || rz >= d.rz_begin + d.rz_count) return;  // another shard's slab
+  const uint32_t lv = ring_to_voxel(d, rx, ry, rz) - d.v_begin;
+  const uint8_t fl = st.vflag[lv];
+  const uint8_t state = fl & VF_STATE;
+  // a CLEAN voxel's stored result is gone with this: it is evaluated again when the voxel is seen again
+  const uint8_t nf = (uint8_t)((state == VF_CLEAN ? VF_DIRTY : state) | VR_UNOBSERVED);
+  if (nf != fl) st.vflag[lv] = nf;
+  if ((fl & VR_MASK) != VR_UNOBSERVED) {
+    sdm_voxel_result out;
+    out.wsum = -1.f;
+    out.track = 0;
+    out.label = 0;
+    out.occ = -1;
+    store_result(st.res + lv, out);
+  }
+}
+
 
 // ---- primitives (primitives.hip) ------------------------------------------------------
 // exclusive prefix sum of n uint32; in == out allowed. scratch must hold scan_scratch_elems(n) uint32.  If n_dev is not

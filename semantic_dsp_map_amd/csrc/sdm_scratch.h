@@ -18,7 +18,7 @@ struct MoveCopy {
   float w;
   uint16_t ts, track, owner;
   uint8_t label, status;
-  uint32_t pad;
+  uint32_t voxel;  // shard-local index of the target voxel
 };
 static_assert(sizeof(MoveCopy) == 32, "MoveCopy layout");
 
@@ -47,7 +47,7 @@ struct FrameArgs {
   MoveSet ms;
   int n_obj;           // moving objects of this frame (= ms.n)
   int n_remove;
-  uint32_t n_move_cnt; // elements of the move-count matrix the scan covers: n_obj * MV_LIST_CAP + 1
+  uint32_t mv_seq;     // number of frames with moving objects so far: its parity selects the per-object totals (Scratch::mv_tot)
   int force_generic;   // test hook: always run the generic 3-D frustum flood
   const float *depth;  // this frame's inputs (device)
   const sdm_labeled_point *cloud;
@@ -85,8 +85,15 @@ struct Scratch {
   uint32_t *bkey_a = nullptr, *bval_a = nullptr, *bkey_b = nullptr, *bval_b = nullptr;
   float4 *bpos = nullptr;
   // object moves
-  uint32_t *mv_cnt = nullptr;      // per-chunk per-object counts / offsets
-  uint32_t *mv_list = nullptr, *mv_nlist = nullptr;  // ascending list of chunks that may hold owned slots
+  // Member count of the moving objects (k_move_members, moves.hip), all per listed chunk ("position" = rank of the chunk
+  // among the flagged ones, ascending): mv_list[pos] the chunk, mv_cnt[obj * MV_LIST_CAP + pos] its members per moving
+  // object, mv_nmem[pos] their number (MV_COMPLEX: the chunk holds older set memberships and is ranked by the apply
+  // kernel's alias path), mv_mem[pos * OWNER_CHUNK + i] the members in ascending slot order:
+  // slot in chunk | object << 12 | rank among the object's members in this chunk << 18.
+  // mv_tot[parity][obj] (one 128-byte line each): members per moving object on this shard, added up with atomics.
+  uint32_t *mv_cnt = nullptr;
+  uint32_t *mv_list = nullptr, *mv_nlist = nullptr;
+  uint32_t *mv_nmem = nullptr, *mv_mem = nullptr, *mv_tot = nullptr;
   MoveCopy *mv_copy = nullptr;     // the moved copies, indexed by global rank (32 B each: two 16-byte accesses)
   uint32_t cap_move = 0;
   // slab-crossing copies: one segment [u32 count, pad to 16 B][halo_cap records] per shard.  Segment d of halo_send holds
@@ -99,11 +106,10 @@ struct Scratch {
   // generic
   uint32_t *scan_scratch = nullptr, *sort_scratch = nullptr;
   uint32_t *scan_scratch_b = nullptr;   // births run on their own stream
-  uint32_t *scan_scratch_m = nullptr;   // so does the member count of the move stage
-  // sort double buffers of the move re-insertion (the birth sort runs concurrently on another stream)
   // re-insertion of the moved copies: per target voxel a linked list of copy ranks (mv_head, one entry per voxel of the
-  // shard, MV_NIL when idle; mv_next per rank) and the list of voxels that got a list this frame
-  uint32_t *mv_head = nullptr, *mv_next = nullptr, *mv_vlist = nullptr;
+  // shard, MV_NIL when idle; mv_next per rank).  A copy knows its target voxel (MoveCopy::voxel); the copy a list's
+  // head points at replays the list.
+  uint32_t *mv_head = nullptr, *mv_next = nullptr;
   Counters *cnt = nullptr;
   Cursors *cur = nullptr;
 };
@@ -130,8 +136,15 @@ void launch_set_frame(FrameArgs *fa_dev, const FrameArgs &fa, hipStream_t s);
 const void *set_frame_kernel();  // the kernel behind launch_set_frame (hipGraph kernel-node parameter updates)
 // k_frame_begin's arguments as one object: the same kernel is launched directly and replayed as a hipGraph node whose
 // parameters are replaced every frame
+// what the member count of the moving objects (move_members_body, moves.hip) writes and reads besides the map's state
+struct MembersArgs {
+  uint32_t *mv_cnt, *mv_list, *mv_nlist, *mv_nmem, *mv_mem, *mv_tot;
+  Cursors *cur;
+  uint32_t n_flags;  // chunks of OWNER_CHUNK slots (= owner_flag bytes in use)
+  size_t n_slots;
+};
 struct FrameBeginLaunch {
-  static constexpr unsigned GRID = 512, BLOCK = 256;
+  static constexpr unsigned GRID = 256, BLOCK = 256;
   Counters *cnt;
   uint32_t *bin_count;
   uint32_t n_bins;
@@ -140,8 +153,10 @@ struct FrameBeginLaunch {
   FrameArgs *dst_main, *dst_side;
   Dims d;
   uint32_t slab_max;
-  void *argv[9];
-  void set(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa, bool with_side);
+  MembersArgs ma;
+  int with_members;  // the launch is also the member count of the frame's moving objects (whole maps; shards run it as a chain of its own)
+  void *argv[11];
+  void set(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa, bool with_side, bool with_members);
   static const void *kernel();
 };
 void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s);
@@ -185,6 +200,9 @@ void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t
 
 size_t move_blocks(const Dims &d);
 size_t move_count_elems();
+size_t move_member_elems();
+size_t move_total_elems();
+void launch_tracks_with_particles(const Dims &d, const State &st, uint32_t *bitmap, hipStream_t s);
 void launch_owner_flags(const Dims &d, const State &st, hipStream_t s);
 void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32_t *counts_local, hipStream_t s,
                         const FrameArgs *by_value = nullptr);

@@ -22,7 +22,7 @@ import numpy as np
 HALO_OBJ = 64            # SDM_HALO_OBJ
 HALO_RECORD_BYTES = 36   # SDM_HALO_RECORD_BYTES
 HALO_HEADER_BYTES = 16   # SDM_HALO_HEADER_BYTES
-HALO_DEFAULT_CAP = 1024  # SDM_HALO_DEFAULT_CAP: records per destination shard
+HALO_DEFAULT_CAP = 4096  # SDM_HALO_DEFAULT_CAP: records per destination shard
 
 
 def weak_scaled_config(base_cfg, world):

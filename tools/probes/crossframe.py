@@ -14,7 +14,7 @@ cfg, params = synth.CONFIGS["C3"], synth.PARAMS["vkitti2"]
 scene = synth.Scene(cfg, n_static=48, n_dynamic=6, seed=7)
 st, ring, _ = synth.prefill_state(cfg, scene, 2000000)
 host = [scene.render(t, params) + (scene.moves(t),) for t in range(10)]
-buf = np.zeros(6 * 8192 * 4 + 2 * 4096 * 4, np.uint64)
+buf = np.zeros(6 * 8192 * 4 + 3 * 4096 * 4, np.uint64)
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     eng = sharded.NativeShardedMap(cfg, params, 0, 1, 0)
     m = eng.map
@@ -46,7 +46,7 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     m.device_synchronize()
     L.sdm_debug_timers(m.h, buf.ctypes.data, 0)
     k = buf[:6 * 8192 * 4].astype(np.int64).reshape(6, 8192, 4)
-    mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(2, 4096, 4)
+    mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(3, 4096, 4)
     occ = k[5]
     occ_end = max(occ[:, 1].max(), occ[:, 3].max())
     occ_start = occ[occ[:, 0] > 0, 0].min()
@@ -60,6 +60,11 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     bsg_start = first(k[2])
     wt_end = k[4][:, 1].max()
     br_start = first(k[0])
+    mm = mv[2]
+    if (mm[:, 0] > 0).any():
+        print("   frame_begin + member count (9): first start %.1f us after the sweep's end, lists done %.1f, last workgroup done %.1f; move_apply ends %.1f, move_replay ends %.1f"
+              % ((first(mm) - occ_end) / 100.0, (mm[:, 1].max() - occ_end) / 100.0, (mm[:, 3].max() - occ_end) / 100.0,
+                 (ap[:, 3].max() - occ_end) / 100.0, (rp_end - occ_end) / 100.0), flush=True)
     print("map %d: %.4f ms/frame | sweep(8) %.1f us; births end -> sweep start %.1f; sweep end -> move_apply(9) start %.1f | frame 8: visibility end -> bin_sort_gather start %.1f, weight end -> birth_replay start %.1f us"
           % (rep, ms, (occ_end - occ_start) / 100.0, (occ_start - birth_end) / 100.0, (ap_start - occ_end) / 100.0,
              (bsg_start - vis_end) / 100.0, (br_start - wt_end) / 100.0), flush=True)

@@ -18,7 +18,7 @@ m.load_state(st)
 m.set_ring_state(ring)
 L = m.L
 L.sdm_debug_timers.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-buf = np.zeros(6 * 8192 * 4 + 2 * 4096 * 4, np.uint64)
+buf = np.zeros(6 * 8192 * 4 + 3 * 4096 * 4, np.uint64)
 us = lambda x: x / 100.0
 
 
@@ -41,10 +41,15 @@ for t in range(10):
     if t < 7:
         continue
     k = buf[:6 * 8192 * 4].astype(np.int64).reshape(6, 8192, 4)
-    mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(2, 4096, 4)
+    mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(3, 4096, 4)
     print("frame %d (thread 0 of every workgroup; 100 MHz wall clock)" % t)
-    a = mv[0].copy(); a[:, 1] = a[:, 3]
-    span("move_apply", a)
+    mm = mv[2].copy()
+    span("move_members (lists)", mm, "| chunks: first done %.1f, all done %.1f us after the kernel's first start" % (us((mm[mm[:, 2] > 0, 2].min() if (mm[:, 2] > 0).any() else 0) - mm[mm[:, 0] > 0, 0].min()), us(mm[:, 3].max() - mm[mm[:, 0] > 0, 0].min())) if (mm[:, 0] > 0).any() else "")
+    a = mv[0].copy()
+    act = (a[:, 0] > 0) & (a[:, 2] > 0)
+    extra = "| prefix %.1f, moves %.1f us (avg, chunks with members)" % (us((a[act, 1] - a[act, 0]).mean()), us((a[act, 2] - a[act, 1]).mean())) if act.any() else ""
+    a[:, 1] = a[:, 3]
+    span("move_apply", a, extra)
     r = mv[1].copy(); r[:, 1] = r[:, 2]
     span("move_replay", r)
     v = k[1]; w = v.copy(); w[:, 1] = w[:, 3]
