@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_BPS = 8.0e12  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+PREFILL_FACTOR = 1.16   # prefilled / live particles after the first sweeps' culls (see main)
 
 
 def timed_run(synth, sharded, dist, rank, world, local_rank, cfg, params, particles_per_shard, steps, warmup, scene_kw,
@@ -48,7 +49,7 @@ def timed_run(synth, sharded, dist, rank, world, local_rank, cfg, params, partic
     for t in range(warmup + steps):
         depth, cloud, pos, q = scene.render(t, params)
         frames.append((depth, cloud, pos, q, scene.moves(t), m.device_put(depth), m.device_put(cloud)))
-    st, ring, _ = synth.prefill_state(cfg, scene, particles_per_shard, shard_rank=rank, shard_count=world, **(prefill_kw or {}))
+    st, ring, _ = synth.prefill_state(cfg, scene, int(particles_per_shard * PREFILL_FACTOR), shard_rank=rank, shard_count=world, **(prefill_kw or {}))
     m.load_state(st)
     m.set_ring_state(ring)
 
@@ -312,6 +313,7 @@ def main():
     ap.add_argument("--only-stress", action="store_true", help="run nothing but the busy scene (development)")
     ap.add_argument("--no-grown", action="store_true", help="skip the run on a map grown from empty (N = 1 only)")
     ap.add_argument("--only-grown", action="store_true", help="run nothing but the grown-map leg (development)")
+    ap.add_argument("--no-adapter", action="store_true", help="skip the end-to-end leg through the C++ class (host buffers in, clouds out)")
     args = ap.parse_args()
 
     host_numa = pin_to_device_node(int(os.environ.get("LOCAL_RANK", "0")))
@@ -364,7 +366,11 @@ def main():
         frames.append((depth, cloud, pos, q, scene.moves(t), m.device_put(depth), m.device_put(cloud)))
     t_render = time.time() - t0
 
-    st, ring, n_pre = synth.prefill_state(cfg, scene, args.particles, shard_rank=rank, shard_count=world)
+    # The first sweeps cull about one prefilled particle in eight (weights below the initial weight, operations.h:410-424):
+    # the map is prefilled with that many more, so that what is LIVE during the timed frames is the 2 M BASELINE.json
+    # quotes the metric on (`live_particles` in the line is counted after the timed region).
+    n_prefill = int(args.particles * PREFILL_FACTOR)
+    st, ring, n_pre = synth.prefill_state(cfg, scene, n_prefill, shard_rank=rank, shard_count=world)
     m.load_state(st)
     m.set_ring_state(ring)
 
@@ -549,6 +555,23 @@ def main():
                                           "frac_on_survey_bytes": round(dense_slot_bytes / surf_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
                                           "track_ids": "every voxel draws one track id, one voxel in 16 two", "launches_timed": 10}
 
+        roofline["survey_dense_frac"] = roofline["dense_case"]["frac_on_survey_bytes"]  # SURVEY.md 8(d)'s 80 B/voxel view, one key away
+        # A13: RingBufferOperations::clear (mc_ring/operations.h:684-723, "290 ms" single thread at :700) on this map -
+        # positions, weights, stamps, status of every slot reset (the forget counts stay), owner sets and results emptied.
+        # Wall clock around sdm_clear + synchronize, three times.
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m.clear()
+            m.synchronize()
+        clear_ms = (time.perf_counter() - t0) * 1e3 / 3
+        n_slots = V * S
+        clear_bytes = n_slots * (16 + 16 + 4 + 2 + 1 + 2) + V * (2 + 1 + 8 + 4 + 1)  # pos4 read + written, w, ts, status, owner; vts, vflag, res, list heads, slot-0 status
+        roofline["clear"] = {"kernel": "sdm_clear: k_clear_slots + memsets + k_clear_status", "bytes_per_call": clear_bytes,
+                             "ms_per_call": round(clear_ms, 4), "achieved": round(clear_bytes / clear_ms / 1e6, 1),
+                             "frac": round(clear_bytes / clear_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
+                             "frac_on_survey_bytes": round(n_slots * 34 / clear_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
+                             "survey_bytes": n_slots * 34, "calls_timed": 3}
+
     # ---- strong scaling (BASELINE.json C4): the same 256^3 map with 8 M particles, split into `world` Z slabs.  Its own
     # map and frames; a separate object in the line (the headline value above stays the weak-scaling one).
     strong = None
@@ -585,6 +608,10 @@ def main():
     if not multi and not args.no_grown and not args.no_cpu:
         grown = side_leg("--only-grown", "grown", grown_run)
 
+    adapter = None
+    if not multi and not args.no_adapter and not args.no_cpu:
+        adapter = adapter_e2e(synth, cfg, params, scene, frames)
+
     if rank == 0:
         out = {
             "metric": "Mvoxels updated/sec (256^3 grid, 2M particles, VKITTI2 camera; whole hot-path frame)",
@@ -596,7 +623,7 @@ def main():
                                    % (args.config if world == 1 else "%s weak-scaled x%d" % (args.config, world),
                                       1 << cfg["x_n"], 1 << cfg["y_n"], 1 << cfg["z_n"], S, cfg["width"], cfg["height"],
                                       cfg["window_half"], synth.CONFIG_PARAMS[args.config], live, n_vis),
-                       "voxels": V, "live_particles": live, "visible_particles": n_vis,
+                       "voxels": V, "live_particles": live, "prefilled_particles": n_pre * world, "visible_particles": n_vis,
                        "parallelism": "zslab%d" % world, "inputs": "depth + LabeledPoint image resident in HBM",
                        "render_s": round(t_render, 1),
                        "host_enqueue_ms_per_step": round(t_enqueue * 1e3 / args.steps, 4), "launch_mode": launch_mode,
@@ -612,6 +639,8 @@ def main():
             out["stress"] = stress
         if grown is not None:
             out["grown"] = grown
+        if adapter is not None:
+            out["adapter_e2e"] = adapter
         if not multi:
             out["stage_ms"] = {k: round(stage_ms[i], 4) for i, k in
                                enumerate(["", "ego", "move", "remove", "visibility", "weight", "birth", "occupancy"]) if k}
@@ -620,7 +649,59 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_FILES = ("r03_sweep_pmc.json", "r02_sweep_pmc.json")  # newest first
+def adapter_e2e(synth, cfg, params, scene, frames, n_frames=12):
+    """The drop-in class end to end: include/semantic_dsp_map.h (SemanticDSPMap::update, the reference's API) compiled
+    against the stand-in Eigen / OpenCV / PCL headers of tests/mock_includes (none of the three is in the image; only their
+    layouts matter here) and linked with libsdm_hip.so, fed the benchmark's first frames from HOST buffers the way
+    src/mapping.cpp feeds the reference: depth cv::Mat + MaskKpts (static mask, six object masks with key points) + pose in,
+    occupied cloud out - mask packing, object layer, uploads, the frame, sdm_synchronize and the download of the cloud
+    included.  A map of its own, grown from empty (the class has no way to load a state), in a process of its own."""
+    import subprocess
+    import tempfile
+    from tests import adapter_clip
+    try:
+        tmp = tempfile.mkdtemp(prefix="sdm_e2e_")
+        exe, clip, out = os.path.join(tmp, "adapter_e2e"), os.path.join(tmp, "clip.bin"), os.path.join(tmp, "out.bin")
+        csrc = os.path.join(ROOT, "semantic_dsp_map_amd", "csrc")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "tests", "mock_includes"), "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", "adapter_parity.cpp"), "-o", exe, "-L", csrc, "-lsdm_hip",
+                               "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"])
+        preset = dict(x_n=cfg["x_n"], y_n=cfg["y_n"], z_n=cfg["z_n"], p_n=cfg["p_n"], voxel_size=cfg["voxel_size"], fx=cfg["fx"], fy=cfg["fy"],
+                      cx=cfg["cx"], cy=cfg["cy"], width=cfg["width"], height=cfg["height"], depth_min=cfg["depth_min"],
+                      depth_max=cfg["depth_max"], window_half=cfg["window_half"], consider_instance=True, src_width=0, src_height=0,
+                      rescale=1.0, zed2_filters=False, object_mode=2)
+
+        def corners(b):
+            return np.array([[x, y, z] for x in (b[0], b[3]) for y in (b[1], b[4]) for z in (b[2], b[5])], np.float64)
+
+        clip_frames = []
+        n = min(n_frames, len(frames))
+        for t in range(n):
+            depth, cloud = frames[t][0], frames[t][1]
+            static_mask, objects = synth.raw_inputs(cfg, cloud, scene)
+            pos, q = scene.pose(t)
+            boxes, prev = scene.dyn_boxes(t), scene.dyn_boxes(t - 1 if t else 0)
+            seg = [dict(track_id=65535, label="static", kpts_current=np.zeros((0, 3)), kpts_previous=None, mask=static_mask)]
+            for i, (trk, _lab, mask) in enumerate(objects):
+                seg.append(dict(track_id=int(trk), label="Car", kpts_current=corners(boxes[i]), kpts_previous=corners(prev[i]), mask=mask))
+            clip_frames.append(dict(depth=depth, seg=seg, pos=pos, q=q, ts=0.1 * t, free=False))
+        adapter_clip.write_binary(clip, preset, params, (0.1, 0.69, 0.2, 0.1), synth.noise_table(n=100003), clip_frames, False)
+        r = subprocess.run([exe, clip, out, "time"], capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("e2e median_ms_per_update")][-1].split()
+        last = [l for l in r.stdout.splitlines() if l.startswith("frame ")][-1]
+        V = 1 << (cfg["x_n"] + cfg["y_n"] + cfg["z_n"])
+        med = float(line[2])
+        return {"ms_per_update": med, "min_ms_per_update": float(line[4]), "frames_timed": int(line[6]),
+                "value": round(V / med / 1e3, 1), "unit": "Mvoxels/s",
+                "path": "SemanticDSPMap::update (include/semantic_dsp_map.h): host cv::Mat depth + 7 MaskKpts in, pcl::PointXYZRGB cloud out, "
+                        "per call: mask packing, built-in object layer, H2D of depth + masks (5.1 MB), the frame, sdm_synchronize, D2H of the cloud",
+                "map": "grown from empty over the %d calls (%s)" % (n, last.split(":")[1].split(",")[0].strip()),
+                "headers": "compiled against tests/mock_includes (stand-ins for Eigen / OpenCV / PCL: none is in the image)"}
+    except Exception as e:  # noqa: BLE001 - a side leg must not take the line down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+PMC_FILES = ("r04_sweep_pmc.json", "r03_sweep_pmc.json", "r02_sweep_pmc.json")  # newest first
 
 
 def pmc_traffic(S, voxels, evaluated, tiles):

@@ -1203,15 +1203,17 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     live[i] = true;
     pos[i] = st.pos4[base + i];
   }
-  int pixv[S];
+  int pixv[S], rowv[S];
   float camz[S], dptv[S];
 #pragma unroll
   for (int i = 1; i < S; ++i) {
     pixv[i] = -1;
+    rowv[i] = 0;
     if (!live[i]) continue;
     int row, col;
     if (project_to_image(d, f, pos[i].x, pos[i].y, pos[i].z, row, col, camz[i])) {
       pixv[i] = row * d.W + col;
+      rowv[i] = row;
       dptv[i] = depth_img[pixv[i]];
     }
   }
@@ -1233,26 +1235,27 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     vis[i] = true;
     nv++;
   }
+  // A visible particle takes its place in its pixel's bin (pib, counted per pixel) and goes on the list of its IMAGE ROW
+  // (one of ROW_SUBS sub-lists per row, picked by workgroup, so that the counters are spread over many cache lines): the
+  // workgroup of k_bin_rows that lays out the row's bins finds the row's particles there.
+  uint32_t rq[S];
 #pragma unroll
   for (int i = 1; i < S; ++i)
-    if (vis[i]) pib[i] = atomicAdd(&sc.bin_count[pixv[i]], 1u);
-  if (nv) {
-    const uint32_t cap_sub = sc.cap_vis / VIS_SHARDS;
-    uint32_t k = atomicAdd(&sc.cnt->shard[shard].vis, nv);
-    if (k + nv <= cap_sub) {
-      k += shard * cap_sub;
-#pragma unroll
-      for (int i = 1; i < S; ++i)
-        if (vis[i]) {
-          sc.vis_pix[k] = (uint32_t)pixv[i];
-          sc.vis_idx[k] = (uint32_t)(((size_t)v << d.p_n) + i);
-          sc.vis_pib[k] = pib[i];
-          ++k;
-        }
-    } else {
-      sc.cnt->overflow = 1;
+    if (vis[i]) {
+      pib[i] = atomicAdd(&sc.bin_count[pixv[i]], 1u);
+      rq[i] = atomicAdd(&sc.row_cnt[(size_t)(rowv[i] * ROW_SUBS + (shard & (ROW_SUBS - 1))) * ROW_CNT_STRIDE], 1u);
     }
-  }
+#pragma unroll
+  for (int i = 1; i < S; ++i)
+    if (vis[i]) {
+      if (rq[i] < sc.row_cap && pib[i] < (1u << 21)) {
+        const uint32_t col = (uint32_t)(pixv[i] - rowv[i] * d.W);
+        sc.row_list[(size_t)(rowv[i] * ROW_SUBS + (shard & (ROW_SUBS - 1))) * sc.row_cap + rq[i]] =
+            make_uint2((uint32_t)(((size_t)v << d.p_n) + i), col | pib[i] << 11);
+      } else {
+        sc.cnt->overflow = 1;
+      }
+    }
   if (dirty) store_vec<rec_align(S)>(st.status + base * REC_STATUS, stv);
   if (dirty || wrote_free) st.vflag[lv] = VF_DIRTY;
   bool stamped = observed;
@@ -1415,23 +1418,6 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
   }
 }
 
-// counting sort of the visible particles by pixel: scatter into the scanned bin ranges.
-// blockIdx.y = shard of the work list; the total (last entry of the scanned counts) becomes n_vis.
-__global__ __launch_bounds__(TPB) void k_bin_fill(State st, Scratch sc, uint32_t hw) {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sc.cnt->n_vis = sc.bin_start[hw];
-  // (the one place of a frame where nobody reads or writes the table of older set memberships: its deleted entries go)
-  if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && threadIdx.x < 64) alias_compact_wave(st);
-  if (sc.cnt->overflow) return;
-  const uint32_t cap_sub = sc.cap_vis / VIS_SHARDS;
-  const uint32_t shard = blockIdx.y;
-  uint32_t n = sc.cnt->shard[shard].vis;
-  if (n > cap_sub) n = cap_sub;
-  const uint32_t base = shard * cap_sub;
-  uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
-    sc.bin_idx[sc.bin_start[sc.vis_pix[base + k]] + sc.vis_pib[base + k]] = sc.vis_idx[base + k];
-}
-
 __device__ __forceinline__ void sift_down(uint32_t *a, uint32_t start, uint32_t end) {
   uint32_t root = start;
   while (2 * root + 1 <= end) {
@@ -1464,38 +1450,162 @@ __device__ __forceinline__ void ck_store(const Filter &flt, const Scratch &sc, f
   }
 }
 
-// Canonical bin order = ascending particle index (the reference's push order is its BFS order),
-// then gather the fields the weight update reads into arrays laid out in bin order (pixel-major), so that
-// a window row is one contiguous segment.
-// The same thread also classifies its pixel for pass 1 of the weight update (the bin ranges are final here): how many
-// particles does its window hold?  None (half of all windows): ck = 0, stored right away.  Up to CK_LIGHT_MAX: left to
-// the one-thread-per-pixel part of k_ck.  More: onto the sharded list of the row-parallel part.  Both parts then run in
-// ONE launch side by side (round 2 ran k_ck_light, which also did this classification, and k_ck_heavy back to back).
-__global__ __launch_bounds__(TPB) void k_bin_sort_gather(Dims d, Filter flt, State st, Scratch sc, float *__restrict__ ck_out, int finish) {
-  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= (uint32_t)(d.W * d.H)) return;
+// The per-pixel bins of the visible particles (buffer.h:90-93, operations.h:1405-1407), one workgroup per IMAGE ROW.
+// A window row of the weight update is a stretch of consecutive pixels of one image row, so all it needs is that the bins
+// of a row lie back to back in pixel order - where a row's block starts is free.  The workgroup scans its row's per-pixel
+// counts, reserves the row's block with ONE atomic on the frame's particle counter (which ends up as n_vis), writes the
+// row's bin offsets (W + 1 per row: the last one is the row's end), drops the row's particles - k_visibility listed them
+// per row - into their bins, and then every pixel's thread brings its bin into the canonical order (ascending particle
+// index; the reference's push order is its BFS order) and gathers the fields the weight update reads into
+// arrays laid out in bin order.  (Round 3: a device-wide scan of the 466 K counts, a scatter kernel, a sort-and-gather
+// kernel - three launches, 35 us with their gaps, for what one row-local launch does.)
+constexpr int BR_TPB = 1024;
+constexpr int BR_WAVES = BR_TPB / 64;
+constexpr int BR_MAXW = 2048;  // image width the row kernel's LDS holds (checked when the map is created)
+__global__ __launch_bounds__(BR_TPB) void k_bin_rows(Dims d, State st, Scratch sc) {
+  __shared__ uint32_t pre[BR_MAXW + 1];
+  __shared__ uint32_t wave_tot[BR_WAVES];
+  __shared__ uint32_t s_base;
+  const int r = blockIdx.x;
   DBG_LANE0(2, 0);
+  // (the one place of a frame where nobody reads or writes the table of older set memberships: its deleted entries go)
+  if (r == (int)gridDim.x - 1 && threadIdx.x < 64) alias_compact_wave(st);
   const bool overflow = sc.cnt->overflow != 0;
-  // ---- classification, first half: its loads go out now, their results are used at the end of the kernel (the sort and
-  // gather below are a chain of dependent loads of their own; the two chains overlap)
-  const sdm_labeled_point o = sc.fa->cloud[p];
-  uint32_t total = 0;
-  if (o.is_valid && !overflow) {
-    const int h = d.window_half;
-    const int i = (int)p / d.W, j = (int)p - i * d.W;
-    const int j0 = j - h < 0 ? 0 : j - h;
-    const int j1 = j + h >= d.W ? d.W - 1 : j + h;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int W = d.W;
+  // ---- the row's counts, two pixels per thread (consecutive: thread t holds columns 2t, 2t + 1), exclusive scan
+  uint32_t c[2] = {0u, 0u};
+  const int j0 = 2 * (int)threadIdx.x;
+  if (!overflow) {
+    if (j0 < W) c[0] = sc.bin_count[r * W + j0];
+    if (j0 + 1 < W) c[1] = sc.bin_count[r * W + j0 + 1];
+  }
+  // the row's sub-lists (counts requested with the bins' counts)
+  uint32_t sub_n = 0;
+  if (threadIdx.x < ROW_SUBS && !overflow) {
+    sub_n = sc.row_cnt[(size_t)(r * ROW_SUBS + threadIdx.x) * ROW_CNT_STRIDE];
+    if (sub_n > sc.row_cap) sub_n = sc.row_cap;
+  }
+  uint32_t inc = c[0] + c[1];
+  const uint32_t mine = inc;
 #pragma unroll
-    for (int r = 0; r < A7_ROWS; ++r) {
-      const int ni = i + r - h;
-      if (r <= 2 * h && ni >= 0 && ni < d.H) total += sc.bin_start[ni * d.W + j1 + 1] - sc.bin_start[ni * d.W + j0];
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wave_tot[wid] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < BR_WAVES; ++w) {
+    if (w < wid) before += wave_tot[w];
+    total += wave_tot[w];
+  }
+  const uint32_t ex = before + inc - mine;
+  if (j0 < W) pre[j0] = ex;
+  if (j0 + 1 < W) pre[j0 + 1] = ex + c[0];
+  if (threadIdx.x == 0) {
+    pre[W] = total;
+    s_base = total ? atomicAdd(&sc.cnt->n_vis, total) : 0u;
+    if (total && (s_base > sc.cap_vis || total > sc.cap_vis - s_base)) {  // the bin-order arrays hold cap_vis particles
+      sc.cnt->overflow = 1;
+      pre[W] = 0;  // (this row is left out; the frame's results are void anyway: SDM_ERR_CAPACITY)
     }
   }
-  // ---- this pixel's bin: canonical order, gather
-  const uint32_t n = overflow ? 0u : sc.bin_count[p];
-  if (n) {
-    const uint32_t s = sc.bin_start[p];
+  // exclusive prefix of the sub-list lengths (wave 0 holds them in its first lanes)
+  uint32_t sub_ex[ROW_SUBS + 1];
+  {
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < ROW_SUBS; ++k) {
+      sub_ex[k] = run;
+      run += (uint32_t)__shfl(sub_n, k, 64);
+    }
+    sub_ex[ROW_SUBS] = run;
+  }
+  __shared__ uint32_t s_sub[ROW_SUBS + 1];
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k <= ROW_SUBS; ++k) s_sub[k] = sub_ex[k];
+  }
+  __syncthreads();
+  const uint32_t base = s_base;
+  // ---- the row's bin offsets
+  uint32_t *__restrict__ bs = sc.bin_start + (size_t)r * (W + 1);
+  const bool row_over = total != 0 && pre[W] == 0;
+  // how many particles does this row put into the window of the pixel in column j of ANY image row near it (columns
+  // j - h .. j + h)?  Saturated to a byte: k_ck_classify only asks whether a window holds none, up to four or more
+  {
+    const int h = d.window_half;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = j0 + u;
+      if (j < W) {
+        const uint32_t n = row_over ? 0u : pre[j + h + 1 > W ? W : j + h + 1] - pre[j - h < 0 ? 0 : j - h];
+        sc.row_win[r * W + j] = (uint8_t)(n > 255u ? 255u : n);
+      }
+    }
+  }
+  for (int j = threadIdx.x; j <= W; j += BR_TPB) bs[j] = row_over ? 0u : base + pre[j];
+  if (total == 0 || row_over) {
+    DBG_LANE0(2, 1);
+    return;  // (workgroup-uniform)
+  }
+  // ---- the row's particles into their bins
+  const uint32_t n_row = s_sub[ROW_SUBS];
+  for (uint32_t g = threadIdx.x; g < n_row; g += BR_TPB) {
+    int sub = 0;
+#pragma unroll
+    for (int k = 1; k < ROW_SUBS; ++k) sub += s_sub[k] <= g ? 1 : 0;
+    const uint2 e = sc.row_list[(size_t)(r * ROW_SUBS + sub) * sc.row_cap + (g - s_sub[sub])];
+    sc.bin_idx[base + pre[e.y & 2047u] + (e.y >> 11)] = e.x;
+  }
+  __syncthreads();  // (the bins were written by this workgroup: its own stores are visible to it behind the barrier)
+  // ---- every pixel's bin: canonical order, gather
+  const size_t slot_base = (size_t)d.v_begin << d.p_n;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const uint32_t n = c[u];
+    if (!n) continue;
+    const uint32_t p = (uint32_t)(r * W + j0 + u);
+    const uint32_t s = base + pre[j0 + u];
     uint32_t *a = sc.bin_idx + s;
+    if (n <= 8) {
+      // the usual bin: its entries in registers (one round trip for all of them), ordered by a sorting network, then the
+      // particles' fields - again all requested before the first is used.  (Sorted in place in memory and gathered entry by
+      // entry, a bin of ten was a chain of sixty dependent memory accesses: the tail this kernel used to end with.)
+      uint32_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (uint32_t)i < n ? a[i] : 0xffffffffu;
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass)
+#pragma unroll
+        for (int i = pass & 1; i + 1 < 8; i += 2) {  // odd-even transposition: 8 passes order 8 keys
+          const uint32_t lo = v[i] < v[i + 1] ? v[i] : v[i + 1], hi = v[i] < v[i + 1] ? v[i + 1] : v[i];
+          v[i] = lo;
+          v[i + 1] = hi;
+        }
+      float4 q[8];
+      float w8[8];
+      uint16_t t8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if ((uint32_t)i < n) {
+          const size_t li = (size_t)v[i] - slot_base;
+          q[i] = st.pos4[li];
+          w8[i] = st.w[rec_index(li, d.p_n, REC_W)];
+          t8[i] = st.track[rec_index(li, d.p_n, REC_TRACK)];
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if ((uint32_t)i < n) {
+          if (n > 1) a[i] = v[i];
+          sc.vp4[s + i] = make_float4(q[i].x, q[i].y, q[i].z, w8[i]);
+          sc.vtf[s + i] = (uint32_t)t8[i] | ((__float_as_uint(q[i].w) & 0xffu) << 16);
+          sc.vpix[s + i] = p;
+        }
+      continue;
+    }
     if (n > 1) {
       if (n <= 32) {
         for (uint32_t i = 1; i < n; ++i) {
@@ -1517,31 +1627,59 @@ __global__ __launch_bounds__(TPB) void k_bin_sort_gather(Dims d, Filter flt, Sta
         }
       }
     }
-    const size_t slot_base = (size_t)d.v_begin << d.p_n;
     for (uint32_t i = 0; i < n; ++i) {
-      size_t li = (size_t)a[i] - slot_base;
-      float4 q = st.pos4[li];
+      const size_t li = (size_t)a[i] - slot_base;
+      const float4 q = st.pos4[li];
       sc.vp4[s + i] = make_float4(q.x, q.y, q.z, st.w[rec_index(li, d.p_n, REC_W)]);
       sc.vtf[s + i] = (uint32_t)st.track[rec_index(li, d.p_n, REC_TRACK)] | ((__float_as_uint(q.w) & 0xffu) << 16);
       sc.vpix[s + i] = p;
     }
   }
-  // ---- classification, second half
+  DBG_LANE0(2, 1);
+}
+
+// Pass 1 of the weight update (A7 below) splits the pixels by the number of particles their window holds: none (half of
+// all windows): ck = 0, stored right away.  Up to CK_LIGHT_MAX: left to the one-thread-per-pixel part of k_ck.  More: onto
+// the sharded list of the row-parallel part.  Both parts then run in ONE launch side by side.
+// One thread per pixel; the window total is the sum of the per-row counts k_bin_rows left in row_win (2 h + 1 byte loads).
+// A wave reserves the list places of its heavy pixels with ONE atomic: a quarter of all pixels are heavy, and an atomic per
+// pixel on the 64 list counters - a cache line each, 12 ns per atomic and line - was 20 us of this step.
+__global__ __launch_bounds__(TPB) void k_ck_classify(Dims d, Filter flt, Scratch sc, float *__restrict__ ck_out, int finish) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = d.W, H = d.H, h = d.window_half;
+  const bool in_image = p < (uint32_t)(W * H);
+  const bool overflow = sc.cnt->overflow != 0;
+  sdm_labeled_point o;
+  o.is_valid = 0;
+  uint32_t total = 0;
+  if (in_image) {
+    o = sc.fa->cloud[p];
+    const int i = (int)p / W;
+#pragma unroll
+    for (int r = 0; r < A7_ROWS; ++r) {
+      const int ni = i + r - h;
+      if (r <= 2 * h && ni >= 0 && ni < H) total += sc.row_win[(int)p + (r - h) * W];
+    }
+  }
   uint8_t cls = CK_DONE;
+  if (in_image && o.is_valid && total != 0 && !overflow) cls = total <= CK_LIGHT_MAX ? CK_LIGHT : CK_HEAVY;
+  const unsigned long long hm = __ballot(cls == CK_HEAVY);
+  if (hm) {  // (wave-uniform)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t shard = blockIdx.x & (VIS_SHARDS - 1);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&sc.cnt->shard[shard].heavy, (uint32_t)__popcll(hm));
+    base = (uint32_t)__shfl((int)base, 0, 64);
+    // cap_heavy covers every pixel a shard's blocks can hold
+    if (cls == CK_HEAVY) sc.ck_heavy[shard * sc.cap_heavy + base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = p;
+  }
+  if (!in_image) return;
   if (!o.is_valid) {
     if (finish) sc.pixt[p] = 0;  // invalid pixel: skipped by pass 2
-  } else if (total == 0) {
+  } else if (cls == CK_DONE) {
     ck_store(flt, sc, ck_out, finish, (int)p, o, 0.f);
-  } else if (total <= CK_LIGHT_MAX) {
-    cls = CK_LIGHT;
-  } else {
-    cls = CK_HEAVY;
-    const uint32_t shard = blockIdx.x & (VIS_SHARDS - 1);
-    const uint32_t k = atomicAdd(&sc.cnt->shard[shard].heavy, 1u);
-    sc.ck_heavy[shard * sc.cap_heavy + k] = p;  // cap_heavy covers every pixel a shard's blocks can hold
   }
   sc.ck_class[p] = cls;
-  DBG_LANE0(2, 1);
 }
 
 // ------------------------------------------------------------------------------------ A7
@@ -1590,8 +1728,8 @@ __device__ __forceinline__ void ck_light_pixel(const Dims &d, const Filter &flt,
       const int ni = i + r - h;
       ss[r] = ee[r] = 0;
       if (r <= 2 * h && ni >= 0 && ni < d.H) {
-        ss[r] = sc.bin_start[ni * d.W + j0];
-        ee[r] = sc.bin_start[ni * d.W + j1 + 1];
+        ss[r] = sc.bin_start[ni * (d.W + 1) + j0];
+        ee[r] = sc.bin_start[ni * (d.W + 1) + j1 + 1];
       }
     }
   }
@@ -1679,8 +1817,8 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, St
       if (r <= 2 * h && ni >= 0 && ni < d.H) {
         const int j0 = j - h < 0 ? 0 : j - h;
         const int j1 = j + h >= d.W ? d.W - 1 : j + h;
-        s = sc.bin_start[ni * d.W + j0];
-        e = sc.bin_start[ni * d.W + j1 + 1];
+        s = sc.bin_start[ni * (d.W + 1) + j0];
+        e = sc.bin_start[ni * (d.W + 1) + j1 + 1];
       }
       if (r == 0) {
         opx[it][0] = o.x;
@@ -2805,10 +2943,9 @@ void launch_visibility(const Dims &d, const Filter &flt, const State &st, const 
     dim3 grid((unsigned)std::min<size_t>(blocks_for(max_words, VIS_WORDS), 2048));
     SDM_DISPATCH_S(k_visibility, grid, s, d, st, sc);
   }
-  // bins: scan the per-pixel counts, scatter, canonical order + gather
-  exclusive_scan_u32(sc.bin_count, sc.bin_start, (size_t)d.W * d.H + 1, sc.scan_scratch, s);
-  hipLaunchKernelGGL(k_bin_fill, dim3(16, VIS_SHARDS), dim3(TPB), 0, s, st, sc, (uint32_t)(d.W * d.H));
-  hipLaunchKernelGGL(k_bin_sort_gather, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, st, sc, ck_out, finish);
+  // bins: one workgroup per image row lays the row's bins out, fills and orders them; then the pixels are classified for pass 1
+  hipLaunchKernelGGL(k_bin_rows, dim3((unsigned)d.H), dim3(BR_TPB), 0, s, d, st, sc);
+  hipLaunchKernelGGL(k_ck_classify, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, ck_out, finish);
 }
 
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s) {

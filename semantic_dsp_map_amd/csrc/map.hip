@@ -236,6 +236,17 @@ sdm_status alloc_tracked(sdm_map *m, T **p, size_t n) {
 
 // GaussianRandomCalculator::calculateGaussianTable, PDF part (utils/basic_algorithms.h:405-407, 456-460):
 // entry i = (1/sqrt(2*(pi/2))) * expf(-x^2/2), x = (i-10000)*0.001.  The quirky normaliser is the reference's.
+// The map's streams beyond the three every frame uses (main, frustum chain, birth-candidate chain) are created when they
+// are first needed - the member-count stream by Z-slab shards, the copy stream by sdm_update_raw with host inputs - and
+// the library stays off the null stream: the runtime hands out at most GPU_MAX_HW_QUEUES (4) hardware queues and lets
+// further streams share them, and a side chain that shares the main stream's queue runs in line with it - every frame
+// 25 us longer (in-kernel clocks: k_frame_begin entered 12 us instead of 1.5 us after the sweep's end, and so on), for
+// some maps of a process and not for others.  (This was the "later maps of a process are slower" of round 3.)
+hipError_t lazy_stream(hipStream_t *s) {
+  if (*s) return hipSuccess;
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 void build_pdf_table(std::vector<float> &pdf) {
   pdf.resize(PDF_NUM);
   const float pi_2 = 1.5707964f;  // M_PI_2f32
@@ -296,7 +307,8 @@ sdm_status ensure_birth_buffers(sdm_map *m) {
   HIP_TRY(re(&m->sc.bval_b, need));
   HIP_TRY(re(&m->sc.bpos, hw * nb));
   HIP_TRY(re(&m->sc.sort_scratch, sort_scratch_elems(need)));
-  HIP_TRY(hipMemset(m->sc.sort_scratch, 0, sort_scratch_elems(need) * 4));  // the one-launch scan's words start at zero
+  HIP_TRY(hipMemsetAsync(m->sc.sort_scratch, 0, sort_scratch_elems(need) * 4, m->stream));  // the one-launch scan's words start at zero
+  HIP_TRY(hipStreamSynchronize(m->stream));
   m->nb_alloc = nb;
   m->sort_cap = need;
   return SDM_OK;
@@ -708,11 +720,19 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->prm.depth_noise_first_order = 0.f;
   m->prm.depth_noise_zero_order = 0.1f;
 
-  HIP_TRY(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+  {
+    const char *e = getenv("SDM_MAIN_PRIORITY");  // (experiment: a main stream of higher priority draws from a queue pool of its own)
+    if (e && e[0] == '1') {
+      int lo = 0, hi = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIP_TRY(hipStreamCreateWithPriority(&m->own_stream, hipStreamNonBlocking, hi));
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+    }
+  }
   m->stream = m->own_stream;
   HIP_TRY(hipStreamCreateWithFlags(&m->s_frustum, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&m->s_birth, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&m->s_moves, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_state, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_begin, hipEventDisableTiming));
@@ -744,7 +764,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(m->st.owner_flag, owner_flag_bytes(n_slots));
   A(m->st.owner_flag2, owner_flag2_bytes(n_slots));
   A(m->st.alias, 2 + 2 * ALIAS_CAP);
-  HIP_TRY(hipMemset(m->st.alias, 0, 8));
+  HIP_TRY(hipMemsetAsync(m->st.alias, 0, 8, m->stream));
   A(m->st.res, d.v_count);
   A(m->st.stamps_x, d.NX);
   A(m->st.stamps_y, d.NY);
@@ -756,7 +776,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   {
     std::vector<float> pdf;
     build_pdf_table(pdf);
-    HIP_TRY(hipMemcpy(m->st.pdf, pdf.data(), PDF_NUM * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(m->st.pdf, pdf.data(), PDF_NUM * 4, hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));  // (the host table goes out of scope)
   }
   Scratch &sc = m->sc;
   sc.wpl = (int)((d.NX + 1 + 63) / 64);
@@ -771,17 +792,24 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.line_reach, n_line_words);
   A(m->d_depth, hw);
   A(m->d_cloud, hw);
-  A(sc.bin_count, hw + 1);
-  A(sc.bin_start, hw + 1);
+  if (d.W > 2047) {
+    set_error("sdm_create", __FILE__, __LINE__, "image width above 2047 (the row kernel of the pixel bins holds one image row in LDS)");
+    return SDM_ERR_INVALID_ARGUMENT;
+  }
+  A(sc.bin_count, hw + 1 + (size_t)d.H * ROW_SUBS * ROW_CNT_STRIDE);
+  A(sc.row_win, hw);
+  sc.row_cnt = sc.bin_count + hw + 1;
+  A(sc.bin_start, (size_t)d.H * (d.W + 1));
   // per-shard capacity is cap_vis / VIS_SHARDS; small maps get head-room for one block's worth of slots per shard
   size_t cap_vis = cfg->max_visible > 0 ? (size_t)cfg->max_visible
                                         : std::min<size_t>(n_slots + (size_t)VIS_SHARDS * 256 * d.S, (size_t)16 << 20);
   cap_vis = (cap_vis + VIS_SHARDS - 1) / VIS_SHARDS * VIS_SHARDS;
   cap_vis = std::min<size_t>(cap_vis, 0xffffff00u);
   sc.cap_vis = (uint32_t)cap_vis;
-  A(sc.vis_pix, cap_vis);
-  A(sc.vis_idx, cap_vis);
-  A(sc.vis_pib, cap_vis);
+  // a row's lists hold 4 x its share of the capacity (particles crowd into the image rows the ground and the objects are
+  // in), a sub-list an eighth of that
+  sc.row_cap = (uint32_t)std::max<size_t>(64, std::min<size_t>(cap_vis, 4 * cap_vis / (size_t)d.H) / ROW_SUBS);
+  A(sc.row_list, (size_t)d.H * ROW_SUBS * sc.row_cap);
   A(sc.bin_idx, cap_vis);
   A(sc.vpix, cap_vis);
   A(sc.vp4, cap_vis);
@@ -789,7 +817,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.pix4, hw);
   A(sc.pixt, hw);
   A(sc.ck_kappa, hw);
-  // pixels reach the heavy list from blocks of TPB consecutive pixels, shard = block & 63
+  // pixels reach the heavy list from blocks of TPB consecutive pixels (k_ck_classify), shard = block & 63
   sc.cap_heavy = (uint32_t)(((hw + 255) / 256 + VIS_SHARDS - 1) / VIS_SHARDS * 256);
   A(sc.ck_heavy, (size_t)sc.cap_heavy * VIS_SHARDS);
   A(sc.ck_class, hw);
@@ -802,7 +830,6 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
     A(r.bbox, 6 * MAX_CLOUD_OBJECTS);
     HIP_TRY(hipEventCreateWithFlags(&r.ev_free, hipEventDisableTiming));
   }
-  HIP_TRY(hipStreamCreateWithFlags(&m->s_copy, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&m->ev_copy, hipEventDisableTiming));
   A(sc.b_valid, hw + 1);
   A(sc.b_rank, hw + 1);
@@ -830,7 +857,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   HIP_TRY(hipMemsetAsync(sc.scan_scratch_b, 0, (scan_scratch_elems(hw + 1) + 16) * 4, m->stream));
   HIP_TRY(hipMemsetAsync(m->scan_scratch_e, 0, (scan_scratch_elems((size_t)d.v_count + 1) + 16) * 4, m->stream));
   A(sc.mv_head, d.v_count);
-  HIP_TRY(hipMemset(sc.mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t)));  // MV_NIL; the replay leaves it that way
+  HIP_TRY(hipMemsetAsync(sc.mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t), m->stream));  // MV_NIL; the replay leaves it that way
   A(sc.mv_next, sc.cap_move);
   A(sc.cnt, 1);
   A(sc.cur, 1);
@@ -1143,6 +1170,7 @@ sdm_status frame_enqueue_start(sdm_map *m) {
   } else if (side_chain) {
     // (its own copy of the frame block travels with its first kernel: nothing of another stream in front of the chain but
     // the previous frame's births)
+    HIP_TRY(lazy_stream(&m->s_moves));
     HIP_TRY(hipStreamWaitEvent(m->s_moves, m->ev_state, 0));
     if (!whole) {
       if (m->mv_pending) HIP_TRY(hipMemsetAsync(m->sc.mv_tot, 0, move_total_elems() * sizeof(uint32_t), m->s_moves));
@@ -1362,7 +1390,7 @@ sdm_status graph_capture(sdm_map *m) {
   m->graph_set_node = nullptr;
   // nothing of an earlier frame may still be running on the side streams when they join the capture
   HIP_TRY(hipStreamSynchronize(m->s_frustum));
-  HIP_TRY(hipStreamSynchronize(m->s_moves));
+  if (m->s_moves) HIP_TRY(hipStreamSynchronize(m->s_moves));
   HIP_TRY(hipStreamSynchronize(m->s_birth));
   m->sc.fa = m->d_fa[0];
   m->sc.fa_side = m->d_fa[1];
@@ -1449,7 +1477,7 @@ sdm_status pieces_capture(sdm_map *m) {
     g = nullptr;
   }
   HIP_TRY(hipStreamSynchronize(m->s_frustum));
-  HIP_TRY(hipStreamSynchronize(m->s_moves));
+  if (m->s_moves) HIP_TRY(hipStreamSynchronize(m->s_moves));
   HIP_TRY(hipStreamSynchronize(m->s_birth));
   m->sc.fa = m->d_fa[0];
   m->sc.fa_side = m->d_fa[1];
@@ -1536,6 +1564,7 @@ extern "C" sdm_status sdm_debug_overlap(sdm_map *m, int32_t which, double out_us
   HIP_TRY(hipSetDevice(m->device));
   unsigned long long *d = nullptr, h[3] = {0, 0, 0};
   HIP_TRY(hipMalloc(&d, sizeof(h)));
+  if (which == 2) HIP_TRY(lazy_stream(&m->s_moves));
   hipStream_t side = which == 0 ? m->s_frustum : (which == 1 ? m->s_birth : m->s_moves);
   HIP_TRY(hipStreamSynchronize(m->stream));
   HIP_TRY(hipStreamSynchronize(side));
@@ -1692,6 +1721,7 @@ sdm_status sdm_update_raw_ex(sdm_map *m, const float *depth, const uint8_t *stat
   // this frame's input set; the copy stream may fill it as soon as the frame that last read it is through
   sdm_map::RawInputs &in = m->raw[m->raw_next];
   m->raw_next ^= 1;
+  HIP_TRY(lazy_stream(&m->s_copy));
   hipStream_t sc_ = m->s_copy;
   HIP_TRY(hipStreamWaitEvent(sc_, in.ev_free, 0));
   // one input image -> its device buffer of the configured size
@@ -1891,7 +1921,7 @@ sdm_status sdm_comm_timing(sdm_map *m, int32_t on) {
 sdm_status sdm_get_comm_times(sdm_map *m, double out_us[4]) {
   if (!m || !out_us || !m->comm) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
-  HIP_TRY(hipStreamSynchronize(m->s_moves));
+  if (m->s_moves) HIP_TRY(hipStreamSynchronize(m->s_moves));
   HIP_TRY(hipStreamSynchronize(m->stream));
   for (int k = 0; k < 4; ++k) {
     out_us[k] = 0.0;
@@ -2038,7 +2068,10 @@ static sdm_status get_points(sdm_map *m, sdm_point *out, size_t cap, size_t *n_o
   HIP_TRY(hipStreamSynchronize(m->stream));
   *n_out = total;
   size_t ncopy = std::min<size_t>(total, cap);
-  if (ncopy) HIP_TRY(hipMemcpy(out, m->d_points, ncopy * sizeof(sdm_point), hipMemcpyDeviceToHost));
+  if (ncopy) {
+    HIP_TRY(hipMemcpyAsync(out, m->d_points, ncopy * sizeof(sdm_point), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+  }
   return SDM_OK;
 }
 sdm_status sdm_get_occupied(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t flags) {
@@ -2090,7 +2123,10 @@ static sdm_status get_points_rgb(sdm_map *m, sdm_point_xyzrgb *out, size_t cap, 
   HIP_TRY(hipStreamSynchronize(m->stream));
   *n_out = total;
   size_t ncopy = std::min<size_t>(total, cap);
-  if (ncopy) HIP_TRY(hipMemcpy(out, m->d_points_rgb, ncopy * sizeof(sdm_point_xyzrgb), hipMemcpyDeviceToHost));
+  if (ncopy) {
+    HIP_TRY(hipMemcpyAsync(out, m->d_points_rgb, ncopy * sizeof(sdm_point_xyzrgb), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+  }
   return SDM_OK;
 }
 sdm_status sdm_get_occupied_rgb(sdm_map *m, sdm_point_xyzrgb *out, size_t cap, size_t *n_out, int32_t flags) {
@@ -2313,7 +2349,8 @@ sdm_status sdm_dump_state(sdm_map *m, float *px, float *py, float *pz, float *w,
     // one owner per slot in the exported array: a slot that sits in several sets (State::alias) reports the largest
     // track id, which is what walking the reference's sets in ascending track order leaves behind
     std::vector<uint32_t> al(2 + 2 * ALIAS_CAP);
-    HIP_TRY(hipMemcpy(al.data(), m->st.alias, al.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(al.data(), m->st.alias, al.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
     const uint32_t na = std::min<uint32_t>(al[0], ALIAS_CAP);
     for (uint32_t k = 0; k < na; ++k) {
       const uint32_t idx = al[2 + 2 * k], trk = al[3 + 2 * k];
@@ -2400,8 +2437,21 @@ sdm_status sdm_get_bins(sdm_map *m, uint32_t *out, int64_t cap, int64_t *n_out) 
   HIP_TRY(hipMemcpyAsync(&c, m->sc.cnt, sizeof(c), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   *n_out = c.n_vis;
-  int64_t ncopy = std::min<int64_t>(std::min<int64_t>(c.n_vis, cap), m->sc.cap_vis);
-  if (ncopy > 0 && out) HIP_TRY(hipMemcpy(out, m->sc.bin_idx, (size_t)ncopy * 4, hipMemcpyDeviceToHost));
+  const int64_t n_vis = std::min<int64_t>(c.n_vis, m->sc.cap_vis);
+  if (n_vis > 0 && out && cap > 0) {
+    // pixel-major order (the order of the reference's bins): the rows' blocks lie in the device array in the order their
+    // workgroups reserved them, so the rows are put in image order here
+    const int W = m->d.W, H = m->d.H;
+    std::vector<uint32_t> idx((size_t)n_vis), bs((size_t)H * (W + 1));
+    HIP_TRY(hipMemcpyAsync(idx.data(), m->sc.bin_idx, idx.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(bs.data(), m->sc.bin_start, bs.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    int64_t at = 0;
+    for (int r = 0; r < H && at < cap; ++r) {
+      const uint32_t a = bs[(size_t)r * (W + 1)], b = bs[(size_t)r * (W + 1) + W];
+      for (uint32_t k = a; k < b && at < cap && k < (uint32_t)n_vis; ++k) out[at++] = idx[k];
+    }
+  }
   return SDM_OK;
 }
 sdm_status sdm_get_extrinsic(sdm_map *m, float *out16) {

@@ -18,11 +18,11 @@
 namespace sdm {
 
 #ifdef SDM_AB_TIMERS
-__device__ unsigned long long g_dbg_m[3][4096 * 4];  // [kernel][workgroup][checkpoint], see kernels.hip
+__device__ unsigned long long g_dbg_m[4][4096 * 4];  // [kernel][workgroup][checkpoint], see kernels.hip
 void debug_timers_moves(unsigned long long *out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_m), sizeof(g_dbg_m));
   if (reset) {
-    static unsigned long long z[3][4096 * 4];
+    static unsigned long long z[4][4096 * 4];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_m), z, sizeof(z));
   }
 }
@@ -91,7 +91,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_t
 constexpr uint32_t MV_COMPLEX = 0xffffffffu;
 constexpr uint32_t MV_CLEAR_FLAG = 0x80000000u;  // in mv_list: the chunk holds no owner, k_move_apply clears its flag
 constexpr uint32_t MV_GROUP_CAP = 4096;   // marked groups a workgroup lists (x 64 chunks >> MV_LIST_CAP)
-constexpr int MV_GRID = (int)FrameBeginLaunch::GRID;  // (all resident beside the previous frame's sweep: one workgroup per CU)
+constexpr int MV_GRID = (int)FrameBeginLaunch::GRID;
 constexpr int MV_PER_WG = (int)(MV_LIST_CAP / MV_GRID);
 constexpr uint32_t MV_TOT_STRIDE = 32;    // uint32 per object in mv_tot: one 128-byte line each
 
@@ -194,7 +194,8 @@ __device__ __forceinline__ void move_members_body(const State &st, const Members
       ow[r] = li < n_slots ? st.owner[li] : OWNER_NONE;
     }
     __syncthreads();  // the LDS tables of the chunk before have been read
-    for (uint32_t k = threadIdx.x; k < (uint32_t)(MV_ITEMS * MV_WAVES * MAX_MOVE_OBJECTS); k += TPB) (&rank_cnt[0][0][0])[k] = 0;
+    // (only the columns of this frame's objects are ever read: thread (row t / 4, t % 4) clears its row's columns t % 4, + 4, ...)
+    for (int k = (int)(threadIdx.x & 3u); k < n_obj; k += 4) (&rank_cnt[0][0][0])[(threadIdx.x >> 2) * MAX_MOVE_OBJECTS + k] = 0;
     if (threadIdx.x < MV_ITEMS * MV_WAVES) (&all_cnt[0][0])[threadIdx.x] = 0;
     if (threadIdx.x < MAX_MOVE_OBJECTS) c_obj[threadIdx.x] = 0;
     if (threadIdx.x == 0) any_owner = 0, n_alias_here = 0;
@@ -205,6 +206,11 @@ __device__ __forceinline__ void move_members_body(const State &st, const Members
 #pragma unroll
     for (int r = 0; r < MV_ITEMS; ++r) {
       some = some || ow[r] != OWNER_NONE;
+      ent[r] = MV_COMPLEX;
+      pre[r] = 0;
+      // (a wave's 64 slots are 8 voxels: in nearly every round nobody owns any of them, and a sparse wave pays for every
+      // instruction it issues - the seven ballots of a round are 40 of them)
+      if (__ballot(ow[r] != OWNER_NONE) == 0ull) continue;
       const uint8_t o = obj_of(ow[r], tracks, n_obj);
       const bool valid = o != 0xFF;
       const uint64_t members = __ballot(valid);
@@ -235,31 +241,31 @@ __device__ __forceinline__ void move_members_body(const State &st, const Members
       }
     }
     __syncthreads();
-    if ((int)threadIdx.x < n_obj) {  // running offsets in (round, wave) order = ascending slot index
-      uint32_t run = 0;
-      for (int r = 0; r < MV_ITEMS; ++r)
+    // Running offsets in (round, wave) order = ascending slot index.  The 64 counts of an object are one per lane of a wave
+    // (lane = round * 4 + wave): a wave scan each, the waves share the objects out; "object n_obj" is the count of all
+    // members.  (One thread per object walking its 64 counts was 64 dependent LDS round trips: 6 us of the kernel's 17.)
+    for (int k = wid; k <= n_obj; k += MV_WAVES) {
+      uint32_t *cell = k < n_obj ? &(&rank_cnt[0][0][0])[lane * MAX_MOVE_OBJECTS + k] : &(&all_cnt[0][0])[lane];
+      const uint32_t c = *cell;
+      uint32_t inc = c;
 #pragma unroll
-        for (int w = 0; w < MV_WAVES; ++w) {
-          const uint32_t c = rank_cnt[r][w][threadIdx.x];
-          rank_cnt[r][w][threadIdx.x] = run;
-          run += c;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t nb = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += nb;
+      }
+      *cell = inc - c;
+      if (lane == 63) {
+        if (k < n_obj) {
+          const uint32_t total = inc + c_obj[k];
+          sc.mv_cnt[(size_t)k * MV_LIST_CAP + pos] = total;
+          if (total) atomicAdd(&tot[k * MV_TOT_STRIDE], total);
+        } else {
+          sc.mv_nmem[pos] = n_alias_here ? MV_COMPLEX : inc;
+          // A flagged chunk that holds no owner any more loses its flag - in k_move_apply, not here: other workgroups of this
+          // launch may still be reading the flags, and they all have to see the same list.
+          sc.mv_list[pos] = chunk | (any_owner == 0 ? MV_CLEAR_FLAG : 0u);
         }
-      const uint32_t c = run + c_obj[threadIdx.x];
-      sc.mv_cnt[(size_t)threadIdx.x * MV_LIST_CAP + pos] = c;
-      if (c) atomicAdd(&tot[threadIdx.x * MV_TOT_STRIDE], c);
-    } else if (threadIdx.x == 64) {
-      uint32_t run = 0;
-      for (int r = 0; r < MV_ITEMS; ++r)
-#pragma unroll
-        for (int w = 0; w < MV_WAVES; ++w) {
-          const uint32_t c = all_cnt[r][w];
-          all_cnt[r][w] = run;
-          run += c;
-        }
-      sc.mv_nmem[pos] = n_alias_here ? MV_COMPLEX : run;
-      // A flagged chunk that holds no owner any more loses its flag - in k_move_apply, not here: other workgroups of this
-      // launch may still be reading the flags, and they all have to see the same list.
-      sc.mv_list[pos] = chunk | (any_owner == 0 ? MV_CLEAR_FLAG : 0u);
+      }
     }
     __syncthreads();
     if (!n_alias_here) {
@@ -307,6 +313,7 @@ __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__
                                                       FrameArgs *__restrict__ dst_side, Dims d, uint32_t slab_max, MembersArgs ma,
                                                       int with_members) {
   const StampUpdates &su = src.su;
+  DBGM(3, 0, DBGM_T());
   if (blockIdx.x == gridDim.x - 1) {
     const uint32_t *s4 = reinterpret_cast<const uint32_t *>(&src);
     uint32_t *m4 = reinterpret_cast<uint32_t *>(dst_main), *e4 = reinterpret_cast<uint32_t *>(dst_side);
@@ -324,6 +331,7 @@ __global__ __launch_bounds__(TPB) void k_frame_begin(Counters *cnt, uint32_t *__
     arr[idx] = su.value;
   }
   for (; i < n_bins; i += gridDim.x * blockDim.x) bin_count[i] = 0;
+  DBGM(3, 1, DBGM_T());
   if (with_members && src.n_obj > 0) move_members_body(st, ma, ma.n_flags, ma.n_slots, src.n_obj, src.ms.track, src.mv_seq);
 }
 
@@ -796,6 +804,15 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
     uint32_t n_ok = 0;
     bool more = true, full = false;
     long long last = -1;  // largest rank replayed so far
+    // The vacant slots as a bit mask, kept up to date by the insertions (the lowest set bit is the "first vacant slot" of
+    // operations.h:790-796).  A sparse wave pays for every instruction it issues, and the walk over status / stamp /
+    // owner arrays per insertion was a few hundred of them per copy - most of this kernel's time.
+    uint32_t vac = 0;
+#pragma unroll
+    for (int i = 1; i < S; ++i)
+      if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) vac |= 1u << i;
+    int last_slot = -1;  // the slot the previous copy went into, and who owns it since
+    uint16_t last_owner = OWNER_NONE;
     while (more && !full) {
       uint32_t best[S - 1];  // the S-1 smallest ranks above `last`, ascending
 #pragma unroll
@@ -819,19 +836,19 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
 #pragma unroll
       for (int u = 0; u < S - 1; ++u)
         if (best[u] != MV_NIL && best[u] != t) cc[u] = sc.mv_copy[best[u]];
+      // (the fetches above are to be under way together before the first insertion's stores: without the fence the compiler
+      // sinks each fetch to the iteration that uses it - a dependent round trip per copy)
+      __asm__ volatile("" ::: "memory");
 #pragma unroll
       for (int u = 0; u < S - 1; ++u) {
         const uint32_t e = best[u];
         if (e == MV_NIL || full) break;
         last = e;
-        int slot = -1;
-#pragma unroll
-        for (int i = S - 1; i >= 1; --i)
-          if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) slot = i;
-        if (slot < 0) {  // voxel full: this copy and all later ones are dropped (operations.h:357)
+        if (vac == 0u) {  // voxel full: this copy and all later ones are dropped (operations.h:357)
           full = true;
           break;
         }
+        const int slot = __ffs((int)vac) - 1;
         const MoveCopy c = e == t ? c0 : cc[u];
         const uint8_t cs = c.status;
         const uint16_t cts = c.ts;
@@ -841,22 +858,20 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
         st.track[base * REC_TRACK + slot] = c.track;
         st.label[base * REC_LABEL + slot] = c.label;
         st.status[base * REC_STATUS + slot] = cs;
-        {  // the new index joins the object's set.  (ONE copy of the insertion with the slot as a run-time value: inside
-           // `if (i == slot)` of an unrolled loop a wave whose lanes fill different slots runs the body once per slot)
-          uint16_t o = OWNER_NONE;
+        {  // the new index joins the object's set
+          uint16_t o = last_owner;
+          if (slot != last_slot) {
 #pragma unroll
-          for (int i = 1; i < S; ++i) o = i == slot ? own[i] : o;
+            for (int i = 1; i < S; ++i) o = i == slot ? own[i] : o;
+          }
           if (!owner_insert_local(st, base + slot, c.owner, o, n_alias, alias_touched)) sc.cnt->overflow = 1;
-#pragma unroll
-          for (int i = 1; i < S; ++i) own[i] = i == slot ? o : own[i];
+          last_slot = slot;
+          last_owner = o;
         }
         flag_owner_chunk(st, base + slot);
-#pragma unroll
-        for (int i = 1; i < S; ++i)
-          if (i == slot) {
-            stv[i] = cs;
-            tsv[i] = cts;
-          }
+        // (a copy that is itself vacant - deleted before it was copied, or older than the slab's stamp - leaves the slot
+        // to the next one)
+        if (!(cs == ST_INVALID || (uint32_t)cts < smax)) vac &= ~(1u << slot);
         ++n_ok;
       }
     }
@@ -1018,7 +1033,7 @@ void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32
 void FrameBeginLaunch::set(const Dims &d_, const State &st_, const Scratch &sc, const FrameArgs &fa_, bool with_side, bool with_members_) {
   cnt = sc.cnt;
   bin_count = sc.bin_count;
-  n_bins = (uint32_t)(d_.W * d_.H + 1);
+  n_bins = (uint32_t)(d_.W * d_.H + 1 + d_.H * (int)(ROW_SUBS * ROW_CNT_STRIDE));  // the per-pixel counts and, behind them, the per-row list counts
   st = st_;
   fa = fa_;
   dst_main = const_cast<FrameArgs *>(sc.fa);

@@ -108,6 +108,8 @@ struct Counters {
 };
 static_assert(sizeof(Counters::ShardLine) == 128, "one cache line per shard");
 constexpr uint32_t VIS_SHARDS = 64;
+constexpr uint32_t ROW_SUBS = 8;  // sub-lists per image row of the visible particles (Scratch::row_list)
+constexpr uint32_t ROW_CNT_STRIDE = 32;  // uint32 per sub-list counter: a cache line each (atomics on one line retire one at a time)
 constexpr uint32_t OWNER_CHUNK = 4096;  // slots per owner_flag byte (= slots per block of the move sweep)
 constexpr uint32_t OWNER_GROUP = 64;    // chunks per owner_flag2 byte
 // sizes of the two flag levels for n_slots slots, padded so that the member count reads them in whole 16-byte pieces

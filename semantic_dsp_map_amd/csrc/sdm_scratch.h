@@ -66,8 +66,16 @@ struct Scratch {
   uint64_t *line_ne = nullptr, *line_ey = nullptr, *line_ez = nullptr, *line_reach = nullptr;
   int wy = 0;
   // per-pixel bins
+  // bin_count: per pixel (H*W + 1 entries), directly behind it row_cnt (H * ROW_SUBS entries), zeroed together at frame
+  // begin.  bin_start: W + 1 offsets per image row (the last one is the row's end); the rows' blocks lie in the bin-order
+  // arrays in the order the rows' workgroups reserved them (k_bin_rows).
   uint32_t *bin_count = nullptr, *bin_start = nullptr;
-  uint32_t *vis_pix = nullptr, *vis_idx = nullptr, *vis_pib = nullptr;
+  // the visible particles as k_visibility lists them: per image row ROW_SUBS lists of row_cap entries
+  // {particle index, column | place in the pixel's bin << 11}
+  uint32_t *row_cnt = nullptr;  // H * ROW_SUBS counters, ROW_CNT_STRIDE words apart
+  uint8_t *row_win = nullptr;   // per pixel: particles its image row puts into a window centred in its column (saturated)
+  uint2 *row_list = nullptr;
+  uint32_t row_cap = 0;
   uint32_t cap_vis = 0;
   // visible particles in bin order
   uint32_t *bin_idx = nullptr, *vpix = nullptr;
@@ -144,7 +152,7 @@ struct MembersArgs {
   size_t n_slots;
 };
 struct FrameBeginLaunch {
-  static constexpr unsigned GRID = 256, BLOCK = 256;
+  static constexpr unsigned GRID = 512, BLOCK = 256;
   Counters *cnt;
   uint32_t *bin_count;
   uint32_t n_bins;

@@ -1,7 +1,12 @@
 // Drives include/semantic_dsp_map.h - the reference's class API - through a committed clip the way src/mapping.cpp drives the
 // reference (setters, then update(depth, MaskKpts, pose, clouds) per frame) and dumps the clouds update() emits, byte for
 // byte, for tests/test_adapter_parity.py to compare with the fixture the oracle produced.
-// usage: adapter_parity <clip.bin> <out.bin>        (clip format: tests/adapter_clip.py write_binary)
+// usage: adapter_parity <clip.bin> <out.bin> [time]  (clip format: tests/adapter_clip.py write_binary)
+// "time": the wall-clock time of every update() call - host buffers in, clouds out, everything the class does in between
+// (mask packing, object layer, uploads, the frame on the GPU, the download of the clouds) - is printed per frame and as the
+// median of the frames after the second (bench.py's adapter_e2e leg).
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +38,8 @@ struct Reader {
 
 int main(int argc, char **argv) {
   if (argc < 3) return 64;
+  const bool timing = argc > 3 && std::string(argv[3]) == "time";
+  std::vector<double> frame_ms;
   Reader r{std::fopen(argv[1], "rb")};
   if (!r.f) return 65;
   char magic[8];
@@ -98,15 +105,22 @@ int main(int argc, char **argv) {
     Eigen::Vector3d pos(pose[0], pose[1], pose[2]);
     Eigen::Quaterniond q(pose[3], pose[4], pose[5], pose[6]);  // w, x, y, z
     pcl::PointCloud<pcl::PointXYZRGB>::Ptr occ(new pcl::PointCloud<pcl::PointXYZRGB>), fr(new pcl::PointCloud<pcl::PointXYZRGB>);
+    const auto t0 = std::chrono::steady_clock::now();
     map.update(depth, seg, pos, q, occ, fr, want_free != 0, pose[7]);
+    frame_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     const uint32_t n_occ = (uint32_t)occ->points.size(), n_free = (uint32_t)fr->points.size();
     std::fwrite(&n_occ, 4, 1, out);
     if (n_occ) std::fwrite(static_cast<const void *>(occ->points.data()), sizeof(pcl::PointXYZRGB), n_occ, out);
     std::fwrite(&n_free, 4, 1, out);
     if (n_free) std::fwrite(static_cast<const void *>(fr->points.data()), sizeof(pcl::PointXYZRGB), n_free, out);
-    std::printf("frame %u: %u occupied, %u free voxels\n", t, n_occ, n_free);
+    std::printf("frame %u: %u occupied, %u free voxels, update() %.3f ms\n", t, n_occ, n_free, frame_ms.back());
   }
   std::fclose(out);
+  if (timing && frame_ms.size() > 3) {
+    std::vector<double> v(frame_ms.begin() + 2, frame_ms.end());
+    std::sort(v.begin(), v.end());
+    std::printf("e2e median_ms_per_update %.4f min %.4f frames %zu\n", v[v.size() / 2], v.front(), v.size());
+  }
   std::printf("adapter parity clip done\n");
   return 0;
 }

@@ -263,7 +263,7 @@ def test_hip_path_against_the_literal_reference_order(cfg_name, params_name, n_f
 
 @pytest.mark.parametrize("name,params_name,n_particles,n_warm,n_frames,scene_kw", [
     # the benchmark state of bench.py: C3 prefilled to 2 M particles, 6 moving objects
-    ("C3_benchmark_state", "vkitti2", 2000000, 0, 10, dict(n_static=48, n_dynamic=6, seed=7)),
+    ("C3_benchmark_state", "vkitti2", 2320000, 0, 10, dict(n_static=48, n_dynamic=6, seed=7)),
     # bench.py's busy scene: 200 static + 12 moving boxes, three noisy births per point, yaw + sideways drift: the 14
     # warm-up frames and 3 of the frames `stress` times (~51 k visible particles per frame)
     ("C3_stress_scene", "vkitti2_nb3", 2000000, 14, 3, dict(n_static=200, n_dynamic=12, seed=11, yaw_rate_deg=1.5, lateral_extra=(0, 0.04))),

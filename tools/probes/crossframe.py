@@ -14,7 +14,7 @@ cfg, params = synth.CONFIGS["C3"], synth.PARAMS["vkitti2"]
 scene = synth.Scene(cfg, n_static=48, n_dynamic=6, seed=7)
 st, ring, _ = synth.prefill_state(cfg, scene, 2000000)
 host = [scene.render(t, params) + (scene.moves(t),) for t in range(10)]
-buf = np.zeros(6 * 8192 * 4 + 3 * 4096 * 4, np.uint64)
+buf = np.zeros(6 * 8192 * 4 + 4 * 4096 * 4, np.uint64)
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     eng = sharded.NativeShardedMap(cfg, params, 0, 1, 0)
     m = eng.map
@@ -41,12 +41,12 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     t0 = time.perf_counter()
     for t in range(6, 9):
         eng.update(*frames[t])
-    m.update(frames[9][0], frames[9][1], frames[9][2], frames[9][3], frames[9][4], stop_after="move", on_device=True)
+    m.update(frames[9][0], frames[9][1], frames[9][2], frames[9][3], frames[9][4], stop_after=os.environ.get("CROSSFRAME_STOP", "move"), on_device=True)
     m.synchronize()
     m.device_synchronize()
     L.sdm_debug_timers(m.h, buf.ctypes.data, 0)
     k = buf[:6 * 8192 * 4].astype(np.int64).reshape(6, 8192, 4)
-    mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(3, 4096, 4)
+    mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(4, 4096, 4)
     occ = k[5]
     occ_end = max(occ[:, 1].max(), occ[:, 3].max())
     occ_start = occ[occ[:, 0] > 0, 0].min()
@@ -61,6 +61,10 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     wt_end = k[4][:, 1].max()
     br_start = first(k[0])
     mm = mv[2]
+    fb = mv[3]
+    if (fb[:, 0] > 0).any():
+        print("   k_frame_begin (9): first workgroup enters %.1f us after the sweep's end, last enters %.1f, duties done (last) %.1f"
+              % ((first(fb) - occ_end) / 100.0, (fb[:, 0].max() - occ_end) / 100.0, (fb[:, 1].max() - occ_end) / 100.0), flush=True)
     if (mm[:, 0] > 0).any():
         print("   frame_begin + member count (9): first start %.1f us after the sweep's end, lists done %.1f, last workgroup done %.1f; move_apply ends %.1f, move_replay ends %.1f"
               % ((first(mm) - occ_end) / 100.0, (mm[:, 1].max() - occ_end) / 100.0, (mm[:, 3].max() - occ_end) / 100.0,

@@ -18,7 +18,7 @@ m.load_state(st)
 m.set_ring_state(ring)
 L = m.L
 L.sdm_debug_timers.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-buf = np.zeros(6 * 8192 * 4 + 3 * 4096 * 4, np.uint64)
+buf = np.zeros(6 * 8192 * 4 + 4 * 4096 * 4, np.uint64)
 us = lambda x: x / 100.0
 
 
@@ -41,7 +41,7 @@ for t in range(10):
     if t < 7:
         continue
     k = buf[:6 * 8192 * 4].astype(np.int64).reshape(6, 8192, 4)
-    mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(3, 4096, 4)
+    mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(4, 4096, 4)
     print("frame %d (thread 0 of every workgroup; 100 MHz wall clock)" % t)
     mm = mv[2].copy()
     span("move_members (lists)", mm, "| chunks: first done %.1f, all done %.1f us after the kernel's first start" % (us((mm[mm[:, 2] > 0, 2].min() if (mm[:, 2] > 0).any() else 0) - mm[mm[:, 0] > 0, 0].min()), us(mm[:, 3].max() - mm[mm[:, 0] > 0, 0].min())) if (mm[:, 0] > 0).any() else "")
@@ -50,8 +50,11 @@ for t in range(10):
     extra = "| prefix %.1f, moves %.1f us (avg, chunks with members)" % (us((a[act, 1] - a[act, 0]).mean()), us((a[act, 2] - a[act, 1]).mean())) if act.any() else ""
     a[:, 1] = a[:, 3]
     span("move_apply", a, extra)
-    r = mv[1].copy(); r[:, 1] = r[:, 2]
-    span("move_replay", r)
+    r = mv[1].copy()
+    hd = (r[:, 0] > 0) & (r[:, 1] > 0) & (r[:, 2] > 0)
+    extra = "| heads (thread 0): list walked %.1f, copies + insertions %.1f us (avg), copies re-inserted avg %.1f" % (us((r[hd, 1] - r[hd, 0]).mean()), us((r[hd, 2] - r[hd, 1]).mean()), r[hd, 3].mean()) if hd.any() else ""
+    r[:, 1] = r[:, 2]
+    span("move_replay", r, extra)
     v = k[1]; w = v.copy(); w[:, 1] = w[:, 3]
     act = (v[:, 0] > 0) & (v[:, 3] > 0)
     span("visibility", w, "| masks %.1f, empty voxels %.1f, full voxels %.1f us (avg)" % (us((v[act, 1] - v[act, 0]).mean()), us((v[act, 2] - v[act, 1]).mean()), us((v[act, 3] - v[act, 2]).mean())) if act.any() else "")
