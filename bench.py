@@ -464,6 +464,10 @@ def main():
         seg = sharded.halo_segment_bytes(sharded.HALO_DEFAULT_CAP)
         collectives = {"us": {k: round(float(v), 1) for k, v in zip(names, ct.tolist())},
                        "frames_timed": 2 * n_extra,
+                       "ck_exchange": ("one all-gather of the whole partial images (SDM_CK_EXCHANGE=allgather: its time is under ck_alltoall, "
+                                       "ck_allgather did not run)" if os.environ.get("SDM_CK_EXCHANGE") == "allgather" else
+                                       "chunk-owner reduction: all-to-all + slab-ordered sum + all-gather (default; SDM_CK_EXCHANGE=allgather "
+                                       "selects the one-collective variant)"),
                        "bytes_received_per_shard_per_frame": {"counts_allgather": (world - 1) * sharded.HALO_OBJ * 4,
                                                               "halo_alltoall": (world - 1) * seg,
                                                               "ck_alltoall": (world - 1) * chunk * 4,
@@ -585,28 +589,18 @@ def main():
         strong["scaling"] = "strong"
         eng4.map.close()
 
-    # The side legs run in processes of their own (bench.py --only-stress / --only-grown): a process's second and later
-    # maps run 17-40 us per frame slower than its first, and a leg should measure its workload, not its
-    # place in this script.  Falls back to running them here if the child fails.
-    def side_leg(flag, key, run_here):
-        import subprocess
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), flag], capture_output=True, text=True, timeout=900)
-            leg = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])[key]
-            leg["process"] = "own process (%s)" % flag
-            return leg
-        except Exception:  # noqa: BLE001
-            leg = run_here(synth, sharded)
-            leg["process"] = "this process (the child failed)"
-            return leg
-
+    # The side legs: maps of their own in this process, one after the other.  (Round 3 ran them as child processes: the
+    # second and later maps of a process ran 17-40 us per frame slower than its first - the launch-mode policy took each
+    # map's own, noisier measurement of the host's speed and replayed later maps from graphs; fixed in sdm_create.)
     stress = None
     if not multi and not args.no_stress and not args.no_cpu:
-        stress = side_leg("--only-stress", "stress", stress_run)
+        stress = stress_run(synth, sharded)
+        stress["process"] = "this process (a later map of it)"
 
     grown = None
     if not multi and not args.no_grown and not args.no_cpu:
-        grown = side_leg("--only-grown", "grown", grown_run)
+        grown = grown_run(synth, sharded)
+        grown["process"] = "this process (a later map of it)"
 
     adapter = None
     if not multi and not args.no_adapter and not args.no_cpu:

@@ -335,6 +335,14 @@ sdm_status sdm_ck_reduce(sdm_map *m, const float *stage_dev, float *full_dev);
 sdm_status sdm_comm_unique_id(uint8_t out[128]);
 /* halo_cap_records: capacity per destination shard of the export segments, 0 = SDM_HALO_DEFAULT_CAP */
 sdm_status sdm_comm_init(sdm_map *m, const uint8_t id[128], int32_t halo_cap_records);
+/* How sdm_update_sharded combines the shards' partial ck images, and how long sdm_synchronize waits for a sharded frame.
+ * ck_exchange: 0 = chunk-owner reduction (all-to-all of the chunks to their owners, slab-ordered sum there, all-gather of the
+ * summed chunks: 2 (G-1)/G images received, two collectives on the critical path; the default), 1 = ONE all-gather of the
+ * whole partial images and the slab-ordered sum on every shard (G-1 images received, one collective), -1 = leave as it is
+ * (environment: SDM_CK_EXCHANGE=allgather).  Both form the same float sums.  All shards must choose alike.
+ * timeout_ms > 0: bound of sdm_synchronize's wait (default 30000, SDM_COMM_TIMEOUT_MS): beyond it - a peer died or fell out
+ * of step - the communicator is aborted and SDM_ERR_COMM returned instead of hanging. */
+sdm_status sdm_comm_set_options(sdm_map *m, int32_t ck_exchange, int32_t timeout_ms);
 sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_point *cloud,
                               const float cam_pos[3], const float cam_q[4],
                               const sdm_object_move *moves, int32_t n_moves,

@@ -647,14 +647,13 @@ class SemanticDSPMap {
       depth_.resize(hw);
       static_mask_.resize(hw);
     }
-    for (int i = 0; i < H; ++i)
-      for (int j = 0; j < W; ++j) depth_[(size_t)i * W + j] = depth.at<float>(i, j);
+    for (int i = 0; i < H; ++i) std::memcpy(&depth_[(size_t)i * W], depth.ptr<float>(i), (size_t)W * sizeof(float));  // (row by row: a cv::Mat need not be continuous)
     have_static_ = false;
     for (const auto &s : seg) {  // :121-143, the first "static" entry
       if (s.label != "static") continue;
       std::fill(static_mask_.begin(), static_mask_.end(), (uint8_t)255);  // uncovered pixels: no label -> Background's instance
       for (int j = 0; j < s.mask.rows && j < H; ++j)
-        for (int k = 0; k < s.mask.cols && k < W; ++k) static_mask_[(size_t)j * W + k] = s.mask.at<uchar>(j, k);
+        std::memcpy(&static_mask_[(size_t)j * W], s.mask.ptr<uchar>(j), (size_t)std::min(s.mask.cols, W));
       have_static_ = true;
       break;
     }
@@ -669,8 +668,7 @@ class SemanticDSPMap {
       for (const auto &s : seg) {
         if (s.label == "static") continue;
         uint8_t *dst = object_masks_.data() + k_obj * hw;
-        for (int j = 0; j < s.mask.rows && j < H; ++j)
-          for (int k = 0; k < s.mask.cols && k < W; ++k) dst[(size_t)j * W + k] = s.mask.at<uchar>(j, k);
+        for (int j = 0; j < s.mask.rows && j < H; ++j) std::memcpy(dst + (size_t)j * W, s.mask.ptr<uchar>(j), (size_t)std::min(s.mask.cols, W));
         auto it = label_id_.find(s.label);
         sdm_instance_mask o;
         o.track_id = s.track_id;

@@ -154,6 +154,7 @@ def load_library():
         "sdm_voxels_device_ptr": [vp, C.POINTER(vp)],
         "sdm_object_particle_count": [vp, i32, C.POINTER(i64)],
         "sdm_tracks_with_particles": [vp, vp, i32, C.POINTER(i32)],
+        "sdm_comm_set_options": [vp, i32, i32],
         "sdm_get_stats": [vp, C.POINTER(Stats), i32],
         "sdm_set_profiling": [vp, i32],
         "sdm_debug_force_generic_flood": [vp, i32],
@@ -355,6 +356,10 @@ class SdmMap:
         buf = np.frombuffer(bytes(id_bytes), np.uint8).copy()
         assert buf.size == 128
         _check(self.L, self.L.sdm_comm_init(self.h, _ptr(buf), halo_cap), "sdm_comm_init")
+
+    def comm_set_options(self, ck_exchange=-1, timeout_ms=0):
+        """ck_exchange: 0 chunk-owner reduction, 1 one all-gather of the whole partial images, -1 unchanged"""
+        _check(self.L, self.L.sdm_comm_set_options(self.h, ck_exchange, timeout_ms), "sdm_comm_set_options")
 
     def update_sharded(self, depth, cloud, cam_pos, cam_q, moves=None, remove_tracks=None, on_device=False, flags=0):
         keep, args = self._frame_args(depth, cloud, cam_pos, cam_q, moves, remove_tracks, on_device)

@@ -1570,26 +1570,27 @@ __global__ __launch_bounds__(BR_TPB) void k_bin_rows(Dims d, State st, Scratch s
     const uint32_t p = (uint32_t)(r * W + j0 + u);
     const uint32_t s = base + pre[j0 + u];
     uint32_t *a = sc.bin_idx + s;
-    if (n <= 8) {
-      // the usual bin: its entries in registers (one round trip for all of them), ordered by a sorting network, then the
-      // particles' fields - again all requested before the first is used.  (Sorted in place in memory and gathered entry by
-      // entry, a bin of ten was a chain of sixty dependent memory accesses: the tail this kernel used to end with.)
-      uint32_t v[8];
+    // the usual bin: its entries in registers (one round trip for all of them), ordered by a sorting network, then the
+    // particles' fields - again all requested before the first is used.  (Sorted in place in memory and gathered entry by
+    // entry, a bin of ten was a chain of sixty dependent memory accesses: the tail this kernel used to end with.)
+    auto small_bin = [&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      uint32_t v[K];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (uint32_t)i < n ? a[i] : 0xffffffffu;
+      for (int i = 0; i < K; ++i) v[i] = (uint32_t)i < n ? a[i] : 0xffffffffu;
 #pragma unroll
-      for (int pass = 0; pass < 8; ++pass)
+      for (int pass = 0; pass < K; ++pass)
 #pragma unroll
-        for (int i = pass & 1; i + 1 < 8; i += 2) {  // odd-even transposition: 8 passes order 8 keys
+        for (int i = pass & 1; i + 1 < K; i += 2) {  // odd-even transposition: K passes order K keys
           const uint32_t lo = v[i] < v[i + 1] ? v[i] : v[i + 1], hi = v[i] < v[i + 1] ? v[i + 1] : v[i];
           v[i] = lo;
           v[i + 1] = hi;
         }
-      float4 q[8];
-      float w8[8];
-      uint16_t t8[8];
+      float4 q[K];
+      float w8[K];
+      uint16_t t8[K];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < K; ++i)
         if ((uint32_t)i < n) {
           const size_t li = (size_t)v[i] - slot_base;
           q[i] = st.pos4[li];
@@ -1597,13 +1598,20 @@ __global__ __launch_bounds__(BR_TPB) void k_bin_rows(Dims d, State st, Scratch s
           t8[i] = st.track[rec_index(li, d.p_n, REC_TRACK)];
         }
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < K; ++i)
         if ((uint32_t)i < n) {
           if (n > 1) a[i] = v[i];
           sc.vp4[s + i] = make_float4(q[i].x, q[i].y, q[i].z, w8[i]);
           sc.vtf[s + i] = (uint32_t)t8[i] | ((__float_as_uint(q[i].w) & 0xffu) << 16);
           sc.vpix[s + i] = p;
         }
+    };
+    if (n <= 8) {
+      small_bin(std::integral_constant<int, 8>{});
+      continue;
+    }
+    if (n <= 16) {
+      small_bin(std::integral_constant<int, 16>{});
       continue;
     }
     if (n > 1) {
@@ -1927,7 +1935,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, St
 
 // ck_kappa from the per-slab partial images, summed in slab order (multi-GPU path)
 __global__ __launch_bounds__(TPB) void k_ck_finish(Dims d, Filter flt, Scratch sc, const float *__restrict__ parts,
-                                                   int n_parts) {
+                                                   int n_parts, size_t part_stride) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.W * d.H) return;
   const sdm_labeled_point o = sc.fa->cloud[p];
@@ -1936,8 +1944,7 @@ __global__ __launch_bounds__(TPB) void k_ck_finish(Dims d, Filter flt, Scratch s
     return;
   }
   float ck = 0.f;
-  size_t hw = (size_t)d.W * d.H;
-  for (int g = 0; g < n_parts; ++g) ck += parts[(size_t)g * hw + p];
+  for (int g = 0; g < n_parts; ++g) ck += parts[(size_t)g * part_stride + p];
   const float ckk = ck * flt.p_detect + flt.noise_number;
   sc.ck_kappa[p] = ckk;
   sc.pix4[p] = make_float4(o.x, o.y, o.z, ckk);
@@ -2952,8 +2959,9 @@ void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch 
   hipLaunchKernelGGL(k_ck, dim3(CK_HEAVY_BLOCKS + blocks_for((size_t)d.W * d.H, A7_ROWS * A7_ITEMS)), dim3(A7_ROWS, A7_ITEMS), 0, s, d, flt, st, sc,
                      ck_out, finish);
 }
-void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s) {
-  hipLaunchKernelGGL(k_ck_finish, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, parts, n_parts);
+void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, size_t part_stride, hipStream_t s) {
+  hipLaunchKernelGGL(k_ck_finish, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, parts, n_parts,
+                     part_stride ? part_stride : (size_t)d.W * d.H);
 }
 void launch_ck_reduce_chunk(const float *stage, float *full, uint32_t chunk, int world, int rank, hipStream_t s) {
   hipLaunchKernelGGL(k_ck_reduce_chunk, dim3((chunk + TPB - 1) / TPB), dim3(TPB), 0, s, stage, full, chunk, world, rank);

@@ -175,7 +175,8 @@ void launch_frustum(const Dims &d, const Scratch &sc, hipStream_t s);
 // visibility + binning; its last kernel also classifies the pixels for launch_ck (same ck_out / finish)
 void launch_visibility(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
-void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, hipStream_t s);
+// part_stride: floats between two partial images (0 = H*W)
+void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, size_t part_stride, hipStream_t s);
 void launch_ck_reduce_chunk(const float *stage, float *full, uint32_t chunk, int world, int rank, hipStream_t s);
 void launch_weight(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
 int launch_birth_prepare(const Dims &d, const Filter &flt, const BirthOrder &bo, const State &st,

@@ -126,7 +126,8 @@ class GlooShardEngine:
                   "halo_recv": m.device_put(np.zeros(hb, np.uint8)),
                   "ck_part": m.device_put(np.zeros(ck, np.float32)),
                   "ck_stage": m.device_put(np.zeros(ck, np.float32)),
-                  "ck_full": m.device_put(np.zeros(ck, np.float32))}
+                  "ck_full": m.device_put(np.zeros(ck, np.float32)),
+                  "ck_all": m.device_put(np.zeros(world * self.hw, np.float32))}
         m.set_ck_buffer(self.d["ck_part"])
         m.set_halo_buffers(self.d["counts_local"], self.d["counts_all"], self.d["halo_send"], self.d["halo_recv"], halo_cap)
         self.counts_local = torch.zeros(HALO_OBJ, dtype=torch.int32)
@@ -137,13 +138,15 @@ class GlooShardEngine:
         self.ck_stage = torch.zeros(ck, dtype=torch.float32)
         self.ck_chunk = torch.zeros(self.chunk, dtype=torch.float32)
         self.ck_full = torch.zeros(ck, dtype=torch.float32)
+        self.ck_all = torch.zeros(world * ck, dtype=torch.float32)   # ck_exchange "allgather": every shard's padded partial image
         # bytes RECEIVED from other shards per exchange, summed over the frames; halo_records = records this shard exported
-        self.bytes_exchanged = {"counts": 0, "halo": 0, "halo_records": 0, "ck_alltoall": 0, "ck_allgather": 0, "frames": 0}
+        self.bytes_exchanged = {"counts": 0, "halo": 0, "halo_records": 0, "ck_alltoall": 0, "ck_allgather": 0, "ck_images": 0, "frames": 0}
 
     # exchange hooks of ShardedDriver: device source -> host tensor before a collective, host tensor -> device after it
     def pull(self, name):
         src, dst = {"counts": ("counts_local", self.counts_local), "halo": ("halo_send", self.halo_send),
-                    "ck_part": ("ck_part", self.ck_part), "ck_chunk": ("ck_full", self.ck_chunk)}[name]
+                    "ck_part": ("ck_part", self.ck_part), "ck_image": ("ck_part", self.ck_part),
+                    "ck_chunk": ("ck_full", self.ck_chunk)}[name]
         host = dst.numpy()
         off = self.rank * self.chunk * 4 if name == "ck_chunk" else 0
         host.view(np.uint8)[:] = self.map.device_download(self.d[src] + off, host.nbytes)
@@ -156,10 +159,16 @@ class GlooShardEngine:
             self.bytes_exchanged["halo_records"] += int(heads.sum())
         elif name == "ck_part":
             self.bytes_exchanged["ck_alltoall"] += self.chunk * 4 * w1
+        elif name == "ck_image":
+            self.bytes_exchanged["ck_images"] += self.chunk * self.world * 4 * w1
         else:
             self.bytes_exchanged["ck_allgather"] += self.chunk * 4 * w1
 
     def push(self, name):
+        if name == "ck_all":  # the gathered images are padded to whole chunks: sdm_update_finish takes them H*W floats apart
+            img = self.ck_all.numpy().reshape(self.world, self.world * self.chunk)[:, :self.hw]
+            self.map.device_upload(self.d["ck_all"], np.ascontiguousarray(img))
+            return
         src, dst = {"counts": (self.counts_all, "counts_all"), "halo": (self.halo_recv, "halo_recv"),
                     "ck_stage": (self.ck_stage, "ck_stage"), "ck_full": (self.ck_full, "ck_full")}[name]
         self.map.device_upload(self.d[dst], src.numpy())
@@ -180,6 +189,10 @@ class GlooShardEngine:
     def finish(self):
         self.map.update_finish(self.d["ck_full"], 1)
 
+    def finish_images(self):
+        """ck_exchange "allgather": the shards' whole partial images, added in slab order by the library"""
+        self.map.update_finish(self.d["ck_all"], self.world)
+
     def close(self):
         self.map.close()
 
@@ -193,8 +206,11 @@ class ShardedDriver:
     ck_full (world chunks each) and ck_chunk (this shard's summed chunk); methods start, moves, predict, ck_reduce, finish;
     optional pull(name) / push(name) around every collective for engines whose buffers have to be staged (GlooShardEngine)."""
 
-    def __init__(self, engine, rank, world, dist=None):
+    def __init__(self, engine, rank, world, dist=None, ck_exchange="chunks"):
+        """ck_exchange: "chunks" = chunk-owner reduction (two collectives, 2 (G-1)/G images received), "allgather" = ONE
+        all-gather of the whole partial images, every shard adds them itself (sdm_comm_set_options, ck_exchange 1)"""
         self.engine, self.rank, self.world, self.dist = engine, rank, world, dist
+        self.ck_exchange = ck_exchange
         if world > 1 and dist is None:
             raise ValueError("world > 1 needs a torch.distributed module")
 
@@ -214,6 +230,15 @@ class ShardedDriver:
             d.all_to_all_single(e.halo_recv, e.halo_send)         # segment s of recv = segment `rank` of shard s's send
             push("halo")
         e.predict()
+        if self.ck_exchange == "allgather":
+            pull("ck_image")
+            if multi:
+                d.all_gather_into_tensor(e.ck_all, e.ck_part)   # image s = shard s's partial sums for every pixel
+            else:
+                e.ck_all[:e.ck_part.numel()] = e.ck_part
+            push("ck_all")
+            e.finish_images()
+            return
         pull("ck_part")
         if multi:
             d.all_to_all_single(e.ck_stage, e.ck_part)            # part s of stage = shard s's sums for my pixels

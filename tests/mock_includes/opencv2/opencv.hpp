@@ -23,6 +23,8 @@ struct Mat {
   bool empty() const { return rows == 0 || cols == 0; }
   template <typename T> T &at(int r, int c) { return *reinterpret_cast<T *>(&buf[((size_t)r * cols + c) * sizeof(T)]); }
   template <typename T> const T &at(int r, int c) const { return *reinterpret_cast<const T *>(&buf[((size_t)r * cols + c) * sizeof(T)]); }
+  template <typename T> T *ptr(int r) { return reinterpret_cast<T *>(&buf[(size_t)r * cols * elem]); }
+  template <typename T> const T *ptr(int r) const { return reinterpret_cast<const T *>(&buf[(size_t)r * cols * elem]); }
 };
 // stand-in: a plain copy (the real conversion is OpenCV's; only the adapter's call sequence is compile-checked here)
 inline void cvtColor(const Mat &src, Mat &dst, int) { dst = src; }

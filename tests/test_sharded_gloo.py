@@ -34,6 +34,7 @@ class FakeEngine:
         self.ck_stage = torch.zeros(world * chunk, dtype=torch.float32)
         self.ck_chunk = torch.zeros(chunk, dtype=torch.float32)
         self.ck_full = torch.zeros(world * chunk, dtype=torch.float32)
+        self.ck_all = torch.zeros(world * world * chunk, dtype=torch.float32)
         self.log = []
 
     def start(self, depth, cloud, pos, q, moves=None, remove_tracks=None, **kw):
@@ -64,6 +65,14 @@ class FakeEngine:
         self.log.append("finish")
         self.final = self.ck_full.clone()
 
+    def finish_images(self):
+        self.log.append("finish_images")
+        img = self.ck_all.reshape(self.world, self.world * self.chunk)
+        acc = self.t.zeros(self.world * self.chunk)
+        for s in range(self.world):   # slab order
+            acc = acc + img[s]
+        self.final = acc
+
 
 def worker(rank, world, port, results):
     import torch
@@ -93,6 +102,15 @@ def worker(rank, world, port, results):
             assert int(row[0]) == 10 * (r + 1) and int(row[1]) == 10 * (r + 1) + 1 and int(row[2]) == 0
             # segment r of the receive buffer: from shard r, addressed to me
             assert torch.all(eng.halo_recv[r * eng.seg:(r + 1) * eng.seg] == 16 * r + rank)
+        # the one-collective variant of the ck exchange: image s of the gathered buffer = shard s's whole partial image, and
+        # the slab-ordered sum comes out the same
+        eng2 = FakeEngine(torch, rank, world)
+        sharded.ShardedDriver(eng2, rank, world, dist, ck_exchange="allgather").update(None, None, None, None, moves=[])
+        assert eng2.log == ["start", "moves", "predict", "finish_images"]
+        img = eng2.ck_all.reshape(world, world * eng2.chunk)
+        for s in range(world):
+            assert torch.equal(img[s], 1000.0 * (s + 1) + p)
+        assert torch.equal(eng2.final, eng.final)
         # rendezvous of the RCCL id: everybody gets rank 0's bytes
         from semantic_dsp_map_amd import binding
         binding.comm_unique_id = lambda: bytes([(7 * i + 3) % 256 for i in range(128)]) if rank == 0 else b"\0" * 128

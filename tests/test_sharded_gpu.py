@@ -143,6 +143,32 @@ def test_native_rccl_single_rank():
     b.close()
 
 
+def test_native_rccl_single_rank_one_collective():
+    """the ck exchange as ONE all-gather of the whole partial images (sdm_comm_set_options): same result, and the timers say
+    which collectives ran"""
+    cfg, params, frames = synth.make_frames("T0", 4, "vkitti2", n_dynamic=2)
+    noise = synth.noise_table()
+    a = binding.SdmMap(cfg, params, noise)
+    b = binding.SdmMap(cfg, params, noise)
+    b.comm_init(binding.comm_unique_id(), 1024)
+    b.comm_set_options(ck_exchange=1, timeout_ms=20000)
+    b.comm_timing(True)
+    for depth, cloud, pos, q, moves in frames:
+        a.update(depth, cloud, pos, q, moves, sync=True)
+        b.update_sharded(depth, cloud, pos, q, moves)
+        b.synchronize()
+        ct = b.comm_times()
+        assert ct["ck_alltoall"] > 0 and ct["ck_allgather"] == 0   # (slot 2 times the one collective, slot 3 did not run)
+    sa, sb = a.dump_state(), b.dump_state()
+    for k in pu.STATE_KEYS:
+        assert pu.diff_report(k, sa[k], sb[k]) is None
+    assert np.array_equal(a.voxels(), b.voxels())
+    with pytest.raises(Exception):
+        b.comm_set_options(ck_exchange=5)
+    a.close()
+    b.close()
+
+
 def test_gloo_rendezvous_then_rccl_in_one_process():
     """The order bench.py uses at N > 1: torch + a gloo process group first (CPU only), then libsdm_hip, the RCCL id
     through sharded.broadcast_unique_id, sdm_comm_init and sharded frames.  Run in a fresh interpreter: torch brings

@@ -70,7 +70,7 @@ def worker(rank, world, port, spec, results):
         cfg, params, scene = scene_and_params(spec)
         noise = synth.noise_table()
         eng = sharded.GlooShardEngine(cfg, params, rank, world, device=0, noise_table=noise)
-        drv = sharded.ShardedDriver(eng, rank, world, dist)
+        drv = sharded.ShardedDriver(eng, rank, world, dist, ck_exchange=spec.get("ck_exchange", "chunks"))
         if spec.get("prefill"):
             st, ring, _ = synth.prefill_state(cfg, scene, spec["prefill"] // world, shard_rank=rank, shard_count=world)
             eng.map.load_state(st)
@@ -179,7 +179,8 @@ def run(world, spec, reference):
     frames = res[0][2]["frames"]
     ex = {k: max(r[2][k] for r in res.values()) // frames for k in ("counts", "halo", "ck_alltoall", "ck_allgather")}
     ex["halo_records_exported_in_all"] = sum(r[2]["halo_records"] for r in res.values())
-    ex["received_per_shard_and_frame"] = ex["counts"] + ex["halo"] + ex["ck_alltoall"] + ex["ck_allgather"]
+    ex["ck_images"] = max(r[2].get("ck_images", 0) for r in res.values()) // frames
+    ex["received_per_shard_and_frame"] = ex["counts"] + ex["halo"] + ex["ck_alltoall"] + ex["ck_allgather"] + ex["ck_images"]
     ex["live_particles"] = sum(r[3] for r in res.values())
     print("world %d %s: bytes received per shard and frame %s" % (world, spec["cfg"], ex))
     return ex
@@ -194,6 +195,20 @@ def test_two_process_real_engine_gloo_C3():
     """C3-sized map (256^3, 8 slots, 1242x375) split in two Z slabs, six dynamic objects, from an empty map."""
     ex = run(2, dict(cfg="C3", params="vkitti2", n_frames=5, scene_kw=dict(n_static=48, n_dynamic=6, seed=7)), reference_oracle)
     assert ex["halo_records_exported_in_all"] > 0, "no particle crossed the slab border"
+
+
+def test_two_process_real_engine_gloo_C3_one_collective():
+    """the same with the partial ck images combined by ONE all-gather and the slab-ordered sum on every shard
+    (sdm_comm_set_options ck_exchange 1): the same float sums, so the same digests"""
+    ex = run(2, dict(cfg="C3", params="vkitti2", n_frames=5, scene_kw=dict(n_static=48, n_dynamic=6, seed=7), ck_exchange="allgather"),
+             reference_oracle)
+    assert ex["halo_records_exported_in_all"] > 0 and ex["ck_images"] > 0 and ex["ck_alltoall"] == 0
+
+
+def test_four_process_real_engine_gloo_small_one_collective():
+    ex = run(4, dict(cfg="T0", params="vkitti2", n_frames=8, scene_kw=dict(n_dynamic=3, dyn_speed=(0.8, 1.6)), ck_exchange="allgather"),
+             reference_oracle)
+    assert ex["ck_images"] > 0 and ex["ck_alltoall"] == 0
 
 
 C4_SPEC = dict(cfg="C4", params="vkitti2", n_frames=10, prefill=8000000, state_frames=(0, 4, 9),

@@ -69,6 +69,8 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
         print("   frame_begin + member count (9): first start %.1f us after the sweep's end, lists done %.1f, last workgroup done %.1f; move_apply ends %.1f, move_replay ends %.1f"
               % ((first(mm) - occ_end) / 100.0, (mm[:, 1].max() - occ_end) / 100.0, (mm[:, 3].max() - occ_end) / 100.0,
                  (ap[:, 3].max() - occ_end) / 100.0, (rp_end - occ_end) / 100.0), flush=True)
+    stt = m.stats()
+    print("   issue: host_enqueue_us %.1f, graph frames %d, direct frames %d" % (stt["host_enqueue_us"], stt["graph_frames"], stt["direct_frames"]), flush=True)
     print("map %d: %.4f ms/frame | sweep(8) %.1f us; births end -> sweep start %.1f; sweep end -> move_apply(9) start %.1f | frame 8: visibility end -> bin_sort_gather start %.1f, weight end -> birth_replay start %.1f us"
           % (rep, ms, (occ_end - occ_start) / 100.0, (occ_start - birth_end) / 100.0, (ap_start - occ_end) / 100.0,
              (bsg_start - vis_end) / 100.0, (br_start - wt_end) / 100.0), flush=True)
