@@ -1772,7 +1772,9 @@ __device__ __forceinline__ void ck_light_pixel(const Dims &d, const Filter &flt,
 // the running row sums stay in registers.
 constexpr uint32_t CK_TERM_CAP = 4096;
 
-constexpr uint32_t CK_HEAVY_BLOCKS = 64 * VIS_SHARDS;
+// (workgroups beyond what the chip holds at once only draw a ticket past the end of their list and leave: 24 per list
+// - 1536, the resident number at this kernel's register and LDS use - measured 37.4 us against 39.4 us with 64 per list)
+constexpr uint32_t CK_HEAVY_BLOCKS = 24 * VIS_SHARDS;
 
 __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, State st, Scratch sc,
                                                           float *__restrict__ ck_out, int finish) {
@@ -1986,7 +1988,9 @@ __global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, St
   static_assert(U * A7_ROWS <= 64, "lanes (u, row) of the row sums");
   DBG_LANE0(4, 0);
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
-  __shared__ float term[WT_WAVES][U][ROUNDS * 64];
+  // (+ 16 floats per particle: the row sums read term[.][lu][lr * side + c] in lanes (lu, lr); with whole multiples of 32
+  // banks between the particles the lanes of two particles met in one bank - 0.29 of the kernel's LDS cycles were conflicts)
+  __shared__ float term[WT_WAVES][U][ROUNDS * 64 + 16];
   __shared__ float rowsum[WT_WAVES][U][A7_ROWS];
   if (sc.cnt->overflow) return;
   const uint32_t n = sc.cnt->n_vis;

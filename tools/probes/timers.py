@@ -60,8 +60,8 @@ for t in range(10):
     span("visibility", w, "| masks %.1f, empty voxels %.1f, full voxels %.1f us (avg)" % (us((v[act, 1] - v[act, 0]).mean()), us((v[act, 2] - v[act, 1]).mean()), us((v[act, 3] - v[act, 2]).mean())) if act.any() else "")
     span("bin_sort_gather", k[2])
     c = k[3]
-    span("ck heavy part", c[:4096], "| batches per workgroup max %d" % c[:4096, 2].max())
-    span("ck light part", c[4096:])
+    span("ck heavy part", c[:1536], "| batches per workgroup max %d" % c[:4096, 2].max())
+    span("ck light part", c[1536:])
     span("weight", k[4])
     b = k[0].copy(); b[:, 1] = b[:, 2]
     span("birth_replay (heads)", b)
