@@ -1699,7 +1699,7 @@ __global__ __launch_bounds__(TPB) void k_ck_classify(Dims d, Filter flt, Scratch
 // identical on the oracle's canonical mode and differs from the reference's single running sum only in rounding.)
 // pass 1 (semantic_dsp_map.h:973-1037): ck of every valid pixel.  finish != 0 also applies ck*P_d + kappa (:1035).
 // Visible particles are far fewer than pixels (C3: ~27 K against 466 K) and clustered: half the windows are empty,
-// the median window holds one particle, the 99th percentile 124.  So the pixels are split (by k_bin_sort_gather, which
+// the median window holds one particle, the 99th percentile 124.  So the pixels are split (by k_ck_classify, which
 // also finishes the empty windows): the light part of k_ck (one thread per pixel) computes every pixel whose window holds
 // at most CK_LIGHT_MAX particles, the heavy part spreads each listed pixel over its window rows.  Both add a row's terms
 // in bin order and the row sums in row order (canonical order) - the value does not depend on which part

@@ -302,7 +302,7 @@ __device__ __forceinline__ void owner_erase_local(const State &st, size_t li, ui
 }
 
 // Garbage collection of the table of older memberships: deleted entries (track OWNER_NONE) go, the live ones keep their
-// order.  Called by ONE wave of a kernel that runs while nobody else touches the table (k_bin_fill: after the frame's
+// order.  Called by ONE wave of a kernel that runs while nobody else touches the table (k_bin_rows: after the frame's
 // moves and removals, before its births).  Batches of 64 entries: a batch is read whole before its survivors are
 // written, and they land at or below the batch's own positions.
 __device__ __forceinline__ void alias_compact_wave(const State &st) {

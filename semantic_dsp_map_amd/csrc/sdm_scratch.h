@@ -58,7 +58,7 @@ static_assert(sizeof(FrameArgs) <= 3400, "FrameArgs travels as a kernel argument
 struct Scratch {
   const FrameArgs *fa = nullptr;       // this frame's block, as the main-stream kernels see it (written by k_frame_begin)
   const FrameArgs *fa_side = nullptr;  // the same for the chains that start before it: frustum, member count (k_set_frame)
-  const FrameArgs *fa_moves = nullptr; // the member-count chain's own copy when it runs on its own stream (k_move_chunks_v)
+  const FrameArgs *fa_moves = nullptr; // the member-count chain's own copy when it runs on its own stream (k_move_members_v: Z-slab shards)
   // frustum vertex bitsets, one line of wpl 64-bit words per (y,z)
   uint64_t *vmask = nullptr, *reach = nullptr;
   int wpl = 0;
@@ -85,7 +85,7 @@ struct Scratch {
   float4 *pix4 = nullptr;
   uint32_t *pixt = nullptr;
   float *ck_kappa = nullptr;
-  uint8_t *ck_class = nullptr;   // per pixel: CK_DONE / CK_LIGHT / CK_HEAVY (k_bin_sort_gather -> k_ck)
+  uint8_t *ck_class = nullptr;   // per pixel: CK_DONE / CK_LIGHT / CK_HEAVY (k_ck_classify -> k_ck)
   uint32_t *ck_heavy = nullptr;  // sharded list of pixels with long windows (cap_heavy entries per shard)
   uint32_t cap_heavy = 0;
   // births
