@@ -92,16 +92,28 @@ __global__ __launch_bounds__(TPB) void k_clear_status(uint8_t *__restrict__ stat
   for (; lv < n_voxels; lv += stride) status[(size_t)lv * voxel_stride] = (uint8_t)ST_TIMEPTC;  // the record was zeroed: INVALID
 }
 
-// RingBufferOperations::clear on a used map (operations.h:697-722): status, position, weight, time stamp
-__global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, size_t n) {
+// RingBufferOperations::clear on a used map (operations.h:697-722): status, position, weight, time stamp; track id,
+// label and forget count stay.  One pass, one thread per slot: everything sdm_clear resets is written here (the
+// per-voxel arrays by the slot-0 lane), so the map's bytes cross HBM once.
+__global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, uint32_t *__restrict__ mv_head, size_t n) {
   size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= n) return;
   float4 p = st.pos4[li];
   p.x = p.y = p.z = 0.f;  // .w carries the forget count, which clear() does not touch
   st.pos4[li] = p;
+  uint32_t slot = (uint32_t)li & (uint32_t)(d.S - 1);
   st.w[rec_index(li, d.p_n, REC_W)] = 0.f;
   st.ts[rec_index(li, d.p_n, REC_TS)] = 0;
-  st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_INVALID;  // slot 0 becomes the time particle again in k_clear_status
+  st.status[rec_index(li, d.p_n, REC_STATUS)] = slot == 0 ? (uint8_t)ST_TIMEPTC : (uint8_t)ST_INVALID;
+  st.owner[li] = OWNER_NONE;
+  if (slot == 0) {
+    size_t lv = li >> d.p_n;
+    st.vts[lv] = 0;
+    st.vflag[lv] = 0;
+    static_assert(sizeof(sdm_voxel_result) == 8, "the result entry is cleared as one 8-byte store");
+    reinterpret_cast<uint2 *>(st.res)[lv] = make_uint2(0u, 0u);
+    mv_head[lv] = 0xffffffffu;
+  }
 }
 
 // first kernel of a frame: the frame's scalars (pose, ring state, stamp updates, object motions, removals, input pointers)
@@ -2874,23 +2886,23 @@ inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb
 // fresh = the buffers have never been written (sdm_create): everything to zero.  Otherwise the reference's clear()
 // (operations.h:697-722) resets status, position, weight and time stamp of every slot and leaves track id, label and
 // forget count of the dead slots as they were.
-void launch_clear(const Dims &d, const State &st, hipStream_t s, bool fresh) {
+void launch_clear(const Dims &d, const State &st, uint32_t *mv_head, hipStream_t s, bool fresh) {
   size_t n = (size_t)d.v_count * d.S;
   if (fresh) {
     hipMemsetAsync(st.pos4, 0, n * sizeof(float4), s);
     hipMemsetAsync(st.rec, 0, n * REC_BYTES_PER_SLOT, s);
+    hipMemsetAsync(st.vts, 0, (size_t)d.v_count * sizeof(uint16_t), s);
+    hipMemsetAsync(st.vflag, 0, (size_t)d.v_count, s);
+    hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
+    hipMemsetAsync(st.res, 0, (size_t)d.v_count * sizeof(sdm_voxel_result), s);
+    hipMemsetAsync(mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_clear_status, dim3(4096), dim3(TPB), 0, s, st.status, (uint32_t)d.v_count, (uint32_t)(d.S * REC_STATUS));
   } else {
-    hipLaunchKernelGGL(k_clear_slots, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, n);
+    hipLaunchKernelGGL(k_clear_slots, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, mv_head, n);
   }
-  hipMemsetAsync(st.vts, 0, (size_t)d.v_count * sizeof(uint16_t), s);
-  hipMemsetAsync(st.vflag, 0, (size_t)d.v_count, s);
-
-  hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
   hipMemsetAsync(st.alias, 0, 8, s);  // no older memberships
   hipMemsetAsync(st.owner_flag, 0, owner_flag_bytes(n), s);
   hipMemsetAsync(st.owner_flag2, 0, owner_flag2_bytes(n), s);
-  hipMemsetAsync(st.res, 0, (size_t)d.v_count * sizeof(sdm_voxel_result), s);
-  hipLaunchKernelGGL(k_clear_status, dim3(4096), dim3(TPB), 0, s, st.status, (uint32_t)d.v_count, (uint32_t)(d.S * REC_STATUS));
 }
 
 #define SDM_DISPATCH_S(kernel, grid, s, ...)                                                      \

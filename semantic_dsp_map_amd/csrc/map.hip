@@ -902,7 +902,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->ev_valid = true;
   // RingBufferOperations::initialize (operations.h:726-767)
   host_initialize(m);
-  launch_clear(d, m->st, m->stream, true);
+  launch_clear(d, m->st, m->sc.mv_head, m->stream, true);
   if ((rc = upload_stamps(m)) != SDM_OK) return rc;
   HIP_TRY(hipStreamSynchronize(m->stream));
   {
@@ -1002,8 +1002,7 @@ sdm_status sdm_clear(sdm_map *m) {
   m->vis_event_valid = false;
   m->sweep_all = true;
   host_initialize(m);
-  HIP_TRY(hipMemsetAsync(m->sc.mv_head, 0xff, (size_t)m->d.v_count * sizeof(uint32_t), m->stream));
-  launch_clear(m->d, m->st, m->stream, false);
+  launch_clear(m->d, m->st, m->sc.mv_head, m->stream, false);
   return upload_stamps(m);
 }
 
