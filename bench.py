@@ -685,7 +685,12 @@ def adapter_e2e(synth, cfg, params, scene, frames, n_frames=12):
         last = [l for l in r.stdout.splitlines() if l.startswith("frame ")][-1]
         V = 1 << (cfg["x_n"] + cfg["y_n"] + cfg["z_n"])
         med = float(line[2])
-        return {"ms_per_update": med, "min_ms_per_update": float(line[4]), "frames_timed": int(line[6]),
+        # SemanticDSPMap::lastUpdateTimes() of the timed calls (the first two are warm-up), medians
+        import re
+        ph = [re.search(r"objects ([\d.]+), pack ([\d.]+), frame ([\d.]+), emit ([\d.]+)", l) for l in r.stdout.splitlines() if l.startswith("frame ")][2:]
+        ph = np.array([[float(x) for x in mm.groups()] for mm in ph if mm])
+        phases = dict(zip(("objects", "pack", "frame_upload_and_enqueue", "wait_and_emit"), np.round(np.median(ph, axis=0), 4).tolist())) if len(ph) else None
+        return {"ms_per_update": med, "min_ms_per_update": float(line[4]), "frames_timed": int(line[6]), "phase_ms": phases,
                 "value": round(V / med / 1e3, 1), "unit": "Mvoxels/s",
                 "path": "SemanticDSPMap::update (include/semantic_dsp_map.h): host cv::Mat depth + 7 MaskKpts in, pcl::PointXYZRGB cloud out, "
                         "per call: mask packing, built-in object layer, H2D of depth + masks (5.1 MB), the frame, sdm_synchronize, D2H of the cloud",

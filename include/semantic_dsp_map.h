@@ -39,6 +39,7 @@
 #include <pcl/point_types.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -47,6 +48,7 @@
 #include <map>
 #include <set>
 #include <memory>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -263,6 +265,46 @@ class SdmBuiltinObjectLayer : public SdmObjectLayer {
   bool have_owner_tracks_ = false;
 };
 
+/// Where the last update() call spent its wall-clock time (milliseconds); see SemanticDSPMap::lastUpdateTimes().
+struct SdmUpdateTimes {
+  double objects = 0;  ///< object layer: update, owner-track query (waits for the previous frame), collect
+  double pack = 0;     ///< depth image and masks into the staging buffers
+  double frame = 0;    ///< sdm_update_raw_ex: uploads, labelled cloud, the frame's launches (returns when the uploads are done)
+  double emit = 0;     ///< waiting for the frame + occupied / free-space clouds back to the host
+  double total = 0;
+};
+
+/// Page-locked host staging for the images handed to sdm_update_raw_ex (sdm_host_alloc): an upload from it is one DMA
+/// transfer at PCIe speed; from a std::vector the runtime first copies through bounce buffers of its own.
+template <typename T>
+class SdmPinnedBuffer {
+ public:
+  SdmPinnedBuffer() = default;
+  SdmPinnedBuffer(const SdmPinnedBuffer &) = delete;
+  SdmPinnedBuffer &operator=(const SdmPinnedBuffer &) = delete;
+  ~SdmPinnedBuffer() { sdm_host_free(p_); }
+  /// n elements, contents undefined after a growth
+  void resize(size_t n) {
+    if (n > cap_) {
+      sdm_host_free(p_);
+      p_ = nullptr;
+      cap_ = 0;
+      void *q = nullptr;
+      if (sdm_host_alloc(n * sizeof(T), &q) != SDM_OK) throw std::bad_alloc();
+      p_ = static_cast<T *>(q);
+      cap_ = n;
+    }
+    n_ = n;
+  }
+  size_t size() const { return n_; }
+  T *data() { return p_; }
+  T &operator[](size_t i) { return p_[i]; }
+
+ private:
+  T *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+};
+
 class SemanticDSPMap {
  public:
   /// semantic_dsp_map.h:25-67
@@ -428,6 +470,10 @@ class SemanticDSPMap {
               Eigen::Quaterniond &camera_orientation, pcl::PointCloud<pcl::PointXYZRGB>::Ptr &occupied_point_cloud,
               pcl::PointCloud<pcl::PointXYZRGB>::Ptr &freespace_point_cloud, bool if_get_freespace = false,
               double time_stamp_double = 0.0) {
+    using clock = std::chrono::steady_clock;
+    const auto ms_since = [](clock::time_point t) { return std::chrono::duration<double, std::milli>(clock::now() - t).count(); };
+    const clock::time_point t_begin = clock::now();
+    times_ = SdmUpdateTimes();
     ensureMap();
     if (preset_.consider_instance && !object_layer_) useBuiltinObjectLayer(preset_.object_mode);  // like the reference's built-in one
     global_time_stamp_ += 1;
@@ -467,10 +513,14 @@ class SemanticDSPMap {
       std::cerr << "sdm: " << moves.size() << " moving objects in one frame, only the first " << SDM_MAX_MOVES << " are moved" << std::endl;
       moves.resize(SDM_MAX_MOVES);
     }
+    times_.objects = ms_since(t_begin);
+    clock::time_point t_phase = clock::now();
     if (packRawInputs(depth_value_mat, ins_seg_result) != 0) {
       frameLost(removals);
       return;
     }
+    times_.pack = ms_since(t_phase);
+    t_phase = clock::now();
 
     // pose in double for the back-projection (pointcloud_tools.h:243-247); the library casts it to float for the
     // map update like the reference does (semantic_dsp_map.h:584, 745)
@@ -495,14 +545,20 @@ class SemanticDSPMap {
       frameLost(removals);
       return;
     }
+    times_.frame = ms_since(t_phase);
+    t_phase = clock::now();
     emit(occupied_point_cloud, false);
     if (if_get_freespace) emit(freespace_point_cloud, true);
     // the getters above waited for the frame: surface what the device flagged (work-list overflows are recorded in
     // counters that the next frame resets)
     check(sdm_synchronize(map_), "sdm_update (device status)");
+    times_.emit = ms_since(t_phase);
+    times_.total = ms_since(t_begin);
   }
 
   sdm_map *handle() { return map_; }
+  /// not in the reference: the phases of the last update() call
+  const SdmUpdateTimes &lastUpdateTimes() const { return times_; }
 
  private:
   sdm_map *map_;
@@ -520,8 +576,8 @@ class SemanticDSPMap {
   std::unordered_map<std::string, int> label_id_;          // g_label_id_map_default
   std::unordered_map<int, int> static_instance_to_label_;   // g_instance_id_to_label_map_default -> label id
   std::unordered_map<int, cv::Vec3b> label_color_;          // g_label_color_map_default (BGR)
-  std::vector<float> depth_;
-  std::vector<uint8_t> static_mask_, object_masks_;
+  SdmPinnedBuffer<float> depth_;
+  SdmPinnedBuffer<uint8_t> static_mask_, object_masks_;
   std::vector<sdm_instance_mask> objects_;
   std::vector<double> boxes_;  // ZED2: per object min x, max x, min y, max y, min z, max z
   uint16_t label_to_inst_[256];  // g_label_to_instance_id_map_default as a table (65535 = Background's instance)
@@ -530,6 +586,7 @@ class SemanticDSPMap {
   std::vector<int32_t> pending_removals_;
   std::vector<int32_t> owner_tracks_;
   std::vector<float> noise_table_;
+  SdmUpdateTimes times_;
   bool tables_from_reference_ = false;
 
   /// a frame that did not reach the map: its removals are offered again
@@ -630,6 +687,15 @@ class SemanticDSPMap {
   /// Host half of PointCloudTools::generateLabeledPointCloud (utils/pointcloud_tools.h:88-213): validate the depth
   /// image and lay the MONO8 masks out as dense H x W buffers; the per-pixel work (:218-304) is the device kernel
   /// behind sdm_update_raw.
+  /// one MONO8 mask into a W x H staging image; what the mask does not cover is set to `fill`
+  static void copyMask(const cv::Mat &mask, uint8_t *dst, int W, int H, int fill) {
+    const int rows = std::max(std::min(mask.rows, H), 0), cols = std::max(std::min(mask.cols, W), 0);
+    for (int j = 0; j < rows; ++j) {
+      std::memcpy(dst + (size_t)j * W, mask.ptr<uchar>(j), (size_t)cols);
+      if (cols < W) std::memset(dst + (size_t)j * W + cols, fill, (size_t)(W - cols));
+    }
+    if (rows < H) std::memset(dst + (size_t)rows * W, fill, (size_t)(H - rows) * W);
+  }
   int packRawInputs(const cv::Mat &depth, const std::vector<MaskKpts> &seg) {
     if (depth.empty()) {
       std::cerr << "Error: depth image is empty." << std::endl;
@@ -651,9 +717,8 @@ class SemanticDSPMap {
     have_static_ = false;
     for (const auto &s : seg) {  // :121-143, the first "static" entry
       if (s.label != "static") continue;
-      std::fill(static_mask_.begin(), static_mask_.end(), (uint8_t)255);  // uncovered pixels: no label -> Background's instance
-      for (int j = 0; j < s.mask.rows && j < H; ++j)
-        std::memcpy(&static_mask_[(size_t)j * W], s.mask.ptr<uchar>(j), (size_t)std::min(s.mask.cols, W));
+      // uncovered pixels: no label -> Background's instance
+      copyMask(s.mask, static_mask_.data(), W, H, 255);
       have_static_ = true;
       break;
     }
@@ -662,13 +727,13 @@ class SemanticDSPMap {
     size_t n_obj = 0;
     if (preset_.consider_instance)
       for (const auto &s : seg) n_obj += s.label != "static";
-    object_masks_.assign(n_obj * hw, 0);
+    object_masks_.resize(n_obj * hw);
     if (preset_.consider_instance) {  // :163-213, later masks override earlier ones
       size_t k_obj = 0;
       for (const auto &s : seg) {
         if (s.label == "static") continue;
         uint8_t *dst = object_masks_.data() + k_obj * hw;
-        for (int j = 0; j < s.mask.rows && j < H; ++j) std::memcpy(dst + (size_t)j * W, s.mask.ptr<uchar>(j), (size_t)std::min(s.mask.cols, W));
+        copyMask(s.mask, dst, W, H, 0);
         auto it = label_id_.find(s.label);
         sdm_instance_mask o;
         o.track_id = s.track_id;

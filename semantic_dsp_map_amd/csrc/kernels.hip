@@ -1160,10 +1160,9 @@ __device__ __forceinline__ bool vbit(const uint64_t *__restrict__ R, size_t line
 // Per-voxel body of getIdxOfVisibleParitlces (operations.h:1344-1436): every voxel that shares a reached
 // in-frustum vertex is handled exactly once (order does not matter: all effects are voxel-local except the
 // per-pixel bins, whose order is made canonical afterwards).
-// Dependent memory steps are kept few: (1) the status row and the depth under the "imaginary particle" of an empty
-// voxel - nine reached voxels in ten are empty and stop there, without touching the stamp row; (2) stamp row and slab
-// stamps; (3) positions of all live slots; (4) the depth pixel under each; (5) all bin-counter atomics and one
-// work-list reservation per voxel.
+// Dependent memory steps are kept few: (1) status row, stamp row, slab stamps and the depth under the voxel's "imaginary
+// particle"; (2) positions of all live slots; (3) the depth pixel under each; (4) all bin-counter atomics and the row
+// list reservations.  (Nine reached voxels in ten are empty and never get here: k_visibility's phase 1.)
 template <int S>
 __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, const State &st, const Scratch &sc,
                                                  const float *__restrict__ depth_img, int ax, int ay, int az) {
@@ -1174,8 +1173,9 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   const uint32_t v = ring_to_voxel(d, rx, ry, rz);
   const uint32_t lv = v - d.v_begin;
   const size_t base = (size_t)lv * S;
-  const uint32_t flag = st.vflag[lv] & VF_STATE;  // VF_EMPTY: every slot INVALID, the record is not touched
-  // imaginary particle at the voxel's min corner, mapXYZIdxToGlobalPose (operations.h:986-991, 1418-1431)
+  // (the caller has seen the voxel's flag byte: it holds something - the empty ones are finished in k_visibility's phase 1)
+  // imaginary particle at the voxel's min corner, mapXYZIdxToGlobalPose (operations.h:986-991, 1418-1431); its depth is
+  // requested together with the record's rows and only looked at when no particle of the voxel was observed
   float im_depth = 0.f, im_z = 0.f;
   bool im_ok;
   {
@@ -1185,13 +1185,6 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     int row, col;
     im_ok = project_to_image(d, f, ix, iy, iz, row, col, im_z);
     if (im_ok) im_depth = depth_img[(size_t)row * d.W + col];
-  }
-  if (!flag) {
-    if (im_ok && im_z <= im_depth) {
-      st.vts[lv] = (uint16_t)f.gts;
-      mark_tile(st, lv, f.epoch);
-    }
-    return;
   }
   const uint32_t smax = stamp_max(st, rx, ry, rz);
   uint8_t stv[S];
@@ -1230,7 +1223,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     }
   }
   bool vis[S];
-  uint32_t pib[S], nv = 0;
+  uint32_t pib[S];
 #pragma unroll
   for (int i = 1; i < S; ++i) {
     vis[i] = false;
@@ -1245,7 +1238,6 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     if (camz[i] > dpt * d.occl_coeff) continue;  // occluded (operations.h:1397-1400)
     observed = true;
     vis[i] = true;
-    nv++;
   }
   // A visible particle takes its place in its pixel's bin (pib, counted per pixel) and goes on the list of its IMAGE ROW
   // (one of ROW_SUBS sub-lists per row, picked by workgroup, so that the counters are spread over many cache lines): the
@@ -1299,7 +1291,9 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
   DBG_LANE0(1, 0);
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   const float *__restrict__ depth_img = sc.fa->depth;
-  const bool force_generic = sc.fa->force_generic != 0;
+  // (requested with the frame's scalars: one dependent step less before the masks)
+  const uint32_t fgen = (uint32_t)sc.fa->force_generic, fcx = (uint32_t)sc.cnt->flood_complex;
+  const bool generic = (fgen | fcx) != 0;
   const int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];  // voxel box [bb0,bb1)
   if (bx <= 0 || by <= 0 || bz <= 0) return;
   const int wlo = f.bb0[0] >> 6, nwx = ((f.bb1[0] - 1) >> 6) - wlo + 1;
@@ -1317,7 +1311,6 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
       const int az = f.bb0[2] + (int)(g / ((uint32_t)nwx * by));
       const uint32_t rz = axis_correct(az + f.eq[2], d.NZ);
       if (rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) {  // else: another shard's slab
-        const bool generic = force_generic || sc.cnt->flood_complex;
         const uint64_t *__restrict__ bits = generic ? sc.reach : sc.vmask;
         const int VY = d.NY + 1;
 #pragma unroll
@@ -2407,26 +2400,37 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   // they are, nearly every wave of the launch carries one or two of them through the whole chain.  So the heads of a
   // workgroup's 256 candidates are compacted first (LDS) and replayed by its first lanes: a quarter of the waves do all
   // the work, the others leave.
-  __shared__ uint32_t heads[TPB];
+  __shared__ uint32_t heads[TPB], head_key[TPB];
   __shared__ uint32_t n_heads;
   if (threadIdx.x == 0) n_heads = 0;
   __syncthreads();
   if (t < total) {
     const uint32_t key = skey[t];
     const uint32_t prev = t > 0 ? skey[t - 1] : 0xffffffffu;
-    if (key < d.V && prev != key) heads[atomicAdd(&n_heads, 1u)] = t;
+    if (key < d.V && prev != key) {
+      const uint32_t q = atomicAdd(&n_heads, 1u);
+      heads[q] = t;
+      head_key[q] = key;
+    }
   }
   __syncthreads();
   if (threadIdx.x >= n_heads) return;
   if (threadIdx.x == 0) DBG_PUT(1, DBG_T());
   t = heads[threadIdx.x];
+  const uint32_t v = head_key[threadIdx.x];
   // How many candidates does the segment hold?  At most 2 (S-1) of them can ever be inserted (the voxel's vacant slots, and
-  // after its one resampling the slots that freed), so the count is needed up to LMAX only.
+  // after its one resampling the slots that freed), so the count is needed up to LMAX only.  The keys that give the count,
+  // the candidates' indices and (below) the voxel's record are all requested in one round: the voxel is known from the
+  // compaction, and which of the candidates make it is a selection among values that are already here.
   constexpr int LMAX = 2 * (S - 1) + 1;
-  uint32_t kb[LMAX];
+  uint32_t kb[LMAX], sv[LMAX];
+  kb[0] = v;
 #pragma unroll
-  for (int j = 0; j < LMAX; ++j) kb[j] = t + j < total ? skey[t + j] : 0xffffffffu;
-  const uint32_t v = kb[0];
+  for (int j = 1; j < LMAX; ++j) kb[j] = t + j < total ? skey[t + j] : 0xffffffffu;
+  if constexpr (!LITERAL) {
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) sv[j] = t + j < total ? sval[t + j] : 0u;
+  }
   uint32_t rx, ry, rz;
   voxel_to_ring(d, v, rx, ry, rz);
   const uint32_t smax = stamp_max(st, rx, ry, rz);
@@ -2518,8 +2522,13 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   uint32_t cidx[S];
   float4 bps[S];
 #pragma unroll
-  for (int i = 1; i < S; ++i)
-    if (cand[i] >= 0) cidx[i] = sval[t + (uint32_t)cand[i]];
+  for (int i = 1; i < S; ++i) {
+    cidx[i] = 0;
+    if (cand[i] >= 0) {
+#pragma unroll
+      for (int j = 0; j < LMAX; ++j) cidx[i] = cand[i] == j ? sv[j] : cidx[i];
+    }
+  }
 #pragma unroll
   for (int i = 1; i < S; ++i)
     if (cand[i] >= 0) bps[i] = sc.bpos[cidx[i]];
@@ -2730,42 +2739,168 @@ __global__ __launch_bounds__(TPB) void k_unpack_pos4(const float4 *pos4, float *
 
 // stable compaction of voxels by result code (getOccupancyResult's emission order = storage order,
 // semantic_dsp_map.h:1244,1353): flag pass, scan, scatter.
-__global__ __launch_bounds__(TPB) void k_flag_results(Dims d, State st, uint32_t *flags, int want_free) {
-  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lv >= d.v_count) return;
-  int8_t occ = st.res[lv].occ;
-  flags[lv] = want_free ? (occ == 0) : (occ > 0);
+// The result lists (getOccupancyResult's output side, semantic_dsp_map.h:1258-1376): the voxels whose result says
+// "occupied" (or "free") in ascending voxel order.  Three launches over one byte per voxel:
+//   k_emit_mark   a thread takes EM_VPT consecutive voxels: the flag bytes first - a voxel whose flag says that its result
+//                 entry holds the "unobserved" constant (VR_UNOBSERVED: most of a map) is on neither list and its entry is
+//                 not read - then the entries of the others; the thread's selection as a bit mask, the workgroup's count;
+//   k_emit_scan   exclusive prefix of the workgroup counts (one workgroup; the total goes behind the last one);
+//   k_emit_write  workgroups that selected something rank their voxels (mask popcounts) and write the points.
+// (Rounds 1-3: a flag word per voxel, a device-wide scan of 16.7 M words and a third pass over all of them - 0.3 ms of
+// the 1.2 ms a SemanticDSPMap::update call took.)
+constexpr int EM_VPT = 8;
+constexpr uint32_t EM_CHUNK = TPB * EM_VPT;
+__host__ __device__ inline uint32_t emit_blocks(uint32_t v_count) { return (v_count + EM_CHUNK - 1) / EM_CHUNK; }
+
+__global__ __launch_bounds__(TPB) void k_emit_mark(Dims d, State st, uint8_t *__restrict__ mask, uint32_t *__restrict__ blk_cnt,
+                                                   int want_free) {
+  __shared__ uint32_t wsum[TPB / 64];
+  const uint32_t t = blockIdx.x * TPB + threadIdx.x;
+  const uint32_t lv0 = t * EM_VPT;
+  uint32_t m = 0;
+  if (lv0 < d.v_count) {
+    const uint32_t n = d.v_count - lv0 < (uint32_t)EM_VPT ? d.v_count - lv0 : (uint32_t)EM_VPT;
+    uint32_t cand = 0;
+    if (n == EM_VPT) {
+      const uint2 fw = *reinterpret_cast<const uint2 *>(st.vflag + lv0);  // (the array is 256-byte aligned, lv0 a multiple of 8)
+#pragma unroll
+      for (int u = 0; u < EM_VPT; ++u) {
+        const uint32_t fl = ((u < 4 ? fw.x : fw.y) >> (8 * (u & 3))) & 0xffu;
+        if ((fl & VR_MASK) != VR_UNOBSERVED) cand |= 1u << u;
+      }
+    } else {
+      for (uint32_t u = 0; u < n; ++u)
+        if ((st.vflag[lv0 + u] & VR_MASK) != VR_UNOBSERVED) cand |= 1u << u;
+    }
+    if (cand) {
+      if (n == EM_VPT) {  // the thread's 64 bytes of result entries, occ = the top byte of an entry's second word
+        const uint4 *rp = reinterpret_cast<const uint4 *>(st.res + lv0);
+#pragma unroll
+        for (int q = 0; q < EM_VPT / 2; ++q) {
+          const uint4 r = rp[q];
+          const int o0 = (int)r.y >> 24, o1 = (int)r.w >> 24;
+          if (want_free ? o0 == 0 : o0 > 0) m |= 1u << (2 * q);
+          if (want_free ? o1 == 0 : o1 > 0) m |= 1u << (2 * q + 1);
+        }
+        m &= cand;
+      } else {
+        for (uint32_t u = 0; u < n; ++u) {
+          const int o = st.res[lv0 + u].occ;
+          if (((cand >> u) & 1u) && (want_free ? o == 0 : o > 0)) m |= 1u << u;
+        }
+      }
+    }
+  }
+  mask[t] = (uint8_t)m;
+  uint32_t c = (uint32_t)__popc(m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) tot += wsum[w];
+    blk_cnt[blockIdx.x] = tot;
+  }
 }
-__global__ __launch_bounds__(TPB) void k_emit_points(Dims d, Frame f, State st, const uint32_t *flags,
-                                                     const uint32_t *offs, sdm_point *out, uint32_t cap, float sub_x,
-                                                     float sub_y, float sub_z, int mark_fov) {
-  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lv >= d.v_count || !flags[lv]) return;
-  uint32_t o = offs[lv];
-  if (o >= cap) return;
+
+constexpr int EM_SCAN_TPB = 1024;
+__global__ __launch_bounds__(EM_SCAN_TPB) void k_emit_scan(const uint32_t *__restrict__ blk_cnt, uint32_t *__restrict__ blk_off, uint32_t n) {
+  __shared__ uint32_t wtot[EM_SCAN_TPB / 64];
+  const uint32_t per = (n + EM_SCAN_TPB - 1) / EM_SCAN_TPB;
+  const uint32_t i0 = threadIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+  uint32_t mine = 0;
+  for (uint32_t i = i0; i < i1; ++i) mine += blk_cnt[i];
+  uint32_t inc = mine;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += v;
+  }
+  if (lane == 63) wtot[wid] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < EM_SCAN_TPB / 64; ++w) {
+    if (w < wid) before += wtot[w];
+    total += wtot[w];
+  }
+  uint32_t run = before + inc - mine;
+  for (uint32_t i = i0; i < i1; ++i) {
+    const uint32_t c = blk_cnt[i];
+    blk_off[i] = run;
+    run += c;
+  }
+  if (threadIdx.x == 0) blk_off[n] = total;
+}
+
+// voxelIdxToGlobalFramePos: ring -> map index -> min corner (operations.h:940-983, 1022-1033)
+__device__ __forceinline__ void emit_voxel_corner(const Dims &d, const Frame &f, uint32_t lv, float &x, float &y, float &z) {
   uint32_t v = d.v_begin + lv, rx, ry, rz;
   voxel_to_ring(d, v, rx, ry, rz);
-  // voxelIdxToGlobalFramePos: ring -> map index -> min corner (operations.h:940-983, 1022-1033)
   uint32_t mx = axis_correct((int)rx - f.eq[0], d.NX);
   uint32_t my = axis_correct((int)ry - f.eq[1], d.NY);
   uint32_t mz = axis_correct((int)rz - f.eq[2], d.NZ);
-  float x = (float)mx * d.voxel_size + d.pmin[0];
-  float y = (float)my * d.voxel_size + d.pmin[1];
-  float z = (float)mz * d.voxel_size + d.pmin[2];
+  x = (float)mx * d.voxel_size + d.pmin[0];
+  y = (float)my * d.voxel_size + d.pmin[1];
+  z = (float)mz * d.voxel_size + d.pmin[2];
   x += f.center[0];
   y += f.center[1];
   z += f.center[2];
-  sdm_voxel_result r = st.res[lv];
-  sdm_point pt;
-  pt.x = x - sub_x;
-  pt.y = y - sub_y;
-  pt.z = z - sub_z;
-  pt.track = r.track;
-  pt.label = r.label;
-  pt.occ = r.occ;
-  // semantic_dsp_map.h:1339-1342: the uncentred voxel position against the frame's frustum
-  if (mark_fov && !point_in_frustum(d, f, x, y, z)) pt.occ = (int8_t)(pt.occ | SDM_OCC_OUT_OF_FOV);
-  out[o] = pt;
+}
+
+struct EmitPlain {
+  sdm_point *out;
+  int mark_fov;
+  __device__ __forceinline__ void operator()(const Dims &d, const Frame &f, const State &st, uint32_t lv, uint32_t o, float sub_x,
+                                             float sub_y, float sub_z) const {
+    float x, y, z;
+    emit_voxel_corner(d, f, lv, x, y, z);
+    sdm_voxel_result r = st.res[lv];
+    sdm_point pt;
+    pt.x = x - sub_x;
+    pt.y = y - sub_y;
+    pt.z = z - sub_z;
+    pt.track = r.track;
+    pt.label = r.label;
+    pt.occ = r.occ;
+    // semantic_dsp_map.h:1339-1342: the uncentred voxel position against the frame's frustum
+    if (mark_fov && !point_in_frustum(d, f, x, y, z)) pt.occ = (int8_t)(pt.occ | SDM_OCC_OUT_OF_FOV);
+    out[o] = pt;
+  }
+};
+
+// the selected voxels of a workgroup's chunk, ranked by the masks' popcounts, go out in ascending order
+template <typename Emit>
+__global__ __launch_bounds__(TPB) void k_emit_write(Dims d, Frame f, State st, const uint8_t *__restrict__ mask,
+                                                    const uint32_t *__restrict__ blk_cnt, const uint32_t *__restrict__ blk_off,
+                                                    uint32_t cap, float sub_x, float sub_y, float sub_z, Emit emit) {
+  __shared__ uint32_t wsum[TPB / 64];
+  if (blk_cnt[blockIdx.x] == 0) return;  // (workgroup-uniform)
+  const uint32_t t = blockIdx.x * TPB + threadIdx.x;
+  uint32_t m = mask[t];
+  const uint32_t c = (uint32_t)__popc(m);
+  uint32_t inc = c;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += v;
+  }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  uint32_t o = blk_off[blockIdx.x] + inc - c;
+#pragma unroll
+  for (int w = 0; w < TPB / 64; ++w)
+    if (w < wid) o += wsum[w];
+  while (m) {
+    const uint32_t u = (uint32_t)__ffs(m) - 1u;
+    m &= m - 1u;
+    if (o < cap) emit(d, f, st, t * EM_VPT + u, o, sub_x, sub_y, sub_z);
+    ++o;
+  }
 }
 
 // ---- N2: colour rules + OpenCV's 8-bit RGB <-> HSV (published algorithm of OpenCV 4.x imgproc color_hsv: RGB2HSV_b with hsv_shift 12,
@@ -2807,26 +2942,15 @@ __device__ __forceinline__ void hsv2rgb_8u(int h, int s, int v, int &r, int &g, 
   r = min(max(__float2int_rn(rf * 255.f), 0), 255);
 }
 
-__global__ __launch_bounds__(TPB) void k_emit_points_rgb(Dims d, Frame f, State st, const ColourTables *__restrict__ ctp,
-                                                         const uint32_t *flags, const uint32_t *offs, sdm_point_xyzrgb *out,
-                                                         uint32_t cap, float sub_x, float sub_y, float sub_z, int want_free) {
-  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lv >= d.v_count || !flags[lv]) return;
-  uint32_t o = offs[lv];
-  if (o >= cap) return;
+struct EmitRgb {
+  sdm_point_xyzrgb *out;
+  const ColourTables *ctp;
+  int want_free;
+  __device__ __forceinline__ void operator()(const Dims &d, const Frame &f, const State &st, uint32_t lv, uint32_t o, float sub_x,
+                                             float sub_y, float sub_z) const {
   const ColourTables &ct = *ctp;
-  uint32_t v = d.v_begin + lv, rx, ry, rz;
-  voxel_to_ring(d, v, rx, ry, rz);
-  // voxelIdxToGlobalFramePos: ring -> map index -> min corner (operations.h:940-983, 1022-1033)
-  uint32_t mx = axis_correct((int)rx - f.eq[0], d.NX);
-  uint32_t my = axis_correct((int)ry - f.eq[1], d.NY);
-  uint32_t mz = axis_correct((int)rz - f.eq[2], d.NZ);
-  float x = (float)mx * d.voxel_size + d.pmin[0];
-  float y = (float)my * d.voxel_size + d.pmin[1];
-  float z = (float)mz * d.voxel_size + d.pmin[2];
-  x += f.center[0];
-  y += f.center[1];
-  z += f.center[2];
+  float x, y, z;
+  emit_voxel_corner(d, f, lv, x, y, z);
   const sdm_voxel_result res = st.res[lv];
   sdm_point_xyzrgb pt;
   pt.x = x - sub_x;
@@ -2876,7 +3000,8 @@ __global__ __launch_bounds__(TPB) void k_emit_points_rgb(Dims d, Frame f, State 
   pt.g = (uint8_t)g;
   pt.b = (uint8_t)b;
   out[o] = pt;
-}
+  }
+};
 
 inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
 
@@ -3153,23 +3278,24 @@ void launch_pack_pos4(float4 *pos4, const float *px, const float *py, const floa
 void launch_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_unpack_pos4, dim3(blocks_for(n)), dim3(TPB), 0, s, pos4, px, py, pz, forget, n);
 }
-void launch_emit_points_rgb(const Dims &d, const Frame &f, const State &st, const ColourTables *ct, uint32_t *flags, uint32_t *offs,
-                            uint32_t *scan_scratch, sdm_point_xyzrgb *out, uint32_t cap, int want_free, const float sub[3],
-                            hipStream_t s) {
-  hipLaunchKernelGGL(k_flag_results, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st, flags, want_free);
-  hipMemsetAsync(flags + d.v_count, 0, 4, s);
-  exclusive_scan_u32(flags, offs, (size_t)d.v_count + 1, scan_scratch, s);
-  hipLaunchKernelGGL(k_emit_points_rgb, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, f, st, ct, flags, offs, out, cap, sub[0], sub[1],
-                     sub[2], want_free);
+void launch_emit_select(const Dims &d, const State &st, const EmitScratch &e, int want_free, hipStream_t s) {
+  const uint32_t nb = emit_blocks(d.v_count);
+  hipLaunchKernelGGL(k_emit_mark, dim3(nb), dim3(TPB), 0, s, d, st, e.mask, e.blk_cnt, want_free);
+  hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(EM_SCAN_TPB), 0, s, e.blk_cnt, e.blk_off, nb);
 }
-void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t *flags, uint32_t *offs,
-                        uint32_t *scan_scratch, sdm_point *out, uint32_t cap, int want_free, const float sub[3],
-                        int mark_fov, hipStream_t s) {
-  hipLaunchKernelGGL(k_flag_results, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st, flags, want_free);
-  hipMemsetAsync(flags + d.v_count, 0, 4, s);
-  exclusive_scan_u32(flags, offs, (size_t)d.v_count + 1, scan_scratch, s);
-  hipLaunchKernelGGL(k_emit_points, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, f, st, flags, offs, out, cap, sub[0],
-                     sub[1], sub[2], mark_fov);
+size_t emit_mask_bytes(const Dims &d) { return (size_t)emit_blocks(d.v_count) * TPB; }
+size_t emit_block_elems(const Dims &d) { return (size_t)emit_blocks(d.v_count) + 1; }
+void launch_emit_points_rgb(const Dims &d, const Frame &f, const State &st, const ColourTables *ct, const EmitScratch &e,
+                            sdm_point_xyzrgb *out, uint32_t cap, int want_free, const float sub[3], hipStream_t s) {
+  launch_emit_select(d, st, e, want_free, s);
+  hipLaunchKernelGGL(k_emit_write<EmitRgb>, dim3(emit_blocks(d.v_count)), dim3(TPB), 0, s, d, f, st, e.mask, e.blk_cnt, e.blk_off, cap, sub[0],
+                     sub[1], sub[2], EmitRgb{out, ct, want_free});
+}
+void launch_emit_points(const Dims &d, const Frame &f, const State &st, const EmitScratch &e, sdm_point *out, uint32_t cap, int want_free,
+                        const float sub[3], int mark_fov, hipStream_t s) {
+  launch_emit_select(d, st, e, want_free, s);
+  hipLaunchKernelGGL(k_emit_write<EmitPlain>, dim3(emit_blocks(d.v_count)), dim3(TPB), 0, s, d, f, st, e.mask, e.blk_cnt, e.blk_off, cap, sub[0],
+                     sub[1], sub[2], EmitPlain{out, mark_fov});
 }
 
 }  // namespace sdm

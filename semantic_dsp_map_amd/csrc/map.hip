@@ -199,6 +199,8 @@ struct sdm_map {
     float *depth = nullptr;
     uint8_t *static_mask = nullptr, *obj_masks = nullptr;
     uint16_t *label_to_inst = nullptr;
+    uint16_t label_host[256];  // what label_to_inst holds (the table rarely changes: it is uploaded when it does)
+    bool label_valid = false;
     double *bbox = nullptr;  // ZED2: per-object boxes
     int obj_masks_cap = 0;
     hipEvent_t ev_free = nullptr;  // the frame that read this set has been issued up to its end
@@ -209,8 +211,11 @@ struct sdm_map {
   unsigned char *d_src_stage = nullptr;  // BOOST mode: one input image at the sensor's size
   size_t src_stage_bytes = 0;
   unsigned long long *d_u64 = nullptr;
-  uint32_t *d_flags = nullptr, *d_offs = nullptr;
-  uint32_t *scan_scratch_e = nullptr;
+  EmitScratch emit;  // compaction of the result lists (getters)
+  // page-locked landing area of the getters: [0] the list's length, from byte 16 on the points
+  unsigned char *h_emit = nullptr;
+  size_t h_emit_bytes = 0;
+  size_t emit_guess = 1024;  // points fetched together with the length (the last list's length and a margin)
   sdm_point *d_points = nullptr;
   size_t points_cap = 0;
   sdm_point_xyzrgb *d_points_rgb = nullptr;
@@ -855,10 +860,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   size_t scan_need = scan_scratch_elems(hw + 1);
   A(sc.scan_scratch, scan_need + 16);
   A(sc.scan_scratch_b, scan_scratch_elems(hw + 1) + 16);
-  A(m->scan_scratch_e, scan_scratch_elems((size_t)d.v_count + 1) + 16);  // compaction of the result lists (getters)
   HIP_TRY(hipMemsetAsync(sc.scan_scratch, 0, (scan_need + 16) * 4, m->stream));
   HIP_TRY(hipMemsetAsync(sc.scan_scratch_b, 0, (scan_scratch_elems(hw + 1) + 16) * 4, m->stream));
-  HIP_TRY(hipMemsetAsync(m->scan_scratch_e, 0, (scan_scratch_elems((size_t)d.v_count + 1) + 16) * 4, m->stream));
   A(sc.mv_head, d.v_count);
   HIP_TRY(hipMemsetAsync(sc.mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t), m->stream));  // MV_NIL; the replay leaves it that way
   A(sc.mv_next, sc.cap_move);
@@ -874,8 +877,9 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->sc.fa_side = m->d_fa[1];
   m->sc.fa_moves = m->d_fa[2];
   A(m->d_u64, 1);
-  A(m->d_flags, (size_t)d.v_count + 1);
-  A(m->d_offs, (size_t)d.v_count + 1);
+  A(m->emit.mask, emit_mask_bytes(d));
+  A(m->emit.blk_cnt, emit_block_elems(d));
+  A(m->emit.blk_off, emit_block_elems(d));
 #undef A
   m->cur_depth = m->d_depth;
   m->cur_cloud = m->d_cloud;
@@ -954,6 +958,7 @@ sdm_status sdm_destroy(sdm_map *m) {
   for (void *p : m->allocs) (void)hipFree(p);
   if (m->d_points_rgb) (void)hipFree(m->d_points_rgb);
   if (m->d_colours) (void)hipFree(m->d_colours);
+  if (m->h_emit) (void)hipHostFree(m->h_emit);
   void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points, m->raw[0].obj_masks, m->raw[1].obj_masks, m->d_src_stage};
   for (void *p : extra)
     if (p) (void)hipFree(p);
@@ -1769,23 +1774,32 @@ sdm_status sdm_update_raw_ex(sdm_map *m, const float *depth, const uint8_t *stat
   }
   if (static_mask) {
     if ((rc = stage_in(static_mask, in.static_mask, 1)) != SDM_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(in.label_to_inst, label_to_static_instance, 512, hipMemcpyHostToDevice, sc_));
+    if (!in.label_valid || memcmp(in.label_host, label_to_static_instance, 512) != 0) {
+      memcpy(in.label_host, label_to_static_instance, 512);
+      HIP_TRY(hipMemcpyAsync(in.label_to_inst, in.label_host, 512, hipMemcpyHostToDevice, sc_));
+      in.label_valid = true;
+    }
   }
   CloudArgsHost a;
   memset(&a, 0, sizeof(a));
+  // masks that lie back to back in the caller's memory (the adapter's do) go up as one transfer
+  bool masks_contiguous = !resize && n_objects > 1;
   for (int k = 0; k < n_objects; ++k) {
     if (!objects[k].mask) return SDM_ERR_INVALID_ARGUMENT;
-    if ((rc = stage_in(objects[k].mask, in.obj_masks + hw * k, 1)) != SDM_OK) return rc;
+    if (k && objects[k].mask != objects[k - 1].mask + hw) masks_contiguous = false;
     a.track[k] = objects[k].track_id;
     a.label[k] = objects[k].label_id;
+  }
+  if (masks_contiguous) {
+    HIP_TRY(hipMemcpyAsync(in.obj_masks, objects[0].mask, hw * (size_t)n_objects, kind, sc_));
+  } else {
+    for (int k = 0; k < n_objects; ++k)
+      if ((rc = stage_in(objects[k].mask, in.obj_masks + hw * k, 1)) != SDM_OK) return rc;
   }
   a.sky_instance = opt ? opt->sky_instance : -1;
   a.has_bbox = opt && opt->object_bbox && n_objects > 0 ? 1 : 0;
   if (a.has_bbox) HIP_TRY(hipMemcpyAsync(in.bbox, opt->object_bbox, sizeof(double) * 6 * n_objects, hipMemcpyHostToDevice, sc_));
   HIP_TRY(hipEventRecord(m->ev_copy, sc_));
-  // host buffers belong to the caller again when this returns (nothing is retained): wait for the copies - the GPU is
-  // still busy with the previous frame on the main stream meanwhile
-  if (!on_dev) HIP_TRY(hipStreamSynchronize(sc_));
   HIP_TRY(hipStreamWaitEvent(s, m->ev_copy, 0));
   // Eigen's Quaternion::toRotationMatrix in double (pointcloud_tools.h:107-110)
   {
@@ -1822,6 +1836,15 @@ sdm_status sdm_update_raw_ex(sdm_map *m, const float *depth, const uint8_t *stat
   rc = sdm_update(m, depth_dev, m->d_cloud, posf, qf, moves, n_moves, remove_tracks, n_remove, flags | SDM_INPUT_ON_DEVICE,
                   stop_after);
   (void)hipEventRecord(in.ev_free, s);
+  // host buffers belong to the caller again when this returns (nothing is retained): wait for the copies, which ran
+  // while the frame's launches were issued above
+  if (!on_dev) {
+    const hipError_t ce = hipStreamSynchronize(sc_);
+    if (ce != hipSuccess && rc == SDM_OK) {
+      set_error("hipStreamSynchronize(copy stream)", __FILE__, __LINE__, hipGetErrorString(ce));
+      rc = SDM_ERR_HIP;
+    }
+  }
   return rc;
 }
 
@@ -2118,6 +2141,41 @@ sdm_status sdm_get_voxels(sdm_map *m, sdm_voxel_result *out) {
   return SDM_OK;
 }
 
+// A result list comes back in one round trip when its length can be guessed: the length and the first `emit_guess`
+// points are copied to page-locked memory behind the kernels, one wait, and only a list that outgrew the guess needs a
+// second copy.  (The length first, then the points: two waits, 30 us each way, and a pageable destination.)
+constexpr size_t EMIT_STAGE_MAX = (size_t)64 << 20;
+static sdm_status fetch_points(sdm_map *m, const void *d_points_v, void *out_v, size_t elem, size_t cap, size_t *n_out) {
+  const unsigned char *d_points = static_cast<const unsigned char *>(d_points_v);
+  unsigned char *out = static_cast<unsigned char *>(out_v);
+  const uint32_t nb = (uint32_t)(emit_block_elems(m->d) - 1);
+  size_t guess = std::min(cap, m->emit_guess);
+  if (16 + guess * elem > EMIT_STAGE_MAX) guess = (EMIT_STAGE_MAX - 16) / elem;
+  const size_t need = 16 + guess * elem;
+  if (need > m->h_emit_bytes) {
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->h_emit) HIP_TRY(hipHostFree(m->h_emit));
+    m->h_emit = nullptr;
+    m->h_emit_bytes = 0;
+    HIP_TRY(hipHostMalloc((void **)&m->h_emit, need, hipHostMallocDefault));
+    m->h_emit_bytes = need;
+  }
+  HIP_TRY(hipMemcpyAsync(m->h_emit, m->emit.blk_off + nb, 4, hipMemcpyDeviceToHost, m->stream));
+  if (guess) HIP_TRY(hipMemcpyAsync(m->h_emit + 16, d_points, guess * elem, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  uint32_t total = 0;
+  memcpy(&total, m->h_emit, 4);
+  *n_out = total;
+  const size_t ncopy = std::min<size_t>(total, cap), first = std::min(ncopy, guess);
+  if (first) memcpy(out, m->h_emit + 16, first * elem);
+  if (ncopy > first) {
+    HIP_TRY(hipMemcpyAsync(out + first * elem, d_points + first * elem, (ncopy - first) * elem, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+  }
+  m->emit_guess = (size_t)total + total / 4 + 1024;
+  return SDM_OK;
+}
+
 static sdm_status get_points(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int flags, int want_free) {
   if (!m || !n_out || (cap && !out)) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
@@ -2132,18 +2190,8 @@ static sdm_status get_points(sdm_map *m, sdm_point *out, size_t cap, size_t *n_o
   if (flags & SDM_POINTS_ZERO_CENTER)
     for (int a = 0; a < 3; ++a) sub[a] = m->cam_p[a];
   uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0xffffffffu);
-  launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->scan_scratch_e, m->d_points, cap32, want_free, sub,
-                     (flags & SDM_POINTS_MARK_FOV) ? 1 : 0, m->stream);
-  uint32_t total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, m->d_offs + m->d.v_count, 4, hipMemcpyDeviceToHost, m->stream));
-  HIP_TRY(hipStreamSynchronize(m->stream));
-  *n_out = total;
-  size_t ncopy = std::min<size_t>(total, cap);
-  if (ncopy) {
-    HIP_TRY(hipMemcpyAsync(out, m->d_points, ncopy * sizeof(sdm_point), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-  }
-  return SDM_OK;
+  launch_emit_points(m->d, m->f, m->st, m->emit, m->d_points, cap32, want_free, sub, (flags & SDM_POINTS_MARK_FOV) ? 1 : 0, m->stream);
+  return fetch_points(m, m->d_points, out, sizeof(sdm_point), cap, n_out);
 }
 sdm_status sdm_get_occupied(sdm_map *m, sdm_point *out, size_t cap, size_t *n_out, int32_t flags) {
   return get_points(m, out, cap, n_out, flags, 0);
@@ -2187,18 +2235,8 @@ static sdm_status get_points_rgb(sdm_map *m, sdm_point_xyzrgb *out, size_t cap, 
   if (flags & SDM_POINTS_ZERO_CENTER)
     for (int a = 0; a < 3; ++a) sub[a] = m->cam_p[a];
   uint32_t cap32 = (uint32_t)std::min<size_t>(cap, 0xffffffffu);
-  launch_emit_points_rgb(m->d, m->f, m->st, m->d_colours, m->d_flags, m->d_offs, m->scan_scratch_e, m->d_points_rgb, cap32, want_free,
-                         sub, m->stream);
-  uint32_t total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, m->d_offs + m->d.v_count, 4, hipMemcpyDeviceToHost, m->stream));
-  HIP_TRY(hipStreamSynchronize(m->stream));
-  *n_out = total;
-  size_t ncopy = std::min<size_t>(total, cap);
-  if (ncopy) {
-    HIP_TRY(hipMemcpyAsync(out, m->d_points_rgb, ncopy * sizeof(sdm_point_xyzrgb), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-  }
-  return SDM_OK;
+  launch_emit_points_rgb(m->d, m->f, m->st, m->d_colours, m->emit, m->d_points_rgb, cap32, want_free, sub, m->stream);
+  return fetch_points(m, m->d_points_rgb, out, sizeof(sdm_point_xyzrgb), cap, n_out);
 }
 sdm_status sdm_get_occupied_rgb(sdm_map *m, sdm_point_xyzrgb *out, size_t cap, size_t *n_out, int32_t flags) {
   return get_points_rgb(m, out, cap, n_out, flags, 0);
@@ -2232,9 +2270,10 @@ sdm_status sdm_tracks_with_particles(sdm_map *m, int32_t *out, int32_t cap, int3
   HIP_TRY(hipMemcpyAsync(bits.data(), m->d_track_bits, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   int32_t n = 0;
-  for (uint32_t t = 0; t < 65535u; ++t)  // (65535 = "no owner")
-    if ((bits[t >> 5] >> (t & 31u)) & 1u) {
-      if (n < cap) out[n] = (int32_t)t;
+  bits[2047] &= 0x7fffffffu;  // (65535 = "no owner")
+  for (uint32_t w = 0; w < 2048u; ++w)
+    for (uint32_t b = bits[w]; b; b &= b - 1u) {
+      if (n < cap) out[n] = (int32_t)(w * 32u + (uint32_t)__builtin_ctz(b));
       ++n;
     }
   *n_out = n;
@@ -2288,10 +2327,9 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
     out->live_voxels = (int64_t)(n >> 36);
     size_t nocc = 0;
     // occupied voxel count from the result array
-    const float zero3[3] = {0.f, 0.f, 0.f};
-    launch_emit_points(m->d, m->f, m->st, m->d_flags, m->d_offs, m->scan_scratch_e, m->d_points, 0, 0, zero3, 0, m->stream);
+    launch_emit_select(m->d, m->st, m->emit, 0, m->stream);
     uint32_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, m->d_offs + m->d.v_count, 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(&total, m->emit.blk_off + (emit_block_elems(m->d) - 1), 4, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     nocc = total;
     out->n_occupied = (int64_t)nocc;

@@ -200,12 +200,20 @@ struct ColourTables {
   sdm_colour_config cfg;
   int32_t sdiv[256], hdiv180[256];
 };
-void launch_emit_points_rgb(const Dims &d, const Frame &f, const State &st, const ColourTables *ct, uint32_t *flags, uint32_t *offs,
-                            uint32_t *scan_scratch, sdm_point_xyzrgb *out, uint32_t cap, int want_free, const float sub[3],
-                            hipStream_t s);
-void launch_emit_points(const Dims &d, const Frame &f, const State &st, uint32_t *flags, uint32_t *offs,
-                        uint32_t *scan_scratch, sdm_point *out, uint32_t cap, int want_free, const float sub[3],
-                        int mark_fov, hipStream_t s);
+// scratch of the result lists (k_emit_mark / k_emit_scan / k_emit_write, kernels.hip)
+struct EmitScratch {
+  uint8_t *mask = nullptr;      // emit_mask_bytes: per thread of k_emit_mark, the voxels it selected
+  uint32_t *blk_cnt = nullptr;  // emit_block_elems: selected voxels per workgroup
+  uint32_t *blk_off = nullptr;  // emit_block_elems: their exclusive prefix; the last element is the total
+};
+size_t emit_mask_bytes(const Dims &d);
+size_t emit_block_elems(const Dims &d);
+// selection only (mask, counts, total)
+void launch_emit_select(const Dims &d, const State &st, const EmitScratch &e, int want_free, hipStream_t s);
+void launch_emit_points_rgb(const Dims &d, const Frame &f, const State &st, const ColourTables *ct, const EmitScratch &e,
+                            sdm_point_xyzrgb *out, uint32_t cap, int want_free, const float sub[3], hipStream_t s);
+void launch_emit_points(const Dims &d, const Frame &f, const State &st, const EmitScratch &e, sdm_point *out, uint32_t cap, int want_free,
+                        const float sub[3], int mark_fov, hipStream_t s);
 
 size_t move_blocks(const Dims &d);
 size_t move_count_elems();

@@ -113,7 +113,9 @@ int main(int argc, char **argv) {
     if (n_occ) std::fwrite(static_cast<const void *>(occ->points.data()), sizeof(pcl::PointXYZRGB), n_occ, out);
     std::fwrite(&n_free, 4, 1, out);
     if (n_free) std::fwrite(static_cast<const void *>(fr->points.data()), sizeof(pcl::PointXYZRGB), n_free, out);
-    std::printf("frame %u: %u occupied, %u free voxels, update() %.3f ms\n", t, n_occ, n_free, frame_ms.back());
+    const SdmUpdateTimes &ut = map.lastUpdateTimes();
+    std::printf("frame %u: %u occupied, %u free voxels, update() %.3f ms (objects %.3f, pack %.3f, frame %.3f, emit %.3f)\n", t, n_occ,
+                n_free, frame_ms.back(), ut.objects, ut.pack, ut.frame, ut.emit);
   }
   std::fclose(out);
   if (timing && frame_ms.size() > 3) {
