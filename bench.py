@@ -654,7 +654,11 @@ def adapter_e2e(synth, cfg, params, scene, frames, n_frames=12):
     import tempfile
     from tests import adapter_clip
     try:
-        tmp = tempfile.mkdtemp(prefix="sdm_e2e_")
+        tmp = os.environ.get("SDM_ADAPTER_DIR")  # (profiling: keep the driver and its clip where a tracer can run them)
+        if tmp:
+            os.makedirs(tmp, exist_ok=True)
+        else:
+            tmp = tempfile.mkdtemp(prefix="sdm_e2e_")
         exe, clip, out = os.path.join(tmp, "adapter_e2e"), os.path.join(tmp, "clip.bin"), os.path.join(tmp, "out.bin")
         csrc = os.path.join(ROOT, "semantic_dsp_map_amd", "csrc")
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "tests", "mock_includes"), "-I", os.path.join(ROOT, "include"),

@@ -770,8 +770,8 @@ class SemanticDSPMap {
     auto get = free_space ? sdm_get_freespace_rgb : sdm_get_occupied_rgb;
     const int32_t flags = visualize_with_zero_center_ ? SDM_POINTS_ZERO_CENTER : 0;
     if (!check(get(map_, points_.data(), points_.size(), &n, flags), "sdm_get_occupied_rgb")) return;
-    if (n > points_.size()) {
-      points_.resize(std::min(n, cap));
+    if (n > points_.size()) {  // (with headroom: a map that grows a little every frame would come here every frame)
+      points_.resize(std::min(n + n / 2 + 1024, cap));
       if (!check(get(map_, points_.data(), points_.size(), &n, flags), "sdm_get_occupied_rgb")) return;
     }
     n = std::min(n, points_.size());

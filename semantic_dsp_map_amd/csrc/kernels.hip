@@ -2740,12 +2740,12 @@ __global__ __launch_bounds__(TPB) void k_unpack_pos4(const float4 *pos4, float *
 // stable compaction of voxels by result code (getOccupancyResult's emission order = storage order,
 // semantic_dsp_map.h:1244,1353): flag pass, scan, scatter.
 // The result lists (getOccupancyResult's output side, semantic_dsp_map.h:1258-1376): the voxels whose result says
-// "occupied" (or "free") in ascending voxel order.  Three launches over one byte per voxel:
+// "occupied" (or "free") in ascending voxel order.  Two launches over one byte per voxel:
 //   k_emit_mark   a thread takes EM_VPT consecutive voxels: the flag bytes first - a voxel whose flag says that its result
 //                 entry holds the "unobserved" constant (VR_UNOBSERVED: most of a map) is on neither list and its entry is
 //                 not read - then the entries of the others; the thread's selection as a bit mask, the workgroup's count;
-//   k_emit_scan   exclusive prefix of the workgroup counts (one workgroup; the total goes behind the last one);
-//   k_emit_write  workgroups that selected something rank their voxels (mask popcounts) and write the points.
+//   k_emit_write  workgroups that selected something find their place in the list (sum of the counts before them), rank
+//                 their voxels (mask popcounts) and write the points.
 // (Rounds 1-3: a flag word per voxel, a device-wide scan of 16.7 M words and a third pass over all of them - 0.3 ms of
 // the 1.2 ms a SemanticDSPMap::update call took.)
 constexpr int EM_VPT = 8;
@@ -2805,35 +2805,23 @@ __global__ __launch_bounds__(TPB) void k_emit_mark(Dims d, State st, uint8_t *__
   }
 }
 
-constexpr int EM_SCAN_TPB = 1024;
-__global__ __launch_bounds__(EM_SCAN_TPB) void k_emit_scan(const uint32_t *__restrict__ blk_cnt, uint32_t *__restrict__ blk_off, uint32_t n) {
-  __shared__ uint32_t wtot[EM_SCAN_TPB / 64];
-  const uint32_t per = (n + EM_SCAN_TPB - 1) / EM_SCAN_TPB;
-  const uint32_t i0 = threadIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
-  uint32_t mine = 0;
-  for (uint32_t i = i0; i < i1; ++i) mine += blk_cnt[i];
-  uint32_t inc = mine;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+// the list's length alone (statistics): the sum of the workgroup counts
+constexpr int EM_SUM_TPB = 1024;
+__global__ __launch_bounds__(EM_SUM_TPB) void k_emit_total(const uint32_t *__restrict__ blk_cnt, uint32_t *__restrict__ total, uint32_t n) {
+  __shared__ uint32_t wtot[EM_SUM_TPB / 64];
+  uint32_t acc = 0;
+#pragma unroll 8
+  for (uint32_t i = threadIdx.x; i < n; i += EM_SUM_TPB) acc += blk_cnt[i];
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t v = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += v;
-  }
-  if (lane == 63) wtot[wid] = inc;
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = acc;
   __syncthreads();
-  uint32_t before = 0, total = 0;
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
 #pragma unroll
-  for (int w = 0; w < EM_SCAN_TPB / 64; ++w) {
-    if (w < wid) before += wtot[w];
-    total += wtot[w];
+    for (int w = 0; w < EM_SUM_TPB / 64; ++w) t += wtot[w];
+    *total = t;
   }
-  uint32_t run = before + inc - mine;
-  for (uint32_t i = i0; i < i1; ++i) {
-    const uint32_t c = blk_cnt[i];
-    blk_off[i] = run;
-    run += c;
-  }
-  if (threadIdx.x == 0) blk_off[n] = total;
 }
 
 // voxelIdxToGlobalFramePos: ring -> map index -> min corner (operations.h:940-983, 1022-1033)
@@ -2872,29 +2860,43 @@ struct EmitPlain {
   }
 };
 
-// the selected voxels of a workgroup's chunk, ranked by the masks' popcounts, go out in ascending order
+// The selected voxels of a workgroup's chunk go out in ascending order: the chunk's place in the list is the sum of the
+// counts of the chunks before it - every workgroup that has something to write adds those up itself (a few thousand
+// words that sit in L2, one round of loads; a scan kernel in between cost 8 us and a launch) - and the voxels of the chunk
+// are ranked by the masks' popcounts.  The last workgroup also leaves the list's length.
 template <typename Emit>
 __global__ __launch_bounds__(TPB) void k_emit_write(Dims d, Frame f, State st, const uint8_t *__restrict__ mask,
-                                                    const uint32_t *__restrict__ blk_cnt, const uint32_t *__restrict__ blk_off,
-                                                    uint32_t cap, float sub_x, float sub_y, float sub_z, Emit emit) {
-  __shared__ uint32_t wsum[TPB / 64];
-  if (blk_cnt[blockIdx.x] == 0) return;  // (workgroup-uniform)
+                                                    const uint32_t *__restrict__ blk_cnt, uint32_t *__restrict__ total, uint32_t cap,
+                                                    float sub_x, float sub_y, float sub_z, Emit emit) {
+  __shared__ uint32_t wsum[TPB / 64], wbase[TPB / 64];
+  const uint32_t my = blk_cnt[blockIdx.x];
+  const bool last = blockIdx.x == gridDim.x - 1;
+  if (my == 0 && !last) return;  // (workgroup-uniform)
   const uint32_t t = blockIdx.x * TPB + threadIdx.x;
-  uint32_t m = mask[t];
+  uint32_t m = my ? mask[t] : 0u;
+  uint32_t acc = 0;
+#pragma unroll 8
+  for (uint32_t i = threadIdx.x; i < blockIdx.x; i += TPB) acc += blk_cnt[i];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   const uint32_t c = (uint32_t)__popc(m);
   uint32_t inc = c;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t v = __shfl_up(inc, off, 64);
     if (lane >= off) inc += v;
   }
+  if (lane == 0) wbase[wid] = acc;
   if (lane == 63) wsum[wid] = inc;
   __syncthreads();
-  uint32_t o = blk_off[blockIdx.x] + inc - c;
+  uint32_t o = inc - c;
 #pragma unroll
-  for (int w = 0; w < TPB / 64; ++w)
+  for (int w = 0; w < TPB / 64; ++w) {
+    o += wbase[w];
     if (w < wid) o += wsum[w];
+  }
+  if (last && threadIdx.x == TPB - 1) *total = o + c;
   while (m) {
     const uint32_t u = (uint32_t)__ffs(m) - 1u;
     m &= m - 1u;
@@ -3278,24 +3280,27 @@ void launch_pack_pos4(float4 *pos4, const float *px, const float *py, const floa
 void launch_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_unpack_pos4, dim3(blocks_for(n)), dim3(TPB), 0, s, pos4, px, py, pz, forget, n);
 }
-void launch_emit_select(const Dims &d, const State &st, const EmitScratch &e, int want_free, hipStream_t s) {
+// the list's length only
+void launch_emit_count(const Dims &d, const State &st, const EmitScratch &e, int want_free, hipStream_t s) {
   const uint32_t nb = emit_blocks(d.v_count);
   hipLaunchKernelGGL(k_emit_mark, dim3(nb), dim3(TPB), 0, s, d, st, e.mask, e.blk_cnt, want_free);
-  hipLaunchKernelGGL(k_emit_scan, dim3(1), dim3(EM_SCAN_TPB), 0, s, e.blk_cnt, e.blk_off, nb);
+  hipLaunchKernelGGL(k_emit_total, dim3(1), dim3(EM_SUM_TPB), 0, s, e.blk_cnt, e.total, nb);
 }
 size_t emit_mask_bytes(const Dims &d) { return (size_t)emit_blocks(d.v_count) * TPB; }
-size_t emit_block_elems(const Dims &d) { return (size_t)emit_blocks(d.v_count) + 1; }
+size_t emit_block_elems(const Dims &d) { return (size_t)emit_blocks(d.v_count); }
 void launch_emit_points_rgb(const Dims &d, const Frame &f, const State &st, const ColourTables *ct, const EmitScratch &e,
                             sdm_point_xyzrgb *out, uint32_t cap, int want_free, const float sub[3], hipStream_t s) {
-  launch_emit_select(d, st, e, want_free, s);
-  hipLaunchKernelGGL(k_emit_write<EmitRgb>, dim3(emit_blocks(d.v_count)), dim3(TPB), 0, s, d, f, st, e.mask, e.blk_cnt, e.blk_off, cap, sub[0],
-                     sub[1], sub[2], EmitRgb{out, ct, want_free});
+  const uint32_t nb = emit_blocks(d.v_count);
+  hipLaunchKernelGGL(k_emit_mark, dim3(nb), dim3(TPB), 0, s, d, st, e.mask, e.blk_cnt, want_free);
+  hipLaunchKernelGGL(k_emit_write<EmitRgb>, dim3(nb), dim3(TPB), 0, s, d, f, st, e.mask, e.blk_cnt, e.total, cap, sub[0], sub[1], sub[2],
+                     EmitRgb{out, ct, want_free});
 }
 void launch_emit_points(const Dims &d, const Frame &f, const State &st, const EmitScratch &e, sdm_point *out, uint32_t cap, int want_free,
                         const float sub[3], int mark_fov, hipStream_t s) {
-  launch_emit_select(d, st, e, want_free, s);
-  hipLaunchKernelGGL(k_emit_write<EmitPlain>, dim3(emit_blocks(d.v_count)), dim3(TPB), 0, s, d, f, st, e.mask, e.blk_cnt, e.blk_off, cap, sub[0],
-                     sub[1], sub[2], EmitPlain{out, mark_fov});
+  const uint32_t nb = emit_blocks(d.v_count);
+  hipLaunchKernelGGL(k_emit_mark, dim3(nb), dim3(TPB), 0, s, d, st, e.mask, e.blk_cnt, want_free);
+  hipLaunchKernelGGL(k_emit_write<EmitPlain>, dim3(nb), dim3(TPB), 0, s, d, f, st, e.mask, e.blk_cnt, e.total, cap, sub[0], sub[1], sub[2],
+                     EmitPlain{out, mark_fov});
 }
 
 }  // namespace sdm

@@ -215,6 +215,7 @@ struct sdm_map {
   // page-locked landing area of the getters: [0] the list's length, from byte 16 on the points
   unsigned char *h_emit = nullptr;
   size_t h_emit_bytes = 0;
+  uint32_t *h_track_bits = nullptr;  // page-locked landing area of sdm_tracks_with_particles
   size_t emit_guess = 1024;  // points fetched together with the length (the last list's length and a margin)
   sdm_point *d_points = nullptr;
   size_t points_cap = 0;
@@ -879,7 +880,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(m->d_u64, 1);
   A(m->emit.mask, emit_mask_bytes(d));
   A(m->emit.blk_cnt, emit_block_elems(d));
-  A(m->emit.blk_off, emit_block_elems(d));
+  A(m->emit.total, 4);
 #undef A
   m->cur_depth = m->d_depth;
   m->cur_cloud = m->d_cloud;
@@ -959,6 +960,7 @@ sdm_status sdm_destroy(sdm_map *m) {
   if (m->d_points_rgb) (void)hipFree(m->d_points_rgb);
   if (m->d_colours) (void)hipFree(m->d_colours);
   if (m->h_emit) (void)hipHostFree(m->h_emit);
+  if (m->h_track_bits) (void)hipHostFree(m->h_track_bits);
   void *extra[] = {m->sc.bkey_a, m->sc.bval_a, m->sc.bkey_b, m->sc.bval_b, m->sc.bpos, m->sc.sort_scratch, m->d_points, m->raw[0].obj_masks, m->raw[1].obj_masks, m->d_src_stage};
   for (void *p : extra)
     if (p) (void)hipFree(p);
@@ -2148,19 +2150,19 @@ constexpr size_t EMIT_STAGE_MAX = (size_t)64 << 20;
 static sdm_status fetch_points(sdm_map *m, const void *d_points_v, void *out_v, size_t elem, size_t cap, size_t *n_out) {
   const unsigned char *d_points = static_cast<const unsigned char *>(d_points_v);
   unsigned char *out = static_cast<unsigned char *>(out_v);
-  const uint32_t nb = (uint32_t)(emit_block_elems(m->d) - 1);
   size_t guess = std::min(cap, m->emit_guess);
   if (16 + guess * elem > EMIT_STAGE_MAX) guess = (EMIT_STAGE_MAX - 16) / elem;
   const size_t need = 16 + guess * elem;
-  if (need > m->h_emit_bytes) {
+  if (need > m->h_emit_bytes) {  // (page-locking memory takes a third of a millisecond: grown in big steps)
+    const size_t grown = std::min(EMIT_STAGE_MAX, std::max(need * 2, (size_t)1 << 20));
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (m->h_emit) HIP_TRY(hipHostFree(m->h_emit));
     m->h_emit = nullptr;
     m->h_emit_bytes = 0;
-    HIP_TRY(hipHostMalloc((void **)&m->h_emit, need, hipHostMallocDefault));
-    m->h_emit_bytes = need;
+    HIP_TRY(hipHostMalloc((void **)&m->h_emit, grown, hipHostMallocDefault));
+    m->h_emit_bytes = grown;
   }
-  HIP_TRY(hipMemcpyAsync(m->h_emit, m->emit.blk_off + nb, 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipMemcpyAsync(m->h_emit, m->emit.total, 4, hipMemcpyDeviceToHost, m->stream));
   if (guess) HIP_TRY(hipMemcpyAsync(m->h_emit + 16, d_points, guess * elem, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   uint32_t total = 0;
@@ -2266,8 +2268,9 @@ sdm_status sdm_tracks_with_particles(sdm_map *m, int32_t *out, int32_t cap, int3
   if (!m || !n_out || cap < 0 || (cap > 0 && !out)) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
   launch_tracks_with_particles(m->d, m->st, m->d_track_bits, m->stream);
-  std::vector<uint32_t> bits(2048);
-  HIP_TRY(hipMemcpyAsync(bits.data(), m->d_track_bits, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
+  if (!m->h_track_bits) HIP_TRY(hipHostMalloc((void **)&m->h_track_bits, 2048 * sizeof(uint32_t), hipHostMallocDefault));
+  uint32_t *bits = m->h_track_bits;
+  HIP_TRY(hipMemcpyAsync(bits, m->d_track_bits, 2048 * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   int32_t n = 0;
   bits[2047] &= 0x7fffffffu;  // (65535 = "no owner")
@@ -2327,9 +2330,9 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
     out->live_voxels = (int64_t)(n >> 36);
     size_t nocc = 0;
     // occupied voxel count from the result array
-    launch_emit_select(m->d, m->st, m->emit, 0, m->stream);
+    launch_emit_count(m->d, m->st, m->emit, 0, m->stream);
     uint32_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, m->emit.blk_off + (emit_block_elems(m->d) - 1), 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(&total, m->emit.total, 4, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     nocc = total;
     out->n_occupied = (int64_t)nocc;

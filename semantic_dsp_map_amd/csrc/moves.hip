@@ -953,8 +953,16 @@ __global__ __launch_bounds__(TPB) void k_owner_flags(const uint16_t *__restrict_
 // reference's sets still hold) - the keys of ObjectParticleHashMap::indices_map with a non-empty set
 // (object_layer.h:20-52, semantic_dsp_map.h:712-736).  bitmap: 2048 uint32, zeroed by the launcher.
 __global__ __launch_bounds__(TPB) void k_tracks_with_particles(State st, size_t n_slots, uint32_t *__restrict__ bitmap) {
+  // one workgroup per group of OWNER_GROUP chunks: the group's flag, then its chunks' flags in one round, then only the
+  // chunks that may hold owners (round 4: a workgroup walked 32 chunk flags one dependent load after the other, 77 us)
   __shared__ uint32_t seen[2048];
+  __shared__ uint32_t list[OWNER_GROUP];
+  __shared__ uint32_t n_list;
+  const size_t n_chunks = (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK;
+  const bool group_set = st.owner_flag2[blockIdx.x] != 0;
+  if (!group_set && blockIdx.x != 0) return;  // (workgroup-uniform)
   for (uint32_t k = threadIdx.x; k < 2048; k += TPB) seen[k] = 0;
+  if (threadIdx.x == 0) n_list = 0;
   __syncthreads();
   if (blockIdx.x == 0) {
     const uint32_t na = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
@@ -963,15 +971,28 @@ __global__ __launch_bounds__(TPB) void k_tracks_with_particles(State st, size_t 
       if (trk != OWNER_NONE) atomicOr(&seen[trk >> 5], 1u << (trk & 31u));
     }
   }
-  const size_t n_chunks = (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK;
-  for (size_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    if (st.owner_flag[chunk] == 0) continue;
-    size_t end = (chunk + 1) * OWNER_CHUNK;
-    if (end > n_slots) end = n_slots;
-    for (size_t i = chunk * OWNER_CHUNK + threadIdx.x; i < end; i += TPB) {
-      const uint16_t o = st.owner[i];
-      if (o != OWNER_NONE && !((seen[o >> 5] >> (o & 31u)) & 1u)) atomicOr(&seen[o >> 5], 1u << (o & 31u));
+  static_assert(OWNER_GROUP == 64, "one wave reads a group's chunk flags");
+  if (group_set && threadIdx.x < OWNER_GROUP) {
+    const size_t chunk = (size_t)blockIdx.x * OWNER_GROUP + threadIdx.x;
+    const bool f = chunk < n_chunks && st.owner_flag[chunk] != 0;
+    const unsigned long long b = __ballot(f);
+    if (f) list[__popcll(b & ((1ull << threadIdx.x) - 1ull))] = (uint32_t)chunk;
+    if (threadIdx.x == 0) n_list = (uint32_t)__popcll(b);
+  }
+  __syncthreads();
+  const uint32_t nl = n_list;
+  for (uint32_t q = 0; q < nl; ++q) {
+    const size_t c0 = (size_t)list[q] * OWNER_CHUNK;
+    constexpr int PER = OWNER_CHUNK / TPB;
+    uint16_t o[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const size_t i = c0 + threadIdx.x + (size_t)j * TPB;
+      o[j] = i < n_slots ? st.owner[i] : OWNER_NONE;
     }
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      if (o[j] != OWNER_NONE && !((seen[o[j] >> 5] >> (o[j] & 31u)) & 1u)) atomicOr(&seen[o[j] >> 5], 1u << (o[j] & 31u));
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < 2048; k += TPB)
@@ -992,7 +1013,8 @@ void launch_owner_flags(const Dims &d, const State &st, hipStream_t s) {
 void launch_tracks_with_particles(const Dims &d, const State &st, uint32_t *bitmap, hipStream_t s) {
   const size_t n_slots = (size_t)d.v_count * d.S;
   hipMemsetAsync(bitmap, 0, 2048 * sizeof(uint32_t), s);
-  hipLaunchKernelGGL(k_tracks_with_particles, dim3(1024), dim3(TPB), 0, s, st, n_slots, bitmap);
+  const size_t n_chunks = (n_slots + OWNER_CHUNK - 1) / OWNER_CHUNK;
+  hipLaunchKernelGGL(k_tracks_with_particles, dim3((unsigned)((n_chunks + OWNER_GROUP - 1) / OWNER_GROUP)), dim3(TPB), 0, s, st, n_slots, bitmap);
 }
 
 size_t move_blocks(const Dims &d) { return ((size_t)d.v_count * d.S + MV_CHUNK - 1) / MV_CHUNK; }

@@ -200,16 +200,16 @@ struct ColourTables {
   sdm_colour_config cfg;
   int32_t sdiv[256], hdiv180[256];
 };
-// scratch of the result lists (k_emit_mark / k_emit_scan / k_emit_write, kernels.hip)
+// scratch of the result lists (k_emit_mark / k_emit_write, kernels.hip)
 struct EmitScratch {
   uint8_t *mask = nullptr;      // emit_mask_bytes: per thread of k_emit_mark, the voxels it selected
   uint32_t *blk_cnt = nullptr;  // emit_block_elems: selected voxels per workgroup
-  uint32_t *blk_off = nullptr;  // emit_block_elems: their exclusive prefix; the last element is the total
+  uint32_t *total = nullptr;    // the list's length
 };
 size_t emit_mask_bytes(const Dims &d);
 size_t emit_block_elems(const Dims &d);
-// selection only (mask, counts, total)
-void launch_emit_select(const Dims &d, const State &st, const EmitScratch &e, int want_free, hipStream_t s);
+// the list's length only
+void launch_emit_count(const Dims &d, const State &st, const EmitScratch &e, int want_free, hipStream_t s);
 void launch_emit_points_rgb(const Dims &d, const Frame &f, const State &st, const ColourTables *ct, const EmitScratch &e,
                             sdm_point_xyzrgb *out, uint32_t cap, int want_free, const float sub[3], hipStream_t s);
 void launch_emit_points(const Dims &d, const Frame &f, const State &st, const EmitScratch &e, sdm_point *out, uint32_t cap, int want_free,
