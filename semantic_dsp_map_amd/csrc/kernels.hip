@@ -1464,10 +1464,16 @@ __device__ __forceinline__ void ck_store(const Filter &flt, const Scratch &sc, f
 // index; the reference's push order is its BFS order) and gathers the fields the weight update reads into
 // arrays laid out in bin order.  (Round 3: a device-wide scan of the 466 K counts, a scatter kernel, a sort-and-gather
 // kernel - three launches, 35 us with their gaps, for what one row-local launch does.)
-constexpr int BR_TPB = 1024;
+// Ten waves per workgroup and at most 96 registers: TWO workgroups fit a CU, so the 375 rows of the benchmark image are all
+// resident at once (with 1024 threads and 128 registers it was one per CU: 256 at a time, the other 119 rows started when
+// the first ones were through - the launch took two rounds, 17 us for 7 us of work per row).  PPT consecutive pixels per
+// thread: 2 up to 1280 columns, 4 beyond.
+constexpr int BR_TPB = 640;
 constexpr int BR_WAVES = BR_TPB / 64;
 constexpr int BR_MAXW = 2048;  // image width the row kernel's LDS holds (checked when the map is created)
-__global__ __launch_bounds__(BR_TPB) void k_bin_rows(Dims d, State st, Scratch sc) {
+template <int PPT>
+__global__ __launch_bounds__(BR_TPB) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_bin_rows(Dims d, State st, Scratch sc) {
+  static_assert(PPT == 2 || PPT * BR_TPB >= BR_MAXW, "four pixels per thread cover the widest image");
   __shared__ uint32_t pre[BR_MAXW + 1];
   __shared__ uint32_t wave_tot[BR_WAVES];
   __shared__ uint32_t s_base;
@@ -1478,20 +1484,20 @@ __global__ __launch_bounds__(BR_TPB) void k_bin_rows(Dims d, State st, Scratch s
   const bool overflow = sc.cnt->overflow != 0;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int W = d.W;
-  // ---- the row's counts, two pixels per thread (consecutive: thread t holds columns 2t, 2t + 1), exclusive scan
-  uint32_t c[2] = {0u, 0u};
-  const int j0 = 2 * (int)threadIdx.x;
-  if (!overflow) {
-    if (j0 < W) c[0] = sc.bin_count[r * W + j0];
-    if (j0 + 1 < W) c[1] = sc.bin_count[r * W + j0 + 1];
-  }
+  // ---- the row's counts, PPT pixels per thread (consecutive: thread t holds columns PPT t ...), exclusive scan
+  uint32_t c[PPT];
+  const int j0 = PPT * (int)threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) c[u] = (!overflow && j0 + u < W) ? sc.bin_count[r * W + j0 + u] : 0u;
   // the row's sub-lists (counts requested with the bins' counts)
   uint32_t sub_n = 0;
   if (threadIdx.x < ROW_SUBS && !overflow) {
     sub_n = sc.row_cnt[(size_t)(r * ROW_SUBS + threadIdx.x) * ROW_CNT_STRIDE];
     if (sub_n > sc.row_cap) sub_n = sc.row_cap;
   }
-  uint32_t inc = c[0] + c[1];
+  uint32_t inc = 0;
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) inc += c[u];
   const uint32_t mine = inc;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -1506,9 +1512,14 @@ __global__ __launch_bounds__(BR_TPB) void k_bin_rows(Dims d, State st, Scratch s
     if (w < wid) before += wave_tot[w];
     total += wave_tot[w];
   }
-  const uint32_t ex = before + inc - mine;
-  if (j0 < W) pre[j0] = ex;
-  if (j0 + 1 < W) pre[j0 + 1] = ex + c[0];
+  {
+    uint32_t run = before + inc - mine;
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      if (j0 + u < W) pre[j0 + u] = run;
+      run += c[u];
+    }
+  }
   if (threadIdx.x == 0) {
     pre[W] = total;
     s_base = total ? atomicAdd(&sc.cnt->n_vis, total) : 0u;
@@ -1543,7 +1554,7 @@ __global__ __launch_bounds__(BR_TPB) void k_bin_rows(Dims d, State st, Scratch s
   {
     const int h = d.window_half;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < PPT; ++u) {
       const int j = j0 + u;
       if (j < W) {
         const uint32_t n = row_over ? 0u : pre[j + h + 1 > W ? W : j + h + 1] - pre[j - h < 0 ? 0 : j - h];
@@ -1569,7 +1580,7 @@ __global__ __launch_bounds__(BR_TPB) void k_bin_rows(Dims d, State st, Scratch s
   // ---- every pixel's bin: canonical order, gather
   const size_t slot_base = (size_t)d.v_begin << d.p_n;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < PPT; ++u) {
     const uint32_t n = c[u];
     if (!n) continue;
     const uint32_t p = (uint32_t)(r * W + j0 + u);
@@ -1591,25 +1602,30 @@ __global__ __launch_bounds__(BR_TPB) void k_bin_rows(Dims d, State st, Scratch s
           v[i] = lo;
           v[i + 1] = hi;
         }
-      float4 q[K];
-      float w8[K];
-      uint16_t t8[K];
+      // (eight entries per round of loads: sixteen positions at once are 64 registers)
 #pragma unroll
-      for (int i = 0; i < K; ++i)
-        if ((uint32_t)i < n) {
-          const size_t li = (size_t)v[i] - slot_base;
-          q[i] = st.pos4[li];
-          w8[i] = st.w[rec_index(li, d.p_n, REC_W)];
-          t8[i] = st.track[rec_index(li, d.p_n, REC_TRACK)];
-        }
+      for (int i0 = 0; i0 < K; i0 += 8) {
+        if ((uint32_t)i0 >= n) break;
+        float4 q[8];
+        float w8[8];
+        uint16_t t8[8];
 #pragma unroll
-      for (int i = 0; i < K; ++i)
-        if ((uint32_t)i < n) {
-          if (n > 1) a[i] = v[i];
-          sc.vp4[s + i] = make_float4(q[i].x, q[i].y, q[i].z, w8[i]);
-          sc.vtf[s + i] = (uint32_t)t8[i] | ((__float_as_uint(q[i].w) & 0xffu) << 16);
-          sc.vpix[s + i] = p;
-        }
+        for (int i = 0; i < 8; ++i)
+          if ((uint32_t)(i0 + i) < n) {
+            const size_t li = (size_t)v[i0 + i] - slot_base;
+            q[i] = st.pos4[li];
+            w8[i] = st.w[rec_index(li, d.p_n, REC_W)];
+            t8[i] = st.track[rec_index(li, d.p_n, REC_TRACK)];
+          }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if ((uint32_t)(i0 + i) < n) {
+            if (n > 1) a[i0 + i] = v[i0 + i];
+            sc.vp4[s + i0 + i] = make_float4(q[i].x, q[i].y, q[i].z, w8[i]);
+            sc.vtf[s + i0 + i] = (uint32_t)t8[i] | ((__float_as_uint(q[i].w) & 0xffu) << 16);
+            sc.vpix[s + i0 + i] = p;
+          }
+      }
     };
     if (n <= 8) {
       small_bin(std::integral_constant<int, 8>{});
@@ -3094,7 +3110,8 @@ void launch_visibility(const Dims &d, const Filter &flt, const State &st, const 
     SDM_DISPATCH_S(k_visibility, grid, s, d, st, sc);
   }
   // bins: one workgroup per image row lays the row's bins out, fills and orders them; then the pixels are classified for pass 1
-  hipLaunchKernelGGL(k_bin_rows, dim3((unsigned)d.H), dim3(BR_TPB), 0, s, d, st, sc);
+  if (d.W <= 2 * BR_TPB) hipLaunchKernelGGL(k_bin_rows<2>, dim3((unsigned)d.H), dim3(BR_TPB), 0, s, d, st, sc);
+  else hipLaunchKernelGGL(k_bin_rows<4>, dim3((unsigned)d.H), dim3(BR_TPB), 0, s, d, st, sc);
   hipLaunchKernelGGL(k_ck_classify, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, ck_out, finish);
 }
 

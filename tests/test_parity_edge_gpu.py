@@ -57,6 +57,21 @@ def test_other_window_sizes(window_half):
     assert st["live_particles"] > 0
 
 
+@pytest.mark.parametrize("width", [1280, 1281, 2047])
+def test_wide_images(width):
+    """k_bin_rows lays out a whole image row per workgroup: two pixels per thread up to 1280 columns, four beyond (up to the
+    2047 the list entries have bits for); the presets stop at 1242."""
+    cfg = dict(synth.CONFIGS["T0"], width=width, height=24, fx=width * 0.6, fy=width * 0.6, cx=width / 2.0, cy=12.0)
+    params = synth.PARAMS["noisy3"]
+    sc = synth.Scene(cfg, n_dynamic=1, seed=17)
+    frames = []
+    for t in range(4):
+        depth, cloud, pos, q = sc.render(t, params)
+        frames.append((depth, cloud, pos, q, sc.moves(t)))
+    st = run_clip(cfg, params, frames)
+    assert st["live_particles"] > 0
+
+
 def test_independent_filter_with_moving_objects():
     cfg = synth.CONFIGS["T0"]
     params = synth.PARAMS["kitti360"]
