@@ -58,7 +58,7 @@ for t in range(10):
     v = k[1]; w = v.copy(); w[:, 1] = w[:, 3]
     act = (v[:, 0] > 0) & (v[:, 3] > 0)
     span("visibility", w, "| masks %.1f, empty voxels %.1f, full voxels %.1f us (avg)" % (us((v[act, 1] - v[act, 0]).mean()), us((v[act, 2] - v[act, 1]).mean()), us((v[act, 3] - v[act, 2]).mean())) if act.any() else "")
-    span("bin_sort_gather", k[2])
+    span("bin_rows", k[2])
     c = k[3]
     span("ck heavy part", c[:1536], "| batches per workgroup max %d" % c[:4096, 2].max())
     span("ck light part", c[1536:])
@@ -76,12 +76,12 @@ for t in range(10):
         ends = a[:, end_col][a[:, end_col] > 0]
         return (a[ran, 0].min(), max(ends.max(), a[ran, 0].max())) if ran.any() and ends.size else None
 
-    order = [("move_apply", mv[0], 3), ("move_replay", mv[1], 2), ("visibility", k[1], 3), ("bin_sort_gather", k[2], 1), ("ck", k[3], 1),
+    order = [("move_apply", mv[0], 3), ("move_replay", mv[1], 2), ("visibility", k[1], 3), ("bin_rows", k[2], 1), ("ck", k[3], 1),
              ("weight", k[4], 1), ("birth_replay", k[0], 2), ("occupancy", k[5], 3)]
     tl = [(n, first_last(a, c)) for n, a, c in order]
     tl = [(n, x) for n, x in tl if x]
     t0 = tl[0][1][0]
-    print("   main stream, first workgroup start -> last recorded end, us from move_apply's start (scan and bin_fill sit between visibility and bin_sort_gather):")
+    print("   main stream, first workgroup start -> last recorded end, us from move_apply's start (k_ck_classify, not instrumented, sits between bin_rows and ck):")
     prev_end = None
     for n, (a0, a1) in tl:
         print("      %-16s %7.1f -> %7.1f%s" % (n, us(a0 - t0), us(a1 - t0), "" if prev_end is None else "   gap to the kernel before: %.1f us" % us(a0 - prev_end)))
