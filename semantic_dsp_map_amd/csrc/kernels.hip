@@ -46,6 +46,27 @@ namespace {
 // most arrays is dead, which otherwise splits a 32-byte row into dword/dwordx3 pieces).
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+// A pointer that was itself loaded from memory (the frame's input images: FrameArgs::depth / cloud) has no address space
+// the compiler can see: its loads become FLAT instructions, which count on both wait counters and complete out of
+// order with everything else - with one of them in flight the compiler waits for ALL outstanding memory operations
+// (vmcnt(0) lgkmcnt(0)) before every later use of any loaded value.  These buffers are device memory: say so.
+template <typename T>
+using gptr = const __attribute__((address_space(1))) T *;
+template <typename T>
+__device__ __forceinline__ gptr<T> as_global(const T *p) {
+  return (gptr<T>)p;
+}
+// a whole labelled point (20 bytes) from such a buffer
+__device__ __forceinline__ sdm_labeled_point load_point(const sdm_labeled_point *cloud, size_t i) {
+  static_assert(sizeof(sdm_labeled_point) == 20, "five words");
+  gptr<uint32_t> w = (gptr<uint32_t>)(cloud + i);
+  uint32_t t[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) t[k] = w[k];
+  sdm_labeled_point o;
+  __builtin_memcpy(&o, t, sizeof(o));
+  return o;
+}
 // A = alignment the caller guarantees for src (record fields: rec_align(S), sdm_internal.h); below the natural
 // alignment of the widest piece (S <= 4 only) the copy is left to the compiler.
 template <int A = 16, typename T, int N>
@@ -113,6 +134,93 @@ __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, uint32_t 
     static_assert(sizeof(sdm_voxel_result) == 8, "the result entry is cleared as one 8-byte store");
     reinterpret_cast<uint2 *>(st.res)[lv] = make_uint2(0u, 0u);
     mv_head[lv] = 0xffffffffu;
+  }
+}
+
+// The same reset with every byte it touches on a lane-linear 16-byte access (S >= 8: a record is a whole number of
+// 16-byte pieces).  k_clear_slots stores a weight, a stamp and a status byte per lane: three store instructions that each
+// leave holes in five or six lines of the record array.  Here a workgroup takes CLR_VOX consecutive voxels: their
+// positions (read, xyz zeroed, .w - the forget count - kept), the pieces of their records that hold weights, stamps and
+// status bytes (the track ids and labels in between are left alone: nothing of a record is read), their owners and the
+// per-voxel arrays, 1 KB contiguous per store instruction, all loads of a thread requested before its first store.
+// Measured on the C3 map (tools/gpu_round4_clear.sh, same box): 1.73 ms per sdm_clear with k_clear_slots, 1.42 ms with
+// this kernel (the kernel itself 1.45 -> 1.33 ms; FETCH_SIZE = the positions and nothing else), 1.63 ms when the kept
+// pieces are read and written back so that every sector of the record array is written whole - the memory side merges
+// the partial sectors better than it serves the extra reads - and 1.62-1.74 ms with plain instead of non-temporal accesses.
+constexpr int CLR_VOX = 256;
+template <int S>
+__global__ __launch_bounds__(TPB) void k_clear_map(Dims d, State st, uint32_t *__restrict__ mv_head) {
+  static_assert(S >= 8 && (10 * S) % 16 == 0, "whole 16-byte pieces per record");
+  constexpr int REC = 10 * S, RP = REC / 16;  // bytes, pieces of one record
+  constexpr uint32_t STATUS_WORD0 = (uint32_t)ST_TIMEPTC | (uint32_t)ST_INVALID << 8 | (uint32_t)ST_INVALID << 16 | (uint32_t)ST_INVALID << 24;
+  constexpr uint32_t STATUS_WORD = (uint32_t)ST_INVALID * 0x01010101u;
+  const uint32_t tid = threadIdx.x;
+  const size_t lv0 = (size_t)blockIdx.x * CLR_VOX;
+  const uint32_t nv = (uint32_t)(d.v_count - lv0 < (size_t)CLR_VOX ? d.v_count - lv0 : (size_t)CLR_VOX);  // a multiple of 8
+  // positions: S pieces per voxel
+  constexpr int PP = CLR_VOX * S / TPB;
+  v4u pos[PP];
+  v4u *pp = reinterpret_cast<v4u *>(st.pos4 + lv0 * S);
+  const uint32_t npos = nv * S;
+#pragma unroll
+  for (int k = 0; k < PP; ++k) {
+    const uint32_t q = k * TPB + tid;
+    pos[k] = __builtin_nontemporal_load(pp + (q < npos ? q : npos - 1u));
+  }
+#pragma unroll
+  for (int k = 0; k < PP; ++k) {
+    const uint32_t q = k * TPB + tid;
+    if (q < npos) {
+      v4u p = pos[k];
+      p.x = p.y = p.z = 0u;
+      __builtin_nontemporal_store(p, pp + q);
+    }
+  }
+  // records: RP pieces per voxel; which words of a piece are zeroed / left alone / status follows from its offset in the
+  // record [w: 4S | ts: 2S | track: 2S | label: S | status: S]
+  constexpr int RPT = (CLR_VOX * RP + TPB - 1) / TPB;
+  v4u *rp = reinterpret_cast<v4u *>(st.rec + lv0 * REC);
+  const uint32_t nrec = nv * RP;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const uint32_t q = k * TPB + tid;
+    if (q >= nrec) continue;
+    const uint32_t r = q % RP;
+    uint32_t wd[4];
+    bool reset[4], all = true;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t ob = r * 16 + c * 4;  // byte offset of the word in the record
+      reset[c] = ob < 6 * S || ob >= 9 * S;
+      wd[c] = ob < 6 * S ? 0u : (ob == 9 * S ? STATUS_WORD0 : STATUS_WORD);
+      all = all && reset[c];
+    }
+    if (all) {
+      __builtin_nontemporal_store(v4u{wd[0], wd[1], wd[2], wd[3]}, rp + q);
+    } else {  // a piece that also holds track ids or labels (S = 8: the 8 status bytes behind the 8 labels)
+      uint32_t *w32 = reinterpret_cast<uint32_t *>(rp + q);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (reset[c]) w32[c] = wd[c];
+    }
+  }
+  // owners (2 B per slot) and the per-voxel arrays
+  {
+    static_assert(OWNER_NONE == 0xFFFF, "owners are cleared as all-ones pieces");
+    static_assert(sizeof(sdm_voxel_result) == 8, "the result entries are cleared as 16-byte pieces");
+    const v4u zero{0u, 0u, 0u, 0u}, ones{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    constexpr int OP = (CLR_VOX * S * 2 / 16 + TPB - 1) / TPB;
+    v4u *op = reinterpret_cast<v4u *>(st.owner + lv0 * S);
+    const uint32_t nown = nv * S * 2 / 16;
+#pragma unroll
+    for (int k = 0; k < OP; ++k) {
+      const uint32_t q = k * TPB + tid;
+      if (q < nown) __builtin_nontemporal_store(ones, op + q);
+    }
+    if (tid < nv * 8 / 16) __builtin_nontemporal_store(zero, reinterpret_cast<v4u *>(st.res + lv0) + tid);
+    if (tid < nv * 4 / 16) __builtin_nontemporal_store(ones, reinterpret_cast<v4u *>(mv_head + lv0) + tid);  // MV_NIL
+    if (tid < nv * 2 / 16) __builtin_nontemporal_store(zero, reinterpret_cast<v4u *>(st.vts + lv0) + tid);
+    if (tid < nv / 8) reinterpret_cast<v2u *>(st.vflag + lv0)[tid] = v2u{0u, 0u};  // (nv is a multiple of 8, not of 16)
   }
 }
 
@@ -508,10 +616,16 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 4 
     load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
     uint32_t rx, ry, rz;
     voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+    const uint32_t smax = stamp_max(st, rx, ry, rz);
+#ifndef SDM_AB_NO_SCHED_BARRIER
+    // everything is requested before anything is looked at (left alone the compiler sinks some of the loads to their
+    // first use: two more dependent round trips in a kernel that is nothing but latency)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // (latency-bound here, not issue-bound: the general version only - the plain one would cost registers, i.e.
     // resident workgroups, i.e. dispatch time of the many workgroups that leave at once)
     sdm_voxel_result out;
-    occupancy_evaluate<S, false>(st, occ_threshold, remark, lv, stamp_max(st, rx, ry, rz), ts1, st1, wv, trk, lab, out);
+    occupancy_evaluate<S, false>(st, occ_threshold, remark, lv, smax, ts1, st1, wv, trk, lab, out);
     store_result(st.res + lv, out);
   }
   __syncthreads();  // the list and the selection are reused by the next tile of this workgroup
@@ -678,9 +792,13 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 
         load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
         uint32_t rx, ry, rz;
         voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+        const uint32_t smax = stamp_max(st, rx, ry, rz);
+        // everything of the record is requested before anything is looked at: left alone, the compiler (held to 64
+        // registers) sank each load to its first use - five dependent round trips per listed voxel instead of one
+        __builtin_amdgcn_sched_barrier(0);
         sdm_voxel_result out;
         // (the general version only: the plain one next to it costs registers and was measured to gain nothing here)
-        occupancy_evaluate<S, false>(st, occ_threshold, remark, lv, stamp_max(st, rx, ry, rz), ts1, st1, wv, trk, lab, out);
+        occupancy_evaluate<S, false>(st, occ_threshold, remark, lv, smax, ts1, st1, wv, trk, lab, out);
         v2u o;
         __builtin_memcpy(&o, &out, 8);
         *stage_slot(tv) = o;
@@ -703,14 +821,20 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 
   }
 }
 
+#ifdef SDM_DENSE_WAVES
+#define DENSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SDM_DENSE_WAVES, SDM_DENSE_WAVES)))
+#else
+#define DENSE_WAVES_ATTR
+#endif
 template <int S>
-__global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_threshold, State st,
+__global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d, float occ_threshold, State st,
                                                          const unsigned long long *__restrict__ need, uint32_t remark) {
   constexpr int REC = 10 * S;                    // bytes of one record
   constexpr int PIECES = OCC_CHUNK * REC / 16;   // 16-byte pieces of one chunk of records
   constexpr int PPL = (PIECES + 63) / 64;
   __shared__ v4u rec_stage[OCC_WAVES][PIECES];  // one chunk of records per wave, for the lane <-> record transposition
   __shared__ uint32_t smax_stage[OCC_WAVES][OCC_CHUNK];  // ... and the slab stamps of its voxels
+  __shared__ uint32_t yz_stage[OCC_WAVES][OCC_CPW];      // max(y stamp, z stamp) of each chunk of the wave
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t lvw = blockIdx.x * OCC_TILE + wave * OCC_CPW * OCC_CHUNK;  // first voxel of this wave
   // the masks of the wave's chunks: lane k holds chunk k's
@@ -726,22 +850,43 @@ __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_thres
                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, k);
     evalbits |= (uint32_t)((m >> lane) & 1ull) << k;
   }
-  // (the slab stamp of this lane's voxel of the chunk travels with the chunk's records: loaded where the evaluation needs
-  // it, it was a dependent L2 round trip in every step)
-  auto fetch = [&](int k, v4u (&buf)[PPL], uint32_t &smax) {  // lane-linear loads of chunk k's records: 1 KB contiguous per instruction
-    const uint32_t lvc = lvw + k * OCC_CHUNK;
-    if (lvc + lane < d.v_count) {
+  // Slab stamps.  The stamp of this lane's voxel of a chunk travels with the chunk's records (loaded where the
+  // evaluation needs it, it was a dependent L2 round trip in every step) - and nothing may be computed from it where it is
+  // requested: a max over the three axis stamps right behind their loads made the compiler wait for ALL outstanding
+  // loads in every fetch (s_waitcnt vmcnt(0): the stamps' own round trip exposed once per chunk, and the chunk
+  // requested one step earlier waited for as well).  With x_n >= 6 a chunk lies in one x row of the ring: its y and z
+  // stamps are one value per chunk, fetched once per wave up front (yz_stage), and a fetch requests the x
+  // stamps only and leaves them raw; the max is taken in the step.  Smaller maps: the per-lane max, as before.
+  const bool rows = d.x_n >= 6;
+  if (lane < (uint32_t)OCC_CPW) {
+    uint32_t yzv = 0;  // (0 where the staged value is the max already)
+    if (rows && lvw + lane * OCC_CHUNK < d.v_count) {
       uint32_t rx, ry, rz;
-      voxel_to_ring(d, d.v_begin + lvc + lane, rx, ry, rz);
-      smax = stamp_max(st, rx, ry, rz);
+      voxel_to_ring(d, d.v_begin + lvw + lane * OCC_CHUNK, rx, ry, rz);
+      const uint32_t b = st.stamps_y[ry], c = st.stamps_z[rz];
+      yzv = b > c ? b : c;
     }
-    const uint32_t nvox = d.v_count - lvc < (uint32_t)OCC_CHUNK ? d.v_count - lvc : (uint32_t)OCC_CHUNK;
-    const uint32_t npieces = nvox * REC / 16;  // nvox is a multiple of 8
+    yz_stage[wave][lane] = yzv;
+  }
+  // lane-linear loads of chunk k's records: 1 KB contiguous per instruction.  Every load is unconditional (a lane
+  // beyond the end of the map repeats the last piece / voxel): a load under a branch of its own is a basic block of its
+  // own, and the compiler then cannot count the loads in flight - it waited for each of the first chunk's five loads
+  // before it requested the next one.
+  auto fetch = [&](int k, v4u (&buf)[PPL], uint32_t &smax) {
+    const uint32_t lvc = lvw + k * OCC_CHUNK;
+    const uint32_t nvox = d.v_count - lvc < (uint32_t)OCC_CHUNK ? d.v_count - lvc : (uint32_t)OCC_CHUNK;  // a multiple of 8, >= 8
+    {
+      uint32_t rx, ry, rz;
+      voxel_to_ring(d, d.v_begin + lvc + (lane < nvox ? lane : nvox - 1u), rx, ry, rz);
+      if (rows) smax = st.stamps_x[rx];
+      else smax = stamp_max(st, rx, ry, rz);
+    }
+    const uint32_t npieces = nvox * REC / 16;
     const v4u *src = reinterpret_cast<const v4u *>(st.rec + (size_t)lvc * REC);
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const uint32_t idx = j * 64 + lane;
-      if (idx < npieces) buf[j] = __builtin_nontemporal_load(src + idx);
+      buf[j] = __builtin_nontemporal_load(src + (idx < npieces ? idx : npieces - 1u));
     }
   };
   auto to_stage = [&](const v4u (&buf)[PPL], uint32_t smax) {
@@ -756,11 +901,15 @@ __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_thres
     const uint32_t rest = densebits & ~((2u << k) - 1u);
     return rest ? __builtin_ctz(rest) : OCC_CPW;
   };
+#ifndef SDM_DENSE_BUFS
+#define SDM_DENSE_BUFS 1
+#endif
+#if SDM_DENSE_BUFS == 2
   // three chunks of the wave are under way at any time: one in the stage, two in registers
   int k = __builtin_ctz(densebits);
   int k1 = next_dense(k);
   int k2 = k1 < OCC_CPW ? next_dense(k1) : OCC_CPW;
-  v4u b0[PPL], b1[PPL];
+  v4u b0[PPL] = {}, b1[PPL] = {};
   uint32_t s0 = 0, s1 = 0;  // slab stamps of the chunks in b0, b1
   {
     v4u first[PPL];
@@ -770,8 +919,27 @@ __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_thres
     if (k2 < OCC_CPW) fetch(k2, b1, s1);
     to_stage(first, sf);
   }
-  // one step: evaluate chunk k out of the stage, move `up` (chunk k1, landed or landing) into the stage, start the loads
-  // of the chunk after k2 into `up`.  The two register buffers alternate, hence the loop body holds two steps.
+#else
+  // two chunks of the wave are under way at any time: one in the stage, one in registers (landing while the one in the
+  // stage is evaluated).  A second register buffer was there until round 4 and bought nothing: the fetches and the
+  // stores of the evaluation sit in branches, so the compiler cannot count what was issued after a buffer's loads and
+  // waits for everything outstanding (s_waitcnt vmcnt(0)) before it moves a buffer into the stage - the younger
+  // buffer's loads included.
+  int k = __builtin_ctz(densebits);
+  int k1 = next_dense(k);
+  constexpr int k2 = OCC_CPW;
+  v4u b0[PPL] = {};
+  uint32_t s0 = 0;  // slab stamps of the chunk in b0
+  {
+    v4u first[PPL];
+    uint32_t sf = 0;
+    fetch(k, first, sf);
+    if (k1 < OCC_CPW) fetch(k1, b0, s0);
+    to_stage(first, sf);
+  }
+#endif
+  // one step: evaluate chunk k out of the stage, move `up` (the next dense chunk, landed or landing) into the stage,
+  // start the loads of the one after it into `up`
   auto step = [&](v4u (&up)[PPL], uint32_t &s_up) {
     const bool mine = (evalbits >> k) & 1u;
     const uint32_t lv = lvw + k * OCC_CHUNK + lane;
@@ -790,35 +958,43 @@ __global__ __launch_bounds__(TPB) void k_occupancy_dense(Dims d, float occ_thres
       __builtin_memcpy(trk, __builtin_assume_aligned(r + 6 * S, RA < 2 * S ? RA : 2 * S), 2 * S);
       __builtin_memcpy(lab, __builtin_assume_aligned(r + 8 * S, RA < S ? RA : S), S);
       __builtin_memcpy(st1, __builtin_assume_aligned(r + 9 * S, RA < S ? RA : S), S);
-#ifdef SDM_AB_DENSE_STAMP_IN_STEP
-      {
-        uint32_t rx, ry, rz;
-        voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
-        smk = stamp_max(st, rx, ry, rz);
-      }
-#else
       smk = smax_stage[wave][lane];
-#endif
     }
-    // the evaluation runs on registers only; the two chunks behind this one are landing meanwhile
+    {
+      const uint32_t yz = yz_stage[wave][k];
+      smk = smk > yz ? smk : yz;
+    }
+    // the evaluation runs on registers only; the chunk behind this one is landing meanwhile
     sdm_voxel_result out;
     occupancy_evaluate_wave<S>(st, occ_threshold, remark, mine, lv, smk, ts1, st1, wv, trk, lab, out);
     if (mine) store_result(st.res + lv, out);
-    // the next chunk moves into the stage (its loads have had two evaluations' time) and the loads of the third start
+    // the next chunk moves into the stage (its loads have had this evaluation's time) and the loads of the one after it start
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     k = k1;
+#if SDM_DENSE_BUFS == 2
     k1 = k2;
     k2 = k2 < OCC_CPW ? next_dense(k2) : OCC_CPW;
     if (k < OCC_CPW) to_stage(up, s_up);
     if (k2 < OCC_CPW) fetch(k2, up, s_up);
+#else
+    k1 = k1 < OCC_CPW ? next_dense(k1) : OCC_CPW;
+    if (k < OCC_CPW) to_stage(up, s_up);
+    if (k1 < OCC_CPW) fetch(k1, up, s_up);
+#endif
   };
+  // (a fixed trip count: with `while (k < OCC_CPW)` and a break in the middle the compiler rotated the loop and left a
+  // wait for all loads right behind the fetch on the back edge)
 #pragma unroll 1
-  while (k < OCC_CPW) {
-    step(b0, s0);
-    if (k >= OCC_CPW) break;
-    step(b1, s1);
+#if SDM_DENSE_BUFS == 2
+  for (int it = 0; it < OCC_CPW / 2; ++it) {
+    if (k < OCC_CPW) step(b0, s0);
+    if (k < OCC_CPW) step(b1, s1);
   }
+#else
+  for (int it = 0; it < OCC_CPW; ++it)
+    if (k < OCC_CPW) step(b0, s0);
+#endif
 }
 
 // slot 0 of the exported stamp array carries the voxel stamp (sdm_dump_state / sdm_load_state keep the reference's
@@ -1165,7 +1341,7 @@ __device__ __forceinline__ bool vbit(const uint64_t *__restrict__ R, size_t line
 // list reservations.  (Nine reached voxels in ten are empty and never get here: k_visibility's phase 1.)
 template <int S>
 __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, const State &st, const Scratch &sc,
-                                                 const float *__restrict__ depth_img, int ax, int ay, int az) {
+                                                 gptr<float> depth_img, int ax, int ay, int az) {
   const uint32_t rx = axis_correct(ax + f.eq[0], d.NX);
   const uint32_t ry = axis_correct(ay + f.eq[1], d.NY);
   const uint32_t rz = axis_correct(az + f.eq[2], d.NZ);
@@ -1191,10 +1367,16 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   uint16_t tsv[S];
   load_vec<rec_align(S)>(stv, st.status + base * REC_STATUS);
   load_vec<rec_align(S)>(tsv, st.ts + base * REC_TS);
+  // the positions of all slots ride with the record's rows - the voxel's S positions are one 16*S-byte block (one line
+  // at S = 8) whatever is live in it; requested slot by slot where a slot turned out live, each load sat in a branch of
+  // its own and was waited for before the next one was requested (S - 1 dependent round trips)
+  float4 pos[S];
+#pragma unroll
+  for (int i = 1; i < S; ++i) pos[i] = st.pos4[base + i];
+  __builtin_amdgcn_sched_barrier(0);
   bool dirty = false, observed = false, wrote_free = false;
   int valid_n = 0;
   bool live[S];
-  float4 pos[S];
 #pragma unroll
   for (int i = 1; i < S; ++i) {
     live[i] = false;
@@ -1206,7 +1388,6 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     }
     valid_n++;
     live[i] = true;
-    pos[i] = st.pos4[base + i];
   }
   int pixv[S], rowv[S];
   float camz[S], dptv[S];
@@ -1290,7 +1471,7 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
   __shared__ uint32_t n_full;
   DBG_LANE0(1, 0);
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
-  const float *__restrict__ depth_img = sc.fa->depth;
+  const gptr<float> depth_img = as_global(sc.fa->depth);
   // (requested with the frame's scalars: one dependent step less before the masks)
   const uint32_t fgen = (uint32_t)sc.fa->force_generic, fcx = (uint32_t)sc.cnt->flood_complex;
   const bool generic = (fgen | fcx) != 0;
@@ -1313,17 +1494,27 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
       if (rz >= d.rz_begin && rz < d.rz_begin + d.rz_count) {  // else: another shard's slab
         const uint64_t *__restrict__ bits = generic ? sc.reach : sc.vmask;
         const int VY = d.NY + 1;
+        // the twelve words of the four lines are requested before any of them is looked at, none under a condition of
+        // its own (a load in a branch of its own is waited for before the next one is requested: this was a chain of
+        // eight dependent round trips at the start of every workgroup)
+        unsigned long long w0[4], w1[4], lr[4];
+        const int wi1 = wi + 1 < (int)sc.wpl ? wi + 1 : wi;
 #pragma unroll
-        for (int dz = 0; dz < 2; ++dz)
+        for (int c = 0; c < 4; ++c) {
+          const int y = ay + (c & 1), z = az + (c >> 1);
+          const size_t lb = ((size_t)z * VY + y) * sc.wpl;
+          lr[c] = sc.line_reach[(size_t)z * sc.wy + (y >> 6)];  // (not looked at in generic mode)
+          w0[c] = bits[lb + wi];
+          w1[c] = bits[lb + wi1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int dy = 0; dy < 2; ++dy) {
-            const int y = ay + dy, z = az + dz;
-            const size_t lb = ((size_t)z * VY + y) * sc.wpl;
-            const bool line_ok = generic || ((sc.line_reach[(size_t)z * sc.wy + (y >> 6)] >> (y & 63)) & 1ull);
-            const unsigned long long w0 = bits[lb + wi];
-            const unsigned long long w1 = wi + 1 < (int)sc.wpl ? bits[lb + wi + 1] : 0ull;
-            if (line_ok) m |= w0 | (w0 >> 1) | (w1 << 63);
-          }
+        for (int c = 0; c < 4; ++c) {
+          const int y = ay + (c & 1);
+          const bool line_ok = generic || ((lr[c] >> (y & 63)) & 1ull);
+          const unsigned long long w1m = wi + 1 < (int)sc.wpl ? w1[c] : 0ull;
+          if (line_ok) m |= w0[c] | (w0[c] >> 1) | (w1m << 63);
+        }
         // voxels of the box only
         const int x0 = wi << 6;
         const int lo = f.bb0[0] > x0 ? f.bb0[0] - x0 : 0;
@@ -1356,24 +1547,29 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
 #pragma unroll
   for (int j = 0; j < VIS_J; ++j) {
     const uint32_t li = threadIdx.x + (uint32_t)j * TPB;
+    // (no branch around this: the flag byte of every candidate of the thread is requested before the first one is
+    // looked at - under `if (li < nl)` each load was waited for where its branch ended, VIS_J dependent round trips)
     code[j] = 0xffffffffu;
     lvv[j] = 0;
     flg[j] = 0;
-    if (li < nl) {
-      int w = 0;
+    if ((uint32_t)j * TPB >= nl) continue;  // workgroup-uniform: nobody has a j-th candidate
+    const bool have = li < nl;
+    int w = 0;
 #pragma unroll
-      for (int k = 1; k < VIS_WORDS; ++k) w += woff[k] <= li ? 1 : 0;
-      const int bit = nth_set_bit(wmask[w], li - woff[w]);
-      code[j] = (uint32_t)(w << 6 | bit);
-      const uint32_t g = g0 + (uint32_t)w;
-      const int ax = ((wlo + (int)(g % nwx)) << 6) + bit;
-      const int ay = f.bb0[1] + (int)((g / nwx) % by);
-      const int az = f.bb0[2] + (int)(g / ((uint32_t)nwx * by));
-      const uint32_t rx = axis_correct(ax + f.eq[0], d.NX), ry = axis_correct(ay + f.eq[1], d.NY), rz = axis_correct(az + f.eq[2], d.NZ);
-      lvv[j] = ring_to_voxel(d, rx, ry, rz) - d.v_begin;
-      flg[j] = st.vflag[lvv[j]] & VF_STATE;  // VF_EMPTY: every slot INVALID, the record is not touched
-    }
+    for (int k = 1; k < VIS_WORDS; ++k) w += woff[k] <= li ? 1 : 0;
+    const int bit = nth_set_bit(wmask[w], li - woff[w]) & 63;
+    const uint32_t g = g0 + (uint32_t)w;
+    const int ax = ((wlo + (int)(g % nwx)) << 6) + bit;
+    const int ay = f.bb0[1] + (int)((g / nwx) % by);
+    const int az = f.bb0[2] + (int)(g / ((uint32_t)nwx * by));
+    const uint32_t rx = axis_correct(ax + f.eq[0], d.NX), ry = axis_correct(ay + f.eq[1], d.NY), rz = axis_correct(az + f.eq[2], d.NZ);
+    code[j] = have ? (uint32_t)(w << 6 | bit) : 0xffffffffu;
+    lvv[j] = have ? ring_to_voxel(d, rx, ry, rz) - d.v_begin : 0u;
+    flg[j] = st.vflag[lvv[j]];  // VF_EMPTY: every slot INVALID, the record is not touched
   }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < VIS_J; ++j) flg[j] = code[j] != 0xffffffffu ? flg[j] & VF_STATE : 0u;
   float imz[VIS_J], imd[VIS_J];
 #pragma unroll
   for (int j = 0; j < VIS_J; ++j) {
@@ -1682,7 +1878,7 @@ __global__ __launch_bounds__(TPB) void k_ck_classify(Dims d, Filter flt, Scratch
   o.is_valid = 0;
   uint32_t total = 0;
   if (in_image) {
-    o = sc.fa->cloud[p];
+    o = load_point(sc.fa->cloud, p);
     const int i = (int)p / W;
 #pragma unroll
     for (int r = 0; r < A7_ROWS; ++r) {
@@ -1747,7 +1943,7 @@ __device__ __forceinline__ void ck_light_pixel(const Dims &d, const Filter &flt,
   sdm_labeled_point o;
   uint32_t ss[A7_ROWS], ee[A7_ROWS];
   if (mine) {
-    o = sc.fa->cloud[p];
+    o = load_point(sc.fa->cloud, p);
     const int h = d.window_half;
     const int i = p / d.W, j = p - i * d.W;
     const int j0 = j - h < 0 ? 0 : j - h;
@@ -1819,7 +2015,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, St
   const uint32_t shard = blockIdx.x & (VIS_SHARDS - 1);
   const uint32_t n = sc.cnt->shard[shard].heavy;
   const float *__restrict__ pdf = st.pdf;
-  const sdm_labeled_point *__restrict__ cloud_img = sc.fa->cloud;
+  const gptr<sdm_labeled_point> cloud_img = as_global(sc.fa->cloud);
   // batches of 16 listed pixels are handed out by a ticket counter (per shard): window sizes are very uneven, a fixed
   // assignment leaves the kernel waiting for the workgroup that drew the long batches.  Which workgroup computes a pixel
   // does not change its value.
@@ -1842,7 +2038,7 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, St
     sdm_labeled_point o;
     if (q < n) {
       p = (int)sc.ck_heavy[shard * sc.cap_heavy + q];
-      o = cloud_img[p];
+      o = load_point(sc.fa->cloud, p);
       const int i = p / d.W, j = p - i * d.W;
       const int ni = i + r - h;
       if (r <= 2 * h && ni >= 0 && ni < d.H) {
@@ -1961,7 +2157,7 @@ __global__ __launch_bounds__(TPB) void k_ck_finish(Dims d, Filter flt, Scratch s
                                                    int n_parts, size_t part_stride) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.W * d.H) return;
-  const sdm_labeled_point o = sc.fa->cloud[p];
+  const sdm_labeled_point o = load_point(sc.fa->cloud, p);
   if (!o.is_valid) {
     sc.pixt[p] = 0;
     return;
@@ -2015,7 +2211,7 @@ __global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, St
   __shared__ float rowsum[WT_WAVES][U][A7_ROWS];
   if (sc.cnt->overflow) return;
   const uint32_t n = sc.cnt->n_vis;
-  const sdm_labeled_point *__restrict__ cloud_img = sc.fa->cloud;
+  const gptr<sdm_labeled_point> cloud_img = as_global(sc.fa->cloud);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = d.window_half, side = 2 * h + 1, pairs = side * side;
@@ -2156,7 +2352,7 @@ __global__ __launch_bounds__(TPB) void k_birth_flags(Dims d, BirthOrder bo, Scra
   if (q >= d.W * d.H) return;
   int i, j;
   birth_seq_to_pixel(bo, q, i, j);
-  sc.b_valid[q] = sc.fa->cloud[i * d.W + j].is_valid ? 1u : 0u;
+  sc.b_valid[q] = as_global(sc.fa->cloud)[i * d.W + j].is_valid ? 1u : 0u;
 }
 
 // One thread per birth candidate b = q * nb + n (q = position in the raster order, n = copy).
@@ -2171,7 +2367,7 @@ __global__ __launch_bounds__(TPB) void k_birth_candidates(Dims d, Filter flt, Bi
   int q = (int)(b / (uint32_t)flt.nb), n = (int)(b % (uint32_t)flt.nb);
   int i, j;
   birth_seq_to_pixel(bo, q, i, j);
-  const sdm_labeled_point pt = sc.fa->cloud[i * d.W + j];
+  const sdm_labeled_point pt = load_point(sc.fa->cloud, (size_t)(i * d.W + j));
   uint32_t key = d.V;  // sorts behind every real voxel
   float x = pt.x, y = pt.y, z = pt.z;
   if (pt.is_valid) {
@@ -2546,8 +2742,8 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
     }
   }
 #pragma unroll
-  for (int i = 1; i < S; ++i)
-    if (cand[i] >= 0) bps[i] = sc.bpos[cidx[i]];
+  for (int i = 1; i < S; ++i) bps[i] = sc.bpos[cidx[i]];  // (unconditional - entry 0 where the slot takes nobody: all S - 1 requests in one round)
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 1; i < S; ++i) {
     if (cand[i] < 0) continue;
@@ -3041,7 +3237,10 @@ void launch_clear(const Dims &d, const State &st, uint32_t *mv_head, hipStream_t
     hipMemsetAsync(mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t), s);
     hipLaunchKernelGGL(k_clear_status, dim3(4096), dim3(TPB), 0, s, st.status, (uint32_t)d.v_count, (uint32_t)(d.S * REC_STATUS));
   } else {
-    hipLaunchKernelGGL(k_clear_slots, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, mv_head, n);
+    if (d.S == 8) hipLaunchKernelGGL(k_clear_map<8>, dim3(blocks_for(d.v_count, CLR_VOX)), dim3(TPB), 0, s, d, st, mv_head);
+    else if (d.S == 16) hipLaunchKernelGGL(k_clear_map<16>, dim3(blocks_for(d.v_count, CLR_VOX)), dim3(TPB), 0, s, d, st, mv_head);
+    else
+      hipLaunchKernelGGL(k_clear_slots, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, mv_head, n);
   }
   hipMemsetAsync(st.alias, 0, 8, s);  // no older memberships
   hipMemsetAsync(st.owner_flag, 0, owner_flag_bytes(n), s);

@@ -774,10 +774,20 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
   const uint32_t epoch = sc.fa->f.epoch;
   const uint32_t stride = gridDim.x * blockDim.x;
   const bool overflow = sc.cnt->overflow != 0;
+  bool first_round = true;
   __shared__ uint32_t n_ok_block;  // (statistic: one global atomic per workgroup, not per voxel)
   if (threadIdx.x == 0) n_ok_block = 0;
   __syncthreads();
-  for (; t < n_copies; t += stride, c0 = t < n_copies ? sc.mv_copy[t] : c0, nx0 = t < n_copies ? sc.mv_next[t] : nx0) {
+  // (no `cond ? object : object` on MoveCopy anywhere here: the conditional operator on two lvalues selects an ADDRESS - one
+  // of them in global memory, the other the thread's own copy - so the compiler kept the thread's copy in scratch memory,
+  // fetched through a FLAT load, and re-read it from scratch for every insertion)
+  for (; t < n_copies; t += stride) {
+    if (first_round) {
+      first_round = false;
+    } else {
+      c0 = sc.mv_copy[t];
+      nx0 = sc.mv_next[t];
+    }
     DBGM(1, 0, DBGM_T());
     const uint32_t lv = c0.voxel;
     if (lv >= d.v_count) continue;
@@ -834,8 +844,7 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
       more = n_above > (uint32_t)(S - 1);  // ranks beyond this batch (a walk of the list is a chain of dependent loads: no second one to find nothing)
       MoveCopy cc[S - 1];  // the batch's copies, requested together
 #pragma unroll
-      for (int u = 0; u < S - 1; ++u)
-        if (best[u] != MV_NIL && best[u] != t) cc[u] = sc.mv_copy[best[u]];
+      for (int u = 0; u < S - 1; ++u) cc[u] = sc.mv_copy[best[u] != MV_NIL ? best[u] : t];  // (no branch per fetch: each one was waited for where its branch ended)
       // (the fetches above are to be under way together before the first insertion's stores: without the fence the compiler
       // sinks each fetch to the iteration that uses it - a dependent round trip per copy)
       __asm__ volatile("" ::: "memory");
@@ -849,7 +858,8 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
           break;
         }
         const int slot = __ffs((int)vac) - 1;
-        const MoveCopy c = e == t ? c0 : cc[u];
+        MoveCopy c = cc[u];
+        if (e == t) c = c0;
         const uint8_t cs = c.status;
         const uint16_t cts = c.ts;
         st.pos4[base + slot] = make_float4(c.x, c.y, c.z, __uint_as_float(c.forget_bits));
