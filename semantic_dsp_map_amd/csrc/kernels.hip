@@ -1880,10 +1880,21 @@ __global__ __launch_bounds__(TPB) void k_ck_classify(Dims d, Filter flt, Scratch
   if (in_image) {
     o = load_point(sc.fa->cloud, p);
     const int i = (int)p / W;
+    // the window's row counts, all requested before the first is added (a row outside the window or the image repeats
+    // the pixel's own row: no branch per load - each one was waited for before the next was requested, 2h + 1 dependent
+    // round trips in a kernel of 8 us)
+    uint32_t rw[A7_ROWS];
 #pragma unroll
     for (int r = 0; r < A7_ROWS; ++r) {
       const int ni = i + r - h;
-      if (r <= 2 * h && ni >= 0 && ni < H) total += sc.row_win[(int)p + (r - h) * W];
+      const bool ok = r <= 2 * h && ni >= 0 && ni < H;
+      rw[r] = sc.row_win[(int)p + (ok ? (r - h) * W : 0)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < A7_ROWS; ++r) {
+      const int ni = i + r - h;
+      total += (r <= 2 * h && ni >= 0 && ni < H) ? rw[r] : 0u;
     }
   }
   uint8_t cls = CK_DONE;
@@ -1928,10 +1939,14 @@ __device__ __forceinline__ float ck_term(const Filter &flt, const float *__restr
                                          const sdm_labeled_point &o, float rsig, bool &skip) {
   const uint16_t ptrack = (uint16_t)(tf & 0xffffu);
   skip = flt.independent && ptrack != o.track_id;
+  // (the forgetting factor is a load too - a table in the kernel's argument block, indexed at run time - and is requested
+  // with the three table values of the term: behind them, in the branch that uses it, it was a second dependent round
+  // trip per term)
+  const float fg = flt.forget[(tf >> 16) & 7];
   float gk = query_pdf_r<FAST>(pdf, pv.x, o.x, o.sigma, rsig) * query_pdf_r<FAST>(pdf, pv.y, o.y, o.sigma, rsig) *
              query_pdf_r<FAST>(pdf, pv.z, o.z, o.sigma, rsig);
   if (!flt.independent) {
-    gk *= flt.forget[(tf >> 16) & 7];
+    gk *= fg;
     if (ptrack != o.track_id) gk *= flt.id_transition;
   }
   return pv.w * gk;
