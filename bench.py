@@ -341,6 +341,8 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29531")  # (the one-process rehearsal is started without a launcher)
         with sharded.stdout_to_stderr():  # gloo prints its connection summary on stdout
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
