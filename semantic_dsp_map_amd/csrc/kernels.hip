@@ -258,11 +258,12 @@ __global__ __launch_bounds__(TPB) void k_set_frame(FrameArgs *__restrict__ dst, 
 // every voting slot's total is the sum of all voting weights in slot order (the very additions the pair loop performs for
 // it, the +0.f terms of the other slots included), the first voting slot wins, nobody beats it (equal total, equal
 // track), and the label is the last voting slot's.
+// (occupancy_evaluate_core hands the voxel's new flag byte back instead of storing it)
 template <int S, bool PLAIN, bool SINGLE = false>
-__device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_threshold, uint32_t remark, uint32_t lv, uint32_t smax,
-                                                   const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv_in)[S],
-                                                   const uint16_t (&trk16)[S], const uint8_t (&lab8)[S],
-                                                   sdm_voxel_result &out) {
+__device__ __forceinline__ void occupancy_evaluate_core(const State &st, float occ_threshold, uint32_t remark, uint32_t lv, uint32_t smax,
+                                                        const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv_in)[S],
+                                                        const uint16_t (&trk16)[S], const uint8_t (&lab8)[S],
+                                                        sdm_voxel_result &out, uint8_t &nflag) {
   float wv[S];
   uint32_t trk[S], lab[S], stv[S];
   bool vote[S];
@@ -323,6 +324,40 @@ __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_th
     have = any_vote && tot > 0.f;
     best_t = t1;
     best_l = have ? l1 : 0u;
+  } else if constexpr (PLAIN) {
+    // Every voting weight lies in [SDM_OCC_INIT_WEIGHT, 1] here (occupancy_is_plain tests the bit patterns: no NaN, no
+    // negative, nothing to clamp), which lets the vote share its comparisons.  e(i, j) = "slots i and j vote for the same
+    // track" is symmetric: 21 comparisons instead of 42, kept as the floats 1 / 0; a slot's total is the chain
+    //   tot = fma(e(i, j), w[j], tot),  j ascending, its own weight added in its place,
+    // the very additions of the pair loop below, bit for bit: 1 * w = w and 0 * w = +0 exactly, so each step rounds
+    // tot + w resp. leaves tot alone.  A slot that does not vote ends at +0 (its sentinel id matches nobody), every voter
+    // above 0: the winner is the largest total, among equal totals the smallest track id (slots of one track carry the
+    // same total), taken with max / compare / min instead of the seven dependent comparisons of the walk.
+    float eq[S][S];
+#pragma unroll
+    for (int i = 1; i < S; ++i)
+#pragma unroll
+      for (int j = i + 1; j < S; ++j) eq[i][j] = tv[i] == tv[j] ? 1.f : 0.f;
+    float tot[S];
+    float best_w = 0.f;
+#pragma unroll
+    for (int i = 1; i < S; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 1; j < S; ++j) {
+        if (j == i) t += wvote[j];
+        else t = __builtin_fmaf(i < j ? eq[i][j] : eq[j][i], wvote[j], t);
+      }
+      tot[i] = t;
+      best_w = fmaxf(best_w, t);
+    }
+    have = best_w > 0.f;
+    uint32_t bt = 0xffffffffu;
+#pragma unroll
+    for (int i = 1; i < S; ++i) bt = min(bt, tot[i] == best_w ? trk[i] : 0xffffffffu);
+    best_t = bt;  // (without a voter: some slot's id - it matches no voting slot below and is replaced by 0 further down)
+#pragma unroll
+    for (int j = 1; j < S; ++j) best_l = tv[j] == best_t ? lab[j] : best_l;
   } else {
     float best_w = 0.f;
 #pragma unroll
@@ -349,7 +384,7 @@ __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_th
     out.track = 0;
     out.label = 0;
     out.occ = 0.f > occ_threshold ? 1 : 0;
-    st.vflag[lv] = (uint8_t)((any ? VF_CLEAN : VF_EMPTY) | VR_EMPTY);  // the entry holds the empty result
+    nflag = (uint8_t)((any ? VF_CLEAN : VF_EMPTY) | VR_EMPTY);  // the entry holds the empty result
     return;
   }
   out.wsum = weight_sum;
@@ -357,7 +392,7 @@ __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_th
   out.label = (uint8_t)best_l;
   out.occ = weight_sum > occ_threshold ? 1 : (guessed >= SDM_OCC_INIT_WEIGHT ? 2 : 0);
   if constexpr (PLAIN) {
-    st.vflag[lv] = VF_CLEAN;
+    nflag = VF_CLEAN;
     return;
   }
   const size_t base = (size_t)lv * S;
@@ -381,8 +416,17 @@ __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_th
     store_vec<rec_align(S)>(st.status + base * REC_STATUS, sout);
     flag = left ? VF_DIRTY : VF_EMPTY;  // a culled slot still counted in this sum
   }
-  st.vflag[lv] = flag;
+  nflag = flag;
   if (flag != VF_CLEAN) mark_tile(st, lv, remark);  // the next sweep evaluates it again resp. writes the empty result
+}
+template <int S, bool PLAIN, bool SINGLE = false>
+__device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_threshold, uint32_t remark, uint32_t lv, uint32_t smax,
+                                                   const uint16_t (&ts1)[S], const uint8_t (&st1)[S], const float (&wv_in)[S],
+                                                   const uint16_t (&trk16)[S], const uint8_t (&lab8)[S],
+                                                   sdm_voxel_result &out) {
+  uint8_t nflag;
+  occupancy_evaluate_core<S, PLAIN, SINGLE>(st, occ_threshold, remark, lv, smax, ts1, st1, wv_in, trk16, lab8, out, nflag);
+  st.vflag[lv] = nflag;
 }
 
 // Conservative test for the PLAIN version above: true only if no slot that could be live carries a weight above 1
@@ -390,25 +434,31 @@ __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_th
 // slots are ignored for the weights (their weight may be anything), which costs the vacancy test the evaluation
 // repeats - still far cheaper than the rules it saves.
 // `single` comes back true iff all live slots carry one track id (the voting slots are among the live ones).
-template <int S>
+template <int S, bool WANT_SINGLE = true>
 __device__ __forceinline__ bool occupancy_is_plain(uint32_t smax, const uint16_t (&ts1)[S], const uint8_t (&st1)[S],
                                                    const float (&wv)[S], const uint16_t (&trk)[S], bool &single) {
-  float lo = SDM_OCC_INIT_WEIGHT, hi = 1.f;
+  // (the weights' bit patterns, compared as unsigned integers: for floats >= +0 that is the float order, and a negative
+  // weight, -0, an infinity or a NaN lies above the pattern of 1.f - such a voxel goes through the general version)
+  constexpr uint32_t LO = 0x3d4ccccdu, HI = 0x3f800000u;  // SDM_OCC_INIT_WEIGHT, 1.f
+  static_assert(SDM_OCC_INIT_WEIGHT == 0.05f, "LO is the bit pattern of the initial weight");
+  uint32_t lo = LO, hi = HI;
   bool guess = false;
   uint32_t tmin = 0xffffffffu, tmax = 0u;
 #pragma unroll
   for (int i = 1; i < S; ++i) {
     const bool live = st1[i] != ST_INVALID && (uint32_t)ts1[i] >= smax;
-    const float w = live ? wv[i] : 0.5f;
-    lo = fminf(lo, w);
-    hi = fmaxf(hi, w);
+    const uint32_t w = live ? __float_as_uint(wv[i]) : HI;
+    lo = min(lo, w);
+    hi = max(hi, w);
     guess = guess || st1[i] == ST_GUESSED_BORN;
-    const uint32_t t = trk[i];
-    tmin = min(tmin, live ? t : 0xffffffffu);
-    tmax = max(tmax, live ? t : 0u);
+    if constexpr (WANT_SINGLE) {
+      const uint32_t t = trk[i];
+      tmin = min(tmin, live ? t : 0xffffffffu);
+      tmax = max(tmax, live ? t : 0u);
+    }
   }
-  single = tmin >= tmax;  // one track id (or no live slot at all: 0xffffffff >= 0)
-  return !guess && lo >= SDM_OCC_INIT_WEIGHT && hi <= 1.f;  // (a NaN weight fails neither test: it takes no rule either)
+  single = WANT_SINGLE && tmin >= tmax;  // one track id (or no live slot at all: 0xffffffff >= 0)
+  return !guess && lo >= LO && hi <= HI;
 }
 
 // one voxel per lane; `mine` = this lane has a voxel to evaluate (its arrays are loaded)

@@ -17,9 +17,10 @@ from tests.dense_state import random_state, stamps_for
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("p_n,seed", [(3, 1), (3, 2), (2, 3), (4, 4), (1, 5)])
-def test_non_incremental_sweep_on_a_dense_random_state(p_n, seed):
-    cfg = dict(synth.CONFIGS["T0"], p_n=p_n)
+# (x_n >= 6: a chunk of 64 voxels lies in one x row of the ring - the dense kernel's "rows" path for the slab stamps)
+@pytest.mark.parametrize("p_n,seed,x_n", [(3, 1, 5), (3, 2, 5), (2, 3, 5), (4, 4, 5), (1, 5, 5), (3, 6, 6), (3, 7, 6), (3, 8, 7), (2, 9, 6)])
+def test_non_incremental_sweep_on_a_dense_random_state(p_n, seed, x_n):
+    cfg = dict(synth.CONFIGS["T0"], p_n=p_n, x_n=x_n)
     params = synth.PARAMS["vkitti2"]
     _, _, frames = synth.make_frames("T0", 2, "vkitti2", n_dynamic=0)
     o, g = pu.make_pair(cfg, params, synth.noise_table())
