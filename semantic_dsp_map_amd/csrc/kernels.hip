@@ -429,6 +429,68 @@ __device__ __forceinline__ void occupancy_evaluate(const State &st, float occ_th
   st.vflag[lv] = nflag;
 }
 
+// The PLAIN evaluation and the test whether it was allowed, in one pass (the dense sweep: the test alone repeats the
+// vacancy test of every slot, and a branch between the two loses the comparison masks).  Nothing is stored: returns true
+// if the voxel needs the general version (then `out` / `nflag` mean nothing), which the caller runs for the whole wave.
+template <int S>
+__device__ __forceinline__ bool occupancy_evaluate_plain_checked(float occ_threshold, uint32_t smax, const uint16_t (&ts1)[S],
+                                                                 const uint8_t (&st1)[S], const float (&wv)[S], const uint16_t (&trk16)[S],
+                                                                 const uint8_t (&lab8)[S], sdm_voxel_result &out, uint8_t &nflag) {
+  constexpr uint32_t LO = 0x3d4ccccdu, HI = 0x3f800000u;  // bit patterns of SDM_OCC_INIT_WEIGHT and 1.f (occupancy_is_plain)
+  uint32_t lo = LO, hi = HI;
+  bool guess = false, any = false, any_live = false;
+  float weight_sum = 0.f;
+  uint32_t trk[S], lab[S], tv[S];
+  float wvote[S];
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    trk[i] = trk16[i];
+    lab[i] = lab8[i];
+    const bool present = st1[i] != ST_INVALID;
+    const bool live = present && (uint32_t)ts1[i] >= smax;  // !isParticleVacant, operations.h:810-816
+    any = any || present;
+    any_live = any_live || live;
+    guess = guess || st1[i] == ST_GUESSED_BORN;
+    const uint32_t wb = live ? __float_as_uint(wv[i]) : HI;
+    lo = min(lo, wb);
+    hi = max(hi, wb);
+    wvote[i] = live ? wv[i] : 0.f;
+    weight_sum += wvote[i];  // (x + 0.f == x: the sum of the live weights in slot order)
+    tv[i] = live ? trk[i] : 0xffffffffu - (uint32_t)i;
+  }
+  // the vote: see the PLAIN branch of occupancy_evaluate_core
+  float eq[S][S];
+#pragma unroll
+  for (int i = 1; i < S; ++i)
+#pragma unroll
+    for (int j = i + 1; j < S; ++j) eq[i][j] = tv[i] == tv[j] ? 1.f : 0.f;
+  float tot[S];
+  float best_w = 0.f;
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 1; j < S; ++j) {
+      if (j == i) t += wvote[j];
+      else t = __builtin_fmaf(i < j ? eq[i][j] : eq[j][i], wvote[j], t);
+    }
+    tot[i] = t;
+    best_w = fmaxf(best_w, t);
+  }
+  const bool have = best_w > 0.f;
+  uint32_t best_t = 0xffffffffu, best_l = 0;
+#pragma unroll
+  for (int i = 1; i < S; ++i) best_t = min(best_t, tot[i] == best_w ? trk[i] : 0xffffffffu);
+#pragma unroll
+  for (int j = 1; j < S; ++j) best_l = tv[j] == best_t ? lab[j] : best_l;
+  out.wsum = any_live ? weight_sum : 0.f;
+  out.track = (uint16_t)(have ? best_t : 0u);
+  out.label = (uint8_t)best_l;  // (0 without a voter: no slot's id matches)
+  out.occ = any_live ? (weight_sum > occ_threshold ? 1 : 0) : (0.f > occ_threshold ? 1 : 0);
+  nflag = any_live ? (uint8_t)VF_CLEAN : (uint8_t)((any ? VF_CLEAN : VF_EMPTY) | VR_EMPTY);
+  return guess || lo < LO || hi > HI;
+}
+
 // Conservative test for the PLAIN version above: true only if no slot that could be live carries a weight above 1
 // (clamp) or below the initial weight (cull candidates), and no slot at all is a guessed birth.  Stale and empty
 // slots are ignored for the weights (their weight may be anything), which costs the vacancy test the evaluation
@@ -751,22 +813,29 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 
   // into L2 or registers meanwhile - was measured: what the loop keeps alive costs 30 registers, one resident workgroup
   // per CU less, 90 us against 75 us on the benchmark state.)
   const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+  // a wave's 512 voxels whose chunks were all dense in the last non-incremental sweep are left to the second launch
+  // whole: that one then classifies them itself (State::grp_hint - a hint about speed only; whatever the voxels hold by
+  // now, the result is the same).  A tile of four such groups: nothing to do here.
+  static_assert(OCC_WAVES == 4 && OCC_CPW * OCC_CHUNK == 512, "one hint byte per wave of this kernel and of k_occupancy_dense");
+  const uint32_t hint4 = reinterpret_cast<const uint32_t *>(st.grp_hint)[tile];
+  if (hint4 == 0x01010101u) return;
+  const bool hinted = (hint4 >> (8 * (tid >> 6))) & 1u;
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   if (tid == 0) n_live = 0;
   OccScanInputs in;
-  occ_scan_fetch(d, st, tile, n_tiles, tid, in);
+  if (!hinted) occ_scan_fetch(d, st, tile, n_tiles, tid, in);
   __syncthreads();
   {
     const uint32_t blk0 = tile * OCC_TILE;
     if (tid == 0) atomicAdd(&cnt->shard[tile & (VIS_SHARDS - 1)].sweep_tiles, 1u);
     const uint32_t lv0 = blk0 + tid * OCC_VPT;  // v_count is a multiple of 8: whole groups only
-    const bool in_range = lv0 < d.v_count;
+    const bool in_range = lv0 < d.v_count && !hinted;
     v2u outw[OCC_VPT];
     uint32_t want = 0, listed = 0;
+    uint8_t nflag[OCC_VPT] = {};
+    bool flags_changed = false;
     if (in_range) {
-      uint8_t nflag[OCC_VPT];
       const bool rows = d.x_n >= 3;
-      bool flags_changed = false;
 #pragma unroll
       for (int u = 0; u < OCC_VPT; ++u) {
         uint32_t smax;
@@ -790,7 +859,6 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 
           listed |= 1u << u;
         }
       }
-      if (flags_changed) store_vec(st.vflag + lv0, nflag);  // the evaluation rewrites the bytes of the listed voxels later
     }
     // which way do this thread's listed voxels go?  Its chunk = the aligned group of eight lanes it sits in.
     bool whole;  // every result of this thread's group is known in this launch: it leaves through the stage
@@ -811,6 +879,20 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 
       uint32_t nw = (uint32_t)__popc(listed);
       for (int off = 32; off > 0; off >>= 1) nw += __shfl_down(nw, off, 64);
       if (lane == 0 && nw) atomicAdd(&cnt->shard[(tile + wave) & (VIS_SHARDS - 1)].sweep, nw);
+      // The flag bytes leave here, eight per thread (the evaluation of a listed voxel rewrites its byte later).  Those of
+      // the voxels left to the second launch are set to what that launch nearly always decides - VF_CLEAN - so that it
+      // stores a flag byte only where it decides otherwise: one-byte stores of a whole map cost a tenth of the dense
+      // sweep's time on some boxes (tools/probes/ring_probe.hip), and a sweep that finds the bytes as it leaves them
+      // writes none.
+      if (dense && listed) {
+#pragma unroll
+        for (int u = 0; u < OCC_VPT; ++u)
+          if ((listed & (1u << u)) && nflag[u] != VF_CLEAN) {
+            nflag[u] = VF_CLEAN;
+            flags_changed = true;
+          }
+      }
+      if (flags_changed) store_vec(st.vflag + lv0, nflag);
     }
     if (whole) {  // constant results into the stage (the slots of listed voxels are filled in by the evaluation)
       const uint32_t sw = (tid >> 1) & 3u;
@@ -876,24 +958,61 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 
 #else
 #define DENSE_WAVES_ATTR
 #endif
+// (Instruction issue bounds this kernel - the SIMDs issue for 86 % of its time on a dense map, profiles/README.md round 5 -
+// so what is not the evaluation is kept off the vector unit: the wave index goes through readfirstlane, which makes a
+// chunk's base address a scalar and its loads `global_load ..., v_lane_offset, s[base]`; the record array is allocated one
+// chunk longer than the map, so no load clamps its address; the plain evaluation runs together with its own admission
+// test, occupancy_evaluate_plain_checked.)
+// (Instruction issue bounds this kernel - the SIMDs issue for 86 % of its time on a dense map, profiles/README.md round 5 -
+// so what is not the evaluation is kept off the vector unit: the wave index goes through readfirstlane, which makes a
+// chunk's base address a scalar and its loads `global_load ..., v_lane_offset, s[base]`; the record array is allocated one
+// chunk longer than the map, so no load clamps its address; the plain evaluation runs together with its own admission
+// test, occupancy_evaluate_plain_checked.)
+#ifndef SDM_DENSE_CPW
+#define SDM_DENSE_CPW 8
+#endif
+constexpr int OCC_DCPW = SDM_DENSE_CPW;  // chunks per wave of k_occupancy_dense (its own partition of the map: the masks are per chunk)
+static_assert(OCC_DCPW <= 32, "one bit per chunk of the wave in a 32-bit word");
+// A wave whose group of 512 voxels has State::grp_hint set (every chunk of it was dense in the last non-incremental
+// sweep) finds nothing from k_occupancy_scan: it classifies its voxels itself - stamp and flag byte of the lane's voxel requested with the
+// chunk's records, occupancy_classify in the step - takes every chunk as dense and writes all 64 results of a chunk, the
+// constant ones included.  That is right whatever the group holds (only slow if it has emptied since: every record is
+// fetched), and the hint is set anew from what this sweep finds.  On a dense map the first launch is then 8192 workgroups
+// that leave after four bytes instead of 24 us of classification in front of a dependent launch.
 template <int S>
-__global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d, float occ_threshold, State st,
+__global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d, float occ_threshold, State st, Counters *cnt,
                                                          const unsigned long long *__restrict__ need, uint32_t remark) {
   constexpr int REC = 10 * S;                    // bytes of one record
   constexpr int PIECES = OCC_CHUNK * REC / 16;   // 16-byte pieces of one chunk of records
   constexpr int PPL = (PIECES + 63) / 64;
-  __shared__ v4u rec_stage[OCC_WAVES][PIECES];  // one chunk of records per wave, for the lane <-> record transposition
-  __shared__ uint32_t smax_stage[OCC_WAVES][OCC_CHUNK];  // ... and the slab stamps of its voxels
+  __shared__ v4u rec_stage[OCC_WAVES][PPL * 64];  // one chunk of records per wave, for the lane <-> record transposition
   __shared__ uint32_t yz_stage[OCC_WAVES][OCC_CPW];      // max(y stamp, z stamp) of each chunk of the wave
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t lvw = blockIdx.x * OCC_TILE + wave * OCC_CPW * OCC_CHUNK;  // first voxel of this wave
-  // the masks of the wave's chunks: lane k holds chunk k's
+  __shared__ v4u meta_t[OCC_WAVES][64];                  // fused: observation stamps of the wave's 512 voxels ...
+  __shared__ v2u meta_f[OCC_WAVES][64];                  // ... and their flag bytes (two wide loads per wave, not two narrow ones per chunk)
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t cw = (blockIdx.x * OCC_WAVES + wave) * OCC_CPW;  // first chunk of this wave (a workgroup = a tile)
+  const uint32_t lvw = cw * OCC_CHUNK;                            // ... and its first voxel
+  const uint32_t hint4 = reinterpret_cast<const uint32_t *>(st.grp_hint)[blockIdx.x];  // the tile's four groups, as k_occupancy_scan saw them
+  const bool fused = (hint4 >> (8 * wave)) & 1u;                                         // wave-uniform
+  // the masks of the wave's chunks: lane k holds chunk k's (fused: every chunk of the map counts as dense)
   unsigned long long mk = 0;
-  if (lane < (uint32_t)OCC_CPW && lvw + lane * OCC_CHUNK < d.v_count)
-    mk = need[(size_t)blockIdx.x * OCC_CHUNKS + wave * OCC_CPW + lane];
+  if (lane < (uint32_t)OCC_CPW && lvw + lane * OCC_CHUNK < d.v_count) mk = fused ? ~0ull : need[cw + lane];
   const uint32_t densebits = (uint32_t)(__ballot(mk != 0ull) & ((1ull << OCC_CPW) - 1ull));
-  if (!densebits) return;  // nothing of this wave's was left to this kernel
-  uint32_t evalbits = 0;   // bit k: this lane's voxel of chunk k is to be evaluated
+  uint32_t hint_ok = 1;  // every chunk of this wave that lies in the map is dense
+  {
+    const uint32_t in_map = lvw >= d.v_count ? 0u : (d.v_count - lvw + OCC_CHUNK - 1) / OCC_CHUNK;
+    const uint32_t mapbits = in_map >= (uint32_t)OCC_CPW ? (1u << OCC_CPW) - 1u : (1u << in_map) - 1u;
+    if (!fused && densebits != mapbits) hint_ok = 0;
+  }
+  uint32_t n_eval = 0;
+  if (!densebits) return;  // nothing of this wave's was left to this kernel (its hint is and stays 0)
+  {
+  if (fused) {  // (lanes beyond the end of the map read the arrays' padding)
+    meta_t[wave][lane] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(st.vts + lvw) + lane);
+    meta_f[wave][lane] = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(st.vflag + lvw) + lane);
+  }
+  uint32_t evalbits = 0;   // bit k: this lane's voxel of chunk k is to be evaluated (fused: decided in the step)
 #pragma unroll
   for (int k = 0; k < OCC_CPW; ++k) {
     const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mk >> 32), k) << 32) |
@@ -903,10 +1022,9 @@ __global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d
   // Slab stamps.  The stamp of this lane's voxel of a chunk travels with the chunk's records (loaded where the
   // evaluation needs it, it was a dependent L2 round trip in every step) - and nothing may be computed from it where it is
   // requested: a max over the three axis stamps right behind their loads made the compiler wait for ALL outstanding
-  // loads in every fetch (s_waitcnt vmcnt(0): the stamps' own round trip exposed once per chunk, and the chunk
-  // requested one step earlier waited for as well).  With x_n >= 6 a chunk lies in one x row of the ring: its y and z
-  // stamps are one value per chunk, fetched once per wave up front (yz_stage), and a fetch requests the x
-  // stamps only and leaves them raw; the max is taken in the step.  Smaller maps: the per-lane max, as before.
+  // loads in every fetch.  With x_n >= 6 a chunk lies in one x row of the ring: its y and z stamps are one value per
+  // chunk, fetched once per wave up front (yz_stage), and a fetch requests the x stamps only and leaves them raw; the max
+  // is taken in the step.  Smaller maps: the per-lane max, as before.
   const bool rows = d.x_n >= 6;
   if (lane < (uint32_t)OCC_CPW) {
     uint32_t yzv = 0;  // (0 where the staged value is the max already)
@@ -918,89 +1036,64 @@ __global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d
     }
     yz_stage[wave][lane] = yzv;
   }
-  // lane-linear loads of chunk k's records: 1 KB contiguous per instruction.  Every load is unconditional (a lane
-  // beyond the end of the map repeats the last piece / voxel): a load under a branch of its own is a basic block of its
-  // own, and the compiler then cannot count the loads in flight - it waited for each of the first chunk's five loads
-  // before it requested the next one.
-  auto fetch = [&](int k, v4u (&buf)[PPL], uint32_t &smax) {
-    const uint32_t lvc = lvw + k * OCC_CHUNK;
-    const uint32_t nvox = d.v_count - lvc < (uint32_t)OCC_CHUNK ? d.v_count - lvc : (uint32_t)OCC_CHUNK;  // a multiple of 8, >= 8
-    {
+  // lane-linear loads of chunk k's records: 1 KB contiguous per instruction, all of them unconditional and in one basic
+  // block (a load under a branch of its own is a basic block of its own, and the compiler then cannot count the loads
+  // in flight).  Lanes beyond the end of the map read the arrays' padding.
+  struct Landing {
+    v4u buf[PPL];
+    uint32_t smax;   // x stamp (rows) or slab stamp of the lane's voxel
+  };
+  auto fetch = [&](int k, Landing &l) {
+    const uint32_t lvc = lvw + k * OCC_CHUNK;  // scalar
+    if (rows) {
+      l.smax = st.stamps_x[((d.v_begin + lvc) & (d.NX - 1)) + lane];
+    } else {
       uint32_t rx, ry, rz;
-      voxel_to_ring(d, d.v_begin + lvc + (lane < nvox ? lane : nvox - 1u), rx, ry, rz);
-      if (rows) smax = st.stamps_x[rx];
-      else smax = stamp_max(st, rx, ry, rz);
+      voxel_to_ring(d, d.v_begin + lvc + lane, rx, ry, rz);
+      l.smax = stamp_max(st, rx, ry, rz);
     }
-    const uint32_t npieces = nvox * REC / 16;
     const v4u *src = reinterpret_cast<const v4u *>(st.rec + (size_t)lvc * REC);
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const uint32_t idx = j * 64 + lane;
-      buf[j] = __builtin_nontemporal_load(src + (idx < npieces ? idx : npieces - 1u));
+      l.buf[j] = __builtin_nontemporal_load(src + (PIECES % 64 == 0 ? idx : (idx < (uint32_t)PIECES ? idx : (uint32_t)PIECES - 1u)));
     }
   };
-  auto to_stage = [&](const v4u (&buf)[PPL], uint32_t smax) {
-    smax_stage[wave][lane] = smax;
+  auto to_stage = [&](const Landing &l) {
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) {
-      const uint32_t idx = j * 64 + lane;
-      if (idx < (uint32_t)PIECES) rec_stage[wave][idx] = buf[j];  // pieces beyond v_count hold nothing anybody reads
-    }
+    for (int j = 0; j < PPL; ++j) rec_stage[wave][j * 64 + lane] = l.buf[j];
   };
   auto next_dense = [&](int k) -> int {  // first dense chunk after k
     const uint32_t rest = densebits & ~((2u << k) - 1u);
     return rest ? __builtin_ctz(rest) : OCC_CPW;
   };
-#ifndef SDM_DENSE_BUFS
-#define SDM_DENSE_BUFS 1
-#endif
-#if SDM_DENSE_BUFS == 2
-  // three chunks of the wave are under way at any time: one in the stage, two in registers
-  int k = __builtin_ctz(densebits);
-  int k1 = next_dense(k);
-  int k2 = k1 < OCC_CPW ? next_dense(k1) : OCC_CPW;
-  v4u b0[PPL] = {}, b1[PPL] = {};
-  uint32_t s0 = 0, s1 = 0;  // slab stamps of the chunks in b0, b1
-  {
-    v4u first[PPL];
-    uint32_t sf = 0;
-    fetch(k, first, sf);
-    if (k1 < OCC_CPW) fetch(k1, b0, s0);
-    if (k2 < OCC_CPW) fetch(k2, b1, s1);
-    to_stage(first, sf);
-  }
-#else
   // two chunks of the wave are under way at any time: one in the stage, one in registers (landing while the one in the
-  // stage is evaluated).  A second register buffer was there until round 4 and bought nothing: the fetches and the
-  // stores of the evaluation sit in branches, so the compiler cannot count what was issued after a buffer's loads and
-  // waits for everything outstanding (s_waitcnt vmcnt(0)) before it moves a buffer into the stage - the younger
-  // buffer's loads included.
+  // stage is evaluated).  A second register buffer was there until round 4 and bought nothing: a step takes the wave
+  // several microseconds (its SIMD is shared by four), the next chunk has landed long before.
   int k = __builtin_ctz(densebits);
   int k1 = next_dense(k);
-  constexpr int k2 = OCC_CPW;
-  v4u b0[PPL] = {};
-  uint32_t s0 = 0;  // slab stamps of the chunk in b0
+  Landing b0 = {};
+  uint32_t s_cur = 0;  // stamps of the chunk in the stage
   {
-    v4u first[PPL];
-    uint32_t sf = 0;
-    fetch(k, first, sf);
-    if (k1 < OCC_CPW) fetch(k1, b0, s0);
-    to_stage(first, sf);
+    Landing first;
+    fetch(k, first);
+    if (k1 < OCC_CPW) fetch(k1, b0);
+    to_stage(first);
+    s_cur = first.smax;
   }
-#endif
-  // one step: evaluate chunk k out of the stage, move `up` (the next dense chunk, landed or landing) into the stage,
-  // start the loads of the one after it into `up`
-  auto step = [&](v4u (&up)[PPL], uint32_t &s_up) {
-    const bool mine = (evalbits >> k) & 1u;
+  // one step: evaluate chunk k out of the stage, move the next dense chunk (landed or landing) into the stage,
+  // start the loads of the one after it
+#pragma unroll 1
+  for (int it = 0; it < OCC_CPW; ++it) {  // (a fixed trip count: with `while (k < OCC_CPW)` the compiler rotated the loop and left a wait for all loads on the back edge)
+    if (k >= OCC_CPW) break;
     const uint32_t lv = lvw + k * OCC_CHUNK + lane;
     uint16_t ts1[S], trk[S];
     uint8_t st1[S], lab[S];
     float wv[S];
-    uint32_t smk = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (mine) {
+    {
       const unsigned char *r = reinterpret_cast<const unsigned char *>(rec_stage[wave]) + lane * REC;
       constexpr int RA = rec_align(S);
       __builtin_memcpy(wv, __builtin_assume_aligned(r, RA), 4 * S);
@@ -1008,43 +1101,71 @@ __global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d
       __builtin_memcpy(trk, __builtin_assume_aligned(r + 6 * S, RA < 2 * S ? RA : 2 * S), 2 * S);
       __builtin_memcpy(lab, __builtin_assume_aligned(r + 8 * S, RA < S ? RA : S), S);
       __builtin_memcpy(st1, __builtin_assume_aligned(r + 9 * S, RA < S ? RA : S), S);
-      smk = smax_stage[wave][lane];
     }
+    uint32_t smk = s_cur;
     {
       const uint32_t yz = yz_stage[wave][k];
       smk = smk > yz ? smk : yz;
     }
-    // the evaluation runs on registers only; the chunk behind this one is landing meanwhile
+    bool mine = (evalbits >> k) & 1u, store_res = mine;
     sdm_voxel_result out;
-    occupancy_evaluate_wave<S>(st, occ_threshold, remark, mine, lv, smk, ts1, st1, wv, trk, lab, out);
-    if (mine) store_result(st.res + lv, out);
+    out.wsum = 0.f;
+    out.track = 0;
+    out.label = 0;
+    out.occ = 0;
+    uint8_t nf = VF_CLEAN;
+    uint32_t oldflag = VF_CLEAN;  // (not fused: k_occupancy_scan has left VF_CLEAN in the bytes of the voxels it handed over)
+    if (fused) {  // wave-uniform
+      oldflag = reinterpret_cast<const uint8_t *>(meta_f[wave])[k * OCC_CHUNK + lane];
+      const uint32_t t0 = reinterpret_cast<const uint16_t *>(meta_t[wave])[k * OCC_CHUNK + lane];
+      const bool valid = lv < d.v_count;
+      const int cls = occupancy_classify(t0, oldflag, smk, occ_threshold, 1, out, nf);  // non-incremental: 1 or 2
+      if (cls == 2) nf = (uint8_t)oldflag;
+      mine = valid && cls == 2;
+      store_res = valid;
+      const uint32_t n = (uint32_t)__popcll(__ballot(mine));
+      n_eval += n;
+      if (n < OCC_DENSE_MIN) hint_ok = 0;
+    }
+    // the evaluation runs on registers only; the chunk behind this one is landing meanwhile
+    {
+      sdm_voxel_result oe;
+      uint8_t ne;
+      const bool special = occupancy_evaluate_plain_checked<S>(occ_threshold, smk, ts1, st1, wv, trk, lab, oe, ne) && mine;
+      if (__ballot(special) != 0ull) {  // wave-uniform and rare: clamp, cull, guessed births
+        if (mine) occupancy_evaluate_core<S, false>(st, occ_threshold, remark, lv, smk, ts1, st1, wv, trk, lab, oe, ne);
+      }
+      if (mine) {
+        out = oe;
+        nf = ne;
+      }
+    }
+    if (store_res) {
+      store_result(st.res + lv, out);
+      if (nf != oldflag) st.vflag[lv] = nf;
+    }
     // the next chunk moves into the stage (its loads have had this evaluation's time) and the loads of the one after it start
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     k = k1;
-#if SDM_DENSE_BUFS == 2
-    k1 = k2;
-    k2 = k2 < OCC_CPW ? next_dense(k2) : OCC_CPW;
-    if (k < OCC_CPW) to_stage(up, s_up);
-    if (k2 < OCC_CPW) fetch(k2, up, s_up);
-#else
     k1 = k1 < OCC_CPW ? next_dense(k1) : OCC_CPW;
-    if (k < OCC_CPW) to_stage(up, s_up);
-    if (k1 < OCC_CPW) fetch(k1, up, s_up);
-#endif
-  };
-  // (a fixed trip count: with `while (k < OCC_CPW)` and a break in the middle the compiler rotated the loop and left a
-  // wait for all loads right behind the fetch on the back edge)
-#pragma unroll 1
-#if SDM_DENSE_BUFS == 2
-  for (int it = 0; it < OCC_CPW / 2; ++it) {
-    if (k < OCC_CPW) step(b0, s0);
-    if (k < OCC_CPW) step(b1, s1);
+    if (k < OCC_CPW) {
+      to_stage(b0);
+      s_cur = b0.smax;
+    }
+    if (k1 < OCC_CPW) fetch(k1, b0);
   }
-#else
-  for (int it = 0; it < OCC_CPW; ++it)
-    if (k < OCC_CPW) step(b0, s0);
-#endif
+  }
+  // the group's hint for the next non-incremental sweep, and (fused) the counters k_occupancy_scan keeps for what it takes
+  if (lane == 0) {
+    const bool whole = lvw + OCC_CPW * OCC_CHUNK <= d.v_count;  // (whole groups only)
+    const uint8_t h = hint_ok && whole ? 1 : 0;
+    if ((uint8_t)(fused ? 1 : 0) != h) st.grp_hint[blockIdx.x * OCC_WAVES + wave] = h;
+    if (fused) {
+      if (n_eval) atomicAdd(&cnt->shard[(blockIdx.x + wave) & (VIS_SHARDS - 1)].sweep, n_eval);
+      if (wave == 0 && hint4 == 0x01010101u) atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep_tiles, 1u);  // (the scan counts the tiles it enters)
+    }
+  }
 }
 
 // slot 0 of the exported stamp array carries the voxel stamp (sdm_dump_state / sdm_load_state keep the reference's
@@ -3307,6 +3428,7 @@ void launch_clear(const Dims &d, const State &st, uint32_t *mv_head, hipStream_t
     else
       hipLaunchKernelGGL(k_clear_slots, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, mv_head, n);
   }
+  hipMemsetAsync(st.grp_hint, 0, grp_hint_bytes(d.v_count), s);  // nothing is dense any more
   hipMemsetAsync(st.alias, 0, 8, s);  // no older memberships
   hipMemsetAsync(st.owner_flag, 0, owner_flag_bytes(n), s);
   hipMemsetAsync(st.owner_flag2, 0, owner_flag2_bytes(n), s);
@@ -3330,8 +3452,11 @@ void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counter
                       hipStream_t s) {
   dim3 grid(blocks_for(d.v_count, OCC_TILE));
   if (all_dirty) {
+    // (Measured and not kept, round 5: the map cut into 2 / 4 / 8 slices of tiles, the scans of slices 1.. on a second
+    // stream next to the dense launches of the slices before them - every cross-stream event costs more than the slice
+    // of classification it hides: 0.285 -> 0.297 / 0.318 / 0.354 ms on the dense case.)
     SDM_DISPATCH_S(k_occupancy_scan, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, grid.x, remark);
-    SDM_DISPATCH_S(k_occupancy_dense, grid, s, d, flt.occ_threshold, st, st.occ_need, remark);
+    SDM_DISPATCH_S(k_occupancy_dense, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, remark);
   } else {
     const uint32_t n_tiles = grid.x;
     // marks per thread of the tile scan, in whole 16-byte loads; 0: too many tiles for one workgroup to scan

@@ -758,17 +758,21 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
 #define A(ptr, n) \
   if ((rc = alloc_tracked(m, &(ptr), (n))) != SDM_OK) return rc;
   A(m->st.pos4, n_slots);
-  A(m->st.rec, n_slots * REC_BYTES_PER_SLOT);  // one record per voxel: w | ts | track | label (sdm_internal.h)
+  // one record per voxel: w | ts | track | label (sdm_internal.h); one chunk of 64 records of padding behind the last, so
+  // that the sweep's chunk-wide loads need no clamp at the end of the map (k_occupancy_dense)
+  A(m->st.rec, (n_slots + (size_t)64 * d.S) * REC_BYTES_PER_SLOT);
   m->st.w = reinterpret_cast<float *>(m->st.rec);
   m->st.ts = reinterpret_cast<uint16_t *>(m->st.rec + 4 * (size_t)d.S);
   m->st.track = reinterpret_cast<uint16_t *>(m->st.rec + 6 * (size_t)d.S);
   m->st.label = reinterpret_cast<uint8_t *>(m->st.rec + 8 * (size_t)d.S);
   m->st.status = m->st.rec + 9 * (size_t)d.S;
-  A(m->st.vts, d.v_count);
-  A(m->st.vflag, d.v_count);
+  A(m->st.vts, (size_t)d.v_count + 64);    // (+ one chunk: the sweep's chunk-wide loads need no clamp at the end of the map)
+  A(m->st.vflag, (size_t)d.v_count + 64);
   m->st.tile_stride = (uint32_t)tile_mark_bytes(d);
   A(m->st.tile_dirty, 2 * (size_t)m->st.tile_stride);
   A(m->st.occ_need, ((size_t)d.v_count + 63) / 64 + 32);
+  A(m->st.grp_hint, grp_hint_bytes(d.v_count));
+  HIP_TRY(hipMemsetAsync(m->st.grp_hint, 0, grp_hint_bytes(d.v_count), m->stream));
   A(m->st.owner, n_slots);
   A(m->st.owner_flag, owner_flag_bytes(n_slots));
   A(m->st.owner_flag2, owner_flag2_bytes(n_slots));
@@ -2482,6 +2486,8 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t s = m->stream;
   const size_t n = (size_t)m->d.v_count * m->d.S;
+  // (which tiles are dense is not known of a state that comes from outside: the first sweep classifies everything)
+  HIP_TRY(hipMemsetAsync(m->st.grp_hint, 0, grp_hint_bytes(m->d.v_count), s));
   float *tx, *ty, *tz;
   uint8_t *tf;
   HIP_TRY(dev_alloc(&tx, n));

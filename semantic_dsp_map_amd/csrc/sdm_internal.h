@@ -177,6 +177,11 @@ struct State {
   uint32_t tile_stride = 0;       // bytes of one of the two
   // per chunk of 64 voxels: the voxels the non-incremental sweep's first launch left to its second (dense chunks)
   unsigned long long *occ_need = nullptr;
+  // per group of 512 voxels (what one wave of the non-incremental sweep's kernels takes): 1 = every chunk of the group
+  // was dense in the last non-incremental sweep; the next one leaves the group to the second launch whole
+  // (k_occupancy_scan skips it, k_occupancy_dense classifies it itself).  A hint about speed only: both launches read
+  // the same bytes, and either way every voxel gets the same result.
+  uint8_t *grp_hint = nullptr;
   uint16_t *track = nullptr;
   uint8_t *label = nullptr;
   uint8_t *status = nullptr;
@@ -204,6 +209,8 @@ struct State {
 // one byte per tile of 2^TILE_SHIFT voxels (State::tile_dirty): set by whoever sets VF_DIRTY on a voxel of the tile or
 // changes its observation stamp; the sweep returns at once from a tile whose byte is 0 and clears the byte otherwise
 constexpr int TILE_SHIFT = 11;
+// bytes of State::grp_hint for v_count voxels: whole tiles (4 groups), so that a workgroup reads its four bytes as one word
+__host__ __device__ constexpr size_t grp_hint_bytes(size_t v_count) { return ((v_count + (1u << 11) - 1) >> 11) * 4; }
 enum : uint8_t { VF_EMPTY = 0, VF_CLEAN = 1, VF_DIRTY = 2, VF_STATE = 3, VR_UNOBSERVED = 1 << 2, VR_EMPTY = 2 << 2, VR_MASK = 3 << 2 };
 // State::tile_dirty holds, per tile, the sweep epoch in which something in the tile was last written or stamped: the
 // frame's kernels mark with the epoch of the frame's sweep (Frame::epoch), the sweep looks for exactly that number and

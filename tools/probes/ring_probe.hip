@@ -53,39 +53,68 @@ __device__ __forceinline__ uint32_t chew(const v4u (&r)[PPL]) {
   return a + b;
 }
 
-template <int F>
+// MODE bits: 1 = result stores, 2 = flag byte stores, 4 = flag stores merged (one lane stores 8 flag bytes of 8 voxels:
+// a stand-in for "whole lines"), 8 = plain instead of non-temporal result stores, 16 = no LDS pass
+// CPW chunks per wave; PERSIST: the grid is what is resident, a wave strides over its groups of CPW chunks
+template <int F, int MODE, int CPW, bool PERSIST>
 __global__ __launch_bounds__(256) void k_regs(const unsigned char *__restrict__ rec, unsigned long long *__restrict__ res,
                                               uint8_t *__restrict__ flag, uint32_t n_chunks) {
   __shared__ v4u stage[4][PIECES];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t c0 = (blockIdx.x * 4 + wave) * 8;
-  auto fetch = [&](uint32_t c, v4u (&buf)[PPL]) {
-    const v4u *src = reinterpret_cast<const v4u *>(rec + (size_t)c * CHUNK * REC);
+  const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t n_groups = n_chunks / CPW;
+  for (uint32_t g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
+    const uint32_t c0 = g * CPW;
+    auto fetch = [&](uint32_t c, v4u (&buf)[PPL]) {
+      const v4u *src = reinterpret_cast<const v4u *>(rec + (size_t)c * CHUNK * REC);
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) buf[j] = __builtin_nontemporal_load(src + j * 64 + lane);
-  };
-  v4u b0[PPL], b1[PPL];
-  fetch(c0, b0);
+      for (int j = 0; j < PPL; ++j) buf[j] = __builtin_nontemporal_load(src + j * 64 + lane);
+    };
+    v4u b0[PPL], b1[PPL];
+    fetch(c0, b0);
 #pragma unroll 1
-  for (uint32_t k = 0; k < 8; ++k) {
-    if (k + 1 < 8) fetch(c0 + k + 1, b1);
+    for (uint32_t k = 0; k < CPW; ++k) {
+      if (k + 1 < CPW) fetch(c0 + k + 1, b1);
+      v4u r[PPL];
+      if (MODE & 16) {
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) stage[wave][j * 64 + lane] = b0[j];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    v4u r[PPL];
-    const v4u *mine = reinterpret_cast<const v4u *>(reinterpret_cast<const unsigned char *>(stage[wave]) + lane * REC);
+        for (int j = 0; j < PPL; ++j) r[j] = b0[j];
+      } else {
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) r[j] = mine[j];
-    const uint32_t h = chew<F>(r);
-    const size_t lv = (size_t)(c0 + k) * CHUNK + lane;
-    res[lv] = ((unsigned long long)h << 32) | lane;
-    flag[lv] = (uint8_t)h;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < PPL; ++j) stage[wave][j * 64 + lane] = b0[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const v4u *mine = reinterpret_cast<const v4u *>(reinterpret_cast<const unsigned char *>(stage[wave]) + lane * REC);
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) b0[j] = b1[j];
+        for (int j = 0; j < PPL; ++j) r[j] = mine[j];
+      }
+      const uint32_t h = chew<F>(r);
+      const size_t lv = (size_t)(c0 + k) * CHUNK + lane;
+      if (MODE & 32) {  // results of two chunks leave together: 16 bytes per lane, 1 KB contiguous per instruction
+        if (k & 1) __builtin_nontemporal_store(v4u{h, lane, h + 1, lane}, reinterpret_cast<v4u *>(res + (size_t)(c0 + k - 1) * CHUNK) + lane);
+      } else if (MODE & 64) {  // ... of four chunks: two such stores back to back
+        if ((k & 3) == 3) {
+          __builtin_nontemporal_store(v4u{h, lane, h + 1, lane}, reinterpret_cast<v4u *>(res + (size_t)(c0 + k - 3) * CHUNK) + lane);
+          __builtin_nontemporal_store(v4u{h, lane, h + 2, lane}, reinterpret_cast<v4u *>(res + (size_t)(c0 + k - 1) * CHUNK) + lane);
+        }
+      } else if (MODE & 1) {
+        if (MODE & 8) res[lv] = ((unsigned long long)h << 32) | lane;
+        else __builtin_nontemporal_store(((unsigned long long)h << 32) | lane, res + lv);
+      }
+      if (MODE & 2) {
+        if (MODE & 4) {
+          if (lane < 8) reinterpret_cast<unsigned long long *>(flag + (size_t)(c0 + k) * CHUNK)[lane] = h * 0x0101010101010101ull;
+        } else {
+          flag[lv] = (uint8_t)h;
+        }
+      }
+      if (!(MODE & 3) && h == 0x12345u) res[0] = h;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) b0[j] = b1[j];
+    }
+    if (!PERSIST) break;
   }
 }
 
@@ -189,34 +218,37 @@ int main() {
     printf("copy %.1f MB read + as much written: %7.2f us  %5.2f TB/s\n", half / 1e6, us, 2.0 * half / us / 1e6);
     hipFree(dst);
   }
-  {
-    const double us = timeit([&] { hipLaunchKernelGGL((k_regs<16>), dim3(NC / 32), dim3(256), 0, 0, rec, res, flag, NC); });
-    printf("regs F=16 (8192 workgroups)             : %7.2f us  %5.2f TB/s\n", us, BYTES / us / 1e6);
-    const double us2 = timeit([&] { hipLaunchKernelGGL((k_regs<400>), dim3(NC / 32), dim3(256), 0, 0, rec, res, flag, NC); });
-    printf("regs F=400                              : %7.2f us  %5.2f TB/s\n", us2, BYTES / us2 / 1e6);
+#define RUN_REGS(F, MODE, CPW, PERSIST, GRID)                                                                                  \
+  {                                                                                                                             \
+    const double us = timeit([&] { hipLaunchKernelGGL((k_regs<F, MODE, CPW, PERSIST>), dim3(GRID), dim3(256), 0, 0, rec, res, flag, NC); }); \
+    const double by = (double)V * (80.0 + ((MODE) & 1 ? 8 : 0) + ((MODE) & 2 ? 1 : 0));                                          \
+    printf("regs F=%3d mode %2d cpw %2d persist %d grid %5u : %7.2f us  %5.2f TB/s\n", F, MODE, CPW, (int)PERSIST, (unsigned)(GRID), us, by / us / 1e6); \
+    fflush(stdout);                                                                                                             \
   }
-  // skeleton alone: ring depth, occupancy, policy, distribution
-  run_ring<2, 4, 16, true, true, true>(3);
-  run_ring<3, 4, 16, true, true, true>(2);
+  RUN_REGS(16, 3, 8, false, NC / 32)
+  RUN_REGS(16, 0, 8, false, NC / 32)
+  RUN_REGS(16, 1, 8, false, NC / 32)
+  RUN_REGS(16, 2, 8, false, NC / 32)
+  RUN_REGS(16, 7, 8, false, NC / 32)
+  RUN_REGS(16, 11, 8, false, NC / 32)
+  RUN_REGS(16, 16, 8, false, NC / 32)
+  RUN_REGS(16, 19, 8, false, NC / 32)
+  RUN_REGS(16, 33, 8, false, NC / 32)
+  RUN_REGS(16, 35, 8, false, NC / 32)
+  RUN_REGS(16, 65, 8, false, NC / 32)
+  RUN_REGS(16, 67, 8, false, NC / 32)
+  RUN_REGS(16, 39, 8, false, NC / 32)
+  RUN_REGS(200, 33, 8, false, NC / 32)
+  RUN_REGS(200, 39, 8, false, NC / 32)
+  RUN_REGS(16, 3, 16, false, NC / 64)
+  RUN_REGS(16, 3, 8, true, 1024)
+  RUN_REGS(16, 3, 8, true, 1280)
+  RUN_REGS(16, 3, 8, true, 2048)
+  RUN_REGS(16, 3, 32, true, 1024)
+  RUN_REGS(200, 3, 8, false, NC / 32)
+  RUN_REGS(200, 3, 8, true, 1024)
+  RUN_REGS(200, 3, 8, true, 1280)
   run_ring<3, 2, 16, true, true, true>(4);
-  run_ring<3, 2, 16, true, true, true>(5);
-  run_ring<4, 2, 16, true, true, true>(3);
-  run_ring<4, 2, 16, true, true, true>(4);
-  run_ring<2, 2, 16, true, true, true>(6);
   run_ring<2, 2, 16, true, true, true>(8);
-  run_ring<3, 1, 16, true, true, true>(8);
-  run_ring<3, 1, 16, true, true, true>(10);
-  run_ring<3, 2, 16, false, true, true>(4);
-  run_ring<3, 2, 16, true, false, true>(4);
-  run_ring<3, 2, 16, true, true, false>(4);
-  // with the evaluation's instruction count as filler
-  run_ring<3, 2, 200, true, true, true>(4);
-  run_ring<3, 2, 400, true, true, true>(4);
-  run_ring<3, 2, 600, true, true, true>(4);
-  run_ring<3, 2, 400, true, true, true>(5);
-  run_ring<2, 2, 400, true, true, true>(8);
-  run_ring<3, 4, 400, true, true, true>(2);
-  run_ring<4, 2, 400, true, true, true>(3);
-  run_ring<3, 1, 400, true, true, true>(10);
   return 0;
 }
