@@ -153,14 +153,17 @@ def stress_run(synth, sharded, steps=8, warmup=14, cpu_frames=4):
     return res
 
 
-def grown_run(synth, sharded, n_grow=180, steps=20, cpu_frames=3):
-    """A map whose population the filter grew itself: start EMPTY, run n_grow frames of a cluttered street with ego
-    motion (forward 0.3 m / frame, yaw 1 deg / frame, sideways drift: slabs recycled on two axes), three noisy births per
-    point, then time `steps` frames issued back to back like the headline run; per-stage GPU times of four more frames on
-    a copy of the state, and the oracle (literal order, one thread) on that very state and frames."""
+def driven_run(synth, sharded, steps=20, cpu_frames=3):
+    """The workload nothing is prefilled for: start with an EMPTY C3 map, drive synth.DRIVEN_FRAMES frames down the
+    cluttered street of synth.DRIVEN_SCENE (0.3 m per frame: 66 m, more than the map is long; ring shifts on two axes; 12
+    moving boxes; three noisy births per point), then time `steps` more frames issued back to back like the headline
+    run; per-stage GPU times of four more frames, and the oracle (literal order, one thread) on the state the timed
+    region started from and its frames.  Every live particle is one the filter put there, every count is what comes out.
+    tests/test_driven_gpu.py runs the oracle BESIDE the GPU over the same drive from frame 0."""
     cfg = synth.CONFIGS["C3"]
-    params = synth.PARAMS["vkitti2_nb3"]
-    scene_kw = dict(n_static=100, n_dynamic=8, seed=13, yaw_rate_deg=1.0, lateral_extra=(0, 0.03))
+    params = synth.PARAMS[synth.DRIVEN_PARAMS]
+    scene_kw = dict(synth.DRIVEN_SCENE)
+    n_grow = synth.DRIVEN_FRAMES
     scene = synth.Scene(cfg, **scene_kw)
     n_prof = 4
     t0 = time.time()
@@ -223,8 +226,11 @@ def grown_run(synth, sharded, n_grow=180, steps=20, cpu_frames=3):
            "stage_ms": {k: round(acc[i] / n_prof, 4) for i, k in enumerate(names) if k},
            "sweep": {"tiles_looked_into": int(np.mean(tiles_l)), "voxels_evaluated_in_full": int(np.mean(live_l))},
            "render_s": round(t_render, 1), "grow_s": round(t_grow, 1),
-           "workload": "grown: C3 grid, empty map, %d frames of 100 static + 8 moving boxes, 3 noisy births per point, forward 0.3 m + yaw "
-                       "1 deg + 0.03 m sideways per frame; then %d timed frames" % (n_grow, steps)}
+           "workload": "driven: C3 grid, EMPTY map, %d frames (%.0f m) down a street of %d static + %d moving boxes, 3 noisy births per point, "
+                       "forward %.1f m + yaw %.1f deg per frame, ring shifts on z and x; then %d timed frames.  No prefill: %d live particles in %d "
+                       "voxels and %d visible per frame are what the filter and the camera yield"
+                       % (n_grow, n_grow * scene.speed, scene_kw["n_static"], scene_kw["n_dynamic"], scene.speed, scene_kw["yaw_rate_deg"], steps,
+                          stats["live_particles"], stats["live_voxels"], int(np.mean(vis_l)))}
     if cpu_frames > 0:
         from oracle import oracle as orc
         o = orc.OracleMap(dict(cfg, bin_order=0), params, noise)
@@ -298,6 +304,42 @@ def pin_to_device_node(device):
         return "not pinned (%s)" % type(e).__name__
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks here -
+    one child process per GPU running this very command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set, what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would do - pass rank 0's
+    stdout (the ONE JSON line) through, keep the other ranks' stdout out of it, return the worst exit code.  A rank that
+    dies takes the others down with it instead of leaving them in a rendezvous."""
+    import socket
+    import subprocess
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            env0["MASTER_PORT"] = str(sk.getsockname()[1])
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in pending:  # (exact children of this process, by handle)
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -311,8 +353,8 @@ def main():
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling run (C4: 256^3 / 8M particles over the GPUs)")
     ap.add_argument("--no-stress", action="store_true", help="skip the busy-scene run (N = 1 only)")
     ap.add_argument("--only-stress", action="store_true", help="run nothing but the busy scene (development)")
-    ap.add_argument("--no-grown", action="store_true", help="skip the run on a map grown from empty (N = 1 only)")
-    ap.add_argument("--only-grown", action="store_true", help="run nothing but the grown-map leg (development)")
+    ap.add_argument("--no-driven", action="store_true", help="skip the drive from an empty map (N = 1 only)")
+    ap.add_argument("--only-driven", action="store_true", help="run nothing but the drive from an empty map (development)")
     ap.add_argument("--no-adapter", action="store_true", help="skip the end-to-end leg through the C++ class (host buffers in, clouds out)")
     args = ap.parse_args()
 
@@ -322,15 +364,26 @@ def main():
     if args.only_stress:
         print(json.dumps({"stress": stress_run(synth, sharded)}))
         return
-    if args.only_grown:
-        print(json.dumps({"grown": grown_run(synth, sharded)}))
+    if args.only_driven:
+        print(json.dumps({"driven": driven_run(synth, sharded)}))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, args.gpus))
+    fake = os.environ.get("SDM_BENCH_FAKE_RANK")
+    if fake and "WORLD_SIZE" in os.environ:
+        # tests/test_bench_contract.py: a rank that only reports the environment the launcher gave it (no GPU needed)
+        if fake == "fail1" and os.environ["RANK"] == "1":
+            raise SystemExit(3)
+        if fake == "fail1":
+            time.sleep(30)  # (rank 0 would sit in the rendezvous: the launcher has to take it down)
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around this process: be the launcher (one process per GPU, rank 0's line on stdout)
+        raise SystemExit(spawn_ranks(args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d under a launcher that set WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
     # SDM_BENCH_SHARDED=1: take the N > 1 code path - gloo process group, RCCL communicator, sdm_update_sharded, collective
     # timers - with whatever world size there is (1 on the boxes with one GPU): a rehearsal of the multi-GPU bench line
     multi = world > 1 or os.environ.get("SDM_BENCH_SHARDED") == "1"
@@ -599,10 +652,10 @@ def main():
         stress = stress_run(synth, sharded)
         stress["process"] = "this process (a later map of it)"
 
-    grown = None
-    if not multi and not args.no_grown and not args.no_cpu:
-        grown = grown_run(synth, sharded)
-        grown["process"] = "this process (a later map of it)"
+    driven = None
+    if not multi and not args.no_driven and not args.no_cpu:
+        driven = driven_run(synth, sharded)
+        driven["process"] = "this process (a later map of it)"
 
     adapter = None
     if not multi and not args.no_adapter and not args.no_cpu:
@@ -615,10 +668,12 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "issue_mode": issue_mode,
             "config": {"workload": "%s: %dx%dx%d voxels, %d slots/voxel, %dx%d image, window %d, %s params, "
-                                   "6 dynamic objects, %d live particles, %d visible/frame"
+                                   "6 dynamic objects, %d live particles of which %d are PREFILLED FILLER the camera cannot see "
+                                   "(below the ground plane, behind the walls: the map carries BASELINE's 2 M, the frame works on "
+                                   "what is visible), %d visible/frame; the workload the filter populated itself is `driven`"
                                    % (args.config if world == 1 else "%s weak-scaled x%d" % (args.config, world),
                                       1 << cfg["x_n"], 1 << cfg["y_n"], 1 << cfg["z_n"], S, cfg["width"], cfg["height"],
-                                      cfg["window_half"], synth.CONFIG_PARAMS[args.config], live, n_vis),
+                                      cfg["window_half"], synth.CONFIG_PARAMS[args.config], live, n_pre * world, n_vis),
                        "voxels": V, "live_particles": live, "prefilled_particles": n_pre * world, "visible_particles": n_vis,
                        "parallelism": "zslab%d" % world, "inputs": "depth + LabeledPoint image resident in HBM",
                        "render_s": round(t_render, 1),
@@ -633,8 +688,8 @@ def main():
             out["strong_scaling"] = strong
         if stress is not None:
             out["stress"] = stress
-        if grown is not None:
-            out["grown"] = grown
+        if driven is not None:
+            out["driven"] = driven
         if adapter is not None:
             out["adapter_e2e"] = adapter
         if not multi:

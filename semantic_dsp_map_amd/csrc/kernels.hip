@@ -1596,21 +1596,25 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     vis[i] = true;
   }
   // A visible particle takes its place in its pixel's bin (pib, counted per pixel) and goes on the list of its IMAGE ROW
-  // (one of ROW_SUBS sub-lists per row, picked by workgroup, so that the counters are spread over many cache lines): the
+  // (one of ROW_SUBS sub-lists per row, so that the counters are spread over many cache lines): the
   // workgroup of k_bin_rows that lays out the row's bins finds the row's particles there.
+  // (the sub-list by workgroup AND lane: picked by workgroup alone - round 4 - the particles of a crowded row that a few
+  // workgroups see went to a few of its sub-lists, and one full sub-list voids the frame although the row and the map had
+  // room; spread over all eight, a row holds ROW_SUBS * row_cap particles whoever finds them)
+  const uint32_t sub = (shard + (threadIdx.x & 63u)) & (ROW_SUBS - 1);
   uint32_t rq[S];
 #pragma unroll
   for (int i = 1; i < S; ++i)
     if (vis[i]) {
       pib[i] = atomicAdd(&sc.bin_count[pixv[i]], 1u);
-      rq[i] = atomicAdd(&sc.row_cnt[(size_t)(rowv[i] * ROW_SUBS + (shard & (ROW_SUBS - 1))) * ROW_CNT_STRIDE], 1u);
+      rq[i] = atomicAdd(&sc.row_cnt[(size_t)(rowv[i] * ROW_SUBS + sub) * ROW_CNT_STRIDE], 1u);
     }
 #pragma unroll
   for (int i = 1; i < S; ++i)
     if (vis[i]) {
       if (rq[i] < sc.row_cap && pib[i] < (1u << 21)) {
         const uint32_t col = (uint32_t)(pixv[i] - rowv[i] * d.W);
-        sc.row_list[(size_t)(rowv[i] * ROW_SUBS + (shard & (ROW_SUBS - 1))) * sc.row_cap + rq[i]] =
+        sc.row_list[(size_t)(rowv[i] * ROW_SUBS + sub) * sc.row_cap + rq[i]] =
             make_uint2((uint32_t)(((size_t)v << d.p_n) + i), col | pib[i] << 11);
       } else {
         sc.cnt->overflow = 1;

@@ -495,7 +495,8 @@ sdm_status check_counters(sdm_map *m, Counters *out) {
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (out) *out = c;
   if (c.overflow) {
-    set_error("capacity", __FILE__, __LINE__, "visible-particle or move list overflowed (raise sdm_config.max_visible)");
+    set_error("capacity", __FILE__, __LINE__, "visible-particle or move list overflowed: more visible particles than sdm_config.max_visible, more in ONE image row than "
+              "max(2 max_visible / height, 2 width slots) - raise max_visible -, or more than 2^21 in one pixel's bin");
     return SDM_ERR_CAPACITY;
   }
   if (c.flood_rounds >= 256 && !c.flood_complex) {
@@ -819,9 +820,14 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   cap_vis = (cap_vis + VIS_SHARDS - 1) / VIS_SHARDS * VIS_SHARDS;
   cap_vis = std::min<size_t>(cap_vis, 0xffffff00u);
   sc.cap_vis = (uint32_t)cap_vis;
-  // a row's lists hold 4 x its share of the capacity (particles crowd into the image rows the ground and the objects are
-  // in), a sub-list an eighth of that
-  sc.row_cap = (uint32_t)std::max<size_t>(64, std::min<size_t>(cap_vis, 4 * cap_vis / (size_t)d.H) / ROW_SUBS);
+  // A row's lists hold 2 x its share of the capacity (particles crowd into the image rows the ground and the objects are
+  // in) and at least two particles per slot and pixel of the row - or, when the user's max_visible is below that, ALL of
+  // the capacity: one crowded row must not void a frame whose particles fit max_visible.  A sub-list holds an eighth of
+  // that plus a quarter (k_visibility spreads a row's particles over its sub-lists by lane: evenly, not exactly).
+  {
+    const size_t row_total = std::min<size_t>(cap_vis, std::max<size_t>(2 * cap_vis / (size_t)d.H, (size_t)2 * d.W * d.S));
+    sc.row_cap = (uint32_t)std::max<size_t>(64, (row_total + row_total / 4) / ROW_SUBS + 64);
+  }
   A(sc.row_list, (size_t)d.H * ROW_SUBS * sc.row_cap);
   A(sc.bin_idx, cap_vis);
   A(sc.vpix, cap_vis);

@@ -106,6 +106,16 @@ CONFIG_PARAMS = {"REF_KITTI360": "kitti360", "REF_CODA": "coda", "REF_VKITTI2": 
                  "T0": "vkitti2", "T1": "zed2"}
 
 
+# bench.py's `driven` leg and tests/test_driven_gpu.py: an EMPTY C3 map and a 66 m drive (220 frames of 0.3 m) down a 28 m
+# wide street with 400 static and 12 moving boxes, three noisy births per point; the camera yaws 0.1 deg and drifts 6 mm
+# sideways per frame (ring shifts on z every frame or two, on x every 33 frames), the moving boxes drive the camera's
+# way at 0.22-0.4 m per frame.  Nothing is prefilled: every particle of the map is one the filter put there.
+DRIVEN_SCENE = dict(n_static=400, n_dynamic=12, seed=17, yaw_rate_deg=0.1, street_half_width=14.0, street_length=130.0,
+                    dyn_all_forward=True, dyn_speed=(0.22, 0.4), lane_half_width=3.5, lateral_rate=0.02)
+DRIVEN_FRAMES = 220
+DRIVEN_PARAMS = "vkitti2_nb3"
+
+
 def noise_table(seed=20250217, n=1000000, stddev=0.05):
     """Host-side stand-in for the reference's gaussian_randoms table (basic_algorithms.h:394-402).
     On the GPU box the table is generated by rocRAND inside the library and read back; this numpy
@@ -130,20 +140,27 @@ class Scene:
     """Street scene scaled to the map extent of a configuration."""
 
     def __init__(self, cfg, n_static=24, n_dynamic=4, seed=7, speed=0.3, yaw_rate_deg=1.0,
-                 invalid_fraction=0.0, dyn_speed=(0.2, 1.0), lateral_extra=None):
+                 invalid_fraction=0.0, dyn_speed=(0.2, 1.0), lateral_extra=None, street_half_width=None, street_length=None,
+                 dyn_all_forward=False, lane_half_width=None, lateral_rate=0.05):
+        """street_half_width / street_length / dyn_all_forward / lane_half_width / lateral_rate (all at their old values by
+        default: the scenes of the committed fixtures do not change): a wider street, static boxes spread over
+        `street_length` metres ahead instead of the map's extent and kept `lane_half_width` metres off the centre line,
+        every moving box driving the camera's way, the camera's sideways drift per metre driven - what a drive longer
+        than the map needs without running the camera into the clutter (bench.py `driven`)."""
         self.cfg = dict(cfg)
         self.rng = np.random.default_rng(seed)
         self.seed = seed
         half = 0.5 * (1 << min(cfg["x_n"], cfg["z_n"])) * cfg["voxel_size"]
         self.half = half
         self.ground_y = min(1.6, 0.35 * (1 << cfg["y_n"]) * cfg["voxel_size"])
-        self.wall_x = min(8.0, 0.8 * half)
+        self.wall_x = min(8.0, 0.8 * half) if street_half_width is None else float(street_half_width)
         self.wall_top = -min(6.0, 0.45 * (1 << cfg["y_n"]) * cfg["voxel_size"])
         self.speed = speed
         self.yaw_rate = math.radians(yaw_rate_deg)
         self.lateral_extra = lateral_extra  # (t0, metres per frame): extra sideways (x) motion from frame t0 on
+        self.lateral_rate = lateral_rate
         self.invalid_fraction = invalid_fraction
-        zmax = max(2.0 * half, 6.0)
+        zmax = max(2.0 * half, 6.0) if street_length is None else float(street_length)
         r = self.rng
         boxes, labels, tracks = [], [], []
         static_kinds = [(LABEL_POLE, TRACK_POLE, (0.3, 3.0, 0.3)), (LABEL_TREE, TRACK_TREE, (1.5, 4.0, 1.5)),
@@ -155,8 +172,9 @@ class Scene:
             sx, sy, sz = sx * s, min(sy * s, self.ground_y - self.wall_top), sz * s
             cx = r.uniform(-0.85 * self.wall_x, 0.85 * self.wall_x)
             cz = r.uniform(1.5, zmax)
-            if abs(cx) < 1.2 * s + sx / 2:  # keep the driving lane free
-                cx = math.copysign(1.2 * s + sx / 2 + 0.2, cx if cx != 0 else 1.0)
+            lane_free = 1.2 * s if lane_half_width is None else float(lane_half_width)
+            if abs(cx) < lane_free + sx / 2:  # keep the driving lane free
+                cx = math.copysign(lane_free + sx / 2 + 0.2, cx if cx != 0 else 1.0)
             boxes.append([cx - sx / 2, self.ground_y - sy, cz - sz / 2, cx + sx / 2, self.ground_y, cz + sz / 2])
             labels.append(lab)
             tracks.append(trk)
@@ -171,7 +189,7 @@ class Scene:
             cz = r.uniform(3.0 * s + 1.0, max(0.9 * half, 4.0))
             dyn.append([lane - sx / 2, self.ground_y - sy, cz - sz / 2, lane + sx / 2, self.ground_y, cz + sz / 2])
             v = r.uniform(*dyn_speed) * s
-            vel.append([0.0, 0.0, v if k % 2 == 0 else -0.5 * v])
+            vel.append([0.0, 0.0, v if (k % 2 == 0 or dyn_all_forward) else -0.5 * v])
         self.dyn_boxes0 = np.array(dyn, np.float64).reshape(-1, 6)
         self.dyn_vel = np.array(vel, np.float64).reshape(-1, 3)
         self.dyn_tracks = np.arange(1, n_dynamic + 1, dtype=np.uint16)
@@ -179,7 +197,7 @@ class Scene:
     # ------------------------------------------------------------ trajectory
     def pose(self, t):
         theta = self.yaw_rate * t
-        pos = np.array([0.05 * t * self.speed, 0.0, self.speed * t], np.float64)
+        pos = np.array([self.lateral_rate * t * self.speed, 0.0, self.speed * t], np.float64)
         if self.lateral_extra is not None and t > self.lateral_extra[0]:
             pos[0] += (t - self.lateral_extra[0]) * self.lateral_extra[1]
         return pos, yaw_quat(theta)
@@ -354,7 +372,7 @@ def render_frames(cfg, params, scene_kw, frames, workers=None):
     import multiprocessing as mp
     import os
     frames = list(frames)
-    workers = min(workers or min(32, os.cpu_count() or 1), len(frames))
+    workers = min(workers or min(64, os.cpu_count() or 1), len(frames))
     jobs = [(cfg, params, scene_kw, t) for t in frames]
     if workers <= 1:
         return [_render_job(j) for j in jobs]

@@ -56,6 +56,40 @@ def test_committed_bench_line_is_self_consistent():
 import pytest  # noqa: E402
 
 
+def _run_bench(args, env_extra, timeout=120):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_bench_gpus_n_without_a_launcher_spawns_its_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE around it (how the driver starts N = 1; its first multi-GPU run must not
+    die on a launch convention): bench.py starts its two ranks itself, each with the launcher's environment, and only
+    rank 0's line reaches stdout.  The ranks here are stand-ins that report their environment (no GPU in this test)."""
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"SDM_BENCH_FAKE_RANK": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.strip().splitlines() if x.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["RANK"] == "0" and d["LOCAL_RANK"] == "0" and d["WORLD_SIZE"] == "2" and d["MASTER_ADDR"] == "127.0.0.1" and int(d["MASTER_PORT"]) > 0
+
+
+def test_bench_self_spawn_propagates_a_dead_rank():
+    """rank 1 dies: the launcher returns its exit code and takes rank 0 (which would wait in the rendezvous) down with it"""
+    import time
+    t0 = time.time()
+    r = _run_bench(["--gpus", "2"], {"SDM_BENCH_FAKE_RANK": "fail1"})
+    assert r.returncode == 3 and time.time() - t0 < 25, (r.returncode, time.time() - t0)
+    assert not r.stdout.strip()
+
+
+def test_bench_gpus_n_under_a_launcher_with_another_world_size_says_so():
+    r = _run_bench(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "SDM_BENCH_FAKE_RANK": ""})
+    assert r.returncode != 0 and "must agree" in r.stderr
+
+
 @pytest.mark.gpu
 def test_sharded_bench_line_rehearsal():
     """The N > 1 path of bench.py - gloo process group, RCCL communicator inside the library, sdm_update_sharded, the

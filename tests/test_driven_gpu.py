@@ -1,0 +1,84 @@
+"""bench.py's `driven` workload with the oracle BESIDE the GPU from frame 0.
+
+An EMPTY C3 map (256^3 voxels, 8 slots) and synth.DRIVEN_FRAMES = 220 frames of a 66 m drive down a cluttered street with
+12 moving objects and three noisy births per point - more than the map is long, ring shifts on z (every frame or two)
+and x.  Nothing is prefilled: the map's ~0.2 M live particles are the ones the filter puts there, and the other parity
+tests at this grid size either start from a prefilled state or hand a GPU-grown state to the oracle.  Here both sides
+start from nothing and run free:
+
+  * canonical order (bin_order = 1), bit for bit: every voxel result every 10 frames, the whole particle state (every field
+    of every slot, ring state, slab stamps) every 40 frames and at the frame where the orders part;
+  * the last 5 frames against the oracle's LITERAL order (bin_order = 0: the reference's BFS push-order sums,
+    semantic_dsp_map.h:1029, mc_ring/operations.h:1405-1407) started from that common state: identical integers in the
+    particle state and the voxel results, probabilities within 1e-4 (north_star's bar).
+
+Reference: SemanticDSPMap::subObjectLevelUpdate, semantic_dsp_map.h:576-955.  About four minutes (220 oracle frames at
+~0.4 s, 220 rendered frames, eleven comparisons of 134 M slots)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc_mod
+from semantic_dsp_map_amd import synth
+from tests import parity_utils as pu
+
+pytestmark = pytest.mark.gpu
+
+
+def test_drive_from_an_empty_map_with_the_oracle_beside_the_gpu():
+    cfg = synth.CONFIGS["C3"]
+    params = synth.PARAMS[synth.DRIVEN_PARAMS]
+    scene_kw = dict(synth.DRIVEN_SCENE)
+    n, n_literal = synth.DRIVEN_FRAMES, 5
+    S = 1 << cfg["p_n"]
+    scene = synth.Scene(cfg, **scene_kw)
+    rendered = synth.render_frames(cfg, params, scene_kw, range(n))
+    noise = synth.noise_table()
+    o, g = pu.make_pair(cfg, params, noise, bin_order=1)
+    n_vis, moved = [], 0
+    t_split = n - n_literal
+    for t in range(t_split):
+        depth, cloud, pos, q = rendered[t]
+        moves = scene.moves(t)
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves, sync=True)
+        so, sg = o.stats(), g.stats()
+        assert so["n_visible"] == sg["n_visible"], "frame %d: visible particles %d (oracle) / %d (gpu)" % (t, so["n_visible"], sg["n_visible"])
+        n_vis.append(sg["n_visible"])
+        moved += sg.get("n_moved", 0)
+        if t % 40 == 39 or t == t_split - 1:
+            rep = pu.compare_maps(o, g, S, check_results=True, tag="frame %d: " % t)
+            assert not rep, "\n".join(rep)
+        elif t % 10 == 9:
+            vo, vg = o.voxels(), g.voxels()
+            for k in ("occ", "label", "track", "wsum"):
+                r = pu.diff_report("frame %d: voxels.%s" % (t, k), vo[k], vg[k])
+                assert not r, r
+    # the drive did what it is meant to: a population the filter grew, objects that moved, the ring shifted on two axes
+    live = g.stats(count_live=True)
+    assert live["live_particles"] > 100000 and min(n_vis[60:]) > 20000, (live["live_particles"], n_vis[-5:])
+    ring = g.ring_state()
+    assert abs(ring["moved_steps"][2]) >= 300 and abs(ring["moved_steps"][0]) >= 3, ring
+    assert moved > 0
+    # the last frames against the literal order, from the common state
+    lit = orc_mod.OracleMap(dict(cfg, bin_order=0), params, noise)
+    lit.load_state(o.dump_state())
+    lit.set_stamps(*o.stamps())
+    lit.set_ring_state(o.ring_state())
+    del o
+    for t in range(t_split, n):
+        depth, cloud, pos, q = rendered[t]
+        moves = scene.moves(t)
+        lit.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves, sync=True)
+        so, sg = lit.dump_state(), g.dump_state()
+        for k in ("status", "ts", "track", "label", "forget", "owner"):
+            assert np.array_equal(so[k], sg[k]), "frame %d: %s differs from the literal-order oracle" % (t, k)
+        alive = so["status"] != 0
+        for k in ("w", "px", "py", "pz"):
+            assert np.max(np.abs(so[k][alive] - sg[k][alive]), initial=0.0) <= 1e-4, "frame %d: %s" % (t, k)
+        vo, vg = lit.voxels(), g.voxels()
+        for k in ("occ", "label", "track"):
+            assert np.array_equal(vo[k], vg[k]), "frame %d: voxels.%s differs from the literal-order oracle" % (t, k)
+        assert np.max(np.abs(vo["wsum"] - vg["wsum"])) <= 1e-4
+        assert lit.stats()["n_visible"] == g.stats()["n_visible"]
+    g.close()
