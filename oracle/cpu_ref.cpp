@@ -1017,6 +1017,15 @@ oracle_map *oracle_create(const oracle_config *cfg) {
   return new oracle_map(*cfg);
 }
 void oracle_destroy(oracle_map *m) { delete m; }
+// A deep copy of the whole map - particles, ring state, table cursors and the owner SETS as they are (an index can sit in
+// two of them, object_layer.h:20-52: dump_state / load_state carry one owner per index and lose the second) - with another
+// summation order for what follows: the way to part a literal-order run from a canonical-order one in mid-drive.
+oracle_map *oracle_clone(const oracle_map *m, int32_t bin_order) {
+  if (!m) return nullptr;
+  oracle_map *c = new oracle_map(*m);
+  c->cfg.bin_order = bin_order;
+  return c;
+}
 void oracle_clear(oracle_map *m) { m->clearAll(); }
 void oracle_set_params(oracle_map *m, const oracle_params *p) { m->prm = *p; }
 void oracle_set_noise_table(oracle_map *m, const float *table, int32_t n) { m->noise.assign(table, table + n); }

@@ -113,6 +113,7 @@ typedef struct {
 
 oracle_map *oracle_create(const oracle_config *cfg);
 void oracle_destroy(oracle_map *m);
+oracle_map *oracle_clone(const oracle_map *m, int32_t bin_order);  /* deep copy (owner sets included), other summation order */
 void oracle_clear(oracle_map *m);
 void oracle_set_params(oracle_map *m, const oracle_params *p);
 /* Gaussian noise table, normally 1,000,000 floats ~ N(0, 0.05^2)

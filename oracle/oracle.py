@@ -94,6 +94,8 @@ def lib():
         L.oracle_create.restype = vp
         L.oracle_create.argtypes = [C.POINTER(Config)]
         L.oracle_destroy.argtypes = [vp]
+        L.oracle_clone.restype = vp
+        L.oracle_clone.argtypes = [vp, C.c_int32]
         L.oracle_clear.argtypes = [vp]
         L.oracle_set_params.argtypes = [vp, C.POINTER(Params)]
         L.oracle_set_noise_table.argtypes = [vp, vp, C.c_int32]
@@ -161,6 +163,16 @@ class OracleMap:
             self.set_params(params)
         if noise_table is not None:
             self.set_noise_table(noise_table)
+
+    def clone(self, bin_order=None):
+        """A deep copy of the whole map (the owner sets with their double memberships included, which dump_state /
+        load_state cannot carry), optionally with the other summation order from here on."""
+        o = OracleMap.__new__(OracleMap)
+        o.L, o.cfg, o.V, o.S, o.W, o.H = self.L, self.cfg, self.V, self.S, self.W, self.H
+        o.h = self.L.oracle_clone(self.h, self.cfg.bin_order if bin_order is None else bin_order)
+        if not o.h:
+            raise MemoryError("oracle_clone")
+        return o
 
     def __del__(self):
         if getattr(self, "h", None):

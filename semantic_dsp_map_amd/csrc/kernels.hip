@@ -143,7 +143,7 @@ __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, uint32_t 
 // positions (read, xyz zeroed, .w - the forget count - kept), the pieces of their records that hold weights, stamps and
 // status bytes (the track ids and labels in between are left alone: nothing of a record is read), their owners and the
 // per-voxel arrays, 1 KB contiguous per store instruction, all loads of a thread requested before its first store.
-// Measured on the C3 map (tools/gpu_round4_clear.sh, same box): 1.73 ms per sdm_clear with k_clear_slots, 1.42 ms with
+// Measured on the C3 map (round 4, tools/probes/clear_time.py with four builds on one box): 1.73 ms per sdm_clear with k_clear_slots, 1.42 ms with
 // this kernel (the kernel itself 1.45 -> 1.33 ms; FETCH_SIZE = the positions and nothing else), 1.63 ms when the kept
 // pieces are read and written back so that every sector of the record array is written whole - the memory side merges
 // the partial sectors better than it serves the extra reads - and 1.62-1.74 ms with plain instead of non-temporal accesses.

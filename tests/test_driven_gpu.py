@@ -17,7 +17,6 @@ Reference: SemanticDSPMap::subObjectLevelUpdate, semantic_dsp_map.h:576-955.  Ab
 import numpy as np
 import pytest
 
-from oracle import oracle as orc_mod
 from semantic_dsp_map_amd import synth
 from tests import parity_utils as pu
 
@@ -60,10 +59,9 @@ def test_drive_from_an_empty_map_with_the_oracle_beside_the_gpu():
     assert abs(ring["moved_steps"][2]) >= 300 and abs(ring["moved_steps"][0]) >= 3, ring
     assert moved > 0
     # the last frames against the literal order, from the common state
-    lit = orc_mod.OracleMap(dict(cfg, bin_order=0), params, noise)
-    lit.load_state(o.dump_state())
-    lit.set_stamps(*o.stamps())
-    lit.set_ring_state(o.ring_state())
+    # (a deep copy: the owner sets of the 12 objects hold indices twice where their particles have met - the reference's sets
+    # are real sets - and a state dump carries one owner per index)
+    lit = o.clone(bin_order=0)
     del o
     for t in range(t_split, n):
         depth, cloud, pos, q = rendered[t]
@@ -75,10 +73,13 @@ def test_drive_from_an_empty_map_with_the_oracle_beside_the_gpu():
             assert np.array_equal(so[k], sg[k]), "frame %d: %s differs from the literal-order oracle" % (t, k)
         alive = so["status"] != 0
         for k in ("w", "px", "py", "pz"):
-            assert np.max(np.abs(so[k][alive] - sg[k][alive]), initial=0.0) <= 1e-4, "frame %d: %s" % (t, k)
+            a, b = so[k][alive], sg[k][alive]
+            assert np.all(np.abs(a - b) <= 1e-4 * np.maximum(1.0, np.abs(a))), "frame %d: %s" % (t, k)
         vo, vg = lit.voxels(), g.voxels()
         for k in ("occ", "label", "track"):
             assert np.array_equal(vo[k], vg[k]), "frame %d: voxels.%s differs from the literal-order oracle" % (t, k)
-        assert np.max(np.abs(vo["wsum"] - vg["wsum"])) <= 1e-4
+        # (a voxel's weight SUM is taken before the clamp and reaches a few hundred on surfaces seen for a hundred frames:
+        # 1e-4 relative there - four float ulps at 400 are 1.2e-4 -, 1e-4 absolute where it is a probability)
+        assert np.all(np.abs(vo["wsum"] - vg["wsum"]) <= 1e-4 * np.maximum(1.0, np.abs(vo["wsum"])))
         assert lit.stats()["n_visible"] == g.stats()["n_visible"]
     g.close()
