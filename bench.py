@@ -624,8 +624,8 @@ def main():
             m.synchronize()
         clear_ms = (time.perf_counter() - t0) * 1e3 / 3
         n_slots = V * S
-        clear_bytes = n_slots * (16 + 16 + 4 + 2 + 1 + 2) + V * (2 + 1 + 8 + 4 + 1)  # pos4 read + written, w, ts, status, owner; vts, vflag, res, list heads, slot-0 status
-        roofline["clear"] = {"kernel": "sdm_clear: k_clear_map<8> (one pass over the map, 16-byte lane-linear accesses) + 3 small memsets", "bytes_per_call": clear_bytes,
+        clear_bytes = n_slots * (16 + 4 + 2 + 1 + 2) + V * (2 + 1 + 8 + 4 + 1)  # pos4 written (nothing read: the forget counts have their own plane), w, ts, status, owner; vts, vflag, res, list heads, slot-0 status
+        roofline["clear"] = {"kernel": "sdm_clear: k_clear_map<8> (one write-only pass over the map, 16-byte lane-linear stores) + 4 small memsets", "bytes_per_call": clear_bytes,
                              "ms_per_call": round(clear_ms, 4), "achieved": round(clear_bytes / clear_ms / 1e6, 1),
                              "frac": round(clear_bytes / clear_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
                              "frac_on_survey_bytes": round(n_slots * 34 / clear_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),

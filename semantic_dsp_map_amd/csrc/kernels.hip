@@ -119,9 +119,7 @@ __global__ __launch_bounds__(TPB) void k_clear_status(uint8_t *__restrict__ stat
 __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, uint32_t *__restrict__ mv_head, size_t n) {
   size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= n) return;
-  float4 p = st.pos4[li];
-  p.x = p.y = p.z = 0.f;  // .w carries the forget count, which clear() does not touch
-  st.pos4[li] = p;
+  st.pos4[li] = make_float4(0.f, 0.f, 0.f, 0.f);  // (the forget count, which clear() does not touch, lives in State::forget)
   uint32_t slot = (uint32_t)li & (uint32_t)(d.S - 1);
   st.w[rec_index(li, d.p_n, REC_W)] = 0.f;
   st.ts[rec_index(li, d.p_n, REC_TS)] = 0;
@@ -140,7 +138,7 @@ __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, uint32_t 
 // The same reset with every byte it touches on a lane-linear 16-byte access (S >= 8: a record is a whole number of
 // 16-byte pieces).  k_clear_slots stores a weight, a stamp and a status byte per lane: three store instructions that each
 // leave holes in five or six lines of the record array.  Here a workgroup takes CLR_VOX consecutive voxels: their
-// positions (read, xyz zeroed, .w - the forget count - kept), the pieces of their records that hold weights, stamps and
+// positions (stored whole; the forget counts have their own plane and are not touched), the pieces of their records that hold weights, stamps and
 // status bytes (the track ids and labels in between are left alone: nothing of a record is read), their owners and the
 // per-voxel arrays, 1 KB contiguous per store instruction, all loads of a thread requested before its first store.
 // Measured on the C3 map (round 4, tools/probes/clear_time.py with four builds on one box): 1.73 ms per sdm_clear with k_clear_slots, 1.42 ms with
@@ -161,24 +159,14 @@ __global__ __launch_bounds__(TPB) void k_clear_map(Dims d, State st, uint32_t *_
   constexpr int PP = CLR_VOX * S / TPB;
   v4u *pp = reinterpret_cast<v4u *>(st.pos4 + lv0 * S);
   const uint32_t npos = nv * S;
-  // (the forget count rides in a position's fourth word and clear() leaves it alone.  Storing x, y, z as 8 + 4 bytes
-  // around it, so that nothing of the map is read, was measured in round 5: 1.59 ms per call against 1.50 ms - twelve
-  // bytes of every sixteen are a partial write of every sector, which costs the memory side more than reading the
-  // positions does.)
-  v4u pos[PP];
+  // (the forget count, which clear() leaves alone, has its own byte plane - State::forget - since round 5: the positions are
+  // stored, not read.  Rounds 1-4 kept it in the positions' fourth word and this kernel read 2.1 GB to write it back;
+  // storing x, y, z around it as 8 + 4 bytes was measured too: 1.59 ms per call against 1.50 ms - twelve bytes of every
+  // sixteen are a partial write of every sector.)
 #pragma unroll
   for (int k = 0; k < PP; ++k) {
     const uint32_t q = k * TPB + tid;
-    pos[k] = __builtin_nontemporal_load(pp + (q < npos ? q : npos - 1u));
-  }
-#pragma unroll
-  for (int k = 0; k < PP; ++k) {
-    const uint32_t q = k * TPB + tid;
-    if (q < npos) {
-      v4u p = pos[k];
-      p.x = p.y = p.z = 0u;
-      __builtin_nontemporal_store(p, pp + q);
-    }
+    if (q < npos) __builtin_nontemporal_store(v4u{0u, 0u, 0u, 0u}, pp + q);
   }
   // records: RP pieces per voxel; which words of a piece are zeroed / left alone / status follows from its offset in the
   // record [w: 4S | ts: 2S | track: 2S | label: S | status: S]
@@ -1989,6 +1977,7 @@ __global__ __launch_bounds__(BR_TPB) __attribute__((amdgpu_waves_per_eu(5, 5))) 
           if ((uint32_t)(i0 + i) < n) {
             const size_t li = (size_t)v[i0 + i] - slot_base;
             q[i] = st.pos4[li];
+            q[i].w = __uint_as_float((uint32_t)st.forget[li]);
             w8[i] = st.w[rec_index(li, d.p_n, REC_W)];
             t8[i] = st.track[rec_index(li, d.p_n, REC_TRACK)];
           }
@@ -2035,7 +2024,7 @@ __global__ __launch_bounds__(BR_TPB) __attribute__((amdgpu_waves_per_eu(5, 5))) 
       const size_t li = (size_t)a[i] - slot_base;
       const float4 q = st.pos4[li];
       sc.vp4[s + i] = make_float4(q.x, q.y, q.z, st.w[rec_index(li, d.p_n, REC_W)]);
-      sc.vtf[s + i] = (uint32_t)st.track[rec_index(li, d.p_n, REC_TRACK)] | ((__float_as_uint(q.w) & 0xffu) << 16);
+      sc.vtf[s + i] = (uint32_t)st.track[rec_index(li, d.p_n, REC_TRACK)] | ((uint32_t)st.forget[li] << 16);
       sc.vpix[s + i] = p;
     }
   }
@@ -2516,11 +2505,7 @@ __global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, St
       st.ts[rec_index(li, d.p_n, REC_TS)] = (uint16_t)f.gts;
       if (!flt.independent) {
         uint32_t nf = right_id ? 0u : (fc < 5u ? fc + 1u : fc);
-        if (nf != fc) {
-          float4 q4 = st.pos4[li];
-          q4.w = __uint_as_float(nf);
-          st.pos4[li] = q4;
-        }
+        if (nf != fc) st.forget[li] = (uint8_t)nf;
       }
     }
     wave_lds_sync();
@@ -2740,7 +2725,8 @@ __device__ __forceinline__ void birth_replay_sequential(const Dims &d, const Fra
           if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) slot = i;  // lowest vacant slot
         if (slot > 0) {
           // addNewParticleWithSemantics (operations.h:171-184)
-          st.pos4[base + slot] = make_float4(bp.x, bp.y, bp.z, __uint_as_float(0u));
+          st.pos4[base + slot] = make_float4(bp.x, bp.y, bp.z, 0.f);
+          st.forget[base + slot] = 0;
           st.w[base * REC_W + slot] = SDM_OCC_INIT_WEIGHT;
           st.ts[base * REC_TS + slot] = (uint16_t)f.gts;
           st.track[base * REC_TRACK + slot] = track;
@@ -2946,7 +2932,8 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
     const uint16_t track = (uint16_t)(tl & 0xffffu);
     const uint8_t label = (uint8_t)((tl >> 16) & 0xffu);
     // addNewParticleWithSemantics (operations.h:171-184)
-    st.pos4[base + i] = make_float4(bp.x, bp.y, bp.z, __uint_as_float(0u));
+    st.pos4[base + i] = make_float4(bp.x, bp.y, bp.z, 0.f);
+    st.forget[base + i] = 0;
     st.w[base * REC_W + i] = SDM_OCC_INIT_WEIGHT;
     st.ts[base * REC_TS + i] = (uint16_t)f.gts;
     st.track[base * REC_TRACK + i] = track;
@@ -3126,12 +3113,15 @@ __global__ __launch_bounds__(TPB) void k_count_owner(Dims d, State st, uint16_t 
 }
 
 // pack / unpack between the C-ABI's SoA dump format and pos4
-__global__ __launch_bounds__(TPB) void k_pack_pos4(float4 *pos4, const float *px, const float *py, const float *pz,
+__global__ __launch_bounds__(TPB) void k_pack_pos4(float4 *pos4, uint8_t *forget_plane, const float *px, const float *py, const float *pz,
                                                    const uint8_t *forget, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) pos4[i] = make_float4(px[i], py[i], pz[i], __uint_as_float((uint32_t)forget[i]));
+  if (i < n) {
+    pos4[i] = make_float4(px[i], py[i], pz[i], 0.f);
+    forget_plane[i] = forget[i];
+  }
 }
-__global__ __launch_bounds__(TPB) void k_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uint8_t *forget,
+__global__ __launch_bounds__(TPB) void k_unpack_pos4(const float4 *pos4, const uint8_t *forget_plane, float *px, float *py, float *pz, uint8_t *forget,
                                                      size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
@@ -3139,7 +3129,7 @@ __global__ __launch_bounds__(TPB) void k_unpack_pos4(const float4 *pos4, float *
     px[i] = q.x;
     py[i] = q.y;
     pz[i] = q.z;
-    forget[i] = (uint8_t)(__float_as_uint(q.w) & 0xffu);
+    forget[i] = forget_plane[i];
   }
 }
 
@@ -3423,6 +3413,7 @@ void launch_clear(const Dims &d, const State &st, uint32_t *mv_head, hipStream_t
   size_t n = (size_t)d.v_count * d.S;
   if (fresh) {
     hipMemsetAsync(st.pos4, 0, n * sizeof(float4), s);
+    hipMemsetAsync(st.forget, 0, n, s);
     hipMemsetAsync(st.rec, 0, n * REC_BYTES_PER_SLOT, s);
     hipMemsetAsync(st.vts, 0, (size_t)d.v_count * sizeof(uint16_t), s);
     hipMemsetAsync(st.vflag, 0, (size_t)d.v_count, s);
@@ -3687,12 +3678,12 @@ void launch_count_owner(const Dims &d, const State &st, uint16_t track, unsigned
   hipMemsetAsync(out, 0, 8, s);
   hipLaunchKernelGGL(k_count_owner, dim3(2048), dim3(TPB), 0, s, d, st, track, out);
 }
-void launch_pack_pos4(float4 *pos4, const float *px, const float *py, const float *pz, const uint8_t *forget, size_t n,
+void launch_pack_pos4(float4 *pos4, uint8_t *forget_plane, const float *px, const float *py, const float *pz, const uint8_t *forget, size_t n,
                       hipStream_t s) {
-  hipLaunchKernelGGL(k_pack_pos4, dim3(blocks_for(n)), dim3(TPB), 0, s, pos4, px, py, pz, forget, n);
+  hipLaunchKernelGGL(k_pack_pos4, dim3(blocks_for(n)), dim3(TPB), 0, s, pos4, forget_plane, px, py, pz, forget, n);
 }
-void launch_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(k_unpack_pos4, dim3(blocks_for(n)), dim3(TPB), 0, s, pos4, px, py, pz, forget, n);
+void launch_unpack_pos4(const float4 *pos4, const uint8_t *forget_plane, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_unpack_pos4, dim3(blocks_for(n)), dim3(TPB), 0, s, pos4, forget_plane, px, py, pz, forget, n);
 }
 // the list's length only
 void launch_emit_count(const Dims &d, const State &st, const EmitScratch &e, int want_free, hipStream_t s) {

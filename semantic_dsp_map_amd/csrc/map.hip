@@ -759,6 +759,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
 #define A(ptr, n) \
   if ((rc = alloc_tracked(m, &(ptr), (n))) != SDM_OK) return rc;
   A(m->st.pos4, n_slots);
+  A(m->st.forget, n_slots);
+  HIP_TRY(hipMemsetAsync(m->st.forget, 0, n_slots, m->stream));
   // one record per voxel: w | ts | track | label (sdm_internal.h); one chunk of 64 records of padding behind the last, so
   // that the sweep's chunk-wide loads need no clamp at the end of the map (k_occupancy_dense)
   A(m->st.rec, (n_slots + (size_t)64 * d.S) * REC_BYTES_PER_SLOT);
@@ -2431,7 +2433,7 @@ sdm_status sdm_dump_state(sdm_map *m, float *px, float *py, float *pz, float *w,
     HIP_TRY(dev_alloc(&ty, n));
     HIP_TRY(dev_alloc(&tz, n));
     HIP_TRY(dev_alloc(&tf, n));
-    launch_unpack_pos4(m->st.pos4, tx, ty, tz, tf, n, s);
+    launch_unpack_pos4(m->st.pos4, m->st.forget, tx, ty, tz, tf, n, s);
     if (px) HIP_TRY(hipMemcpyAsync(px, tx, n * 4, hipMemcpyDeviceToHost, s));
     if (py) HIP_TRY(hipMemcpyAsync(py, ty, n * 4, hipMemcpyDeviceToHost, s));
     if (pz) HIP_TRY(hipMemcpyAsync(pz, tz, n * 4, hipMemcpyDeviceToHost, s));
@@ -2504,7 +2506,7 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
   HIP_TRY(hipMemcpyAsync(ty, py, n * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(tz, pz, n * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(tf, forget, n, hipMemcpyHostToDevice, s));
-  launch_pack_pos4(m->st.pos4, tx, ty, tz, tf, n, s);
+  launch_pack_pos4(m->st.pos4, m->st.forget, tx, ty, tz, tf, n, s);
   {
     float *tw;
     uint16_t *tts, *ttr;

@@ -399,6 +399,7 @@ struct MoveLoaded {
 // (in two steps: the particle's own fields need its slot only, the noise draw its global rank)
 __device__ __forceinline__ void move_load_particle(const Dims &d, const State &st, size_t li, bool copy_invalid, MoveLoaded &m) {
   m.p = st.pos4[li];
+  m.p.w = __uint_as_float((uint32_t)st.forget[li]);  // (the forget count travels in the copy's fourth word, as it did when it lived there)
   m.w = st.w[rec_index(li, d.p_n, REC_W)];
   m.ts = st.ts[rec_index(li, d.p_n, REC_TS)];
   m.track = st.track[rec_index(li, d.p_n, REC_TRACK)];
@@ -862,7 +863,8 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
         if (e == t) c = c0;
         const uint8_t cs = c.status;
         const uint16_t cts = c.ts;
-        st.pos4[base + slot] = make_float4(c.x, c.y, c.z, __uint_as_float(c.forget_bits));
+        st.pos4[base + slot] = make_float4(c.x, c.y, c.z, 0.f);
+        st.forget[base + slot] = (uint8_t)c.forget_bits;
         st.w[base * REC_W + slot] = c.w;
         st.ts[base * REC_TS + slot] = cts;
         st.track[base * REC_TRACK + slot] = c.track;

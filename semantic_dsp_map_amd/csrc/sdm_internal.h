@@ -1,7 +1,8 @@
 // sdm_internal.h — shared declarations of libsdm_hip (not part of the C ABI).
 //
 // Data layout in HBM (particle index = voxel << p_n | slot, the reference's, mc_ring/operations.h:370,788):
-//   dense, per slot     pos4   float4  x, y, z, forget_count (as uint bits)
+//   dense, per slot     pos4   float4  x, y, z, 0
+//                       forget u8      forget count
 //                       owner  u16     track id of the owner set holding this index, 0xFFFF = none
 //   dense, per voxel    vts    u16     observation stamp (the reference's slot-0 time particle)
 //                       vflag  u8      0 = every slot INVALID
@@ -159,7 +160,11 @@ constexpr RecStride REC_W{5}, REC_TS{10}, REC_TRACK{10}, REC_LABEL{20}, REC_STAT
 __host__ __device__ constexpr int rec_align(int S) { return 10 * S % 16 == 0 ? 16 : (10 * S % 8 == 0 ? 8 : 4); }
 
 struct State {
-  float4 *pos4 = nullptr;
+  float4 *pos4 = nullptr;        // x, y, z, 0
+  // forget count per slot.  Its own byte plane since round 5 (rounds 1-4: the positions' fourth word): clear() resets the
+  // positions and leaves the forget counts alone (operations.h:697-722), so k_clear_map STORES the positions without
+  // reading them; the weight update changes a byte instead of reading and rewriting a position.
+  uint8_t *forget = nullptr;
   unsigned char *rec = nullptr;  // v_count records of 10*S bytes
   float *w = nullptr;
   uint16_t *ts = nullptr;

@@ -185,9 +185,9 @@ void launch_birth_replay(const Dims &d, const Filter &flt, const State &st, cons
                          hipStream_t s);
 void launch_count_live(const Dims &d, const State &st, unsigned long long *out, hipStream_t s);
 void launch_count_owner(const Dims &d, const State &st, uint16_t track, unsigned long long *out, hipStream_t s);
-void launch_pack_pos4(float4 *pos4, const float *px, const float *py, const float *pz, const uint8_t *forget, size_t n,
+void launch_pack_pos4(float4 *pos4, uint8_t *forget_plane, const float *px, const float *py, const float *pz, const uint8_t *forget, size_t n,
                       hipStream_t s);
-void launch_unpack_pos4(const float4 *pos4, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s);
+void launch_unpack_pos4(const float4 *pos4, const uint8_t *forget_plane, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s);
 // slot 0 of the stamp array <-> the dense voxel-stamp array (state export / import)
 void launch_rec_pack(const Dims &d, const State &st, const float *w, const uint16_t *ts, const uint16_t *track,
                      const uint8_t *label, const uint8_t *status, hipStream_t s);

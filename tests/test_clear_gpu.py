@@ -72,3 +72,29 @@ def test_clear_of_a_dense_random_state(name):
         rep = pu.compare_maps(o, g, S, tag="frame %d after clear: " % t)
         assert not rep, "\n".join(rep)
     g.close()
+
+
+def test_clear_after_frames_keeps_the_forget_counts_the_frames_left():
+    """The forget counts live in a byte plane of their own (round 5) that the weight update, the births and the object moves
+    write: a map those stages have worked on - not a loaded state - is cleared, and every field of every slot, the forget
+    counts of live and dead slots included, must come out like the oracle's."""
+    cfg = synth.CONFIGS["T0"]
+    params = synth.PARAMS["zed2"]
+    o, g = pu.make_pair(cfg, params, synth.noise_table())
+    S = 1 << cfg["p_n"]
+    sc = synth.Scene(cfg, n_dynamic=3, seed=21)
+    for t in range(9):
+        depth, cloud, pos, q = sc.render(t, params)
+        moves = sc.moves(t)
+        o.update(depth, cloud, pos, q, moves)
+        g.update(depth, cloud, pos, q, moves, sync=True)
+    so = o.dump_state()
+    assert (so["forget"] > 0).sum() >= 40 and (so["forget"][so["status"] == 0] > 0).sum() >= 20, "the clip leaves forget counts behind, in dead slots too"
+    rep = pu.compare_maps(o, g, S, tag="before clear: ")
+    assert not rep, "\n".join(rep)
+    o.clear()
+    g.clear()
+    rep = pu.compare_maps(o, g, S, check_results=False, tag="after clear: ")
+    assert not rep, "\n".join(rep)
+    assert np.array_equal(g.dump_state()["forget"], so["forget"])
+    g.close()
