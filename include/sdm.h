@@ -165,6 +165,11 @@ typedef struct {
   double host_enqueue_us;   /* host time to issue 50 empty kernel launches (a frame's worth), measured at sdm_create */
   int64_t halo_dropped;     /* sharded maps: slab-crossing copies of the last update beyond the export capacity towards their
                                destination shard (dropped; SDM_ERR_CAPACITY at the next sdm_synchronize) */
+  int64_t alias_entries;    /* indices that sit in a second owner set besides their latest one (the reference's sets are real
+                               sets, object_layer.h:20-52), as of now - deleted entries included until the next frame's
+                               garbage collection */
+  int64_t alias_overflowed; /* 1 = that table has overflowed (8192 entries) since the last sdm_clear / sdm_load_state: the
+                               sets are incomplete, SDM_ERR_CAPACITY is reported at every synchronisation from then on */
 } sdm_stats;
 
 /* ---- host placement.  A frame is a chain of ~50 dependent launches; the command processor fetches every packet and

@@ -84,7 +84,7 @@ class Stats(C.Structure):
                 ("sweep_tiles", C.c_int64),
                 ("stage_ms", C.c_double * 8), ("restamped_slabs", C.c_int64 * 3),
                 ("graph_frames", C.c_int64), ("direct_frames", C.c_int64), ("host_enqueue_us", C.c_double),
-                ("halo_dropped", C.c_int64)]
+                ("halo_dropped", C.c_int64), ("alias_entries", C.c_int64), ("alias_overflowed", C.c_int64)]
 
 
 class SdmError(RuntimeError):

@@ -3428,7 +3428,8 @@ void launch_clear(const Dims &d, const State &st, uint32_t *mv_head, hipStream_t
       hipLaunchKernelGGL(k_clear_slots, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, mv_head, n);
   }
   hipMemsetAsync(st.grp_hint, 0, grp_hint_bytes(d.v_count), s);  // nothing is dense any more
-  hipMemsetAsync(st.alias, 0, 8, s);  // no older memberships
+  hipMemsetAsync(st.alias, 0, 8, s);  // no older memberships (count and the sticky overflow word)
+  hipMemsetAsync(st.alias_filter, 0, ALIAS_FILTER_WORDS * 4, s);
   hipMemsetAsync(st.owner_flag, 0, owner_flag_bytes(n), s);
   hipMemsetAsync(st.owner_flag2, 0, owner_flag2_bytes(n), s);
 }

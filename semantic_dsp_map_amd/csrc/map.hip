@@ -781,6 +781,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(m->st.owner_flag2, owner_flag2_bytes(n_slots));
   A(m->st.alias, 2 + 2 * ALIAS_CAP);
   HIP_TRY(hipMemsetAsync(m->st.alias, 0, 8, m->stream));
+  A(m->st.alias_filter, ALIAS_FILTER_WORDS);
+  HIP_TRY(hipMemsetAsync(m->st.alias_filter, 0, ALIAS_FILTER_WORDS * 4, m->stream));
   A(m->st.res, d.v_count);
   A(m->st.stamps_x, d.NX);
   A(m->st.stamps_y, d.NY);
@@ -2324,6 +2326,13 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
   out->direct_frames = (int64_t)m->n_direct_frames;
   out->host_enqueue_us = m->enqueue_us;
   out->halo_dropped = c.n_halo_dropped;
+  {
+    uint32_t al[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(al, m->st.alias, 8, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    out->alias_entries = al[0] < ALIAS_CAP ? al[0] : ALIAS_CAP;
+    out->alias_overflowed = (al[0] > ALIAS_CAP || al[1] != 0) ? 1 : 0;
+  }
   if (m->profiling) {
     int prev = 0;
     for (int sidx = 1; sidx <= 7; ++sidx) {
@@ -2533,6 +2542,7 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
   else HIP_TRY(hipMemsetAsync(m->st.owner, 0xFF, n * 2, s));
   launch_owner_flags(m->d, m->st, s);
   HIP_TRY(hipMemsetAsync(m->st.alias, 0, 8, s));  // the imported owner array is all there is to the sets
+  HIP_TRY(hipMemsetAsync(m->st.alias_filter, 0, ALIAS_FILTER_WORDS * 4, s));
   launch_vts_sync(m->d, m->st, 0, s);  // voxel stamps from slot 0 of the stamp rows, "something here" flags from the status rows
   HIP_TRY(hipStreamSynchronize(s));
   (void)hipFree(tx);

@@ -174,7 +174,7 @@ __device__ __forceinline__ void move_members_body(const State &st, const Members
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     sc.mv_nlist[0] = n_list;
-    sc.cur->move_list_overflow = (overflow || st.alias[0] > ALIAS_CAP) ? 1u : 0u;
+    sc.cur->move_list_overflow = (overflow || st.alias[0] > ALIAS_CAP || st.alias[1] != 0u) ? 1u : 0u;  // (alias[1]: the table overflowed in an earlier frame - sticky)
   }
   __syncthreads();
   DBGM(2, 1, DBGM_T());
@@ -751,6 +751,7 @@ __global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int wor
 // holds, no list head of this frame points at it.)
 constexpr int RP_TPB = 64;
 constexpr int RP_GRID = 1024;
+constexpr int RP_KEEP = 96;  // ranks of a voxel's list kept in LDS (24 KB per workgroup)
 template <int S>
 __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, State st, Scratch sc) {
   // (the thread's copy and its successor on the list: their addresses depend on the thread's number only, so they are
@@ -777,6 +778,7 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
   const bool overflow = sc.cnt->overflow != 0;
   bool first_round = true;
   __shared__ uint32_t n_ok_block;  // (statistic: one global atomic per workgroup, not per voxel)
+  __shared__ uint32_t kept[RP_KEEP][RP_TPB];  // the ranks on the list this thread replays (column = thread: conflict-free)
   if (threadIdx.x == 0) n_ok_block = 0;
   __syncthreads();
   // (no `cond ? object : object` on MoveCopy anywhere here: the conditional operator on two lvalues selects an ADDRESS - one
@@ -824,13 +826,20 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
       if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) vac |= 1u << i;
     int last_slot = -1;  // the slot the previous copy went into, and who owns it since
     uint16_t last_owner = OWNER_NONE;
+    // The list is walked ONCE - a chain of dependent loads, 0.6 us each - and its ranks are kept in LDS; every later batch
+    // selects from there.  (Round 4 walked the list again for every batch of S-1: a voxel on the surface of an object that
+    // has been tracked for a hundred frames receives dozens of copies of which many are vacant themselves - dead members of
+    // the set are copied too, operations.h:334-349 - and fill no slot, so its list took five or six walks: the kernel's
+    // 250 us tail on the `driven` workload.)  A list longer than RP_KEEP is walked again for what LDS could not hold.
+    uint32_t n_list = 0;
+    bool first_pass = true;
     while (more && !full) {
       uint32_t best[S - 1];  // the S-1 smallest ranks above `last`, ascending
 #pragma unroll
       for (int i = 0; i < S - 1; ++i) best[i] = MV_NIL;
       uint32_t n_above = 0;  // ranks above `last` on the list
-      for (uint32_t cur = head; cur != MV_NIL; cur = cur == t ? nx0 : sc.mv_next[cur]) {
-        if ((long long)cur <= last) continue;
+      auto offer = [&](uint32_t cur) {
+        if ((long long)cur <= last) return;
         ++n_above;
         uint32_t x = cur;
 #pragma unroll
@@ -840,6 +849,18 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
             best[i] = x;
             x = y;
           }
+      };
+      if (first_pass || n_list > (uint32_t)RP_KEEP) {
+        uint32_t k = 0;
+        for (uint32_t cur = head; cur != MV_NIL; cur = cur == t ? nx0 : sc.mv_next[cur]) {
+          if (first_pass && k < (uint32_t)RP_KEEP) kept[k][threadIdx.x] = cur;
+          ++k;
+          offer(cur);
+        }
+        if (first_pass) n_list = k;
+        first_pass = false;
+      } else {
+        for (uint32_t k = 0; k < n_list; ++k) offer(kept[k][threadIdx.x]);
       }
       DBGM(1, 1, DBGM_T() + (stv[1] == 0xEE ? 1 : 0) + (own[1] == 0xEEEE ? 1 : 0));
       more = n_above > (uint32_t)(S - 1);  // ranks beyond this batch (a walk of the list is a chain of dependent loads: no second one to find nothing)

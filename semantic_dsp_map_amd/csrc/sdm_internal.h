@@ -205,6 +205,11 @@ struct State {
   // (slot index, track) here.  alias[0] = number of entries (deleted ones carry track OWNER_NONE until the next
   // compaction), entries from alias[2]: index, track.  Nearly always empty.
   uint32_t *alias = nullptr;
+  // 65536 bits, one per hash of a slot index: set when an entry for the slot goes into `alias`, rebuilt by the table's
+  // garbage collection.  Every insertion into / removal from an owner set has to look for older memberships of its slot;
+  // with the bit clear there is none and the table is not walked (a drive with a dozen objects keeps a few hundred entries
+  // alive, and every one of 20 k re-insertions per frame walked them all: alias_may_hold).
+  uint32_t *alias_filter = nullptr;
   sdm_voxel_result *res = nullptr;
   uint32_t *stamps_x = nullptr, *stamps_y = nullptr, *stamps_z = nullptr;
   float *pdf = nullptr;
@@ -228,6 +233,17 @@ __device__ __host__ __forceinline__ uint32_t next_epoch(uint32_t e) { return e %
 __device__ __forceinline__ uint8_t *tile_marks(const State &st, uint32_t epoch) { return st.tile_dirty + (epoch & 1u) * st.tile_stride; }
 __device__ __forceinline__ void mark_tile(const State &st, size_t lv, uint32_t epoch) { tile_marks(st, epoch)[lv >> TILE_SHIFT] = (uint8_t)epoch; }
 constexpr uint32_t ALIAS_CAP = 8192;
+constexpr uint32_t ALIAS_FILTER_WORDS = 2048;
+__device__ __forceinline__ uint32_t alias_hash(size_t li) { return ((uint32_t)li * 2654435761u) >> 16; }
+// may the table hold an entry for slot li?  (read past the vector L1: the bit may have been set by this very kernel)
+__device__ __forceinline__ bool alias_may_hold(const State &st, size_t li) {
+  const uint32_t h = alias_hash(li);
+  return (__hip_atomic_load(st.alias_filter + (h >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (h & 31u)) & 1u;
+}
+__device__ __forceinline__ void alias_note(const State &st, size_t li) {
+  const uint32_t h = alias_hash(li);
+  atomicOr(st.alias_filter + (h >> 5), 1u << (h & 31u));
+}
 // the slot with shard-local index li has (or may have) an owner: both levels of the chunk flags
 __device__ __forceinline__ void flag_owner_chunk(const State &st, size_t li) {
   const size_t c = li / OWNER_CHUNK;
@@ -256,13 +272,15 @@ __device__ __forceinline__ bool owner_insert(const State &st, size_t li, uint16_
   st.owner[li] = track;
   uint32_t n = st.alias[0];
   if (n > ALIAS_CAP) n = ALIAS_CAP;
-  for (uint32_t k = 0; k < n; ++k)  // a set holds an index once
-    if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+  if (n && alias_may_hold(st, li))
+    for (uint32_t k = 0; k < n; ++k)  // a set holds an index once
+      if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
   if (prev == OWNER_NONE || prev == track) return true;
   const uint32_t k = atomicAdd(&st.alias[0], 1u);  // prev's set keeps the index
   if (k >= ALIAS_CAP) return false;
   st.alias[2 + 2 * k] = (uint32_t)li;
   st.alias[3 + 2 * k] = prev;
+  alias_note(st, li);
   return true;
 }
 // removeParticleFromObj (object_layer.h:35-37): slot li leaves track's set
@@ -273,8 +291,9 @@ __device__ __forceinline__ void owner_erase(const State &st, size_t li, uint16_t
   }
   uint32_t n = st.alias[0];
   if (n > ALIAS_CAP) n = ALIAS_CAP;
-  for (uint32_t k = 0; k < n; ++k)
-    if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+  if (n && alias_may_hold(st, li))
+    for (uint32_t k = 0; k < n; ++k)
+      if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
 }
 
 // The same two for a kernel in which ONE thread owns all slots of a voxel (the ordered replays): `own` is the thread's
@@ -290,14 +309,16 @@ __device__ __forceinline__ bool owner_insert_local(const State &st, size_t li, u
   own = track;
   uint32_t n = touched ? st.alias[0] : n_alias;
   if (n > ALIAS_CAP) n = ALIAS_CAP;
-  for (uint32_t k = 0; k < n; ++k)  // a set holds an index once
-    if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+  if (n && alias_may_hold(st, li))
+    for (uint32_t k = 0; k < n; ++k)  // a set holds an index once
+      if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
   if (prev == OWNER_NONE || prev == track) return true;
   const uint32_t k = atomicAdd(&st.alias[0], 1u);  // prev's set keeps the index
   touched = true;
   if (k >= ALIAS_CAP) return false;
   st.alias[2 + 2 * k] = (uint32_t)li;
   st.alias[3 + 2 * k] = prev;
+  alias_note(st, li);
   return true;
 }
 __device__ __forceinline__ void owner_erase_local(const State &st, size_t li, uint16_t track, uint16_t &own, uint32_t n_alias,
@@ -309,8 +330,9 @@ __device__ __forceinline__ void owner_erase_local(const State &st, size_t li, ui
   }
   uint32_t n = touched ? st.alias[0] : n_alias;
   if (n > ALIAS_CAP) n = ALIAS_CAP;
-  for (uint32_t k = 0; k < n; ++k)
-    if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+  if (n && alias_may_hold(st, li))
+    for (uint32_t k = 0; k < n; ++k)
+      if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
 }
 
 // Garbage collection of the table of older memberships: deleted entries (track OWNER_NONE) go, the live ones keep their
@@ -321,7 +343,15 @@ __device__ __forceinline__ void alias_compact_wave(const State &st) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t na = st.alias[0];
   if (na == 0) return;
-  if (na > ALIAS_CAP) na = ALIAS_CAP;
+  if (na > ALIAS_CAP) {
+    // entries beyond the table's capacity were dropped: the sets are incomplete from here on.  alias[1] keeps saying so
+    // (SDM_ERR_CAPACITY at every synchronisation, sdm_stats.alias_overflowed) until sdm_clear / sdm_load_state - this
+    // very function used to erase the only trace of it by writing the clamped count back.
+    if (lane == 0) st.alias[1] = 1u;
+    na = ALIAS_CAP;
+  }
+  for (uint32_t k = lane; k < ALIAS_FILTER_WORDS; k += 64) st.alias_filter[k] = 0u;  // rebuilt from the survivors below
+  __threadfence();
   uint32_t keep = 0;
   for (uint32_t b0 = 0; b0 < na; b0 += 64) {
     const uint32_t k = b0 + lane;
@@ -336,6 +366,7 @@ __device__ __forceinline__ void alias_compact_wave(const State &st) {
       const uint32_t at = keep + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       st.alias[2 + 2 * at] = idx;
       st.alias[3 + 2 * at] = trk;
+      alias_note(st, idx);
     }
     keep += (uint32_t)__popcll(m);
   }

@@ -31,8 +31,9 @@ def main():
         dt = time.perf_counter() - t0
         if t % 20 == 19 or t == n - 1:
             st = m.stats(count_live=True)
-            print("frame %3d: live %7d particles in %6d voxels, visible %6d, births %6d, valid px %6d, %.2f ms (host-synchronised)" % (
-                t, st["live_particles"], st["live_voxels"], st["n_visible"], st.get("n_birth_success", -1), int(cloud["is_valid"].sum()), dt * 1e3), flush=True)
+            print("frame %3d: live %7d particles in %6d voxels, visible %6d, births %6d, moved %6d (re-inserted %6d), alias %5d, valid px %6d, %.2f ms (host-synchronised)" % (
+                t, st["live_particles"], st["live_voxels"], st["n_visible"], st.get("n_birth_success", -1), st.get("n_moved", -1),
+                st.get("n_move_reinserted", -1), st.get("alias_entries", -1), int(cloud["is_valid"].sum()), dt * 1e3), flush=True)
 
 
 if __name__ == "__main__":  # (render_frames spawns worker processes that import this module)
