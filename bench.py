@@ -668,9 +668,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "issue_mode": issue_mode,
             "config": {"workload": "%s: %dx%dx%d voxels, %d slots/voxel, %dx%d image, window %d, %s params, "
-                                   "6 dynamic objects, %d live particles of which %d are PREFILLED FILLER the camera cannot see "
-                                   "(below the ground plane, behind the walls: the map carries BASELINE's 2 M, the frame works on "
-                                   "what is visible), %d visible/frame; the workload the filter populated itself is `driven`"
+                                   "6 dynamic objects, %d live particles - what the first sweeps left of %d PREFILLED ones, FILLER the camera "
+                                   "cannot see (below the ground plane, behind the walls: the map carries BASELINE's 2 M, the frame works on "
+                                   "what is visible) -, %d visible/frame; the workload the filter populated itself is `driven`"
                                    % (args.config if world == 1 else "%s weak-scaled x%d" % (args.config, world),
                                       1 << cfg["x_n"], 1 << cfg["y_n"], 1 << cfg["z_n"], S, cfg["width"], cfg["height"],
                                       cfg["window_half"], synth.CONFIG_PARAMS[args.config], live, n_pre * world, n_vis),

@@ -1642,6 +1642,11 @@ __global__ __launch_bounds__(TPB) void k_visibility(Dims d, State st, Scratch sc
   // (requested with the frame's scalars: one dependent step less before the masks)
   const uint32_t fgen = (uint32_t)sc.fa->force_generic, fcx = (uint32_t)sc.cnt->flood_complex;
   const bool generic = (fgen | fcx) != 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // (this kernel is the flood's last consumer: Counters::vis_*)
+    sc.cnt->vis_flood_complex = fcx;
+    sc.cnt->vis_flood_rounds = sc.cnt->flood_rounds;
+    sc.cnt->vis_start_in_frustum = sc.cnt->start_in_frustum;
+  }
   const int bx = f.bb1[0] - f.bb0[0], by = f.bb1[1] - f.bb0[1], bz = f.bb1[2] - f.bb0[2];  // voxel box [bb0,bb1)
   if (bx <= 0 || by <= 0 || bz <= 0) return;
   const int wlo = f.bb0[0] >> 6, nwx = ((f.bb1[0] - 1) >> 6) - wlo + 1;

@@ -499,7 +499,7 @@ sdm_status check_counters(sdm_map *m, Counters *out) {
               "max(2 max_visible / height, 2 width slots) - raise max_visible -, or more than 2^21 in one pixel's bin");
     return SDM_ERR_CAPACITY;
   }
-  if (c.flood_rounds >= 256 && !c.flood_complex) {
+  if (c.vis_flood_rounds >= 256 && !c.vis_flood_complex) {
     set_error("flood", __FILE__, __LINE__, "frustum flood fill did not converge");
     return SDM_ERR_NOT_CONVERGED;
   }
@@ -864,7 +864,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.mv_nlist, 4);
   HIP_TRY(hipMemsetAsync(sc.mv_nlist, 0, 4 * sizeof(uint32_t), m->stream));
   A(sc.mv_nmem, 8192);
-  A(sc.mv_mem, move_member_elems());
+  A(sc.mv_mem, move_member_elems(n_slots));
   A(sc.mv_tot, move_total_elems());
   HIP_TRY(hipMemsetAsync(sc.mv_tot, 0, move_total_elems() * sizeof(uint32_t), m->stream));
   A(m->d_track_bits, 2048);
@@ -1782,6 +1782,15 @@ sdm_status sdm_update_raw_ex(sdm_map *m, const float *depth, const uint8_t *stat
     HIP_TRY(dev_alloc(&in.obj_masks, hw * n_objects));
     in.obj_masks_cap = n_objects;
   }
+  // (every argument is looked at before the first copy is queued, and every exit behind the first copy goes through the
+  // epilogue below that waits for the copy stream: the caller's buffers are its own again when this returns, also when it
+  // returns an error - the adapter rewrites its page-locked depth and mask buffers in place for the next update())
+  for (int k = 0; k < n_objects; ++k)
+    if (!objects[k].mask) {
+      set_error("sdm_update_raw_ex", __FILE__, __LINE__, "objects[k].mask is null");
+      return SDM_ERR_INVALID_ARGUMENT;
+    }
+  auto queue_and_run = [&]() -> sdm_status {
   sdm_status rc;
   const float *depth_dev = depth;
   if (!on_dev || resize) {
@@ -1801,7 +1810,6 @@ sdm_status sdm_update_raw_ex(sdm_map *m, const float *depth, const uint8_t *stat
   // masks that lie back to back in the caller's memory (the adapter's do) go up as one transfer
   bool masks_contiguous = !resize && n_objects > 1;
   for (int k = 0; k < n_objects; ++k) {
-    if (!objects[k].mask) return SDM_ERR_INVALID_ARGUMENT;
     if (k && objects[k].mask != objects[k - 1].mask + hw) masks_contiguous = false;
     a.track[k] = objects[k].track_id;
     a.label[k] = objects[k].label_id;
@@ -1849,8 +1857,10 @@ sdm_status sdm_update_raw_ex(sdm_map *m, const float *depth, const uint8_t *stat
   launch_labeled_cloud(d, a, depth_dev, in.static_mask, in.label_to_inst, in.obj_masks, in.bbox, m->d_cloud, s);
   const float posf[3] = {(float)cam_pos[0], (float)cam_pos[1], (float)cam_pos[2]};       // semantic_dsp_map.h:584
   const float qf[4] = {(float)cam_q[0], (float)cam_q[1], (float)cam_q[2], (float)cam_q[3]};  // :745
-  rc = sdm_update(m, depth_dev, m->d_cloud, posf, qf, moves, n_moves, remove_tracks, n_remove, flags | SDM_INPUT_ON_DEVICE,
-                  stop_after);
+  return sdm_update(m, depth_dev, m->d_cloud, posf, qf, moves, n_moves, remove_tracks, n_remove, flags | SDM_INPUT_ON_DEVICE,
+                    stop_after);
+  };
+  sdm_status rc = queue_and_run();
   (void)hipEventRecord(in.ev_free, s);
   // host buffers belong to the caller again when this returns (nothing is retained): wait for the copies, which ran
   // while the frame's launches were issued above
@@ -2315,12 +2325,12 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
   out->n_moved = c.n_moved;
   out->n_move_reinserted = c.n_move_reinserted;
   for (uint32_t k = 0; k < VIS_SHARDS; ++k) out->n_frustum_voxels += c.shard[k].fv;
-  out->bfs_start_in_frustum = c.start_in_frustum;
+  out->bfs_start_in_frustum = c.vis_start_in_frustum;
   for (uint32_t k = 0; k < VIS_SHARDS; ++k) {
     out->sweep_live_voxels += c.shard[k].sweep;
     out->sweep_tiles += c.shard[k].sweep_tiles;
   }
-  out->flood_rounds = c.flood_rounds;
+  out->flood_rounds = c.vis_flood_rounds;
   for (int a = 0; a < 3; ++a) out->restamped_slabs[a] = m->restamped[a];
   out->graph_frames = (int64_t)m->n_graph_frames;
   out->direct_frames = (int64_t)m->n_direct_frames;

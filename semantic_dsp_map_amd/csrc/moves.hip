@@ -1052,7 +1052,13 @@ void launch_tracks_with_particles(const Dims &d, const State &st, uint32_t *bitm
 
 size_t move_blocks(const Dims &d) { return ((size_t)d.v_count * d.S + MV_CHUNK - 1) / MV_CHUNK; }
 size_t move_count_elems() { return (size_t)MAX_MOVE_OBJECTS * MV_LIST_CAP + 1; }
-size_t move_member_elems() { return (size_t)MV_LIST_CAP * MV_CHUNK; }
+// member lists: one stretch of MV_CHUNK entries per listed chunk.  A map cannot list more chunks than it has; k_move_apply's
+// 1024 workgroups request their first position's stretch before they know the list's length, so at least that many
+// stretches exist (128 MiB for every map until round 5, 16 MiB for the small ones now).
+size_t move_member_elems(size_t n_slots) {
+  const size_t n_chunks = (n_slots + MV_CHUNK - 1) / MV_CHUNK;
+  return std::min<size_t>(MV_LIST_CAP, std::max<size_t>(n_chunks, 1024)) * MV_CHUNK;
+}
 size_t move_total_elems() { return (size_t)2 * MAX_MOVE_OBJECTS * MV_TOT_STRIDE; }
 
 // The launch sequence below is the same every frame (hipGraph): kernels of a frame without moving objects / removals
@@ -1120,6 +1126,7 @@ void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s) {
 // step 2 (after the counts of all shards are known): global ranks, transform, export of slab-crossing copies
 void launch_moves_transform(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, const int32_t *counts_all, int world,
                             int rank, hipStream_t s) {
+  // (1024 workgroups: move_member_elems counts on it)
   hipLaunchKernelGGL(k_move_apply, dim3(1024), dim3(TPB), 0, s, d, flt, st, sc, d.v_count != d.V ? counts_all : nullptr, world, rank);
 }
 

@@ -84,7 +84,10 @@ struct Counters {
   uint32_t overflow;
   uint32_t n_valid_px;
   uint32_t n_halo_dropped;  // slab-crossing copies beyond the export capacity of their destination (dropped, SDM_ERR_CAPACITY)
-  uint32_t pad[7];
+  // the flood flags (below) as THIS frame's visibility pass found them: the frustum chain of the next frame may start -
+  // and reset them - while this frame's later stages run, so what the host reads after the frame are these copies
+  uint32_t vis_flood_complex, vis_flood_rounds, vis_start_in_frustum;
+  uint32_t pad[4];
   // Atomics on one cache line retire one at a time (~12 ns each on MI355X) - same address or not.  Counters that
   // every wave bumps are therefore sharded by block index, one 128-byte line per shard; the per-shard
   // visible-particle counters also index per-shard regions of the work list.

@@ -217,7 +217,7 @@ void launch_emit_points(const Dims &d, const Frame &f, const State &st, const Em
 
 size_t move_blocks(const Dims &d);
 size_t move_count_elems();
-size_t move_member_elems();
+size_t move_member_elems(size_t n_slots);
 size_t move_total_elems();
 void launch_tracks_with_particles(const Dims &d, const State &st, uint32_t *bitmap, hipStream_t s);
 void launch_owner_flags(const Dims &d, const State &st, hipStream_t s);

@@ -7,6 +7,9 @@
 #   <tag>_sweep_pmc.json (+ CSVs)    HBM traffic of the sweep launches (FETCH_SIZE / WRITE_SIZE, separate passes)
 #   <tag>_dense_pmc.txt              SQ counters of the sweep kernels on the dense case
 #   <tag>_a7_sq.json                 SQ counters of the weight-update / visibility / birth / sweep kernels, C3 + busy scene
+#   <tag>_driven.json, <tag>_driven_kernel_stats.txt   the `driven` leg alone and its kernel trace
+#   <tag>_dense_split.txt            per-kernel times of the non-incremental sweep on the dense case + the streaming probes of this box
+#   <tag>_clear.txt                  sdm_clear, ten calls
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=${1:-r03}
 mkdir -p gpurun_out
@@ -19,4 +22,7 @@ rm -rf gpurun_out/prof_${tag}_stress
 tools/pmc_sweep.sh $tag
 tools/pmc_dense.sh $tag
 tools/pmc_a7.sh $tag
+tools/gpu_driven_stats.sh $tag > /dev/null 2>&1     # <tag>_driven.json, <tag>_driven_kernel_stats.txt
+tools/gpu_dense_split.sh > /dev/null 2>&1; cp gpurun_out/dense_split.txt gpurun_out/${tag}_dense_split.txt
+timeout 300 python tools/probes/clear_time.py 10 > gpurun_out/${tag}_clear.txt 2>&1
 ls -la gpurun_out | grep $tag
