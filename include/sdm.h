@@ -109,9 +109,12 @@ typedef struct {
   int8_t occ;
 } sdm_point;
 
-/* Per-frame limits of the object lists (the lists travel to the device as kernel arguments).  A caller with more
- * moving objects or removals in one frame splits them over calls: sdm_update rejects longer lists with
- * SDM_ERR_INVALID_ARGUMENT (sdm_last_error says so) and leaves the map untouched. */
+/* What one block of kernel arguments holds of the object lists.  A whole map takes lists of ANY length (round 5): they are
+ * worked off in batches of this size inside the frame - every object's particles are taken out before any is re-inserted
+ * and the noise draws run on across the batches, like moveParticlesInSetsByTransformations does it
+ * (mc_ring/operations.h:321-362); a frame with longer lists is issued launch by launch, not from the captured graph.
+ * A Z-slab SHARD (sdm_update_sharded, the split entry points) still rejects longer lists with SDM_ERR_INVALID_ARGUMENT:
+ * the shards exchange per-object counts and copies once per frame. */
 #define SDM_MAX_MOVES 48
 #define SDM_MAX_REMOVALS 128
 

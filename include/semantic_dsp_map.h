@@ -501,18 +501,10 @@ class SemanticDSPMap {
       }
       object_layer_->collect(global_time_stamp_, params_.max_obersevation_lost_time, moves, removals);
     }
-    // per-frame limits of the C ABI (SDM_MAX_MOVES / SDM_MAX_REMOVALS): a crowded frame degrades instead of being
-    // dropped - removals beyond the limit wait for the next frame, objects beyond it keep their particles in place
+    // (the lists go to the library whole: it works lists longer than SDM_MAX_MOVES / SDM_MAX_REMOVALS off in batches inside
+    // the frame, with the reference's order - semantic_dsp_map.h:588-736 loops over whatever the object layer hands it)
     removals.insert(removals.begin(), pending_removals_.begin(), pending_removals_.end());
     pending_removals_.clear();
-    if (removals.size() > (size_t)SDM_MAX_REMOVALS) {
-      pending_removals_.assign(removals.begin() + SDM_MAX_REMOVALS, removals.end());
-      removals.resize(SDM_MAX_REMOVALS);
-    }
-    if (moves.size() > (size_t)SDM_MAX_MOVES) {
-      std::cerr << "sdm: " << moves.size() << " moving objects in one frame, only the first " << SDM_MAX_MOVES << " are moved" << std::endl;
-      moves.resize(SDM_MAX_MOVES);
-    }
     times_.objects = ms_since(t_begin);
     clock::time_point t_phase = clock::now();
     if (packRawInputs(depth_value_mat, ins_seg_result) != 0) {

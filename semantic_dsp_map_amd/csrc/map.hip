@@ -127,6 +127,10 @@ struct sdm_map {
   int32_t stop_after = 0;
   uint32_t frame_flags = 0;
   int n_moves = 0, n_remove = 0;
+  // object lists longer than the frame block holds (MAX_MOVE_OBJECTS / MAX_REMOVE_TRACKS): the whole lists, worked off in
+  // batches by sdm_frame_moves / sdm_frame_predict (whole maps, launch by launch)
+  std::vector<sdm_object_move> moves_all;
+  std::vector<int32_t> removes_all;
   uint32_t mv_seq = 0;            // frames with moving objects so far (FrameArgs::mv_seq)
   uint32_t *d_track_bits = nullptr;  // sdm_tracks_with_particles: one bit per track id
   int32_t *d_counts_local = nullptr;
@@ -1111,11 +1115,18 @@ inline void stage_mark(sdm_map *m, int stage) {
 // frustum box; the frame block is complete afterwards except for the input pointers.
 sdm_status frame_host_prepare(sdm_map *m, const float cam_pos[3], const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
                               const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after) {
-  if (n_moves > MAX_MOVE_OBJECTS || n_remove > MAX_REMOVE_TRACKS) {
+  // Lists longer than the frame block holds are worked off in batches (sdm_frame_moves, sdm_frame_predict) - on a whole
+  // map.  A Z-slab shard exchanges per-object member counts and copies with the other shards once per frame: there the
+  // block's capacity is the limit.
+  if ((n_moves > MAX_MOVE_OBJECTS || n_remove > MAX_REMOVE_TRACKS) && (m->d.v_count != m->d.V || m->comm || m->capturing)) {
     set_error("sdm_update", __FILE__, __LINE__,
-              "more than SDM_MAX_MOVES (48) moving objects or SDM_MAX_REMOVALS (128) removals in one frame: split the call");
+              "more than SDM_MAX_MOVES (48) moving objects or SDM_MAX_REMOVALS (128) removals in one frame of a SHARDED map: split the call");
     return SDM_ERR_INVALID_ARGUMENT;
   }
+  m->moves_all.clear();
+  m->removes_all.clear();
+  if (n_moves > MAX_MOVE_OBJECTS) m->moves_all.assign(moves, moves + n_moves);
+  if (n_remove > MAX_REMOVE_TRACKS) m->removes_all.assign(remove_tracks, remove_tracks + n_remove);
   m->stop_after = stop_after;
   m->frame_flags = flags;
   for (int i = 0; i < 9; ++i) m->stage_ran[i] = false;
@@ -1137,18 +1148,20 @@ sdm_status frame_host_prepare(sdm_map *m, const float cam_pos[3], const float ca
   fa.f = m->f;
   // P2 / P3 inputs: the objects the object layer decided to move (semantic_dsp_map.h:588-693) and to wipe (:702-736)
   memset(&fa.ms, 0, sizeof(fa.ms));
-  fa.ms.n = n_moves;
-  for (int k = 0; k < n_moves; ++k) {
+  const int n_first = n_moves < MAX_MOVE_OBJECTS ? n_moves : MAX_MOVE_OBJECTS;  // (the first batch rides in the frame's first kernel)
+  fa.ms.n = n_first;
+  for (int k = 0; k < n_first; ++k) {
     fa.ms.track[k] = (uint16_t)moves[k].track_id;
     memcpy(fa.ms.T[k], moves[k].T, 12 * sizeof(float));
   }
-  fa.n_obj = n_moves;
+  fa.n_obj = n_first;
+  fa.mv_batch = 0;
   // (the parity of the per-object totals the member count adds up and k_move_apply reads and resets: it advances with
   // every frame in which the two run)
   if (n_moves > 0 && !stage_done(stop_after, 1)) m->mv_seq++;
   fa.mv_seq = m->mv_seq;
-  fa.n_remove = n_remove;
-  for (int k = 0; k < n_remove; ++k) fa.remove[k] = (uint16_t)remove_tracks[k];
+  fa.n_remove = n_remove < MAX_REMOVE_TRACKS ? n_remove : MAX_REMOVE_TRACKS;
+  for (int k = 0; k < fa.n_remove; ++k) fa.remove[k] = (uint16_t)remove_tracks[k];
   fa.force_generic = m->force_generic_flood;
   m->n_moves = n_moves;
   m->n_remove = n_remove;
@@ -1308,6 +1321,25 @@ sdm_status sdm_frame_moves(sdm_map *m) {
   if (m->capturing || m->n_moves > 0) {
     launch_moves_transform(m->d, m->flt, m->st, m->sc, counts_all, w, r, m->stream);
     m->mv_pending = false;  // k_move_apply has reset the totals the next member count adds to
+    // the rest of a long object list, MAX_MOVE_OBJECTS at a time: the block's list is replaced (one launch that is also
+    // the batch's member count), then its members are copied out and invalidated.  The reference takes ALL objects'
+    // particles out before it re-inserts any (operations.h:321-362): so does this - k_move_replay comes after the last
+    // batch - and the ranks, i.e. the noise draws and the insertion order, run on from batch to batch.
+    for (size_t k0 = MAX_MOVE_OBJECTS; k0 < m->moves_all.size(); k0 += MAX_MOVE_OBJECTS) {
+      const int nb = (int)std::min<size_t>(MAX_MOVE_OBJECTS, m->moves_all.size() - k0);
+      FrameArgs &fa = m->fa;
+      memset(&fa.ms, 0, sizeof(fa.ms));
+      fa.ms.n = nb;
+      for (int k = 0; k < nb; ++k) {
+        fa.ms.track[k] = (uint16_t)m->moves_all[k0 + k].track_id;
+        memcpy(fa.ms.T[k], m->moves_all[k0 + k].T, 12 * sizeof(float));
+      }
+      fa.n_obj = nb;
+      fa.mv_seq = ++m->mv_seq;
+      fa.mv_batch += 1;
+      launch_moves_batch(m->d, m->st, m->sc, fa, m->stream);
+      launch_moves_transform(m->d, m->flt, m->st, m->sc, counts_all, w, r, m->stream);
+    }
   }
   return SDM_OK;
 }
@@ -1327,6 +1359,13 @@ sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev) {
 
   // P3: removals (semantic_dsp_map.h:702-736)
   if (m->capturing || m->n_remove > 0) launch_remove(d, m->st, m->sc, s);
+  for (size_t k0 = MAX_REMOVE_TRACKS; k0 < m->removes_all.size(); k0 += MAX_REMOVE_TRACKS) {  // the rest of a long removal list
+    FrameArgs &fa = m->fa;
+    fa.n_remove = (int)std::min<size_t>(MAX_REMOVE_TRACKS, m->removes_all.size() - k0);
+    for (int k = 0; k < fa.n_remove; ++k) fa.remove[k] = (uint16_t)m->removes_all[k0 + k];
+    launch_set_frame(m->d_fa[0], fa, s);
+    launch_remove(d, m->st, m->sc, s);
+  }
   stage_mark(m, 3);
   if (stage_done(stop_after, 3)) return SDM_OK;
 
@@ -1663,6 +1702,7 @@ sdm_status sdm_update(sdm_map *m, const float *depth, const sdm_labeled_point *c
   const bool would_be_plain = stop_after == 0 && (flags & ~(uint32_t)SDM_INPUT_ON_DEVICE) == 0 && !m->profiling &&
                               m->cfg.shard_count == 1 && !m->comm && !m->ck_user && !m->counts_local_user &&
                               m->stream == m->own_stream && !m->sweep_all && !m->stamps_dirty &&
+                              n_moves <= MAX_MOVE_OBJECTS && n_remove <= MAX_REMOVE_TRACKS &&  // (longer lists: batches, launch by launch)
                               m->global_time_stamp <= 65535u;  // (beyond: the literal birth replay, not in the captured graphs)
   const bool plain = m->use_graph && would_be_plain;
   if (plain) {

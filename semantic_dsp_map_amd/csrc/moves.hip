@@ -576,6 +576,10 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   const MoveSet &ms = sc.fa->ms;
   const uint32_t par = sc.fa->mv_seq & 1u;
+  // ranks continue where the batch of objects before this one ended (nobody writes that word in this launch: block 0
+  // writes the OTHER parity's)
+  const uint32_t batch = sc.fa->mv_batch;
+  const uint32_t e_base = batch ? sc.cnt->n_moved_b[(batch - 1u) & 1u] : 0u;
   __shared__ uint32_t obj_base[MAX_MOVE_OBJECTS];  // global rank of the object's next member in this chunk
   __shared__ uint32_t obj_first[MAX_MOVE_OBJECTS]; // global rank of the object's first member on this shard
   __shared__ uint32_t c_here[MAX_MOVE_OBJECTS];    // the object's members in this chunk
@@ -600,7 +604,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
     } else {
       for (int k = 0; k < (int)threadIdx.x; ++k) run += tot_l[k];
     }
-    obj_first[threadIdx.x] = run;
+    obj_first[threadIdx.x] = e_base + run;
   }
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) {
@@ -611,8 +615,9 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
       } else {
         for (int k = 0; k < n_obj; ++k) total += tot_l[k];
       }
-      sc.cnt->n_moved = total;
-      if (total > sc.cap_move || sc.cur->move_list_overflow) sc.cnt->overflow = 1;
+      sc.cnt->n_moved = e_base + total;
+      sc.cnt->n_moved_b[batch & 1u] = e_base + total;
+      if (e_base + total > sc.cap_move || sc.cur->move_list_overflow) sc.cnt->overflow = 1;
     }
     // the totals of the next frame with moving objects start at zero (its member count runs after this kernel)
     if (threadIdx.x < MAX_MOVE_OBJECTS) sc.mv_tot[((size_t)(par ^ 1u) * MAX_MOVE_OBJECTS + threadIdx.x) * MV_TOT_STRIDE] = 0;
@@ -1088,6 +1093,13 @@ void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32
     hipLaunchKernelGGL(k_move_members, dim3(MV_GRID), dim3(TPB), 0, s, st, ma, fa);
   // the per-object counts are only needed as a separate row when they are exchanged between shards
   if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, counts_local, sc, fa);
+}
+
+// the next batch of a long object list: the frame block with that batch's objects replaces the main block, and the member
+// count of those objects runs - in the same launch (k_move_members_v: one block stores the block, all count)
+void launch_moves_batch(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa_batch, hipStream_t s) {
+  const MembersArgs ma = members_args(d, sc);
+  hipLaunchKernelGGL(k_move_members_v, dim3(MV_GRID), dim3(TPB), 0, s, st, ma, fa_batch, const_cast<FrameArgs *>(sc.fa));
 }
 
 // arguments of k_frame_begin in the order of its parameter list; `fa` is the frame block that goes by value

@@ -87,7 +87,8 @@ struct Counters {
   // the flood flags (below) as THIS frame's visibility pass found them: the frustum chain of the next frame may start -
   // and reset them - while this frame's later stages run, so what the host reads after the frame are these copies
   uint32_t vis_flood_complex, vis_flood_rounds, vis_start_in_frustum;
-  uint32_t pad[4];
+  uint32_t n_moved_b[2];  // members moved up to and including batch b of this frame's object list, by batch parity (FrameArgs::mv_batch)
+  uint32_t pad[2];
   // Atomics on one cache line retire one at a time (~12 ns each on MI355X) - same address or not.  Counters that
   // every wave bumps are therefore sharded by block index, one 128-byte line per shard; the per-shard
   // visible-particle counters also index per-shard regions of the work list.

@@ -48,6 +48,11 @@ struct FrameArgs {
   int n_obj;           // moving objects of this frame (= ms.n)
   int n_remove;
   uint32_t mv_seq;     // number of frames with moving objects so far: its parity selects the per-object totals (Scratch::mv_tot)
+  // A frame with more than MAX_MOVE_OBJECTS moving objects runs member count + k_move_apply once per BATCH of objects (the
+  // block's object list is rewritten between them), then ONE k_move_replay: all copies are taken and invalidated before any
+  // is re-inserted, and the global ranks run on across the batches (operations.h:321-362).  mv_batch = index of the batch
+  // the block holds; batch b starts its ranks where batch b - 1 ended (Counters::n_moved_b).
+  uint32_t mv_batch;
   int force_generic;   // test hook: always run the generic 3-D frustum flood
   const float *depth;  // this frame's inputs (device)
   const sdm_labeled_point *cloud;
@@ -168,6 +173,7 @@ struct FrameBeginLaunch {
   static const void *kernel();
 };
 void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s);
+void launch_moves_batch(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa_batch, hipStream_t s);
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, const FrameArgs *fa, uint32_t remark,
                       hipStream_t s);
 size_t tile_mark_bytes(const Dims &d);  // State::tile_dirty, padded for the sweep's tile scan
