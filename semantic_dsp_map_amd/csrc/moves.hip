@@ -508,9 +508,15 @@ __device__ __forceinline__ void move_round_with_aliases(const Dims &d, const Fra
         sc.cnt->overflow = 1;  // a slot in more than four moving sets at once: not handled
       }
     }
-  // members of object k in this wave = lanes one of whose memberships is k, in lane (= index) order.  (This path is
-  // rare; one ballot per moving object keeps it light on registers.)
-  for (int k = 0; k < n_obj; ++k) {
+  // members of object k in this wave = lanes one of whose memberships is k, in lane (= index) order.  (One ballot per
+  // moving object keeps it light on registers.  A wave's 64 slots are 8 voxels: in nearly every round none of them belongs
+  // to a moving object, and the wave skips the ballots - a dozen objects x 16 rounds of them were most of what a chunk
+  // with an older membership cost, 30 us per such chunk on the `driven` workload.)
+  bool any_member = false;
+#pragma unroll
+  for (int c = 0; c < MAXM; ++c) any_member = any_member || mo[c] != 0xFF;
+  const bool wave_has_members = __ballot(any_member) != 0ull;
+  for (int k = 0; wave_has_members && k < n_obj; ++k) {
     int q = -1;
 #pragma unroll
     for (int c = 0; c < MAXM; ++c)
