@@ -372,7 +372,7 @@ def render_frames(cfg, params, scene_kw, frames, workers=None):
     import multiprocessing as mp
     import os
     frames = list(frames)
-    workers = min(workers or min(64, os.cpu_count() or 1), len(frames))
+    workers = min(workers or min(128, os.cpu_count() or 1), len(frames))
     jobs = [(cfg, params, scene_kw, t) for t in frames]
     if workers <= 1:
         return [_render_job(j) for j in jobs]
