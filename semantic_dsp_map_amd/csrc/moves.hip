@@ -488,7 +488,7 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
 // then belong to several moving objects.  mo[0] is its primary membership (owner[]), mo[1..] the older ones.
 constexpr uint32_t CA_CAP = 512;
 __device__ __forceinline__ void move_round_with_aliases(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms,
-                                                     const State &st, const Scratch &sc, size_t li, size_t n_slots, int n_obj,
+                                                     const State &st, const Scratch &sc, size_t li, uint16_t owner_li, int n_obj,
                                                      const uint16_t *tracks, const uint32_t *obj_base,
                                                      uint32_t (*wave_cnt)[MAX_MOVE_OBJECTS], const uint32_t *ca_idx,
                                                      const uint32_t *ca_ent, const uint8_t *ca_obj, uint32_t n_ca, uint64_t lt_mask,
@@ -496,7 +496,7 @@ __device__ __forceinline__ void move_round_with_aliases(const Dims &d, const Fra
   constexpr int MAXM = 4;
   uint8_t mo[MAXM] = {0xFF, 0xFF, 0xFF, 0xFF};
   uint32_t ment[MAXM] = {0, 0, 0, 0}, mrank[MAXM] = {0, 0, 0, 0};
-  if (li < n_slots) mo[0] = obj_of(st.owner[li], tracks, n_obj);
+  mo[0] = obj_of(owner_li, tracks, n_obj);  // (OWNER_NONE beyond the map's slots: no object)
   int nm = 1;
   for (uint32_t c = 0; c < n_ca; ++c)
     if (ca_idx[c] == (uint32_t)li) {
@@ -594,6 +594,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
   __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
   __shared__ uint32_t ca_idx[CA_CAP], ca_ent[CA_CAP], ca_n;
   __shared__ uint8_t ca_obj[CA_CAP];
+  __shared__ uint16_t ca_own[MV_ITEMS][TPB];  // the owner entries of a chunk on the alias path (column = thread)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const size_t n_slots = (size_t)d.v_count * d.S;
   if (threadIdx.x < MAX_MOVE_OBJECTS) {
@@ -688,6 +689,20 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
         __syncthreads();
         const uint32_t n_ca = ca_n < CA_CAP ? ca_n : CA_CAP;
         if (threadIdx.x == 0 && ca_n > CA_CAP) sc.cnt->overflow = 1;
+        // (the thread's sixteen owner entries, requested together and parked in LDS: loaded round by round they were
+        // sixteen dependent round trips, most of what such a chunk cost; the round loop stays rolled - unrolled it is
+        // sixteen copies of the ranking code, more than the instruction cache holds)
+        {
+          uint16_t ow[MV_ITEMS];
+#pragma unroll
+          for (int r = 0; r < MV_ITEMS; ++r) {
+            const size_t li = base + (size_t)r * TPB + threadIdx.x;
+            ow[r] = li < n_slots ? st.owner[li] : OWNER_NONE;
+          }
+#pragma unroll
+          for (int r = 0; r < MV_ITEMS; ++r) ca_own[r][threadIdx.x] = ow[r];
+        }
+#pragma unroll 1
         for (int r = 0; r < MV_ITEMS; ++r) {
           if (threadIdx.x < MAX_MOVE_OBJECTS) {
 #pragma unroll
@@ -695,7 +710,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
           }
           __syncthreads();
           const size_t li = base + (size_t)r * TPB + threadIdx.x;
-          move_round_with_aliases(d, f, flt, ms, st, sc, li, n_slots, n_obj, tracks, obj_base, wave_cnt, ca_idx, ca_ent, ca_obj, n_ca,
+          move_round_with_aliases(d, f, flt, ms, st, sc, li, ca_own[r][threadIdx.x], n_obj, tracks, obj_base, wave_cnt, ca_idx, ca_ent, ca_obj, n_ca,
                                   lt_mask, wid);
           __syncthreads();
           if (threadIdx.x < MAX_MOVE_OBJECTS) {

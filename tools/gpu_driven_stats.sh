@@ -7,7 +7,7 @@ tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 timeout 900 python bench.py --only-driven > gpurun_out/${tag}_driven.json 2> gpurun_out/${tag}_driven.err
-SDM_GRAPH=0 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag}_drv -o drv -- python bench.py --only-driven > gpurun_out/${tag}_driven_prof.log 2>&1
+SDM_GRAPH=0 SDM_RENDER_WORKERS=32 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag}_drv -o drv -- python bench.py --only-driven > gpurun_out/${tag}_driven_prof.log 2>&1
 python tools/trace_db.py gpurun_out/prof_${tag}_drv/drv_results.db 6 > gpurun_out/${tag}_driven_kernel_stats.txt 2>&1
 rm -rf gpurun_out/prof_${tag}_drv
 python - <<PY
