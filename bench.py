@@ -167,7 +167,15 @@ def driven_run(synth, sharded, steps=20, cpu_frames=3):
     scene = synth.Scene(cfg, **scene_kw)
     n_prof = 4
     t0 = time.time()
-    rendered = synth.render_frames(cfg, params, scene_kw, range(n_grow + steps + n_prof))  # worker processes: ~1 s per frame on one core
+    cache = os.environ.get("SDM_DRIVEN_CACHE")  # (development: A/B runs of the library on the same rendered frames)
+    if cache and os.path.exists(cache):
+        import pickle
+        rendered = pickle.load(open(cache, "rb"))
+    else:
+        rendered = synth.render_frames(cfg, params, scene_kw, range(n_grow + steps + n_prof))  # worker processes: seconds per frame on one core
+        if cache:
+            import pickle
+            pickle.dump(rendered, open(cache, "wb"), protocol=4)
     t_render = time.time() - t0
     eng = sharded.NativeShardedMap(cfg, params, 0, 1, 0)
     m = eng.map

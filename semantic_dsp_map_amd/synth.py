@@ -373,7 +373,7 @@ def render_frames(cfg, params, scene_kw, frames, workers=None):
     import os
     frames = list(frames)
     # (SDM_RENDER_WORKERS: fewer of them under a profiler that attaches to every child process)
-    workers = min(workers or int(os.environ.get("SDM_RENDER_WORKERS", "0")) or min(128, os.cpu_count() or 1), len(frames))
+    workers = min(workers or int(os.environ.get("SDM_RENDER_WORKERS", "0")) or min(64, os.cpu_count() or 1), len(frames))
     jobs = [(cfg, params, scene_kw, t) for t in frames]
     if workers <= 1:
         return [_render_job(j) for j in jobs]
