@@ -457,6 +457,10 @@ sdm_status sdm_debug_fill_dense(sdm_map *m);
  * worst case for the track vote; mode 1: every voxel draws one (a voxel of a real map holds particles of one surface),
  * one voxel in 16 two */
 sdm_status sdm_debug_fill_dense_ex(sdm_map *m, int32_t mode);
+/* Test hook: how many groups of 512 voxels carry the non-incremental sweep's "every chunk was dense" hint right now, i.e.
+ * will be skipped by its classification launch and classified by the evaluating launch itself next time
+ * (tests/test_sweep_dense_gpu.py makes sure its repeated sweeps do take that path). */
+sdm_status sdm_debug_hinted_groups(sdm_map *m, int64_t *n_out);
 
 /* ---- device-side unit tests of the hand-written primitives (tests/test_primitives_gpu.py) */
 sdm_status sdm_test_scan(const uint32_t *in, uint32_t *out, int64_t n);

@@ -174,6 +174,7 @@ def load_library():
         "sdm_host_numa_node_early": [i32],
         "sdm_debug_fill_dense": [vp],
         "sdm_debug_fill_dense_ex": [vp, i32],
+        "sdm_debug_hinted_groups": [vp, C.POINTER(C.c_int64)],
         "sdm_test_scan": [vp, vp, i64],
         "sdm_test_sort_pairs": [vp, vp, vp, vp, i64, i32],
     }
@@ -557,6 +558,11 @@ class SdmMap:
 
     def fill_dense_ex(self, mode):
         _check(self.L, self.L.sdm_debug_fill_dense_ex(self.h, mode), "sdm_debug_fill_dense_ex")
+
+    def hinted_groups(self):
+        n = C.c_int64()
+        _check(self.L, self.L.sdm_debug_hinted_groups(self.h, C.byref(n)), "sdm_debug_hinted_groups")
+        return n.value
 
     def fill_dense(self):
         _check(self.L, self.L.sdm_debug_fill_dense(self.h), "sdm_debug_fill_dense")

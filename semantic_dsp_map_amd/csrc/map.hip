@@ -2677,6 +2677,17 @@ sdm_status sdm_debug_fill_dense_ex(sdm_map *m, int32_t mode) {
   return SDM_OK;
 }
 sdm_status sdm_debug_fill_dense(sdm_map *m) { return sdm_debug_fill_dense_ex(m, 0); }
+sdm_status sdm_debug_hinted_groups(sdm_map *m, int64_t *n_out) {
+  if (!m || !n_out) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  std::vector<uint8_t> h(grp_hint_bytes(m->d.v_count));
+  HIP_TRY(hipMemcpyAsync(h.data(), m->st.grp_hint, h.size(), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  int64_t n = 0;
+  for (uint8_t b : h) n += b != 0;
+  *n_out = n;
+  return SDM_OK;
+}
 
 #ifdef SDM_AB_TIMERS
 extern "C++" {

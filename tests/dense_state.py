@@ -7,7 +7,9 @@ import numpy as np
 from semantic_dsp_map_amd import binding
 
 
-def random_state(cfg, seed):
+def random_state(cfg, seed, run=1):
+    """run: chunks of one kind come in aligned runs of this many (run = 8: whole 512-voxel groups - what one wave of the
+    non-incremental sweep's kernels takes - are dense, sparse or empty, so that the sweep's group hints come into play)"""
     rng = np.random.default_rng(seed)
     NX, NY, NZ, S = 1 << cfg["x_n"], 1 << cfg["y_n"], 1 << cfg["z_n"], 1 << cfg["p_n"]
     V = NX * NY * NZ
@@ -18,7 +20,8 @@ def random_state(cfg, seed):
     vox = np.arange(V, dtype=np.int64)
     vx, vy, vz = vox & (NX - 1), (vox >> cfg["x_n"]) & (NY - 1), vox >> (cfg["x_n"] + cfg["y_n"])
     # per chunk of 64 voxels: 0 = empty, 1 = a few voxels hold something, 2 = every voxel does
-    kind = rng.choice(3, size=(V + 63) // 64, p=[0.25, 0.25, 0.5])[vox >> 6]
+    n_runs = ((V + 63) // 64 + run - 1) // run
+    kind = rng.choice(3, size=n_runs, p=[0.25, 0.25, 0.5])[(vox >> 6) // run]
     holds = (kind == 2) | ((kind == 1) & (rng.random(V) < 0.1))
     status = st["status"].reshape(V, S)
     status[:, 0] = 5                                              # TIMEPTC

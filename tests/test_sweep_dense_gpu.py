@@ -40,3 +40,43 @@ def test_non_incremental_sweep_on_a_dense_random_state(p_n, seed, x_n):
     # the state does exercise the rules: occupied, guessed-occupied and empty results all occur
     assert (vo["occ"] == 1).any() and (vo["occ"] == 2).any() and (vo["occ"] == 0).any() and (vo["occ"] < 0).any()
     g.close()
+
+
+@pytest.mark.parametrize("seed,x_n", [(11, 5), (12, 6), (13, 7)])
+def test_group_hints_repeated_non_incremental_sweeps(seed, x_n):
+    """The second and later non-incremental sweeps of a map: groups of 512 voxels whose chunks were all dense in the sweep
+    before are skipped by k_occupancy_scan and classified by k_occupancy_dense itself (State::grp_hint).  The hint is about
+    speed only - so the sweeps must give the oracle's results whatever has happened to a hinted group in between:
+    nothing, births, culls and object moves in it, ring shifts on z (every frame) and on x and y (frames 4-5) that re-stamp
+    slabs through it (voxels of hinted groups become unobserved, are emptied by culls, get new particles).  Every
+    frame here ends in a NON-incremental sweep (sdm_set_params before it: the threshold 'may have changed'), compared
+    bit for bit: state, flags' effects and every voxel result."""
+    cfg = dict(synth.CONFIGS["T0"], p_n=3, x_n=x_n)
+    params = synth.PARAMS["vkitti2"]
+    sc = synth.Scene(cfg, n_dynamic=2, seed=5)
+    o, g = pu.make_pair(cfg, params, synth.noise_table())
+    st = random_state(cfg, seed, run=8)      # whole groups dense / sparse / empty
+    (sx, sy, sz), ring = stamps_for(o)
+    for m in (o, g):
+        m.load_state(st)
+        m.set_stamps(sx, sy, sz)
+        m.set_ring_state(ring)
+    n_occ, n_hint = [], []
+    for t in range(6):
+        depth, cloud, pos, q = sc.render(t, params)
+        pos = pos + np.array([0.0, 0.0, 0.45 * t], np.float32)   # (a ring shift on z every frame: slabs through hinted groups are re-stamped)
+        if t >= 4:   # the camera jumps sideways and up: x and y slabs through EVERY group are re-stamped, part of each hinted group turns unobserved
+            pos = pos + np.array([2.1, 0.9, 0.0], np.float32) * (t - 3)
+        for m in (o, g):
+            m.set_params(params)     # the next sweep is a non-incremental one
+        o.update(depth, cloud, pos, q, sc.moves(t))
+        g.update(depth, cloud, pos, q, sc.moves(t), sync=True)
+        rep = pu.compare_maps(o, g, 8, check_results=True, tag="frame %d: " % t)
+        assert not rep, "\n".join(rep)
+        n_occ.append(int((g.voxels()["occ"] > 0).sum()))
+        n_hint.append(g.hinted_groups())
+    assert min(n_occ) > 1000, n_occ
+    # the sweeps after the first one did find hinted groups (about half of the state's groups are dense), and the jumps took
+    # some of the hints away again
+    assert n_hint[0] > (1 << (x_n + 10)) // 512 // 8 and n_hint[-1] < n_hint[0], n_hint
+    g.close()
