@@ -239,6 +239,15 @@ def driven_run(synth, sharded, steps=20, cpu_frames=3):
                        "voxels and %d visible per frame are what the filter and the camera yield"
                        % (n_grow, n_grow * scene.speed, scene_kw["n_static"], scene_kw["n_dynamic"], scene.speed, scene_kw["yaw_rate_deg"], steps,
                           stats["live_particles"], stats["live_voxels"], int(np.mean(vis_l)))}
+    # the non-incremental sweep on this map (what the first sweep after sdm_load_state / sdm_set_params costs on a map the
+    # filter built: its live voxels are surfaces, not the evenly strewn filler of the headline map), bytes as in
+    # roofline.full_evaluation: stamp, flag read, result and flag written per voxel + the records of the live voxels
+    m.time_occupancy_sweep(iters=200)
+    full_ms = m.time_occupancy_sweep(iters=10)
+    full_bytes = V * (2 + 1 + 8 + 1) + stats["live_voxels"] * 10 * (1 << cfg["p_n"])
+    res["full_evaluation"] = {"avg_launch_ms": round(full_ms, 5), "bytes_per_launch": int(full_bytes),
+                              "frac": round(full_bytes / full_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4), "launches_timed": 10,
+                              "untimed_launches_before": 201}
     if cpu_frames > 0:
         from oracle import oracle as orc
         o = orc.OracleMap(dict(cfg, bin_order=0), params, noise)
@@ -595,14 +604,18 @@ def main():
         # first the non-incremental launch on the benchmark state: every tile, every voxel's result written, every voxel
         # that holds a live slot evaluated (what each sweep did before the clean/dirty state, and what the first sweep
         # after sdm_load_state / sdm_set_params does)
+        # (the CPU leg above left the GPU idle for seconds: the clocks come back up over the first milliseconds of work, and
+        # ten launches are over in less than one - untimed launches first, for each case)
+        m.time_occupancy_sweep(iters=200)
         full_ms = m.time_occupancy_sweep(iters=10)
         full_bytes = V * (2 + 1 + 8 + 1) + live_vox_local * 10 * S
         roofline["full_evaluation"] = {"kernel": "k_occupancy_scan<%d> + k_occupancy_dense<%d> (two launches, timed together)" % (S, S), "bytes_per_launch": full_bytes,
                                        "avg_launch_ms": round(full_ms, 5),
                                        "achieved": round(full_bytes / full_ms / 1e6, 1),
                                        "frac": round(full_bytes / full_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
-                                       "launches_timed": 10}
+                                       "launches_timed": 10, "untimed_launches_before": 201}
         m.fill_dense()
+        m.time_occupancy_sweep(iters=40)
         dense_ms = m.time_occupancy_sweep(iters=10)
         dense_bytes = V * (2 + 1 + 8 + 1 + 10 * S)  # stamp, flag read; result, flag written; record read
         roofline["dense_case"] = {"kernel": "k_occupancy_scan<%d> + k_occupancy_dense<%d> (two launches, timed together)" % (S, S), "bytes_per_launch": dense_bytes,
@@ -615,6 +628,7 @@ def main():
         # the same with the track ids of a real map: a voxel holds particles of ONE surface, i.e. one track id (one voxel
         # in 16 two: object borders) - the vote then takes its single-track path
         m.fill_dense_ex(1)
+        m.time_occupancy_sweep(iters=40)
         surf_ms = m.time_occupancy_sweep(iters=10)
         roofline["dense_case_surface"] = {"kernel": roofline["dense_case"]["kernel"], "bytes_per_launch": dense_bytes,
                                           "avg_launch_ms": round(surf_ms, 5), "achieved": round(dense_bytes / surf_ms / 1e6, 1),

@@ -761,7 +761,7 @@ constexpr int OCC_CHUNKS = OCC_TILE / OCC_CHUNK;
 constexpr int OCC_WAVES = TPB / 64;
 constexpr int OCC_CPW = OCC_CHUNKS / OCC_WAVES;  // chunks per wave
 #ifndef SDM_OCC_DENSE_MIN
-#define SDM_OCC_DENSE_MIN 16
+#define SDM_OCC_DENSE_MIN 32
 #endif
 constexpr uint32_t OCC_DENSE_MIN = SDM_OCC_DENSE_MIN;
 
@@ -788,13 +788,14 @@ __device__ __forceinline__ void occ_scan_fetch(const Dims &d, const State &st, u
 
 // (registers: told to fit 8 waves per SIMD the compiler finds an allocation with 64 registers and no spills at S <= 8;
 // left alone it takes 91, i.e. 5 resident workgroups per CU instead of 8 - this launch lives on resident workgroups)
-template <int S>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 : 4, S <= 8 ? 8 : 4))) void k_occupancy_scan(Dims d, float occ_threshold, State st, Counters *cnt,
-                                                        unsigned long long *__restrict__ need, uint32_t n_tiles, uint32_t remark) {
+template <int S, bool LISTS>
+__device__ __forceinline__ void occupancy_scan_tile(const Dims &d, float occ_threshold, const State &st, Counters *cnt, unsigned long long *__restrict__ need,
+                                                    uint32_t n_tiles, uint32_t remark) {
   // the tile's results, 64 bytes (8 voxels) per thread; the 16-byte pieces of a row are swizzled so that neither the
   // row-wise writes nor the lane-linear reads run into bank conflicts
   __shared__ v4u res_stage[TPB * 4];
   __shared__ uint16_t live_list[OCC_CHUNKS * (OCC_DENSE_MIN - 1)];  // a sparse chunk lists fewer than OCC_DENSE_MIN
+  static_assert(OCC_CHUNKS * (OCC_DENSE_MIN - 1) <= OCC_LIST_CAP, "a tile's list fits its segment of State::occ_list");
   __shared__ unsigned long long chunk_mask[OCC_CHUNKS];
   __shared__ uint32_t n_live;
   auto stage_slot = [&](uint32_t v) -> v2u * {  // where voxel v of the tile sits in the stage
@@ -900,35 +901,78 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 
     if (tid < OCC_CHUNKS && blk0 + tid * OCC_CHUNK < d.v_count)
       need[(size_t)tile * OCC_CHUNKS + tid] = chunk_mask[tid];
     const uint32_t nl = n_live;
-#pragma unroll 1
-    for (uint32_t k0 = 0; k0 < nl; k0 += TPB) {  // workgroup-uniform
-      const uint32_t k = k0 + tid;
-      if (k < nl) {
-        const uint32_t tv = live_list[k], lv = blk0 + tv;
-        uint16_t ts1[S], trk[S];
-        uint8_t st1[S], lab[S];
-        float wv[S];
-        const size_t base = (size_t)lv * S;
-        load_vec<rec_align(S)>(st1, st.status + base * REC_STATUS);
-        load_vec<rec_align(S)>(wv, st.w + base * REC_W);
-        load_vec<rec_align(S)>(ts1, st.ts + base * REC_TS);
-        load_vec<rec_align(S)>(trk, st.track + base * REC_TRACK);
-        load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
-        uint32_t rx, ry, rz;
-        voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
-        const uint32_t smax = stamp_max(st, rx, ry, rz);
-        // everything of the record is requested before anything is looked at: left alone, the compiler (held to 64
-        // registers) sank each load to its first use - five dependent round trips per listed voxel instead of one
-        __builtin_amdgcn_sched_barrier(0);
-        sdm_voxel_result out;
-        // (the general version only: the plain one next to it costs registers and was measured to gain nothing here)
-        occupancy_evaluate<S, false>(st, occ_threshold, remark, lv, smax, ts1, st1, wv, trk, lab, out);
-        v2u o;
-        __builtin_memcpy(&o, &out, 8);
-        *stage_slot(tv) = o;
+    // The voxels the tile's sparse chunks listed.  Two ways, chosen by the host per sweep from what the sweep before it
+    // found (State::occ_shard; every voxel gets the same result either way):
+    //
+    // LISTS - the tile hands its list over (State::occ_list, one unit of State::occ_unit per OCC_LIST_UNIT entries) and
+    // k_occupancy_listed, the launch behind this one, gives every unit a workgroup of its own, all at once; the result
+    // slots leave here as zeros with the rest of the tile.  This is for maps the filter grew: particles on surfaces, a
+    // few hundred tiles with dozens to hundreds of listed voxels among thousands with none.  Evaluated here, each such
+    // tile went round trip, evaluation, round trip, evaluation while its 16 KB of results waited in LDS, and the launch
+    // ran on when the rest had drained: 65 us against 40 us for the empty map on the `driven` map (36 K voxels that hold
+    // something), 41 + 7 us with the lists.
+    //
+    // not LISTS - the loop below.  For a map where no tile or nearly every tile lists something the extra launch is 4 us
+    // for nothing or worse: on the benchmark map (291 K voxels that hold something, strewn evenly - 35 per tile, none
+    // in a dense chunk) the list launch takes 32 us - 17 us for 291 K records of 80 bytes at random places (two 128-byte
+    // lines each: 73 MB, DRAM rows opened for 128 bytes), 10 us for the 8-byte results written into lines this launch
+    // has just stored, 1.5 us for the evaluation itself - 83 us in all against 75 with the loop, which hides part of
+    // the records behind the stream (41 us for this launch with the loop cut out, 65 us with it).  Also measured there
+    // and not kept (tools/gpu_full_split.sh): the rows nothing is evaluated in stored before the loop (73 against 68);
+    // the plain evaluation with its admission test (spills at 64 registers, 74 against 69 at 72); the loop dealt out
+    // to the four waves (79 against 73) or to the wave tile % 4 (no change).
+    if constexpr (LISTS) {
+      if (nl) {
+        if (tid == 0) {
+          // (a bijection on every 64 consecutive tiles - no shard gets more than its share - that also spreads tiles
+          // which agree in their low bits: the tiles of a ground plane do, and went to two shards)
+          const uint32_t sh = (tile ^ (tile >> 6) ^ (tile >> 12)) & (OCC_LIST_SHARDS - 1);
+          st.occ_list_n[tile] = nl;
+          const uint32_t units = (nl + OCC_LIST_UNIT - 1) / OCC_LIST_UNIT;
+          const uint32_t slot = (uint32_t)atomicAdd(&st.occ_shard[sh].word, (1ull << 32) | units);  // (a tile and its units)
+          for (uint32_t u = 0; u < units && slot + u < st.occ_unit_cap; ++u)
+            st.occ_unit[(size_t)sh * st.occ_unit_cap + slot + u] = make_uint2(tile, u * OCC_LIST_UNIT);
+        }
+        for (uint32_t k = tid; k < nl; k += TPB) st.occ_list[(size_t)tile * OCC_LIST_CAP + k] = live_list[k];
       }
+    } else {
+      // (whether lists would pay next time is a matter of one tile in eight, counted eightfold: an atomic per tile, 128 to
+      // a line, was 3 us of this launch on a map where every tile lists something)
+      if (nl && tid == 0 && ((tile * 2654435761u) >> 29) == 0u)
+        atomicAdd(&st.occ_shard[(tile ^ (tile >> 6) ^ (tile >> 12)) & (OCC_LIST_SHARDS - 1)].word, 8ull << 32);
+#ifdef SDM_SCAN_NOEVAL  // (development, timing only: the launch without its evaluations)
+      if (nl) return;
+#endif
+#pragma unroll 1
+      for (uint32_t k0 = 0; k0 < nl; k0 += TPB) {  // workgroup-uniform
+        const uint32_t k = k0 + tid;
+        if (k < nl) {
+          const uint32_t tv = live_list[k], lv = blk0 + tv;
+          uint16_t ts1[S], trk[S];
+          uint8_t st1[S], lab[S];
+          float wv[S];
+          const size_t base = (size_t)lv * S;
+          load_vec<rec_align(S)>(st1, st.status + base * REC_STATUS);
+          load_vec<rec_align(S)>(wv, st.w + base * REC_W);
+          load_vec<rec_align(S)>(ts1, st.ts + base * REC_TS);
+          load_vec<rec_align(S)>(trk, st.track + base * REC_TRACK);
+          load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
+          uint32_t rx, ry, rz;
+          voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+          const uint32_t smax = stamp_max(st, rx, ry, rz);
+          // everything of the record is requested before anything is looked at: left alone, the compiler (held to 64
+          // registers) sank each load to its first use - five dependent round trips per listed voxel instead of one
+          __builtin_amdgcn_sched_barrier(0);
+          sdm_voxel_result out;
+          // (the general version only: the plain one next to it costs registers and was measured to gain nothing here)
+          occupancy_evaluate<S, false>(st, occ_threshold, remark, lv, smax, ts1, st1, wv, trk, lab, out);
+          v2u o;
+          __builtin_memcpy(&o, &out, 8);
+          *stage_slot(tv) = o;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
     // the stage leaves as lane-linear 16-byte stores: 1 KB contiguous per instruction
     {
       const unsigned long long whole_mask = __ballot(whole);
@@ -945,16 +989,23 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 
   }
 }
 
+#define SCAN_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 : 4, S <= 8 ? 8 : 4)))
+template <int S>
+__global__ __launch_bounds__(TPB) SCAN_WAVES_ATTR void k_occupancy_scan(Dims d, float occ_threshold, State st, Counters *cnt,
+                                                                       unsigned long long *__restrict__ need, uint32_t n_tiles, uint32_t remark) {
+  occupancy_scan_tile<S, false>(d, occ_threshold, st, cnt, need, n_tiles, remark);
+}
+template <int S>
+__global__ __launch_bounds__(TPB) SCAN_WAVES_ATTR void k_occupancy_scan_lists(Dims d, float occ_threshold, State st, Counters *cnt,
+                                                                             unsigned long long *__restrict__ need, uint32_t n_tiles, uint32_t remark) {
+  occupancy_scan_tile<S, true>(d, occ_threshold, st, cnt, need, n_tiles, remark);
+}
+
 #ifdef SDM_DENSE_WAVES
 #define DENSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SDM_DENSE_WAVES, SDM_DENSE_WAVES)))
 #else
 #define DENSE_WAVES_ATTR
 #endif
-// (Instruction issue bounds this kernel - the SIMDs issue for 86 % of its time on a dense map, profiles/README.md round 5 -
-// so what is not the evaluation is kept off the vector unit: the wave index goes through readfirstlane, which makes a
-// chunk's base address a scalar and its loads `global_load ..., v_lane_offset, s[base]`; the record array is allocated one
-// chunk longer than the map, so no load clamps its address; the plain evaluation runs together with its own admission
-// test, occupancy_evaluate_plain_checked.)
 // (Instruction issue bounds this kernel - the SIMDs issue for 86 % of its time on a dense map, profiles/README.md round 5 -
 // so what is not the evaluation is kept off the vector unit: the wave index goes through readfirstlane, which makes a
 // chunk's base address a scalar and its loads `global_load ..., v_lane_offset, s[base]`; the record array is allocated one
@@ -971,9 +1022,73 @@ static_assert(OCC_DCPW <= 32, "one bit per chunk of the wave in a 32-bit word");
 // constant ones included.  That is right whatever the group holds (only slow if it has emptied since: every record is
 // fetched), and the hint is set anew from what this sweep finds.  On a dense map the first launch is then 8192 workgroups
 // that leave after four bytes instead of 24 us of classification in front of a dependent launch.
+// The units k_occupancy_scan_lists left (State::occ_unit): OCC_LIST_UNIT listed voxels of one tile per workgroup,
+// one record per lane, fetched by the lane (80 bytes in five loads, all requested before the first is looked at), the
+// plain evaluation with its admission test and the general one for a wave that holds a voxel the rare rules apply to.
+// The result overwrites the zero the first launch stored, the flag byte is stored whatever it is.
+#ifndef SDM_LISTED_GRID
+#define SDM_LISTED_GRID 2048
+#endif
+constexpr int OCC_LISTED_GRID = SDM_LISTED_GRID;
+template <int S>
+__device__ __forceinline__ void occupancy_listed_units(const Dims &d, float occ_threshold, const State &st, uint32_t remark, uint32_t bid) {
+  static_assert(OCC_LIST_UNIT == TPB, "one entry per thread");
+  static_assert(OCC_LISTED_GRID % OCC_LIST_SHARDS == 0, "a workgroup stays with one shard's units");
+  const uint32_t sh = bid & (OCC_LIST_SHARDS - 1);
+  uint32_t n_units = (uint32_t)st.occ_shard[sh].word;
+  n_units = n_units < st.occ_unit_cap ? n_units : st.occ_unit_cap;
+#pragma unroll 1
+  for (uint32_t h = bid / OCC_LIST_SHARDS; h < n_units; h += OCC_LISTED_GRID / OCC_LIST_SHARDS) {
+    const uint2 un = st.occ_unit[(size_t)sh * st.occ_unit_cap + h];
+    const uint32_t tile = un.x;
+    uint32_t nl = st.occ_list_n[tile];
+    nl = nl < OCC_LIST_CAP ? nl : OCC_LIST_CAP;
+    const uint32_t k = un.y + threadIdx.x;
+    if (k < nl) {
+      const uint32_t tv = st.occ_list[(size_t)tile * OCC_LIST_CAP + k];
+      const uint32_t lv = tile * OCC_TILE + tv;
+      uint16_t ts1[S], trk[S];
+      uint8_t st1[S], lab[S];
+      float wv[S];
+      const size_t base = (size_t)lv * S;
+      load_vec<rec_align(S)>(st1, st.status + base * REC_STATUS);
+      load_vec<rec_align(S)>(wv, st.w + base * REC_W);
+      load_vec<rec_align(S)>(ts1, st.ts + base * REC_TS);
+      load_vec<rec_align(S)>(trk, st.track + base * REC_TRACK);
+      load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
+      uint32_t rx, ry, rz;
+      voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
+      const uint32_t smax = stamp_max(st, rx, ry, rz);
+      __builtin_amdgcn_sched_barrier(0);
+      sdm_voxel_result out;
+      uint8_t nf;
+      const bool special = occupancy_evaluate_plain_checked<S>(occ_threshold, smax, ts1, st1, wv, trk, lab, out, nf);
+      if (__ballot(special) != 0ull) occupancy_evaluate_core<S, false>(st, occ_threshold, remark, lv, smax, ts1, st1, wv, trk, lab, out, nf);
+      store_result(st.res + lv, out);
+      st.vflag[lv] = nf;
+    }
+  }
+}
+
+// the sweep's units are done: the counters go back to zero, and how many tiles listed anything becomes the hint for the
+// next non-incremental sweep (first wave of one workgroup)
+__device__ __forceinline__ void occupancy_listed_wrap(const State &st, uint32_t n_tiles) {
+  static_assert(OCC_LIST_SHARDS == 64, "one shard per lane of the first wave");
+  uint32_t t = (uint32_t)(st.occ_shard[threadIdx.x].word >> 32);
+  st.occ_shard[threadIdx.x].word = 0;
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  // 2: few tiles listed anything - surfaces - and the lists pay; 1: none did or most did, two launches do
+  if (threadIdx.x == 0) st.occ_shard[OCC_LIST_SHARDS].word = t > 0 && t <= n_tiles / 4 ? 2u : 1u;
+}
+template <int S>
+__global__ __launch_bounds__(TPB) void k_occupancy_listed(Dims d, float occ_threshold, State st, uint32_t remark) {
+  occupancy_listed_units<S>(d, occ_threshold, st, remark, blockIdx.x);
+}
+
 template <int S>
 __global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d, float occ_threshold, State st, Counters *cnt,
-                                                         const unsigned long long *__restrict__ need, uint32_t remark) {
+                                                         const unsigned long long *__restrict__ need, uint32_t remark, uint32_t n_tiles) {
+  if (blockIdx.x == 0 && threadIdx.x < OCC_LIST_SHARDS) occupancy_listed_wrap(st, n_tiles);  // (the units are done: the launch before this one)
   constexpr int REC = 10 * S;                    // bytes of one record
   constexpr int PIECES = OCC_CHUNK * REC / 16;   // 16-byte pieces of one chunk of records
   constexpr int PPL = (PIECES + 63) / 64;
@@ -3458,14 +3573,24 @@ size_t tile_mark_bytes(const Dims &d) {
   return (std::max<size_t>(n_tiles, (size_t)TPB * OCC_SEG_MAX) + 16 + 15) / 16 * 16;  // one of the two arrays
 }
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, const FrameArgs *fa, uint32_t remark,
-                      hipStream_t s) {
+                      hipStream_t s, int lists) {
   dim3 grid(blocks_for(d.v_count, OCC_TILE));
   if (all_dirty) {
     // (Measured and not kept, round 5: the map cut into 2 / 4 / 8 slices of tiles, the scans of slices 1.. on a second
     // stream next to the dense launches of the slices before them - every cross-stream event costs more than the slice
     // of classification it hides: 0.285 -> 0.297 / 0.318 / 0.354 ms on the dense case.)
-    SDM_DISPATCH_S(k_occupancy_scan, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, grid.x, remark);
-    SDM_DISPATCH_S(k_occupancy_dense, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, remark);
+    // lists: the tiles' sparse voxels go through a launch of their own (k_occupancy_scan says when that pays).  (Measured
+    // and not kept: the listed units as extra workgroups of the last launch, the last of them to finish wrapping up - one
+    // launch less, and 55 us against 47 us on an empty map: that kernel then holds 126 registers and its workgroups' LDS
+    // whatever a workgroup does; the lists worked off by the last launch's own workgroup of the tile - 67 us against 56
+    // on the `driven` map, four resident workgroups per CU.)
+    if (lists) {
+      SDM_DISPATCH_S(k_occupancy_scan_lists, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, grid.x, remark);
+      SDM_DISPATCH_S(k_occupancy_listed, dim3(OCC_LISTED_GRID), s, d, flt.occ_threshold, st, remark);
+    } else {
+      SDM_DISPATCH_S(k_occupancy_scan, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, grid.x, remark);
+    }
+    SDM_DISPATCH_S(k_occupancy_dense, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, remark, grid.x);
   } else {
     const uint32_t n_tiles = grid.x;
     // marks per thread of the tile scan, in whole 16-byte loads; 0: too many tiles for one workgroup to scan

@@ -190,6 +190,12 @@ struct sdm_map {
   int restamped[3]{};        // slabs re-stamped by the last frame's ring shift, per axis
   bool stamps_dirty = true;  // device copy of the stamp arrays needs a full upload
   bool sweep_all = true;     // the next occupancy sweep evaluates every voxel that holds something, changed or not
+  // A non-incremental sweep hands the sparse voxels of its tiles to a launch of their own (State::occ_list) - or, where
+  // that launch would only cost its 4 us, evaluates them in its first launch: every such sweep leaves word of which it
+  // should have been (State::occ_shard: few tiles listed anything = surfaces, lists pay; none or most did, they do not),
+  // and the host picks the word up at its next wait (sweep_mode_latch).  Either way every voxel gets the same result.
+  bool sweep_lists = true;
+  bool sweep_rec_pending = false;
   uint32_t sweep_epoch = 1;  // the number the next sweep looks for in State::tile_dirty (mark_tile): advanced by every sweep issued
 
   // owned device buffers for inputs
@@ -491,12 +497,28 @@ void host_initialize(sdm_map *m) {
   m->global_time_stamp = 0;
 }
 
+// (m->stream is idle) what the last non-incremental sweep recommends for the next
+sdm_status sweep_mode_latch(sdm_map *m) {
+  if (!m->sweep_rec_pending) return SDM_OK;
+  uint32_t rec = 0;
+  HIP_TRY(hipMemcpyAsync(&rec, &m->st.occ_shard[OCC_LIST_SHARDS].word, 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (rec == 1) m->sweep_lists = false;
+  if (rec == 2) m->sweep_lists = true;
+  m->sweep_rec_pending = false;
+  return SDM_OK;
+}
+
 sdm_status check_counters(sdm_map *m, Counters *out) {
   Counters c;
   HIP_TRY(hipStreamSynchronize(m->s_frustum));
   HIP_TRY(hipStreamSynchronize(m->s_birth));
   HIP_TRY(hipMemcpyAsync(&c, m->sc.cnt, sizeof(Counters), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
+  {
+    const sdm_status rc = sweep_mode_latch(m);
+    if (rc != SDM_OK) return rc;
+  }
   if (out) *out = c;
   if (c.overflow) {
     set_error("capacity", __FILE__, __LINE__, "visible-particle or move list overflowed: more visible particles than sdm_config.max_visible, more in ONE image row than "
@@ -778,6 +800,12 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->st.tile_stride = (uint32_t)tile_mark_bytes(d);
   A(m->st.tile_dirty, 2 * (size_t)m->st.tile_stride);
   A(m->st.occ_need, ((size_t)d.v_count + 63) / 64 + 32);
+  A(m->st.occ_list, occ_list_tiles(d.v_count) * OCC_LIST_CAP);
+  A(m->st.occ_list_n, occ_list_tiles(d.v_count) + 64);
+  m->st.occ_unit_cap = (uint32_t)((occ_list_tiles(d.v_count) + OCC_LIST_SHARDS - 1) / OCC_LIST_SHARDS * (OCC_LIST_CAP / OCC_LIST_UNIT));
+  A(m->st.occ_unit, (size_t)OCC_LIST_SHARDS * m->st.occ_unit_cap);
+  A(m->st.occ_shard, OCC_LIST_SHARDS + 1);
+  HIP_TRY(hipMemsetAsync(m->st.occ_shard, 0, (OCC_LIST_SHARDS + 1) * sizeof(State::OccListShard), m->stream));
   A(m->st.grp_hint, grp_hint_bytes(d.v_count));
   HIP_TRY(hipMemsetAsync(m->st.grp_hint, 0, grp_hint_bytes(d.v_count), m->stream));
   A(m->st.owner, n_slots);
@@ -1443,7 +1471,8 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
   if (stage_done(stop_after, 6)) return SDM_OK;
   if (!(flags & SDM_SKIP_OCCUPANCY)) {
     // (under capture nothing runs: the frame the graph is then launched for advances the epoch)
-    launch_occupancy(d, m->flt, m->st, m->sc.cnt, m->sweep_all ? 1 : 0, m->sc.fa, next_epoch(m->f.epoch), s);
+    launch_occupancy(d, m->flt, m->st, m->sc.cnt, m->sweep_all ? 1 : 0, m->sc.fa, next_epoch(m->f.epoch), s, m->sweep_lists ? 1 : 0);
+    if (m->sweep_all) m->sweep_rec_pending = true;
     m->sweep_all = false;
     if (!m->capturing) m->sweep_epoch = next_epoch(m->f.epoch);
   }
@@ -2655,11 +2684,20 @@ sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms) {
   HIP_TRY(hipEventCreate(&a));
   HIP_TRY(hipEventCreate(&b));
   // (what these sweeps have to see again, the next frame's sweep has to see: marked with its epoch)
-  launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->sc.fa, m->sweep_epoch, m->stream);  // warm-up; all_dirty: the full evaluation every time
+  // (warm-up, and the launch whose word decides how the timed ones run: all_dirty - the full evaluation every time)
+  launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->sc.fa, m->sweep_epoch, m->stream, m->sweep_lists ? 1 : 0);
+  m->sweep_rec_pending = true;
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  {
+    const sdm_status rc = sweep_mode_latch(m);
+    if (rc != SDM_OK) return rc;
+  }
+  const int lists = m->sweep_lists ? 1 : 0;
   HIP_TRY(hipEventRecord(a, m->stream));
-  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->sc.fa, m->sweep_epoch, m->stream);
+  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->sc.fa, m->sweep_epoch, m->stream, lists);
   HIP_TRY(hipEventRecord(b, m->stream));
   HIP_TRY(hipEventSynchronize(b));
+  m->sweep_rec_pending = true;
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, a, b));
   *avg_ms = ms / iters;

@@ -186,6 +186,22 @@ struct State {
   uint32_t tile_stride = 0;       // bytes of one of the two
   // per chunk of 64 voxels: the voxels the non-incremental sweep's first launch left to its second (dense chunks)
   unsigned long long *occ_need = nullptr;
+  // The voxels of a tile's sparse chunks that hold something, listed by the non-incremental sweep's first launch (index
+  // inside the tile, OCC_LIST_CAP entries per tile, occ_list_n of them) for the launch behind it, which evaluates them
+  // one workgroup per unit of OCC_LIST_UNIT entries, all units at once.  A unit is a (tile, first entry) pair in one of
+  // OCC_LIST_SHARDS arrays (occ_unit_cap pairs each), its slot handed out by the shard's counter, which also counts the
+  // tiles that listed anything; the sweep's last launch zeroes the counters and turns the tile count into
+  // occ_shard[OCC_LIST_SHARDS].word, the word the host reads before the next non-incremental sweep: 2 = few tiles list
+  // anything (surfaces), the lists pay; 1 = none or most do, evaluate in the first launch (map.hip, sweep_lists).
+  uint16_t *occ_list = nullptr;
+  uint32_t *occ_list_n = nullptr;
+  uint2 *occ_unit = nullptr;
+  uint32_t occ_unit_cap = 0;
+  struct alignas(128) OccListShard {
+    unsigned long long word;  // low half: units handed out; high half: tiles that listed anything (one atomic for both)
+    uint32_t pad[30];
+  };
+  OccListShard *occ_shard = nullptr;
   // per group of 512 voxels (what one wave of the non-incremental sweep's kernels takes): 1 = every chunk of the group
   // was dense in the last non-incremental sweep; the next one leaves the group to the second launch whole
   // (k_occupancy_scan skips it, k_occupancy_dense classifies it itself).  A hint about speed only: both launches read
@@ -223,6 +239,8 @@ struct State {
 // one byte per tile of 2^TILE_SHIFT voxels (State::tile_dirty): set by whoever sets VF_DIRTY on a voxel of the tile or
 // changes its observation stamp; the sweep returns at once from a tile whose byte is 0 and clears the byte otherwise
 constexpr int TILE_SHIFT = 11;
+constexpr uint32_t OCC_LIST_CAP = 2048, OCC_LIST_UNIT = 256, OCC_LIST_SHARDS = 64;  // State::occ_list (kernels.hip: 32 sparse chunks of fewer than 64 voxels each)
+__host__ __device__ constexpr size_t occ_list_tiles(size_t v_count) { return (v_count + ((size_t)1 << TILE_SHIFT) - 1) >> TILE_SHIFT; }
 // bytes of State::grp_hint for v_count voxels: whole tiles (4 groups), so that a workgroup reads its four bytes as one word
 __host__ __device__ constexpr size_t grp_hint_bytes(size_t v_count) { return ((v_count + (1u << 11) - 1) >> 11) * 4; }
 enum : uint8_t { VF_EMPTY = 0, VF_CLEAN = 1, VF_DIRTY = 2, VF_STATE = 3, VR_UNOBSERVED = 1 << 2, VR_EMPTY = 2 << 2, VR_MASK = 3 << 2 };

@@ -174,8 +174,9 @@ struct FrameBeginLaunch {
 };
 void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s);
 void launch_moves_batch(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa_batch, hipStream_t s);
+// lists (non-incremental sweeps only): the tiles' sparse voxels go through State::occ_list and a launch of their own
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, const FrameArgs *fa, uint32_t remark,
-                      hipStream_t s);
+                      hipStream_t s, int lists = 0);
 size_t tile_mark_bytes(const Dims &d);  // State::tile_dirty, padded for the sweep's tile scan
 void launch_frustum(const Dims &d, const Scratch &sc, hipStream_t s);
 // visibility + binning; its last kernel also classifies the pixels for launch_ck (same ck_out / finish)
