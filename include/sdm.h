@@ -461,6 +461,10 @@ sdm_status sdm_debug_fill_dense_ex(sdm_map *m, int32_t mode);
  * will be skipped by its classification launch and classified by the evaluating launch itself next time
  * (tests/test_sweep_dense_gpu.py makes sure its repeated sweeps do take that path). */
 sdm_status sdm_debug_hinted_groups(sdm_map *m, int64_t *n_out);
+/* Test hook.  A non-incremental sweep evaluates the voxels of its sparse chunks either in its first launch or through
+ * per-tile lists and a launch of their own; the library picks per sweep from what the sweep before found (speed only:
+ * the results are the same).  mode 1 / 0: always / never the lists; -1: the library picks again. */
+sdm_status sdm_debug_sweep_lists(sdm_map *m, int32_t mode);
 
 /* ---- device-side unit tests of the hand-written primitives (tests/test_primitives_gpu.py) */
 sdm_status sdm_test_scan(const uint32_t *in, uint32_t *out, int64_t n);

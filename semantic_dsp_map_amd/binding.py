@@ -175,6 +175,7 @@ def load_library():
         "sdm_debug_fill_dense": [vp],
         "sdm_debug_fill_dense_ex": [vp, i32],
         "sdm_debug_hinted_groups": [vp, C.POINTER(C.c_int64)],
+        "sdm_debug_sweep_lists": [vp, i32],
         "sdm_test_scan": [vp, vp, i64],
         "sdm_test_sort_pairs": [vp, vp, vp, vp, i64, i32],
     }
@@ -563,6 +564,11 @@ class SdmMap:
         n = C.c_int64()
         _check(self.L, self.L.sdm_debug_hinted_groups(self.h, C.byref(n)), "sdm_debug_hinted_groups")
         return n.value
+
+    def force_sweep_lists(self, mode):
+        """Test hook: 1 / 0 = the non-incremental sweeps always / never hand their sparse voxels to per-tile lists, -1 = the
+        library picks per sweep (sdm_debug_sweep_lists)."""
+        _check(self.L, self.L.sdm_debug_sweep_lists(self.h, int(mode)), "sdm_debug_sweep_lists")
 
     def fill_dense(self):
         _check(self.L, self.L.sdm_debug_fill_dense(self.h), "sdm_debug_fill_dense")

@@ -196,6 +196,7 @@ struct sdm_map {
   // and the host picks the word up at its next wait (sweep_mode_latch).  Either way every voxel gets the same result.
   bool sweep_lists = true;
   bool sweep_rec_pending = false;
+  int sweep_lists_forced = -1;  // sdm_debug_sweep_lists
   uint32_t sweep_epoch = 1;  // the number the next sweep looks for in State::tile_dirty (mark_tile): advanced by every sweep issued
 
   // owned device buffers for inputs
@@ -505,6 +506,7 @@ sdm_status sweep_mode_latch(sdm_map *m) {
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (rec == 1) m->sweep_lists = false;
   if (rec == 2) m->sweep_lists = true;
+  if (m->sweep_lists_forced >= 0) m->sweep_lists = m->sweep_lists_forced != 0;
   m->sweep_rec_pending = false;
   return SDM_OK;
 }
@@ -2715,6 +2717,12 @@ sdm_status sdm_debug_fill_dense_ex(sdm_map *m, int32_t mode) {
   return SDM_OK;
 }
 sdm_status sdm_debug_fill_dense(sdm_map *m) { return sdm_debug_fill_dense_ex(m, 0); }
+sdm_status sdm_debug_sweep_lists(sdm_map *m, int32_t mode) {
+  if (!m || mode < -1 || mode > 1) return SDM_ERR_INVALID_ARGUMENT;
+  m->sweep_lists_forced = mode;
+  if (mode >= 0) m->sweep_lists = mode != 0;
+  return SDM_OK;
+}
 sdm_status sdm_debug_hinted_groups(sdm_map *m, int64_t *n_out) {
   if (!m || !n_out) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));

@@ -42,6 +42,38 @@ def test_non_incremental_sweep_on_a_dense_random_state(p_n, seed, x_n):
     g.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("seed,x_n", [(21, 5), (22, 6)])
+def test_sparse_voxels_inline_and_through_lists(mode, seed, x_n):
+    """A non-incremental sweep evaluates the voxels of its sparse chunks in its first launch (k_occupancy_scan) or hands
+    them to per-tile lists and a launch of their own (k_occupancy_scan_lists, k_occupancy_listed); the library picks per
+    sweep from what the sweep before found.  Here each way is forced for every sweep of a run - four frames, each ending
+    in a non-incremental sweep, with births, moves and ring shifts in between - and held to the oracle bit for bit.
+    (Tiles with a few listed voxels and tiles with hundreds: the random state has sparse runs of chunks.)"""
+    cfg = dict(synth.CONFIGS["T0"], p_n=3, x_n=x_n)
+    params = synth.PARAMS["vkitti2"]
+    sc = synth.Scene(cfg, n_dynamic=2, seed=6)
+    o, g = pu.make_pair(cfg, params, synth.noise_table())
+    g.force_sweep_lists(mode)
+    st = random_state(cfg, seed, run=8)
+    (sx, sy, sz), ring = stamps_for(o)
+    for m in (o, g):
+        m.load_state(st)
+        m.set_stamps(sx, sy, sz)
+        m.set_ring_state(ring)
+    for t in range(4):
+        depth, cloud, pos, q = sc.render(t, params)
+        pos = pos + np.array([0.0, 0.0, 0.45 * t], np.float32)
+        for m in (o, g):
+            m.set_params(params)     # the next sweep is a non-incremental one
+        o.update(depth, cloud, pos, q, sc.moves(t))
+        g.update(depth, cloud, pos, q, sc.moves(t), sync=True)
+        rep = pu.compare_maps(o, g, 8, check_results=True, tag="lists %d, frame %d: " % (mode, t))
+        assert not rep, "\n".join(rep)
+    assert int((g.voxels()["occ"] > 0).sum()) > 1000
+    g.close()
+
+
 @pytest.mark.parametrize("seed,x_n", [(11, 5), (12, 6), (13, 7)])
 def test_group_hints_repeated_non_incremental_sweeps(seed, x_n):
     """The second and later non-incremental sweeps of a map: groups of 512 voxels whose chunks were all dense in the sweep

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 export SDM_DRIVEN_CACHE=/tmp/sdm_driven_frames_$$.pkl
 {
-  timeout 1200 python -m pytest tests/test_driven_gpu.py tests/test_long_object_lists_gpu.py tests/test_parity_gpu.py tests/test_sharded_gpu.py -x -q -m gpu 2>&1 | tail -3
+  timeout 1200 python -m pytest tests/test_driven_gpu.py tests/test_long_object_lists_gpu.py tests/test_parity_gpu.py tests/test_sharded_gpu.py tests/test_sweep_dense_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error" | tail -3
   timeout 900 python bench.py --only-driven 2>/dev/null | grep '"metric"\|driven' | python -c "
 import sys, json
 for l in sys.stdin:
