@@ -234,7 +234,8 @@ __global__ __launch_bounds__(TPB) void k_set_frame(FrameArgs *__restrict__ dst, 
 //                    dispatched quickly;
 //   k_occupancy_scan + k_occupancy_dense  the non-incremental sweep (first sweep of a state: sdm_load_state,
 //                    sdm_set_params, sdm_clear, a wholesale stamp upload): every voxel gets its result, HBM-bound,
-//                    records of dense chunks fetched cooperatively.
+//                    records of dense chunks fetched cooperatively.  On a map whose particles sit on surfaces:
+//                    k_occupancy_scan_lists + k_occupancy_listed + k_occupancy_dense (the host picks: map.hip, sweep_lists).
 
 // A voxel that holds something: weight sum, clamp / cull write-backs and the track vote
 // (calculateWeightAndSemanticsInVoxel, operations.h:390-448).  Written without branches - every decision is a select on
@@ -741,7 +742,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 4 
 //
 // k_occupancy_scan   streams stamps and flags of every voxel like the in-frame kernel (8 consecutive voxels per thread,
 //   wide loads) and finds the constant results.  Voxels that hold something: chunks of 64 voxels with fewer than
-//   OCC_DENSE_MIN of them put them on the workgroup's list and they are evaluated here, one record per lane; denser
+//   OCC_DENSE_MIN of them put them on the workgroup's list and they are evaluated here, one record per lane - or, in
+//   the variant k_occupancy_scan_lists, handed to k_occupancy_listed, a launch in between that gives every 256 listed
+//   voxels of a tile a workgroup of their own (the evaluation loop says when which); denser
 //   chunks are left to the second kernel as a 64-bit mask per chunk.  All results of the tile - constant or evaluated -
 //   are collected in LDS and leave as lane-linear 16-byte stores, 1 KB contiguous per instruction, every line written
 //   whole and once (stored from registers they are 8-byte pieces 64 bytes apart with holes where the evaluated voxels

@@ -3,10 +3,10 @@
 
 Launch order of the bench command: one non-incremental sweep (k_occupancy_scan + k_occupancy_dense, first frame after
 sdm_load_state), k_occupancy<S> for the other warm-up + timed frames, then 6 profiled frames (the ones bench.py takes the
-in-frame launch time, tile and voxel counts from), 6 x-shift frames, then 11 non-incremental sweeps on the benchmark map
-(1 warm-up + 10 timed), 11 on the dense map (eight track ids per slot) and 11 on the dense map with one track id per
-voxel (`dense_case_surface`).  A non-incremental sweep is two launches: their counters and durations
-are added.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated there for
+in-frame launch time, tile and voxel counts from), 6 x-shift frames, then the non-incremental sweeps on the benchmark map
+(201 untimed, 1 + 10 timed), on the dense map (eight track ids per slot: 41 untimed, 1 + 10 timed) and on the dense map with one
+track id per voxel (`dense_case_surface`, the same).  A non-incremental sweep is two launches (three where the library took the
+lists): their counters and durations are added.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated there for
 wide coalesced streaming reads, so for the in-frame launch with its scattered record fetches the corrected figure is an
 upper estimate)."""
 import csv
@@ -24,18 +24,26 @@ for c in ["FETCH_SIZE", "WRITE_SIZE"]:
     def one(r):
         return [(float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)]
     inc = [one(r) for r in rows if "k_occupancy<" in r["Kernel_Name"]]
-    scan = [r for r in rows if "k_occupancy_scan" in r["Kernel_Name"]]
-    dense = [r for r in rows if "k_occupancy_dense" in r["Kernel_Name"]]
-    assert len(scan) == len(dense) == 34 and len(inc) + len(scan) + len(dense) == len(rows), (len(scan), len(dense), len(inc), len(rows))
-    allr = [one(a) + one(b) for a, b in zip(scan, dense)]
-    sets = {"in_frame": inc[-12:-6], "x_shift_frames": inc[-6:], "full_evaluation": allr[2:12], "dense_case": allr[13:23],
-            "dense_case_surface": allr[24:34]}
+    # a non-incremental sweep = k_occupancy_scan (or k_occupancy_scan_lists + k_occupancy_listed) + k_occupancy_dense, in launch order
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    allr = []
+    for r in rows:
+        n = r["Kernel_Name"]
+        if "k_occupancy_scan" in n:
+            allr.append(one(r))
+        elif "k_occupancy_listed" in n or "k_occupancy_dense" in n:
+            allr[-1] += one(r)
+    n = len(allr)
+    # 1 (first frame) + 201 + 11 (benchmark map: untimed, then 1 + 10 timed) + 41 + 11 (dense case) + 41 + 11 (dense case, one track id per voxel)
+    assert n == 317 and all(len(x) >= 2 for x in allr), (n, len(rows))
+    sets = {"in_frame": inc[-12:-6], "x_shift_frames": inc[-6:], "full_evaluation": allr[n - 114:n - 104], "dense_case": allr[n - 62:n - 52],
+            "dense_case_surface": allr[n - 10:]}
     for name, rs in sets.items():
         v = [sum(x[0] for x in r) for r in rs]
         d = [sum(x[1] for x in r) for r in rs]
         res.setdefault(name, {})[c] = (sum(v) / len(v), sum(d) / len(d), len(v))
     shutil.copy(g + "%s_sweep_%s.csv" % (tag, c), "profiles/%s_sweep_pmc_%s.csv" % (tag, c.lower()))
-out = {"kernel": rf["kernel"], "non_incremental_kernels": "k_occupancy_scan + k_occupancy_dense (two launches, added)", "voxels": rf["voxels"], "voxels_evaluated_in_full": rf["voxels_evaluated_in_full"], "tiles": rf["tiles"],
+out = {"kernel": rf["kernel"], "non_incremental_kernels": "k_occupancy_scan + k_occupancy_dense (two launches, added; the first sweep of a map: k_occupancy_scan_lists + k_occupancy_listed + k_occupancy_dense)", "voxels": rf["voxels"], "voxels_evaluated_in_full": rf["voxels_evaluated_in_full"], "tiles": rf["tiles"],
        "tiles_looked_into": rf["tiles_looked_into"],
        "fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section)", "cases": {},
        "commands": ["SDM_GRAPH=0 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -- python bench.py --no-cpu --no-strong --no-stress --steps 20 --warmup 5",

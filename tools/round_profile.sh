@@ -10,6 +10,7 @@
 #   <tag>_driven.json, <tag>_driven_kernel_stats.txt   the `driven` leg alone and its kernel trace
 #   <tag>_dense_split.txt            per-kernel times of the non-incremental sweep on the dense case + the streaming probes of this box
 #   <tag>_clear.txt                  sdm_clear, ten calls
+#   <tag>_driven_sweep.txt           the non-incremental sweep on a map the filter grew (150 frames of the driven scene), per launch and per kernel
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=${1:-r03}
 mkdir -p gpurun_out
@@ -25,4 +26,5 @@ tools/pmc_a7.sh $tag
 tools/gpu_driven_stats.sh $tag > /dev/null 2>&1     # <tag>_driven.json, <tag>_driven_kernel_stats.txt
 tools/gpu_dense_split.sh > /dev/null 2>&1; cp gpurun_out/dense_split.txt gpurun_out/${tag}_dense_split.txt
 timeout 300 python tools/probes/clear_time.py 10 > gpurun_out/${tag}_clear.txt 2>&1
+tools/gpu_driven_sweep.sh > /dev/null 2>&1; cp gpurun_out/driven_sweep.txt gpurun_out/${tag}_driven_sweep.txt
 ls -la gpurun_out | grep $tag
