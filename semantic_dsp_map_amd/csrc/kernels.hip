@@ -2914,7 +2914,9 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
                                                       uint32_t total) {
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+#ifndef SDM_TIMERS_BIRTH
   if (threadIdx.x == 0) DBG_PUT(0, DBG_T());
+#endif
   // The kernel is a chain of dependent loads in the few lanes that are segment heads (one candidate in fifty): left where
   // they are, nearly every wave of the launch carries one or two of them through the whole chain.  So the heads of a
   // workgroup's 256 candidates are compacted first (LDS) and replayed by its first lanes: a quarter of the waves do all
@@ -2934,7 +2936,9 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   }
   __syncthreads();
   if (threadIdx.x >= n_heads) return;
+#ifndef SDM_TIMERS_BIRTH
   if (threadIdx.x == 0) DBG_PUT(1, DBG_T());
+#endif
   t = heads[threadIdx.x];
   const uint32_t v = head_key[threadIdx.x];
   // How many candidates does the segment hold?  At most 2 (S-1) of them can ever be inserted (the voxel's vacant slots, and
@@ -3000,6 +3004,19 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   //     full with the resampling used up (or impossible) ends the walk: nothing later can change the voxel.
   // Phase A = insertions before the resampling, phase B = after it.  One pass over the slots per phase instead of a loop
   // over candidates whose every iteration was a few hundred dependent instructions for the slowest lane of the wave.
+  // Everything requested above is waited for HERE, once.  What follows is divergent code with stores in it (the
+  // resampling: a branch or two per slot), and the compiler, which cannot count loads across branches, guarded every use
+  // of a row in every branch with s_waitcnt vmcnt(0) - which on this architecture also waits for every store issued before
+  // it.  With the wait here those are gone from the code (tools/isa_skeleton.py).  It is not where this kernel's time
+  // goes, though: in-kernel clocks (round 5, tools/probes/timers_birth.py, thread 0 = a workgroup's first head) - rows
+  // arrived 2 us after the start in every workgroup; from there to the end of the resampling 3 us for the faster half of
+  // the workgroups, 7 us for the next four tenths, 15 us for the slowest tenth, 18-19 us for the slowest five, with or
+  // without these waits and with or without the alias paths compiled in; positions arrived and stores issued in less
+  // than 1 us after that.  13 active lanes of one wave going through up to 1500 instructions of branches: DESIGN.md 8.
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+#ifdef SDM_TIMERS_BIRTH
+  if (threadIdx.x == 0) DBG_PUT(0, DBG_T());
+#endif
   const bool noise_flavour = flt.consider_depth_noise != 0;
   uint32_t vac0 = 0;
 #pragma unroll
@@ -3037,6 +3054,9 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
     }
   }
   const uint32_t n_success = nA + nB;
+#ifdef SDM_TIMERS_BIRTH
+  if (threadIdx.x == 0) DBG_PUT(1, DBG_T() + (n_success == 77u ? 1 : 0) + (n_resamp == 77u ? 1 : 0) + (stv[S - 1] == 0xEE ? 1 : 0));
+#endif
   // the candidates that made it: index, then position / track / label - two rounds for all of them
   uint32_t cidx[S];
   float4 bps[S];
@@ -3051,6 +3071,9 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
 #pragma unroll
   for (int i = 1; i < S; ++i) bps[i] = sc.bpos[cidx[i]];  // (unconditional - entry 0 where the slot takes nobody: all S - 1 requests in one round)
   __builtin_amdgcn_sched_barrier(0);
+#ifdef SDM_TIMERS_BIRTH
+  if (threadIdx.x == 0) DBG_PUT(2, DBG_T() + (bps[1].x == 1234.5f ? 1 : 0) + (bps[S - 1].x == 1234.5f ? 1 : 0));
+#endif
 #pragma unroll
   for (int i = 1; i < S; ++i) {
     if (cand[i] < 0) continue;
@@ -3072,8 +3095,12 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
     }
   }
   if (threadIdx.x == 0) {
+#ifdef SDM_TIMERS_BIRTH
+    DBG_PUT(3, DBG_T());
+#else
     DBG_PUT(2, DBG_T());
     DBG_PUT(3, n_success);
+#endif
   }
   // same-address atomics retire one at a time: counters every wave bumps are sharded by block
   if (n_success || n_resamp) {
