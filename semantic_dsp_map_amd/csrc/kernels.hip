@@ -3004,16 +3004,15 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   //     full with the resampling used up (or impossible) ends the walk: nothing later can change the voxel.
   // Phase A = insertions before the resampling, phase B = after it.  One pass over the slots per phase instead of a loop
   // over candidates whose every iteration was a few hundred dependent instructions for the slowest lane of the wave.
-  // Everything requested above is waited for HERE, once.  What follows is divergent code with stores in it (the
-  // resampling: a branch or two per slot), and the compiler, which cannot count loads across branches, guarded every use
-  // of a row in every branch with s_waitcnt vmcnt(0) - which on this architecture also waits for every store issued before
-  // it.  With the wait here those are gone from the code (tools/isa_skeleton.py).  It is not where this kernel's time
-  // goes, though: in-kernel clocks (round 5, tools/probes/timers_birth.py, thread 0 = a workgroup's first head) - rows
-  // arrived 2 us after the start in every workgroup; from there to the end of the resampling 3 us for the faster half of
-  // the workgroups, 7 us for the next four tenths, 15 us for the slowest tenth, 18-19 us for the slowest five, with or
-  // without these waits and with or without the alias paths compiled in; positions arrived and stores issued in less
-  // than 1 us after that.  13 active lanes of one wave going through up to 1500 instructions of branches: DESIGN.md 8.
-  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  // (Round 5, measured and not kept - none of them moved the kernel's 23 us or the frame, three rounds alternating in one
+  // call each: one s_waitcnt vmcnt(0) here, in front of the divergent code, which takes the compiler's own vmcnt(0) out of
+  // every branch of the resampling - those also wait for the stores before them, the counter being in order; the same
+  // behind the requests for the candidates' positions, so that no insertion waits for the stores of the one before it;
+  // the resampling as a chain of selects with the voxel's rows stored once each, whole, no branch per slot; the alias
+  // paths compiled out.  The instruction cache is not it either: 850 misses per launch over 128 caches,
+  // tools/pmc_icache.sh.  In-kernel clocks say where the time is NOT - rows arrive 2 us after the start in every
+  // workgroup, tools/probes/timers_birth.py - but their checkpoints inside straight-line code are not to be trusted:
+  // s_memrealtime orders with memory operations only, the compiler places it anywhere between two of them.)
 #ifdef SDM_TIMERS_BIRTH
   if (threadIdx.x == 0) DBG_PUT(0, DBG_T());
 #endif

@@ -3,7 +3,7 @@
 # build against build/ab/libsdm_<tag>.so, three rounds alternating (variants are only comparable inside one call)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=$1
-for i in 1 2 3; do
+for i in 1 2; do
   for lib in default $tag; do
     if [ $lib = default ]; then unset SDM_LIB_PATH; else export SDM_LIB_PATH=build/ab/libsdm_$lib.so; fi
     timeout 300 python bench.py --no-dense --no-strong --no-driven --no-adapter --cpu-frames 0 2>/dev/null | python -c "
