@@ -3013,8 +3013,8 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   // tools/pmc_icache.sh.  In-kernel clocks say where the time is NOT - rows arrive 2 us after the start in every
   // workgroup, tools/probes/timers_birth.py - but their checkpoints inside straight-line code are not to be trusted:
   // s_memrealtime orders with memory operations only, the compiler places it anywhere between two of them.)
-#ifdef SDM_TIMERS_BIRTH
-  if (threadIdx.x == 0) DBG_PUT(0, DBG_T());
+#ifdef SDM_TIMERS_BIRTH  // (the clock read is made to depend on the rows: it cannot be taken before they have arrived)
+  if (threadIdx.x == 0) DBG_PUT(0, DBG_T() + (stv[1] == 0xEE ? 1 : 0) + (own[1] == 0xEEEE ? 1 : 0) + (wv0[1] == 1234.5f ? 1 : 0) + (trk0[1] == 0xEEEE ? 1 : 0) + (kb[LMAX - 1] == 0xEEEEEEEEu ? 1 : 0) + (sv[LMAX - 1] == 0xEEEEEEEEu ? 1 : 0));
 #endif
   const bool noise_flavour = flt.consider_depth_noise != 0;
   uint32_t vac0 = 0;
