@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/gpu_frame_ab3.sh <tag of an A/B build under build/ab> : C3 frame and busy-scene frame of the default
-# build against build/ab/libsdm_<tag>.so, three rounds alternating (variants are only comparable inside one call)
+# build against build/ab/libsdm_<tag>.so, two rounds alternating (variants are only comparable inside one call)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=$1
 for i in 1 2; do
