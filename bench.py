@@ -38,10 +38,12 @@ PREFILL_FACTOR = 1.16   # prefilled / live particles after the first sweeps' cul
 
 
 def timed_run(synth, sharded, dist, rank, world, local_rank, cfg, params, particles_per_shard, steps, warmup, scene_kw,
-              prefill_kw=None):
+              prefill_kw=None, force_comm=None):
     """One more map of its own: frames rendered and uploaded, map prefilled, `warmup` + `steps` frames issued back to back,
-    barrier + synchronize on both sides of the timed ones, max over ranks.  Returns the numbers and the engine (open)."""
-    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist, force_comm=dist is not None)
+    barrier + synchronize on both sides of the timed ones, max over ranks.  Returns the numbers and the engine (open).
+    force_comm: the frames go through sdm_update_sharded on an RCCL communicator whatever the world size."""
+    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist,
+                                   force_comm=(dist is not None) if force_comm is None else force_comm)
     m = eng.map
     m.generate_noise_table(seed=20250217)
     scene = synth.Scene(cfg, **scene_kw)
@@ -244,7 +246,7 @@ def driven_run(synth, sharded, steps=20, cpu_frames=3):
     # roofline.full_evaluation: stamp, flag read, result and flag written per voxel + the records of the live voxels
     m.time_occupancy_sweep(iters=200)
     full_ms = m.time_occupancy_sweep(iters=10)
-    full_bytes = V * (2 + 1 + 8 + 1) + stats["live_voxels"] * 10 * (1 << cfg["p_n"])
+    full_bytes = V * (2 + 1 + 8 + 1) + stats["live_voxels"] * 10 * ((1 << cfg["p_n"]) - 1)
     res["full_evaluation"] = {"avg_launch_ms": round(full_ms, 5), "bytes_per_launch": int(full_bytes),
                               "frac": round(full_bytes / full_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4), "launches_timed": 10,
                               "untimed_launches_before": 201}
@@ -368,6 +370,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-case sweep timing after the run")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling run (C4: 256^3 / 8M particles over the GPUs)")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="skip the one-rank run of the sharded frame (N = 1 only)")
     ap.add_argument("--no-stress", action="store_true", help="skip the busy-scene run (N = 1 only)")
     ap.add_argument("--only-stress", action="store_true", help="run nothing but the busy scene (development)")
     ap.add_argument("--no-driven", action="store_true", help="skip the drive from an empty map (N = 1 only)")
@@ -552,7 +555,8 @@ def main():
     value = V / (dt / args.steps) / 1e6  # Mvoxels / s, whole map (all shards)
     # Roofline of the occupancy / semantic sweep.  `frac` = bytes the launch has to move in this layout / launch time /
     # peak: one byte per 2048-voxel tile; for the tiles something was written or stamped in since the previous sweep,
-    # the 2-byte observation stamp and 1-byte flag of every voxel; the record (10 S bytes), the 8-byte result and the
+    # the 2-byte observation stamp and 1-byte flag of every voxel; the record (10 (S - 1) bytes: round 6 took the time
+    # particle's row out of it, its stamp lives in the dense stamp array), the 8-byte result and the
     # flag byte of the voxels that were written to.  (Result entries that flip to "unobserved" / "empty" are also
     # written, 9 B each, but not counted.)  `traffic` is the PMC measurement of the same launches where a committed
     # profile matches.  SURVEY.md 8(d) counts the dense-slot figure - (S-1) x 10 B + 2 B read + 8 B written per voxel,
@@ -564,7 +568,7 @@ def main():
     dense_slot_bytes = vox * ((S - 1) * 10 + 2 + 8)
 
     def in_frame_bytes(tiles, evaluated):
-        return vox // TILE + tiles * TILE * (2 + 1) + evaluated * (10 * S + 8 + 1)
+        return vox // TILE + tiles * TILE * (2 + 1) + evaluated * (10 * (S - 1) + 8 + 1)
 
     layout_bytes = in_frame_bytes(sweep_tiles_avg, sweep_live_avg)
     achieved = layout_bytes / (sweep_ms * 1e-3)
@@ -608,7 +612,7 @@ def main():
         # ten launches are over in less than one - untimed launches first, for each case)
         m.time_occupancy_sweep(iters=200)
         full_ms = m.time_occupancy_sweep(iters=10)
-        full_bytes = V * (2 + 1 + 8 + 1) + live_vox_local * 10 * S
+        full_bytes = V * (2 + 1 + 8 + 1) + live_vox_local * 10 * (S - 1)
         roofline["full_evaluation"] = {"kernel": "k_occupancy_scan<%d> + k_occupancy_dense<%d> (two launches, timed together)" % (S, S), "bytes_per_launch": full_bytes,
                                        "avg_launch_ms": round(full_ms, 5),
                                        "achieved": round(full_bytes / full_ms / 1e6, 1),
@@ -617,7 +621,9 @@ def main():
         m.fill_dense()
         m.time_occupancy_sweep(iters=40)
         dense_ms = m.time_occupancy_sweep(iters=10)
-        dense_bytes = V * (2 + 1 + 8 + 1 + 10 * S)  # stamp, flag read; result, flag written; record read
+        # stamp, flag read; result written; record read (10 (S - 1) B: the SURVEY's own per-voxel figure); the flag byte is
+        # only written where it changes (on this map: never after the first sweep) and is not counted: 81 B/voxel at S = 8
+        dense_bytes = V * (2 + 1 + 8 + 10 * (S - 1))
         roofline["dense_case"] = {"kernel": "k_occupancy_scan<%d> + k_occupancy_dense<%d> (two launches, timed together)" % (S, S), "bytes_per_launch": dense_bytes,
                                   "avg_launch_ms": round(dense_ms, 5),
                                   "achieved": round(dense_bytes / dense_ms / 1e6, 1),
@@ -646,7 +652,7 @@ def main():
             m.synchronize()
         clear_ms = (time.perf_counter() - t0) * 1e3 / 3
         n_slots = V * S
-        clear_bytes = n_slots * (16 + 4 + 2 + 1 + 2) + V * (2 + 1 + 8 + 4 + 1)  # pos4 written (nothing read: the forget counts have their own plane), w, ts, status, owner; vts, vflag, res, list heads, slot-0 status
+        clear_bytes = n_slots * (16 + 2) + V * (S - 1) * (4 + 2 + 1) + V * (2 + 1 + 8 + 4)  # pos4, owner per slot; w, ts, status per particle slot (nothing read); vts, vflag, res, list heads
         roofline["clear"] = {"kernel": "sdm_clear: k_clear_map<8> (one write-only pass over the map, 16-byte lane-linear stores) + 4 small memsets", "bytes_per_call": clear_bytes,
                              "ms_per_call": round(clear_ms, 4), "achieved": round(clear_bytes / clear_ms / 1e6, 1),
                              "frac": round(clear_bytes / clear_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),
@@ -665,6 +671,36 @@ def main():
         strong["config"] = "C4: 256x256x256 voxels, 8 slots/voxel, 8 M particles prefilled in all, Z-slab shards over %d GPU(s)" % world
         strong["scaling"] = "strong"
         eng4.map.close()
+
+    # The N > 1 code path with the one rank a one-GPU box has: the same map, the same frames, issued through
+    # sdm_update_sharded on an RCCL communicator of one rank (member-count all-gather, export all-to-all, ck chunk exchange
+    # + slab-ordered sum + all-gather, every one of them issued).  What it costs OVER the plain frame above is what the
+    # sharded path adds before a single byte crosses xGMI; the driver sees it in every --gpus 1 line.
+    sharded_one = None
+    if not multi and not args.no_sharded_leg:
+        try:
+            m.close()  # (a map created while another is alive runs slower for its whole life: DESIGN.md 9)
+            s1, eng1, _, _, _ = timed_run(synth, sharded, None, 0, 1, 0, cfg, params, args.particles, args.steps, max(args.warmup, 6),
+                                          dict(n_static=48, n_dynamic=6, seed=7), force_comm=True)
+            m1 = eng1.map
+            m1.comm_timing(True)
+            comm1 = {}
+            sc1 = synth.Scene(cfg, n_static=48, n_dynamic=6, seed=7)
+            for t in range(n_frames, n_frames + 6):
+                depth, cloud, pos, q = sc1.render(t, params)
+                eng1.update(m1.device_put(depth), m1.device_put(cloud), pos, q, sc1.moves(t))
+                m1.synchronize()
+                for k, v in m1.comm_times().items():
+                    comm1.setdefault(k, []).append(v)
+            m1.comm_timing(False)
+            sharded_one = {"ms_per_step": s1["ms_per_step"], "over_plain_frame_ms": round(s1["ms_per_step"] - ms_per_step, 4),
+                           "steps": s1["steps"], "warmup": s1["warmup"], "live_particles": s1["live_particles"],
+                           "collectives_us": {k: round(float(np.mean(v)), 1) for k, v in sorted(comm1.items())},
+                           "path": "sdm_update_sharded, RCCL communicator of 1 rank, launch by launch (sharded frames are never replayed from a graph)",
+                           "ck_exchange": os.environ.get("SDM_CK_EXCHANGE", "chunks")}
+            m1.close()
+        except Exception as e:  # noqa: BLE001 - a side leg must not take the line down
+            sharded_one = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # The side legs: maps of their own in this process, one after the other.  (Round 3 ran them as child processes: the
     # second and later maps of a process ran 17-40 us per frame slower than its first - the launch-mode policy took each
@@ -708,6 +744,8 @@ def main():
             out["collectives_us"] = collectives
         if strong is not None:
             out["strong_scaling"] = strong
+        if sharded_one is not None:
+            out["sharded_one_rank"] = sharded_one
         if stress is not None:
             out["stress"] = stress
         if driven is not None:
@@ -783,7 +821,7 @@ def adapter_e2e(synth, cfg, params, scene, frames, n_frames=12):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-PMC_FILES = ("r04_sweep_pmc.json", "r03_sweep_pmc.json", "r02_sweep_pmc.json")  # newest first
+PMC_FILES = ("r06_sweep_pmc.json",)  # this layout only (round 6: 70-byte records)
 
 
 def pmc_traffic(S, voxels, evaluated, tiles):

@@ -109,12 +109,12 @@ typedef struct {
   int8_t occ;
 } sdm_point;
 
-/* What one block of kernel arguments holds of the object lists.  A whole map takes lists of ANY length (round 5): they are
- * worked off in batches of this size inside the frame - every object's particles are taken out before any is re-inserted
- * and the noise draws run on across the batches, like moveParticlesInSetsByTransformations does it
- * (mc_ring/operations.h:321-362); a frame with longer lists is issued launch by launch, not from the captured graph.
- * A Z-slab SHARD (sdm_update_sharded, the split entry points) still rejects longer lists with SDM_ERR_INVALID_ARGUMENT:
- * the shards exchange per-object counts and copies once per frame. */
+/* What one block of kernel arguments holds of the object lists.  Every entry point takes lists of ANY length (whole maps:
+ * round 5; Z-slab shards: round 6): they are worked off in batches of this size inside the frame - every object's
+ * particles are taken out before any is re-inserted and the noise draws run on across the batches, like
+ * moveParticlesInSetsByTransformations does it (mc_ring/operations.h:321-362); a frame with longer lists is issued launch
+ * by launch, not from the captured graph.  On a Z-slab shard every batch's per-object member counts are exchanged before
+ * the batch is applied: sdm_update_sharded does that itself, the split entry points through sdm_frame_moves_pending. */
 #define SDM_MAX_MOVES 48
 #define SDM_MAX_REMOVALS 128
 
@@ -171,7 +171,7 @@ typedef struct {
   int64_t alias_entries;    /* indices that sit in a second owner set besides their latest one (the reference's sets are real
                                sets, object_layer.h:20-52), as of now - deleted entries included until the next frame's
                                garbage collection */
-  int64_t alias_overflowed; /* 1 = that table has overflowed (8192 entries) since the last sdm_clear / sdm_load_state: the
+  int64_t alias_overflowed; /* 1 = that table has overflowed (65536 entries) since the last sdm_clear / sdm_load_state: the
                                sets are incomplete, SDM_ERR_CAPACITY is reported at every synchronisation from then on */
 } sdm_stats;
 
@@ -314,6 +314,11 @@ sdm_status sdm_frame_start(sdm_map *m, const float *depth, const sdm_labeled_poi
                            const sdm_object_move *moves, int32_t n_moves,
                            const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after);
 sdm_status sdm_frame_moves(sdm_map *m);
+/* More than SDM_MAX_MOVES moving objects on a Z-slab shard: sdm_frame_moves applies ONE batch and, if objects are left,
+ * issues the next batch's member count and publishes its per-object counts in counts_local; *pending = 1 then says: gather
+ * the count rows once more (the same all-gather as behind sdm_frame_start) and call sdm_frame_moves again.  The export
+ * segments collect the copies of all batches; they are exchanged once, when nothing is pending any more. */
+sdm_status sdm_frame_moves_pending(sdm_map *m, int32_t *pending);
 sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev);
 sdm_status sdm_set_halo_buffers(sdm_map *m, int32_t *counts_local, const int32_t *counts_all, void *send,
                                 const void *recv_all, int32_t cap_records);
@@ -465,6 +470,9 @@ sdm_status sdm_debug_hinted_groups(sdm_map *m, int64_t *n_out);
  * per-tile lists and a launch of their own; the library picks per sweep from what the sweep before found (speed only:
  * the results are the same).  mode 1 / 0: always / never the lists; -1: the library picks again. */
 sdm_status sdm_debug_sweep_lists(sdm_map *m, int32_t mode);
+/* Test hook.  The table of older owner-set memberships (sdm_stats.alias_entries) takes 65536 entries; `cap` (1..65536)
+ * makes it report its overflow earlier, so that a test can reach it on a small map.  Call before the map's first frame. */
+sdm_status sdm_debug_alias_cap(sdm_map *m, int32_t cap);
 
 /* ---- device-side unit tests of the hand-written primitives (tests/test_primitives_gpu.py) */
 sdm_status sdm_test_scan(const uint32_t *in, uint32_t *out, int64_t n);

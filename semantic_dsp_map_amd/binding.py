@@ -127,6 +127,7 @@ def load_library():
         "sdm_update_finish": [vp, vp, i32, u32, i32],
         "sdm_frame_start": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32, i32],
         "sdm_frame_moves": [vp],
+        "sdm_frame_moves_pending": [vp, C.POINTER(C.c_int32)],
         "sdm_frame_predict": [vp, C.POINTER(vp)],
         "sdm_set_halo_buffers": [vp, vp, vp, vp, vp, i32],
         "sdm_comm_unique_id": [vp],
@@ -176,6 +177,7 @@ def load_library():
         "sdm_debug_fill_dense_ex": [vp, i32],
         "sdm_debug_hinted_groups": [vp, C.POINTER(C.c_int64)],
         "sdm_debug_sweep_lists": [vp, i32],
+        "sdm_debug_alias_cap": [vp, i32],
         "sdm_test_scan": [vp, vp, i64],
         "sdm_test_sort_pairs": [vp, vp, vp, vp, i64, i32],
     }
@@ -345,6 +347,12 @@ class SdmMap:
     def frame_moves(self):
         _check(self.L, self.L.sdm_frame_moves(self.h), "sdm_frame_moves")
 
+    def frame_moves_pending(self):
+        """True: a further batch of a long object list has published its counts and waits for their exchange"""
+        n = C.c_int32()
+        _check(self.L, self.L.sdm_frame_moves_pending(self.h, C.byref(n)), "sdm_frame_moves_pending")
+        return bool(n.value)
+
     def frame_predict(self):
         ck = C.c_void_p()
         _check(self.L, self.L.sdm_frame_predict(self.h, C.byref(ck)), "sdm_frame_predict")
@@ -480,9 +488,16 @@ class SdmMap:
         _check(self.L, self.L.sdm_tracks_with_particles(self.h, _ptr(out), out.size, C.byref(n)), "sdm_tracks_with_particles")
         return out[:n.value].copy()
 
-    def stats(self, count_live=False):
+    def stats_unchecked(self):
+        """sdm_get_stats without raising on the status it returns (it reports the frame's capacity errors and fills the
+        structure all the same)"""
+        return self.stats(check=False)
+
+    def stats(self, count_live=False, check=True):
         s = Stats()
-        _check(self.L, self.L.sdm_get_stats(self.h, C.byref(s), 1 if count_live else 0), "sdm_get_stats")
+        rc = self.L.sdm_get_stats(self.h, C.byref(s), 1 if count_live else 0)
+        if check:
+            _check(self.L, rc, "sdm_get_stats")
         d = {k: getattr(s, k) for k, _ in Stats._fields_ if k not in ("stage_ms", "restamped_slabs")}
         d["stage_ms"] = list(s.stage_ms)
         d["restamped_slabs"] = list(s.restamped_slabs)
@@ -569,6 +584,10 @@ class SdmMap:
         """Test hook: 1 / 0 = the non-incremental sweeps always / never hand their sparse voxels to per-tile lists, -1 = the
         library picks per sweep (sdm_debug_sweep_lists)."""
         _check(self.L, self.L.sdm_debug_sweep_lists(self.h, int(mode)), "sdm_debug_sweep_lists")
+
+    def set_alias_cap(self, cap):
+        """Test hook: the table of older owner-set memberships reports its overflow at `cap` entries (before the first frame)."""
+        _check(self.L, self.L.sdm_debug_alias_cap(self.h, int(cap)), "sdm_debug_alias_cap")
 
     def fill_dense(self):
         _check(self.L, self.L.sdm_debug_fill_dense(self.h), "sdm_debug_fill_dense")

@@ -67,7 +67,7 @@ __device__ __forceinline__ sdm_labeled_point load_point(const sdm_labeled_point 
   __builtin_memcpy(&o, t, sizeof(o));
   return o;
 }
-// A = alignment the caller guarantees for src (record fields: rec_align(S), sdm_internal.h); below the natural
+// A = alignment the caller guarantees for src; below the natural
 // alignment of the widest piece (S <= 4 only) the copy is left to the compiler.
 template <int A = 16, typename T, int N>
 __device__ __forceinline__ void load_vec(T (&dst)[N], const T *src) {
@@ -98,6 +98,111 @@ __device__ __forceinline__ void store_vec(T *dst, const T (&src)[N]) {
   __builtin_memcpy(__builtin_assume_aligned(dst, AL), src, B);
 }
 
+// ---- whole-record access (layout: sdm_internal.h, SlotRef).  A record - the S - 1 particle slots of one voxel, 10 (S - 1)
+// bytes at a 2-byte aligned address - is fetched as raw words: 16-byte pieces and one 8-byte piece where the length asks
+// for it, each an under-aligned access (global_load_dwordx4 / ds_read_b128 take any address on gfx950), up to 6 bytes
+// beyond the record's end (the next record or the array's padding), all requested before anything is looked at; the
+// fields are then taken out of the registers with shifts at compile-time offsets.  The arrays the callers work on keep
+// one entry per SLOT (index 0 = the time particle: constants nobody reads) so that slot numbers stay what they are in
+// the reference.
+template <int S>
+struct RecRaw {
+  static constexpr int L = S - 1, BYTES = 10 * L, N8 = (BYTES + 7) / 8;  // particle slots, bytes, 8-byte units fetched
+  uint32_t d[2 * N8];
+};
+template <int S, bool NT = true>
+__device__ __forceinline__ void rec_fetch(RecRaw<S> &raw, const unsigned char *r) {
+  constexpr int N8 = RecRaw<S>::N8;
+#pragma unroll
+  for (int j = 0; j < N8 / 2; ++j) {
+    const rec_v4u *q = reinterpret_cast<const rec_v4u *>(r + 16 * j);
+    const rec_v4u t = NT ? __builtin_nontemporal_load(q) : *q;
+    raw.d[4 * j + 0] = t.x;
+    raw.d[4 * j + 1] = t.y;
+    raw.d[4 * j + 2] = t.z;
+    raw.d[4 * j + 3] = t.w;
+  }
+  if constexpr (N8 & 1) {
+    const rec_v2u *q = reinterpret_cast<const rec_v2u *>(r + 16 * (N8 / 2));
+    const rec_v2u t = NT ? __builtin_nontemporal_load(q) : *q;
+    raw.d[2 * N8 - 2] = t.x;
+    raw.d[2 * N8 - 1] = t.y;
+  }
+}
+__device__ __forceinline__ uint32_t raw_u16(const uint32_t *d, int off) { return (d[off >> 2] >> ((off & 3) * 8)) & 0xffffu; }  // off even
+__device__ __forceinline__ uint32_t raw_u8(const uint32_t *d, int off) { return (d[off >> 2] >> ((off & 3) * 8)) & 0xffu; }
+template <int S>
+__device__ __forceinline__ void rec_unpack(const RecRaw<S> &raw, float (&wv)[S], uint16_t (&ts)[S], uint16_t (&trk)[S], uint8_t (&lab)[S],
+                                           uint8_t (&stv)[S]) {
+  constexpr int L = S - 1;
+  wv[0] = 0.f;
+  ts[0] = 0;
+  trk[0] = 0;
+  lab[0] = 0;
+  stv[0] = ST_TIMEPTC;
+#pragma unroll
+  for (int k = 0; k < L; ++k) {
+    wv[k + 1] = __uint_as_float(raw.d[k]);
+    ts[k + 1] = (uint16_t)raw_u16(raw.d, 4 * L + 2 * k);
+    trk[k + 1] = (uint16_t)raw_u16(raw.d, 6 * L + 2 * k);
+    lab[k + 1] = (uint8_t)raw_u8(raw.d, 8 * L + k);
+    stv[k + 1] = (uint8_t)raw_u8(raw.d, 9 * L + k);
+  }
+}
+// the whole record of one voxel into per-slot arrays
+template <int S>
+__device__ __forceinline__ void rec_load(const unsigned char *r, float (&wv)[S], uint16_t (&ts)[S], uint16_t (&trk)[S], uint8_t (&lab)[S],
+                                         uint8_t (&stv)[S]) {
+  RecRaw<S> raw;
+  rec_fetch<S>(raw, r);
+  rec_unpack<S>(raw, wv, ts, trk, lab, stv);
+}
+// status and time-stamp rows only (visibility, the replays): the status bytes are the record's last L bytes - one 8- or
+// 16-byte piece that ends with the record -, the stamps 2 L bytes from offset 4 L in 8-byte units
+template <int S>
+__device__ __forceinline__ void rec_load_st_ts(const unsigned char *r, uint8_t (&stv)[S], uint16_t (&ts)[S]) {
+  constexpr int L = S - 1;
+  stv[0] = ST_TIMEPTC;
+  ts[0] = 0;
+  if constexpr (L <= 8) {
+    const rec_v2u t = __builtin_nontemporal_load(reinterpret_cast<const rec_v2u *>(r + 10 * L - 8));
+    const uint32_t d[2] = {t.x, t.y};
+#pragma unroll
+    for (int k = 0; k < L; ++k) stv[k + 1] = (uint8_t)raw_u8(d, 8 - L + k);
+  } else {
+    const rec_v4u t = __builtin_nontemporal_load(reinterpret_cast<const rec_v4u *>(r + 10 * L - 16));
+    const uint32_t d[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int k = 0; k < L; ++k) stv[k + 1] = (uint8_t)raw_u8(d, 16 - L + k);
+  }
+  constexpr int N8 = (2 * L + 7) / 8;
+  uint32_t d[2 * N8];
+#pragma unroll
+  for (int j = 0; j < N8 / 2; ++j) {
+    const rec_v4u t = __builtin_nontemporal_load(reinterpret_cast<const rec_v4u *>(r + 4 * L + 16 * j));
+    d[4 * j + 0] = t.x;
+    d[4 * j + 1] = t.y;
+    d[4 * j + 2] = t.z;
+    d[4 * j + 3] = t.w;
+  }
+  if constexpr (N8 & 1) {
+    const rec_v2u t = __builtin_nontemporal_load(reinterpret_cast<const rec_v2u *>(r + 4 * L + 16 * (N8 / 2)));
+    d[2 * N8 - 2] = t.x;
+    d[2 * N8 - 1] = t.y;
+  }
+#pragma unroll
+  for (int k = 0; k < L; ++k) ts[k + 1] = (uint16_t)raw_u16(d, 2 * k);
+}
+// whole rows back (rare paths: clamp / cull write-backs of the sweep, stale slots deleted by the visibility pass)
+template <int S>
+__device__ __forceinline__ void rec_store_w(unsigned char *r, const float (&wv)[S]) {
+  __builtin_memcpy(__builtin_assume_aligned(r, 2), &wv[1], 4 * (S - 1));
+}
+template <int S>
+__device__ __forceinline__ void rec_store_status(unsigned char *r, const uint8_t (&stv)[S]) {
+  __builtin_memcpy(r + 9 * (S - 1), &stv[1], S - 1);
+}
+
 __device__ __forceinline__ uint32_t stamp_max(const State &st, uint32_t rx, uint32_t ry, uint32_t rz) {
   uint32_t a = st.stamps_x[rx], b = st.stamps_y[ry], c = st.stamps_z[rz];
   uint32_t m = a > b ? a : b;
@@ -105,14 +210,8 @@ __device__ __forceinline__ uint32_t stamp_max(const State &st, uint32_t rx, uint
 }
 
 // ------------------------------------------------------------------------------------ A13
-// RingBufferOperations::clear (mc_ring/operations.h:684-723): slot 0 = TIMEPTC, others INVALID.
-// (the zero fields are cleared with hipMemsetAsync by the launcher)
-__global__ __launch_bounds__(TPB) void k_clear_status(uint8_t *__restrict__ status, uint32_t n_voxels, uint32_t voxel_stride) {
-  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t stride = gridDim.x * blockDim.x;
-  for (; lv < n_voxels; lv += stride) status[(size_t)lv * voxel_stride] = (uint8_t)ST_TIMEPTC;  // the record was zeroed: INVALID
-}
-
+// RingBufferOperations::clear (mc_ring/operations.h:684-723).  A fresh map is all zeros (launch_clear: hipMemsetAsync;
+// INVALID = 0, and the time particles' TIMEPTC status is not stored).
 // RingBufferOperations::clear on a used map (operations.h:697-722): status, position, weight, time stamp; track id,
 // label and forget count stay.  One pass, one thread per slot: everything sdm_clear resets is written here (the
 // per-voxel arrays by the slot-0 lane), so the map's bytes cross HBM once.
@@ -121,9 +220,12 @@ __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, uint32_t 
   if (li >= n) return;
   st.pos4[li] = make_float4(0.f, 0.f, 0.f, 0.f);  // (the forget count, which clear() does not touch, lives in State::forget)
   uint32_t slot = (uint32_t)li & (uint32_t)(d.S - 1);
-  st.w[rec_index(li, d.p_n, REC_W)] = 0.f;
-  st.ts[rec_index(li, d.p_n, REC_TS)] = 0;
-  st.status[rec_index(li, d.p_n, REC_STATUS)] = slot == 0 ? (uint8_t)ST_TIMEPTC : (uint8_t)ST_INVALID;
+  if (slot) {
+    const SlotRef r = slot_ref_li(st, d.p_n, li);
+    r.set_w(0.f);
+    r.set_ts(0);
+    r.set_status(ST_INVALID);
+  }
   st.owner[li] = OWNER_NONE;
   if (slot == 0) {
     size_t lv = li >> d.p_n;
@@ -135,8 +237,7 @@ __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, uint32_t 
   }
 }
 
-// The same reset with every byte it touches on a lane-linear 16-byte access (S >= 8: a record is a whole number of
-// 16-byte pieces).  k_clear_slots stores a weight, a stamp and a status byte per lane: three store instructions that each
+// The same reset with every byte it touches on a lane-linear 16-byte access (S >= 8).  k_clear_slots stores a weight, a stamp and a status byte per lane: three store instructions that each
 // leave holes in five or six lines of the record array.  Here a workgroup takes CLR_VOX consecutive voxels: their
 // positions (stored whole; the forget counts have their own plane and are not touched), the pieces of their records that hold weights, stamps and
 // status bytes (the track ids and labels in between are left alone: nothing of a record is read), their owners and the
@@ -148,10 +249,9 @@ __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, uint32_t 
 constexpr int CLR_VOX = 256;
 template <int S>
 __global__ __launch_bounds__(TPB) void k_clear_map(Dims d, State st, uint32_t *__restrict__ mv_head) {
-  static_assert(S >= 8 && (10 * S) % 16 == 0, "whole 16-byte pieces per record");
-  constexpr int REC = 10 * S, RP = REC / 16;  // bytes, pieces of one record
-  constexpr uint32_t STATUS_WORD0 = (uint32_t)ST_TIMEPTC | (uint32_t)ST_INVALID << 8 | (uint32_t)ST_INVALID << 16 | (uint32_t)ST_INVALID << 24;
-  constexpr uint32_t STATUS_WORD = (uint32_t)ST_INVALID * 0x01010101u;
+  static_assert(S >= 8 && (CLR_VOX * 10 * (S - 1)) % 16 == 0, "a workgroup's records are whole 16-byte pieces");
+  constexpr int L = S - 1, REC = 10 * L;  // particle slots, bytes of one record
+  static_assert(ST_INVALID == 0, "every byte clear() resets in a record is a zero byte");
   const uint32_t tid = threadIdx.x;
   const size_t lv0 = (size_t)blockIdx.x * CLR_VOX;
   const uint32_t nv = (uint32_t)(d.v_count - lv0 < (size_t)CLR_VOX ? d.v_count - lv0 : (size_t)CLR_VOX);  // a multiple of 8
@@ -168,32 +268,39 @@ __global__ __launch_bounds__(TPB) void k_clear_map(Dims d, State st, uint32_t *_
     const uint32_t q = k * TPB + tid;
     if (q < npos) __builtin_nontemporal_store(v4u{0u, 0u, 0u, 0u}, pp + q);
   }
-  // records: RP pieces per voxel; which words of a piece are zeroed / left alone / status follows from its offset in the
-  // record [w: 4S | ts: 2S | track: 2S | label: S | status: S]
-  constexpr int RPT = (CLR_VOX * RP + TPB - 1) / TPB;
-  v4u *rp = reinterpret_cast<v4u *>(st.rec + lv0 * REC);
-  const uint32_t nrec = nv * RP;
+  // records: the workgroup's nv records are one block of nv * REC bytes that starts on a 16-byte boundary; piece q of it
+  // begins at byte (16 q) mod REC of some record.  In the record [w: 4L | ts: 2L | track: 2L | label: L | status: L] the
+  // bytes below 6 L and from 9 L on are reset (to zero), the track ids and labels in between are left alone: nothing of a
+  // record is read.  Whole pieces go out as one 16-byte store, the others word by word resp. byte by byte.
+  const uint32_t nrec = (nv * REC + 15u) / 16u;  // (nv is a multiple of 8: 80 L bytes, whole pieces)
+  constexpr int RPT = (CLR_VOX * REC / 16 + TPB - 1) / TPB;
+  unsigned char *rb = st.rec + lv0 * REC;
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     const uint32_t q = k * TPB + tid;
     if (q >= nrec) continue;
-    const uint32_t r = q % RP;
-    uint32_t wd[4];
-    bool reset[4], all = true;
+    const uint32_t o = (q * 16u) % (uint32_t)REC;
+    uint32_t keep = 0;  // bit c: byte c of the piece holds a track id or a label
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const uint32_t ob = r * 16 + c * 4;  // byte offset of the word in the record
-      reset[c] = ob < 6 * S || ob >= 9 * S;
-      wd[c] = ob < 6 * S ? 0u : (ob == 9 * S ? STATUS_WORD0 : STATUS_WORD);
-      all = all && reset[c];
+    for (int c = 0; c < 16; ++c) {
+      uint32_t off = o + c;
+      off = off >= (uint32_t)REC ? off - REC : off;
+      keep |= (off >= 6u * L && off < 9u * L ? 1u : 0u) << c;
     }
-    if (all) {
-      __builtin_nontemporal_store(v4u{wd[0], wd[1], wd[2], wd[3]}, rp + q);
-    } else {  // a piece that also holds track ids or labels (S = 8: the 8 status bytes behind the 8 labels)
-      uint32_t *w32 = reinterpret_cast<uint32_t *>(rp + q);
+    if (keep == 0u) {
+      __builtin_nontemporal_store(v4u{0u, 0u, 0u, 0u}, reinterpret_cast<v4u *>(rb) + q);
+    } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (reset[c]) w32[c] = wd[c];
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const uint32_t kb = (keep >> (4 * c4)) & 15u;
+        if (kb == 0u) {
+          reinterpret_cast<uint32_t *>(rb + (size_t)q * 16)[c4] = 0u;
+        } else if (kb != 15u) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (!((kb >> c) & 1u)) rb[(size_t)q * 16 + c4 * 4 + c] = 0;
+        }
+      }
     }
   }
   // owners (2 B per slot) and the per-voxel arrays
@@ -388,13 +495,13 @@ __device__ __forceinline__ void occupancy_evaluate_core(const State &st, float o
     nflag = VF_CLEAN;
     return;
   }
-  const size_t base = (size_t)lv * S;
+  unsigned char *const rec = rec_ptr(st, S, lv);
   if (dirty_w) {
     float wout[S];
     wout[0] = wv_in[0];
 #pragma unroll
     for (int i = 1; i < S; ++i) wout[i] = wv[i];
-    store_vec<rec_align(S)>(st.w + base * REC_W, wout);
+    rec_store_w<S>(rec, wout);
   }
   uint8_t flag = dirty_w ? VF_DIRTY : VF_CLEAN;  // the sum above used the unclamped weights: the next evaluation differs
   if (dirty_s) {
@@ -406,7 +513,7 @@ __device__ __forceinline__ void occupancy_evaluate_core(const State &st, float o
       sout[i] = (uint8_t)stv[i];
       left = left || stv[i] != ST_INVALID;
     }
-    store_vec<rec_align(S)>(st.status + base * REC_STATUS, sout);
+    rec_store_status<S>(rec, sout);
     flag = left ? VF_DIRTY : VF_EMPTY;  // a culled slot still counted in this sum
   }
   nflag = flag;
@@ -710,15 +817,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 4 
   if (threadIdx.x == 0 && nl) atomicAdd(&cnt->shard[tile & (VIS_SHARDS - 1)].sweep, nl);
   for (uint32_t k = threadIdx.x; k < nl; k += TPB) {
     const uint32_t lv = blk0 + live_list[k];
-    const size_t base = (size_t)lv * S;
     uint16_t ts1[S], trk[S];
     uint8_t st1[S], lab[S];
     float wv[S];
-    load_vec<rec_align(S)>(st1, st.status + base * REC_STATUS);
-    load_vec<rec_align(S)>(wv, st.w + base * REC_W);  // the whole record (one or two lines at S = 8) in one go
-    load_vec<rec_align(S)>(ts1, st.ts + base * REC_TS);
-    load_vec<rec_align(S)>(trk, st.track + base * REC_TRACK);
-    load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
+    rec_load<S>(rec_ptr(st, S, lv), wv, ts1, trk, lab, st1);  // the whole record (one or two lines at S = 8) in one go
     uint32_t rx, ry, rz;
     voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
     const uint32_t smax = stamp_max(st, rx, ry, rz);
@@ -751,9 +853,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(S <= 8 ? 4 
 //   are: measured 75 us against 46 us for the same bytes on the benchmark state).  On a sparse map this launch is all
 //   there is.
 // k_occupancy_dense  a wave owns 8 consecutive chunks, lane = voxel, and leaves at once when none of them has a mask.
-//   A chunk's 64 records are one contiguous block of 640*S bytes: fetched with lane-linear 16-byte loads (1 KB per
-//   instruction), passed through LDS, where every lane picks up its own record (record stride 80 B at S = 8:
-//   conflict-free ds_read_b128); a per-lane fetch of 80-byte records would touch all of the block's lines with every
+//   A chunk's 64 records are one contiguous block of 640*(S-1) bytes: fetched with lane-linear 16-byte loads (1 KB per
+//   instruction), passed through LDS, where every lane picks up its own record (record stride 70 B at S = 8);
+//   a per-lane fetch of the records would touch all of the block's lines with every
 //   load instruction (measured: 0.70 ms for the dense case against 0.33 ms).  The loads of the wave's next two chunks
 //   are in flight while one is evaluated.
 // What bounds the dense case (rocprofv3 SQ counters, profiles/r02_dense_pmc.txt): not the bytes alone - the
@@ -954,12 +1056,7 @@ __device__ __forceinline__ void occupancy_scan_tile(const Dims &d, float occ_thr
           uint16_t ts1[S], trk[S];
           uint8_t st1[S], lab[S];
           float wv[S];
-          const size_t base = (size_t)lv * S;
-          load_vec<rec_align(S)>(st1, st.status + base * REC_STATUS);
-          load_vec<rec_align(S)>(wv, st.w + base * REC_W);
-          load_vec<rec_align(S)>(ts1, st.ts + base * REC_TS);
-          load_vec<rec_align(S)>(trk, st.track + base * REC_TRACK);
-          load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
+          rec_load<S>(rec_ptr(st, S, lv), wv, ts1, trk, lab, st1);  // the whole record (one or two lines at S = 8) in one go
           uint32_t rx, ry, rz;
           voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
           const uint32_t smax = stamp_max(st, rx, ry, rz);
@@ -1053,12 +1150,7 @@ __device__ __forceinline__ void occupancy_listed_units(const Dims &d, float occ_
       uint16_t ts1[S], trk[S];
       uint8_t st1[S], lab[S];
       float wv[S];
-      const size_t base = (size_t)lv * S;
-      load_vec<rec_align(S)>(st1, st.status + base * REC_STATUS);
-      load_vec<rec_align(S)>(wv, st.w + base * REC_W);
-      load_vec<rec_align(S)>(ts1, st.ts + base * REC_TS);
-      load_vec<rec_align(S)>(trk, st.track + base * REC_TRACK);
-      load_vec<rec_align(S)>(lab, st.label + base * REC_LABEL);
+      rec_load<S>(rec_ptr(st, S, lv), wv, ts1, trk, lab, st1);  // the whole record (one or two lines at S = 8) in one go
       uint32_t rx, ry, rz;
       voxel_to_ring(d, d.v_begin + lv, rx, ry, rz);
       const uint32_t smax = stamp_max(st, rx, ry, rz);
@@ -1092,7 +1184,8 @@ template <int S>
 __global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d, float occ_threshold, State st, Counters *cnt,
                                                          const unsigned long long *__restrict__ need, uint32_t remark, uint32_t n_tiles) {
   if (blockIdx.x == 0 && threadIdx.x < OCC_LIST_SHARDS) occupancy_listed_wrap(st, n_tiles);  // (the units are done: the launch before this one)
-  constexpr int REC = 10 * S;                    // bytes of one record
+  constexpr int REC = 10 * (S - 1);              // bytes of one record
+  static_assert((OCC_CHUNK * REC) % 128 == 0, "a chunk of records starts on a cache line");
   constexpr int PIECES = OCC_CHUNK * REC / 16;   // 16-byte pieces of one chunk of records
   constexpr int PPL = (PIECES + 63) / 64;
   __shared__ v4u rec_stage[OCC_WAVES][PPL * 64];  // one chunk of records per wave, for the lane <-> record transposition
@@ -1203,14 +1296,10 @@ __global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-      const unsigned char *r = reinterpret_cast<const unsigned char *>(rec_stage[wave]) + lane * REC;
-      constexpr int RA = rec_align(S);
-      __builtin_memcpy(wv, __builtin_assume_aligned(r, RA), 4 * S);
-      __builtin_memcpy(ts1, __builtin_assume_aligned(r + 4 * S, RA < 2 * S ? RA : 2 * S), 2 * S);
-      __builtin_memcpy(trk, __builtin_assume_aligned(r + 6 * S, RA < 2 * S ? RA : 2 * S), 2 * S);
-      __builtin_memcpy(lab, __builtin_assume_aligned(r + 8 * S, RA < S ? RA : S), S);
-      __builtin_memcpy(st1, __builtin_assume_aligned(r + 9 * S, RA < S ? RA : S), S);
+    {  // the lane's record out of the stage (2-byte aligned: under-aligned ds_read_b128s)
+      RecRaw<S> raw;
+      rec_fetch<S, false>(raw, reinterpret_cast<const unsigned char *>(rec_stage[wave]) + lane * REC);
+      rec_unpack<S>(raw, wv, ts1, trk, lab, st1);
     }
     uint32_t smk = s_cur;
     {
@@ -1278,18 +1367,14 @@ __global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d
   }
 }
 
-// slot 0 of the exported stamp array carries the voxel stamp (sdm_dump_state / sdm_load_state keep the reference's
-// layout: the time particle is slot 0 of the voxel, buffer.h:57-79)
-__global__ __launch_bounds__(TPB) void k_vts_to_slot0(Dims d, State st) {
-  uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lv < d.v_count) st.ts[(size_t)lv * d.S * REC_TS] = st.vts[lv];
-}
-__global__ __launch_bounds__(TPB) void k_vts_from_slot0(Dims d, State st) {
+// after sdm_load_state: the "something here" flag of every voxel from the status rows (the voxel stamps were taken from
+// slot 0 of the imported stamp array by k_rec_pack: sdm_dump_state / sdm_load_state keep the reference's layout, the time
+// particle is slot 0 of the voxel, buffer.h:57-79)
+__global__ __launch_bounds__(TPB) void k_vflag_from_records(Dims d, State st) {
   uint32_t lv = blockIdx.x * blockDim.x + threadIdx.x;
   if (lv >= d.v_count) return;
-  st.vts[lv] = st.ts[(size_t)lv * d.S * REC_TS];
   bool any = false;
-  for (uint32_t i = 1; i < d.S; ++i) any = any || st.status[(size_t)lv * d.S * REC_STATUS + i] != ST_INVALID;
+  for (uint32_t i = 1; i < d.S; ++i) any = any || slot_ref(st, d.S, lv, i).status() != ST_INVALID;
   st.vflag[lv] = any ? VF_DIRTY : VF_EMPTY;
 }
 
@@ -1646,8 +1731,8 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
   const uint32_t smax = stamp_max(st, rx, ry, rz);
   uint8_t stv[S];
   uint16_t tsv[S];
-  load_vec<rec_align(S)>(stv, st.status + base * REC_STATUS);
-  load_vec<rec_align(S)>(tsv, st.ts + base * REC_TS);
+  unsigned char *const rec = rec_ptr(st, S, lv);
+  rec_load_st_ts<S>(rec, stv, tsv);
   // the positions of all slots ride with the record's rows - the voxel's S positions are one 16*S-byte block (one line
   // at S = 8) whatever is live in it; requested slot by slot where a slot turned out live, each load sat in a branch of
   // its own and was waited for before the next one was requested (S - 1 dependent round trips)
@@ -1692,7 +1777,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
     if (!live[i] || pixv[i] < 0) continue;
     const float dpt = dptv[i];
     if (dpt > d.dmax) {  // nothing measurable along this ray: free (operations.h:1389-1395)
-      st.w[base * REC_W + i] = SDM_OCC_INIT_WEIGHT;
+      SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_w(SDM_OCC_INIT_WEIGHT);
       wrote_free = true;
       observed = true;
       continue;
@@ -1726,7 +1811,7 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
         sc.cnt->overflow = 1;
       }
     }
-  if (dirty) store_vec<rec_align(S)>(st.status + base * REC_STATUS, stv);
+  if (dirty) rec_store_status<S>(rec, stv);
   if (dirty || wrote_free) st.vflag[lv] = VF_DIRTY;
   bool stamped = observed;
   if (!observed && valid_n == 0) stamped = im_ok && im_z <= im_depth;
@@ -2101,8 +2186,9 @@ __global__ __launch_bounds__(BR_TPB) __attribute__((amdgpu_waves_per_eu(5, 5))) 
             const size_t li = (size_t)v[i0 + i] - slot_base;
             q[i] = st.pos4[li];
             q[i].w = __uint_as_float((uint32_t)st.forget[li]);
-            w8[i] = st.w[rec_index(li, d.p_n, REC_W)];
-            t8[i] = st.track[rec_index(li, d.p_n, REC_TRACK)];
+            const SlotRef sr = slot_ref_li(st, d.p_n, li);
+            w8[i] = sr.w();
+            t8[i] = sr.track();
           }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -2146,8 +2232,9 @@ __global__ __launch_bounds__(BR_TPB) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     for (uint32_t i = 0; i < n; ++i) {
       const size_t li = (size_t)a[i] - slot_base;
       const float4 q = st.pos4[li];
-      sc.vp4[s + i] = make_float4(q.x, q.y, q.z, st.w[rec_index(li, d.p_n, REC_W)]);
-      sc.vtf[s + i] = (uint32_t)st.track[rec_index(li, d.p_n, REC_TRACK)] | ((uint32_t)st.forget[li] << 16);
+      const SlotRef sr = slot_ref_li(st, d.p_n, li);
+      sc.vp4[s + i] = make_float4(q.x, q.y, q.z, sr.w());
+      sc.vtf[s + i] = (uint32_t)sr.track() | ((uint32_t)st.forget[li] << 16);
       sc.vpix[s + i] = p;
     }
   }
@@ -2625,11 +2712,12 @@ __global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, St
         if (lu == u) my_bi = bi[u], my_tf = tf[u], my_w = pv[u].w, right_id = rb[u] != 0ull;
       const size_t li = (size_t)my_bi - slot_base;
       const uint32_t fc = (my_tf >> 16) & 0xffu;
-      st.w[rec_index(li, d.p_n, REC_W)] = my_w * (a * flt.p_detect + 1.f - flt.p_detect);
-      st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_UPDATED;
+      const SlotRef sr = slot_ref_li(st, d.p_n, li);
+      sr.set_w(my_w * (a * flt.p_detect + 1.f - flt.p_detect));
+      sr.set_status(ST_UPDATED);
       st.vflag[li >> d.p_n] = VF_DIRTY;
       mark_tile(st, li >> d.p_n, f.epoch);
-      st.ts[rec_index(li, d.p_n, REC_TS)] = (uint16_t)f.gts;
+      sr.set_ts((uint16_t)f.gts);
       if (!flt.independent) {
         uint32_t nf = right_id ? 0u : (fc < 5u ? fc + 1u : fc);
         if (nf != fc) st.forget[li] = (uint8_t)nf;
@@ -2714,6 +2802,7 @@ __global__ void k_birth_cursor(Dims d, Filter flt, Scratch sc) {
 template <int S>
 __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t base, uint8_t (&stv)[S], uint16_t (&own)[S],
                                                uint32_t n_alias, bool touched, const float (&wv)[S], const uint16_t (&trk)[S]) {
+  unsigned char *const rec = st.rec + base / S * rec_bytes(S);  // (base = lv * S)
   float weight_sum = 0.f;
   uint32_t updated = 0;
 #pragma unroll
@@ -2729,7 +2818,7 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
     for (int i = 1; i < S; ++i)
       if (stv[i] == ST_UPDATED) {
         stv[i] = ST_INVALID;
-        st.status[base * REC_STATUS + i] = ST_INVALID;
+        SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_status(ST_INVALID);
         owner_erase_local(st, base + i, trk[i], own[i], n_alias, touched);  // removeParticleFromObj
       }
     return true;
@@ -2743,10 +2832,10 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
       run += wv[i];
       if (run < thr) {
         stv[i] = ST_INVALID;
-        st.status[base * REC_STATUS + i] = ST_INVALID;
+        SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_status(ST_INVALID);
         owner_erase_local(st, base + i, trk[i], own[i], n_alias, touched);
       } else {
-        st.w[base * REC_W + i] = wpp;
+        SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_w(wpp);
         thr += wpp;
         while (run > thr) thr += wpp;
       }
@@ -2760,8 +2849,13 @@ template <int S>
 __device__ __forceinline__ bool resample_voxel_seq(const Dims &d, State &st, size_t base, uint8_t (&stv)[S]) {
   float weight_sum = 0.f;
   uint32_t updated = 0;
+  unsigned char *const rec = st.rec + base / S * rec_bytes(S);  // (base = lv * S)
   float wv[S];
-  load_vec<rec_align(S)>(wv, st.w + base * REC_W);
+  {
+    uint16_t t1[S], t2[S];
+    uint8_t l1[S], s1[S];
+    rec_load<S>(rec, wv, t1, t2, l1, s1);
+  }
 #pragma unroll
   for (int i = 1; i < S; ++i)
     if (stv[i] == ST_UPDATED) {
@@ -2775,8 +2869,8 @@ __device__ __forceinline__ bool resample_voxel_seq(const Dims &d, State &st, siz
     for (int i = 1; i < S; ++i)
       if (stv[i] == ST_UPDATED) {
         stv[i] = ST_INVALID;
-        st.status[base * REC_STATUS + i] = ST_INVALID;
-        owner_erase(st, base + i, st.track[base * REC_TRACK + i]);  // removeParticleFromObj
+        SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_status(ST_INVALID);
+        owner_erase(st, base + i, SlotRef{rec, S - 1, (uint32_t)i - 1u}.track());  // removeParticleFromObj
       }
     return true;
   }
@@ -2789,10 +2883,10 @@ __device__ __forceinline__ bool resample_voxel_seq(const Dims &d, State &st, siz
       run += wv[i];
       if (run < thr) {
         stv[i] = ST_INVALID;
-        st.status[base * REC_STATUS + i] = ST_INVALID;
-        owner_erase(st, base + i, st.track[base * REC_TRACK + i]);
+        SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_status(ST_INVALID);
+        owner_erase(st, base + i, SlotRef{rec, S - 1, (uint32_t)i - 1u}.track());
       } else {
-        st.w[base * REC_W + i] = wpp;
+        SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_w(wpp);
         thr += wpp;
         while (run > thr) thr += wpp;
       }
@@ -2812,8 +2906,8 @@ __device__ __forceinline__ void birth_replay_sequential(const Dims &d, const Fra
   const size_t base = (size_t)(v - d.v_begin) * S;
   uint8_t stv[S];
   uint16_t tsv[S];
-  load_vec<rec_align(S)>(stv, st.status + base * REC_STATUS);
-  load_vec<rec_align(S)>(tsv, st.ts + base * REC_TS);
+  unsigned char *const rec = rec_ptr(st, S, v - d.v_begin);
+  rec_load_st_ts<S>(rec, stv, tsv);
   bool resampled = false, checked = false;
   uint32_t n_success = 0, n_resamp = 0;
   // The candidates of a voxel are consecutive in the sorted list; eight at a time are fetched before the first is
@@ -2854,11 +2948,12 @@ __device__ __forceinline__ void birth_replay_sequential(const Dims &d, const Fra
           // addNewParticleWithSemantics (operations.h:171-184)
           st.pos4[base + slot] = make_float4(bp.x, bp.y, bp.z, 0.f);
           st.forget[base + slot] = 0;
-          st.w[base * REC_W + slot] = SDM_OCC_INIT_WEIGHT;
-          st.ts[base * REC_TS + slot] = (uint16_t)f.gts;
-          st.track[base * REC_TRACK + slot] = track;
-          st.label[base * REC_LABEL + slot] = label;
-          st.status[base * REC_STATUS + slot] = ST_REGULAR_BORN;
+          const SlotRef sr{rec, S - 1, (uint32_t)slot - 1u};
+          sr.set_w(SDM_OCC_INIT_WEIGHT);
+          sr.set_ts((uint16_t)f.gts);
+          sr.set_track(track);
+          sr.set_label(label);
+          sr.set_status(ST_REGULAR_BORN);
           if ((int)track <= d.max_movable) {  // addParticleToObj
             if (!owner_insert(st, base + slot, track)) sc.cnt->overflow = 1;
             flag_owner_chunk(st, base + slot);
@@ -2971,18 +3066,19 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   const size_t base = (size_t)(v - d.v_begin) * S;
   uint8_t stv[S];
   uint16_t tsv[S];
-  load_vec<rec_align(S)>(stv, st.status + base * REC_STATUS);
-  load_vec<rec_align(S)>(tsv, st.ts + base * REC_TS);
+  unsigned char *const rec = rec_ptr(st, S, v - d.v_begin);
+  float wv0[S];
+  uint16_t trk0[S];
+  {  // the whole record in one round: status and stamps, and the rows the one resampling of the voxel reads
+    uint8_t lab0[S];
+    rec_load<S>(rec, wv0, tsv, trk0, lab0, stv);
+  }
   // the voxel's owner entries and the length of the table of older memberships (addParticleToObj / removeParticleFromObj),
   // and the rows the one resampling of the voxel reads: everything the replay needs of the voxel, in one round
   uint16_t own[S];
   load_vec<(2 * S < 16 ? 2 * S : 16)>(own, st.owner + base);
   const uint32_t n_alias = st.alias[0];
   bool alias_touched = false;
-  float wv0[S];
-  uint16_t trk0[S];
-  load_vec<rec_align(S)>(wv0, st.w + base * REC_W);
-  load_vec<rec_align(S)>(trk0, st.track + base * REC_TRACK);
   uint32_t L = 0;  // candidates of the segment, capped at LMAX
   {
     bool run = true;
@@ -3083,11 +3179,12 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
     // addNewParticleWithSemantics (operations.h:171-184)
     st.pos4[base + i] = make_float4(bp.x, bp.y, bp.z, 0.f);
     st.forget[base + i] = 0;
-    st.w[base * REC_W + i] = SDM_OCC_INIT_WEIGHT;
-    st.ts[base * REC_TS + i] = (uint16_t)f.gts;
-    st.track[base * REC_TRACK + i] = track;
-    st.label[base * REC_LABEL + i] = label;
-    st.status[base * REC_STATUS + i] = ST_REGULAR_BORN;
+    const SlotRef sr{rec, S - 1, (uint32_t)i - 1u};
+    sr.set_w(SDM_OCC_INIT_WEIGHT);
+    sr.set_ts((uint16_t)f.gts);
+    sr.set_track(track);
+    sr.set_label(label);
+    sr.set_status(ST_REGULAR_BORN);
     if ((int)track <= d.max_movable) {  // addParticleToObj
       if (!owner_insert_local(st, base + i, track, own[i], n_alias, alias_touched)) sc.cnt->overflow = 1;
       flag_owner_chunk(st, base + i);
@@ -3235,9 +3332,10 @@ __global__ __launch_bounds__(TPB) void k_count_live(Dims d, State st, unsigned l
     uint32_t v = d.v_begin + lv, rx, ry, rz;
     voxel_to_ring(d, v, rx, ry, rz);
     uint32_t smax = stamp_max(st, rx, ry, rz);
-    size_t base = (size_t)lv * d.S;
-    for (uint32_t i = 1; i < d.S; ++i)
-      if (st.status[base * REC_STATUS + i] != ST_INVALID && (uint32_t)st.ts[base * REC_TS + i] >= smax) c++;
+    for (uint32_t i = 1; i < d.S; ++i) {
+      const SlotRef sr = slot_ref(st, d.S, lv, i);
+      if (sr.status() != ST_INVALID && (uint32_t)sr.ts() >= smax) c++;
+    }
     // bits 36..: voxels that pass isVoxelValid and hold a live slot (the ones the sweep fetches in full)
     const uint32_t t0 = st.vts[lv];
     if (c && t0 != 0 && t0 >= smax) cv = 1;
@@ -3257,7 +3355,7 @@ __global__ __launch_bounds__(TPB) void k_count_owner(Dims d, State st, uint16_t 
     if (st.owner[i] == track) c++;
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // older memberships the reference's set still holds
     uint32_t na = st.alias[0];
-    if (na > ALIAS_CAP) na = ALIAS_CAP;
+    if (na > st.alias_cap) na = st.alias_cap;
     for (uint32_t k = 0; k < na; ++k)
       if (st.alias[3 + 2 * k] == track) c++;
   }
@@ -3567,13 +3665,12 @@ void launch_clear(const Dims &d, const State &st, uint32_t *mv_head, hipStream_t
   if (fresh) {
     hipMemsetAsync(st.pos4, 0, n * sizeof(float4), s);
     hipMemsetAsync(st.forget, 0, n, s);
-    hipMemsetAsync(st.rec, 0, n * REC_BYTES_PER_SLOT, s);
+    hipMemsetAsync(st.rec, 0, (size_t)d.v_count * rec_bytes(d.S), s);  // INVALID = 0 (the time particles' status is not stored)
     hipMemsetAsync(st.vts, 0, (size_t)d.v_count * sizeof(uint16_t), s);
     hipMemsetAsync(st.vflag, 0, (size_t)d.v_count, s);
     hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
     hipMemsetAsync(st.res, 0, (size_t)d.v_count * sizeof(sdm_voxel_result), s);
     hipMemsetAsync(mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(k_clear_status, dim3(4096), dim3(TPB), 0, s, st.status, (uint32_t)d.v_count, (uint32_t)(d.S * REC_STATUS));
   } else {
     if (d.S == 8) hipLaunchKernelGGL(k_clear_map<8>, dim3(blocks_for(d.v_count, CLR_VOX)), dim3(TPB), 0, s, d, st, mv_head);
     else if (d.S == 16) hipLaunchKernelGGL(k_clear_map<16>, dim3(blocks_for(d.v_count, CLR_VOX)), dim3(TPB), 0, s, d, st, mv_head);
@@ -3751,22 +3848,36 @@ __global__ __launch_bounds__(TPB) void k_rec_pack(Dims d, State st, const float 
                                                   const uint8_t *__restrict__ status, size_t n) {
   size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= n) return;
-  st.status[rec_index(li, d.p_n, REC_STATUS)] = status[li];
-  st.w[rec_index(li, d.p_n, REC_W)] = w[li];
-  st.ts[rec_index(li, d.p_n, REC_TS)] = ts[li];
-  st.track[rec_index(li, d.p_n, REC_TRACK)] = track[li];
-  st.label[rec_index(li, d.p_n, REC_LABEL)] = label[li];
+  if ((li & (d.S - 1)) == 0) {  // the time particle (buffer.h:57-79): its stamp is the voxel's observation stamp, nothing else of it is kept
+    st.vts[li >> d.p_n] = ts[li];
+    return;
+  }
+  const SlotRef sr = slot_ref_li(st, d.p_n, li);
+  sr.set_status(status[li]);
+  sr.set_w(w[li]);
+  sr.set_ts(ts[li]);
+  sr.set_track(track[li]);
+  sr.set_label(label[li]);
 }
 __global__ __launch_bounds__(TPB) void k_rec_unpack(Dims d, State st, float *__restrict__ w, uint16_t *__restrict__ ts,
                                                     uint16_t *__restrict__ track, uint8_t *__restrict__ label,
                                                     uint8_t *__restrict__ status, size_t n) {
   size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= n) return;
-  status[li] = st.status[rec_index(li, d.p_n, REC_STATUS)];
-  w[li] = st.w[rec_index(li, d.p_n, REC_W)];
-  ts[li] = st.ts[rec_index(li, d.p_n, REC_TS)];
-  track[li] = st.track[rec_index(li, d.p_n, REC_TRACK)];
-  label[li] = st.label[rec_index(li, d.p_n, REC_LABEL)];
+  if ((li & (d.S - 1)) == 0) {  // slot 0 as the reference holds it: TIMEPTC, the voxel's observation stamp, zeros
+    status[li] = ST_TIMEPTC;
+    w[li] = 0.f;
+    ts[li] = st.vts[li >> d.p_n];
+    track[li] = 0;
+    label[li] = 0;
+    return;
+  }
+  const SlotRef sr = slot_ref_li(st, d.p_n, li);
+  status[li] = sr.status();
+  w[li] = sr.w();
+  ts[li] = sr.ts();
+  track[li] = sr.track();
+  label[li] = sr.label();
 }
 
 void launch_rec_pack(const Dims &d, const State &st, const float *w, const uint16_t *ts, const uint16_t *track,
@@ -3795,9 +3906,12 @@ __global__ __launch_bounds__(TPB) void k_fill_dense(Dims d, State st, uint32_t s
   h ^= h >> 15;
   h *= 2246822519u;
   h ^= h >> 13;
-  st.status[rec_index(li, d.p_n, REC_STATUS)] = i == 0 ? (uint8_t)ST_TIMEPTC : (uint8_t)((h & 7u) == 0 ? ST_REGULAR_BORN : ST_UPDATED);
-  st.w[rec_index(li, d.p_n, REC_W)] = 0.06f + (float)(h >> 20) * (0.3f / 4096.f);
-  st.ts[rec_index(li, d.p_n, REC_TS)] = (uint16_t)stamp;
+  if (i) {
+    const SlotRef sr = slot_ref_li(st, d.p_n, li);
+    sr.set_status((uint8_t)((h & 7u) == 0 ? ST_REGULAR_BORN : ST_UPDATED));
+    sr.set_w(0.06f + (float)(h >> 20) * (0.3f / 4096.f));
+    sr.set_ts((uint16_t)stamp);
+  }
   uint32_t pick = (h >> 8) & 7u;
   if (mode == 1) {
     uint32_t hv = (uint32_t)lv * 2654435761u;
@@ -3807,8 +3921,11 @@ __global__ __launch_bounds__(TPB) void k_fill_dense(Dims d, State st, uint32_t s
     pick = (hv >> 8) & 7u;
     if (((hv >> 4) & 15u) == 0 && (i & 1u)) pick = (pick + 1u) & 7u;  // a border voxel: two tracks
   }
-  st.track[rec_index(li, d.p_n, REC_TRACK)] = (uint16_t)(65524u + pick);
-  st.label[rec_index(li, d.p_n, REC_LABEL)] = (uint8_t)(5u + pick);
+  if (i) {
+    const SlotRef sr = slot_ref_li(st, d.p_n, li);
+    sr.set_track((uint16_t)(65524u + pick));
+    sr.set_label((uint8_t)(5u + pick));
+  }
   st.owner[li] = OWNER_NONE;
   if (i == 0) {
     st.vts[lv] = (uint16_t)stamp;
@@ -3829,9 +3946,8 @@ void launch_fill_dense(const Dims &d, const State &st, uint32_t stamp, int mode,
   hipLaunchKernelGGL(k_fill_dense, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, stamp, mode);
 }
 
-void launch_vts_sync(const Dims &d, const State &st, int to_slot0, hipStream_t s) {
-  if (to_slot0) hipLaunchKernelGGL(k_vts_to_slot0, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st);
-  else hipLaunchKernelGGL(k_vts_from_slot0, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st);
+void launch_vflag_from_records(const Dims &d, const State &st, hipStream_t s) {
+  hipLaunchKernelGGL(k_vflag_from_records, dim3(blocks_for(d.v_count)), dim3(TPB), 0, s, d, st);
 }
 
 void launch_count_live(const Dims &d, const State &st, unsigned long long *out, hipStream_t s) {

@@ -131,6 +131,8 @@ struct sdm_map {
   // batches by sdm_frame_moves / sdm_frame_predict (whole maps, launch by launch)
   std::vector<sdm_object_move> moves_all;
   std::vector<int32_t> removes_all;
+  size_t mv_batch_next = 0;     // first object of the next batch of a long object list (0: none left)
+  bool mv_batch_ready = false;  // Z-slab shard: that batch's member count is issued, its counts await their exchange
   uint32_t mv_seq = 0;            // frames with moving objects so far (FrameArgs::mv_seq)
   uint32_t *d_track_bits = nullptr;  // sdm_tracks_with_particles: one bit per track id
   int32_t *d_counts_local = nullptr;
@@ -515,13 +517,22 @@ sdm_status check_counters(sdm_map *m, Counters *out) {
   Counters c;
   HIP_TRY(hipStreamSynchronize(m->s_frustum));
   HIP_TRY(hipStreamSynchronize(m->s_birth));
+  uint32_t al[2] = {0, 0};  // length and sticky overflow word of the table of older set memberships (State::alias)
   HIP_TRY(hipMemcpyAsync(&c, m->sc.cnt, sizeof(Counters), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipMemcpyAsync(al, m->st.alias, 8, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   {
     const sdm_status rc = sweep_mode_latch(m);
     if (rc != SDM_OK) return rc;
   }
   if (out) *out = c;
+  if (al[1] != 0 || al[0] > m->st.alias_cap) {
+    // sticky (include/sdm.h): once entries were dropped the owner sets are incomplete, and every later frame - also one
+    // with removals or births only, which never looks at Counters::overflow's move-list bit - works on incomplete sets
+    set_error("capacity", __FILE__, __LINE__, "the table of older owner-set memberships overflowed (more than 8192 particle slots that sit in two "
+              "moving objects' sets at once): the owner sets are incomplete until sdm_clear / sdm_load_state");
+    return SDM_ERR_CAPACITY;
+  }
   if (c.overflow) {
     set_error("capacity", __FILE__, __LINE__, "visible-particle or move list overflowed: more visible particles than sdm_config.max_visible, more in ONE image row than "
               "max(2 max_visible / height, 2 width slots) - raise max_visible -, or more than 2^21 in one pixel's bin");
@@ -791,12 +802,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   HIP_TRY(hipMemsetAsync(m->st.forget, 0, n_slots, m->stream));
   // one record per voxel: w | ts | track | label (sdm_internal.h); one chunk of 64 records of padding behind the last, so
   // that the sweep's chunk-wide loads need no clamp at the end of the map (k_occupancy_dense)
-  A(m->st.rec, (n_slots + (size_t)64 * d.S) * REC_BYTES_PER_SLOT);
-  m->st.w = reinterpret_cast<float *>(m->st.rec);
-  m->st.ts = reinterpret_cast<uint16_t *>(m->st.rec + 4 * (size_t)d.S);
-  m->st.track = reinterpret_cast<uint16_t *>(m->st.rec + 6 * (size_t)d.S);
-  m->st.label = reinterpret_cast<uint8_t *>(m->st.rec + 8 * (size_t)d.S);
-  m->st.status = m->st.rec + 9 * (size_t)d.S;
+  A(m->st.rec, rec_array_bytes(d.v_count, d.S));
   A(m->st.vts, (size_t)d.v_count + 64);    // (+ one chunk: the sweep's chunk-wide loads need no clamp at the end of the map)
   A(m->st.vflag, (size_t)d.v_count + 64);
   m->st.tile_stride = (uint32_t)tile_mark_bytes(d);
@@ -814,6 +820,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(m->st.owner_flag, owner_flag_bytes(n_slots));
   A(m->st.owner_flag2, owner_flag2_bytes(n_slots));
   A(m->st.alias, 2 + 2 * ALIAS_CAP);
+  m->st.alias_cap = ALIAS_CAP;
   HIP_TRY(hipMemsetAsync(m->st.alias, 0, 8, m->stream));
   A(m->st.alias_filter, ALIAS_FILTER_WORDS);
   HIP_TRY(hipMemsetAsync(m->st.alias_filter, 0, ALIAS_FILTER_WORDS * 4, m->stream));
@@ -1145,16 +1152,18 @@ inline void stage_mark(sdm_map *m, int stage) {
 // frustum box; the frame block is complete afterwards except for the input pointers.
 sdm_status frame_host_prepare(sdm_map *m, const float cam_pos[3], const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
                               const int32_t *remove_tracks, int32_t n_remove, uint32_t flags, int32_t stop_after) {
-  // Lists longer than the frame block holds are worked off in batches (sdm_frame_moves, sdm_frame_predict) - on a whole
-  // map.  A Z-slab shard exchanges per-object member counts and copies with the other shards once per frame: there the
-  // block's capacity is the limit.
-  if ((n_moves > MAX_MOVE_OBJECTS || n_remove > MAX_REMOVE_TRACKS) && (m->d.v_count != m->d.V || m->comm || m->capturing)) {
-    set_error("sdm_update", __FILE__, __LINE__,
-              "more than SDM_MAX_MOVES (48) moving objects or SDM_MAX_REMOVALS (128) removals in one frame of a SHARDED map: split the call");
+  // Lists longer than the frame block holds are worked off in batches (sdm_frame_moves, sdm_frame_predict).  On a Z-slab
+  // shard every batch's per-object member counts are exchanged with the other shards before the batch is applied
+  // (sdm_frame_moves / sdm_frame_moves_pending; sdm_update_sharded does it itself).  Only a frame that is being captured
+  // into a graph cannot take them - and sdm_update never captures one with long lists.
+  if ((n_moves > MAX_MOVE_OBJECTS || n_remove > MAX_REMOVE_TRACKS) && m->capturing) {
+    set_error("sdm_update", __FILE__, __LINE__, "object lists beyond one frame block inside a graph capture");
     return SDM_ERR_INVALID_ARGUMENT;
   }
   m->moves_all.clear();
   m->removes_all.clear();
+  m->mv_batch_next = n_moves > MAX_MOVE_OBJECTS ? (size_t)MAX_MOVE_OBJECTS : 0;
+  m->mv_batch_ready = false;
   if (n_moves > MAX_MOVE_OBJECTS) m->moves_all.assign(moves, moves + n_moves);
   if (n_remove > MAX_REMOVE_TRACKS) m->removes_all.assign(remove_tracks, remove_tracks + n_remove);
   m->stop_after = stop_after;
@@ -1349,13 +1358,18 @@ sdm_status sdm_frame_moves(sdm_map *m) {
     r = 0;
   }
   if (m->capturing || m->n_moves > 0) {
+    // (first call of the frame: the first batch, counted by sdm_frame_start; a later call on a shard: the batch the call
+    // before prepared, whose counts the caller has exchanged meanwhile)
     launch_moves_transform(m->d, m->flt, m->st, m->sc, counts_all, w, r, m->stream);
     m->mv_pending = false;  // k_move_apply has reset the totals the next member count adds to
+    m->mv_batch_ready = false;
     // the rest of a long object list, MAX_MOVE_OBJECTS at a time: the block's list is replaced (one launch that is also
     // the batch's member count), then its members are copied out and invalidated.  The reference takes ALL objects'
     // particles out before it re-inserts any (operations.h:321-362): so does this - k_move_replay comes after the last
     // batch - and the ranks, i.e. the noise draws and the insertion order, run on from batch to batch.
-    for (size_t k0 = MAX_MOVE_OBJECTS; k0 < m->moves_all.size(); k0 += MAX_MOVE_OBJECTS) {
+    const bool shard = m->d.v_count != m->d.V;
+    while (m->mv_batch_next && m->mv_batch_next < m->moves_all.size()) {
+      const size_t k0 = m->mv_batch_next;
       const int nb = (int)std::min<size_t>(MAX_MOVE_OBJECTS, m->moves_all.size() - k0);
       FrameArgs &fa = m->fa;
       memset(&fa.ms, 0, sizeof(fa.ms));
@@ -1367,15 +1381,32 @@ sdm_status sdm_frame_moves(sdm_map *m) {
       fa.n_obj = nb;
       fa.mv_seq = ++m->mv_seq;
       fa.mv_batch += 1;
-      launch_moves_batch(m->d, m->st, m->sc, fa, m->stream);
+      m->mv_batch_next = k0 + MAX_MOVE_OBJECTS;
+      launch_moves_batch(m->d, m->st, m->sc, fa, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->stream);
+      if (shard) {
+        // the batch's counts are published: the caller exchanges them (all-gather, like the first batch's) and calls again
+        m->mv_batch_ready = true;
+        return SDM_OK;
+      }
       launch_moves_transform(m->d, m->flt, m->st, m->sc, counts_all, w, r, m->stream);
     }
+    m->mv_batch_next = 0;
   }
+  return SDM_OK;
+}
+
+sdm_status sdm_frame_moves_pending(sdm_map *m, int32_t *pending) {
+  if (!m || !pending) return SDM_ERR_INVALID_ARGUMENT;
+  *pending = m->mv_batch_ready ? 1 : 0;
   return SDM_OK;
 }
 
 sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev) {
   if (!m) return SDM_ERR_INVALID_ARGUMENT;
+  if (m->mv_batch_ready) {
+    set_error("sdm_frame_predict", __FILE__, __LINE__, "a batch of the frame's object list is still waiting for its counts: sdm_frame_moves_pending");
+    return SDM_ERR_INVALID_ARGUMENT;
+  }
   const int stop_after = m->stop_after;
   if (stage_done(stop_after, SDM_STAGE_EGO)) return SDM_OK;
   if (!m->capturing) HIP_TRY(hipSetDevice(m->device));
@@ -1426,6 +1457,7 @@ sdm_status sdm_update_begin(sdm_map *m, const float *depth, const sdm_labeled_po
   const int32_t *keep_all = m->counts_all_user;
   m->counts_all_user = nullptr;
   rc = sdm_frame_moves(m);
+  while (rc == SDM_OK && m->mv_batch_ready) rc = sdm_frame_moves(m);  // (a shard on its own: its local counts are all there is)
   if (rc == SDM_OK) rc = sdm_frame_predict(m, ck_part_dev);
   m->counts_all_user = keep_all;
   return rc;
@@ -2163,6 +2195,10 @@ sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_
   if (rc != SDM_OK) return rc;
   rc = sdm_frame_moves(m);
   if (rc != SDM_OK) return rc;
+  while (m->mv_batch_ready) {  // the further batches of a long object list: counts all-gathered on the main stream, batch applied
+    NCCL_TRY(ncclAllGather(m->d_counts_local, m->d_counts_all, HALO_OBJ, ncclInt32, m->comm, m->stream));
+    if ((rc = sdm_frame_moves(m)) != SDM_OK) return rc;
+  }
   if (n_moves > 0) {
     CommTimer t(m, 1, m->stream);
     if ((rc = all_to_all(m, m->d_halo_send, m->d_halo_recv, halo_segment_bytes(m->halo_cap_own), m->stream)) != SDM_OK) return rc;
@@ -2411,8 +2447,8 @@ sdm_status sdm_get_stats(sdm_map *m, sdm_stats *out, int32_t count_live) {
     uint32_t al[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(al, m->st.alias, 8, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    out->alias_entries = al[0] < ALIAS_CAP ? al[0] : ALIAS_CAP;
-    out->alias_overflowed = (al[0] > ALIAS_CAP || al[1] != 0) ? 1 : 0;
+    out->alias_entries = al[0] < m->st.alias_cap ? al[0] : m->st.alias_cap;
+    out->alias_overflowed = (al[0] > m->st.alias_cap || al[1] != 0) ? 1 : 0;
   }
   if (m->profiling) {
     int prev = 0;
@@ -2543,7 +2579,6 @@ sdm_status sdm_dump_state(sdm_map *m, float *px, float *py, float *pz, float *w,
     HIP_TRY(dev_alloc(&ttr, n));
     HIP_TRY(dev_alloc(&tl, n));
     HIP_TRY(dev_alloc(&tst, n));
-    launch_vts_sync(m->d, m->st, 1, s);  // slot 0 of the exported stamp row carries the voxel stamp
     launch_rec_unpack(m->d, m->st, tw, tts, ttr, tl, tst, s);
     if (status) HIP_TRY(hipMemcpyAsync(status, tst, n, hipMemcpyDeviceToHost, s));
     if (w) HIP_TRY(hipMemcpyAsync(w, tw, n * 4, hipMemcpyDeviceToHost, s));
@@ -2565,7 +2600,7 @@ sdm_status sdm_dump_state(sdm_map *m, float *px, float *py, float *pz, float *w,
     std::vector<uint32_t> al(2 + 2 * ALIAS_CAP);
     HIP_TRY(hipMemcpyAsync(al.data(), m->st.alias, al.size() * 4, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    const uint32_t na = std::min<uint32_t>(al[0], ALIAS_CAP);
+    const uint32_t na = std::min<uint32_t>(al[0], m->st.alias_cap);
     for (uint32_t k = 0; k < na; ++k) {
       const uint32_t idx = al[2 + 2 * k], trk = al[3 + 2 * k];
       if (trk == OWNER_NONE || idx >= n) continue;
@@ -2624,7 +2659,7 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
   launch_owner_flags(m->d, m->st, s);
   HIP_TRY(hipMemsetAsync(m->st.alias, 0, 8, s));  // the imported owner array is all there is to the sets
   HIP_TRY(hipMemsetAsync(m->st.alias_filter, 0, ALIAS_FILTER_WORDS * 4, s));
-  launch_vts_sync(m->d, m->st, 0, s);  // voxel stamps from slot 0 of the stamp rows, "something here" flags from the status rows
+  launch_vflag_from_records(m->d, m->st, s);  // "something here" flags from the status rows (the voxel stamps came with slot 0 of the stamp rows)
   HIP_TRY(hipStreamSynchronize(s));
   (void)hipFree(tx);
   (void)hipFree(ty);
@@ -2721,6 +2756,12 @@ sdm_status sdm_debug_sweep_lists(sdm_map *m, int32_t mode) {
   if (!m || mode < -1 || mode > 1) return SDM_ERR_INVALID_ARGUMENT;
   m->sweep_lists_forced = mode;
   if (mode >= 0) m->sweep_lists = mode != 0;
+  return SDM_OK;
+}
+sdm_status sdm_debug_alias_cap(sdm_map *m, int32_t cap) {
+  if (!m || cap < 1 || (uint32_t)cap > ALIAS_CAP) return SDM_ERR_INVALID_ARGUMENT;
+  if (m->n_graph_frames || m->n_direct_frames) return SDM_ERR_INVALID_ARGUMENT;  // (captured graphs hold the State by value)
+  m->st.alias_cap = (uint32_t)cap;
   return SDM_OK;
 }
 sdm_status sdm_debug_hinted_groups(sdm_map *m, int64_t *n_out) {

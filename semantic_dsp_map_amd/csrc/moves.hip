@@ -174,12 +174,12 @@ __device__ __forceinline__ void move_members_body(const State &st, const Members
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     sc.mv_nlist[0] = n_list;
-    sc.cur->move_list_overflow = (overflow || st.alias[0] > ALIAS_CAP || st.alias[1] != 0u) ? 1u : 0u;  // (alias[1]: the table overflowed in an earlier frame - sticky)
+    sc.cur->move_list_overflow = (overflow || st.alias[0] > st.alias_cap || st.alias[1] != 0u) ? 1u : 0u;  // (alias[1]: the table overflowed in an earlier frame - sticky)
   }
   __syncthreads();
   DBGM(2, 1, DBGM_T());
   // ---- 2. this workgroup's chunks
-  const uint32_t na_total = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
+  const uint32_t na_total = st.alias[0] < st.alias_cap ? st.alias[0] : st.alias_cap;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   uint32_t *tot = sc.mv_tot + (size_t)(mv_seq & 1u) * MAX_MOVE_OBJECTS * MV_TOT_STRIDE;
   for (int j = 0; j < MV_PER_WG; ++j) {
@@ -357,12 +357,13 @@ struct HaloRecord {
 };
 static_assert(sizeof(HaloRecord) == HALO_RECORD_BYTES, "halo record layout");
 
-__global__ void k_move_local_counts(int32_t *counts_local, Scratch sc, const FrameArgs *__restrict__ fa) {
+// reset_export: the first batch of a frame's object list (a later batch appends to the frame's export segments)
+__global__ void k_move_local_counts(int32_t *counts_local, Scratch sc, const FrameArgs *__restrict__ fa, int reset_export) {
   const int k = threadIdx.x;
   const int n_obj = fa->n_obj;  // (runs with the member count, on its stream)
   // this frame's export counters, one per destination shard
   const uint32_t world = sc.halo_world;
-  if (sc.halo_send)
+  if (sc.halo_send && reset_export)
     for (uint32_t dst = (uint32_t)k; dst < world; dst += blockDim.x)
       *reinterpret_cast<uint32_t *>(sc.halo_send + (size_t)dst * halo_segment_bytes(sc.halo_cap)) = 0;
   if (k >= HALO_OBJ) return;
@@ -400,11 +401,12 @@ struct MoveLoaded {
 __device__ __forceinline__ void move_load_particle(const Dims &d, const State &st, size_t li, bool copy_invalid, MoveLoaded &m) {
   m.p = st.pos4[li];
   m.p.w = __uint_as_float((uint32_t)st.forget[li]);  // (the forget count travels in the copy's fourth word, as it did when it lived there)
-  m.w = st.w[rec_index(li, d.p_n, REC_W)];
-  m.ts = st.ts[rec_index(li, d.p_n, REC_TS)];
-  m.track = st.track[rec_index(li, d.p_n, REC_TRACK)];
-  m.label = st.label[rec_index(li, d.p_n, REC_LABEL)];
-  m.status = copy_invalid ? (uint8_t)ST_INVALID : st.status[rec_index(li, d.p_n, REC_STATUS)];
+  const SlotRef sr = slot_ref_li(st, d.p_n, li);
+  m.w = sr.w();
+  m.ts = sr.ts();
+  m.track = sr.track();
+  m.label = sr.label();
+  m.status = copy_invalid ? (uint8_t)ST_INVALID : sr.status();
 }
 __device__ __forceinline__ void move_load_noise(const Filter &flt, const State &st, long long cursor, uint32_t e, MoveLoaded &m) {
   const long long draw = cursor + 3ll * e;
@@ -433,7 +435,7 @@ __device__ __forceinline__ void move_store(const Dims &d, const Frame &f, const 
   const uint16_t pts = m.ts, ptrack = m.track;
   const uint8_t plabel = m.label, pstatus = m.status;
   const uint16_t powner = ms.track[obj];
-  st.status[rec_index(li, d.p_n, REC_STATUS)] = ST_INVALID;  // deleteParticleByIndex
+  slot_ref_li(st, d.p_n, li).set_status(ST_INVALID);  // deleteParticleByIndex
   st.vflag[li >> d.p_n] = VF_DIRTY;
   mark_tile(st, li >> d.p_n, f.epoch);
   if (!alias) st.owner[li] = OWNER_NONE;  // the object's set is replaced by the re-inserted indices (semantic_dsp_map.h:697-699)
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
     if (threadIdx.x < MAX_MOVE_OBJECTS) sc.mv_tot[((size_t)(par ^ 1u) * MAX_MOVE_OBJECTS + threadIdx.x) * MV_TOT_STRIDE] = 0;
   }
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const uint32_t na_total = na_raw < ALIAS_CAP ? na_raw : ALIAS_CAP;
+  const uint32_t na_total = na_raw < st.alias_cap ? na_raw : st.alias_cap;
   while (pos < n) {
     const uint32_t chunk = listed & ~MV_CLEAR_FLAG;
     const size_t base = (size_t)chunk * MV_CHUNK;
@@ -829,8 +831,13 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
     const size_t base = (size_t)lv * S;
     uint8_t stv[S];
     uint16_t tsv[S];
-    __builtin_memcpy(stv, st.status + base * REC_STATUS, S);
-    __builtin_memcpy(tsv, st.ts + base * REC_TS, 2 * S);
+    unsigned char *const rec = rec_ptr(st, S, lv);
+    {  // status bytes (the record's last S - 1) and time stamps of the particle slots; entry 0 = the time particle, not looked at
+      stv[0] = ST_TIMEPTC;
+      tsv[0] = 0;
+      __builtin_memcpy(&stv[1], rec + 9 * (S - 1), S - 1);
+      __builtin_memcpy(&tsv[1], rec + 4 * (S - 1), 2 * (S - 1));
+    }
     // the voxel's owner entries and the length of the table of older memberships, with the rows above (owner_insert_local)
     uint16_t own[S];
     __builtin_memcpy(own, st.owner + base, 2 * S);
@@ -912,11 +919,12 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
         const uint16_t cts = c.ts;
         st.pos4[base + slot] = make_float4(c.x, c.y, c.z, 0.f);
         st.forget[base + slot] = (uint8_t)c.forget_bits;
-        st.w[base * REC_W + slot] = c.w;
-        st.ts[base * REC_TS + slot] = cts;
-        st.track[base * REC_TRACK + slot] = c.track;
-        st.label[base * REC_LABEL + slot] = c.label;
-        st.status[base * REC_STATUS + slot] = cs;
+        const SlotRef sr{rec, S - 1, (uint32_t)slot - 1u};
+        sr.set_w(c.w);
+        sr.set_ts(cts);
+        sr.set_track(c.track);
+        sr.set_label(c.label);
+        sr.set_status(cs);
         {  // the new index joins the object's set
           uint16_t o = last_owner;
           if (slot != last_slot) {
@@ -953,13 +961,13 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
   const uint32_t epoch = fa->f.epoch;
   const uint16_t *__restrict__ tracks = fa->remove;
   if (blockIdx.x == 0) {  // older memberships of the removed objects (State::alias)
-    const uint32_t na = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
+    const uint32_t na = st.alias[0] < st.alias_cap ? st.alias[0] : st.alias_cap;
     for (uint32_t k = threadIdx.x; k < na; k += blockDim.x) {
       const uint32_t trk = st.alias[3 + 2 * k];
       if (trk == OWNER_NONE) continue;
       for (int q = 0; q < n; ++q)
         if (tracks[q] == trk) {
-          st.status[rec_index(st.alias[2 + 2 * k], p_n, REC_STATUS)] = ST_INVALID;
+          slot_ref_li(st, p_n, st.alias[2 + 2 * k]).set_status(ST_INVALID);
           st.vflag[st.alias[2 + 2 * k] >> p_n] = VF_DIRTY;
           mark_tile(st, st.alias[2 + 2 * k] >> p_n, epoch);
           st.alias[3 + 2 * k] = OWNER_NONE;
@@ -976,10 +984,10 @@ __global__ __launch_bounds__(TPB) void k_remove(State st, size_t n_slots, const 
     if (end > n_slots) end = n_slots;
     for (; i < end; i += blockDim.x) {
       uint16_t o = st.owner[i];
-      if (o == OWNER_NONE) continue;
+      if (o == OWNER_NONE || (i & (((size_t)1 << p_n) - 1)) == 0) continue;  // (slot 0, the time particle, is in nobody's set)
       for (int k = 0; k < n; ++k)
         if (tracks[k] == o) {
-          st.status[rec_index(i, p_n, REC_STATUS)] = ST_INVALID;
+          slot_ref_li(st, p_n, i).set_status(ST_INVALID);
           st.vflag[i >> p_n] = VF_DIRTY;
           mark_tile(st, i >> p_n, epoch);
           st.owner[i] = OWNER_NONE;
@@ -1024,7 +1032,7 @@ __global__ __launch_bounds__(TPB) void k_tracks_with_particles(State st, size_t 
   if (threadIdx.x == 0) n_list = 0;
   __syncthreads();
   if (blockIdx.x == 0) {
-    const uint32_t na = st.alias[0] < ALIAS_CAP ? st.alias[0] : ALIAS_CAP;
+    const uint32_t na = st.alias[0] < st.alias_cap ? st.alias[0] : st.alias_cap;
     for (uint32_t k = threadIdx.x; k < na; k += TPB) {
       const uint32_t trk = st.alias[3 + 2 * k];
       if (trk != OWNER_NONE) atomicOr(&seen[trk >> 5], 1u << (trk & 31u));
@@ -1113,14 +1121,17 @@ void launch_moves_count(const Dims &d, const State &st, const Scratch &sc, int32
   else
     hipLaunchKernelGGL(k_move_members, dim3(MV_GRID), dim3(TPB), 0, s, st, ma, fa);
   // the per-object counts are only needed as a separate row when they are exchanged between shards
-  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, counts_local, sc, fa);
+  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, counts_local, sc, fa, 1);
 }
 
 // the next batch of a long object list: the frame block with that batch's objects replaces the main block, and the member
 // count of those objects runs - in the same launch (k_move_members_v: one block stores the block, all count)
-void launch_moves_batch(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa_batch, hipStream_t s) {
+// A Z-slab shard also publishes the batch's per-object counts (counts_local: exchanged with the other shards before the
+// batch's k_move_apply, like the first batch's).
+void launch_moves_batch(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa_batch, int32_t *counts_local, hipStream_t s) {
   const MembersArgs ma = members_args(d, sc);
   hipLaunchKernelGGL(k_move_members_v, dim3(MV_GRID), dim3(TPB), 0, s, st, ma, fa_batch, const_cast<FrameArgs *>(sc.fa));
+  if (d.v_count != d.V) hipLaunchKernelGGL(k_move_local_counts, dim3(1), dim3(HALO_OBJ), 0, s, counts_local, sc, sc.fa, 0);
 }
 
 // arguments of k_frame_begin in the order of its parameter list; `fa` is the frame block that goes by value

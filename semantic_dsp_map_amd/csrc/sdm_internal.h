@@ -4,10 +4,10 @@
 //   dense, per slot     pos4   float4  x, y, z, 0
 //                       forget u8      forget count
 //                       owner  u16     track id of the owner set holding this index, 0xFFFF = none
-//   dense, per voxel    vts    u16     observation stamp (the reference's slot-0 time particle)
+//   dense, per voxel    vts    u16     observation stamp (the reference's slot-0 time particle; its only home)
 //                       vflag  u8      0 = every slot INVALID
 //                       res    8 B     result of the occupancy sweep
-//   one record per voxel (10*S bytes)  weight, time stamp, track, label, status of its S slots (see REC_* below)
+//   one record per voxel (10*(S-1) bytes)  weight, time stamp, track, label, status of its S-1 particle slots (SlotRef below)
 // plus the three per-axis slab stamp arrays.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -140,28 +140,43 @@ struct Cursors {
 };
 
 // Slot attributes that are only touched where a particle lives - weight, time stamp, track id, label, status - share
-// one record of 10*S bytes per voxel (80 B at S = 8), records back to back with no padding:
-//   [w: 4S | ts: 2S | track: 2S | label: S | status: S].
-// These are exactly the 10 bytes per slot SURVEY.md 8(d) counts for the occupancy sweep, so a sweep over a dense map
-// moves the algorithmic bytes and nothing else; a single live voxel costs one or two 128-byte lines.
-// State::w / ts / track / label / status point at the first voxel's field; the index of slot i of local voxel lv is
-//   w[lv*S*REC_W + i], ts[lv*S*REC_TS + i], track[lv*S*REC_TRACK + i], label[lv*S*REC_LABEL + i],
-//   status[lv*S*REC_STATUS + i]
-// where REC_* is the record stride per slot in elements of the field's type (2.5 floats, 5 u16, 10 bytes): a
-// RecStride counts half elements, and lv*S is even.  Field alignment inside a record: min(16, 10*S & -10*S) bytes,
-// i.e. 16 at S >= 8, 8 at S = 4, 4 at S = 2.
+// one record per voxel.  Slot 0 of a voxel is its time particle (mc_ring/buffer.h:57-79, operations.h:824-837): of its
+// fields the map only ever needs the time stamp, which lives in the dense array State::vts; the record holds the
+// L = S - 1 PARTICLE slots and nothing else,
+//   [w: 4L | ts: 2L | track: 2L | label: L | status: L]        10 L bytes (70 B at S = 8), records back to back.
+// These are exactly the (S - 1) * 10 bytes per voxel SURVEY.md 8(d) counts for the occupancy sweep, so a sweep over a
+// dense map moves the algorithmic bytes, the 2-byte stamp, the 8-byte result and one flag byte: 81 B/voxel (rounds 2-5
+// kept a slot-0 row in the record - 80 B records, 92 B/voxel moved, 1.15 x the survey's figure).  A record is 2-byte
+// aligned and no more: every access below is written as an under-aligned access (gfx950 runs with unaligned access mode
+// on for global memory and LDS; a chunk of 64 records - 640 L bytes - starts on a 128-byte line, which is what the
+// chunk-wide loads of the non-incremental sweep go by).  sdm_dump_state reports slot 0 as {TIMEPTC, w 0, ts = the
+// voxel's observation stamp, track 0, label 0}, which is all the reference's slot 0 ever holds; sdm_load_state takes
+// the stamp from slot 0 of the stamp array and ignores its other fields.
 // What whole-map sweeps stream stays dense: the per-voxel stamp and "something here" flag, owner, positions.
 constexpr size_t REC_BYTES_PER_SLOT = 10;
-struct RecStride {
-  uint32_t half;  // stride per slot in half elements
+__host__ __device__ constexpr uint32_t rec_bytes(uint32_t S) { return (uint32_t)REC_BYTES_PER_SLOT * (S - 1u); }
+// bytes the record array needs for v_count voxels: one chunk of padding (the sweep's chunk-wide loads need no clamp at
+// the map's end) and a piece more for the whole-record fetch, which reads up to the next multiple of 8 bytes
+__host__ __device__ constexpr size_t rec_array_bytes(size_t v_count, uint32_t S) { return (v_count + 64) * rec_bytes(S) + 64; }
+typedef float rec_f32 __attribute__((aligned(2)));  // a float at a 2-byte aligned address (typed: not a char access)
+typedef uint32_t rec_v4u __attribute__((ext_vector_type(4), aligned(2)));
+typedef uint32_t rec_v2u __attribute__((ext_vector_type(2), aligned(2)));
+
+// One particle slot of a voxel's record: r = the record, L = S - 1, k = slot - 1 (slot 1..S-1; slot 0 has no entry).
+struct SlotRef {
+  unsigned char *r;
+  uint32_t L, k;
+  __host__ __device__ __forceinline__ float w() const { return *reinterpret_cast<const rec_f32 *>(r + 4u * k); }
+  __host__ __device__ __forceinline__ uint16_t ts() const { return *reinterpret_cast<const uint16_t *>(r + 4u * L + 2u * k); }
+  __host__ __device__ __forceinline__ uint16_t track() const { return *reinterpret_cast<const uint16_t *>(r + 6u * L + 2u * k); }
+  __host__ __device__ __forceinline__ uint8_t label() const { return r[8u * L + k]; }
+  __host__ __device__ __forceinline__ uint8_t status() const { return r[9u * L + k]; }
+  __host__ __device__ __forceinline__ void set_w(float v) const { *reinterpret_cast<rec_f32 *>(r + 4u * k) = v; }
+  __host__ __device__ __forceinline__ void set_ts(uint16_t v) const { *reinterpret_cast<uint16_t *>(r + 4u * L + 2u * k) = v; }
+  __host__ __device__ __forceinline__ void set_track(uint16_t v) const { *reinterpret_cast<uint16_t *>(r + 6u * L + 2u * k) = v; }
+  __host__ __device__ __forceinline__ void set_label(uint8_t v) const { r[8u * L + k] = v; }
+  __host__ __device__ __forceinline__ void set_status(uint8_t v) const { r[9u * L + k] = v; }
 };
-template <typename I>
-__host__ __device__ constexpr size_t operator*(I base, RecStride r) {
-  return (size_t)base * r.half / 2;
-}
-constexpr RecStride REC_W{5}, REC_TS{10}, REC_TRACK{10}, REC_LABEL{20}, REC_STATUS{20};
-// alignment (bytes) every field of a record is guaranteed to have
-__host__ __device__ constexpr int rec_align(int S) { return 10 * S % 16 == 0 ? 16 : (10 * S % 8 == 0 ? 8 : 4); }
 
 struct State {
   float4 *pos4 = nullptr;        // x, y, z, 0
@@ -169,9 +184,7 @@ struct State {
   // positions and leaves the forget counts alone (operations.h:697-722), so k_clear_map STORES the positions without
   // reading them; the weight update changes a byte instead of reading and rewriting a position.
   uint8_t *forget = nullptr;
-  unsigned char *rec = nullptr;  // v_count records of 10*S bytes
-  float *w = nullptr;
-  uint16_t *ts = nullptr;
+  unsigned char *rec = nullptr;  // v_count records of rec_bytes(S) = 10 (S - 1) bytes
   // observation stamp of every voxel = time stamp of its slot-0 "time particle" (operations.h:824-837), kept as a
   // dense array of its own: the sweeps read it for every voxel, the slot rows only where something lives
   uint16_t *vts = nullptr;
@@ -207,9 +220,6 @@ struct State {
   // (k_occupancy_scan skips it, k_occupancy_dense classifies it itself).  A hint about speed only: both launches read
   // the same bytes, and either way every voxel gets the same result.
   uint8_t *grp_hint = nullptr;
-  uint16_t *track = nullptr;
-  uint8_t *label = nullptr;
-  uint8_t *status = nullptr;
   uint16_t *owner = nullptr;
   // one byte per OWNER_CHUNK consecutive slots: 1 if any slot of the chunk may have an owner.  Lets the object-move
   // and removal sweeps skip the (vast) part of the map no dynamic object ever touched.
@@ -225,6 +235,7 @@ struct State {
   // (slot index, track) here.  alias[0] = number of entries (deleted ones carry track OWNER_NONE until the next
   // compaction), entries from alias[2]: index, track.  Nearly always empty.
   uint32_t *alias = nullptr;
+  uint32_t alias_cap = 0;  // entries the table takes before it reports an overflow (ALIAS_CAP unless a test lowered it)
   // 65536 bits, one per hash of a slot index: set when an entry for the slot goes into `alias`, rebuilt by the table's
   // garbage collection.  Every insertion into / removal from an owner set has to look for older memberships of its slot;
   // with the bit clear there is none and the table is not walked (a drive with a dozen objects keeps a few hundred entries
@@ -254,7 +265,7 @@ enum : uint8_t { VF_EMPTY = 0, VF_CLEAN = 1, VF_DIRTY = 2, VF_STATE = 3, VR_UNOB
 __device__ __host__ __forceinline__ uint32_t next_epoch(uint32_t e) { return e % 254u + 1u; }
 __device__ __forceinline__ uint8_t *tile_marks(const State &st, uint32_t epoch) { return st.tile_dirty + (epoch & 1u) * st.tile_stride; }
 __device__ __forceinline__ void mark_tile(const State &st, size_t lv, uint32_t epoch) { tile_marks(st, epoch)[lv >> TILE_SHIFT] = (uint8_t)epoch; }
-constexpr uint32_t ALIAS_CAP = 8192;
+constexpr uint32_t ALIAS_CAP = 65536;  // entries allocated (State::alias_cap of them in use: sdm_debug_alias_cap lowers it for the overflow tests)
 constexpr uint32_t ALIAS_FILTER_WORDS = 2048;
 __device__ __forceinline__ uint32_t alias_hash(size_t li) { return ((uint32_t)li * 2654435761u) >> 16; }
 // may the table hold an entry for slot li?  (read past the vector L1: the bit may have been set by this very kernel)
@@ -293,13 +304,13 @@ __device__ __forceinline__ bool owner_insert(const State &st, size_t li, uint16_
   const uint16_t prev = st.owner[li];
   st.owner[li] = track;
   uint32_t n = st.alias[0];
-  if (n > ALIAS_CAP) n = ALIAS_CAP;
+  if (n > st.alias_cap) n = st.alias_cap;
   if (n && alias_may_hold(st, li))
     for (uint32_t k = 0; k < n; ++k)  // a set holds an index once
       if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
   if (prev == OWNER_NONE || prev == track) return true;
   const uint32_t k = atomicAdd(&st.alias[0], 1u);  // prev's set keeps the index
-  if (k >= ALIAS_CAP) return false;
+  if (k >= st.alias_cap) return false;
   st.alias[2 + 2 * k] = (uint32_t)li;
   st.alias[3 + 2 * k] = prev;
   alias_note(st, li);
@@ -312,7 +323,7 @@ __device__ __forceinline__ void owner_erase(const State &st, size_t li, uint16_t
     return;
   }
   uint32_t n = st.alias[0];
-  if (n > ALIAS_CAP) n = ALIAS_CAP;
+  if (n > st.alias_cap) n = st.alias_cap;
   if (n && alias_may_hold(st, li))
     for (uint32_t k = 0; k < n; ++k)
       if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
@@ -330,14 +341,14 @@ __device__ __forceinline__ bool owner_insert_local(const State &st, size_t li, u
   st.owner[li] = track;
   own = track;
   uint32_t n = touched ? st.alias[0] : n_alias;
-  if (n > ALIAS_CAP) n = ALIAS_CAP;
+  if (n > st.alias_cap) n = st.alias_cap;
   if (n && alias_may_hold(st, li))
     for (uint32_t k = 0; k < n; ++k)  // a set holds an index once
       if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
   if (prev == OWNER_NONE || prev == track) return true;
   const uint32_t k = atomicAdd(&st.alias[0], 1u);  // prev's set keeps the index
   touched = true;
-  if (k >= ALIAS_CAP) return false;
+  if (k >= st.alias_cap) return false;
   st.alias[2 + 2 * k] = (uint32_t)li;
   st.alias[3 + 2 * k] = prev;
   alias_note(st, li);
@@ -351,7 +362,7 @@ __device__ __forceinline__ void owner_erase_local(const State &st, size_t li, ui
     return;
   }
   uint32_t n = touched ? st.alias[0] : n_alias;
-  if (n > ALIAS_CAP) n = ALIAS_CAP;
+  if (n > st.alias_cap) n = st.alias_cap;
   if (n && alias_may_hold(st, li))
     for (uint32_t k = 0; k < n; ++k)
       if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
@@ -365,12 +376,12 @@ __device__ __forceinline__ void alias_compact_wave(const State &st) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t na = st.alias[0];
   if (na == 0) return;
-  if (na > ALIAS_CAP) {
+  if (na > st.alias_cap) {
     // entries beyond the table's capacity were dropped: the sets are incomplete from here on.  alias[1] keeps saying so
     // (SDM_ERR_CAPACITY at every synchronisation, sdm_stats.alias_overflowed) until sdm_clear / sdm_load_state - this
     // very function used to erase the only trace of it by writing the clamped count back.
     if (lane == 0) st.alias[1] = 1u;
-    na = ALIAS_CAP;
+    na = st.alias_cap;
   }
   for (uint32_t k = lane; k < ALIAS_FILTER_WORDS; k += 64) st.alias_filter[k] = 0u;  // rebuilt from the survivors below
   __threadfence();
@@ -399,9 +410,14 @@ __device__ __forceinline__ void alias_compact_wave(const State &st) {
   if (lane == 0) st.alias[0] = keep;
 }
 
-// field index of global-slot-order index li = lv << p_n | slot (see the record layout above)
-__host__ __device__ __forceinline__ size_t rec_index(size_t li, int p_n, RecStride mult) {
-  return ((li >> p_n) << p_n) * mult + (li & (((size_t)1 << p_n) - 1));
+// the record of local voxel lv / slot `slot` (1..S-1) of it / the slot with shard-local index li = lv << p_n | slot
+__host__ __device__ __forceinline__ unsigned char *rec_ptr(const State &st, uint32_t S, size_t lv) { return st.rec + lv * rec_bytes(S); }
+__host__ __device__ __forceinline__ SlotRef slot_ref(const State &st, uint32_t S, size_t lv, uint32_t slot) {
+  return SlotRef{rec_ptr(st, S, lv), S - 1u, slot - 1u};
+}
+__host__ __device__ __forceinline__ SlotRef slot_ref_li(const State &st, int p_n, size_t li) {
+  const uint32_t S = 1u << p_n;
+  return SlotRef{rec_ptr(st, S, li >> p_n), S - 1u, ((uint32_t)li & (S - 1u)) - 1u};
 }
 
 // ---- device helpers ------------------------------------------------------------------

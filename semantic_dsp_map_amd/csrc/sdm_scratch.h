@@ -173,7 +173,7 @@ struct FrameBeginLaunch {
   static const void *kernel();
 };
 void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s);
-void launch_moves_batch(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa_batch, hipStream_t s);
+void launch_moves_batch(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa_batch, int32_t *counts_local, hipStream_t s);
 // lists (non-incremental sweeps only): the tiles' sparse voxels go through State::occ_list and a launch of their own
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, const FrameArgs *fa, uint32_t remark,
                       hipStream_t s, int lists = 0);
@@ -195,13 +195,13 @@ void launch_count_owner(const Dims &d, const State &st, uint16_t track, unsigned
 void launch_pack_pos4(float4 *pos4, uint8_t *forget_plane, const float *px, const float *py, const float *pz, const uint8_t *forget, size_t n,
                       hipStream_t s);
 void launch_unpack_pos4(const float4 *pos4, const uint8_t *forget_plane, float *px, float *py, float *pz, uint8_t *forget, size_t n, hipStream_t s);
-// slot 0 of the stamp array <-> the dense voxel-stamp array (state export / import)
+// the reference's slot-order arrays <-> records + voxel stamps (state export / import; slot 0 = the time particle)
 void launch_rec_pack(const Dims &d, const State &st, const float *w, const uint16_t *ts, const uint16_t *track,
                      const uint8_t *label, const uint8_t *status, hipStream_t s);
 void launch_rec_unpack(const Dims &d, const State &st, float *w, uint16_t *ts, uint16_t *track, uint8_t *label, uint8_t *status,
                        hipStream_t s);
 void launch_fill_dense(const Dims &d, const State &st, uint32_t stamp, int mode, hipStream_t s);
-void launch_vts_sync(const Dims &d, const State &st, int to_slot0, hipStream_t s);
+void launch_vflag_from_records(const Dims &d, const State &st, hipStream_t s);
 // N2: colour tables on the device (sdm_colour_config + the two division tables of OpenCV's 8-bit RGB2HSV)
 struct ColourTables {
   sdm_colour_config cfg;

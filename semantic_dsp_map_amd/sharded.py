@@ -82,9 +82,10 @@ class NativeShardedMap:
         self.map = binding.SdmMap(cfg, params, noise_table, device=device, shard_rank=rank, shard_count=world,
                                   max_visible=max_visible)
         if self.sharded:
-            if dist is None:
+            if dist is None and world > 1:
                 raise ValueError("world > 1 needs a torch.distributed module for the rendezvous")
-            uid = broadcast_unique_id(dist, rank)
+            # (a communicator of ONE rank needs no rendezvous: bench.py's `sharded_one_rank` leg runs without torch)
+            uid = broadcast_unique_id(dist, rank) if dist is not None else binding.comm_unique_id()
             with stdout_to_stderr():  # RCCL prints a version banner on stdout at communicator creation
                 self.map.comm_init(uid, halo_cap)
 
@@ -180,6 +181,9 @@ class GlooShardEngine:
     def moves(self):
         self.map.frame_moves()
 
+    def moves_pending(self):
+        return self.map.frame_moves_pending()
+
     def predict(self):
         self.map.frame_predict()
 
@@ -199,7 +203,8 @@ class GlooShardEngine:
 
 class ShardedDriver:
     """The frame protocol over a generic engine:
-        start -> [counts: all-gather] -> moves -> [export segments: all-to-all] -> predict
+        start -> [counts: all-gather] -> moves (-> [counts] -> moves, per further batch of a long object list)
+              -> [export segments: all-to-all] -> predict
               -> [partial ck chunks: all-to-all] -> ck_reduce -> [summed chunks: all-gather] -> finish
     where [x] is a collective over the shards (the first two only when objects move).  Engine attributes (torch tensors
     on the engine's device): counts_local / counts_all, halo_send / halo_recv (world segments each), ck_part / ck_stage /
@@ -225,6 +230,14 @@ class ShardedDriver:
             d.all_gather_into_tensor(e.counts_all, e.counts_local)
             push("counts")
         e.moves()
+        # a list of more than SDM_MAX_MOVES objects: batch by batch, every batch's counts gathered before it is applied
+        pending = getattr(e, "moves_pending", lambda: False)
+        while has_moves and pending():
+            if multi:
+                pull("counts")
+                d.all_gather_into_tensor(e.counts_all, e.counts_local)
+                push("counts")
+            e.moves()
         if has_moves and multi:
             pull("halo")
             d.all_to_all_single(e.halo_recv, e.halo_send)         # segment s of recv = segment `rank` of shard s's send

@@ -48,16 +48,21 @@ def all_to_all(shards, src_attr, dst_attr, piece):
     return src
 
 
-def run_frame(shards, frame):
+def run_frame(shards, frame, remove_tracks=None):
     depth, cloud, pos, q, moves = frame
     G = len(shards)
     has_moves = len(moves) > 0
     for s in shards:
-        s.m.frame_start(depth, cloud, pos, q, moves)
+        s.m.frame_start(depth, cloud, pos, q, moves, remove_tracks)
     if has_moves:
         gather(shards, "counts_local", "counts_all", sharded.HALO_OBJ * 4)
     for s in shards:
         s.m.frame_moves()
+    while shards[0].m.frame_moves_pending():   # a list of more than SDM_MAX_MOVES objects: batch by batch (every shard alike)
+        assert all(s.m.frame_moves_pending() for s in shards)
+        gather(shards, "counts_local", "counts_all", sharded.HALO_OBJ * 4)
+        for s in shards:
+            s.m.frame_moves()
     exported = 0
     if has_moves:
         src = all_to_all(shards, "send", "recv", shards[0].seg)
@@ -237,3 +242,71 @@ def test_shards_match_oracle_on_random_frames(G, params_name, seed):
     assert exported > 0 and o.stats()["alias_events"] > 0
     for s in shards:
         s.m.close()
+
+
+@pytest.mark.parametrize("G,params_name,seed", [(4, "vkitti2", 11), (2, "noisy3", 12)])
+def test_shards_take_object_lists_of_any_length(G, params_name, seed):
+    """200 moving objects and 300 removals in ONE frame of a Z-slab sharded map (the reference loops over whatever the object
+    layer hands it, semantic_dsp_map.h:588-736): the frames of tests/test_long_object_lists_gpu.py through G shards - every
+    batch of 48 objects with its own exchange of member counts, the copies of all batches in one export exchange, ranks and
+    noise draws running on from batch to batch and from shard to shard - against the unsharded oracle, bit for bit."""
+    from tests.test_long_object_lists_gpu import N_TRACKS, frame as ll_frame, moves_of
+    cfg = synth.CONFIGS["T0"]
+    params = synth.PARAMS[params_name]
+    rng = np.random.default_rng(seed)
+    noise = synth.noise_table()
+    o = orc.OracleMap(dict(cfg, bin_order=1, ck_slabs=G), params, noise)
+    shards = [Shard(cfg, params, noise, r, G, halo_cap=4096) for r in range(G)]
+    S = 1 << cfg["p_n"]
+    pos, yaw = np.zeros(3), 0.0
+    exported, n_moved_max = 0, 0
+    for t in range(8):
+        pos = pos + rng.normal(0, 0.2, 3) * np.array([1.0, 0.1, 1.0])
+        yaw += rng.normal(0, 0.03)
+        depth, cloud = ll_frame(rng, cfg, params, pos, yaw)
+        if t < 2:
+            mv, remove = moves_of(rng, []), None
+        elif t % 3 == 2:
+            mv, remove = moves_of(rng, rng.permutation(np.arange(1, N_TRACKS + 1))[:200]), None
+        elif t % 3 == 0:
+            mv = moves_of(rng, rng.permutation(np.arange(1, N_TRACKS + 1))[:60])
+            remove = [int(x) for x in rng.permutation(np.arange(1, 401))[:300]]
+        else:
+            mv = moves_of(rng, rng.permutation(np.arange(1, N_TRACKS + 1))[:150])
+            remove = [int(x) for x in rng.permutation(np.arange(1, 401))[:140]]
+        fr = (depth, cloud, pos.astype(np.float32), synth.yaw_quat(yaw).astype(np.float32), mv)
+        o.update(*fr, remove)
+        exported += run_frame(shards, fr, remove)
+        compare_union(o, shards, t, S)
+        n_moved_max = max(n_moved_max, o.stats()["n_moved"])
+    assert exported > 0 and n_moved_max > 2000, (exported, n_moved_max)
+    for s in shards:
+        s.m.close()
+
+
+def test_native_rccl_single_rank_long_lists():
+    """sdm_update_sharded with more moving objects and removals than one frame block holds (a communicator of one rank: the
+    count all-gather of every batch is issued): same result as the plain frame."""
+    from tests.test_long_object_lists_gpu import N_TRACKS, frame as ll_frame, moves_of
+    cfg, params = synth.CONFIGS["T0"], synth.PARAMS["vkitti2"]
+    rng = np.random.default_rng(4)
+    noise = synth.noise_table()
+    a = binding.SdmMap(cfg, params, noise)
+    b = binding.SdmMap(cfg, params, noise)
+    b.comm_init(binding.comm_unique_id(), 1024)
+    pos = np.zeros(3, np.float32)
+    q = synth.yaw_quat(0.0).astype(np.float32)
+    for t in range(5):
+        depth, cloud = ll_frame(rng, cfg, params, pos.astype(np.float64), 0.0)
+        mv = moves_of(rng, rng.permutation(np.arange(1, N_TRACKS + 1))[:130] if t >= 2 else [])
+        remove = [int(x) for x in rng.permutation(np.arange(1, 401))[:200]] if t == 3 else None
+        a.update(depth, cloud, pos, q, mv, remove, sync=True)
+        b.update_sharded(depth, cloud, pos, q, mv, remove)
+        b.synchronize()
+    sa, sb = a.dump_state(), b.dump_state()
+    for k in pu.STATE_KEYS:
+        assert pu.diff_report(k, sa[k], sb[k]) is None
+    assert np.array_equal(a.voxels(), b.voxels())
+    assert a.stats()["n_moved"] == b.stats()["n_moved"] > 0
+    a.close()
+    b.close()
