@@ -895,7 +895,7 @@ __device__ __forceinline__ void occ_scan_fetch(const Dims &d, const State &st, u
 // left alone it takes 91, i.e. 5 resident workgroups per CU instead of 8 - this launch lives on resident workgroups)
 template <int S, bool LISTS>
 __device__ __forceinline__ void occupancy_scan_tile(const Dims &d, float occ_threshold, const State &st, Counters *cnt, unsigned long long *__restrict__ need,
-                                                    uint32_t n_tiles, uint32_t remark) {
+                                                    uint32_t n_tiles, uint32_t remark, const uint32_t tile) {
   // the tile's results, 64 bytes (8 voxels) per thread; the 16-byte pieces of a row are swizzled so that neither the
   // row-wise writes nor the lane-linear reads run into bank conflicts
   __shared__ v4u res_stage[TPB * 4];
@@ -910,7 +910,7 @@ __device__ __forceinline__ void occupancy_scan_tile(const Dims &d, float occ_thr
   // (One tile per workgroup.  A persistent version - 1024 workgroups walking the tiles, the next tile's inputs pulled
   // into L2 or registers meanwhile - was measured: what the loop keeps alive costs 30 registers, one resident workgroup
   // per CU less, 90 us against 75 us on the benchmark state.)
-  const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x;
   // a wave's 512 voxels whose chunks were all dense in the last non-incremental sweep are left to the second launch
   // whole: that one then classifies them itself (State::grp_hint - a hint about speed only; whatever the voxels hold by
   // now, the result is the same).  A tile of four such groups: nothing to do here.
@@ -1090,15 +1090,24 @@ __device__ __forceinline__ void occupancy_scan_tile(const Dims &d, float occ_thr
 }
 
 #define SCAN_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(S <= 8 ? 8 : 4, S <= 8 ? 8 : 4)))
+// (Measured and not kept, round 6: four consecutive tiles per workgroup, so that a map whose groups are all hinted costs a
+// quarter of the workgroups that leave after their hint bytes - 0.3 us of the dense case's 245, and the empty and the
+// benchmark map went from 45 / 70 us to 125 / 155: a workgroup that walks four tiles holds its slot four times as long,
+// and the launch lives on workgroups that come and go.)
+template <int S, bool LISTS>
+__device__ __forceinline__ void occupancy_scan_tiles(const Dims &d, float occ_threshold, const State &st, Counters *cnt,
+                                                     unsigned long long *__restrict__ need, uint32_t n_tiles, uint32_t remark) {
+  occupancy_scan_tile<S, LISTS>(d, occ_threshold, st, cnt, need, n_tiles, remark, blockIdx.x);
+}
 template <int S>
 __global__ __launch_bounds__(TPB) SCAN_WAVES_ATTR void k_occupancy_scan(Dims d, float occ_threshold, State st, Counters *cnt,
                                                                        unsigned long long *__restrict__ need, uint32_t n_tiles, uint32_t remark) {
-  occupancy_scan_tile<S, false>(d, occ_threshold, st, cnt, need, n_tiles, remark);
+  occupancy_scan_tiles<S, false>(d, occ_threshold, st, cnt, need, n_tiles, remark);
 }
 template <int S>
 __global__ __launch_bounds__(TPB) SCAN_WAVES_ATTR void k_occupancy_scan_lists(Dims d, float occ_threshold, State st, Counters *cnt,
                                                                              unsigned long long *__restrict__ need, uint32_t n_tiles, uint32_t remark) {
-  occupancy_scan_tile<S, true>(d, occ_threshold, st, cnt, need, n_tiles, remark);
+  occupancy_scan_tiles<S, true>(d, occ_threshold, st, cnt, need, n_tiles, remark);
 }
 
 #ifdef SDM_DENSE_WAVES
@@ -1111,11 +1120,6 @@ __global__ __launch_bounds__(TPB) SCAN_WAVES_ATTR void k_occupancy_scan_lists(Di
 // chunk's base address a scalar and its loads `global_load ..., v_lane_offset, s[base]`; the record array is allocated one
 // chunk longer than the map, so no load clamps its address; the plain evaluation runs together with its own admission
 // test, occupancy_evaluate_plain_checked.)
-#ifndef SDM_DENSE_CPW
-#define SDM_DENSE_CPW 8
-#endif
-constexpr int OCC_DCPW = SDM_DENSE_CPW;  // chunks per wave of k_occupancy_dense (its own partition of the map: the masks are per chunk)
-static_assert(OCC_DCPW <= 32, "one bit per chunk of the wave in a 32-bit word");
 // A wave whose group of 512 voxels has State::grp_hint set (every chunk of it was dense in the last non-incremental
 // sweep) finds nothing from k_occupancy_scan: it classifies its voxels itself - stamp and flag byte of the lane's voxel requested with the
 // chunk's records, occupancy_classify in the step - takes every chunk as dense and writes all 64 results of a chunk, the
@@ -1180,6 +1184,13 @@ __global__ __launch_bounds__(TPB) void k_occupancy_listed(Dims d, float occ_thre
   occupancy_listed_units<S>(d, occ_threshold, st, remark, blockIdx.x);
 }
 
+// (Round 6, measured and not kept - the kernel is where the memory system and the vote's 320 vector instructions per chunk
+// leave it, 0.242-0.255 ms over the round's boxes for 1.36 GB: its arguments pinned in scalar register pairs of their own -
+// the compiler parks eight-word argument groups in the lanes of a vector register when the vote's comparison masks crowd
+// the scalar file, and brings a whole group back, eight v_readlane, for one store's base address: 56 -> 38 v_readlane per
+// step, no change in time; the step loop compiled twice, hinted and not, x rows and not: 138 registers; a wave's results
+// kept in LDS and stored in one 4 KB burst when its eight chunks are through: 4 % faster where every voxel holds one track
+// id - the cheaper vote -, 2 % slower on the eight-track case; tools/gpu_dense_ab.sh.)
 template <int S>
 __global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d, float occ_threshold, State st, Counters *cnt,
                                                          const unsigned long long *__restrict__ need, uint32_t remark, uint32_t n_tiles) {
@@ -3710,11 +3721,12 @@ void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counter
     // launch less, and 55 us against 47 us on an empty map: that kernel then holds 126 registers and its workgroups' LDS
     // whatever a workgroup does; the lists worked off by the last launch's own workgroup of the tile - 67 us against 56
     // on the `driven` map, four resident workgroups per CU.)
+    const dim3 sgrid = grid;
     if (lists) {
-      SDM_DISPATCH_S(k_occupancy_scan_lists, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, grid.x, remark);
+      SDM_DISPATCH_S(k_occupancy_scan_lists, sgrid, s, d, flt.occ_threshold, st, cnt, st.occ_need, grid.x, remark);
       SDM_DISPATCH_S(k_occupancy_listed, dim3(OCC_LISTED_GRID), s, d, flt.occ_threshold, st, remark);
     } else {
-      SDM_DISPATCH_S(k_occupancy_scan, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, grid.x, remark);
+      SDM_DISPATCH_S(k_occupancy_scan, sgrid, s, d, flt.occ_threshold, st, cnt, st.occ_need, grid.x, remark);
     }
     SDM_DISPATCH_S(k_occupancy_dense, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, remark, grid.x);
   } else {

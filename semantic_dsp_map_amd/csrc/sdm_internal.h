@@ -253,7 +253,7 @@ constexpr int TILE_SHIFT = 11;
 constexpr uint32_t OCC_LIST_CAP = 2048, OCC_LIST_UNIT = 256, OCC_LIST_SHARDS = 64;  // State::occ_list (kernels.hip: 32 sparse chunks of fewer than 64 voxels each)
 __host__ __device__ constexpr size_t occ_list_tiles(size_t v_count) { return (v_count + ((size_t)1 << TILE_SHIFT) - 1) >> TILE_SHIFT; }
 // bytes of State::grp_hint for v_count voxels: whole tiles (4 groups), so that a workgroup reads its four bytes as one word
-__host__ __device__ constexpr size_t grp_hint_bytes(size_t v_count) { return ((v_count + (1u << 11) - 1) >> 11) * 4; }
+__host__ __device__ constexpr size_t grp_hint_bytes(size_t v_count) { return (((v_count + (1u << 11) - 1) >> 11) * 4 + 15) / 16 * 16; }  // (whole 16-byte pieces)
 enum : uint8_t { VF_EMPTY = 0, VF_CLEAN = 1, VF_DIRTY = 2, VF_STATE = 3, VR_UNOBSERVED = 1 << 2, VR_EMPTY = 2 << 2, VR_MASK = 3 << 2 };
 // State::tile_dirty holds, per tile, the sweep epoch in which something in the tile was last written or stamped: the
 // frame's kernels mark with the epoch of the frame's sweep (Frame::epoch), the sweep looks for exactly that number and

@@ -12,7 +12,6 @@ m = binding.SdmMap(synth.CONFIGS["C3"], synth.PARAMS["vkitti2"], None, device=0)
 V = 1 << 24
 for mode in modes:
     m.fill_dense_ex(mode)
-    m.time_occupancy_sweep(iters=2)
-    m.fill_dense_ex(mode)
+    m.time_occupancy_sweep(iters=30)   # (the first sweeps set the group hints and bring the clocks up)
     ms = m.time_occupancy_sweep(iters=n)
-    print("dense mode %d: %.4f ms  %.3f of 8 TB/s on layout bytes (92 B/voxel)" % (mode, ms, V * 92 / ms / 1e6 / 8000.0))
+    print("dense mode %d: %.4f ms  %.3f of 8 TB/s on layout bytes (81 B/voxel), %.3f on SURVEY 8(d) bytes (80)" % (mode, ms, V * 81 / ms / 1e6 / 8000.0, V * 80 / ms / 1e6 / 8000.0))
