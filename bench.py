@@ -169,15 +169,9 @@ def driven_run(synth, sharded, steps=20, cpu_frames=3):
     scene = synth.Scene(cfg, **scene_kw)
     n_prof = 4
     t0 = time.time()
-    cache = os.environ.get("SDM_DRIVEN_CACHE")  # (development: A/B runs of the library on the same rendered frames)
-    if cache and os.path.exists(cache):
-        import pickle
-        rendered = pickle.load(open(cache, "rb"))
-    else:
-        rendered = synth.render_frames(cfg, params, scene_kw, range(n_grow + steps + n_prof))  # worker processes: seconds per frame on one core
-        if cache:
-            import pickle
-            pickle.dump(rendered, open(cache, "wb"), protocol=4)
+    # (SDM_DRIVEN_CACHE=<file>.npz, development: A/B runs of the library on the same rendered frames; the file is keyed by
+    # everything the frames depend on and holds plain arrays)
+    rendered = synth.render_frames_cached(cfg, params, scene_kw, range(n_grow + steps + n_prof), os.environ.get("SDM_DRIVEN_CACHE"))  # worker processes: seconds per frame on one core
     t_render = time.time() - t0
     eng = sharded.NativeShardedMap(cfg, params, 0, 1, 0)
     m = eng.map

@@ -381,6 +381,32 @@ def render_frames(cfg, params, scene_kw, frames, workers=None):
         return pool.map(_render_job, jobs, chunksize=1)
 
 
+def render_frames_cached(cfg, params, scene_kw, frames, cache_path=None):
+    """render_frames with the result kept in an .npz file (development: A/B runs of the library on the same rendered
+    frames).  The file carries a digest of everything the frames depend on - configuration, parameters, scene, frame
+    numbers - and is ignored (and rewritten) when that does not match: plain arrays only, nothing in it is executed."""
+    import hashlib
+    import json
+    import os
+    frames = list(frames)
+    if not cache_path:
+        return render_frames(cfg, params, scene_kw, frames)
+    key = hashlib.sha1(json.dumps([sorted(cfg.items()), sorted(params.items()), sorted(scene_kw.items()), frames],
+                                  default=str).encode()).hexdigest()
+    if os.path.exists(cache_path):
+        try:
+            with np.load(cache_path, allow_pickle=False) as z:
+                if str(z["key"]) == key and int(z["n"]) == len(frames):
+                    return [(z["depth"][i], z["cloud"][i].view(LABELED_POINT).reshape(-1), z["pos"][i], z["q"][i]) for i in range(len(frames))]
+        except (OSError, KeyError, ValueError):
+            pass
+    out = render_frames(cfg, params, scene_kw, frames)
+    np.savez(cache_path, key=np.array(key), n=np.array(len(out)), depth=np.stack([f[0] for f in out]),
+             cloud=np.stack([np.ascontiguousarray(f[1]).view(np.uint8).reshape(-1) for f in out]),
+             pos=np.stack([np.asarray(f[2]) for f in out]), q=np.stack([np.asarray(f[3]) for f in out]))
+    return out
+
+
 STATE_FIELDS = [("px", np.float32), ("py", np.float32), ("pz", np.float32), ("w", np.float32),
                 ("ts", np.uint16), ("track", np.uint16), ("label", np.uint8), ("status", np.uint8),
                 ("forget", np.uint8), ("owner", np.uint16)]

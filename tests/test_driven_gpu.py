@@ -7,13 +7,14 @@ tests at this grid size either start from a prefilled state or hand a GPU-grown 
 start from nothing and run free:
 
   * canonical order (bin_order = 1), bit for bit: every voxel result every 10 frames, the whole particle state (every field
-    of every slot, ring state, slab stamps) every 40 frames and at the frame where the orders part;
+    of every slot, ring state, slab stamps) every 80 frames and at the frame where the orders part;
   * the last 5 frames against the oracle's LITERAL order (bin_order = 0: the reference's BFS push-order sums,
     semantic_dsp_map.h:1029, mc_ring/operations.h:1405-1407) started from that common state: identical integers in the
-    particle state and the voxel results, probabilities within 1e-4 (north_star's bar).
+    particle state and the voxel results, POSITIONS bit for bit (a summation order cannot move a particle), weights within
+    an absolute 1e-4 (north_star's bar), the un-clamped weight sums within 1e-4 relative where they exceed 1.
 
 Reference: SemanticDSPMap::subObjectLevelUpdate, semantic_dsp_map.h:576-955.  About four minutes (220 oracle frames at
-~0.4 s, 220 rendered frames, eleven comparisons of 134 M slots)."""
+~0.4 s, 220 rendered frames, five comparisons of 134 M slots - round 5 made eleven, a minute more)."""
 import numpy as np
 import pytest
 
@@ -44,7 +45,7 @@ def test_drive_from_an_empty_map_with_the_oracle_beside_the_gpu():
         assert so["n_visible"] == sg["n_visible"], "frame %d: visible particles %d (oracle) / %d (gpu)" % (t, so["n_visible"], sg["n_visible"])
         n_vis.append(sg["n_visible"])
         moved += sg.get("n_moved", 0)
-        if t % 40 == 39 or t == t_split - 1:
+        if t % 80 == 79 or t == t_split - 1:
             rep = pu.compare_maps(o, g, S, check_results=True, tag="frame %d: " % t)
             assert not rep, "\n".join(rep)
         elif t % 10 == 9:
@@ -68,13 +69,14 @@ def test_drive_from_an_empty_map_with_the_oracle_beside_the_gpu():
         moves = scene.moves(t)
         lit.update(depth, cloud, pos, q, moves)
         g.update(depth, cloud, pos, q, moves, sync=True)
-        so, sg = lit.dump_state(), g.dump_state()
-        for k in ("status", "ts", "track", "label", "forget", "owner"):
-            assert np.array_equal(so[k], sg[k]), "frame %d: %s differs from the literal-order oracle" % (t, k)
-        alive = so["status"] != 0
-        for k in ("w", "px", "py", "pz"):
-            a, b = so[k][alive], sg[k][alive]
-            assert np.all(np.abs(a - b) <= 1e-4 * np.maximum(1.0, np.abs(a))), "frame %d: %s" % (t, k)
+        if t in (t_split, n - 1):  # every field of every slot at both ends of the literal phase (the results: every frame)
+            so, sg = lit.dump_state(), g.dump_state()
+            for k in ("status", "ts", "track", "label", "forget", "owner", "px", "py", "pz"):
+                assert np.array_equal(pu.bits(so[k]), pu.bits(sg[k])), "frame %d: %s differs from the literal-order oracle" % (t, k)
+            alive = so["status"] != 0
+            a, b = so["w"][alive], sg["w"][alive]
+            assert np.all(np.abs(a - b) <= 1e-4), "frame %d: w, max |diff| %g" % (t, float(np.max(np.abs(a - b))))
+            del so, sg
         vo, vg = lit.voxels(), g.voxels()
         for k in ("occ", "label", "track"):
             assert np.array_equal(vo[k], vg[k]), "frame %d: voxels.%s differs from the literal-order oracle" % (t, k)

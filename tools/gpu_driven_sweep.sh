@@ -3,7 +3,7 @@
 # `driven` scene, per launch and per kernel
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-export SDM_DRIVEN_CACHE=/tmp/sdm_driven_sweep_$$.pkl
+export SDM_DRIVEN_CACHE=/tmp/sdm_driven_sweep_$$.npz
 {
   timeout 600 python tools/probes/driven_sweep.py
   for tag in "$@"; do SDM_LIB_PATH=build/ab/libsdm_$tag.so timeout 600 python tools/probes/driven_sweep.py; done

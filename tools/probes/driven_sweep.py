@@ -3,7 +3,6 @@ under `rocprofv3 --kernel-trace` - its kernels.  SDM_DRIVEN_CACHE=<file>: the re
 once unprofiled, profile the second run)."""
 import json
 import os
-import pickle
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -15,13 +14,7 @@ def main():
     params = synth.PARAMS[synth.DRIVEN_PARAMS]
     scene = synth.Scene(cfg, **synth.DRIVEN_SCENE)
     n = 150
-    cache = os.environ.get("SDM_DRIVEN_CACHE")
-    if cache and os.path.exists(cache):
-        frames = pickle.load(open(cache, "rb"))
-    else:
-        frames = synth.render_frames(cfg, params, synth.DRIVEN_SCENE, range(n))
-        if cache:
-            pickle.dump(frames, open(cache, "wb"), protocol=4)
+    frames = synth.render_frames_cached(cfg, params, synth.DRIVEN_SCENE, range(n), os.environ.get("SDM_DRIVEN_CACHE"))
     m = binding.SdmMap(cfg, params, None, device=0)
     m.generate_noise_table(seed=20250217)
     out = {"empty_ms": round(m.time_occupancy_sweep(iters=10), 5)}
