@@ -86,9 +86,10 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_t
 //      per chunk and object, every object on a cache line of its own) + (members of its object in the chunks before its
 //      own: the workgroup that applies the chunk sums that row of mv_cnt up to its position - a few hundred words) +
 //      its rank in the chunk.
-// Chunks that hold older set memberships (State::alias; nearly never) are only counted; k_move_apply ranks them on its
-// alias path.  A flagged chunk without any owner clears its flag, a marked group without flagged chunk its mark.
-constexpr uint32_t MV_COMPLEX = 0xffffffffu;
+// Chunks that also hold older set memberships of moving objects (State::alias) get their primary members listed like any
+// other chunk and a flag in mv_nmem; k_move_apply merges the few older memberships into the ranks (its alias path).  A flagged chunk without any owner clears its flag, a marked group without flagged chunk its mark.
+constexpr uint32_t MV_COMPLEX = 0xffffffffu;     // (an `ent` of the member count: no member)
+constexpr uint32_t MV_COMPLEX_BIT = 0x80000000u;  // in mv_nmem: the chunk also holds older set memberships of moving objects
 constexpr uint32_t MV_CLEAR_FLAG = 0x80000000u;  // in mv_list: the chunk holds no owner, k_move_apply clears its flag
 constexpr uint32_t MV_GROUP_CAP = 4096;   // marked groups a workgroup lists (x 64 chunks >> MV_LIST_CAP)
 constexpr int MV_GRID = (int)FrameBeginLaunch::GRID;
@@ -260,7 +261,7 @@ __device__ __forceinline__ void move_members_body(const State &st, const Members
           sc.mv_cnt[(size_t)k * MV_LIST_CAP + pos] = total;
           if (total) atomicAdd(&tot[k * MV_TOT_STRIDE], total);
         } else {
-          sc.mv_nmem[pos] = n_alias_here ? MV_COMPLEX : inc;
+          sc.mv_nmem[pos] = inc | (n_alias_here ? MV_COMPLEX_BIT : 0u);  // (inc <= MV_CHUNK: the primary members, listed below)
           // A flagged chunk that holds no owner any more loses its flag - in k_move_apply, not here: other workgroups of this
           // launch may still be reading the flags, and they all have to see the same list.
           sc.mv_list[pos] = chunk | (any_owner == 0 ? MV_CLEAR_FLAG : 0u);
@@ -268,7 +269,7 @@ __device__ __forceinline__ void move_members_body(const State &st, const Members
       }
     }
     __syncthreads();
-    if (!n_alias_here) {
+    {
       uint32_t *mem = sc.mv_mem + (size_t)pos * MV_CHUNK;
 #pragma unroll
       for (int r = 0; r < MV_ITEMS; ++r) {
@@ -486,67 +487,64 @@ __device__ __forceinline__ void move_one(const Dims &d, const Frame &f, const Fi
   move_store(d, f, ms, st, sc, m, obj, e, li, alias);
 }
 
-// One round (TPB consecutive slots) of k_move_apply in a chunk that holds older set memberships (State::alias): a slot can
-// then belong to several moving objects.  mo[0] is its primary membership (owner[]), mo[1..] the older ones.
+// k_move_apply in a chunk that also holds older set memberships of moving objects (State::alias: a slot can then belong to
+// several of them).  The member count has listed and ranked the chunk's PRIMARY members (owner[]) like any other chunk's;
+// the older memberships - a handful per chunk - are merged in here:
+//   rank of a membership (slot s, object o) among o's members in the chunk
+//       = primary members of o below s  +  older memberships of o below s.
+// A slot that several moving objects hold is moved by each of them, in object order, and all but the first copy a particle
+// that has just been invalidated (operations.h:339-349 runs object by object): ONE thread handles all memberships of such a
+// slot - the thread of its primary member if it has one, else the thread of its first table entry - so that nobody reads a
+// status byte somebody else is writing.  (Rounds 3-5 ranked such a chunk round by round, 256 slots at a time with three
+// barriers and a ballot per object and round, its moves a chain of sixteen dependent trips: 30-40 us for ONE chunk, and
+// k_move_apply - which ends with its slowest workgroup - took 42 us on the `driven` workload against 14 us on maps without
+// such memberships.)
 constexpr uint32_t CA_CAP = 512;
-__device__ __forceinline__ void move_round_with_aliases(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms,
-                                                     const State &st, const Scratch &sc, size_t li, uint16_t owner_li, int n_obj,
-                                                     const uint16_t *tracks, const uint32_t *obj_base,
-                                                     uint32_t (*wave_cnt)[MAX_MOVE_OBJECTS], const uint32_t *ca_idx,
-                                                     const uint32_t *ca_ent, const uint8_t *ca_obj, uint32_t n_ca, uint64_t lt_mask,
-                                                     int wid) {
-  constexpr int MAXM = 4;
-  uint8_t mo[MAXM] = {0xFF, 0xFF, 0xFF, 0xFF};
-  uint32_t ment[MAXM] = {0, 0, 0, 0}, mrank[MAXM] = {0, 0, 0, 0};
-  mo[0] = obj_of(owner_li, tracks, n_obj);  // (OWNER_NONE beyond the map's slots: no object)
-  int nm = 1;
-  for (uint32_t c = 0; c < n_ca; ++c)
-    if (ca_idx[c] == (uint32_t)li) {
-      if (nm < MAXM) {
-        mo[nm] = ca_obj[c];
-        ment[nm] = ca_ent[c];
-        ++nm;
-      } else {
-        sc.cnt->overflow = 1;  // a slot in more than four moving sets at once: not handled
-      }
-    }
-  // members of object k in this wave = lanes one of whose memberships is k, in lane (= index) order.  (One ballot per
-  // moving object keeps it light on registers.  A wave's 64 slots are 8 voxels: in nearly every round none of them belongs
-  // to a moving object, and the wave skips the ballots - a dozen objects x 16 rounds of them were most of what a chunk
-  // with an older membership cost, 30 us per such chunk on the `driven` workload.)
-  bool any_member = false;
-#pragma unroll
-  for (int c = 0; c < MAXM; ++c) any_member = any_member || mo[c] != 0xFF;
-  const bool wave_has_members = __ballot(any_member) != 0ull;
-  for (int k = 0; wave_has_members && k < n_obj; ++k) {
-    int q = -1;
-#pragma unroll
-    for (int c = 0; c < MAXM; ++c)
-      if (mo[c] == (uint8_t)k) q = c;
-    const uint64_t mm = __ballot(q >= 0);
-    if (q >= 0) {
-      mrank[q] = (uint32_t)__popcll(mm & lt_mask);
-      if (mrank[q] == 0) wave_cnt[wid][k] = (uint32_t)__popcll(mm);
-    }
+struct ChunkAliases {
+  const uint32_t *idx;   // slot index (shard-local) of entry c
+  const uint32_t *ent;   // its position in State::alias
+  const uint8_t *obj;    // rank of its track among the frame's moving objects
+  uint32_t n;
+};
+// older memberships of object o in this chunk below slot index li
+__device__ __forceinline__ uint32_t aliases_below(const ChunkAliases &ca, uint32_t o, uint32_t li) {
+  uint32_t c = 0;
+  for (uint32_t k = 0; k < ca.n; ++k) c += (ca.obj[k] == o && ca.idx[k] < li) ? 1u : 0u;
+  return c;
+}
+// primary members of object o in this chunk below slot-in-chunk s (the member list is in ascending slot order)
+__device__ __forceinline__ uint32_t primaries_below(const uint32_t *mem, uint32_t nm, uint32_t o, uint32_t s) {
+  uint32_t c = 0;
+  for (uint32_t i = 0; i < nm; ++i) {
+    const uint32_t en = mem[i];
+    if ((en & 4095u) >= s) break;
+    c += ((en >> 12) & 63u) == o ? 1u : 0u;
   }
-  __syncthreads();
-  // a slot that several moving objects hold is moved by each of them, in object order: all but the first copy a
-  // particle that has just been invalidated
+  return c;
+}
+// all memberships of one slot, in object order.  prim_o: the object of its primary membership (0xFF: none that moves),
+// prim_rank: that membership's rank among the primary members of its object in the chunk.
+__device__ __forceinline__ void move_slot_memberships(const Dims &d, const Frame &f, const Filter &flt, const MoveSet &ms, const State &st,
+                                                      const Scratch &sc, const ChunkAliases &ca, const uint32_t *mem, uint32_t nm,
+                                                      const uint32_t *obj_base, size_t li, uint32_t s, uint32_t prim_o, uint32_t prim_rank) {
+  int last = -1;  // object of the membership handled last
   bool first = true;
-  for (int done_n = 0; done_n < MAXM; ++done_n) {
-    int q = -1;
-#pragma unroll
-    for (int c = 0; c < MAXM; ++c)
-      if (mo[c] != 0xFF && (q < 0 || mo[c] < mo[q])) q = c;
-    if (q < 0) break;
-    const uint8_t ob = mo[q];
-    uint32_t e = obj_base[ob] + mrank[q];
-#pragma unroll
-    for (int w = 0; w < MV_WAVES; ++w)
-      if (w < wid) e += wave_cnt[w][ob];
-    move_one(d, f, flt, ms, st, sc, (int)ob, e, li, q != 0, !first);
-    if (q != 0) st.alias[3 + 2 * ment[q]] = OWNER_NONE;  // the object's set is rebuilt from its re-inserted copies
-    mo[q] = 0xFF;
+  for (;;) {
+    // the membership with the smallest object above `last`
+    uint32_t ob = 0xFFu, entry = 0;
+    bool is_alias = false;
+    if (prim_o != 0xFFu && (int)prim_o > last) ob = prim_o;
+    for (uint32_t k = 0; k < ca.n; ++k)
+      if (ca.idx[k] == (uint32_t)li && (int)ca.obj[k] > last && ca.obj[k] < ob) {
+        ob = ca.obj[k];
+        entry = ca.ent[k];
+        is_alias = true;
+      }
+    if (ob == 0xFFu) break;
+    const uint32_t below = (!is_alias ? prim_rank : primaries_below(mem, nm, ob, s)) + aliases_below(ca, ob, (uint32_t)li);
+    move_one(d, f, flt, ms, st, sc, (int)ob, obj_base[ob] + below, li, is_alias, !first);
+    if (is_alias) st.alias[3 + 2 * entry] = OWNER_NONE;  // the object's set is rebuilt from its re-inserted copies
+    last = (int)ob;
     first = false;
   }
 }
@@ -593,10 +591,9 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
   __shared__ uint32_t c_here[MAX_MOVE_OBJECTS];    // the object's members in this chunk
   __shared__ uint32_t tot_l[MAX_MOVE_OBJECTS];     // the object's members on this shard
   __shared__ uint16_t tracks[MAX_MOVE_OBJECTS];
-  __shared__ uint32_t wave_cnt[MV_WAVES][MAX_MOVE_OBJECTS];
   __shared__ uint32_t ca_idx[CA_CAP], ca_ent[CA_CAP], ca_n;
   __shared__ uint8_t ca_obj[CA_CAP];
-  __shared__ uint16_t ca_own[MV_ITEMS][TPB];  // the owner entries of a chunk on the alias path (column = thread)
+  __shared__ uint32_t cm_mem[MV_CHUNK];  // the member list of a chunk on the alias path
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const size_t n_slots = (size_t)d.v_count * d.S;
   if (threadIdx.x < MAX_MOVE_OBJECTS) {
@@ -642,11 +639,13 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
     // the thread's member of the chunk (nearly always the only one: a chunk holds a dozen members on average): its own
     // fields are requested before the ranks are known
     MoveLoaded ml;
-    const bool simple = nm != MV_COMPLEX;
-    const bool mine = simple && threadIdx.x < nm;
+    const bool simple = (nm & MV_COMPLEX_BIT) == 0u;
+    const uint32_t nm_raw = nm;
+    nm &= ~MV_COMPLEX_BIT;  // the chunk's primary members
+    const bool mine = threadIdx.x < nm;
     if (mine) move_load_particle(d, st, base + (first_entry & 4095u), false, ml);
     __syncthreads();
-    if (nm != 0) {  // (workgroup-uniform)
+    if (nm_raw != 0) {  // (workgroup-uniform)
       // the object's members in the chunks before this one: every wave takes the objects of its number
       for (int k = wid; k < n_obj; k += MV_WAVES) {
         if (c_here[k] == 0) continue;  // (wave-uniform)
@@ -675,6 +674,7 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
       } else {
         // older memberships of moving objects inside this chunk (State::alias): slot, object rank, entry
         if (threadIdx.x == 0) ca_n = 0;
+        for (uint32_t i = threadIdx.x; i < nm; i += TPB) cm_mem[i] = i == threadIdx.x ? first_entry : sc.mv_mem[(size_t)pos * MV_CHUNK + i];
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < na_total; k += blockDim.x) {
           const uint32_t idx = st.alias[2 + 2 * k], trk = st.alias[3 + 2 * k];
@@ -689,39 +689,44 @@ __global__ __launch_bounds__(TPB) void k_move_apply(Dims d, Filter flt, State st
           }
         }
         __syncthreads();
-        const uint32_t n_ca = ca_n < CA_CAP ? ca_n : CA_CAP;
+        ChunkAliases ca;
+        ca.idx = ca_idx;
+        ca.ent = ca_ent;
+        ca.obj = ca_obj;
+        ca.n = ca_n < CA_CAP ? ca_n : CA_CAP;
         if (threadIdx.x == 0 && ca_n > CA_CAP) sc.cnt->overflow = 1;
-        // (the thread's sixteen owner entries, requested together and parked in LDS: loaded round by round they were
-        // sixteen dependent round trips, most of what such a chunk cost; the round loop stays rolled - unrolled it is
-        // sixteen copies of the ranking code, more than the instruction cache holds)
-        {
-          uint16_t ow[MV_ITEMS];
-#pragma unroll
-          for (int r = 0; r < MV_ITEMS; ++r) {
-            const size_t li = base + (size_t)r * TPB + threadIdx.x;
-            ow[r] = li < n_slots ? st.owner[li] : OWNER_NONE;
+        // the primary members: one thread each.  A slot nobody else holds is moved like any other chunk's (the thread's
+        // first member: with the particle it requested above), its rank moved up by its object's older memberships below it.
+        for (uint32_t i = threadIdx.x; i < nm; i += TPB) {
+          const uint32_t en = cm_mem[i], sl = en & 4095u, o = (en >> 12) & 63u;
+          const size_t li = base + sl;
+          bool shared_slot = false;
+          for (uint32_t k = 0; k < ca.n; ++k) shared_slot = shared_slot || ca.idx[k] == (uint32_t)li;
+          if (!shared_slot) {
+            const uint32_t e = obj_base[o] + (en >> 18) + aliases_below(ca, o, (uint32_t)li);
+            if (i == threadIdx.x) {
+              move_load_noise(flt, st, cursor, e, ml);
+              move_store(d, f, ms, st, sc, ml, (int)o, e, li, false);
+            } else {
+              move_one(d, f, flt, ms, st, sc, (int)o, e, li);
+            }
+          } else {
+            move_slot_memberships(d, f, flt, ms, st, sc, ca, cm_mem, nm, obj_base, li, sl, o, en >> 18);
           }
-#pragma unroll
-          for (int r = 0; r < MV_ITEMS; ++r) ca_own[r][threadIdx.x] = ow[r];
         }
-#pragma unroll 1
-        for (int r = 0; r < MV_ITEMS; ++r) {
-          if (threadIdx.x < MAX_MOVE_OBJECTS) {
-#pragma unroll
-            for (int w = 0; w < MV_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+        // older memberships of slots whose primary owner is not moving: the thread of the slot's first table entry
+        for (uint32_t c = threadIdx.x; c < ca.n; c += TPB) {
+          const uint32_t li = ca.idx[c], sl = li - (uint32_t)base;
+          bool other = false;
+          for (uint32_t k = 0; k < c; ++k) other = other || ca.idx[k] == li;
+          for (uint32_t i = 0; i < nm && !other; ++i) {
+            const uint32_t s2 = cm_mem[i] & 4095u;
+            if (s2 >= sl) {
+              other = s2 == sl;
+              break;
+            }
           }
-          __syncthreads();
-          const size_t li = base + (size_t)r * TPB + threadIdx.x;
-          move_round_with_aliases(d, f, flt, ms, st, sc, li, ca_own[r][threadIdx.x], n_obj, tracks, obj_base, wave_cnt, ca_idx, ca_ent, ca_obj, n_ca,
-                                  lt_mask, wid);
-          __syncthreads();
-          if (threadIdx.x < MAX_MOVE_OBJECTS) {
-            uint32_t add = 0;
-#pragma unroll
-            for (int w = 0; w < MV_WAVES; ++w) add += wave_cnt[w][threadIdx.x];
-            obj_base[threadIdx.x] += add;
-          }
-          __syncthreads();
+          if (!other) move_slot_memberships(d, f, flt, ms, st, sc, ca, cm_mem, nm, obj_base, li, sl, 0xFFu, 0u);
         }
       }
     }

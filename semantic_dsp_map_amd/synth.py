@@ -382,9 +382,11 @@ def render_frames(cfg, params, scene_kw, frames, workers=None):
 
 
 def render_frames_cached(cfg, params, scene_kw, frames, cache_path=None):
-    """render_frames with the result kept in an .npz file (development: A/B runs of the library on the same rendered
-    frames).  The file carries a digest of everything the frames depend on - configuration, parameters, scene, frame
-    numbers - and is ignored (and rewritten) when that does not match: plain arrays only, nothing in it is executed."""
+    """render_frames with the result kept in files <cache_path>.{key,depth,cloud,pose}.npy (development: A/B runs of the
+    library on the same rendered frames).  The key file carries a digest of everything the frames depend on - configuration,
+    parameters, scene, frame numbers - and the cache is ignored (and rewritten) when that does not match.  Plain arrays,
+    written frame by frame into memory-mapped files and read back as views of them: no second copy of a few gigabytes of
+    frames in RAM (the GPU boxes' memory limit is not generous), and nothing in the files is executed."""
     import hashlib
     import json
     import os
@@ -393,18 +395,40 @@ def render_frames_cached(cfg, params, scene_kw, frames, cache_path=None):
         return render_frames(cfg, params, scene_kw, frames)
     key = hashlib.sha1(json.dumps([sorted(cfg.items()), sorted(params.items()), sorted(scene_kw.items()), frames],
                                   default=str).encode()).hexdigest()
-    if os.path.exists(cache_path):
-        try:
-            with np.load(cache_path, allow_pickle=False) as z:
-                if str(z["key"]) == key and int(z["n"]) == len(frames):
-                    return [(z["depth"][i], z["cloud"][i].view(LABELED_POINT).reshape(-1), z["pos"][i], z["q"][i]) for i in range(len(frames))]
-        except (OSError, KeyError, ValueError):
-            pass
+    names = {k: "%s.%s.npy" % (cache_path, k) for k in ("key", "depth", "cloud", "pose")}
+    n, hw = len(frames), cfg["width"] * cfg["height"]
+    try:
+        if str(np.load(names["key"], allow_pickle=False)) == key:
+            depth = np.load(names["depth"], mmap_mode="r", allow_pickle=False)
+            cloud = np.load(names["cloud"], mmap_mode="r", allow_pickle=False)
+            pose = np.load(names["pose"], allow_pickle=False)
+            if depth.shape[0] == n and cloud.shape == (n, hw * LABELED_POINT.itemsize):
+                return [(depth[i], cloud[i].view(LABELED_POINT), pose[i, :3].copy(), pose[i, 3:].copy()) for i in range(n)]
+    except (OSError, ValueError):
+        pass
     out = render_frames(cfg, params, scene_kw, frames)
-    np.savez(cache_path, key=np.array(key), n=np.array(len(out)), depth=np.stack([f[0] for f in out]),
-             cloud=np.stack([np.ascontiguousarray(f[1]).view(np.uint8).reshape(-1) for f in out]),
-             pos=np.stack([np.asarray(f[2]) for f in out]), q=np.stack([np.asarray(f[3]) for f in out]))
+    depth = np.lib.format.open_memmap(names["depth"], mode="w+", dtype=np.float32, shape=(n, cfg["height"], cfg["width"]))
+    cloud = np.lib.format.open_memmap(names["cloud"], mode="w+", dtype=np.uint8, shape=(n, hw * LABELED_POINT.itemsize))
+    pose = np.zeros((n, 7), np.float32)
+    for i, f in enumerate(out):
+        depth[i] = f[0]
+        cloud[i] = np.ascontiguousarray(f[1]).view(np.uint8).reshape(-1)
+        pose[i, :3], pose[i, 3:] = f[2], f[3]
+    depth.flush()
+    cloud.flush()
+    del depth, cloud
+    np.save(names["pose"], pose)
+    np.save(names["key"], np.array(key))
     return out
+
+
+def remove_frame_cache(cache_path):
+    import os
+    for k in ("key", "depth", "cloud", "pose"):
+        try:
+            os.remove("%s.%s.npy" % (cache_path, k))
+        except OSError:
+            pass
 
 
 STATE_FIELDS = [("px", np.float32), ("py", np.float32), ("pz", np.float32), ("w", np.float32),

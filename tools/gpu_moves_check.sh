@@ -3,7 +3,7 @@
 # driven leg of bench.py (frames rendered once and cached)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-export SDM_DRIVEN_CACHE=/tmp/sdm_driven_frames_$$.pkl
+export SDM_DRIVEN_CACHE=/tmp/sdm_driven_frames_$$
 {
   timeout 1200 python -m pytest tests/test_driven_gpu.py tests/test_long_object_lists_gpu.py tests/test_parity_gpu.py tests/test_sharded_gpu.py tests/test_sweep_dense_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error" | tail -3
   timeout 900 python bench.py --only-driven 2>/dev/null | grep '"metric"\|driven' | python -c "
