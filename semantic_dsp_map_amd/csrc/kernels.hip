@@ -2812,7 +2812,7 @@ __global__ void k_birth_cursor(Dims d, Filter flt, Scratch sc) {
 // insertions before it, they cost a store drain and a round trip in the middle of the replay.)
 template <int S>
 __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t base, uint8_t (&stv)[S], uint16_t (&own)[S],
-                                               uint32_t n_alias, bool touched, const float (&wv)[S], const uint16_t (&trk)[S]) {
+                                               uint32_t n_alias, bool touched, uint32_t fbits, const float (&wv)[S], const uint16_t (&trk)[S]) {
   unsigned char *const rec = st.rec + base / S * rec_bytes(S);  // (base = lv * S)
   float weight_sum = 0.f;
   uint32_t updated = 0;
@@ -2830,7 +2830,7 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
       if (stv[i] == ST_UPDATED) {
         stv[i] = ST_INVALID;
         SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_status(ST_INVALID);
-        owner_erase_local(st, base + i, trk[i], own[i], n_alias, touched);  // removeParticleFromObj
+        owner_erase_local(st, base + i, trk[i], own[i], n_alias, touched, fbits, i);  // removeParticleFromObj
       }
     return true;
   }
@@ -2844,7 +2844,7 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
       if (run < thr) {
         stv[i] = ST_INVALID;
         SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_status(ST_INVALID);
-        owner_erase_local(st, base + i, trk[i], own[i], n_alias, touched);
+        owner_erase_local(st, base + i, trk[i], own[i], n_alias, touched, fbits, i);
       } else {
         SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_w(wpp);
         thr += wpp;
@@ -3090,6 +3090,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   load_vec<(2 * S < 16 ? 2 * S : 16)>(own, st.owner + base);
   const uint32_t n_alias = st.alias[0];
   bool alias_touched = false;
+  uint32_t fbits = n_alias ? alias_filter_bits<S>(st, base) : 0u;  // (with the voxel's rows: one round)
   uint32_t L = 0;  // candidates of the segment, capped at LMAX
   {
     bool run = true;
@@ -3143,7 +3144,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   }
   const bool try_resample = noise_flavour ? L > V0 : L >= 1;
   uint32_t n_resamp = 0;
-  if (try_resample && resample_voxel<S>(d, st, base, stv, own, n_alias, alias_touched, wv0, trk0)) n_resamp = 1;
+  if (try_resample && resample_voxel<S>(d, st, base, stv, own, n_alias, alias_touched, fbits, wv0, trk0)) n_resamp = 1;
   uint32_t nB = 0;
   if (try_resample) {
     const uint32_t consumed = noise_flavour ? V0 : 1u;  // (noise flavour: the candidate that found the voxel full retries)
@@ -3197,7 +3198,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
     sr.set_label(label);
     sr.set_status(ST_REGULAR_BORN);
     if ((int)track <= d.max_movable) {  // addParticleToObj
-      if (!owner_insert_local(st, base + i, track, own[i], n_alias, alias_touched)) sc.cnt->overflow = 1;
+      if (!owner_insert_local(st, base + i, track, own[i], n_alias, alias_touched, fbits, i)) sc.cnt->overflow = 1;
       flag_owner_chunk(st, base + i);
     }
   }

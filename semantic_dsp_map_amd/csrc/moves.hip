@@ -28,9 +28,14 @@ void debug_timers_moves(unsigned long long *out, int reset) {
 }
 #define DBGM(k, i, v) do { if (blockIdx.x < 4096 && threadIdx.x == 0) g_dbg_m[k][blockIdx.x * 4 + (i)] = (unsigned long long)(v); } while (0)
 #define DBGM_T() wall_clock64()
+// every head of k_move_replay (not only thread 0 of a workgroup): maxima / sums over the launch, behind the rows of its 1024 workgroups
+#define DBGM_MAX(i, v) atomicMax(&g_dbg_m[1][2048 * 4 + (i)], (unsigned long long)(v))
+#define DBGM_ADD(i, v) atomicAdd(&g_dbg_m[1][2048 * 4 + (i)], (unsigned long long)(v))
 #else
 #define DBGM(k, i, v)
 #define DBGM_T() 0ull
+#define DBGM_MAX(i, v)
+#define DBGM_ADD(i, v)
 #endif
 
 namespace {
@@ -825,6 +830,7 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
       nx0 = sc.mv_next[t];
     }
     DBGM(1, 0, DBGM_T());
+    [[maybe_unused]] const unsigned long long dbg_t0 = DBGM_T();
     const uint32_t lv = c0.voxel;
     if (lv >= d.v_count) continue;
     // the list head, and - requested with it, whoever turns out to be the head - the voxel's rows
@@ -846,6 +852,8 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
     // the voxel's owner entries and the length of the table of older memberships, with the rows above (owner_insert_local)
     uint16_t own[S];
     __builtin_memcpy(own, st.owner + base, 2 * S);
+    // ... and the filter bits of its slots (owner_insert_local; n_alias: wave-uniform)
+    uint32_t fbits = n_alias ? alias_filter_bits<S>(st, base) : 0u;
     if (head != t) continue;  // another copy replays this voxel's list (or the entry is a stale one)
     sc.mv_head[lv] = MV_NIL;
     if (overflow) continue;
@@ -901,6 +909,12 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
         for (uint32_t k = 0; k < n_list; ++k) offer(kept[k][threadIdx.x]);
       }
       DBGM(1, 1, DBGM_T() + (stv[1] == 0xEE ? 1 : 0) + (own[1] == 0xEEEE ? 1 : 0));
+      if (n_above == n_list) {  // (the first pass of this list)
+        DBGM_MAX(0, DBGM_T() - dbg_t0 + (stv[1] == 0xEE ? 1 : 0));
+        DBGM_MAX(2, n_list);
+        DBGM_ADD(3, n_list);
+        DBGM_ADD(4, 1);
+      }
       more = n_above > (uint32_t)(S - 1);  // ranks beyond this batch (a walk of the list is a chain of dependent loads: no second one to find nothing)
       MoveCopy cc[S - 1];  // the batch's copies, requested together
 #pragma unroll
@@ -936,7 +950,7 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
 #pragma unroll
             for (int i = 1; i < S; ++i) o = i == slot ? own[i] : o;
           }
-          if (!owner_insert_local(st, base + slot, c.owner, o, n_alias, alias_touched)) sc.cnt->overflow = 1;
+          if (!owner_insert_local(st, base + slot, c.owner, o, n_alias, alias_touched, fbits, slot)) sc.cnt->overflow = 1;
           last_slot = slot;
           last_owner = o;
         }
@@ -949,6 +963,8 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
     }
     DBGM(1, 2, DBGM_T());
     DBGM(1, 3, n_ok);
+    DBGM_MAX(1, DBGM_T() - dbg_t0 + (n_ok == 0xEEEE ? 1 : 0));
+    DBGM_MAX(5, n_ok);
     if (n_ok) {
       st.vflag[lv] = VF_DIRTY;
       mark_tile(st, lv, epoch);

@@ -335,16 +335,32 @@ __device__ __forceinline__ void owner_erase(const State &st, size_t li, uint16_t
 // voxels' slots and cannot match li, so the length read at the start serves until this thread adds one itself.  What the
 // generic versions load between the stores of one insertion and the next - the owner entry, the table length: two
 // dependent round trips per insertion - is already there.
+// fbits: the filter bits of the voxel's slots (bit i = the table may hold an entry for slot i), fetched for all slots in
+// ONE round before the replay starts (alias_filter_bits) and kept up to date by this thread's own additions.  Read per
+// insertion - alias_may_hold, a load past the L1 - it was a dependent round trip in front of every insertion of a voxel's
+// replay: seventeen in a row for the longest list of a frame of the `driven` workload, 20 of that head's 30 us.  Nobody
+// else can add an entry for one of this voxel's slots while the kernel runs, and a bit another voxel's slot shares with
+// one of these only ever costs a walk.
+template <int S>
+__device__ __forceinline__ uint32_t alias_filter_bits(const State &st, size_t base) {
+  uint32_t w[S], bits = 0;
+#pragma unroll
+  for (int i = 1; i < S; ++i) w[i] = __hip_atomic_load(st.alias_filter + (alias_hash(base + i) >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int i = 1; i < S; ++i) bits |= ((w[i] >> (alias_hash(base + i) & 31u)) & 1u) << i;
+  return bits;
+}
 __device__ __forceinline__ bool owner_insert_local(const State &st, size_t li, uint16_t track, uint16_t &own, uint32_t n_alias,
-                                                   bool &touched) {
+                                                   bool &touched, uint32_t &fbits, int slot) {
   const uint16_t prev = own;
   st.owner[li] = track;
   own = track;
-  uint32_t n = touched ? st.alias[0] : n_alias;
-  if (n > st.alias_cap) n = st.alias_cap;
-  if (n && alias_may_hold(st, li))
+  if ((fbits >> slot) & 1u) {
+    uint32_t n = touched ? st.alias[0] : n_alias;
+    if (n > st.alias_cap) n = st.alias_cap;
     for (uint32_t k = 0; k < n; ++k)  // a set holds an index once
       if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+  }
   if (prev == OWNER_NONE || prev == track) return true;
   const uint32_t k = atomicAdd(&st.alias[0], 1u);  // prev's set keeps the index
   touched = true;
@@ -352,20 +368,22 @@ __device__ __forceinline__ bool owner_insert_local(const State &st, size_t li, u
   st.alias[2 + 2 * k] = (uint32_t)li;
   st.alias[3 + 2 * k] = prev;
   alias_note(st, li);
+  fbits |= 1u << slot;
   return true;
 }
 __device__ __forceinline__ void owner_erase_local(const State &st, size_t li, uint16_t track, uint16_t &own, uint32_t n_alias,
-                                                  bool touched) {
+                                                  bool touched, uint32_t fbits, int slot) {
   if (own == track) {
     st.owner[li] = OWNER_NONE;
     own = OWNER_NONE;
     return;
   }
-  uint32_t n = touched ? st.alias[0] : n_alias;
-  if (n > st.alias_cap) n = st.alias_cap;
-  if (n && alias_may_hold(st, li))
+  if ((fbits >> slot) & 1u) {
+    uint32_t n = touched ? st.alias[0] : n_alias;
+    if (n > st.alias_cap) n = st.alias_cap;
     for (uint32_t k = 0; k < n; ++k)
       if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+  }
 }
 
 // Garbage collection of the table of older memberships: deleted entries (track OWNER_NONE) go, the live ones keep their

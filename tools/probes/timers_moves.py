@@ -1,0 +1,44 @@
+"""Development aid: where k_move_replay's time goes on the `driven` workload (library built with
+tools/ab_build.sh timers -DSDM_AB_TIMERS=1, SDM_LIB_PATH=build/ab/libsdm_timers.so; SDM_DRIVEN_CACHE keeps the rendered
+frames).  Per frame of the last stretch of the drive: the slowest head's list walk and whole replay (100 MHz wall clock),
+the longest list, the number of lists, the copies re-inserted."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from semantic_dsp_map_amd import binding, synth  # noqa: E402
+
+
+def main():
+    cfg, params = synth.CONFIGS["C3"], synth.PARAMS[synth.DRIVEN_PARAMS]
+    n = synth.DRIVEN_FRAMES + 20
+    frames = synth.render_frames_cached(cfg, params, synth.DRIVEN_SCENE, range(n), os.environ.get("SDM_DRIVEN_CACHE"))
+    scene = synth.Scene(cfg, **synth.DRIVEN_SCENE)
+    m = binding.SdmMap(cfg, params, None, device=0)
+    m.generate_noise_table(seed=20250217)
+    L = m.L
+    L.sdm_debug_timers.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    buf = np.zeros(6 * 8192 * 4 + 4 * 4096 * 4, np.uint64)
+    for t, (depth, cloud, pos, q) in enumerate(frames):
+        if t >= synth.DRIVEN_FRAMES - 10:
+            L.sdm_debug_timers(m.h, buf.ctypes.data, 1)
+        m.update(depth, cloud, pos, q, scene.moves(t), sync=t >= synth.DRIVEN_FRAMES - 10)
+        if t < synth.DRIVEN_FRAMES - 10:
+            continue
+        L.sdm_debug_timers(m.h, buf.ctypes.data, 0)
+        mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(4, 4096, 4)
+        s = mv[1].reshape(-1)[2048 * 4:]
+        r = mv[1][:1024]
+        ran = (r[:, 0] > 0) & (r[:, 2] > 0)
+        span = (r[ran, 2].max() - r[ran, 0].min()) / 100.0 if ran.any() else 0.0
+        st = m.stats()
+        print("frame %d: replay span (thread 0 of the workgroups) %.1f us | slowest head: walk %.1f us, whole %.1f us | lists %d, longest %d, mean %.1f, most copies re-inserted by one head %d | moved %d re-inserted %d"
+              % (t, span, s[0] / 100.0, s[1] / 100.0, s[4], s[2], s[3] / max(s[4], 1), s[5], st["n_moved"], st["n_move_reinserted"]))
+    m.close()
+
+
+if __name__ == "__main__":
+    main()
