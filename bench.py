@@ -689,6 +689,7 @@ def main():
             m1.comm_timing(False)
             sharded_one = {"ms_per_step": s1["ms_per_step"], "over_plain_frame_ms": round(s1["ms_per_step"] - ms_per_step, 4),
                            "steps": s1["steps"], "warmup": s1["warmup"], "live_particles": s1["live_particles"],
+                           "host_enqueue_ms_per_step": s1["host_enqueue_ms_per_step"],
                            "collectives_us": {k: round(float(np.mean(v)), 1) for k, v in sorted(comm1.items())},
                            "path": "sdm_update_sharded, RCCL communicator of 1 rank, launch by launch (sharded frames are never replayed from a graph)",
                            "ck_exchange": os.environ.get("SDM_CK_EXCHANGE", "chunks")}

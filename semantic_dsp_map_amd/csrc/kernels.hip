@@ -2299,6 +2299,13 @@ __global__ __launch_bounds__(TPB) void k_ck_classify(Dims d, Filter flt, Scratch
     if (cls == CK_HEAVY) sc.ck_heavy[shard * sc.cap_heavy + base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = p;
   }
   if (!in_image) return;
+  if (!finish) {
+    // Z-slab shards: pass 1 leaves partial sums that are exchanged and summed before pass 2.  The per-pixel operands of pass 2
+    // that do not depend on the sums - position, track, validity - are written here, so that pass 2 can take the summed image
+    // as it comes out of the exchange (k_weight's ck_raw) and no per-pixel launch has to sit between the exchange and it.
+    sc.pix4[p] = make_float4(o.x, o.y, o.z, 0.f);
+    sc.pixt[p] = o.is_valid ? ((uint32_t)o.track_id | (1u << 16)) : 0u;
+  }
   if (!o.is_valid) {
     if (finish) sc.pixt[p] = 0;  // invalid pixel: skipped by pass 2
   } else if (cls == CK_DONE) {
@@ -2582,12 +2589,14 @@ __global__ __launch_bounds__(TPB) void k_ck_finish(Dims d, Filter flt, Scratch s
 // shard r owns chunk r.  stage holds, for this shard's chunk, the `world` partial sums of all shards (part s = what shard
 // s computed for these pixels, received by an all-to-all); they are added in slab order - the same float sums as
 // k_ck_finish forms from whole images - into this shard's chunk of the full image, which is then all-gathered.
-__global__ __launch_bounds__(TPB) void k_ck_reduce_chunk(const float *__restrict__ stage, float *__restrict__ full, uint32_t chunk,
-                                                         int world, int rank) {
+// own_part: this shard's partial image (its own part of its own chunk is read from there: the exchange copies nothing from
+// a shard to itself); nullptr: part `rank` of the stage holds it (the split entry points, whose caller fills the stage).
+__global__ __launch_bounds__(TPB) void k_ck_reduce_chunk(const float *__restrict__ stage, const float *__restrict__ own_part,
+                                                         float *__restrict__ full, uint32_t chunk, int world, int rank) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= chunk) return;
   float ck = 0.f;
-  for (int g = 0; g < world; ++g) ck += stage[(size_t)g * chunk + i];
+  for (int g = 0; g < world; ++g) ck += (g == rank && own_part) ? own_part[(size_t)rank * chunk + i] : stage[(size_t)g * chunk + i];
   full[(size_t)rank * chunk + i] = ck;
 }
 
@@ -2608,8 +2617,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 constexpr int WT_WAVES = 4;
 constexpr int WT_GRID = 2048;  // x 4 waves = the 8192 waves the chip holds at once
-template <int U, int ROUNDS>
-__global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, State st, Scratch sc) {
+template <int U, int ROUNDS, bool RAW>
+__global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, State st, Scratch sc, const float *__restrict__ ck_raw) {
   static_assert(U * A7_ROWS <= 64, "lanes (u, row) of the row sums");
   DBG_LANE0(4, 0);
   const Frame f = sc.fa->f;  // a copy (uniform registers): stores of the kernel cannot alias it
@@ -2646,6 +2655,7 @@ __global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, St
     }
     uint32_t ot[U][ROUNDS];
     float4 o[U][ROUNDS];
+    float cr[U][ROUNDS];  // ck_raw != nullptr (Z-slab shards): the pixel's summed ck as the exchange left it; ck + kappa is formed here
     bool all_fast = true;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -2658,9 +2668,11 @@ __global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, St
         const int ni = i + wr[rd] - h, nj = j + wc[rd] - h;
         ot[u][rd] = 0;
         o[u][rd] = make_float4(0.f, 0.f, 0.f, 1.f);
+        cr[u][rd] = 0.f;
         if (k0 + u < n && rd * 64 + lane < pairs && ni >= 0 && ni < d.H && nj >= 0 && nj < d.W) {
           ot[u][rd] = sc.pixt[ni * d.W + nj];
           o[u][rd] = sc.pix4[ni * d.W + nj];  // x, y, z, ck+kappa (beside the validity word, not behind it)
+          if constexpr (RAW) cr[u][rd] = ck_raw[ni * d.W + nj];  // (the same round of loads)
         }
       }
     }
@@ -2668,6 +2680,12 @@ __global__ __launch_bounds__(64 * WT_WAVES) void k_weight(Dims d, Filter flt, St
     for (int u = 0; u < U; ++u) {
       rsig[u] = div_recip(sigma[u]);
       all_fast = all_fast && rsig[u] != 0.f;
+    }
+    if constexpr (RAW) {  // ck * P_d + kappa (semantic_dsp_map.h:1035), the very expression ck_store / k_ck_finish evaluate
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) o[u][rd].w = cr[u][rd] * flt.p_detect + flt.noise_number;
     }
     int right[U];
     auto terms = [&](auto fast) {
@@ -3785,18 +3803,23 @@ void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const
   hipLaunchKernelGGL(k_ck_finish, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, parts, n_parts,
                      part_stride ? part_stride : (size_t)d.W * d.H);
 }
-void launch_ck_reduce_chunk(const float *stage, float *full, uint32_t chunk, int world, int rank, hipStream_t s) {
-  hipLaunchKernelGGL(k_ck_reduce_chunk, dim3((chunk + TPB - 1) / TPB), dim3(TPB), 0, s, stage, full, chunk, world, rank);
+void launch_ck_reduce_chunk(const float *stage, const float *own_part, float *full, uint32_t chunk, int world, int rank, hipStream_t s) {
+  hipLaunchKernelGGL(k_ck_reduce_chunk, dim3((chunk + TPB - 1) / TPB), dim3(TPB), 0, s, stage, own_part, full, chunk, world, rank);
 }
-void launch_weight(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s) {
+void launch_weight(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s, const float *ck_raw) {
   // four particles per wave while a window fits two rounds of 64 lanes (window_half <= 5), two beyond
   const int side = 2 * d.window_half + 1;
-  if (side * side <= 64)
-    hipLaunchKernelGGL((k_weight<4, 1>), dim3(WT_GRID), dim3(64 * WT_WAVES), 0, s, d, flt, st, sc);
-  else if (side * side <= 128)
-    hipLaunchKernelGGL((k_weight<4, 2>), dim3(WT_GRID), dim3(64 * WT_WAVES), 0, s, d, flt, st, sc);
-  else
-    hipLaunchKernelGGL((k_weight<2, 4>), dim3(WT_GRID), dim3(64 * WT_WAVES), 0, s, d, flt, st, sc);
+#define SDM_WEIGHT(UU, RR)                                                                                              \
+  if (ck_raw) hipLaunchKernelGGL((k_weight<UU, RR, true>), dim3(WT_GRID), dim3(64 * WT_WAVES), 0, s, d, flt, st, sc, ck_raw); \
+  else hipLaunchKernelGGL((k_weight<UU, RR, false>), dim3(WT_GRID), dim3(64 * WT_WAVES), 0, s, d, flt, st, sc, ck_raw);
+  if (side * side <= 64) {
+    SDM_WEIGHT(4, 1)
+  } else if (side * side <= 128) {
+    SDM_WEIGHT(4, 2)
+  } else {
+    SDM_WEIGHT(2, 4)
+  }
+#undef SDM_WEIGHT
 }
 
 // Birth candidates and their stable sort by target voxel depend on the input cloud only: side stream.

@@ -124,6 +124,7 @@ struct sdm_map {
   int birth_which = 0;
   float *ck_user = nullptr;
   bool fused_ck = false;  // single-GPU sdm_update: pass 1 writes ck+kappa directly
+  const float *ck_raw_last = nullptr;  // the last frame's summed ck image when pass 2 formed ck + kappa itself (sdm_get_ck_kappa finishes it on demand)
   int32_t stop_after = 0;
   uint32_t frame_flags = 0;
   int n_moves = 0, n_remove = 0;
@@ -1490,9 +1491,18 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
   hipStream_t s = m->stream;
   const Dims &d = m->d;
   const float *own = m->ck_user ? m->ck_user : m->d_ck_part;
-  if (!m->fused_ck) launch_ck_finish(d, m->flt, m->sc, ck_parts_dev ? ck_parts_dev : own, ck_parts_dev ? n_parts : 1, m->ck_part_stride, s);
+  // One image that is summed already (the chunk-owner exchange of a sharded map, or this shard's own image): pass 2 forms
+  // ck + kappa itself from it (k_weight's ck_raw; the pixels' other operands were written by k_ck_classify) - no per-pixel
+  // launch between the exchange and the weight update.  Several whole images (the one-collective exchange): k_ck_finish adds
+  // them in slab order.
+  const float *ck_raw = nullptr;
+  if (!m->fused_ck) {
+    if (!ck_parts_dev || n_parts == 1) ck_raw = ck_parts_dev ? ck_parts_dev : own;
+    else launch_ck_finish(d, m->flt, m->sc, ck_parts_dev, n_parts, m->ck_part_stride, s);
+  }
+  m->ck_raw_last = ck_raw;
   m->ck_part_stride = 0;
-  launch_weight(d, m->flt, m->st, m->sc, s);
+  launch_weight(d, m->flt, m->st, m->sc, s, ck_raw);
   stage_mark(m, 5);
   if (stage_done(stop_after, 5)) return SDM_OK;
   HIP_TRY(hipStreamWaitEvent(s, m->capturing ? m->cap_birth : m->ev_birth, 0));  // join the birth-candidate stream
@@ -2114,7 +2124,7 @@ sdm_status sdm_ck_reduce(sdm_map *m, const float *stage_dev, float *full_dev) {
   if (!m || !stage_dev || !full_dev) return SDM_ERR_INVALID_ARGUMENT;
   if (stage_done(m->stop_after, SDM_STAGE_VISIBILITY)) return SDM_OK;
   HIP_TRY(hipSetDevice(m->device));
-  launch_ck_reduce_chunk(stage_dev, full_dev, m->ck_chunk, m->cfg.shard_count, m->cfg.shard_rank, m->stream);
+  launch_ck_reduce_chunk(stage_dev, nullptr, full_dev, m->ck_chunk, m->cfg.shard_count, m->cfg.shard_rank, m->stream);
   return SDM_OK;
 }
 
@@ -2144,11 +2154,11 @@ sdm_status sdm_get_comm_times(sdm_map *m, double out_us[4]) {
 }
 
 namespace {
-// ncclSend / ncclRecv of one equally sized piece per peer (all-to-all); this rank's own piece is a device copy
+// ncclSend / ncclRecv of one equally sized piece per peer (all-to-all).  This rank's own piece stays where it is: nobody
+// imports a shard's export segment to itself, and the chunk reduction reads its own part from the partial image (until
+// round 6 it was a device copy on the frame's critical path, 5 us each).
 sdm_status all_to_all(sdm_map *m, const void *send, void *recv, size_t piece_bytes, hipStream_t s) {
   const int world = m->cfg.shard_count, rank = m->cfg.shard_rank;
-  HIP_TRY(hipMemcpyAsync((char *)recv + (size_t)rank * piece_bytes, (const char *)send + (size_t)rank * piece_bytes, piece_bytes,
-                         hipMemcpyDeviceToDevice, s));
   if (world == 1) return SDM_OK;
   NCCL_TRY(ncclGroupStart());
   for (int peer = 0; peer < world; ++peer) {
@@ -2223,7 +2233,7 @@ sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_
     CommTimer t(m, 2, m->stream);
     if ((rc = all_to_all(m, part, m->d_ck_stage, (size_t)m->ck_chunk * 4, m->stream)) != SDM_OK) return rc;
   }
-  launch_ck_reduce_chunk(m->d_ck_stage, m->d_ck_full, m->ck_chunk, world, rank, m->stream);
+  launch_ck_reduce_chunk(m->d_ck_stage, part, m->d_ck_full, m->ck_chunk, world, rank, m->stream);
   {
     CommTimer t(m, 3, m->stream);
     NCCL_TRY(ncclAllGather(m->d_ck_full + (size_t)rank * m->ck_chunk, m->d_ck_full, m->ck_chunk, ncclFloat32, m->comm, m->stream));
@@ -2671,6 +2681,7 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
 sdm_status sdm_get_ck_kappa(sdm_map *m, float *out) {
   if (!m || !out) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
+  if (m->ck_raw_last) launch_ck_finish(m->d, m->flt, m->sc, m->ck_raw_last, 1, 0, m->stream);  // (debug read-out of a sharded frame)
   HIP_TRY(hipMemcpyAsync(out, m->sc.ck_kappa, (size_t)m->d.W * m->d.H * 4, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return SDM_OK;

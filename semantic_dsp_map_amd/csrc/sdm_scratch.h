@@ -184,8 +184,9 @@ void launch_visibility(const Dims &d, const Filter &flt, const State &st, const 
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
 // part_stride: floats between two partial images (0 = H*W)
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, size_t part_stride, hipStream_t s);
-void launch_ck_reduce_chunk(const float *stage, float *full, uint32_t chunk, int world, int rank, hipStream_t s);
-void launch_weight(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s);
+void launch_ck_reduce_chunk(const float *stage, const float *own_part, float *full, uint32_t chunk, int world, int rank, hipStream_t s);
+// ck_raw: the summed (not yet finished) ck image of a sharded frame, nullptr = pix4 holds ck + kappa
+void launch_weight(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, hipStream_t s, const float *ck_raw = nullptr);
 int launch_birth_prepare(const Dims &d, const Filter &flt, const BirthOrder &bo, const State &st,
                          const Scratch &sc, hipStream_t s);
 void launch_birth_replay(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, int which, bool literal,
