@@ -38,12 +38,13 @@ PREFILL_FACTOR = 1.16   # prefilled / live particles after the first sweeps' cul
 
 
 def timed_run(synth, sharded, dist, rank, world, local_rank, cfg, params, particles_per_shard, steps, warmup, scene_kw,
-              prefill_kw=None, force_comm=None):
+              prefill_kw=None, force_comm=None, exchange=None):
     """One more map of its own: frames rendered and uploaded, map prefilled, `warmup` + `steps` frames issued back to back,
     barrier + synchronize on both sides of the timed ones, max over ranks.  Returns the numbers and the engine (open).
     force_comm: the frames go through sdm_update_sharded on an RCCL communicator whatever the world size."""
     eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist,
-                                   force_comm=(dist is not None) if force_comm is None else force_comm)
+                                   force_comm=(dist is not None) if force_comm is None else force_comm,
+                                   exchange=exchange or os.environ.get("SDM_EXCHANGE", "rccl"))
     m = eng.map
     m.generate_noise_table(seed=20250217)
     scene = synth.Scene(cfg, **scene_kw)
@@ -365,6 +366,7 @@ def main():
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-case sweep timing after the run")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling run (C4: 256^3 / 8M particles over the GPUs)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the one-rank run of the sharded frame (N = 1 only)")
+    ap.add_argument("--sharded-leg", action="store_true", help="run it also with --no-cpu (which skips the side legs)")
     ap.add_argument("--no-stress", action="store_true", help="skip the busy-scene run (N = 1 only)")
     ap.add_argument("--only-stress", action="store_true", help="run nothing but the busy scene (development)")
     ap.add_argument("--no-driven", action="store_true", help="skip the drive from an empty map (N = 1 only)")
@@ -420,7 +422,8 @@ def main():
     S = 1 << cfg["p_n"]
     n_frames = args.warmup + args.steps
 
-    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist, force_comm=multi)
+    # (SDM_EXCHANGE=ipc: the exchanges of a sharded frame through peer-mapped arenas instead of RCCL)
+    eng = sharded.NativeShardedMap(cfg, params, rank, world, local_rank, dist=dist, force_comm=multi, exchange=os.environ.get("SDM_EXCHANGE", "rccl"))
     m = eng.map
     # noise table: rocRAND on the device, read back so that the CPU baseline uses the same floats
     m.generate_noise_table(seed=20250217)
@@ -671,29 +674,35 @@ def main():
     # + slab-ordered sum + all-gather, every one of them issued).  What it costs OVER the plain frame above is what the
     # sharded path adds before a single byte crosses xGMI; the driver sees it in every --gpus 1 line.
     sharded_one = None
-    if not multi and not args.no_sharded_leg:
+    if not multi and not args.no_sharded_leg and (not args.no_cpu or args.sharded_leg):
         try:
             m.close()  # (a map created while another is alive runs slower for its whole life: DESIGN.md 9)
-            s1, eng1, _, _, _ = timed_run(synth, sharded, None, 0, 1, 0, cfg, params, args.particles, args.steps, max(args.warmup, 6),
-                                          dict(n_static=48, n_dynamic=6, seed=7), force_comm=True)
-            m1 = eng1.map
-            m1.comm_timing(True)
-            comm1 = {}
-            sc1 = synth.Scene(cfg, n_static=48, n_dynamic=6, seed=7)
-            for t in range(n_frames, n_frames + 6):
-                depth, cloud, pos, q = sc1.render(t, params)
-                eng1.update(m1.device_put(depth), m1.device_put(cloud), pos, q, sc1.moves(t))
-                m1.synchronize()
-                for k, v in m1.comm_times().items():
-                    comm1.setdefault(k, []).append(v)
-            m1.comm_timing(False)
-            sharded_one = {"ms_per_step": s1["ms_per_step"], "over_plain_frame_ms": round(s1["ms_per_step"] - ms_per_step, 4),
-                           "steps": s1["steps"], "warmup": s1["warmup"], "live_particles": s1["live_particles"],
-                           "host_enqueue_ms_per_step": s1["host_enqueue_ms_per_step"],
-                           "collectives_us": {k: round(float(np.mean(v)), 1) for k, v in sorted(comm1.items())},
-                           "path": "sdm_update_sharded, RCCL communicator of 1 rank, launch by launch (sharded frames are never replayed from a graph)",
-                           "ck_exchange": os.environ.get("SDM_CK_EXCHANGE", "chunks")}
-            m1.close()
+            sharded_one = {}
+            for exch in ("rccl", "ipc"):
+                s1, eng1, _, _, _ = timed_run(synth, sharded, None, 0, 1, 0, cfg, params, args.particles, args.steps, max(args.warmup, 6),
+                                              dict(n_static=48, n_dynamic=6, seed=7), force_comm=True, exchange=exch)
+                m1 = eng1.map
+                m1.comm_timing(True)
+                comm1 = {}
+                sc1 = synth.Scene(cfg, n_static=48, n_dynamic=6, seed=7)
+                for t in range(n_frames, n_frames + 6):
+                    depth, cloud, pos, q = sc1.render(t, params)
+                    eng1.update(m1.device_put(depth), m1.device_put(cloud), pos, q, sc1.moves(t))
+                    m1.synchronize()
+                    for k, v in m1.comm_times().items():
+                        comm1.setdefault(k, []).append(v)
+                m1.comm_timing(False)
+                leg = {"ms_per_step": s1["ms_per_step"], "over_plain_frame_ms": round(s1["ms_per_step"] - ms_per_step, 4),
+                       "steps": s1["steps"], "warmup": s1["warmup"], "live_particles": s1["live_particles"],
+                       "host_enqueue_ms_per_step": s1["host_enqueue_ms_per_step"],
+                       "exchanges_us": {k: round(float(np.mean(v)), 1) for k, v in sorted(comm1.items())}}
+                m1.close()
+                if exch == "rccl":
+                    sharded_one = dict(leg, path="sdm_update_sharded, RCCL communicator of 1 rank, launch by launch (sharded frames are never replayed from a graph)",
+                                       ck_exchange=os.environ.get("SDM_CK_EXCHANGE", "chunks"))
+                else:
+                    sharded_one["ipc_exchange"] = dict(leg, path="the same frame, its exchanges through the shard's hipIpc arena (sdm_ipc_create / sdm_ipc_connect): "
+                                                                 "one k_ipc_exchange launch each, no RCCL")
         except Exception as e:  # noqa: BLE001 - a side leg must not take the line down
             sharded_one = {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -348,6 +348,14 @@ sdm_status sdm_ck_reduce(sdm_map *m, const float *stage_dev, float *full_dev);
 sdm_status sdm_comm_unique_id(uint8_t out[128]);
 /* halo_cap_records: capacity per destination shard of the export segments, 0 = SDM_HALO_DEFAULT_CAP */
 sdm_status sdm_comm_init(sdm_map *m, const uint8_t id[128], int32_t halo_cap_records);
+/* The same exchanges WITHOUT RCCL, through peer-mapped memory (xGMI is point to point: a shard writes its pieces straight
+ * into the peers' HBM and raises a flag; one small kernel per exchange, no collective launch, no host call but that).
+ * sdm_ipc_create allocates this shard's receive arena and returns its hipIpc handle (64 bytes); the caller gathers the
+ * handles of all shards - any transport, the order is the shard order - and sdm_ipc_connect maps the peers' arenas.
+ * sdm_update_sharded then runs on them (sdm_comm_init is not needed; a map uses one or the other).  A shard that is missing
+ * or out of step: SDM_ERR_COMM at the next sdm_synchronize, after SDM_COMM_TIMEOUT_MS (sdm_comm_set_options(m, -1, ms)). */
+sdm_status sdm_ipc_create(sdm_map *m, int32_t halo_cap_records, uint8_t handle_out[64]);
+sdm_status sdm_ipc_connect(sdm_map *m, const uint8_t *handles_all);
 /* How sdm_update_sharded combines the shards' partial ck images, and how long sdm_synchronize waits for a sharded frame.
  * ck_exchange: 0 = chunk-owner reduction (all-to-all of the chunks to their owners, slab-ordered sum there, all-gather of the
  * summed chunks: 2 (G-1)/G images received, two collectives on the critical path; the default), 1 = ONE all-gather of the

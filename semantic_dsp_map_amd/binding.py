@@ -132,6 +132,8 @@ def load_library():
         "sdm_set_halo_buffers": [vp, vp, vp, vp, vp, i32],
         "sdm_comm_unique_id": [vp],
         "sdm_comm_init": [vp, vp, i32],
+        "sdm_ipc_create": [vp, i32, vp],
+        "sdm_ipc_connect": [vp, vp],
         "sdm_update_sharded": [vp, vp, vp, vp, vp, vp, i32, vp, i32, u32],
         "sdm_ck_chunk_elems": [vp, C.POINTER(i64)],
         "sdm_ck_reduce": [vp, vp, vp],
@@ -366,6 +368,17 @@ class SdmMap:
         buf = np.frombuffer(bytes(id_bytes), np.uint8).copy()
         assert buf.size == 128
         _check(self.L, self.L.sdm_comm_init(self.h, _ptr(buf), halo_cap), "sdm_comm_init")
+
+    def ipc_create(self, halo_cap=0):
+        """This shard's receive arena for the exchanges without RCCL; returns its 64-byte hipIpc handle (sdm_ipc_create)."""
+        buf = np.zeros(64, np.uint8)
+        _check(self.L, self.L.sdm_ipc_create(self.h, halo_cap, _ptr(buf)), "sdm_ipc_create")
+        return buf.tobytes()
+
+    def ipc_connect(self, handles_all):
+        """handles_all: the handles of all shards, in shard order (shard_count x 64 bytes)"""
+        buf = np.frombuffer(bytes(handles_all), np.uint8).copy()
+        _check(self.L, self.L.sdm_ipc_connect(self.h, _ptr(buf)), "sdm_ipc_connect")
 
     def comm_set_options(self, ck_exchange=-1, timeout_ms=0):
         """ck_exchange: 0 chunk-owner reduction, 1 one all-gather of the whole partial images, -1 unchanged"""

@@ -75,6 +75,75 @@ __global__ void k_spin(unsigned long long ticks, unsigned long long *out) {
 }
 __global__ void k_stamp(unsigned long long *out) { *out = wall_clock64(); }
 
+// ---- exchanges of a sharded frame through peer-mapped memory ------------------------------------------------------
+// xGMI is point to point: a shard can write into a peer's HBM directly, and what a sharded frame exchanges is small (a row
+// of 64 counts, a few KB of records, 230 KB of partial sums per peer).  A collective library pays a launch, a handshake and
+// a proxy round for each of them - 5-7 us with ONE rank on this part, 20 us for the count row on its side stream, and the
+// frame has three to four on its critical path.  Here an exchange is one launch of `world` workgroups: workgroup p copies
+// this shard's piece for shard p into p's arena (plain stores over the fabric), makes them visible (system-scope fence),
+// raises this shard's flag in p's arena to the exchange's sequence number, and waits until p's flag in its OWN arena
+// carries that number - then p's piece for this shard has landed.  The kernels behind it on the stream read what arrived.
+// No host call but the launch, nothing to hand-shake: the lock step of the frames orders the buffers' reuse (a peer can
+// only be one exchange ahead, and every arena region is written by one exchange kind only).
+// The wait is bounded (SDM_COMM_TIMEOUT_MS): a shard that is missing leaves an error word, not a hung GPU.
+constexpr int IPC_MAX_SHARDS = 16;
+constexpr uint32_t IPC_FLAG_STRIDE = 128;  // bytes between two flags: a line each
+enum { IPC_COUNTS = 0, IPC_HALO = 1, IPC_CK_PARTS = 2, IPC_CK_FULL = 3, IPC_KINDS = 4 };
+constexpr size_t IPC_OFF_ERR = (size_t)IPC_KINDS * IPC_MAX_SHARDS * IPC_FLAG_STRIDE;
+constexpr size_t IPC_OFF_DATA = IPC_OFF_ERR + 256;
+struct IpcXchg {
+  unsigned char *arena[IPC_MAX_SHARDS];
+  int world, rank;
+  uint32_t kind, seq;
+  const unsigned char *src;  // the piece for shard p: src + p * src_stride
+  size_t src_stride;
+  size_t dst_off, dst_stride;  // it lands at p's arena + dst_off + rank * dst_stride
+  uint32_t piece_bytes;        // a multiple of 4
+  uint32_t halo_cap;           // != 0: the piece is an export segment - its header and the records it counts travel, not its capacity
+  int copy_own;                // the piece for this shard itself is copied too (all-gather kinds)
+  unsigned long long timeout_ticks;  // of the 100 MHz wall clock
+};
+__global__ __launch_bounds__(1024) void k_ipc_exchange(const IpcXchg a) {
+  const int p = blockIdx.x;
+  const unsigned char *src = a.src + (size_t)p * a.src_stride;
+  unsigned char *dst = a.arena[p] + a.dst_off + (size_t)a.rank * a.dst_stride;
+  uint32_t n = a.piece_bytes;
+  if (a.halo_cap) {
+    uint32_t c = *reinterpret_cast<const uint32_t *>(src);
+    c = c < a.halo_cap ? c : a.halo_cap;
+    n = sdm::HALO_HEADER_BYTES + c * sdm::HALO_RECORD_BYTES;
+  }
+  if (dst != src && (p != a.rank || a.copy_own)) {
+    if (((uintptr_t)src | (uintptr_t)dst) % 16 == 0) {
+      const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
+      uint4 *d16 = reinterpret_cast<uint4 *>(dst);
+      for (uint32_t i = threadIdx.x; i < n / 16; i += blockDim.x) d16[i] = s16[i];
+      for (uint32_t i = (n / 16) * 4 + threadIdx.x; i < n / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+    } else {
+      for (uint32_t i = threadIdx.x; i < n / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+    }
+  }
+  __threadfence_system();  // this thread's stores are visible to the peer before the flag can be
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t *theirs = reinterpret_cast<uint32_t *>(a.arena[p] + ((size_t)a.kind * IPC_MAX_SHARDS + a.rank) * IPC_FLAG_STRIDE);
+    __hip_atomic_store(theirs, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t *mine = reinterpret_cast<uint32_t *>(a.arena[a.rank] + ((size_t)a.kind * IPC_MAX_SHARDS + p) * IPC_FLAG_STRIDE);
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+      const uint32_t v = __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((int32_t)(v - a.seq) >= 0) break;
+      if (wall_clock64() - t0 > a.timeout_ticks) {
+        *reinterpret_cast<uint32_t *>(a.arena[a.rank] + IPC_OFF_ERR) = a.kind + 1u;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
+}
+
 void set_error(const char *what, const char *file, int line, const char *detail) {
   char buf[512];
   snprintf(buf, sizeof(buf), "%s (%s:%d): %s", what, file, line, detail ? detail : "");
@@ -139,6 +208,16 @@ struct sdm_map {
   int32_t *d_counts_local = nullptr;
   // native RCCL path (sdm_comm_init): communicator + exchange buffers owned by the map
   ncclComm_t comm = nullptr;
+  // the exchanges of a sharded frame WITHOUT RCCL (sdm_ipc_create / sdm_ipc_connect): every shard owns one receive arena -
+  // flags, gathered count rows, import segments, ck parts and summed ck chunks - that its peers have mapped through hipIpc;
+  // an exchange is one small kernel that writes this shard's pieces into the peers' arenas, raises a flag per peer and
+  // waits for the peers' flags in its own (k_ipc_exchange)
+  bool ipc = false;
+  unsigned char *ipc_arena = nullptr;
+  void *ipc_peer[16] = {};  // [shard]: that shard's arena as this process sees it ([own rank] = ipc_arena)
+  uint32_t ipc_seq[4] = {0, 0, 0, 0};  // exchanges issued so far, per kind: the value the flags of the next one carry
+  size_t ipc_off_counts = 0, ipc_off_halo = 0, ipc_off_stage = 0, ipc_off_full = 0, ipc_bytes = 0;
+  int ipc_fine_grained = 0;
   int32_t *d_counts_all = nullptr;
   unsigned char *d_halo_send = nullptr, *d_halo_recv = nullptr;
   float *d_ck_stage = nullptr, *d_ck_full = nullptr;  // chunk-owner exchange of the partial ck images (sdm_update_sharded)
@@ -527,6 +606,19 @@ sdm_status check_counters(sdm_map *m, Counters *out) {
     if (rc != SDM_OK) return rc;
   }
   if (out) *out = c;
+  if (m->ipc) {
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, m->ipc_arena + IPC_OFF_ERR, 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (err) {
+      static const char *const kind[] = {"member counts", "export segments", "partial ck chunks", "summed ck chunks"};
+      char buf[160];
+      snprintf(buf, sizeof(buf), "an exchange through the peers' arenas (%s) did not complete in time: a shard is missing or out of step",
+               kind[(err - 1) & 3]);
+      set_error("sdm_update_sharded", __FILE__, __LINE__, buf);
+      return SDM_ERR_COMM;
+    }
+  }
   if (al[1] != 0 || al[0] > m->st.alias_cap) {
     // sticky (include/sdm.h): once entries were dropped the owner sets are incomplete, and every later frame - also one
     // with removals or births only, which never looks at Counters::overflow's move-list bit - works on incomplete sets
@@ -1021,9 +1113,16 @@ sdm_status sdm_destroy(sdm_map *m) {
   for (void *p : extra)
     if (p) (void)hipFree(p);
   if (m->comm) (void)ncclCommDestroy(m->comm);
-  void *comm_bufs[] = {m->d_counts_all, m->d_halo_send, m->d_halo_recv, m->d_ck_stage, m->d_ck_full, m->d_ck_all};
-  for (void *p : comm_bufs)
-    if (p) (void)hipFree(p);
+  if (m->ipc_arena) {  // (the exchange buffers are regions of the arena)
+    for (int p = 0; p < m->cfg.shard_count && p < 16; ++p)
+      if (m->ipc_peer[p] && m->ipc_peer[p] != m->ipc_arena) (void)hipIpcCloseMemHandle(m->ipc_peer[p]);
+    (void)hipFree(m->ipc_arena);
+    if (m->d_halo_send) (void)hipFree(m->d_halo_send);
+  } else {
+    void *comm_bufs[] = {m->d_counts_all, m->d_halo_send, m->d_halo_recv, m->d_ck_stage, m->d_ck_full, m->d_ck_all};
+    for (void *p : comm_bufs)
+      if (p) (void)hipFree(p);
+  }
   for (hipEvent_t e : m->ev_comm)
     if (e) (void)hipEventDestroy(e);
   if (m->ev_valid)
@@ -1208,6 +1307,7 @@ sdm_status frame_host_prepare(sdm_map *m, const float cam_pos[3], const float ca
   return SDM_OK;
 }
 
+sdm_status exchange_counts(sdm_map *m, hipStream_t s);  // (the all-gather of the member-count rows: RCCL or the peers' arenas, below)
 // launches of sdm_frame_start: the frame block goes to the device, the chains that depend on nothing but it start
 sdm_status frame_enqueue_start(sdm_map *m) {
   hipStream_t s = m->stream;
@@ -1253,7 +1353,7 @@ sdm_status frame_enqueue_start(sdm_map *m) {
   // (launch by launch the host knows that a frame has no moving objects / removals and skips those launches; inside a
   // graph they are always there and return at once)
   // (a whole map counts in k_frame_begin; a shard in a chain of its own, whose counts the all-gather below picks up)
-  const bool side_chain = !m->capturing && m->n_moves > 0 && (!whole || (m->comm && m->sharded_frame));
+  const bool side_chain = !m->capturing && m->n_moves > 0 && (!whole || ((m->comm || m->ipc) && m->sharded_frame));
   if (m->capturing) {
     if (!whole) launch_moves_count(d, m->st, m->sc, m->d_counts_local, s);
   } else if (side_chain) {
@@ -1266,15 +1366,14 @@ sdm_status frame_enqueue_start(sdm_map *m) {
       launch_moves_count(d, m->st, m->sc, m->counts_local_user ? m->counts_local_user : m->d_counts_local, m->s_moves, &m->fa);
       m->mv_pending = true;
     }
-    if (m->comm && m->sharded_frame) {
+    if ((m->comm || m->ipc) && m->sharded_frame) {
       // exchange 1 of a sharded frame rides the member-count stream: it runs beside the previous frame's sweep.  (Every
       // use of the communicator is ordered by events: this one behind the previous frame's births, the next one - the
       // export all-to-all on the main stream - behind ev_counts.)
       if (m->comm_timing) HIP_TRY(hipEventRecord(m->ev_comm[0], m->s_moves));
-      ncclResult_t r_ = ncclAllGather(m->d_counts_local, m->d_counts_all, HALO_OBJ, ncclInt32, m->comm, m->s_moves);
-      if (r_ != ncclSuccess) {
-        set_error("ncclAllGather(counts)", __FILE__, __LINE__, ncclGetErrorString(r_));
-        return SDM_ERR_COMM;
+      {
+        const sdm_status rc_ = exchange_counts(m, m->s_moves);
+        if (rc_ != SDM_OK) return rc_;
       }
       if (m->comm_timing) {
         HIP_TRY(hipEventRecord(m->ev_comm[1], m->s_moves));
@@ -2105,7 +2204,89 @@ sdm_status sdm_comm_init(sdm_map *m, const uint8_t id_bytes[128], int32_t halo_c
   return sdm_set_halo_buffers(m, m->d_counts_local, m->d_counts_all, m->d_halo_send, m->d_halo_recv, (int32_t)m->halo_cap_own);
 }
 
+// The exchanges without RCCL.  sdm_ipc_create allocates this shard's receive arena (fine-grained device memory where the
+// runtime hands out an IPC handle for it: peers write into it while this GPU's kernels poll its flags; SDM_IPC_ALLOC=coarse
+// forces plain device memory) and returns its hipIpc handle; the caller hands the handles of all shards round (64 bytes
+// each, any transport) and sdm_ipc_connect maps the peers' arenas.  sdm_update_sharded then uses them.
+sdm_status sdm_ipc_create(sdm_map *m, int32_t halo_cap_records, uint8_t handle_out[64]) {
+  if (!m || !handle_out || halo_cap_records < 0 || m->comm || m->ipc_arena) return SDM_ERR_INVALID_ARGUMENT;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+  HIP_TRY(hipSetDevice(m->device));
+  const int world = m->cfg.shard_count;
+  if (world > IPC_MAX_SHARDS) {
+    set_error("sdm_ipc_create", __FILE__, __LINE__, "more than 16 shards");
+    return SDM_ERR_INVALID_ARGUMENT;
+  }
+  m->halo_cap_own = halo_cap_records > 0 ? (uint32_t)halo_cap_records : (uint32_t)SDM_HALO_DEFAULT_CAP;
+  const size_t seg = halo_segment_bytes(m->halo_cap_own);
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  m->ipc_off_counts = IPC_OFF_DATA;
+  m->ipc_off_halo = up(m->ipc_off_counts + (size_t)world * HALO_OBJ * 4);
+  m->ipc_off_stage = up(m->ipc_off_halo + (size_t)world * seg);
+  m->ipc_off_full = up(m->ipc_off_stage + (size_t)world * m->ck_chunk * 4);
+  m->ipc_bytes = up(m->ipc_off_full + (size_t)world * m->ck_chunk * 4);
+  const char *mode = getenv("SDM_IPC_ALLOC");
+  void *p = nullptr;
+  hipIpcMemHandle_t h;
+  bool have = false;
+  if (!(mode && !strcmp(mode, "coarse"))) {
+    if (hipExtMallocWithFlags(&p, m->ipc_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+      if (hipIpcGetMemHandle(&h, p) == hipSuccess) {
+        have = true;
+        m->ipc_fine_grained = 1;
+      } else {
+        (void)hipFree(p);
+        p = nullptr;
+      }
+    }
+    (void)hipGetLastError();
+  }
+  if (!have) {
+    HIP_TRY(hipMalloc(&p, m->ipc_bytes));
+    HIP_TRY(hipIpcGetMemHandle(&h, p));
+  }
+  m->ipc_arena = (unsigned char *)p;
+  HIP_TRY(hipMemsetAsync(p, 0, m->ipc_bytes, m->stream));
+  // the frame's exchange buffers are regions of the arena; the export segments stay local (pushed by the exchange kernel)
+  m->d_counts_all = (int32_t *)(m->ipc_arena + m->ipc_off_counts);
+  m->d_halo_recv = m->ipc_arena + m->ipc_off_halo;
+  m->d_ck_stage = (float *)(m->ipc_arena + m->ipc_off_stage);
+  m->d_ck_full = (float *)(m->ipc_arena + m->ipc_off_full);
+  HIP_TRY(dev_alloc(&m->d_halo_send, seg * (size_t)world));
+  HIP_TRY(hipMemsetAsync(m->d_halo_send, 0, seg * (size_t)world, m->stream));
+  HIP_TRY(hipMemsetAsync(m->d_ck_part, 0, (size_t)m->ck_chunk * world * 4, m->stream));
+  for (hipEvent_t &e : m->ev_comm) HIP_TRY(hipEventCreate(&e));
+  {
+    const char *t = getenv("SDM_COMM_TIMEOUT_MS");
+    if (t && atoi(t) > 0) m->comm_timeout_ms = atoi(t);
+  }
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  memcpy(handle_out, &h, 64);
+  return sdm_set_halo_buffers(m, m->d_counts_local, m->d_counts_all, m->d_halo_send, m->d_halo_recv, (int32_t)m->halo_cap_own);
+}
+
+sdm_status sdm_ipc_connect(sdm_map *m, const uint8_t *handles_all) {
+  if (!m || !handles_all || !m->ipc_arena || m->ipc) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  const int world = m->cfg.shard_count, rank = m->cfg.shard_rank;
+  for (int p = 0; p < world; ++p) {
+    if (p == rank) {
+      m->ipc_peer[p] = m->ipc_arena;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles_all + (size_t)p * 64, 64);
+    HIP_TRY(hipIpcOpenMemHandle(&m->ipc_peer[p], h, hipIpcMemLazyEnablePeerAccess));
+  }
+  m->ipc = true;
+  return SDM_OK;
+}
+
 sdm_status sdm_comm_set_options(sdm_map *m, int32_t ck_exchange, int32_t timeout_ms) {
+  if (m && m->ipc && ck_exchange < 0 && timeout_ms > 0) {
+    m->comm_timeout_ms = timeout_ms;
+    return SDM_OK;
+  }
   if (!m || !m->comm || ck_exchange < -1 || ck_exchange > 1) return SDM_ERR_INVALID_ARGUMENT;
   if (ck_exchange >= 0) m->ck_exchange = ck_exchange;
   if (timeout_ms > 0) m->comm_timeout_ms = timeout_ms;
@@ -2139,7 +2320,7 @@ sdm_status sdm_comm_timing(sdm_map *m, int32_t on) {
 // issue): [0] member counts (all-gather, beside the previous frame's sweep), [1] slab-crossing copies (all-to-all),
 // [2] partial ck chunks to their owners (all-to-all), [3] summed chunks (all-gather).  Waits for the frame.
 sdm_status sdm_get_comm_times(sdm_map *m, double out_us[4]) {
-  if (!m || !out_us || !m->comm) return SDM_ERR_INVALID_ARGUMENT;
+  if (!m || !out_us || (!m->comm && !m->ipc)) return SDM_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(m->device));
   if (m->s_moves) HIP_TRY(hipStreamSynchronize(m->s_moves));
   HIP_TRY(hipStreamSynchronize(m->stream));
@@ -2154,6 +2335,35 @@ sdm_status sdm_get_comm_times(sdm_map *m, double out_us[4]) {
 }
 
 namespace {
+// one exchange through the peers' arenas (k_ipc_exchange): kind, where this shard's pieces lie, where they land
+sdm_status ipc_exchange(sdm_map *m, uint32_t kind, const void *src, size_t src_stride, size_t dst_off, size_t dst_stride, size_t piece_bytes,
+                        uint32_t halo_cap, bool copy_own, hipStream_t s) {
+  IpcXchg a;
+  memset(&a, 0, sizeof(a));
+  const int world = m->cfg.shard_count;
+  for (int p = 0; p < world; ++p) a.arena[p] = (unsigned char *)m->ipc_peer[p];
+  a.world = world;
+  a.rank = m->cfg.shard_rank;
+  a.kind = kind;
+  a.seq = ++m->ipc_seq[kind];
+  a.src = (const unsigned char *)src;
+  a.src_stride = src_stride;
+  a.dst_off = dst_off;
+  a.dst_stride = dst_stride;
+  a.piece_bytes = (uint32_t)piece_bytes;
+  a.halo_cap = halo_cap;
+  a.copy_own = copy_own ? 1 : 0;
+  a.timeout_ticks = (unsigned long long)m->comm_timeout_ms * 100000ull;
+  hipLaunchKernelGGL(k_ipc_exchange, dim3((unsigned)world), dim3(1024), 0, s, a);
+  HIP_TRY(hipGetLastError());
+  return SDM_OK;
+}
+// the count rows of all shards (all-gather), on stream s
+sdm_status exchange_counts(sdm_map *m, hipStream_t s) {
+  if (m->ipc) return ipc_exchange(m, IPC_COUNTS, m->d_counts_local, 0, m->ipc_off_counts, HALO_OBJ * sizeof(int32_t), HALO_OBJ * sizeof(int32_t), 0, true, s);
+  NCCL_TRY(ncclAllGather(m->d_counts_local, m->d_counts_all, HALO_OBJ, ncclInt32, m->comm, s));
+  return SDM_OK;
+}
 // ncclSend / ncclRecv of one equally sized piece per peer (all-to-all).  This rank's own piece stays where it is: nobody
 // imports a shard's export segment to itself, and the chunk reduction reads its own part from the partial image (until
 // round 6 it was a device copy on the frame's critical path, 5 us each).
@@ -2196,7 +2406,7 @@ struct CommTimer {
 sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_point *cloud, const float cam_pos[3],
                               const float cam_q[4], const sdm_object_move *moves, int32_t n_moves,
                               const int32_t *remove_tracks, int32_t n_remove, uint32_t flags) {
-  if (!m || !m->comm) return SDM_ERR_INVALID_ARGUMENT;
+  if (!m || (!m->comm && !m->ipc)) return SDM_ERR_INVALID_ARGUMENT;
   const int world = m->cfg.shard_count, rank = m->cfg.shard_rank;
   for (bool &b : m->comm_timed) b = false;
   m->sharded_frame = true;
@@ -2206,17 +2416,20 @@ sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_
   rc = sdm_frame_moves(m);
   if (rc != SDM_OK) return rc;
   while (m->mv_batch_ready) {  // the further batches of a long object list: counts all-gathered on the main stream, batch applied
-    NCCL_TRY(ncclAllGather(m->d_counts_local, m->d_counts_all, HALO_OBJ, ncclInt32, m->comm, m->stream));
+    if ((rc = exchange_counts(m, m->stream)) != SDM_OK) return rc;
     if ((rc = sdm_frame_moves(m)) != SDM_OK) return rc;
   }
   if (n_moves > 0) {
     CommTimer t(m, 1, m->stream);
-    if ((rc = all_to_all(m, m->d_halo_send, m->d_halo_recv, halo_segment_bytes(m->halo_cap_own), m->stream)) != SDM_OK) return rc;
+    const size_t seg = halo_segment_bytes(m->halo_cap_own);
+    rc = m->ipc ? ipc_exchange(m, IPC_HALO, m->d_halo_send, seg, m->ipc_off_halo, seg, seg, m->halo_cap_own, false, m->stream)
+                : all_to_all(m, m->d_halo_send, m->d_halo_recv, seg, m->stream);
+    if (rc != SDM_OK) return rc;
   }
   const float *part = nullptr;
   rc = sdm_frame_predict(m, &part);
   if (rc != SDM_OK) return rc;
-  if (m->ck_exchange == 1) {
+  if (m->ck_exchange == 1 && !m->ipc) {
     // ONE collective: every shard gets every shard's whole partial image ((G - 1) x H*W floats received instead of
     // 2 (G - 1) / G x H*W) and adds the G of them itself, in slab order (k_ck_finish) - the same float sums, one
     // latency-bound RCCL launch less on the frame's critical path.  Which of the two wins at 8 ranks is a question for the
@@ -2231,12 +2444,20 @@ sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_
   }
   {
     CommTimer t(m, 2, m->stream);
-    if ((rc = all_to_all(m, part, m->d_ck_stage, (size_t)m->ck_chunk * 4, m->stream)) != SDM_OK) return rc;
+    const size_t cb = (size_t)m->ck_chunk * 4;
+    rc = m->ipc ? ipc_exchange(m, IPC_CK_PARTS, part, cb, m->ipc_off_stage, cb, cb, 0, false, m->stream)
+                : all_to_all(m, part, m->d_ck_stage, cb, m->stream);
+    if (rc != SDM_OK) return rc;
   }
   launch_ck_reduce_chunk(m->d_ck_stage, part, m->d_ck_full, m->ck_chunk, world, rank, m->stream);
   {
     CommTimer t(m, 3, m->stream);
-    NCCL_TRY(ncclAllGather(m->d_ck_full + (size_t)rank * m->ck_chunk, m->d_ck_full, m->ck_chunk, ncclFloat32, m->comm, m->stream));
+    if (m->ipc) {  // this shard's summed chunk (it lies in its own arena already) into every peer's
+      const size_t cb = (size_t)m->ck_chunk * 4;
+      if ((rc = ipc_exchange(m, IPC_CK_FULL, m->d_ck_full + (size_t)rank * m->ck_chunk, 0, m->ipc_off_full, cb, cb, 0, true, m->stream)) != SDM_OK) return rc;
+    } else {
+      NCCL_TRY(ncclAllGather(m->d_ck_full + (size_t)rank * m->ck_chunk, m->d_ck_full, m->ck_chunk, ncclFloat32, m->comm, m->stream));
+    }
   }
   return sdm_update_finish(m, m->d_ck_full, 1, flags, 0);
 }

@@ -72,22 +72,40 @@ def broadcast_unique_id(dist, rank):
     return bytes(t.numpy().tobytes())
 
 
-class NativeShardedMap:
-    """A libsdm_hip shard whose exchanges run inside the library on RCCL."""
+def gather_ipc_handles(dist, handle, world):
+    """the 64-byte arena handles of all shards, in shard order (gloo all-gather)"""
+    import torch
+    mine = torch.frombuffer(bytearray(handle), dtype=torch.uint8).clone()
+    allh = torch.zeros(64 * world, dtype=torch.uint8)
+    dist.all_gather_into_tensor(allh, mine)
+    return bytes(allh.numpy().tobytes())
 
-    def __init__(self, cfg, params, rank, world, device, dist=None, noise_table=None, halo_cap=0, max_visible=0, force_comm=False):
+
+class NativeShardedMap:
+    """A libsdm_hip shard whose exchanges run inside the library: on RCCL (exchange="rccl", the default) or through the
+    peers' arenas mapped with hipIpc (exchange="ipc": one small kernel per exchange, no collective launches)."""
+
+    def __init__(self, cfg, params, rank, world, device, dist=None, noise_table=None, halo_cap=0, max_visible=0, force_comm=False,
+                 exchange="rccl"):
         from . import binding
         self.rank, self.world = rank, world
-        self.sharded = world > 1 or force_comm   # force_comm: the RCCL path with a communicator of one rank (rehearsal)
+        self.sharded = world > 1 or force_comm   # force_comm: the sharded frame with one rank (rehearsal)
+        self.exchange = exchange
         self.map = binding.SdmMap(cfg, params, noise_table, device=device, shard_rank=rank, shard_count=world,
                                   max_visible=max_visible)
         if self.sharded:
             if dist is None and world > 1:
                 raise ValueError("world > 1 needs a torch.distributed module for the rendezvous")
-            # (a communicator of ONE rank needs no rendezvous: bench.py's `sharded_one_rank` leg runs without torch)
-            uid = broadcast_unique_id(dist, rank) if dist is not None else binding.comm_unique_id()
-            with stdout_to_stderr():  # RCCL prints a version banner on stdout at communicator creation
-                self.map.comm_init(uid, halo_cap)
+            if exchange == "ipc":
+                handle = self.map.ipc_create(halo_cap)
+                self.map.ipc_connect(gather_ipc_handles(dist, handle, world) if world > 1 else handle)
+                if dist is not None:
+                    dist.barrier()  # every shard has mapped every arena before the first frame writes into one
+            else:
+                # (a communicator of ONE rank needs no rendezvous: bench.py's `sharded_one_rank` leg runs without torch)
+                uid = broadcast_unique_id(dist, rank) if dist is not None else binding.comm_unique_id()
+                with stdout_to_stderr():  # RCCL prints a version banner on stdout at communicator creation
+                    self.map.comm_init(uid, halo_cap)
 
     def update(self, depth, cloud, pos, q, moves=None, remove_tracks=None, on_device=True):
         if not self.sharded:

@@ -310,3 +310,27 @@ def test_native_rccl_single_rank_long_lists():
     assert a.stats()["n_moved"] == b.stats()["n_moved"] > 0
     a.close()
     b.close()
+
+
+def test_native_ipc_single_rank():
+    """sdm_ipc_create + sdm_ipc_connect + sdm_update_sharded with one shard: every exchange kernel is issued (member counts,
+    export segments, ck parts, summed ck chunks) and the result is the plain frame's."""
+    cfg, params, frames = synth.make_frames("T0", 5, "vkitti2", n_dynamic=2)
+    noise = synth.noise_table()
+    a = binding.SdmMap(cfg, params, noise)
+    b = binding.SdmMap(cfg, params, noise)
+    b.ipc_connect(b.ipc_create(1024))
+    b.comm_timing(True)
+    for depth, cloud, pos, q, moves in frames:
+        a.update(depth, cloud, pos, q, moves, sync=True)
+        b.update_sharded(depth, cloud, pos, q, moves)
+        b.synchronize()
+        ct = b.comm_times()
+        assert ct["ck_alltoall"] > 0 and ct["ck_allgather"] > 0
+        assert (ct["counts_allgather"] > 0) == (len(moves) > 0) == (ct["halo_alltoall"] > 0)
+    sa, sb = a.dump_state(), b.dump_state()
+    for k in pu.STATE_KEYS:
+        assert pu.diff_report(k, sa[k], sb[k]) is None
+    assert np.array_equal(a.voxels(), b.voxels())
+    a.close()
+    b.close()

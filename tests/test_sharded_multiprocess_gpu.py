@@ -69,8 +69,21 @@ def worker(rank, world, port, spec, results):
         from semantic_dsp_map_amd import sharded, synth
         cfg, params, scene = scene_and_params(spec)
         noise = synth.noise_table()
-        eng = sharded.GlooShardEngine(cfg, params, rank, world, device=0, noise_table=noise)
-        drv = sharded.ShardedDriver(eng, rank, world, dist, ck_exchange=spec.get("ck_exchange", "chunks"))
+        native = spec.get("engine") == "native_ipc"
+        if native:
+            # sdm_update_sharded itself, its exchanges through the peers' arenas (hipIpc): gloo only hands the handles round
+            eng = sharded.NativeShardedMap(cfg, params, rank, world, 0, dist=dist, noise_table=noise, halo_cap=1024, exchange="ipc")
+            eng.map.comm_set_options(-1, 20000)
+
+            class _Drv:
+                def update(self, depth, cloud, pos, q, moves):
+                    eng.update(depth, cloud, pos, q, moves, on_device=False)
+            drv = _Drv()
+            eng.bytes_exchanged = {}
+            eng.close = eng.map.close
+        else:
+            eng = sharded.GlooShardEngine(cfg, params, rank, world, device=0, noise_table=noise)
+            drv = sharded.ShardedDriver(eng, rank, world, dist, ck_exchange=spec.get("ck_exchange", "chunks"))
         if spec.get("prefill"):
             st, ring, _ = synth.prefill_state(cfg, scene, spec["prefill"] // world, shard_rank=rank, shard_count=world)
             eng.map.load_state(st)
@@ -176,6 +189,8 @@ def run(world, spec, reference):
             assert got.keys() == want.keys()
             bad += ["frame %d shard %d %s" % (t, r, k) for k in want if got[k] != want[k]]
     assert not bad, "%d digests differ, first: %s" % (len(bad), bad[:12])
+    if spec.get("engine") == "native_ipc":
+        return {"live_particles": sum(r[3] for r in res.values())}
     frames = res[0][2]["frames"]
     ex = {k: max(r[2][k] for r in res.values()) // frames for k in ("counts", "halo", "ck_alltoall", "ck_allgather")}
     ex["halo_records_exported_in_all"] = sum(r[2]["halo_records"] for r in res.values())
@@ -236,3 +251,17 @@ def test_eight_process_real_engine_gloo_C5():
     ex = run(8, spec, reference_in_process)
     assert ex["halo_records_exported_in_all"] > 0 and ex["live_particles"] >= 14000000, ex
     assert ex["received_per_shard_and_frame"] <= 4 * 1000 * 1000, ex
+
+
+def test_two_and_four_process_native_frame_with_ipc_exchange():
+    """sdm_update_sharded with its exchanges through peer-mapped arenas (sdm_ipc_create / sdm_ipc_connect: one small kernel
+    per exchange, no RCCL), one process per shard on GPU 0, against the oracle - moving objects cross the slab borders."""
+    for world in (2, 4):
+        ex = run(world, dict(cfg="T0", params="vkitti2", n_frames=8, scene_kw=dict(n_dynamic=3, dyn_speed=(0.8, 1.6)), engine="native_ipc"),
+                 reference_oracle)
+        assert ex["live_particles"] > 0
+
+
+def test_two_process_native_frame_with_ipc_exchange_C3():
+    """the same at C3 size (256^3, 8 slots, 1242x375), six dynamic objects, from an empty map"""
+    run(2, dict(cfg="C3", params="vkitti2", n_frames=5, scene_kw=dict(n_static=48, n_dynamic=6, seed=7), engine="native_ipc"), reference_oracle)
