@@ -102,7 +102,34 @@ struct IpcXchg {
   uint32_t halo_cap;           // != 0: the piece is an export segment - its header and the records it counts travel, not its capacity
   int copy_own;                // the piece for this shard itself is copied too (all-gather kinds)
   unsigned long long timeout_ticks;  // of the 100 MHz wall clock
+  // != nullptr: what arrived from shard p is copied on into ordinary device memory, local + p * dst_stride.  The arena is
+  // fine-grained memory - peers write it while this GPU reads it, so it is not cached - and a kernel that reads a piece
+  // many times (the count rows in k_move_apply) wants it cached.
+  unsigned char *local;
 };
+__device__ __forceinline__ void ipc_copy(unsigned char *dst, const unsigned char *src, uint32_t n, uint32_t t, uint32_t nt) {
+  if (((uintptr_t)src | (uintptr_t)dst) % 16 == 0) {
+    const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d16 = reinterpret_cast<uint4 *>(dst);
+    for (uint32_t i = t; i < n / 16; i += nt) d16[i] = s16[i];
+    for (uint32_t i = (n / 16) * 4 + t; i < n / 4; i += nt) reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+  } else {
+    for (uint32_t i = t; i < n / 4; i += nt) reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+  }
+}
+// wait until *flag has reached seq (a peer's release store); false: timed out
+__device__ __forceinline__ bool ipc_wait(const uint32_t *flag, uint32_t seq, unsigned long long timeout_ticks) {
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    const uint32_t v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int32_t)(v - seq) >= 0) return true;
+    if (wall_clock64() - t0 > timeout_ticks) return false;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+__device__ __forceinline__ uint32_t *ipc_flag(unsigned char *arena, uint32_t kind, int shard) {
+  return reinterpret_cast<uint32_t *>(arena + ((size_t)kind * IPC_MAX_SHARDS + shard) * IPC_FLAG_STRIDE);
+}
 __global__ __launch_bounds__(1024) void k_ipc_exchange(const IpcXchg a) {
   const int p = blockIdx.x;
   const unsigned char *src = a.src + (size_t)p * a.src_stride;
@@ -113,35 +140,110 @@ __global__ __launch_bounds__(1024) void k_ipc_exchange(const IpcXchg a) {
     c = c < a.halo_cap ? c : a.halo_cap;
     n = sdm::HALO_HEADER_BYTES + c * sdm::HALO_RECORD_BYTES;
   }
-  if (dst != src && (p != a.rank || a.copy_own)) {
-    if (((uintptr_t)src | (uintptr_t)dst) % 16 == 0) {
-      const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
-      uint4 *d16 = reinterpret_cast<uint4 *>(dst);
-      for (uint32_t i = threadIdx.x; i < n / 16; i += blockDim.x) d16[i] = s16[i];
-      for (uint32_t i = (n / 16) * 4 + threadIdx.x; i < n / 4; i += blockDim.x)
-        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
-    } else {
-      for (uint32_t i = threadIdx.x; i < n / 4; i += blockDim.x)
-        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
-    }
+  if (dst != src && (p != a.rank || a.copy_own)) ipc_copy(dst, src, n, threadIdx.x, blockDim.x);
+  // The workgroup's stores are ordered before the flag by the barrier and ONE system-scope release (thread 0's store below).
+  // (A __threadfence_system() in every thread is a write-back of the whole L2 per wave: the first version of k_ipc_ck spent
+  // 40 of its 49 us in them.)
+  __syncthreads();
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(ipc_flag(a.arena[p], a.kind, a.rank), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    ok = ipc_wait(ipc_flag(a.arena[a.rank], a.kind, p), a.seq, a.timeout_ticks) ? 1 : 0;
+    if (!ok) *reinterpret_cast<uint32_t *>(a.arena[a.rank] + IPC_OFF_ERR) = a.kind + 1u;
   }
-  __threadfence_system();  // this thread's stores are visible to the peer before the flag can be
+  __syncthreads();
+  if (a.local && ok)
+    ipc_copy(a.local + (size_t)p * a.dst_stride, a.arena[a.rank] + a.dst_off + (size_t)p * a.dst_stride, a.piece_bytes, threadIdx.x, blockDim.x);
+}
+
+// The whole exchange of the partial ck images in ONE launch (chunk-owner reduction): the parts of every
+// shard's chunk go to its owner, the owner adds them in slab order - the float sums a single map split into the same slabs
+// forms - and the summed chunk goes to every shard.  With a collective library that is all-to-all, a kernel, all-gather:
+// three launches and two hand-shakes on the frame's critical path.  Here: `world` x split workgroups,
+//   A  workgroup (p, q) writes share q of this shard's part of chunk p into p's arena; the last of p's workgroups raises the flag;
+//   B  it waits for p's flag in the own arena; a barrier over the launch's workgroups: all parts of the own chunk are here;
+//   C  the own chunk is summed (every workgroup a stretch of it) and written into every peer's arena and the local image;
+//      barrier; the flags of the second round go up;
+//   D  workgroup (p, q) waits for p's second flag and copies share q of p's summed chunk from the arena (uncached) into
+//      the local image (ordinary device memory), which the weight update reads.
+// The launch's workgroups are resident together (64 of them), so the barrier is an atomic counter.
+struct IpcCk {
+  int split;           // workgroups per peer: 64 / world of them, at least 4 (one shard alone sums the whole image: 64 workgroups)
+  unsigned char *arena[IPC_MAX_SHARDS];
+  int world, rank;
+  uint32_t seq;        // of kind IPC_CK_PARTS; the second round's flags are kind IPC_CK_FULL with the same number
+  uint32_t chunk;      // floats per chunk
+  size_t off_stage, off_full;
+  const float *part;   // this shard's partial image, world chunks
+  float *local_full;   // the summed image, world chunks (ordinary device memory)
+  uint32_t *sync;      // [0..15] arrivals per peer (round A), [16] / [17] barrier counters (never reset: they count launches)
+  unsigned long long timeout_ticks;
+};
+__device__ __forceinline__ void ipc_grid_barrier(uint32_t *counter, uint32_t target, unsigned long long timeout_ticks, bool system_release) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t *theirs = reinterpret_cast<uint32_t *>(a.arena[p] + ((size_t)a.kind * IPC_MAX_SHARDS + a.rank) * IPC_FLAG_STRIDE);
-    __hip_atomic_store(theirs, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    uint32_t *mine = reinterpret_cast<uint32_t *>(a.arena[a.rank] + ((size_t)a.kind * IPC_MAX_SHARDS + p) * IPC_FLAG_STRIDE);
+    if (system_release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // the workgroup's stores into the peers' arenas, before anybody raises a flag
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long t0 = wall_clock64();
-    for (;;) {
-      const uint32_t v = __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-      if ((int32_t)(v - a.seq) >= 0) break;
-      if (wall_clock64() - t0 > a.timeout_ticks) {
-        *reinterpret_cast<uint32_t *>(a.arena[a.rank] + IPC_OFF_ERR) = a.kind + 1u;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(32);
+    while ((int32_t)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      if (wall_clock64() - t0 > timeout_ticks) break;
+      __builtin_amdgcn_s_sleep(8);
     }
   }
+  __syncthreads();
+}
+__global__ __launch_bounds__(1024) void k_ipc_ck(const IpcCk a) {
+  const int SPLIT = a.split;
+  const int p = blockIdx.x / SPLIT, q = blockIdx.x % SPLIT;
+  const uint32_t nb = gridDim.x, C = a.chunk;
+  const uint32_t share = (C / SPLIT + 3) / 4 * 4;  // floats per share (whole 16-byte pieces; the last share takes the rest)
+  const uint32_t s0 = q * share < C ? q * share : C, s1 = (q + 1 == SPLIT || (q + 1) * share > C) ? C : (q + 1) * share;
+  unsigned char *mine = a.arena[a.rank];
+  __shared__ int ok;
+  // ---- A: this shard's part of chunk p -> shard p
+  if (p != a.rank)
+    ipc_copy(a.arena[p] + a.off_stage + ((size_t)a.rank * C + s0) * 4, reinterpret_cast<const unsigned char *>(a.part + (size_t)p * C + s0),
+             (s1 - s0) * 4, threadIdx.x, blockDim.x);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ok = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (system scope: this workgroup's share, before the arrival count and the flag)
+    const uint32_t arrived = __hip_atomic_fetch_add(a.sync + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived % (uint32_t)SPLIT == (uint32_t)SPLIT - 1u)  // the last of p's workgroups: every share is on its way
+      __hip_atomic_store(ipc_flag(a.arena[p], IPC_CK_PARTS, a.rank), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- B: shard p's part of the own chunk
+    if (!ipc_wait(ipc_flag(mine, IPC_CK_PARTS, p), a.seq, a.timeout_ticks)) {
+      *reinterpret_cast<uint32_t *>(mine + IPC_OFF_ERR) = IPC_CK_PARTS + 1u;
+      ok = 0;
+    }
+  }
+  ipc_grid_barrier(a.sync + 16, a.seq * nb, a.timeout_ticks, false);
+  // ---- C: the own chunk, summed in slab order, to everybody
+  {
+    const float *stage = reinterpret_cast<const float *>(mine + a.off_stage);
+    const float *own = a.part + (size_t)a.rank * C;
+    float *lf = a.local_full + (size_t)a.rank * C;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += nb * blockDim.x) {
+      float ck = 0.f;
+      for (int g = 0; g < a.world; ++g) ck += g == a.rank ? own[i] : stage[(size_t)g * C + i];
+      lf[i] = ck;
+      for (int g = 0; g < a.world; ++g)
+        if (g != a.rank) reinterpret_cast<float *>(a.arena[g] + a.off_full)[(size_t)a.rank * C + i] = ck;
+    }
+  }
+  ipc_grid_barrier(a.sync + 17, a.seq * nb, a.timeout_ticks, true);
+  if (threadIdx.x == 0) {
+    if (q == 0) __hip_atomic_store(ipc_flag(a.arena[p], IPC_CK_FULL, a.rank), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- D: shard p's summed chunk
+    if (!ipc_wait(ipc_flag(mine, IPC_CK_FULL, p), a.seq, a.timeout_ticks)) {
+      *reinterpret_cast<uint32_t *>(mine + IPC_OFF_ERR) = IPC_CK_FULL + 1u;
+      ok = 0;
+    }
+  }
+  __syncthreads();
+  if (p != a.rank && ok)
+    ipc_copy(reinterpret_cast<unsigned char *>(a.local_full + (size_t)p * C + s0), mine + a.off_full + ((size_t)p * C + s0) * 4, (s1 - s0) * 4,
+             threadIdx.x, blockDim.x);
 }
 
 void set_error(const char *what, const char *file, int line, const char *detail) {
@@ -218,6 +320,9 @@ struct sdm_map {
   uint32_t ipc_seq[4] = {0, 0, 0, 0};  // exchanges issued so far, per kind: the value the flags of the next one carry
   size_t ipc_off_counts = 0, ipc_off_halo = 0, ipc_off_stage = 0, ipc_off_full = 0, ipc_bytes = 0;
   int ipc_fine_grained = 0;
+  float *d_ck_full_local = nullptr;      // the summed ck image in ordinary device memory (k_ipc_ck writes it, the weight update reads it)
+  int32_t *d_counts_all_local = nullptr; // the gathered count rows, likewise
+  uint32_t *d_ipc_sync = nullptr;        // k_ipc_ck's arrival and barrier counters
   int32_t *d_counts_all = nullptr;
   unsigned char *d_halo_send = nullptr, *d_halo_recv = nullptr;
   float *d_ck_stage = nullptr, *d_ck_full = nullptr;  // chunk-owner exchange of the partial ck images (sdm_update_sharded)
@@ -1117,7 +1222,8 @@ sdm_status sdm_destroy(sdm_map *m) {
     for (int p = 0; p < m->cfg.shard_count && p < 16; ++p)
       if (m->ipc_peer[p] && m->ipc_peer[p] != m->ipc_arena) (void)hipIpcCloseMemHandle(m->ipc_peer[p]);
     (void)hipFree(m->ipc_arena);
-    if (m->d_halo_send) (void)hipFree(m->d_halo_send);
+    for (void *p : {(void *)m->d_halo_send, (void *)m->d_counts_all_local, (void *)m->d_ck_full_local, (void *)m->d_ipc_sync})
+      if (p) (void)hipFree(p);
   } else {
     void *comm_bufs[] = {m->d_counts_all, m->d_halo_send, m->d_halo_recv, m->d_ck_stage, m->d_ck_full, m->d_ck_all};
     for (void *p : comm_bufs)
@@ -2246,9 +2352,18 @@ sdm_status sdm_ipc_create(sdm_map *m, int32_t halo_cap_records, uint8_t handle_o
     HIP_TRY(hipIpcGetMemHandle(&h, p));
   }
   m->ipc_arena = (unsigned char *)p;
+  if (getenv("SDM_IPC_VERBOSE"))
+    fprintf(stderr, "sdm_ipc_create: shard %d of %d, arena %zu bytes, %s device memory\n", m->cfg.shard_rank, world, m->ipc_bytes,
+            m->ipc_fine_grained ? "fine-grained" : "coarse-grained");
   HIP_TRY(hipMemsetAsync(p, 0, m->ipc_bytes, m->stream));
   // the frame's exchange buffers are regions of the arena; the export segments stay local (pushed by the exchange kernel)
-  m->d_counts_all = (int32_t *)(m->ipc_arena + m->ipc_off_counts);
+  HIP_TRY(dev_alloc(&m->d_counts_all_local, (size_t)world * HALO_OBJ));
+  HIP_TRY(dev_alloc(&m->d_ck_full_local, (size_t)world * m->ck_chunk));
+  HIP_TRY(dev_alloc(&m->d_ipc_sync, 32));
+  HIP_TRY(hipMemsetAsync(m->d_counts_all_local, 0, (size_t)world * HALO_OBJ * 4, m->stream));
+  HIP_TRY(hipMemsetAsync(m->d_ck_full_local, 0, (size_t)world * m->ck_chunk * 4, m->stream));
+  HIP_TRY(hipMemsetAsync(m->d_ipc_sync, 0, 32 * 4, m->stream));
+  m->d_counts_all = m->d_counts_all_local;  // (k_move_apply reads the rows from there: the exchange copies them on)
   m->d_halo_recv = m->ipc_arena + m->ipc_off_halo;
   m->d_ck_stage = (float *)(m->ipc_arena + m->ipc_off_stage);
   m->d_ck_full = (float *)(m->ipc_arena + m->ipc_off_full);
@@ -2337,7 +2452,7 @@ sdm_status sdm_get_comm_times(sdm_map *m, double out_us[4]) {
 namespace {
 // one exchange through the peers' arenas (k_ipc_exchange): kind, where this shard's pieces lie, where they land
 sdm_status ipc_exchange(sdm_map *m, uint32_t kind, const void *src, size_t src_stride, size_t dst_off, size_t dst_stride, size_t piece_bytes,
-                        uint32_t halo_cap, bool copy_own, hipStream_t s) {
+                        uint32_t halo_cap, bool copy_own, hipStream_t s, void *local = nullptr) {
   IpcXchg a;
   memset(&a, 0, sizeof(a));
   const int world = m->cfg.shard_count;
@@ -2353,6 +2468,7 @@ sdm_status ipc_exchange(sdm_map *m, uint32_t kind, const void *src, size_t src_s
   a.piece_bytes = (uint32_t)piece_bytes;
   a.halo_cap = halo_cap;
   a.copy_own = copy_own ? 1 : 0;
+  a.local = (unsigned char *)local;
   a.timeout_ticks = (unsigned long long)m->comm_timeout_ms * 100000ull;
   hipLaunchKernelGGL(k_ipc_exchange, dim3((unsigned)world), dim3(1024), 0, s, a);
   HIP_TRY(hipGetLastError());
@@ -2360,7 +2476,9 @@ sdm_status ipc_exchange(sdm_map *m, uint32_t kind, const void *src, size_t src_s
 }
 // the count rows of all shards (all-gather), on stream s
 sdm_status exchange_counts(sdm_map *m, hipStream_t s) {
-  if (m->ipc) return ipc_exchange(m, IPC_COUNTS, m->d_counts_local, 0, m->ipc_off_counts, HALO_OBJ * sizeof(int32_t), HALO_OBJ * sizeof(int32_t), 0, true, s);
+  if (m->ipc)
+    return ipc_exchange(m, IPC_COUNTS, m->d_counts_local, 0, m->ipc_off_counts, HALO_OBJ * sizeof(int32_t), HALO_OBJ * sizeof(int32_t), 0, true, s,
+                        m->d_counts_all_local);
   NCCL_TRY(ncclAllGather(m->d_counts_local, m->d_counts_all, HALO_OBJ, ncclInt32, m->comm, s));
   return SDM_OK;
 }
@@ -2442,22 +2560,36 @@ sdm_status sdm_update_sharded(sdm_map *m, const float *depth, const sdm_labeled_
     m->ck_part_stride = padded;
     return sdm_update_finish(m, m->d_ck_all, world, flags, 0);
   }
+  if (m->ipc) {  // parts to their owners, slab-ordered sum, summed chunks to everybody: one launch (k_ipc_ck)
+    {
+      CommTimer t(m, 2, m->stream);
+      IpcCk a;
+      memset(&a, 0, sizeof(a));
+      for (int p = 0; p < world; ++p) a.arena[p] = (unsigned char *)m->ipc_peer[p];
+      a.world = world;
+      a.rank = rank;
+      a.seq = ++m->ipc_seq[IPC_CK_PARTS];
+      a.chunk = m->ck_chunk;
+      a.split = std::max(4, 64 / world);
+      a.off_stage = m->ipc_off_stage;
+      a.off_full = m->ipc_off_full;
+      a.part = part;
+      a.local_full = m->d_ck_full_local;
+      a.sync = m->d_ipc_sync;
+      a.timeout_ticks = (unsigned long long)m->comm_timeout_ms * 100000ull;
+      hipLaunchKernelGGL(k_ipc_ck, dim3((unsigned)(world * a.split)), dim3(1024), 0, m->stream, a);
+      HIP_TRY(hipGetLastError());
+    }
+    return sdm_update_finish(m, m->d_ck_full_local, 1, flags, 0);
+  }
   {
     CommTimer t(m, 2, m->stream);
-    const size_t cb = (size_t)m->ck_chunk * 4;
-    rc = m->ipc ? ipc_exchange(m, IPC_CK_PARTS, part, cb, m->ipc_off_stage, cb, cb, 0, false, m->stream)
-                : all_to_all(m, part, m->d_ck_stage, cb, m->stream);
-    if (rc != SDM_OK) return rc;
+    if ((rc = all_to_all(m, part, m->d_ck_stage, (size_t)m->ck_chunk * 4, m->stream)) != SDM_OK) return rc;
   }
   launch_ck_reduce_chunk(m->d_ck_stage, part, m->d_ck_full, m->ck_chunk, world, rank, m->stream);
   {
     CommTimer t(m, 3, m->stream);
-    if (m->ipc) {  // this shard's summed chunk (it lies in its own arena already) into every peer's
-      const size_t cb = (size_t)m->ck_chunk * 4;
-      if ((rc = ipc_exchange(m, IPC_CK_FULL, m->d_ck_full + (size_t)rank * m->ck_chunk, 0, m->ipc_off_full, cb, cb, 0, true, m->stream)) != SDM_OK) return rc;
-    } else {
-      NCCL_TRY(ncclAllGather(m->d_ck_full + (size_t)rank * m->ck_chunk, m->d_ck_full, m->ck_chunk, ncclFloat32, m->comm, m->stream));
-    }
+    NCCL_TRY(ncclAllGather(m->d_ck_full + (size_t)rank * m->ck_chunk, m->d_ck_full, m->ck_chunk, ncclFloat32, m->comm, m->stream));
   }
   return sdm_update_finish(m, m->d_ck_full, 1, flags, 0);
 }

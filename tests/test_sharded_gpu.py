@@ -326,7 +326,7 @@ def test_native_ipc_single_rank():
         b.update_sharded(depth, cloud, pos, q, moves)
         b.synchronize()
         ct = b.comm_times()
-        assert ct["ck_alltoall"] > 0 and ct["ck_allgather"] > 0
+        assert ct["ck_alltoall"] > 0 and ct["ck_allgather"] == 0   # (the whole ck exchange is one launch, timed in the first slot)
         assert (ct["counts_allgather"] > 0) == (len(moves) > 0) == (ct["halo_alltoall"] > 0)
     sa, sb = a.dump_state(), b.dump_state()
     for k in pu.STATE_KEYS:
