@@ -271,7 +271,8 @@ def test_hip_path_against_the_literal_reference_order(cfg_name, params_name, n_f
 def test_literal_reference_order_on_the_benchmark_workloads(name, params_name, n_particles, n_warm, n_frames, scene_kw):
     """The same bar on the workloads the numbers of bench.py are quoted on (the bit-exact tests hold them in canonical
     order only): free-running against the literal-order oracle, identical integers in the particle state and the
-    voxel results, probabilities within 1e-4, frame after frame."""
+    voxel results, probabilities within 1e-4, frame after frame.  (The workload nothing is prefilled for - bench.py's
+    `driven` - is held to the literal order by tests/test_driven_gpu.py, which runs the oracle beside the GPU from frame 0.)"""
     cfg = synth.CONFIGS["C3"]
     params = synth.PARAMS[params_name]
     scene = synth.Scene(cfg, **scene_kw)
@@ -289,12 +290,17 @@ def test_literal_reference_order_on_the_benchmark_workloads(name, params_name, n
         moves = scene.moves(t)
         o.update(depth, cloud, pos, q, moves)
         g.update(depth, cloud, pos, q, moves, sync=True)
-        so, sg = o.dump_state(), g.dump_state()
-        for k in ("status", "ts", "track", "label", "forget", "owner"):
-            assert np.array_equal(so[k], sg[k]), "%s frame %d: %s differs from the literal-order oracle" % (name, t, k)
-        live = so["status"] != 0
-        for k in ("w", "px", "py", "pz"):
-            assert np.max(np.abs(so[k][live] - sg[k][live]), initial=0.0) <= 1e-4, "%s frame %d: %s" % (name, t, k)
+        # every field of every slot (134 M of them: seconds per comparison) in the frames the numbers are quoted on, in every
+        # fourth frame before them and in the last one; the voxel results in every frame - both sides run free, so what
+        # parted in a frame that was not dumped is still apart in the next one that is
+        if t >= n_warm + n_frames - 3 or t % 4 == 3:
+            so, sg = o.dump_state(), g.dump_state()
+            for k in ("status", "ts", "track", "label", "forget", "owner"):
+                assert np.array_equal(so[k], sg[k]), "%s frame %d: %s differs from the literal-order oracle" % (name, t, k)
+            live = so["status"] != 0
+            for k in ("w", "px", "py", "pz"):
+                assert np.max(np.abs(so[k][live] - sg[k][live]), initial=0.0) <= 1e-4, "%s frame %d: %s" % (name, t, k)
+            del so, sg
         vo, vg = o.voxels(), g.voxels()
         for k in ("occ", "label", "track"):
             assert np.array_equal(vo[k], vg[k]), "%s frame %d: voxels.%s differs from the literal-order oracle" % (name, t, k)
@@ -302,46 +308,4 @@ def test_literal_reference_order_on_the_benchmark_workloads(name, params_name, n
         assert o.stats()["n_visible"] == g.stats()["n_visible"]
         n_vis.append(g.stats()["n_visible"])
     assert (min(n_vis[n_warm:]) > 40000) if n_warm else (max(n_vis) > 15000), n_vis  # (the benchmark state's first frame sees births only)
-    g.close()
-
-
-def test_literal_reference_order_on_the_grown_map():
-    """bench.py's third workload - a map whose population the filter grew itself from empty (180 frames of 100 static + 8
-    moving boxes, three noisy births per point, ego motion with yaw and sideways drift) - held to the oracle's LITERAL
-    order like the other two: the map is grown on the GPU, its state handed to the oracle, then both run the 5 frames
-    bench.py starts its timed region with, free-running: identical integers in the particle state and the voxel
-    results, probabilities within 1e-4, frame after frame."""
-    cfg = synth.CONFIGS["C3"]
-    params = synth.PARAMS["vkitti2_nb3"]
-    scene_kw = dict(n_static=100, n_dynamic=8, seed=13, yaw_rate_deg=1.0, lateral_extra=(0, 0.03))
-    n_grow, n_frames = 180, 5
-    scene = synth.Scene(cfg, **scene_kw)
-    rendered = synth.render_frames(cfg, params, scene_kw, range(n_grow + n_frames))
-    o, g = pu.make_pair(cfg, params, synth.noise_table(), bin_order=0)
-    for t in range(n_grow):
-        depth, cloud, pos, q = rendered[t]
-        g.update(depth, cloud, pos, q, scene.moves(t))
-    g.synchronize()
-    o.load_state(g.dump_state())
-    o.set_stamps(*g.stamps())
-    o.set_ring_state(g.ring_state())
-    n_vis = []
-    for t in range(n_grow, n_grow + n_frames):
-        depth, cloud, pos, q = rendered[t]
-        moves = scene.moves(t)
-        o.update(depth, cloud, pos, q, moves)
-        g.update(depth, cloud, pos, q, moves, sync=True)
-        so, sg = o.dump_state(), g.dump_state()
-        for k in ("status", "ts", "track", "label", "forget", "owner"):
-            assert np.array_equal(so[k], sg[k]), "grown map, frame %d: %s differs from the literal-order oracle" % (t, k)
-        live = so["status"] != 0
-        for k in ("w", "px", "py", "pz"):
-            assert np.max(np.abs(so[k][live] - sg[k][live]), initial=0.0) <= 1e-4, "grown map, frame %d: %s" % (t, k)
-        vo, vg = o.voxels(), g.voxels()
-        for k in ("occ", "label", "track"):
-            assert np.array_equal(vo[k], vg[k]), "grown map, frame %d: voxels.%s differs from the literal-order oracle" % (t, k)
-        assert np.max(np.abs(vo["wsum"] - vg["wsum"])) <= 1e-4
-        assert o.stats()["n_visible"] == g.stats()["n_visible"]
-        n_vis.append(g.stats()["n_visible"])
-    assert min(n_vis) > 50000, n_vis  # (bench.py reports ~80 k visible particles per frame on this leg)
     g.close()
