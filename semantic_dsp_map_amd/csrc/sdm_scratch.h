@@ -157,7 +157,10 @@ struct MembersArgs {
   size_t n_slots;
 };
 struct FrameBeginLaunch {
-  static constexpr unsigned GRID = 512, BLOCK = 256;
+#ifndef SDM_FB_GRID
+#define SDM_FB_GRID 1024  // (round 6: 512 -> 1024 workgroups halve the chunks a workgroup of the member count ranks one after the other: driven -3.7 us, headline -1 us, tools/gpu_driven_ab.sh)
+#endif
+  static constexpr unsigned GRID = SDM_FB_GRID, BLOCK = 256;
   Counters *cnt;
   uint32_t *bin_count;
   uint32_t n_bins;

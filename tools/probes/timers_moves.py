@@ -34,6 +34,19 @@ def main():
         r = mv[1][:1024]
         ran = (r[:, 0] > 0) & (r[:, 2] > 0)
         span = (r[ran, 2].max() - r[ran, 0].min()) / 100.0 if ran.any() else 0.0
+        fb, mm = mv[3], mv[2]
+        ranf = (fb[:, 0] > 0) & (mm[:, 3] > 0)
+        if ranf.any():
+            t0 = fb[ranf, 0].min()
+            print("   k_frame_begin: starts spread %.1f us | zeroing + slab marks done (avg) %.1f | chunk lists built (avg) %.1f, slowest %.1f | end avg %.1f, last %.1f us after the first start"
+                  % ((fb[ranf, 0].max() - t0) / 100.0, (fb[ranf, 1] - t0).mean() / 100.0, (mm[ranf, 1] - t0).mean() / 100.0, (mm[ranf, 1] - t0).max() / 100.0,
+                     (mm[ranf, 3] - t0).mean() / 100.0, (mm[ranf, 3] - t0).max() / 100.0))
+        a = mv[0]
+        rana = (a[:, 0] > 0) & (a[:, 3] > 0)
+        if rana.any():
+            t0 = a[rana, 0].min()
+            print("   k_move_apply: workgroups with chunks %d | prefix done avg %.1f | first moves done avg %.1f | end avg %.1f, last %.1f us"
+                  % (rana.sum(), (a[rana, 1] - a[rana, 0]).mean() / 100.0, (a[rana, 2] - a[rana, 0]).mean() / 100.0, (a[rana, 3] - t0).mean() / 100.0, (a[rana, 3] - t0).max() / 100.0))
         st = m.stats()
         print("frame %d: replay span (thread 0 of the workgroups) %.1f us | slowest head: walk %.1f us, whole %.1f us | lists %d, longest %d, mean %.1f, most copies re-inserted by one head %d | moved %d re-inserted %d"
               % (t, span, s[0] / 100.0, s[1] / 100.0, s[4], s[2], s[3] / max(s[4], 1), s[5], st["n_moved"], st["n_move_reinserted"]))
