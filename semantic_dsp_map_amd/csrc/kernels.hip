@@ -202,6 +202,25 @@ template <int S>
 __device__ __forceinline__ void rec_store_status(unsigned char *r, const uint8_t (&stv)[S]) {
   __builtin_memcpy(r + 9 * (S - 1), &stv[1], S - 1);
 }
+// the whole record from per-slot arrays: packed into words, stored as 16-byte pieces and what is left - exactly 10 (S - 1)
+// bytes, nothing of the next record is touched
+template <int S>
+__device__ __forceinline__ void rec_store_all(unsigned char *r, const float (&wv)[S], const uint16_t (&ts)[S], const uint16_t (&trk)[S],
+                                              const uint8_t (&lab)[S], const uint8_t (&stv)[S]) {
+  constexpr int L = S - 1, NW = (10 * L + 3) / 4;
+  uint32_t d[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) d[i] = 0;
+#pragma unroll
+  for (int k = 0; k < L; ++k) {
+    d[k] = __float_as_uint(wv[k + 1]);
+    d[(4 * L + 2 * k) >> 2] |= (uint32_t)ts[k + 1] << (((4 * L + 2 * k) & 3) * 8);
+    d[(6 * L + 2 * k) >> 2] |= (uint32_t)trk[k + 1] << (((6 * L + 2 * k) & 3) * 8);
+    d[(8 * L + k) >> 2] |= (uint32_t)lab[k + 1] << (((8 * L + k) & 3) * 8);
+    d[(9 * L + k) >> 2] |= (uint32_t)stv[k + 1] << (((9 * L + k) & 3) * 8);
+  }
+  __builtin_memcpy(__builtin_assume_aligned(r, 2), d, 10 * L);
+}
 
 __device__ __forceinline__ uint32_t stamp_max(const State &st, uint32_t rx, uint32_t ry, uint32_t rz) {
   uint32_t a = st.stamps_x[rx], b = st.stamps_y[ry], c = st.stamps_z[rz];
@@ -2830,8 +2849,8 @@ __global__ void k_birth_cursor(Dims d, Filter flt, Scratch sc) {
 // insertions before it, they cost a store drain and a round trip in the middle of the replay.)
 template <int S>
 __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t base, uint8_t (&stv)[S], uint16_t (&own)[S],
-                                               uint32_t n_alias, bool touched, uint32_t fbits, const float (&wv)[S], const uint16_t (&trk)[S]) {
-  unsigned char *const rec = st.rec + base / S * rec_bytes(S);  // (base = lv * S)
+                                               uint32_t n_alias, bool touched, uint32_t fbits, float (&wv)[S], const uint16_t (&trk)[S]) {
+  // (on the register copy of the voxel: the caller stores the rows)
   float weight_sum = 0.f;
   uint32_t updated = 0;
 #pragma unroll
@@ -2847,7 +2866,6 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
     for (int i = 1; i < S; ++i)
       if (stv[i] == ST_UPDATED) {
         stv[i] = ST_INVALID;
-        SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_status(ST_INVALID);
         owner_erase_local(st, base + i, trk[i], own[i], n_alias, touched, fbits, i);  // removeParticleFromObj
       }
     return true;
@@ -2861,10 +2879,9 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
       run += wv[i];
       if (run < thr) {
         stv[i] = ST_INVALID;
-        SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_status(ST_INVALID);
         owner_erase_local(st, base + i, trk[i], own[i], n_alias, touched, fbits, i);
       } else {
-        SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_w(wpp);
+        wv[i] = wpp;
         thr += wpp;
         while (run > thr) thr += wpp;
       }
@@ -3096,12 +3113,16 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
   uint8_t stv[S];
   uint16_t tsv[S];
   unsigned char *const rec = rec_ptr(st, S, v - d.v_begin);
+  // The voxel's whole record, its forget counts and (below) its owner entries in one round.  The replay works on these
+  // register copies and stores every row ONCE at the end: stored field by field per insertion - seven stores and up to
+  // three for the owner set, up to fourteen insertions - a head ran into the 64 memory operations a wave may have in
+  // flight and waited for its own stores to retire, a microsecond per insertion (tools/probes/timers_moves.py measured it on the
+  // replay of the moved copies, which had the same shape).
   float wv0[S];
   uint16_t trk0[S];
-  {  // the whole record in one round: status and stamps, and the rows the one resampling of the voxel reads
-    uint8_t lab0[S];
-    rec_load<S>(rec, wv0, tsv, trk0, lab0, stv);
-  }
+  uint8_t lab0[S], fg[S];
+  rec_load<S>(rec, wv0, tsv, trk0, lab0, stv);
+  __builtin_memcpy(fg, st.forget + base, S);
   // the voxel's owner entries and the length of the table of older memberships (addParticleToObj / removeParticleFromObj),
   // and the rows the one resampling of the voxel reads: everything the replay needs of the voxel, in one round
   uint16_t own[S];
@@ -3179,6 +3200,7 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
     }
   }
   const uint32_t n_success = nA + nB;
+  bool any_owner = false;
 #ifdef SDM_TIMERS_BIRTH
   if (threadIdx.x == 0) DBG_PUT(1, DBG_T() + (n_success == 77u ? 1 : 0) + (n_resamp == 77u ? 1 : 0) + (stv[S - 1] == 0xEE ? 1 : 0));
 #endif
@@ -3208,17 +3230,22 @@ __global__ __launch_bounds__(TPB) void k_birth_replay(Dims d, Filter flt, State 
     const uint8_t label = (uint8_t)((tl >> 16) & 0xffu);
     // addNewParticleWithSemantics (operations.h:171-184)
     st.pos4[base + i] = make_float4(bp.x, bp.y, bp.z, 0.f);
-    st.forget[base + i] = 0;
-    const SlotRef sr{rec, S - 1, (uint32_t)i - 1u};
-    sr.set_w(SDM_OCC_INIT_WEIGHT);
-    sr.set_ts((uint16_t)f.gts);
-    sr.set_track(track);
-    sr.set_label(label);
-    sr.set_status(ST_REGULAR_BORN);
+    fg[i] = 0;
+    wv0[i] = SDM_OCC_INIT_WEIGHT;
+    tsv[i] = (uint16_t)f.gts;
+    trk0[i] = track;
+    lab0[i] = label;
+    stv[i] = ST_REGULAR_BORN;
     if ((int)track <= d.max_movable) {  // addParticleToObj
       if (!owner_insert_local(st, base + i, track, own[i], n_alias, alias_touched, fbits, i)) sc.cnt->overflow = 1;
-      flag_owner_chunk(st, base + i);
+      any_owner = true;
     }
+  }
+  if (n_success || n_resamp) {  // the voxel's rows, once
+    rec_store_all<S>(rec, wv0, tsv, trk0, lab0, stv);
+    __builtin_memcpy(st.owner + base, own, 2 * S);
+    if (n_success) __builtin_memcpy(st.forget + base, fg, S);
+    if (any_owner) flag_owner_chunk(st, base + 1);  // (a voxel's slots lie in one chunk)
   }
   if (threadIdx.x == 0) {
 #ifdef SDM_TIMERS_BIRTH

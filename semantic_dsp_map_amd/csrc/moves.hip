@@ -843,12 +843,31 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
     uint8_t stv[S];
     uint16_t tsv[S];
     unsigned char *const rec = rec_ptr(st, S, lv);
-    {  // status bytes (the record's last S - 1) and time stamps of the particle slots; entry 0 = the time particle, not looked at
+    // The voxel's whole record and its forget counts: the replay works on register copies of the voxel's rows and stores
+    // each row ONCE when the list is through.  (Until round 6 an insertion stored its ten fields one by one: a list of
+    // seventeen copies is 170 store instructions of a wave that may have 64 memory operations in flight - the head waited
+    // for its own stores to retire, a microsecond per insertion, 18 of the slowest head's 30 us on the `driven` workload,
+    // tools/probes/timers_moves.py.)
+    float wv[S];
+    uint16_t trk[S];
+    uint8_t lab[S], fg[S];
+    {
       stv[0] = ST_TIMEPTC;
       tsv[0] = 0;
-      __builtin_memcpy(&stv[1], rec + 9 * (S - 1), S - 1);
+      wv[0] = 0.f;
+      trk[0] = 0;
+      lab[0] = 0;
+      __builtin_memcpy(&wv[1], __builtin_assume_aligned(rec, 2), 4 * (S - 1));
       __builtin_memcpy(&tsv[1], rec + 4 * (S - 1), 2 * (S - 1));
+      __builtin_memcpy(&trk[1], rec + 6 * (S - 1), 2 * (S - 1));
+      __builtin_memcpy(&lab[1], rec + 8 * (S - 1), S - 1);
+      __builtin_memcpy(&stv[1], rec + 9 * (S - 1), S - 1);
+      __builtin_memcpy(fg, st.forget + base, S);
     }
+    float px[S], py[S], pz[S];  // positions of the slots written (touched)
+#pragma unroll
+    for (int i = 0; i < S; ++i) px[i] = py[i] = pz[i] = 0.f;
+    uint32_t touched = 0;
     // the voxel's owner entries and the length of the table of older memberships, with the rows above (owner_insert_local)
     uint16_t own[S];
     __builtin_memcpy(own, st.owner + base, 2 * S);
@@ -870,8 +889,6 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
 #pragma unroll
     for (int i = 1; i < S; ++i)
       if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) vac |= 1u << i;
-    int last_slot = -1;  // the slot the previous copy went into, and who owns it since
-    uint16_t last_owner = OWNER_NONE;
     // The list is walked ONCE - a chain of dependent loads, 0.6 us each - and its ranks are kept in LDS; every later batch
     // selects from there.  (Round 4 walked the list again for every batch of S-1: a voxel on the surface of an object that
     // has been tracked for a hundred frames receives dozens of copies of which many are vacant themselves - dead members of
@@ -879,7 +896,9 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
     // 250 us tail on the `driven` workload.)  A list longer than RP_KEEP is walked again for what LDS could not hold.
     uint32_t n_list = 0;
     bool first_pass = true;
+    [[maybe_unused]] unsigned long long dbg_sel = 0, dbg_fetch = 0, dbg_ins = 0;
     while (more && !full) {
+      [[maybe_unused]] const unsigned long long dbg_a = DBGM_T();
       uint32_t best[S - 1];  // the S-1 smallest ranks above `last`, ascending
 #pragma unroll
       for (int i = 0; i < S - 1; ++i) best[i] = MV_NIL;
@@ -922,6 +941,8 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
       // (the fetches above are to be under way together before the first insertion's stores: without the fence the compiler
       // sinks each fetch to the iteration that uses it - a dependent round trip per copy)
       __asm__ volatile("" ::: "memory");
+      [[maybe_unused]] const unsigned long long dbg_b = DBGM_T() + (best[0] == 0xEEEEEEEEu ? 1 : 0);
+      [[maybe_unused]] const unsigned long long dbg_c = DBGM_T() + (cc[0].voxel == 0xEEEEEEEEu ? 1 : 0) + (cc[S - 2].voxel == 0xEEEEEEEEu ? 1 : 0);
 #pragma unroll
       for (int u = 0; u < S - 1; ++u) {
         const uint32_t e = best[u];
@@ -936,36 +957,65 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
         if (e == t) c = c0;
         const uint8_t cs = c.status;
         const uint16_t cts = c.ts;
-        st.pos4[base + slot] = make_float4(c.x, c.y, c.z, 0.f);
-        st.forget[base + slot] = (uint8_t)c.forget_bits;
-        const SlotRef sr{rec, S - 1, (uint32_t)slot - 1u};
-        sr.set_w(c.w);
-        sr.set_ts(cts);
-        sr.set_track(c.track);
-        sr.set_label(c.label);
-        sr.set_status(cs);
-        {  // the new index joins the object's set
-          uint16_t o = last_owner;
-          if (slot != last_slot) {
+        uint16_t o = OWNER_NONE;
 #pragma unroll
-            for (int i = 1; i < S; ++i) o = i == slot ? own[i] : o;
-          }
-          if (!owner_insert_local(st, base + slot, c.owner, o, n_alias, alias_touched, fbits, slot)) sc.cnt->overflow = 1;
-          last_slot = slot;
-          last_owner = o;
+        for (int i = 1; i < S; ++i) o = i == slot ? own[i] : o;
+        // the new index joins the object's set
+        if (!owner_insert_local(st, base + slot, c.owner, o, n_alias, alias_touched, fbits, slot)) sc.cnt->overflow = 1;
+#pragma unroll
+        for (int i = 1; i < S; ++i) {  // the slot's row entries (registers: selects, no indexing)
+          const bool here = i == slot;
+          px[i] = here ? c.x : px[i];
+          py[i] = here ? c.y : py[i];
+          pz[i] = here ? c.z : pz[i];
+          fg[i] = here ? (uint8_t)c.forget_bits : fg[i];
+          wv[i] = here ? c.w : wv[i];
+          tsv[i] = here ? cts : tsv[i];
+          trk[i] = here ? c.track : trk[i];
+          lab[i] = here ? c.label : lab[i];
+          stv[i] = here ? cs : stv[i];
+          own[i] = here ? o : own[i];
         }
-        flag_owner_chunk(st, base + slot);
+        touched |= 1u << slot;
         // (a copy that is itself vacant - deleted before it was copied, or older than the slab's stamp - leaves the slot
         // to the next one)
         if (!(cs == ST_INVALID || (uint32_t)cts < smax)) vac &= ~(1u << slot);
         ++n_ok;
       }
+      [[maybe_unused]] const unsigned long long dbg_d = DBGM_T() + (n_ok == 0xEEEEu ? 1 : 0) + (vac == 0xEEEEEEEEu ? 1 : 0);
+      dbg_sel += dbg_b - dbg_a;
+      dbg_fetch += dbg_c - dbg_b;
+      dbg_ins += dbg_d - dbg_c;
     }
+    DBGM_MAX(6, dbg_sel);
+    DBGM_MAX(7, dbg_fetch);
+    DBGM_MAX(8, dbg_ins);
     DBGM(1, 2, DBGM_T());
     DBGM(1, 3, n_ok);
     DBGM_MAX(1, DBGM_T() - dbg_t0 + (n_ok == 0xEEEE ? 1 : 0));
     DBGM_MAX(5, n_ok);
-    if (n_ok) {
+    if (n_ok) {  // the voxel's rows, once
+      {
+        constexpr int L = S - 1, NW = (10 * L + 3) / 4;
+        uint32_t dw[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) dw[i] = 0;
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+          dw[k] = __float_as_uint(wv[k + 1]);
+          dw[(4 * L + 2 * k) >> 2] |= (uint32_t)tsv[k + 1] << (((4 * L + 2 * k) & 3) * 8);
+          dw[(6 * L + 2 * k) >> 2] |= (uint32_t)trk[k + 1] << (((6 * L + 2 * k) & 3) * 8);
+          dw[(8 * L + k) >> 2] |= (uint32_t)lab[k + 1] << (((8 * L + k) & 3) * 8);
+          dw[(9 * L + k) >> 2] |= (uint32_t)stv[k + 1] << (((9 * L + k) & 3) * 8);
+        }
+        __builtin_memcpy(__builtin_assume_aligned(rec, 2), dw, 10 * L);
+      }
+      __builtin_memcpy(st.owner + base, own, 2 * S);
+      __builtin_memcpy(st.forget + base, fg, S);
+#pragma unroll
+      for (int i = 1; i < S; ++i)
+        if ((touched >> i) & 1u) st.pos4[base + i] = make_float4(px[i], py[i], pz[i], 0.f);
+      flag_owner_chunk(st, base + 1);  // (a voxel's slots lie in one chunk)
       st.vflag[lv] = VF_DIRTY;
       mark_tile(st, lv, epoch);
       atomicAdd(&n_ok_block, n_ok);

@@ -330,7 +330,9 @@ __device__ __forceinline__ void owner_erase(const State &st, size_t li, uint16_t
 }
 
 // The same two for a kernel in which ONE thread owns all slots of a voxel (the ordered replays): `own` is the thread's
-// register copy of the slot's owner entry (loaded with the voxel's other rows), n_alias the table length read once at
+// register copy of the slot's owner entry (loaded with the voxel's other rows; the replay works on the register copy of the
+// whole voxel and stores its rows once, at the end - round 6: a replay that stored ten fields per insertion ran into the 64
+// memory operations a wave may have in flight, and its longest voxels paid a microsecond per insertion for it), n_alias the table length read once at
 // kernel start, touched = this thread has added an entry since.  Entries other threads add meanwhile concern other
 // voxels' slots and cannot match li, so the length read at the start serves until this thread adds one itself.  What the
 // generic versions load between the stores of one insertion and the next - the owner entry, the table length: two
@@ -353,8 +355,7 @@ __device__ __forceinline__ uint32_t alias_filter_bits(const State &st, size_t ba
 __device__ __forceinline__ bool owner_insert_local(const State &st, size_t li, uint16_t track, uint16_t &own, uint32_t n_alias,
                                                    bool &touched, uint32_t &fbits, int slot) {
   const uint16_t prev = own;
-  st.owner[li] = track;
-  own = track;
+  own = track;  // (the caller stores the voxel's owner row once, when its replay is through)
   if ((fbits >> slot) & 1u) {
     uint32_t n = touched ? st.alias[0] : n_alias;
     if (n > st.alias_cap) n = st.alias_cap;
@@ -374,8 +375,7 @@ __device__ __forceinline__ bool owner_insert_local(const State &st, size_t li, u
 __device__ __forceinline__ void owner_erase_local(const State &st, size_t li, uint16_t track, uint16_t &own, uint32_t n_alias,
                                                   bool touched, uint32_t fbits, int slot) {
   if (own == track) {
-    st.owner[li] = OWNER_NONE;
-    own = OWNER_NONE;
+    own = OWNER_NONE;  // (stored with the voxel's owner row by the caller)
     return;
   }
   if ((fbits >> slot) & 1u) {

@@ -48,8 +48,8 @@ def main():
             print("   k_move_apply: workgroups with chunks %d | prefix done avg %.1f | first moves done avg %.1f | end avg %.1f, last %.1f us"
                   % (rana.sum(), (a[rana, 1] - a[rana, 0]).mean() / 100.0, (a[rana, 2] - a[rana, 0]).mean() / 100.0, (a[rana, 3] - t0).mean() / 100.0, (a[rana, 3] - t0).max() / 100.0))
         st = m.stats()
-        print("frame %d: replay span (thread 0 of the workgroups) %.1f us | slowest head: walk %.1f us, whole %.1f us | lists %d, longest %d, mean %.1f, most copies re-inserted by one head %d | moved %d re-inserted %d"
-              % (t, span, s[0] / 100.0, s[1] / 100.0, s[4], s[2], s[3] / max(s[4], 1), s[5], st["n_moved"], st["n_move_reinserted"]))
+        print("frame %d: replay span (thread 0 of the workgroups) %.1f us | slowest head: walk %.1f us, whole %.1f us | lists %d, longest %d, mean %.1f, most copies re-inserted by one head %d | moved %d re-inserted %d | largest per-head sums: walk + selection %.1f us, waiting for the batches' copies %.1f, insertions %.1f"
+              % (t, span, s[0] / 100.0, s[1] / 100.0, s[4], s[2], s[3] / max(s[4], 1), s[5], st["n_moved"], st["n_move_reinserted"], s[6] / 100.0, s[7] / 100.0, s[8] / 100.0))
     m.close()
 
 
