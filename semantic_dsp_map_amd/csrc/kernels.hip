@@ -1833,10 +1833,10 @@ __device__ __forceinline__ void visibility_voxel(const Dims &d, const Frame &f, 
 #pragma unroll
   for (int i = 1; i < S; ++i)
     if (vis[i]) {
-      if (rq[i] < sc.row_cap && pib[i] < (1u << 21)) {
+      if (rq[i] < sc.row_cap && pib[i] < (1u << ROW_PIB_BITS)) {
         const uint32_t col = (uint32_t)(pixv[i] - rowv[i] * d.W);
         sc.row_list[(size_t)(rowv[i] * ROW_SUBS + sub) * sc.row_cap + rq[i]] =
-            make_uint2((uint32_t)(((size_t)v << d.p_n) + i), col | pib[i] << 11);
+            make_uint2((uint32_t)(((size_t)v << d.p_n) + i), col | pib[i] << ROW_COL_BITS);
       } else {
         sc.cnt->overflow = 1;
       }
@@ -2071,10 +2071,10 @@ __device__ __forceinline__ void ck_store(const Filter &flt, const Scratch &sc, f
 // thread: 2 up to 1280 columns, 4 beyond.
 constexpr int BR_TPB = 640;
 constexpr int BR_WAVES = BR_TPB / 64;
-constexpr int BR_MAXW = 2048;  // image width the row kernel's LDS holds (checked when the map is created)
+constexpr int BR_MAXW = 1 << ROW_COL_BITS;  // image width the row kernel's LDS holds and a row-list entry's column field takes (checked when the map is created)
 template <int PPT>
-__global__ __launch_bounds__(BR_TPB) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_bin_rows(Dims d, State st, Scratch sc) {
-  static_assert(PPT == 2 || PPT * BR_TPB >= BR_MAXW, "four pixels per thread cover the widest image");
+__global__ __launch_bounds__(BR_TPB) __attribute__((amdgpu_waves_per_eu(PPT <= 4 ? 5 : 4, PPT <= 4 ? 5 : 4))) void k_bin_rows(Dims d, State st, Scratch sc) {
+  static_assert(PPT == 2 || PPT == 4 || PPT * BR_TPB >= BR_MAXW, "eight pixels per thread cover the widest image");
   __shared__ uint32_t pre[BR_MAXW + 1];
   __shared__ uint32_t wave_tot[BR_WAVES];
   __shared__ uint32_t s_base;
@@ -2175,7 +2175,7 @@ __global__ __launch_bounds__(BR_TPB) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 #pragma unroll
     for (int k = 1; k < ROW_SUBS; ++k) sub += s_sub[k] <= g ? 1 : 0;
     const uint2 e = sc.row_list[(size_t)(r * ROW_SUBS + sub) * sc.row_cap + (g - s_sub[sub])];
-    sc.bin_idx[base + pre[e.y & 2047u] + (e.y >> 11)] = e.x;
+    sc.bin_idx[base + pre[e.y & (uint32_t)(BR_MAXW - 1)] + (e.y >> ROW_COL_BITS)] = e.x;
   }
   __syncthreads();  // (the bins were written by this workgroup: its own stores are visible to it behind the barrier)
   // ---- every pixel's bin: canonical order, gather
@@ -3818,7 +3818,8 @@ void launch_visibility(const Dims &d, const Filter &flt, const State &st, const 
   }
   // bins: one workgroup per image row lays the row's bins out, fills and orders them; then the pixels are classified for pass 1
   if (d.W <= 2 * BR_TPB) hipLaunchKernelGGL(k_bin_rows<2>, dim3((unsigned)d.H), dim3(BR_TPB), 0, s, d, st, sc);
-  else hipLaunchKernelGGL(k_bin_rows<4>, dim3((unsigned)d.H), dim3(BR_TPB), 0, s, d, st, sc);
+  else if (d.W <= 4 * BR_TPB) hipLaunchKernelGGL(k_bin_rows<4>, dim3((unsigned)d.H), dim3(BR_TPB), 0, s, d, st, sc);
+  else hipLaunchKernelGGL(k_bin_rows<8>, dim3((unsigned)d.H), dim3(BR_TPB), 0, s, d, st, sc);  // (up to 4095 columns: round 6)
   hipLaunchKernelGGL(k_ck_classify, dim3(blocks_for((size_t)d.W * d.H)), dim3(TPB), 0, s, d, flt, sc, ck_out, finish);
 }
 

@@ -733,7 +733,7 @@ sdm_status check_counters(sdm_map *m, Counters *out) {
   }
   if (c.overflow) {
     set_error("capacity", __FILE__, __LINE__, "visible-particle or move list overflowed: more visible particles than sdm_config.max_visible, more in ONE image row than "
-              "max(2 max_visible / height, 2 width slots) - raise max_visible -, or more than 2^21 in one pixel's bin");
+              "max(2 max_visible / height, 2 width slots) - raise max_visible -, or more than 2^20 in one pixel's bin");
     return SDM_ERR_CAPACITY;
   }
   if (c.vis_flood_rounds >= 256 && !c.vis_flood_complex) {
@@ -1049,8 +1049,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.line_reach, n_line_words);
   A(m->d_depth, hw);
   A(m->d_cloud, hw);
-  if (d.W > 2047) {
-    set_error("sdm_create", __FILE__, __LINE__, "image width above 2047 (the row kernel of the pixel bins holds one image row in LDS)");
+  if (d.W >= (1 << ROW_COL_BITS)) {
+    set_error("sdm_create", __FILE__, __LINE__, "image width above 4095 (the row kernel of the pixel bins holds one image row in LDS)");
     return SDM_ERR_INVALID_ARGUMENT;
   }
   A(sc.bin_count, hw + 1 + (size_t)d.H * ROW_SUBS * ROW_CNT_STRIDE);

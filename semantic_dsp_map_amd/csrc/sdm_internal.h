@@ -114,6 +114,9 @@ struct Counters {
 static_assert(sizeof(Counters::ShardLine) == 128, "one cache line per shard");
 constexpr uint32_t VIS_SHARDS = 64;
 constexpr uint32_t ROW_SUBS = 8;  // sub-lists per image row of the visible particles (Scratch::row_list)
+// a row-list entry's second word: column | place in the pixel's bin << ROW_COL_BITS (images up to 4095 pixels wide - round 6; 2047
+// before -, up to 2^20 particles in one pixel's bin)
+constexpr int ROW_COL_BITS = 12, ROW_PIB_BITS = 32 - ROW_COL_BITS;
 constexpr uint32_t ROW_CNT_STRIDE = 32;  // uint32 per sub-list counter: a cache line each (atomics on one line retire one at a time)
 constexpr uint32_t OWNER_CHUNK = 4096;  // slots per owner_flag byte (= slots per block of the move sweep)
 constexpr uint32_t OWNER_GROUP = 64;    // chunks per owner_flag2 byte

@@ -76,7 +76,7 @@ struct Scratch {
   // arrays in the order the rows' workgroups reserved them (k_bin_rows).
   uint32_t *bin_count = nullptr, *bin_start = nullptr;
   // the visible particles as k_visibility lists them: per image row ROW_SUBS lists of row_cap entries
-  // {particle index, column | place in the pixel's bin << 11}
+  // {particle index, column | place in the pixel's bin << ROW_COL_BITS}
   uint32_t *row_cnt = nullptr;  // H * ROW_SUBS counters, ROW_CNT_STRIDE words apart
   uint8_t *row_win = nullptr;   // per pixel: particles its image row puts into a window centred in its column (saturated)
   uint2 *row_list = nullptr;

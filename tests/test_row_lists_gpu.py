@@ -63,3 +63,26 @@ def test_a_crowded_image_row_with_a_small_max_visible():
     rep = pu.compare_maps(o, g, 1 << cfg["p_n"], check_bins=True)
     assert not rep, "\n".join(rep)
     g.close()
+
+
+def test_an_image_3000_pixels_wide():
+    """The reference takes any g_image_width (settings/settings.h); the row kernel of the pixel bins holds one image row in LDS
+    and took at most 2047 columns until round 6.  A 3000 x 40 camera (eight pixels per thread of k_bin_rows) on the T0 grid,
+    a street scene with moving objects, six frames against the oracle with the bins compared."""
+    cfg = dict(synth.CONFIGS["T0"], width=3000, height=40, fx=1200.0, fy=200.0, cx=1500.0, cy=20.0)
+    params = synth.PARAMS["noisy3"]
+    sc = synth.Scene(cfg, n_dynamic=2)
+    o, g = pu.make_pair(cfg, params, synth.noise_table())
+    n_vis = 0
+    for t in range(6):
+        depth, cloud, pos, q = sc.render(t, params)
+        o.update(depth, cloud, pos, q, sc.moves(t))
+        g.update(depth, cloud, pos, q, sc.moves(t), sync=True)
+        rep = pu.compare_maps(o, g, 1 << cfg["p_n"], check_bins=True, tag="frame %d: " % t)
+        assert not rep, "\n".join(rep)
+        n_vis = max(n_vis, g.stats()["n_visible"])
+    assert n_vis > 100, n_vis
+    assert g.bin_counts().reshape(cfg["height"], cfg["width"])[:, 2048:].sum() > 0   # particles binned beyond the old limit's columns
+    g.close()
+    with pytest.raises(binding.SdmError):
+        binding.SdmMap(dict(cfg, width=4096), params, synth.noise_table())
