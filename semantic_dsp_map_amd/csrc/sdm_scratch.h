@@ -52,6 +52,11 @@ struct FrameArgs {
   // block's object list is rewritten between them), then ONE k_move_replay: all copies are taken and invalidated before any
   // is re-inserted, and the global ranks run on across the batches (operations.h:321-362).  mv_batch = index of the batch
   // the block holds; batch b starts its ranks where batch b - 1 ended (Counters::n_moved_b).
+  // In such a frame the MAIN block is rewritten between the batches (k_move_members_v, launch_set_frame for long removal
+  // lists), on the main stream, behind the kernels that read the batch before: afterwards ms / n_obj / mv_seq / mv_batch /
+  // n_remove / remove[] hold the LAST batch only.  Nothing behind the move and removal stages reads them (k_move_replay reads
+  // n_obj as "did anything move": every batch has objects), and the chains on the side streams read their own copy of the
+  // block (fa_side, fa_moves), of which they use the pose, the inputs and the first batch's list.
   uint32_t mv_batch;
   int force_generic;   // test hook: always run the generic 3-D frustum flood
   const float *depth;  // this frame's inputs (device)
