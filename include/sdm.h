@@ -478,6 +478,11 @@ sdm_status sdm_debug_hinted_groups(sdm_map *m, int64_t *n_out);
  * per-tile lists and a launch of their own; the library picks per sweep from what the sweep before found (speed only:
  * the results are the same).  mode 1 / 0: always / never the lists; -1: the library picks again. */
 sdm_status sdm_debug_sweep_lists(sdm_map *m, int32_t mode);
+/* Test hook: how the next non-incremental sweep would be issued, from what the last one reported (waits for the map's
+ * stream).  Bit 0: the sparse voxels go through per-tile lists; bit 1: every group of 512 voxels was dense, the
+ * classification launch is left out and the evaluation launch takes every group (one launch instead of two; the
+ * environment variable SDM_SWEEP_SKIP_SCAN=0 keeps both).  Either way every voxel gets the same result. */
+sdm_status sdm_debug_sweep_mode(sdm_map *m, int32_t *mode_out);
 /* Test hook.  The table of older owner-set memberships (sdm_stats.alias_entries) takes 65536 entries; `cap` (1..65536)
  * makes it report its overflow earlier, so that a test can reach it on a small map.  Call before the map's first frame. */
 sdm_status sdm_debug_alias_cap(sdm_map *m, int32_t cap);

@@ -179,6 +179,7 @@ def load_library():
         "sdm_debug_fill_dense_ex": [vp, i32],
         "sdm_debug_hinted_groups": [vp, C.POINTER(C.c_int64)],
         "sdm_debug_sweep_lists": [vp, i32],
+        "sdm_debug_sweep_mode": [vp, C.POINTER(i32)],
         "sdm_debug_alias_cap": [vp, i32],
         "sdm_test_scan": [vp, vp, i64],
         "sdm_test_sort_pairs": [vp, vp, vp, vp, i64, i32],
@@ -597,6 +598,13 @@ class SdmMap:
         """Test hook: 1 / 0 = the non-incremental sweeps always / never hand their sparse voxels to per-tile lists, -1 = the
         library picks per sweep (sdm_debug_sweep_lists)."""
         _check(self.L, self.L.sdm_debug_sweep_lists(self.h, int(mode)), "sdm_debug_sweep_lists")
+
+    def sweep_mode(self):
+        """Test hook: bit 0 - the next non-incremental sweep uses per-tile lists; bit 1 - it is one launch (every group of
+        512 voxels was dense in the last one) (sdm_debug_sweep_mode)."""
+        v = C.c_int32(0)
+        _check(self.L, self.L.sdm_debug_sweep_mode(self.h, C.byref(v)), "sdm_debug_sweep_mode")
+        return v.value
 
     def set_alias_cap(self, cap):
         """Test hook: the table of older owner-set memberships reports its overflow at `cap` entries (before the first frame)."""

@@ -362,6 +362,8 @@ __global__ __launch_bounds__(TPB) void k_set_frame(FrameArgs *__restrict__ dst, 
 //                    sdm_set_params, sdm_clear, a wholesale stamp upload): every voxel gets its result, HBM-bound,
 //                    records of dense chunks fetched cooperatively.  On a map whose particles sit on surfaces:
 //                    k_occupancy_scan_lists + k_occupancy_listed + k_occupancy_dense (the host picks: map.hip, sweep_lists).
+//                    On a map whose every group of 512 voxels was dense last time: k_occupancy_dense alone
+//                    (launch_occupancy, OCC_SKIP_SCAN).
 
 // A voxel that holds something: weight sum, clamp / cull write-backs and the track vote
 // (calculateWeightAndSemanticsInVoxel, operations.h:390-448).  Written without branches - every decision is a select on
@@ -936,6 +938,7 @@ __device__ __forceinline__ void occupancy_scan_tile(const Dims &d, float occ_thr
   static_assert(OCC_WAVES == 4 && OCC_CPW * OCC_CHUNK == 512, "one hint byte per wave of this kernel and of k_occupancy_dense");
   const uint32_t hint4 = reinterpret_cast<const uint32_t *>(st.grp_hint)[tile];
   if (hint4 == 0x01010101u) return;
+  if (tid == 0) st.occ_shard[OCC_LIST_SHARDS].aux[0] = 1u;  // this launch was needed (k_occupancy_dense passes it on)
   const bool hinted = (hint4 >> (8 * (tid >> 6))) & 1u;
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   if (tid == 0) n_live = 0;
@@ -1190,13 +1193,20 @@ __device__ __forceinline__ void occupancy_listed_units(const Dims &d, float occ_
 
 // the sweep's units are done: the counters go back to zero, and how many tiles listed anything becomes the hint for the
 // next non-incremental sweep (first wave of one workgroup)
-__device__ __forceinline__ void occupancy_listed_wrap(const State &st, uint32_t n_tiles) {
+__device__ __forceinline__ void occupancy_listed_wrap(const State &st, uint32_t n_tiles, bool scan_ran) {
   static_assert(OCC_LIST_SHARDS == 64, "one shard per lane of the first wave");
   uint32_t t = (uint32_t)(st.occ_shard[threadIdx.x].word >> 32);
   st.occ_shard[threadIdx.x].word = 0;
   for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
   // 2: few tiles listed anything - surfaces - and the lists pay; 1: none did or most did, two launches do
-  if (threadIdx.x == 0) st.occ_shard[OCC_LIST_SHARDS].word = t > 0 && t <= n_tiles / 4 ? 2u : 1u;
+  if (threadIdx.x == 0) {
+    State::OccListShard &w = st.occ_shard[OCC_LIST_SHARDS];
+    w.word = t > 0 && t <= n_tiles / 4 ? 2u : 1u;
+    if (scan_ran) {  // did k_occupancy_scan enter any tile?  If not, the next sweep can do without it.  (When it did not
+      w.aux[1] = w.aux[0] ? 1u : 2u;  // run, the waves of THIS launch say so when they find a group that is not dense.)
+      w.aux[0] = 0u;
+    }
+  }
 }
 template <int S>
 __global__ __launch_bounds__(TPB) void k_occupancy_listed(Dims d, float occ_threshold, State st, uint32_t remark) {
@@ -1212,8 +1222,10 @@ __global__ __launch_bounds__(TPB) void k_occupancy_listed(Dims d, float occ_thre
 // id - the cheaper vote -, 2 % slower on the eight-track case; tools/gpu_dense_ab.sh.)
 template <int S>
 __global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d, float occ_threshold, State st, Counters *cnt,
-                                                         const unsigned long long *__restrict__ need, uint32_t remark, uint32_t n_tiles) {
-  if (blockIdx.x == 0 && threadIdx.x < OCC_LIST_SHARDS) occupancy_listed_wrap(st, n_tiles);  // (the units are done: the launch before this one)
+                                                         const unsigned long long *__restrict__ need, uint32_t remark, uint32_t n_tiles_all) {
+  // (top bit of n_tiles_all: k_occupancy_scan did not run - launch_occupancy, OCC_SKIP_SCAN - and every group is taken as hinted)
+  const bool all_groups = n_tiles_all >> 31;
+  if (blockIdx.x == 0 && threadIdx.x < OCC_LIST_SHARDS) occupancy_listed_wrap(st, n_tiles_all & 0x7fffffffu, !all_groups);  // (the units are done: the launch before this one)
   constexpr int REC = 10 * (S - 1);              // bytes of one record
   static_assert((OCC_CHUNK * REC) % 128 == 0, "a chunk of records starts on a cache line");
   constexpr int PIECES = OCC_CHUNK * REC / 16;   // 16-byte pieces of one chunk of records
@@ -1227,7 +1239,7 @@ __global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d
   const uint32_t cw = (blockIdx.x * OCC_WAVES + wave) * OCC_CPW;  // first chunk of this wave (a workgroup = a tile)
   const uint32_t lvw = cw * OCC_CHUNK;                            // ... and its first voxel
   const uint32_t hint4 = reinterpret_cast<const uint32_t *>(st.grp_hint)[blockIdx.x];  // the tile's four groups, as k_occupancy_scan saw them
-  const bool fused = (hint4 >> (8 * wave)) & 1u;                                         // wave-uniform
+  const bool fused = ((hint4 >> (8 * wave)) & 1u) || all_groups;                         // wave-uniform
   // the masks of the wave's chunks: lane k holds chunk k's (fused: every chunk of the map counts as dense)
   unsigned long long mk = 0;
   if (lane < (uint32_t)OCC_CPW && lvw + lane * OCC_CHUNK < d.v_count) mk = fused ? ~0ull : need[cw + lane];
@@ -1389,10 +1401,11 @@ __global__ __launch_bounds__(TPB) DENSE_WAVES_ATTR void k_occupancy_dense(Dims d
   if (lane == 0) {
     const bool whole = lvw + OCC_CPW * OCC_CHUNK <= d.v_count;  // (whole groups only)
     const uint8_t h = hint_ok && whole ? 1 : 0;
-    if ((uint8_t)(fused ? 1 : 0) != h) st.grp_hint[blockIdx.x * OCC_WAVES + wave] = h;
+    if ((uint8_t)((hint4 >> (8 * wave)) & 1u) != h) st.grp_hint[blockIdx.x * OCC_WAVES + wave] = h;
+    if (all_groups && !h) st.occ_shard[OCC_LIST_SHARDS].aux[1] = 1u;  // the next sweep needs its first launch again
     if (fused) {
       if (n_eval) atomicAdd(&cnt->shard[(blockIdx.x + wave) & (VIS_SHARDS - 1)].sweep, n_eval);
-      if (wave == 0 && hint4 == 0x01010101u) atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep_tiles, 1u);  // (the scan counts the tiles it enters)
+      if (wave == 0 && (hint4 == 0x01010101u || all_groups)) atomicAdd(&cnt->shard[blockIdx.x & (VIS_SHARDS - 1)].sweep_tiles, 1u);  // (the scan counts the tiles it enters)
     }
   }
 }
@@ -2417,13 +2430,27 @@ __device__ __forceinline__ void ck_light_pixel(const Dims &d, const Filter &flt,
 // to the 256 lanes - each computes a contiguous chunk of terms into LDS - and then lane (pixel, row) adds its row's
 // terms in bin order; the row sums are added in row order.  More terms than the LDS buffer holds: several passes,
 // the running row sums stay in registers.
-constexpr uint32_t CK_TERM_CAP = 4096;
+// (Round 6: 3584 terms per pass instead of 4096 and the kernel held to 72 registers (it took 79) make it seven resident
+// workgroups per CU instead of six, by LDS - 21.5 KB - and by registers: weight stage 57 -> 55 us on the benchmark frames,
+// 77 -> 76 us on `driven`, in two A/B calls.  Eight (64 registers, 2048 terms) spills and is slower: 61 / 83 us.)
+#ifndef SDM_CK_TERM_CAP
+#define SDM_CK_TERM_CAP 3584
+#endif
+constexpr uint32_t CK_TERM_CAP = SDM_CK_TERM_CAP;
 
-// (workgroups beyond what the chip holds at once only draw a ticket past the end of their list and leave: 24 per list
-// - 1536, the resident number at this kernel's register and LDS use - measured 37.4 us against 39.4 us with 64 per list)
-constexpr uint32_t CK_HEAVY_BLOCKS = 24 * VIS_SHARDS;
+// (workgroups beyond what the chip holds at once only draw a ticket past the end of their list and leave: 28 per list
+// - 1792, the resident number at this kernel's register and LDS use; round 4, at 24 resident per list: 37.4 us against
+// 39.4 us with 64 per list)
+#ifndef SDM_CK_HEAVY_PER_LIST
+#define SDM_CK_HEAVY_PER_LIST 28
+#endif
+constexpr uint32_t CK_HEAVY_BLOCKS = SDM_CK_HEAVY_PER_LIST * VIS_SHARDS;
+#ifndef SDM_CK_WAVES
+#define SDM_CK_WAVES 7
+#endif
+#define CK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SDM_CK_WAVES, SDM_CK_WAVES)))
 
-__global__ __launch_bounds__(A7_ROWS *A7_ITEMS) void k_ck(Dims d, Filter flt, State st, Scratch sc,
+__global__ __launch_bounds__(A7_ROWS *A7_ITEMS) CK_WAVES_ATTR void k_ck(Dims d, Filter flt, State st, Scratch sc,
                                                           float *__restrict__ ck_out, int finish) {
   DBG_LANE0(3, 0);
   if (blockIdx.x >= CK_HEAVY_BLOCKS) {  // light part: one thread per pixel
@@ -3756,9 +3783,12 @@ size_t tile_mark_bytes(const Dims &d) {
   return (std::max<size_t>(n_tiles, (size_t)TPB * OCC_SEG_MAX) + 16 + 15) / 16 * 16;  // one of the two arrays
 }
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, const FrameArgs *fa, uint32_t remark,
-                      hipStream_t s, int lists) {
+                      hipStream_t s, int mode) {
   dim3 grid(blocks_for(d.v_count, OCC_TILE));
-  if (all_dirty) {
+  const int lists = mode & OCC_LISTS;
+  if (all_dirty && (mode & OCC_SKIP_SCAN)) {
+    SDM_DISPATCH_S(k_occupancy_dense, grid, s, d, flt.occ_threshold, st, cnt, st.occ_need, remark, grid.x | 0x80000000u);
+  } else if (all_dirty) {
     // (Measured and not kept, round 5: the map cut into 2 / 4 / 8 slices of tiles, the scans of slices 1.. on a second
     // stream next to the dense launches of the slices before them - every cross-stream event costs more than the slice
     // of classification it hides: 0.285 -> 0.297 / 0.318 / 0.354 ms on the dense case.)

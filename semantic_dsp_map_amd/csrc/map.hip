@@ -382,6 +382,10 @@ struct sdm_map {
   // should have been (State::occ_shard: few tiles listed anything = surfaces, lists pay; none or most did, they do not),
   // and the host picks the word up at its next wait (sweep_mode_latch).  Either way every voxel gets the same result.
   bool sweep_lists = true;
+  // ... and whether its first launch found anything to do: on a map whose every group of 512 voxels is dense it does not
+  // (State::grp_hint), and the next non-incremental sweep is one launch (launch_occupancy, OCC_SKIP_SCAN).
+  bool sweep_skip_scan = false;
+  bool sweep_skip_allowed = true;  // SDM_SWEEP_SKIP_SCAN=0: always both launches (A/B)
   bool sweep_rec_pending = false;
   int sweep_lists_forced = -1;  // sdm_debug_sweep_lists
   uint32_t sweep_epoch = 1;  // the number the next sweep looks for in State::tile_dirty (mark_tile): advanced by every sweep issued
@@ -685,15 +689,20 @@ void host_initialize(sdm_map *m) {
   m->global_time_stamp = 0;
 }
 
+int sweep_mode(const sdm_map *m) { return (m->sweep_lists ? OCC_LISTS : 0) | (m->sweep_skip_scan ? OCC_SKIP_SCAN : 0); }
+
 // (m->stream is idle) what the last non-incremental sweep recommends for the next
 sdm_status sweep_mode_latch(sdm_map *m) {
   if (!m->sweep_rec_pending) return SDM_OK;
-  uint32_t rec = 0;
-  HIP_TRY(hipMemcpyAsync(&rec, &m->st.occ_shard[OCC_LIST_SHARDS].word, 4, hipMemcpyDeviceToHost, m->stream));
+  uint32_t rec[4] = {0, 0, 0, 0};  // word (two halves), aux[0], aux[1]
+  static_assert(offsetof(State::OccListShard, aux) == 8, "the sweep's words to the host are one 16-byte read");
+  HIP_TRY(hipMemcpyAsync(rec, &m->st.occ_shard[OCC_LIST_SHARDS].word, 16, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
-  if (rec == 1) m->sweep_lists = false;
-  if (rec == 2) m->sweep_lists = true;
+  if (rec[0] == 1) m->sweep_lists = false;
+  if (rec[0] == 2) m->sweep_lists = true;
   if (m->sweep_lists_forced >= 0) m->sweep_lists = m->sweep_lists_forced != 0;
+  if (rec[3] == 1) m->sweep_skip_scan = false;
+  if (rec[3] == 2) m->sweep_skip_scan = m->sweep_skip_allowed;
   m->sweep_rec_pending = false;
   return SDM_OK;
 }
@@ -1142,6 +1151,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
     if (e && e[0] >= '0' && e[0] <= '4') m->graph_mode = e[0] - '0';
     m->use_graph = m->graph_mode != 0;
     m->graph_shape = m->graph_mode == 1 ? GRAPH_BRANCHED : (m->graph_mode == 3 ? GRAPH_CHAIN : GRAPH_PIECES);
+    if (const char *k = getenv("SDM_SWEEP_SKIP_SCAN")) m->sweep_skip_allowed = atoi(k) != 0;
     m->host_timing = getenv("SDM_HOST_TIMING") != nullptr;  // debugging aid: per-step host time of sdm_update on stderr at destroy
   }
   {
@@ -1269,6 +1279,8 @@ sdm_status sdm_clear(sdm_map *m) {
   m->state_event_valid = false;
   m->vis_event_valid = false;
   m->sweep_all = true;
+  m->sweep_skip_scan = false;  // (the groups' hints go with the map; what an unlatched sweep said about them is void)
+  m->sweep_rec_pending = false;
   host_initialize(m);
   launch_clear(m->d, m->st, m->sc.mv_head, m->stream, false);
   return upload_stamps(m);
@@ -1720,7 +1732,7 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
   if (stage_done(stop_after, 6)) return SDM_OK;
   if (!(flags & SDM_SKIP_OCCUPANCY)) {
     // (under capture nothing runs: the frame the graph is then launched for advances the epoch)
-    launch_occupancy(d, m->flt, m->st, m->sc.cnt, m->sweep_all ? 1 : 0, m->sc.fa, next_epoch(m->f.epoch), s, m->sweep_lists ? 1 : 0);
+    launch_occupancy(d, m->flt, m->st, m->sc.cnt, m->sweep_all ? 1 : 0, m->sc.fa, next_epoch(m->f.epoch), s, sweep_mode(m));
     if (m->sweep_all) m->sweep_rec_pending = true;
     m->sweep_all = false;
     if (!m->capturing) m->sweep_epoch = next_epoch(m->f.epoch);
@@ -2984,6 +2996,8 @@ sdm_status sdm_load_state(sdm_map *m, const float *px, const float *py, const fl
   const size_t n = (size_t)m->d.v_count * m->d.S;
   // (which tiles are dense is not known of a state that comes from outside: the first sweep classifies everything)
   HIP_TRY(hipMemsetAsync(m->st.grp_hint, 0, grp_hint_bytes(m->d.v_count), s));
+  m->sweep_skip_scan = false;
+  m->sweep_rec_pending = false;
   float *tx, *ty, *tz;
   uint8_t *tf;
   HIP_TRY(dev_alloc(&tx, n));
@@ -3086,16 +3100,16 @@ sdm_status sdm_time_occupancy_sweep(sdm_map *m, int32_t iters, float *avg_ms) {
   HIP_TRY(hipEventCreate(&b));
   // (what these sweeps have to see again, the next frame's sweep has to see: marked with its epoch)
   // (warm-up, and the launch whose word decides how the timed ones run: all_dirty - the full evaluation every time)
-  launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->sc.fa, m->sweep_epoch, m->stream, m->sweep_lists ? 1 : 0);
+  launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->sc.fa, m->sweep_epoch, m->stream, sweep_mode(m));
   m->sweep_rec_pending = true;
   HIP_TRY(hipStreamSynchronize(m->stream));
   {
     const sdm_status rc = sweep_mode_latch(m);
     if (rc != SDM_OK) return rc;
   }
-  const int lists = m->sweep_lists ? 1 : 0;
+  const int mode = sweep_mode(m);
   HIP_TRY(hipEventRecord(a, m->stream));
-  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->sc.fa, m->sweep_epoch, m->stream, lists);
+  for (int i = 0; i < iters; ++i) launch_occupancy(m->d, m->flt, m->st, m->sc.cnt, 1, m->sc.fa, m->sweep_epoch, m->stream, mode);
   HIP_TRY(hipEventRecord(b, m->stream));
   HIP_TRY(hipEventSynchronize(b));
   m->sweep_rec_pending = true;
@@ -3120,6 +3134,15 @@ sdm_status sdm_debug_sweep_lists(sdm_map *m, int32_t mode) {
   if (!m || mode < -1 || mode > 1) return SDM_ERR_INVALID_ARGUMENT;
   m->sweep_lists_forced = mode;
   if (mode >= 0) m->sweep_lists = mode != 0;
+  return SDM_OK;
+}
+sdm_status sdm_debug_sweep_mode(sdm_map *m, int32_t *mode_out) {
+  if (!m || !mode_out) return SDM_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  const sdm_status rc = sweep_mode_latch(m);
+  if (rc != SDM_OK) return rc;
+  *mode_out = sweep_mode(m);
   return SDM_OK;
 }
 sdm_status sdm_debug_alias_cap(sdm_map *m, int32_t cap) {

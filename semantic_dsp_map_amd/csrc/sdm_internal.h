@@ -215,7 +215,10 @@ struct State {
   uint32_t occ_unit_cap = 0;
   struct alignas(128) OccListShard {
     unsigned long long word;  // low half: units handed out; high half: tiles that listed anything (one atomic for both)
-    uint32_t pad[30];
+    // entry OCC_LIST_SHARDS only (the sweep's word to the host, sweep_mode_latch): aux[0] - k_occupancy_scan entered a
+    // tile (some group of the map was not hinted); aux[1] - 2: the sweep's first launch had nothing to do, the next
+    // non-incremental sweep may leave it out (launch_occupancy, OCC_SKIP_SCAN); 1: it may not
+    uint32_t aux[30];
   };
   OccListShard *occ_shard = nullptr;
   // per group of 512 voxels (what one wave of the non-incremental sweep's kernels takes): 1 = every chunk of the group

@@ -183,8 +183,12 @@ struct FrameBeginLaunch {
 void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s);
 void launch_moves_batch(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa_batch, int32_t *counts_local, hipStream_t s);
 // lists (non-incremental sweeps only): the tiles' sparse voxels go through State::occ_list and a launch of their own
+// mode (non-incremental sweeps only): OCC_LISTS | OCC_SKIP_SCAN - every group of the map was hinted when the last such
+// sweep ran (State::grp_hint), so the first launch would be workgroups that leave after four bytes: it is left out and
+// k_occupancy_dense takes every group as hinted, whatever its byte says by now (right for any map, fast for a dense one)
+constexpr int OCC_LISTS = 1, OCC_SKIP_SCAN = 2;
 void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counters *cnt, int all_dirty, const FrameArgs *fa, uint32_t remark,
-                      hipStream_t s, int lists = 0);
+                      hipStream_t s, int mode = 0);
 size_t tile_mark_bytes(const Dims &d);  // State::tile_dirty, padded for the sweep's tile scan
 void launch_frustum(const Dims &d, const Scratch &sc, hipStream_t s);
 // visibility + binning; its last kernel also classifies the pixels for launch_ck (same ck_out / finish)

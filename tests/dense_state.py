@@ -7,9 +7,10 @@ import numpy as np
 from semantic_dsp_map_amd import binding
 
 
-def random_state(cfg, seed, run=1):
+def random_state(cfg, seed, run=1, kinds=(0.25, 0.25, 0.5)):
     """run: chunks of one kind come in aligned runs of this many (run = 8: whole 512-voxel groups - what one wave of the
-    non-incremental sweep's kernels takes - are dense, sparse or empty, so that the sweep's group hints come into play)"""
+    non-incremental sweep's kernels takes - are dense, sparse or empty, so that the sweep's group hints come into play);
+    kinds: how often a run is empty / sparse / dense"""
     rng = np.random.default_rng(seed)
     NX, NY, NZ, S = 1 << cfg["x_n"], 1 << cfg["y_n"], 1 << cfg["z_n"], 1 << cfg["p_n"]
     V = NX * NY * NZ
@@ -21,7 +22,7 @@ def random_state(cfg, seed, run=1):
     vx, vy, vz = vox & (NX - 1), (vox >> cfg["x_n"]) & (NY - 1), vox >> (cfg["x_n"] + cfg["y_n"])
     # per chunk of 64 voxels: 0 = empty, 1 = a few voxels hold something, 2 = every voxel does
     n_runs = ((V + 63) // 64 + run - 1) // run
-    kind = rng.choice(3, size=n_runs, p=[0.25, 0.25, 0.5])[(vox >> 6) // run]
+    kind = rng.choice(3, size=n_runs, p=list(kinds))[(vox >> 6) // run]
     holds = (kind == 2) | ((kind == 1) & (rng.random(V) < 0.1))
     status = st["status"].reshape(V, S)
     status[:, 0] = 5                                              # TIMEPTC

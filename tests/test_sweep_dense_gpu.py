@@ -112,3 +112,44 @@ def test_group_hints_repeated_non_incremental_sweeps(seed, x_n):
     # some of the hints away again
     assert n_hint[0] > (1 << (x_n + 10)) // 512 // 8 and n_hint[-1] < n_hint[0], n_hint
     g.close()
+
+
+@pytest.mark.parametrize("seed,x_n", [(31, 6), (32, 7)])
+def test_a_map_of_dense_groups_is_swept_in_one_launch(seed, x_n):
+    """When the classification launch of a non-incremental sweep found every group of 512 voxels hinted, the next such
+    sweep leaves it out: k_occupancy_dense alone, every group taken as hinted whatever its byte says
+    (launch_occupancy, OCC_SKIP_SCAN).  A matter of speed only - so: a state whose every group is dense, frames that each
+    end in a non-incremental sweep; the first sweep classifies (no hints yet), the second finds nothing to classify, the
+    third and fourth are one launch; then the camera moves on, ring shifts re-stamp slabs through the groups, the
+    single launch finds groups that are not dense any more and says so, and the sweeps after it are two launches again.
+    Bit for bit against the oracle after every frame, and the way each sweep was issued is checked."""
+    cfg = dict(synth.CONFIGS["T0"], p_n=3, x_n=x_n)
+    params = synth.PARAMS["vkitti2"]
+    sc = synth.Scene(cfg, n_dynamic=2, seed=5)
+    o, g = pu.make_pair(cfg, params, synth.noise_table())
+    st = random_state(cfg, seed, run=8, kinds=(0.0, 0.0, 1.0))
+    ring = dict(o.ring_state(), global_time_stamp=3)
+    for m in (o, g):
+        m.load_state(st)
+        m.set_ring_state(ring)
+    n_groups = (1 << (x_n + cfg["y_n"] + cfg["z_n"])) // 512
+    modes, hints = [], []
+    for t in range(8):
+        depth, cloud, pos, q = sc.render(0 if t < 4 else t, params)
+        if t >= 4:
+            pos = pos + np.array([0.0, 0.0, 0.45 * (t - 3)], np.float32)
+        if t >= 6:
+            pos = pos + np.array([2.1, 0.9, 0.0], np.float32) * (t - 5)
+        for m in (o, g):
+            m.set_params(params)     # the next sweep is a non-incremental one
+        modes.append(g.sweep_mode() >> 1)    # how this frame's sweep will be issued
+        o.update(depth, cloud, pos, q, sc.moves(t))
+        g.update(depth, cloud, pos, q, sc.moves(t), sync=True)
+        rep = pu.compare_maps(o, g, 8, check_results=True, tag="frame %d: " % t)
+        assert not rep, "\n".join(rep)
+        hints.append(g.hinted_groups())
+    assert hints[0] == n_groups, (hints, n_groups)
+    assert modes[:4] == [0, 0, 1, 1], modes      # classify / nothing to classify / one launch / one launch
+    assert modes[4] == 1 and hints[4] < n_groups, (modes, hints)   # the single launch meets the re-stamped slabs ...
+    assert modes[5:] == [0, 0, 0], modes         # ... and the classification launch is back
+    g.close()
