@@ -649,7 +649,7 @@ def main():
             m.synchronize()
         clear_ms = (time.perf_counter() - t0) * 1e3 / 3
         n_slots = V * S
-        clear_bytes = n_slots * (16 + 2) + V * (S - 1) * (4 + 2 + 1) + V * (2 + 1 + 8 + 4)  # pos4, owner per slot; w, ts, status per particle slot (nothing read); vts, vflag, res, list heads
+        clear_bytes = n_slots * (16 + 2) + V * (S - 1) * (4 + 2 + 1) + V * (2 + 1 + 8)  # pos4, owner per slot; w, ts, status per particle slot (nothing read); vts, vflag, res
         roofline["clear"] = {"kernel": "sdm_clear: k_clear_map<8> (one write-only pass over the map, 16-byte lane-linear stores) + 4 small memsets", "bytes_per_call": clear_bytes,
                              "ms_per_call": round(clear_ms, 4), "achieved": round(clear_bytes / clear_ms / 1e6, 1),
                              "frac": round(clear_bytes / clear_ms / 1e6 / (HBM_PEAK_BPS / 1e9), 4),

@@ -13,6 +13,7 @@
 
 #include <type_traits>
 
+#include <hip/hip_ext.h>
 #include "sdm_internal.h"
 #include "sdm_scratch.h"
 
@@ -234,7 +235,7 @@ __device__ __forceinline__ uint32_t stamp_max(const State &st, uint32_t rx, uint
 // RingBufferOperations::clear on a used map (operations.h:697-722): status, position, weight, time stamp; track id,
 // label and forget count stay.  One pass, one thread per slot: everything sdm_clear resets is written here (the
 // per-voxel arrays by the slot-0 lane), so the map's bytes cross HBM once.
-__global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, uint32_t *__restrict__ mv_head, size_t n) {
+__global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, size_t n) {
   size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= n) return;
   st.pos4[li] = make_float4(0.f, 0.f, 0.f, 0.f);  // (the forget count, which clear() does not touch, lives in State::forget)
@@ -252,7 +253,6 @@ __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, uint32_t 
     st.vflag[lv] = 0;
     static_assert(sizeof(sdm_voxel_result) == 8, "the result entry is cleared as one 8-byte store");
     reinterpret_cast<uint2 *>(st.res)[lv] = make_uint2(0u, 0u);
-    mv_head[lv] = 0xffffffffu;
   }
 }
 
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TPB) void k_clear_slots(Dims d, State st, uint32_t 
 // the partial sectors better than it serves the extra reads - and 1.62-1.74 ms with plain instead of non-temporal accesses.
 constexpr int CLR_VOX = 256;
 template <int S>
-__global__ __launch_bounds__(TPB) void k_clear_map(Dims d, State st, uint32_t *__restrict__ mv_head) {
+__global__ __launch_bounds__(TPB) void k_clear_map(Dims d, State st) {
   static_assert(S >= 8 && (CLR_VOX * 10 * (S - 1)) % 16 == 0, "a workgroup's records are whole 16-byte pieces");
   constexpr int L = S - 1, REC = 10 * L;  // particle slots, bytes of one record
   static_assert(ST_INVALID == 0, "every byte clear() resets in a record is a zero byte");
@@ -336,7 +336,6 @@ __global__ __launch_bounds__(TPB) void k_clear_map(Dims d, State st, uint32_t *_
       if (q < nown) __builtin_nontemporal_store(ones, op + q);
     }
     if (tid < nv * 8 / 16) __builtin_nontemporal_store(zero, reinterpret_cast<v4u *>(st.res + lv0) + tid);
-    if (tid < nv * 4 / 16) __builtin_nontemporal_store(ones, reinterpret_cast<v4u *>(mv_head + lv0) + tid);  // MV_NIL
     if (tid < nv * 2 / 16) __builtin_nontemporal_store(zero, reinterpret_cast<v4u *>(st.vts + lv0) + tid);
     if (tid < nv / 8) reinterpret_cast<v2u *>(st.vflag + lv0)[tid] = v2u{0u, 0u};  // (nv is a multiple of 8, not of 16)
   }
@@ -3744,7 +3743,7 @@ inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb
 // fresh = the buffers have never been written (sdm_create): everything to zero.  Otherwise the reference's clear()
 // (operations.h:697-722) resets status, position, weight and time stamp of every slot and leaves track id, label and
 // forget count of the dead slots as they were.
-void launch_clear(const Dims &d, const State &st, uint32_t *mv_head, hipStream_t s, bool fresh) {
+void launch_clear(const Dims &d, const State &st, hipStream_t s, bool fresh) {
   size_t n = (size_t)d.v_count * d.S;
   if (fresh) {
     hipMemsetAsync(st.pos4, 0, n * sizeof(float4), s);
@@ -3754,12 +3753,11 @@ void launch_clear(const Dims &d, const State &st, uint32_t *mv_head, hipStream_t
     hipMemsetAsync(st.vflag, 0, (size_t)d.v_count, s);
     hipMemsetAsync(st.owner, 0xFF, n * sizeof(uint16_t), s);
     hipMemsetAsync(st.res, 0, (size_t)d.v_count * sizeof(sdm_voxel_result), s);
-    hipMemsetAsync(mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t), s);
   } else {
-    if (d.S == 8) hipLaunchKernelGGL(k_clear_map<8>, dim3(blocks_for(d.v_count, CLR_VOX)), dim3(TPB), 0, s, d, st, mv_head);
-    else if (d.S == 16) hipLaunchKernelGGL(k_clear_map<16>, dim3(blocks_for(d.v_count, CLR_VOX)), dim3(TPB), 0, s, d, st, mv_head);
+    if (d.S == 8) hipLaunchKernelGGL(k_clear_map<8>, dim3(blocks_for(d.v_count, CLR_VOX)), dim3(TPB), 0, s, d, st);
+    else if (d.S == 16) hipLaunchKernelGGL(k_clear_map<16>, dim3(blocks_for(d.v_count, CLR_VOX)), dim3(TPB), 0, s, d, st);
     else
-      hipLaunchKernelGGL(k_clear_slots, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, mv_head, n);
+      hipLaunchKernelGGL(k_clear_slots, dim3(blocks_for(n)), dim3(TPB), 0, s, d, st, n);
   }
   hipMemsetAsync(st.grp_hint, 0, grp_hint_bytes(d.v_count), s);  // nothing is dense any more
   hipMemsetAsync(st.alias, 0, 8, s);  // no older memberships (count and the sticky overflow word)
@@ -3840,11 +3838,21 @@ void launch_frustum(const Dims &d, const Scratch &sc, hipStream_t s) {
   hipLaunchKernelGGL(k_flood_generic, dim3(1), dim3(1024), 0, s, d, sc.fa_side, sc.vmask, sc.reach, sc.wpl, sc.cnt);
 }
 
-void launch_visibility(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s) {
+void launch_visibility(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s,
+                       hipEvent_t vis_done) {
   {
     const size_t max_words = (size_t)((d.NX + 63) / 64 + 1) * d.NY * d.NZ;
     dim3 grid((unsigned)std::min<size_t>(blocks_for(max_words, VIS_WORDS), 2048));
-    SDM_DISPATCH_S(k_visibility, grid, s, d, st, sc);
+    if (vis_done) {
+      switch (d.p_n) {
+        case 1: hipExtLaunchKernelGGL(k_visibility<2>, grid, dim3(TPB), 0, s, nullptr, vis_done, 0, d, st, sc); break;
+        case 2: hipExtLaunchKernelGGL(k_visibility<4>, grid, dim3(TPB), 0, s, nullptr, vis_done, 0, d, st, sc); break;
+        case 3: hipExtLaunchKernelGGL(k_visibility<8>, grid, dim3(TPB), 0, s, nullptr, vis_done, 0, d, st, sc); break;
+        default: hipExtLaunchKernelGGL(k_visibility<16>, grid, dim3(TPB), 0, s, nullptr, vis_done, 0, d, st, sc); break;
+      }
+    } else {
+      SDM_DISPATCH_S(k_visibility, grid, s, d, st, sc);
+    }
   }
   // bins: one workgroup per image row lays the row's bins out, fills and orders them; then the pixels are classified for pass 1
   if (d.W <= 2 * BR_TPB) hipLaunchKernelGGL(k_bin_rows<2>, dim3((unsigned)d.H), dim3(BR_TPB), 0, s, d, st, sc);

@@ -1125,8 +1125,8 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   A(sc.scan_scratch_b, scan_scratch_elems(hw + 1) + 16);
   HIP_TRY(hipMemsetAsync(sc.scan_scratch, 0, (scan_need + 16) * 4, m->stream));
   HIP_TRY(hipMemsetAsync(sc.scan_scratch_b, 0, (scan_scratch_elems(hw + 1) + 16) * 4, m->stream));
-  A(sc.mv_head, d.v_count);
-  HIP_TRY(hipMemsetAsync(sc.mv_head, 0xff, (size_t)d.v_count * sizeof(uint32_t), m->stream));  // MV_NIL; the replay leaves it that way
+  A(sc.mv_row, (size_t)d.v_count * MV_ROW);  // (64 bytes per voxel: 1.07 GB at 256^3 - the part has 288 GB)
+  HIP_TRY(hipMemsetAsync(sc.mv_row, 0xff, (size_t)d.v_count * MV_ROW * sizeof(uint32_t), m->stream));  // idle: counters and chain heads all ones; the replay leaves them that way
   A(sc.mv_next, sc.cap_move);
   A(sc.cnt, 1);
   A(sc.cur, 1);
@@ -1170,7 +1170,7 @@ sdm_status sdm_create(const sdm_config *cfg, sdm_map **out) {
   m->ev_valid = true;
   // RingBufferOperations::initialize (operations.h:726-767)
   host_initialize(m);
-  launch_clear(d, m->st, m->sc.mv_head, m->stream, true);
+  launch_clear(d, m->st, m->stream, true);
   if ((rc = upload_stamps(m)) != SDM_OK) return rc;
   HIP_TRY(hipStreamSynchronize(m->stream));
   {
@@ -1282,7 +1282,7 @@ sdm_status sdm_clear(sdm_map *m) {
   m->sweep_skip_scan = false;  // (the groups' hints go with the map; what an unlatched sweep said about them is void)
   m->sweep_rec_pending = false;
   host_initialize(m);
-  launch_clear(m->d, m->st, m->sc.mv_head, m->stream, false);
+  launch_clear(m->d, m->st, m->stream, false);
   return upload_stamps(m);
 }
 
@@ -1451,7 +1451,13 @@ sdm_status frame_enqueue_start(sdm_map *m) {
     // The frustum reach set and the member count of the moving objects depend on the pose / the owner sets only,
     // which were final when the previous frame's births were done (ev_state): they get their own copy of the frame
     // block there and start - next to the previous frame's sweep when frames are issued back to back.
-    if (!m->state_event_valid) HIP_TRY(hipEventRecord(m->ev_state, s));
+    // (recorded only where somebody waits for it: a marker between two launches of the main stream costs 2-3 us of the
+    // frame - tools/probes/timers_frame_gaps.py - and a whole map's plain frames need none after the first)
+    const bool side_chain_now = m->n_moves > 0 && (!whole || ((m->comm || m->ipc) && m->sharded_frame));
+    if (!m->state_event_valid && (!m->vis_event_valid || side_chain_now)) {
+      HIP_TRY(hipEventRecord(m->ev_state, s));
+      m->state_event_valid = true;
+    }
     // (the frustum chain reads the pose only; its bitmaps and flood flags are last read by the previous frame's
     // k_visibility: it starts behind THAT, a hundred microseconds before the births are done, and is off the path that
     // leads from one frame's sweep to the next frame's visibility pass)
@@ -1460,7 +1466,9 @@ sdm_status frame_enqueue_start(sdm_map *m) {
     HIP_TRY(hipEventRecord(m->ev_fa, m->s_frustum));
     if (whole && m->mv_pending) HIP_TRY(hipMemsetAsync(m->sc.mv_tot, 0, move_total_elems() * sizeof(uint32_t), s));
     m->fb.set(d, m->st, m->sc, m->fa, false, whole);
-    launch_frame_begin(m->fb, s);
+    // (ev_begin - the birth-candidate chain starts behind this kernel - rides on the launch itself, its packet's completion
+    // signal, instead of a marker packet behind it: frame_begin -> k_move_apply 6.4 -> 3 us)
+    launch_frame_begin(m->fb, s, !stage_done(stop_after, 5) ? m->ev_begin : nullptr);
     if (whole && m->n_moves > 0) m->mv_pending = true;
   }
   stage_mark(m, 1);
@@ -1511,10 +1519,7 @@ sdm_status frame_enqueue_start(sdm_map *m) {
   }
   if (!stage_done(stop_after, 5)) {
     // the birth candidates read this frame's cloud and the birth cursor: after this frame's k_frame_begin
-    if (!m->capturing) {
-      HIP_TRY(hipEventRecord(m->ev_begin, s));
-      HIP_TRY(hipStreamWaitEvent(m->s_birth, m->ev_begin, 0));
-    }
+    if (!m->capturing) HIP_TRY(hipStreamWaitEvent(m->s_birth, m->ev_begin, 0));  // (recorded by k_frame_begin's launch)
     m->birth_which = launch_birth_prepare(d, m->flt, m->bo, m->st, m->sc, m->s_birth);
     HIP_TRY(hipEventRecord(m->capturing ? m->cap_birth : m->ev_birth, m->s_birth));
   }
@@ -1651,11 +1656,10 @@ sdm_status sdm_frame_predict(sdm_map *m, const float **ck_part_dev) {
   // U1: visibility + binning (semantic_dsp_map.h:749); join the frustum stream first
   HIP_TRY(hipStreamWaitEvent(s, m->capturing ? m->cap_frustum : m->ev_frustum, 0));
   float *ck_dst = m->ck_user ? m->ck_user : m->d_ck_part;
-  launch_visibility(d, m->flt, m->st, m->sc, ck_dst, m->fused_ck ? 1 : 0, s);
-  if (!m->capturing) {
-    HIP_TRY(hipEventRecord(m->ev_vis, s));  // the next frame's frustum chain may overwrite what this pass read
-    m->vis_event_valid = true;
-  }
+  // (ev_vis: the next frame's frustum chain may overwrite what k_visibility read - recorded by that launch's own completion,
+  // not by a marker behind the binning launches that follow it)
+  launch_visibility(d, m->flt, m->st, m->sc, ck_dst, m->fused_ck ? 1 : 0, s, m->capturing ? nullptr : m->ev_vis);
+  if (!m->capturing) m->vis_event_valid = true;
   stage_mark(m, 4);
   if (stage_done(stop_after, 4)) return SDM_OK;
 
@@ -1725,8 +1729,14 @@ sdm_status sdm_update_finish(sdm_map *m, const float *ck_parts_dev, int32_t n_pa
   HIP_TRY(hipStreamWaitEvent(s, m->capturing ? m->cap_birth : m->ev_birth, 0));  // join the birth-candidate stream
   launch_birth_replay(d, m->flt, m->st, m->sc, m->birth_which, m->global_time_stamp > 65535u, s);
   if (!m->capturing) {
-    HIP_TRY(hipEventRecord(m->ev_state, s));
-    m->state_event_valid = true;
+    // ev_state: the particles are final here.  The member-count chain of a shard / a sharded frame starts behind it; a
+    // whole map's plain frames have nobody waiting (frame_enqueue_start records it where it is needed after all)
+    if (d.v_count != d.V || m->comm || m->ipc) {
+      HIP_TRY(hipEventRecord(m->ev_state, s));
+      m->state_event_valid = true;
+    } else {
+      m->state_event_valid = false;
+    }
   }
   stage_mark(m, 6);
   if (stage_done(stop_after, 6)) return SDM_OK;

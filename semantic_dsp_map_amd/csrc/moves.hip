@@ -10,6 +10,7 @@
 // counters across waves, one exclusive scan across blocks) — the result is every moving object's
 // particle list in ascending particle index, which is the iteration order the oracle pins for the
 // reference's std::unordered_set (DESIGN.md "pinned choices").
+#include <hip/hip_ext.h>
 #include "sdm_internal.h"
 #include "sdm_scratch.h"
 
@@ -379,14 +380,25 @@ __global__ void k_move_local_counts(int32_t *counts_local, Scratch sc, const Fra
 
 constexpr uint32_t MV_NIL = 0xffffffffu;
 
-// A moved copy of global rank e joins the list of its target voxel (push-front; the replay restores rank order).  The copy
-// itself says where it went (MoveCopy::voxel), so the replay needs no list of touched voxels: the thread of the copy a
-// list's head points at replays the list.  (Round 3 kept such a list: an atomic per touched voxel on one word, then one
-// per workgroup through LDS plus a flush - two more dependent steps at the end of k_move_apply.)
-__device__ __forceinline__ void move_link(const Dims &d, const Scratch &sc, uint32_t v, uint32_t e) {
+// A moved copy of global rank e joins its target voxel's list (Scratch::mv_row): word 0 of the voxel's row hands out
+// places; the first MV_DIRECT arrivals write their rank into the row - the replay fetches all of them with one 64-byte
+// load - the later ones are chained through the row's last word and mv_next (push-front; the replay restores rank order
+// either way).  The copy that arrived FIRST replays the list, and its entry says so (MV_FIRST, set here, behind the
+// copy's own store): the replay needs no list of touched voxels, and the thread of any other copy leaves after one load.
+// (Rounds 4-6 chained every arrival and made every copy's thread look the voxel up: a list of seventeen copies was
+// seventeen dependent loads, and half of the replay's threads fetched a record, an owner row, a forget row and a list head
+// for a list that was not theirs - the kernel is bound by the scattered lines it touches, tools/probes/timers_moves.py.)
+__device__ __forceinline__ void move_link(const Dims &d, const Scratch &sc, uint32_t v, uint32_t e, uint32_t forget_bits) {
   const uint32_t lv = v - d.v_begin;
-  const uint32_t prev = atomicExch(&sc.mv_head[lv], e);
-  sc.mv_next[e] = prev;
+  uint32_t *row = sc.mv_row + (size_t)lv * MV_ROW;
+  const uint32_t k = atomicAdd(&row[0], 1u) + 1u;  // (idle: all ones)
+  if (k < (uint32_t)MV_DIRECT) {
+    row[1 + k] = e;
+    if (k == 0u) sc.mv_copy[e].forget_bits = forget_bits | MV_FIRST;
+  } else {
+    const uint32_t prev = atomicExch(&row[MV_ROW - 1], e);  // (MV_NIL when idle: the replay leaves it that way)
+    sc.mv_next[e] = prev;
+  }
 }
 
 // one member of moving object `obj`, global rank e, local slot li
@@ -454,7 +466,7 @@ __device__ __forceinline__ void move_store(const Dims &d, const Frame &f, const 
     c.x = nx;
     c.y = ny;
     c.z = nz;
-    c.forget_bits = __float_as_uint(p.w);
+    c.forget_bits = __float_as_uint(p.w) & 0xffu;
     c.w = pw;
     c.ts = pts;
     c.track = ptrack;
@@ -463,7 +475,7 @@ __device__ __forceinline__ void move_store(const Dims &d, const Frame &f, const 
     c.status = pstatus;
     c.voxel = v - d.v_begin;
     sc.mv_copy[e] = c;
-    move_link(d, sc, v, e);
+    move_link(d, sc, v, e, c.forget_bits);
   } else if (sc.halo_send) {  // crosses into another slab: export to the shard that owns it
     unsigned char *seg = sc.halo_send + (size_t)(rz / d.rz_count) * halo_segment_bytes(sc.halo_cap);
     uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(seg), 1u);
@@ -767,7 +779,7 @@ __global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int wor
     c.x = r.x;
     c.y = r.y;
     c.z = r.z;
-    c.forget_bits = r.forget_bits;
+    c.forget_bits = r.forget_bits & 0xffu;
     c.w = r.w;
     c.ts = (uint16_t)(r.ts_track & 0xffffu);
     c.track = (uint16_t)(r.ts_track >> 16);
@@ -776,32 +788,40 @@ __global__ __launch_bounds__(TPB) void k_move_import(Dims d, Scratch sc, int wor
     c.status = (uint8_t)(r.owner_label_status >> 24);
     c.voxel = r.voxel - d.v_begin;
     sc.mv_copy[e] = c;
-    move_link(d, sc, r.voxel, e);
+    move_link(d, sc, r.voxel, e, c.forget_bits);
   }
 }
 
 // phase 2 (operations.h:351-361): re-insert the copies, first vacant slot, in (object, index) order = ascending global
-// rank.  One thread per COPY: it looks up its target voxel's list head, and the one copy the head points at walks the
-// list, picks the next S-1 ranks in ascending order, replays them, and repeats while the voxel still has a vacant slot (a
-// copy whose own stamp is older than the slab's leaves its slot vacant, so a list can be longer than the voxel; once the
-// voxel is full every later copy is dropped, operations.h:357).  The list head is left idle again.  (Copies that left
-// the map, went to another shard or belong to other shards' members were not written this frame: whatever their entry
-// holds, no list head of this frame points at it.)
+// rank.  One thread per COPY: the copy that arrived first at its voxel (MV_FIRST; the others leave at once) fetches the
+// voxel's row, sorts the ranks, fetches the copies - all of them in one round - and replays them in rank order while the voxel has a vacant slot
+// (a copy whose own stamp is older than the slab's leaves its slot vacant, so a list can be longer than the voxel; once
+// the voxel is full every later copy is dropped, operations.h:357).  Counter and chain head are left idle again.  (Copies
+// that left the map, went to another shard or belong to other shards' members were not written this frame: whatever their
+// entry holds, word 0 of no row of this frame names it.)
+// A list of more than MV_DIRECT copies (a voxel on the surface of an object that has been tracked for a hundred frames
+// receives dozens of copies of which many are vacant themselves - dead members of the set are copied too,
+// operations.h:334-349) takes the path of rounds 4-6 for what the row does not hold: the chain is walked once, the ranks
+// kept in LDS, and batches of S-1 ranks are selected from there.
 constexpr int RP_TPB = 64;
 constexpr int RP_GRID = 1024;
 constexpr int RP_KEEP = 96;  // ranks of a voxel's list kept in LDS (24 KB per workgroup)
+// Batcher's odd-even merge sort of 16 keys: 63 compare-exchanges, no branch (checked with the 0-1 principle when it was generated)
+constexpr uint8_t RP_SORT16[63][2] = {
+    {0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6}, {0, 4}, {2, 6}, {2, 4}, {1, 5}, {3, 7}, {3, 5},
+    {1, 2}, {3, 4}, {5, 6}, {8, 9}, {10, 11}, {8, 10}, {9, 11}, {9, 10}, {12, 13}, {14, 15}, {12, 14}, {13, 15}, {13, 14}, {8, 12},
+    {10, 14}, {10, 12}, {9, 13}, {11, 15}, {11, 13}, {9, 10}, {11, 12}, {13, 14}, {0, 8}, {4, 12}, {4, 8}, {2, 10}, {6, 14}, {6, 10},
+    {2, 4}, {6, 8}, {10, 12}, {1, 9}, {5, 13}, {5, 9}, {3, 11}, {7, 15}, {7, 11}, {3, 5}, {7, 9}, {11, 13}, {1, 2}, {3, 4}, {5, 6},
+    {7, 8}, {9, 10}, {11, 12}, {13, 14}};
+static_assert(MV_ROW == 16, "the row's ranks are sorted by a 16-key network");
 template <int S>
 __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, State st, Scratch sc) {
-  // (the thread's copy and its successor on the list: their addresses depend on the thread's number only, so they are
-  // requested before anything else is looked at - stale or garbage beyond this frame's copies, where nobody looks)
+  // (the thread's copy: its address depends on the thread's number only, so it is requested before anything else is
+  // looked at - stale or garbage beyond this frame's copies, where nobody looks)
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   MoveCopy c0;
   c0.voxel = MV_NIL;
-  uint32_t nx0 = MV_NIL;
-  if (t < sc.cap_move) {
-    c0 = sc.mv_copy[t];
-    nx0 = sc.mv_next[t];
-  }
+  if (t < sc.cap_move) c0 = sc.mv_copy[t];
   const uint32_t n_alias = st.alias[0];
   if (sc.fa->n_obj <= 0) return;
   const uint32_t n_moved = sc.cnt->n_moved;
@@ -816,7 +836,7 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
   const bool overflow = sc.cnt->overflow != 0;
   bool first_round = true;
   __shared__ uint32_t n_ok_block;  // (statistic: one global atomic per workgroup, not per voxel)
-  __shared__ uint32_t kept[RP_KEEP][RP_TPB];  // the ranks on the list this thread replays (column = thread: conflict-free)
+  __shared__ uint32_t kept[RP_KEEP][RP_TPB];  // long lists: the ranks this thread replays (column = thread: conflict-free)
   if (threadIdx.x == 0) n_ok_block = 0;
   __syncthreads();
   // (no `cond ? object : object` on MoveCopy anywhere here: the conditional operator on two lvalues selects an ADDRESS - one
@@ -827,14 +847,25 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
       first_round = false;
     } else {
       c0 = sc.mv_copy[t];
-      nx0 = sc.mv_next[t];
     }
     DBGM(1, 0, DBGM_T());
     [[maybe_unused]] const unsigned long long dbg_t0 = DBGM_T();
     const uint32_t lv = c0.voxel;
-    if (lv >= d.v_count) continue;
-    // the list head, and - requested with it, whoever turns out to be the head - the voxel's rows
-    const uint32_t head = sc.mv_head[lv];
+    if (lv >= d.v_count || !(c0.forget_bits & MV_FIRST)) continue;  // not the first arrival at its voxel: nothing to do
+    // the voxel's row, and - requested with it - the voxel's rows of the map
+    uint32_t *const row = sc.mv_row + (size_t)lv * MV_ROW;
+    uint32_t rk[MV_ROW];
+    {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(row);
+#pragma unroll
+      for (int q = 0; q < MV_ROW / 4; ++q) {
+        const uint4 x = rp[q];
+        rk[4 * q] = x.x;
+        rk[4 * q + 1] = x.y;
+        rk[4 * q + 2] = x.z;
+        rk[4 * q + 3] = x.w;
+      }
+    }
     const uint32_t v = d.v_begin + lv;
     uint32_t rx, ry, rz;
     voxel_to_ring(d, v, rx, ry, rz);
@@ -873,15 +904,18 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
     __builtin_memcpy(own, st.owner + base, 2 * S);
     // ... and the filter bits of its slots (owner_insert_local; n_alias: wave-uniform)
     uint32_t fbits = n_alias ? alias_filter_bits<S>(st, base) : 0u;
-    if (head != t) continue;  // another copy replays this voxel's list (or the entry is a stale one)
-    sc.mv_head[lv] = MV_NIL;
+    // (an entry this frame did not write may carry the mark of an older frame: the row says who was first in this one)
+    if (rk[0] == MV_NIL || rk[1] != t) continue;
+    const uint32_t n_list = rk[0] + 1u;
+    row[0] = MV_NIL;
+    const uint32_t chain = rk[MV_ROW - 1];
+    if (n_list > (uint32_t)MV_DIRECT) row[MV_ROW - 1] = MV_NIL;
     if (overflow) continue;
     uint32_t smax = a > b ? a : b;
     smax = smax > c ? smax : c;
     bool alias_touched = false;
     uint32_t n_ok = 0;
-    bool more = true, full = false;
-    long long last = -1;  // largest rank replayed so far
+    bool full = false;
     // The vacant slots as a bit mask, kept up to date by the insertions (the lowest set bit is the "first vacant slot" of
     // operations.h:790-796).  A sparse wave pays for every instruction it issues, and the walk over status / stamp /
     // owner arrays per insertion was a few hundred of them per copy - most of this kernel's time.
@@ -889,103 +923,137 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
 #pragma unroll
     for (int i = 1; i < S; ++i)
       if (stv[i] == ST_INVALID || (uint32_t)tsv[i] < smax) vac |= 1u << i;
-    // The list is walked ONCE - a chain of dependent loads, 0.6 us each - and its ranks are kept in LDS; every later batch
-    // selects from there.  (Round 4 walked the list again for every batch of S-1: a voxel on the surface of an object that
-    // has been tracked for a hundred frames receives dozens of copies of which many are vacant themselves - dead members of
-    // the set are copied too, operations.h:334-349 - and fill no slot, so its list took five or six walks: the kernel's
-    // 250 us tail on the `driven` workload.)  A list longer than RP_KEEP is walked again for what LDS could not hold.
-    uint32_t n_list = 0;
-    bool first_pass = true;
+    // one copy of the list, rank e, into the first vacant slot
+    auto insert = [&](uint32_t e, const MoveCopy &cin) {
+      const int slot = __ffs((int)vac) - 1;
+      MoveCopy c = cin;
+      if (e == t) c = c0;
+      const uint8_t cs = c.status;
+      const uint16_t cts = c.ts;
+      uint16_t o = OWNER_NONE;
+#pragma unroll
+      for (int i = 1; i < S; ++i) o = i == slot ? own[i] : o;
+      // the new index joins the object's set
+      if (!owner_insert_local(st, base + slot, c.owner, o, n_alias, alias_touched, fbits, slot)) sc.cnt->overflow = 1;
+#pragma unroll
+      for (int i = 1; i < S; ++i) {  // the slot's row entries (registers: selects, no indexing)
+        const bool here = i == slot;
+        px[i] = here ? c.x : px[i];
+        py[i] = here ? c.y : py[i];
+        pz[i] = here ? c.z : pz[i];
+        fg[i] = here ? (uint8_t)c.forget_bits : fg[i];
+        wv[i] = here ? c.w : wv[i];
+        tsv[i] = here ? cts : tsv[i];
+        trk[i] = here ? c.track : trk[i];
+        lab[i] = here ? c.label : lab[i];
+        stv[i] = here ? cs : stv[i];
+        own[i] = here ? o : own[i];
+      }
+      touched |= 1u << slot;
+      // (a copy that is itself vacant - deleted before it was copied, or older than the slab's stamp - leaves the slot
+      // to the next one)
+      if (!(cs == ST_INVALID || (uint32_t)cts < smax)) vac &= ~(1u << slot);
+      ++n_ok;
+    };
+    DBGM_MAX(2, n_list);
+    DBGM_ADD(3, n_list);
+    DBGM_ADD(4, 1);
     [[maybe_unused]] unsigned long long dbg_sel = 0, dbg_fetch = 0, dbg_ins = 0;
-    while (more && !full) {
-      [[maybe_unused]] const unsigned long long dbg_a = DBGM_T();
-      uint32_t best[S - 1];  // the S-1 smallest ranks above `last`, ascending
+    if (n_list <= (uint32_t)MV_DIRECT) {
+      // ---- the usual list: its ranks are in registers.  Sorted once, all copies requested together, replayed in order.
+      [[maybe_unused]] const unsigned long long dbg_a = DBGM_T() + (rk[0] == 0xEEEEEEEEu ? 1 : 0);
+      uint32_t e[MV_ROW];
 #pragma unroll
-      for (int i = 0; i < S - 1; ++i) best[i] = MV_NIL;
-      uint32_t n_above = 0;  // ranks above `last` on the list
-      auto offer = [&](uint32_t cur) {
-        if ((long long)cur <= last) return;
-        ++n_above;
-        uint32_t x = cur;
+      for (int j = 0; j < MV_ROW; ++j) e[j] = j < MV_DIRECT && (uint32_t)j < n_list ? rk[1 + j] : MV_NIL;  // (words beyond the count: older frames')
 #pragma unroll
-        for (int i = 0; i < S - 1; ++i)
-          if (x < best[i]) {
-            const uint32_t y = best[i];
-            best[i] = x;
-            x = y;
-          }
-      };
-      if (first_pass || n_list > (uint32_t)RP_KEEP) {
-        uint32_t k = 0;
-        for (uint32_t cur = head; cur != MV_NIL; cur = cur == t ? nx0 : sc.mv_next[cur]) {
-          if (first_pass && k < (uint32_t)RP_KEEP) kept[k][threadIdx.x] = cur;
-          ++k;
-          offer(cur);
-        }
-        if (first_pass) n_list = k;
-        first_pass = false;
-      } else {
-        for (uint32_t k = 0; k < n_list; ++k) offer(kept[k][threadIdx.x]);
+      for (int q = 0; q < 63; ++q) {
+        const int i0 = RP_SORT16[q][0], i1 = RP_SORT16[q][1];
+        const uint32_t lo = e[i0] < e[i1] ? e[i0] : e[i1], hi = e[i0] < e[i1] ? e[i1] : e[i0];
+        e[i0] = lo;
+        e[i1] = hi;
       }
-      DBGM(1, 1, DBGM_T() + (stv[1] == 0xEE ? 1 : 0) + (own[1] == 0xEEEE ? 1 : 0));
-      if (n_above == n_list) {  // (the first pass of this list)
-        DBGM_MAX(0, DBGM_T() - dbg_t0 + (stv[1] == 0xEE ? 1 : 0));
-        DBGM_MAX(2, n_list);
-        DBGM_ADD(3, n_list);
-        DBGM_ADD(4, 1);
-      }
-      more = n_above > (uint32_t)(S - 1);  // ranks beyond this batch (a walk of the list is a chain of dependent loads: no second one to find nothing)
-      MoveCopy cc[S - 1];  // the batch's copies, requested together
+      MoveCopy cc[MV_DIRECT];
 #pragma unroll
-      for (int u = 0; u < S - 1; ++u) cc[u] = sc.mv_copy[best[u] != MV_NIL ? best[u] : t];  // (no branch per fetch: each one was waited for where its branch ended)
-      // (the fetches above are to be under way together before the first insertion's stores: without the fence the compiler
-      // sinks each fetch to the iteration that uses it - a dependent round trip per copy)
+      for (int j = 0; j < MV_DIRECT; ++j) cc[j] = sc.mv_copy[e[j] != MV_NIL ? e[j] : t];  // (no branch per fetch: each one was waited for where its branch ended)
+      // (the fetches above are to be under way together before the first insertion: without the fence the compiler sinks
+      // each fetch to the iteration that uses it - a dependent round trip per copy)
       __asm__ volatile("" ::: "memory");
-      [[maybe_unused]] const unsigned long long dbg_b = DBGM_T() + (best[0] == 0xEEEEEEEEu ? 1 : 0);
-      [[maybe_unused]] const unsigned long long dbg_c = DBGM_T() + (cc[0].voxel == 0xEEEEEEEEu ? 1 : 0) + (cc[S - 2].voxel == 0xEEEEEEEEu ? 1 : 0);
+      [[maybe_unused]] const unsigned long long dbg_b = DBGM_T() + (e[0] == 0xEEEEEEEEu ? 1 : 0);
+      DBGM_MAX(0, dbg_a - dbg_t0);
+      [[maybe_unused]] const unsigned long long dbg_c = DBGM_T() + (cc[0].voxel == 0xEEEEEEEEu ? 1 : 0) + (cc[MV_DIRECT - 1].voxel == 0xEEEEEEEEu ? 1 : 0);
 #pragma unroll
-      for (int u = 0; u < S - 1; ++u) {
-        const uint32_t e = best[u];
-        if (e == MV_NIL || full) break;
-        last = e;
-        if (vac == 0u) {  // voxel full: this copy and all later ones are dropped (operations.h:357)
-          full = true;
-          break;
-        }
-        const int slot = __ffs((int)vac) - 1;
-        MoveCopy c = cc[u];
-        if (e == t) c = c0;
-        const uint8_t cs = c.status;
-        const uint16_t cts = c.ts;
-        uint16_t o = OWNER_NONE;
-#pragma unroll
-        for (int i = 1; i < S; ++i) o = i == slot ? own[i] : o;
-        // the new index joins the object's set
-        if (!owner_insert_local(st, base + slot, c.owner, o, n_alias, alias_touched, fbits, slot)) sc.cnt->overflow = 1;
-#pragma unroll
-        for (int i = 1; i < S; ++i) {  // the slot's row entries (registers: selects, no indexing)
-          const bool here = i == slot;
-          px[i] = here ? c.x : px[i];
-          py[i] = here ? c.y : py[i];
-          pz[i] = here ? c.z : pz[i];
-          fg[i] = here ? (uint8_t)c.forget_bits : fg[i];
-          wv[i] = here ? c.w : wv[i];
-          tsv[i] = here ? cts : tsv[i];
-          trk[i] = here ? c.track : trk[i];
-          lab[i] = here ? c.label : lab[i];
-          stv[i] = here ? cs : stv[i];
-          own[i] = here ? o : own[i];
-        }
-        touched |= 1u << slot;
-        // (a copy that is itself vacant - deleted before it was copied, or older than the slab's stamp - leaves the slot
-        // to the next one)
-        if (!(cs == ST_INVALID || (uint32_t)cts < smax)) vac &= ~(1u << slot);
-        ++n_ok;
+      for (int j = 0; j < MV_DIRECT; ++j) {
+        if (e[j] == MV_NIL || vac == 0u) break;  // through, or the voxel is full: the later copies are dropped (operations.h:357)
+        insert(e[j], cc[j]);
       }
       [[maybe_unused]] const unsigned long long dbg_d = DBGM_T() + (n_ok == 0xEEEEu ? 1 : 0) + (vac == 0xEEEEEEEEu ? 1 : 0);
-      dbg_sel += dbg_b - dbg_a;
-      dbg_fetch += dbg_c - dbg_b;
-      dbg_ins += dbg_d - dbg_c;
+      dbg_sel = dbg_b - dbg_a;
+      dbg_fetch = dbg_c - dbg_b;
+      dbg_ins = dbg_d - dbg_c;
+    } else {
+      // ---- a long list: the row's ranks and the chain's go to LDS; batches of the next S-1 ranks are selected from there
+      // (a list longer than RP_KEEP is gone through again, row and chain, for every batch)
+      bool more = true;
+      long long last = -1;  // largest rank replayed so far
+      bool first_pass = true;
+      while (more && !full) {
+        [[maybe_unused]] const unsigned long long dbg_a = DBGM_T();
+        uint32_t best[S - 1];  // the S-1 smallest ranks above `last`, ascending
+#pragma unroll
+        for (int i = 0; i < S - 1; ++i) best[i] = MV_NIL;
+        uint32_t n_above = 0;  // ranks above `last` on the list
+        auto offer = [&](uint32_t cur) {
+          if ((long long)cur <= last) return;
+          ++n_above;
+          uint32_t x = cur;
+#pragma unroll
+          for (int i = 0; i < S - 1; ++i)
+            if (x < best[i]) {
+              const uint32_t y = best[i];
+              best[i] = x;
+              x = y;
+            }
+        };
+        if (first_pass || n_list > (uint32_t)RP_KEEP) {
+          uint32_t k = 0;
+#pragma unroll
+          for (int j = 0; j < MV_DIRECT; ++j) {
+            if (first_pass) kept[j][threadIdx.x] = rk[1 + j];
+            offer(rk[1 + j]);
+          }
+          k = MV_DIRECT;
+          // (bounded by the count: a chain can only be as long as the arrivals the counter saw)
+          for (uint32_t cur = chain; cur != MV_NIL && k < n_list; cur = sc.mv_next[cur]) {
+            if (first_pass && k < (uint32_t)RP_KEEP) kept[k][threadIdx.x] = cur;
+            ++k;
+            offer(cur);
+          }
+          first_pass = false;
+        } else {
+          for (uint32_t k = 0; k < n_list; ++k) offer(kept[k][threadIdx.x]);
+        }
+        DBGM(1, 1, DBGM_T() + (stv[1] == 0xEE ? 1 : 0) + (own[1] == 0xEEEE ? 1 : 0));
+        more = n_above > (uint32_t)(S - 1);  // ranks beyond this batch
+        MoveCopy cc[S - 1];  // the batch's copies, requested together
+#pragma unroll
+        for (int u = 0; u < S - 1; ++u) cc[u] = sc.mv_copy[best[u] != MV_NIL ? best[u] : t];
+        __asm__ volatile("" ::: "memory");
+        [[maybe_unused]] const unsigned long long dbg_b = DBGM_T() + (best[0] == 0xEEEEEEEEu ? 1 : 0);
+#pragma unroll
+        for (int u = 0; u < S - 1; ++u) {
+          const uint32_t e = best[u];
+          if (e == MV_NIL || full) break;
+          last = e;
+          if (vac == 0u) {  // voxel full: this copy and all later ones are dropped (operations.h:357)
+            full = true;
+            break;
+          }
+          insert(e, cc[u]);
+        }
+        [[maybe_unused]] const unsigned long long dbg_d = DBGM_T() + (n_ok == 0xEEEEu ? 1 : 0) + (vac == 0xEEEEEEEEu ? 1 : 0);
+        dbg_sel += dbg_b - dbg_a;
+        dbg_ins += dbg_d - dbg_b;
+      }
     }
     DBGM_MAX(6, dbg_sel);
     DBGM_MAX(7, dbg_fetch);
@@ -1234,8 +1302,9 @@ void FrameBeginLaunch::set(const Dims &d_, const State &st_, const Scratch &sc, 
 }
 const void *FrameBeginLaunch::kernel() { return reinterpret_cast<const void *>(k_frame_begin); }
 
-void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s) {
-  (void)hipLaunchKernel(FrameBeginLaunch::kernel(), dim3(FrameBeginLaunch::GRID), dim3(FrameBeginLaunch::BLOCK), a.argv, 0, s);
+void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s, hipEvent_t done) {
+  if (done) (void)hipExtLaunchKernel(FrameBeginLaunch::kernel(), dim3(FrameBeginLaunch::GRID), dim3(FrameBeginLaunch::BLOCK), a.argv, 0, s, nullptr, done, 0);
+  else (void)hipLaunchKernel(FrameBeginLaunch::kernel(), dim3(FrameBeginLaunch::GRID), dim3(FrameBeginLaunch::BLOCK), a.argv, 0, s);
 }
 
 // step 2 (after the counts of all shards are known): global ranks, transform, export of slab-crossing copies

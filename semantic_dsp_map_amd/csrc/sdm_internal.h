@@ -621,6 +621,6 @@ size_t sort_scratch_elems(size_t n);
 int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, size_t n, int nbits,
                      uint32_t *scratch, hipStream_t s, const uint32_t *n_dev = nullptr);
 
-void launch_clear(const Dims &d, const State &st, uint32_t *mv_head, hipStream_t s, bool fresh);
+void launch_clear(const Dims &d, const State &st, hipStream_t s, bool fresh);
 
 }  // namespace sdm

@@ -65,6 +65,9 @@ struct FrameArgs {
 };
 static_assert(sizeof(FrameArgs) <= 3400, "FrameArgs travels as a kernel argument (4 KB limit, with the launch's other arguments)");
 
+constexpr int MV_ROW = 16;              // words of a voxel's row of Scratch::mv_row: one 64-byte load
+constexpr int MV_DIRECT = MV_ROW - 2;   // ranks held in the row itself (word 0: arrivals - 1; last word: head of the chain of the others)
+constexpr uint32_t MV_FIRST = 0x100u;   // MoveCopy::forget_bits: this copy was the first to arrive at its voxel and replays the voxel's list
 struct Scratch {
   const FrameArgs *fa = nullptr;       // this frame's block, as the main-stream kernels see it (written by k_frame_begin)
   const FrameArgs *fa_side = nullptr;  // the same for the chains that start before it: frustum, member count (k_set_frame)
@@ -124,10 +127,12 @@ struct Scratch {
   // generic
   uint32_t *scan_scratch = nullptr, *sort_scratch = nullptr;
   uint32_t *scan_scratch_b = nullptr;   // births run on their own stream
-  // re-insertion of the moved copies: per target voxel a linked list of copy ranks (mv_head, one entry per voxel of the
-  // shard, MV_NIL when idle; mv_next per rank).  A copy knows its target voxel (MoveCopy::voxel); the copy a list's
-  // head points at replays the list.
-  uint32_t *mv_head = nullptr, *mv_next = nullptr;
+  // re-insertion of the moved copies: per target voxel of the shard a row of MV_ROW words (mv_row) - word 0 the number of
+  // copies that arrived, less one (all ones when idle), then the ranks of the first MV_DIRECT arrivals, in the last word the
+  // head of the chain of the later ones (all ones when idle; mv_next per rank).  A copy knows its target voxel
+  // (MoveCopy::voxel) and whether it arrived first (MV_FIRST): that one replays the list and leaves the row idle
+  // (move_link, k_move_replay).
+  uint32_t *mv_row = nullptr, *mv_next = nullptr;
   Counters *cnt = nullptr;
   Cursors *cur = nullptr;
 };
@@ -180,7 +185,8 @@ struct FrameBeginLaunch {
   void set(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa, bool with_side, bool with_members);
   static const void *kernel();
 };
-void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s);
+// done: recorded when the kernel has completed (the launch packet's own completion signal: no marker packet behind it)
+void launch_frame_begin(FrameBeginLaunch &a, hipStream_t s, hipEvent_t done = nullptr);
 void launch_moves_batch(const Dims &d, const State &st, const Scratch &sc, const FrameArgs &fa_batch, int32_t *counts_local, hipStream_t s);
 // lists (non-incremental sweeps only): the tiles' sparse voxels go through State::occ_list and a launch of their own
 // mode (non-incremental sweeps only): OCC_LISTS | OCC_SKIP_SCAN - every group of the map was hinted when the last such
@@ -192,7 +198,8 @@ void launch_occupancy(const Dims &d, const Filter &flt, const State &st, Counter
 size_t tile_mark_bytes(const Dims &d);  // State::tile_dirty, padded for the sweep's tile scan
 void launch_frustum(const Dims &d, const Scratch &sc, hipStream_t s);
 // visibility + binning; its last kernel also classifies the pixels for launch_ck (same ck_out / finish)
-void launch_visibility(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
+void launch_visibility(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s,
+                       hipEvent_t vis_done = nullptr);  // vis_done: recorded when k_visibility - the first of the three launches - has completed
 void launch_ck(const Dims &d, const Filter &flt, const State &st, const Scratch &sc, float *ck_out, int finish, hipStream_t s);
 // part_stride: floats between two partial images (0 = H*W)
 void launch_ck_finish(const Dims &d, const Filter &flt, const Scratch &sc, const float *parts, int n_parts, size_t part_stride, hipStream_t s);

@@ -1,0 +1,86 @@
+"""Development aid: where a frame's time goes BETWEEN its kernels, frames issued back to back as bench.py issues them
+(library built with tools/ab_build.sh timers -DSDM_AB_TIMERS=1, SDM_LIB_PATH=build/ab/libsdm_timers.so).  The kernels of
+the main stream stamp a 100 MHz wall clock per workgroup at their start and end; after a stretch of frames the stamps of
+the LAST frame are read: per kernel the first start and the last end, the gap to the kernel before it.
+usage: timers_frame_gaps.py [driven|c3]   (driven: SDM_DRIVEN_CACHE keeps the rendered frames)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from semantic_dsp_map_amd import sharded, synth  # noqa: E402
+
+
+def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else "driven"
+    cfg = synth.CONFIGS["C3"]
+    steps = 20
+    if mode == "driven":
+        params = synth.PARAMS[synth.DRIVEN_PARAMS]
+        scene = synth.Scene(cfg, **synth.DRIVEN_SCENE)
+        n_grow = synth.DRIVEN_FRAMES
+        rendered = synth.render_frames_cached(cfg, params, dict(synth.DRIVEN_SCENE), range(n_grow + steps), os.environ.get("SDM_DRIVEN_CACHE"))
+        eng = sharded.NativeShardedMap(cfg, params, 0, 1, 0)
+        m = eng.map
+        m.generate_noise_table(seed=20250217)
+        for t in range(n_grow):
+            depth, cloud, pos, q = rendered[t]
+            m.update(depth, cloud, pos, q, scene.moves(t), sync=(t % 8 == 7))
+        m.synchronize()
+        frames = [(rendered[t][2], rendered[t][3], scene.moves(t), m.device_put(rendered[t][0]), m.device_put(rendered[t][1])) for t in range(n_grow, n_grow + steps)]
+    else:
+        params = synth.PARAMS["vkitti2"]
+        scene = synth.Scene(cfg, n_static=48, n_dynamic=6, seed=7)
+        eng = sharded.NativeShardedMap(cfg, params, 0, 1, 0)
+        m = eng.map
+        m.generate_noise_table(seed=20250217)
+        frames = []
+        for t in range(steps + 5):
+            depth, cloud, pos, q = scene.render(t, params)
+            frames.append((pos, q, scene.moves(t), m.device_put(depth), m.device_put(cloud)))
+        st, ring, _ = synth.prefill_state(cfg, scene, 2000000)
+        m.load_state(st)
+        m.set_ring_state(ring)
+    L = m.L
+    L.sdm_debug_timers.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    buf = np.zeros(6 * 8192 * 4 + 4 * 4096 * 4, np.uint64)
+    for f in frames[:5]:
+        eng.update(f[3], f[4], f[0], f[1], f[2])
+    m.synchronize()
+    L.sdm_debug_timers(m.h, buf.ctypes.data, 1)
+    import time
+    t_a = time.perf_counter()
+    for f in frames[5:]:
+        eng.update(f[3], f[4], f[0], f[1], f[2])
+    m.synchronize()
+    ms = (time.perf_counter() - t_a) * 1e3 / (len(frames) - 5)
+    L.sdm_debug_timers(m.h, buf.ctypes.data, 0)
+    print("%.4f ms per frame (wall clock over the stretch, the library with its clocks compiled in)" % ms)
+    k = buf[:6 * 8192 * 4].astype(np.int64).reshape(6, 8192, 4)
+    mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(4, 4096, 4)
+    fb0 = mv[3][:1024, 0]
+    t0 = fb0[fb0 > 0].max() - 3000   # the last frame's k_frame_begin starts within 30 us of its latest workgroup
+    chain = [("k_frame_begin", mv[3][:, 0], mv[2][:, 3]), ("k_move_apply", mv[0][:, 0], mv[0][:, 3]), ("k_move_replay", mv[1][:1024, 0], mv[1][:1024, 2]),
+             ("k_visibility", k[1][:, 0], k[1][:, 3]), ("k_bin_rows", k[2][:, 0], k[2][:, 1]), ("k_ck", k[3][:, 0], k[3][:, 1]),
+             ("k_weight", k[4][:, 0], k[4][:, 1]), ("k_birth_replay", k[0][:, 0], k[0][:, 2]), ("k_occupancy", k[5][:, 0], k[5][:, 3])]
+    prev_end = None
+    print("%s: the last of %d frames issued back to back (us from the first workgroup of its k_frame_begin)" % (mode, len(frames) - 5))
+    base = None
+    for name, s, e in chain:
+        s, e = s[s >= t0], e[e >= t0]
+        if not len(s) or not len(e):
+            print("  %-16s no stamps" % name)
+            continue
+        if base is None:
+            base = s.min()
+        a, b = (s.min() - base) / 100.0, (e.max() - base) / 100.0
+        print("  %-16s first start %7.1f  last end %7.1f  (%5.1f us, %5d workgroups stamped)%s"
+              % (name, a, b, b - a, len(s), "" if prev_end is None else "   gap to the kernel before: %5.1f us" % (a - prev_end)))
+        prev_end = b
+    m.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,10 +23,12 @@ def main():
     L.sdm_debug_timers.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     buf = np.zeros(6 * 8192 * 4 + 4 * 4096 * 4, np.uint64)
     for t, (depth, cloud, pos, q) in enumerate(frames):
-        if t >= synth.DRIVEN_FRAMES - 10:
+        # (the last stretch: frames issued back to back, every fifth one waited for - its clocks are the ones read)
+        read = t >= synth.DRIVEN_FRAMES - 10 and t % 5 == 4
+        if t >= synth.DRIVEN_FRAMES - 10 and t % 5 == 0:   # (the reset waits for the device: before the stretch, not inside it; the maxima are over the five frames)
             L.sdm_debug_timers(m.h, buf.ctypes.data, 1)
-        m.update(depth, cloud, pos, q, scene.moves(t), sync=t >= synth.DRIVEN_FRAMES - 10)
-        if t < synth.DRIVEN_FRAMES - 10:
+        m.update(depth, cloud, pos, q, scene.moves(t), sync=read)
+        if not read:
             continue
         L.sdm_debug_timers(m.h, buf.ctypes.data, 0)
         mv = buf[6 * 8192 * 4:].astype(np.int64).reshape(4, 4096, 4)
@@ -47,9 +49,12 @@ def main():
             t0 = a[rana, 0].min()
             print("   k_move_apply: workgroups with chunks %d | prefix done avg %.1f | first moves done avg %.1f | end avg %.1f, last %.1f us"
                   % (rana.sum(), (a[rana, 1] - a[rana, 0]).mean() / 100.0, (a[rana, 2] - a[rana, 0]).mean() / 100.0, (a[rana, 3] - t0).mean() / 100.0, (a[rana, 3] - t0).max() / 100.0))
+        if ranf.any() and rana.any() and ran.any():
+            print("   gaps: k_frame_begin's last end -> k_move_apply's first start %.1f us | k_move_apply's last end -> k_move_replay's first thread-0 stamp %.1f us"
+                  % ((a[rana, 0].min() - mm[ranf, 3].max()) / 100.0, (r[ran, 0].min() - a[rana, 3].max()) / 100.0))
         st = m.stats()
-        print("frame %d: replay span (thread 0 of the workgroups) %.1f us | slowest head: walk %.1f us, whole %.1f us | lists %d, longest %d, mean %.1f, most copies re-inserted by one head %d | moved %d re-inserted %d | largest per-head sums: walk + selection %.1f us, waiting for the batches' copies %.1f, insertions %.1f"
-              % (t, span, s[0] / 100.0, s[1] / 100.0, s[4], s[2], s[3] / max(s[4], 1), s[5], st["n_moved"], st["n_move_reinserted"], s[6] / 100.0, s[7] / 100.0, s[8] / 100.0))
+        print("frame %d: replay span (thread 0 of the workgroups) %.1f us | slowest head: walk %.1f us, whole %.1f us | lists %d, longest %d, mean %.1f, most copies re-inserted by one head %d | moved %d re-inserted %d | largest per-head sums: walk + selection %.1f us, waiting for the batches' copies %.1f, insertions %.1f | older memberships in the table %d"
+              % (t, span, s[0] / 100.0, s[1] / 100.0, s[4], s[2], s[3] / max(s[4], 1), s[5], st["n_moved"], st["n_move_reinserted"], s[6] / 100.0, s[7] / 100.0, s[8] / 100.0, st["alias_entries"]))
     m.close()
 
 
