@@ -68,8 +68,8 @@ def main():
     prev_end = None
     print("%s: the last of %d frames issued back to back (us from the first workgroup of its k_frame_begin)" % (mode, len(frames) - 5))
     base = None
-    for name, s, e in chain:
-        s, e = s[s >= t0], e[e >= t0]
+    for name, s0, e0 in chain:
+        s, e = s0[s0 >= t0], e0[e0 >= t0]
         if not len(s) or not len(e):
             print("  %-16s no stamps" % name)
             continue
@@ -79,6 +79,23 @@ def main():
         print("  %-16s first start %7.1f  last end %7.1f  (%5.1f us, %5d workgroups stamped)%s"
               % (name, a, b, b - a, len(s), "" if prev_end is None else "   gap to the kernel before: %5.1f us" % (a - prev_end)))
         prev_end = b
+        both = (s0 >= t0) & (e0 >= t0) & (e0 >= s0)
+        if both.any():
+            life = (e0[both] - s0[both]) / 100.0
+            st = (s0[both] - s0[both].min()) / 100.0
+            print("  %-16s   a workgroup lives %.1f us on average (median %.1f, 99th percentile %.1f, longest %.1f); the starts spread over %.1f us (median start %.1f)"
+                  % ("", life.mean(), np.median(life), np.percentile(life, 99), life.max(), st.max(), np.median(st)))
+    # k_birth_replay, workgroup by workgroup (stamps: start, heads compacted, end; fourth word: thread 0's insertions)
+    b = k[0]
+    ok = (b[:, 0] >= t0) & (b[:, 2] >= b[:, 0]) & (b[:, 1] >= b[:, 0])
+    if ok.any():
+        life = (b[ok, 2] - b[ok, 0]) / 100.0
+        front = (b[ok, 1] - b[ok, 0]) / 100.0
+        order = np.argsort(life)
+        print("  k_birth_replay by workgroup: start -> heads compacted %.1f us on average (99th percentile %.1f), compacted -> end %.1f (99th percentile %.1f)"
+              % (front.mean(), np.percentile(front, 99), (life - front).mean(), np.percentile(life - front, 99)))
+        slow = order[-12:]
+        print("    the twelve slowest: " + ", ".join("%.1f = %.1f + %.1f (wg %d, start +%.1f)" % (life[i], front[i], life[i] - front[i], np.flatnonzero(ok)[i], (b[ok, 0][i] - b[ok, 0].min()) / 100.0) for i in slow))
     m.close()
 
 
