@@ -96,6 +96,17 @@ def main():
               % (front.mean(), np.percentile(front, 99), (life - front).mean(), np.percentile(life - front, 99)))
         slow = order[-12:]
         print("    the twelve slowest: " + ", ".join("%.1f = %.1f + %.1f (wg %d, start +%.1f)" % (life[i], front[i], life[i] - front[i], np.flatnonzero(ok)[i], (b[ok, 0][i] - b[ok, 0].min()) / 100.0) for i in slow))
+    # k_visibility, workgroup by workgroup (stamps: start; masks of the LAST round known; its empty candidates done; end)
+    vv = k[1][:2048]
+    ok = (vv[:, 0] >= t0) & (vv[:, 3] >= vv[:, 0])
+    if ok.any():
+        life = (vv[ok, 3] - vv[ok, 0]) / 100.0
+        print("  k_visibility by workgroup: lifetime percentiles 10 / 50 / 90 / 99 / 100: %s us" % " / ".join("%.1f" % np.percentile(life, q) for q in (10, 50, 90, 99, 100)))
+        full = ok & (vv[:, 1] >= vv[:, 0]) & (vv[:, 2] >= vv[:, 1])
+        if full.any():
+            a0, a1, a2 = (vv[full, 1] - vv[full, 0]) / 100.0, (vv[full, 2] - vv[full, 1]) / 100.0, (vv[full, 3] - vv[full, 2]) / 100.0
+            print("    workgroups whose last round had candidates (%d): start -> its masks %.1f us (99th percentile %.1f: earlier rounds are in here), empty candidates %.1f (%.1f), voxels that hold something %.1f (%.1f)"
+                  % (full.sum(), a0.mean(), np.percentile(a0, 99), a1.mean(), np.percentile(a1, 99), a2.mean(), np.percentile(a2, 99)))
     m.close()
 
 
