@@ -22,7 +22,7 @@ for i in range(n + 2):
     m.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
 ts = sorted(ts[2:])
-b = V * S * (16 + 4 + 2 + 1 + 2) + V * (2 + 1 + 8 + 4 + 1)
+b = V * S * (16 + 2) + V * (S - 1) * (4 + 2 + 1) + V * (2 + 1 + 8)   # pos4, owner per slot; w, ts, status per particle slot; vts, vflag, res
 med = ts[len(ts) // 2]
 print(os.path.basename(os.environ.get("SDM_LIB_PATH", "default")),
       json.dumps({"clear_ms_median": round(med, 4), "min": round(ts[0], 4), "max": round(ts[-1], 4), "bytes": b,
