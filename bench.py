@@ -480,7 +480,7 @@ def main():
                    "host_us_per_launched_frame": round(stats["host_enqueue_us"], 1),
                    "policy": "SDM_GRAPH=%s (0 launch by launch, 1 one branched hipGraph, 3 one chain graph, 4 five chain graphs on the "
                              "frame's streams, 2 = default: by the host's speed at issuing 50 empty kernel launches, measured "
-                             "when the map is created - launch by launch up to 75 us, the five graphs up to 170 us, the chain beyond)" % os.environ.get("SDM_GRAPH", "2")}
+                             "when the map is created - launch by launch up to 110 us, the five graphs up to 170 us, the chain beyond)" % os.environ.get("SDM_GRAPH", "2")}
     live, n_vis, live_vox_local = stats["live_particles"], stats["n_visible"], stats["live_voxels"]
     if dist is not None:
         lt = torch.tensor([live, n_vis], dtype=torch.int64)

@@ -61,7 +61,11 @@ __attribute__((constructor(101))) void sdm_runtime_defaults() {
 // the map is created: the time to issue 50 launches - a frame's worth - of an empty kernel (this host: 34-40 us; the
 // frame's real launches, with their arguments and events, take it 105-160 us).
 enum { GRAPH_PIECES = 0, GRAPH_BRANCHED = 1, GRAPH_CHAIN = 2 };
-constexpr double GRAPH_PIECES_US = 75.0, GRAPH_CHAIN_US = 170.0;
+// (Round 6: 75 -> 110 us.  The line was drawn when a frame took 0.31 ms on the GPU and the five graphs 0.34; at 0.206 ms
+// launch by launch the graphs' frame is 0.26 ms, and a host that measures 76 us - the round's final profile box did, the
+// pool's usual 56-73 us - still issues a frame in 0.15 ms, ahead of the GPU.  Launch by launch stops paying where the host
+// needs longer than the graphs' frame: about twice the burst figure, 130 us.)
+constexpr double GRAPH_PIECES_US = 110.0, GRAPH_CHAIN_US = 170.0;
 constexpr int LAUNCHES_PER_FRAME = 50;
 
 __global__ void k_noop() {}
