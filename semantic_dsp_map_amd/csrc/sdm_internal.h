@@ -304,6 +304,33 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, uint32_t n) {
   return pos;
 }
 
+// The entries (li, track) among the table's first n go (track = OWNER_NONE: deleted; alias_compact_wave collects them).
+// Sixteen entries are requested before the first is looked at, and nothing is stored inside the walk: written as
+// `if (entry matches) entry.track = NONE` per entry, every load came after a store that might have hit it, and the walk
+// was one round trip PER ENTRY - a table of a hundred older memberships cost an insertion of k_move_replay 10-20 us, the
+// 100-250 us spikes of that kernel in the middle of the `driven` drive (tools/probes/timers_moves.py, SDM_TIMERS_FROM).
+__device__ __forceinline__ void alias_drop(const State &st, uint32_t n, uint32_t li, uint32_t track) {
+  const uint2 *e = reinterpret_cast<const uint2 *>(st.alias + 2);  // (8-byte aligned: the table starts at word 2)
+  uint32_t hits = 0, last = 0;
+  for (uint32_t k0 = 0; k0 < n; k0 += 16) {
+    uint2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = e[k0 + u < n ? k0 + u : n - 1];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (k0 + u < n && v[u].x == li && v[u].y == track) {
+        ++hits;
+        last = k0 + u;
+      }
+  }
+  if (hits == 1) {
+    st.alias[3 + 2 * last] = OWNER_NONE;
+  } else if (hits > 1) {  // (a set holds an index once: not expected - the plain walk takes them all)
+    for (uint32_t k = 0; k < n; ++k)
+      if (st.alias[2 + 2 * k] == li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+  }
+}
+
 // ObjectParticleHashMap::addParticleToObj (object_layer.h:31-33): slot li joins track's set.  li is the shard-local slot
 // index.  Returns false when the alias table is full.
 __device__ __forceinline__ bool owner_insert(const State &st, size_t li, uint16_t track) {
@@ -312,8 +339,7 @@ __device__ __forceinline__ bool owner_insert(const State &st, size_t li, uint16_
   uint32_t n = st.alias[0];
   if (n > st.alias_cap) n = st.alias_cap;
   if (n && alias_may_hold(st, li))
-    for (uint32_t k = 0; k < n; ++k)  // a set holds an index once
-      if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+    alias_drop(st, n, (uint32_t)li, track);  // a set holds an index once
   if (prev == OWNER_NONE || prev == track) return true;
   const uint32_t k = atomicAdd(&st.alias[0], 1u);  // prev's set keeps the index
   if (k >= st.alias_cap) return false;
@@ -331,8 +357,7 @@ __device__ __forceinline__ void owner_erase(const State &st, size_t li, uint16_t
   uint32_t n = st.alias[0];
   if (n > st.alias_cap) n = st.alias_cap;
   if (n && alias_may_hold(st, li))
-    for (uint32_t k = 0; k < n; ++k)
-      if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+    alias_drop(st, n, (uint32_t)li, track);
 }
 
 // The same two for a kernel in which ONE thread owns all slots of a voxel (the ordered replays): `own` is the thread's
@@ -365,8 +390,7 @@ __device__ __forceinline__ bool owner_insert_local(const State &st, size_t li, u
   if ((fbits >> slot) & 1u) {
     uint32_t n = touched ? st.alias[0] : n_alias;
     if (n > st.alias_cap) n = st.alias_cap;
-    for (uint32_t k = 0; k < n; ++k)  // a set holds an index once
-      if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+    alias_drop(st, n, (uint32_t)li, track);  // a set holds an index once
   }
   if (prev == OWNER_NONE || prev == track) return true;
   const uint32_t k = atomicAdd(&st.alias[0], 1u);  // prev's set keeps the index
@@ -387,8 +411,7 @@ __device__ __forceinline__ void owner_erase_local(const State &st, size_t li, ui
   if ((fbits >> slot) & 1u) {
     uint32_t n = touched ? st.alias[0] : n_alias;
     if (n > st.alias_cap) n = st.alias_cap;
-    for (uint32_t k = 0; k < n; ++k)
-      if (st.alias[2 + 2 * k] == (uint32_t)li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+    alias_drop(st, n, (uint32_t)li, track);
   }
 }
 

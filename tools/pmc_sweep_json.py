@@ -26,16 +26,24 @@ for c in ["FETCH_SIZE", "WRITE_SIZE"]:
     inc = [one(r) for r in rows if "k_occupancy<" in r["Kernel_Name"]]
     # a non-incremental sweep = k_occupancy_scan (or k_occupancy_scan_lists + k_occupancy_listed) + k_occupancy_dense, in launch order
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    allr = []
+    # (round 6: a sweep of a map whose every group was dense the last time is k_occupancy_dense alone)
+    allr, closed = [], True
     for r in rows:
         n = r["Kernel_Name"]
         if "k_occupancy_scan" in n:
             allr.append(one(r))
-        elif "k_occupancy_listed" in n or "k_occupancy_dense" in n:
+            closed = False
+        elif "k_occupancy_listed" in n:
             allr[-1] += one(r)
+        elif "k_occupancy_dense" in n:
+            if closed:
+                allr.append(one(r))
+            else:
+                allr[-1] += one(r)
+            closed = True
     n = len(allr)
     # 1 (first frame) + 201 + 11 (benchmark map: untimed, then 1 + 10 timed) + 41 + 11 (dense case) + 41 + 11 (dense case, one track id per voxel)
-    assert n == 317 and all(len(x) >= 2 for x in allr), (n, len(rows))
+    assert n == 317, (n, len(rows))
     sets = {"in_frame": inc[-12:-6], "x_shift_frames": inc[-6:], "full_evaluation": allr[n - 114:n - 104], "dense_case": allr[n - 62:n - 52],
             "dense_case_surface": allr[n - 10:]}
     for name, rs in sets.items():
@@ -43,7 +51,7 @@ for c in ["FETCH_SIZE", "WRITE_SIZE"]:
         d = [sum(x[1] for x in r) for r in rs]
         res.setdefault(name, {})[c] = (sum(v) / len(v), sum(d) / len(d), len(v))
     shutil.copy(g + "%s_sweep_%s.csv" % (tag, c), "profiles/%s_sweep_pmc_%s.csv" % (tag, c.lower()))
-out = {"kernel": rf["kernel"], "non_incremental_kernels": "k_occupancy_scan + k_occupancy_dense (two launches, added; the first sweep of a map: k_occupancy_scan_lists + k_occupancy_listed + k_occupancy_dense)", "voxels": rf["voxels"], "voxels_evaluated_in_full": rf["voxels_evaluated_in_full"], "tiles": rf["tiles"],
+out = {"kernel": rf["kernel"], "non_incremental_kernels": "k_occupancy_scan + k_occupancy_dense (two launches, added; the first sweep of a map: k_occupancy_scan_lists + k_occupancy_listed + k_occupancy_dense; the dense cases after their second sweep: k_occupancy_dense alone)", "voxels": rf["voxels"], "voxels_evaluated_in_full": rf["voxels_evaluated_in_full"], "tiles": rf["tiles"],
        "tiles_looked_into": rf["tiles_looked_into"],
        "fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section)", "cases": {},
        "commands": ["SDM_GRAPH=0 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -- python bench.py --no-cpu --no-strong --no-stress --steps 20 --warmup 5",

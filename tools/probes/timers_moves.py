@@ -24,8 +24,9 @@ def main():
     buf = np.zeros(6 * 8192 * 4 + 4 * 4096 * 4, np.uint64)
     for t, (depth, cloud, pos, q) in enumerate(frames):
         # (the last stretch: frames issued back to back, every fifth one waited for - its clocks are the ones read)
-        read = t >= synth.DRIVEN_FRAMES - 10 and t % 5 == 4
-        if t >= synth.DRIVEN_FRAMES - 10 and t % 5 == 0:   # (the reset waits for the device: before the stretch, not inside it; the maxima are over the five frames)
+        first = int(os.environ.get("SDM_TIMERS_FROM", synth.DRIVEN_FRAMES - 10))   # (SDM_TIMERS_FROM=40: the middle of the drive too)
+        read = t >= first and t % 5 == 4
+        if t >= first and t % 5 == 0:   # (the reset waits for the device: before the stretch, not inside it; the maxima are over the five frames)
             L.sdm_debug_timers(m.h, buf.ctypes.data, 1)
         m.update(depth, cloud, pos, q, scene.moves(t), sync=read)
         if not read:
