@@ -2479,6 +2479,10 @@ __global__ __launch_bounds__(A7_ROWS *A7_ITEMS) CK_WAVES_ATTR void k_ck(Dims d, 
   // round trips - fetched while this batch is computed.  Bit-exact, and the frame went 0.2186-0.2198 -> 0.2230-0.2243 ms in
   // one run with both builds: the prefetched values live across the batch's nine barriers and the kernel loses resident
   // workgroups for them.)
+  // (Round 6, the lean version of the same: only the ticket, drawn two batches ahead, and the listed pixel, requested one
+  // batch ahead - one word of LDS, one register, 72 registers as before.  Weight stage of `driven` 77 -> 85 us, the benchmark
+  // frames +- 0: a workgroup that holds the tickets of its next two batches keeps them while others run dry - the list's
+  // tail is three batches long instead of one.)
   __shared__ uint32_t s_q0, s_slow;
   for (;;) {
     __syncthreads();
