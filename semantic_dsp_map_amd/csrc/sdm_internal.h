@@ -309,26 +309,33 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, uint32_t n) {
 // `if (entry matches) entry.track = NONE` per entry, every load came after a store that might have hit it, and the walk
 // was one round trip PER ENTRY - a table of a hundred older memberships cost an insertion of k_move_replay 10-20 us, the
 // 100-250 us spikes of that kernel in the middle of the `driven` drive (tools/probes/timers_moves.py, SDM_TIMERS_FROM).
-__device__ __forceinline__ void alias_drop(const State &st, uint32_t n, uint32_t li, uint32_t track) {
-  const uint2 *e = reinterpret_cast<const uint2 *>(st.alias + 2);  // (8-byte aligned: the table starts at word 2)
+// (Not inlined: it sits behind every insertion of the replays, whose loops are unrolled - fourteen copies of it in
+// k_move_replay alone doubled the code objects.  The table comes as a pointer to GLOBAL memory, by value: through a
+// reference to State a function that is not inlined sees a generic pointer and loads through FLAT instructions.)
+__device__ __attribute__((noinline)) void alias_drop_global(__attribute__((address_space(1))) uint32_t *alias, uint32_t n, uint32_t li, uint32_t track) {
+  const __attribute__((address_space(1))) unsigned long long *e = (const __attribute__((address_space(1))) unsigned long long *)(alias + 2);  // (8-byte aligned: the table starts at word 2; low word = slot, high word = track)
   uint32_t hits = 0, last = 0;
   for (uint32_t k0 = 0; k0 < n; k0 += 16) {
-    uint2 v[16];
+    unsigned long long v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) v[u] = e[k0 + u < n ? k0 + u : n - 1];
+    const unsigned long long want = ((unsigned long long)track << 32) | li;
 #pragma unroll
     for (int u = 0; u < 16; ++u)
-      if (k0 + u < n && v[u].x == li && v[u].y == track) {
+      if (k0 + u < n && v[u] == want) {
         ++hits;
         last = k0 + u;
       }
   }
   if (hits == 1) {
-    st.alias[3 + 2 * last] = OWNER_NONE;
+    alias[3 + 2 * last] = OWNER_NONE;
   } else if (hits > 1) {  // (a set holds an index once: not expected - the plain walk takes them all)
     for (uint32_t k = 0; k < n; ++k)
-      if (st.alias[2 + 2 * k] == li && st.alias[3 + 2 * k] == track) st.alias[3 + 2 * k] = OWNER_NONE;
+      if (alias[2 + 2 * k] == li && alias[3 + 2 * k] == track) alias[3 + 2 * k] = OWNER_NONE;
   }
+}
+__device__ __forceinline__ void alias_drop(const State &st, uint32_t n, uint32_t li, uint32_t track) {
+  alias_drop_global((__attribute__((address_space(1))) uint32_t *)st.alias, n, li, track);
 }
 
 // ObjectParticleHashMap::addParticleToObj (object_layer.h:31-33): slot li joins track's set.  li is the shard-local slot
