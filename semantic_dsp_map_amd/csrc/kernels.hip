@@ -2873,6 +2873,22 @@ __global__ void k_birth_cursor(Dims d, Filter flt, Scratch sc) {
   }
 }
 
+// `while (run > thr) thr += wpp;` of resampleParticlesInVoxel (semantic_dsp_map.h:1448-1519).  wpp is the voxel's weight sum
+// over S/2, capped at 1 - and a weight the update has just multiplied up can be in the hundreds before the next sweep clamps
+// it: the loop then runs once per unit of weight, in ONE lane of a sparse wave.  (Written when k_birth_replay's slowest
+// workgroups - 22 us against a median of 7, tools/probes/timers_frame_gaps.py - were still unexplained; the A/B call then
+// landed on a box where NEITHER build has that tail - births 18 us instead of 33, the frame 0.196 ms instead of 0.206, every
+// other stage as on the other boxes - so the tail is the box's, not this loop's, and the closed form is kept for the
+// weights in the hundreds it was written for.)  With wpp capped, thr is a whole number (1 + 1 + ...) and the loop's result is the
+// smallest whole number that is not below run: ceilf, exact for every float (below 2^24 the additions of 1.f are exact too;
+// beyond it the reference's loop does not end).  Uncapped, run is at most the weight sum = S/2 * wpp: a few rounds.
+__device__ __forceinline__ float resample_next_threshold(float run, float thr, float wpp) {
+  if (!(run > thr)) return thr;
+  if (wpp == 1.f) return ceilf(run);
+  while (run > thr) thr += wpp;
+  return thr;
+}
+
 // resampleParticlesInVoxel (semantic_dsp_map.h:1448-1519) on the register copy of one voxel (status row, owner row).
 // wv / trk: the voxel's weight and track rows as they were when the replay started - the slots the resampling looks at
 // (UPDATED ones) are not written by births, so the rows are still theirs.  (Loaded here, behind the stores of the
@@ -2913,7 +2929,7 @@ __device__ __forceinline__ bool resample_voxel(const Dims &d, State &st, size_t 
       } else {
         wv[i] = wpp;
         thr += wpp;
-        while (run > thr) thr += wpp;
+        thr = resample_next_threshold(run, thr, wpp);
       }
     }
   return true;
@@ -2964,7 +2980,7 @@ __device__ __forceinline__ bool resample_voxel_seq(const Dims &d, State &st, siz
       } else {
         SlotRef{rec, S - 1, (uint32_t)i - 1u}.set_w(wpp);
         thr += wpp;
-        while (run > thr) thr += wpp;
+        thr = resample_next_threshold(run, thr, wpp);
       }
     }
   return true;
