@@ -2875,11 +2875,12 @@ __global__ void k_birth_cursor(Dims d, Filter flt, Scratch sc) {
 
 // `while (run > thr) thr += wpp;` of resampleParticlesInVoxel (semantic_dsp_map.h:1448-1519).  wpp is the voxel's weight sum
 // over S/2, capped at 1 - and a weight the update has just multiplied up can be in the hundreds before the next sweep clamps
-// it: the loop then runs once per unit of weight, in ONE lane of a sparse wave.  (Written when k_birth_replay's slowest
-// workgroups - 22 us against a median of 7, tools/probes/timers_frame_gaps.py - were still unexplained; the A/B call then
-// landed on a box where NEITHER build has that tail - births 18 us instead of 33, the frame 0.196 ms instead of 0.206, every
-// other stage as on the other boxes - so the tail is the box's, not this loop's, and the closed form is kept for the
-// weights in the hundreds it was written for.)  With wpp capped, thr is a whole number (1 + 1 + ...) and the loop's result is the
+// it: the loop then runs once per unit of weight, in ONE lane of a sparse wave, and that lane is the workgroup's, and a
+// handful of such workgroups the kernel's, last 15 us: k_birth_replay's median workgroup lived 7 us, its slowest 22 - for four
+// rounds (tools/probes/timers_frame_gaps.py; tools/probes/timers_birth.py had put the time between "rows arrived" and
+// "candidates chosen", where there is nothing but registers - and this loop).  Closed form: the kernel 23 -> 9 us, the
+// benchmark frame 0.208 -> 0.1965 ms, `driven` 0.2925 -> 0.279 ms, two rounds alternating in one call.
+// With wpp capped, thr is a whole number (1 + 1 + ...) and the loop's result is the
 // smallest whole number that is not below run: ceilf, exact for every float (below 2^24 the additions of 1.f are exact too;
 // beyond it the reference's loop does not end).  Uncapped, run is at most the weight sum = S/2 * wpp: a few rounds.
 __device__ __forceinline__ float resample_next_threshold(float run, float thr, float wpp) {
