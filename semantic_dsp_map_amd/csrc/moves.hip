@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(RP_TPB) void k_move_replay(Dims d, Filter flt, Stat
   }
   __syncthreads();
   if (threadIdx.x == 0 && n_ok_block) atomicAdd(&sc.cnt->n_move_reinserted, n_ok_block);
+  DBGM(1, 2, DBGM_T());  // (the workgroup's end: the stamp above is thread 0's own list only)
 }
 
 // removeObjectByTrackID (object_layer.h:414-425): every index of the set -> INVALID, set erased.
